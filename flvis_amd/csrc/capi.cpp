@@ -1,0 +1,265 @@
+// flvis_amd: extern "C" shim (include/flvis_hip.h) over the HIP kernels.  No CPU fallback anywhere: without a HIP
+// device every entry point fails with FLVIS_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/flvis_hip.h"
+#include "ctx.hpp"
+
+using namespace flvis;
+
+void* flvis_ctx::scratch(const std::string& name, size_t bytes, bool zero_on_alloc) {
+  Buf& b = bufs[name];
+  if (b.bytes >= bytes && b.p) return b.p;
+  if (b.p) {
+    hipStreamSynchronize(stream);
+    hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  size_t want = (bytes + 255) / 256 * 256;
+  if (hipMalloc(&b.p, want) != hipSuccess) {
+    b.p = nullptr;
+    return nullptr;
+  }
+  b.bytes = want;
+  if (zero_on_alloc) hipMemsetAsync(b.p, 0, want, stream);
+  return b.p;
+}
+
+#define CHECK_CTX(ctx) \
+  if (!(ctx)) return FLVIS_ERR_INVALID_ARG;
+#define CHECK_LAUNCH(ctx, what)                                  \
+  do {                                                           \
+    hipError_t e__ = hipGetLastError();                          \
+    if (e__ != hipSuccess) return (ctx)->hip_fail(e__, what);    \
+  } while (0)
+
+extern "C" {
+
+const char* flvis_version(void) { return "flvis_hip 0.1 (gfx950)"; }
+
+int flvis_hip_create(int device, void* hip_stream, flvis_ctx** out) {
+  if (!out) return FLVIS_ERR_INVALID_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    (void)hipGetLastError();
+    return FLVIS_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) return FLVIS_ERR_NO_DEVICE;
+  flvis_ctx* c = new flvis_ctx();
+  c->device = device;
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return FLVIS_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  if (img_kernels_init() != hipSuccess) {
+    (void)hipGetLastError();
+  }
+  *out = c;
+  return FLVIS_OK;
+}
+
+void flvis_pipeline_destroy_internal(flvis_ctx* ctx);  // pipeline.cpp
+
+void flvis_hip_destroy(flvis_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  flvis_pipeline_destroy_internal(ctx);
+  for (auto& kv : ctx->bufs)
+    if (kv.second.p) hipFree(kv.second.p);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* flvis_last_error(const flvis_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int flvis_hip_synchronize(flvis_ctx* ctx) {
+  CHECK_CTX(ctx);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ctx->hip_fail(e, "hipStreamSynchronize");
+  return FLVIS_OK;
+}
+
+void* flvis_hip_stream(flvis_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int flvis_hip_equalize_hist(flvis_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n_img) {
+  CHECK_CTX(ctx);
+  if (!d_src || !d_dst || w <= 0 || h <= 0 || n_img <= 0 || (w & 3)) return ctx->fail(FLVIS_ERR_INVALID_ARG, "equalize_hist: bad args (w % 4 must be 0)");
+  unsigned* hist = (unsigned*)ctx->scratch("eq_hist", sizeof(unsigned) * 256 * n_img, true);
+  uint8_t* lut = (uint8_t*)ctx->scratch("eq_lut", 256 * (size_t)n_img);
+  if (!hist || !lut) return ctx->fail(FLVIS_ERR_HIP, "equalize_hist: scratch allocation failed");
+  launch_equalize_hist(ctx->stream, img_plain(d_src), img_plain(d_dst), w, h, w, w, (size_t)w * h, (size_t)w * h, n_img,
+                       hist, lut, nullptr);
+  CHECK_LAUNCH(ctx, "equalize_hist");
+  return FLVIS_OK;
+}
+
+int flvis_hip_pyr_down(flvis_ctx* ctx, const uint8_t* d_src, int w, int h, int src_pitch, uint8_t* d_dst,
+                       int dst_pitch, int n_img) {
+  CHECK_CTX(ctx);
+  if (!d_src || !d_dst || w < 2 || h < 2 || n_img <= 0 || (src_pitch & 3) || src_pitch < w || dst_pitch < (w + 1) / 2)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "pyr_down: bad args (src_pitch % 4 must be 0)");
+  launch_pyr_down(ctx->stream, img_plain(d_src), w, h, src_pitch, (size_t)src_pitch * h, img_plain(d_dst), dst_pitch,
+                  (size_t)dst_pitch * ((h + 1) / 2), n_img, nullptr);
+  CHECK_LAUNCH(ctx, "pyr_down");
+  return FLVIS_OK;
+}
+
+static int lk_levels(int w, int h, int win, int max_level) {
+  int level = 0;
+  for (; level <= max_level; ++level) {
+    w = (w + 1) / 2;
+    h = (h + 1) / 2;
+    if (w <= win || h <= win) return level;
+  }
+  return max_level;
+}
+
+// builds levels 1..L of `img` ([n][h][w]) into scratch `name`, fills `pyr`
+static int build_pyramid(flvis_ctx* ctx, const char* name, const uint8_t* d_img, int w, int h, int n_img, int L,
+                         PyrSel& pyr) {
+  pyr.levels = L;
+  pyr.lvl[0] = img_plain(d_img);
+  pyr.w[0] = w;
+  pyr.h[0] = h;
+  pyr.pitch[0] = w;
+  pyr.stride[0] = (size_t)w * h;
+  size_t total = 0;
+  size_t off[LK_MAX_LEVELS] = {0};
+  int lw = w, lh = h;
+  for (int l = 1; l <= L; l++) {
+    lw = (lw + 1) / 2;
+    lh = (lh + 1) / 2;
+    pyr.w[l] = lw;
+    pyr.h[l] = lh;
+    pyr.pitch[l] = align_up(lw, 16);
+    pyr.stride[l] = (size_t)pyr.pitch[l] * lh;
+    off[l] = total;
+    total += pyr.stride[l] * n_img + 256;
+    total = (total + 255) / 256 * 256;
+  }
+  uint8_t* base = (uint8_t*)ctx->scratch(name, total + 256);
+  if (!base && L > 0) return ctx->fail(FLVIS_ERR_HIP, "pyramid scratch allocation failed");
+  for (int l = 1; l <= L; l++) {
+    pyr.lvl[l] = img_plain(base + off[l]);
+    launch_pyr_down(ctx->stream, pyr.lvl[l - 1], pyr.w[l - 1], pyr.h[l - 1], pyr.pitch[l - 1], pyr.stride[l - 1],
+                    pyr.lvl[l], pyr.pitch[l], pyr.stride[l], n_img, nullptr);
+  }
+  return FLVIS_OK;
+}
+
+int flvis_hip_lk_track(flvis_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_next, int w, int h, int n_img,
+                       const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, const int* d_count, int nmax,
+                       int max_level, int max_iter, double eps, int use_initial_flow) {
+  CHECK_CTX(ctx);
+  if (!d_prev || !d_next || !d_prev_pts || !d_next_pts || !d_status || !d_count || w < 32 || h < 32 || (w & 3) ||
+      n_img <= 0 || nmax <= 0 || max_level < 0)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "lk_track: bad args");
+  int L = lk_levels(w, h, 31, max_level);
+  if (L >= LK_MAX_LEVELS) L = LK_MAX_LEVELS - 1;
+  PyrSel pp, pn;
+  int rc = build_pyramid(ctx, "lk_pyr_prev", d_prev, w, h, n_img, L, pp);
+  if (rc) return rc;
+  rc = build_pyramid(ctx, "lk_pyr_next", d_next, w, h, n_img, L, pn);
+  if (rc) return rc;
+  LKParams prm;
+  prm.max_iter = max_iter < 0 ? 0 : (max_iter > 100 ? 100 : max_iter);
+  double e = eps < 0 ? 0 : (eps > 10 ? 10 : eps);
+  prm.eps2 = e * e;
+  prm.min_eig = 1e-4f;
+  prm.use_initial = use_initial_flow ? 1 : 0;
+  launch_lk_track(ctx->stream, pp, pn, d_prev_pts, d_next_pts, d_status, d_count, nmax, n_img, prm, nullptr);
+  CHECK_LAUNCH(ctx, "lk_track");
+  return FLVIS_OK;
+}
+
+static int gftt_scratch(flvis_ctx* ctx, int w, int h, int n_img, GfttScratch& sc) {
+  int cap = 1;
+  while (cap < (w / 2 + 1) * (h / 2 + 1)) cap <<= 1;  // strict 3x3 local maxima cannot exceed ~w*h/4
+  sc.cap = cap;
+  sc.maxenc = (unsigned*)ctx->scratch("gftt_max", sizeof(unsigned) * n_img);
+  sc.nkeys = (int*)ctx->scratch("gftt_nkeys", sizeof(int) * n_img);
+  sc.keys = (unsigned long long*)ctx->scratch("gftt_keys", sizeof(unsigned long long) * (size_t)cap * n_img);
+  if (!sc.maxenc || !sc.nkeys || !sc.keys) return ctx->fail(FLVIS_ERR_HIP, "gftt: scratch allocation failed");
+  return FLVIS_OK;
+}
+
+int flvis_hip_gftt(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img, int max_corners, double quality,
+                   double min_distance, float* d_out_xy, int* d_out_count) {
+  CHECK_CTX(ctx);
+  if (!d_img || !d_out_xy || !d_out_count || w < 8 || h < 8 || (w & 3) || n_img <= 0 || max_corners <= 0)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "gftt: bad args");
+  if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "gftt: image too large for the LDS bitmap");
+  GfttScratch sc;
+  int rc = gftt_scratch(ctx, w, h, n_img, sc);
+  if (rc) return rc;
+  launch_gftt(ctx->stream, img_plain(d_img), w, h, w, (size_t)w * h, n_img, sc, nullptr, quality, nullptr, max_corners,
+              min_distance, d_out_xy, d_out_count, max_corners, nullptr);
+  CHECK_LAUNCH(ctx, "gftt");
+  return FLVIS_OK;
+}
+
+static DemParams dem_params(int w, int h, const double* f) {
+  DemParams p;
+  p.regionWidth = (int)std::floor(w / 4.0);
+  p.regionHeight = (int)std::floor(h / 4.0);
+  p.boundary_dis = (int)std::floor(f[2] / 2.0);
+  p.max_region_feature_num = (unsigned)f[0];
+  return p;
+}
+
+static int dem_common(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img, const double* f_para, int mode,
+                      const double* d_exist_xy, const int* d_exist_count, int exist_cap, float* d_out_xy,
+                      int* d_out_count, int out_cap) {
+  if (!d_img || !f_para || !d_out_xy || !d_out_count || w < 8 || h < 8 || (w & 3) || n_img <= 0 || out_cap <= 0)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "feature_dem: bad args");
+  int gftt_num = (int)f_para[3];
+  int maxc = mode == 1 ? 2 * gftt_num : gftt_num;
+  if (maxc <= 0 || maxc > 2048) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_dem: gftt_num out of range (<=1024)");
+  GfttScratch sc;
+  int rc = gftt_scratch(ctx, w, h, n_img, sc);
+  if (rc) return rc;
+  float* corners = (float*)ctx->scratch("dem_corners", sizeof(float) * 2 * (size_t)maxc * n_img);
+  int* ncorners = (int*)ctx->scratch("dem_ncorners", sizeof(int) * n_img);
+  int* modes = (int*)ctx->scratch("dem_mode", sizeof(int) * n_img);
+  if (!corners || !ncorners || !modes) return ctx->fail(FLVIS_ERR_HIP, "feature_dem: scratch allocation failed");
+  std::vector<int> hm(n_img, mode);
+  hipMemcpyAsync(modes, hm.data(), sizeof(int) * n_img, hipMemcpyHostToDevice, ctx->stream);
+  hipStreamSynchronize(ctx->stream);  // hm is a stack-lifetime host buffer
+  launch_gftt(ctx->stream, img_plain(d_img), w, h, w, (size_t)w * h, n_img, sc, nullptr, f_para[4], nullptr, maxc,
+              (double)(int)f_para[5], corners, ncorners, maxc, nullptr);
+  launch_feature_dem(ctx->stream, img_plain(d_img), w, h, w, (size_t)w * h, n_img, dem_params(w, h, f_para), corners,
+                     ncorners, maxc, modes, d_exist_xy, d_exist_count, exist_cap, d_out_xy, d_out_count, out_cap);
+  CHECK_LAUNCH(ctx, "feature_dem");
+  return FLVIS_OK;
+}
+
+int flvis_hip_feature_dem_detect(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img, const double* f_para,
+                                 float* d_out_xy, int* d_out_count, int out_cap) {
+  CHECK_CTX(ctx);
+  return dem_common(ctx, d_img, w, h, n_img, f_para, 1, nullptr, nullptr, 0, d_out_xy, d_out_count, out_cap);
+}
+
+int flvis_hip_feature_dem_redetect(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img, const double* f_para,
+                                   const double* d_exist_xy, const int* d_exist_count, int exist_cap, float* d_out_xy,
+                                   int* d_out_count, int out_cap) {
+  CHECK_CTX(ctx);
+  if (!d_exist_xy || !d_exist_count || exist_cap <= 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "feature_dem_redetect: bad args");
+  return dem_common(ctx, d_img, w, h, n_img, f_para, 2, d_exist_xy, d_exist_count, exist_cap, d_out_xy, d_out_count,
+                    out_cap);
+}
+
+}  // extern "C"
+
+// until pipeline.cpp exists
+__attribute__((weak)) void flvis_pipeline_destroy_internal(flvis_ctx*) {}

@@ -1,0 +1,63 @@
+// flvis_amd device-side common helpers (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FLVIS_WAVE 64
+
+namespace flvis {
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// reflect, then clamp (tiles hanging far over the image edge read defined-but-unused pixels)
+__device__ __forceinline__ int reflect101c(int i, int n) {
+  i = reflect101(i, n);
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+// order-preserving float -> uint32 (larger float => larger uint)
+__device__ __forceinline__ uint32_t f32_ordered(float f) {
+  uint32_t b = __float_as_uint(f);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(uint32_t u) {
+  uint32_t b = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+  return __uint_as_float(b);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// wave64 reductions over all 64 lanes (result valid in every lane)
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+// number of set bits in `mask` strictly below this lane
+__device__ __forceinline__ int lane_prefix(unsigned long long mask) {
+  return __popcll(mask & ((1ull << lane_id()) - 1ull));
+}
+
+}  // namespace flvis

@@ -1,0 +1,677 @@
+// flvis_amd: image-scan kernels of the FLVIS front-end for gfx950 (CDNA4), batched over S independent streams.
+//
+//   k_hist256 / k_equalize_lut / k_lut_apply   -> cv::equalizeHist        (reference: src/frontend/f2f_tracking.cpp:141-145)
+//   k_pyr_down                                 -> cv::pyrDown levels of calcOpticalFlowPyrLK's pyramids
+//                                                 (reference: src/processing/lkorb_tracking.cpp:64-73, camera_frame.cpp:124-128)
+//   k_eig<0> (max) / k_eig<1> (threshold+NMS)  -> cornerMinEigenVal + minMaxLoc + threshold + dilate==val
+//   k_sort_keys / k_select_mindist             -> sort by response + min-distance selection of cv::goodFeaturesToTrack
+//                                                 (reference: src/processing/feature_dem.cpp:160,221)
+//   k_feature_dem                              -> FeatureDEM::detect / ::redetect (feature_dem.cpp:92-266, quirks kept)
+//
+// All are HBM-bound streaming passes (u8 images, O(1) flop/byte): tiles are staged in LDS with dword global loads,
+// one workgroup per (tile, stream); blockIdx.z = stream so consecutive workgroups of one stream share an XCD-local L2.
+// Built with -ffp-contract=off: float arithmetic is op-for-op the oracle's (tests compare bit-exactly).
+#include "dev_common.hpp"
+#include "img_kernels.hpp"
+
+namespace flvis {
+
+// ------------------------------------------------------------------------------------------------ tile loader
+// Loads a (TH x TW) u8 tile whose top-left image coordinate is (x0,y0) (may be negative / beyond the image: REFLECT_101)
+// into LDS `tile` with row stride TS.  x0 must be a multiple of 4 (dword path for interior dwords).
+template <int TH, int TW, int TS>
+__device__ __forceinline__ void load_tile_u8(const uint8_t* __restrict__ img, int w, int h, int pitch, int x0, int y0,
+                                             uint8_t* tile) {
+  static_assert(TW % 4 == 0, "tile width must be a multiple of 4");
+  constexpr int DW = TW / 4;
+  for (int i = threadIdx.x; i < TH * DW; i += blockDim.x) {
+    int r = i / DW, c = i - r * DW;
+    int gy = reflect101c(y0 + r, h);
+    int gx = x0 + 4 * c;
+    const uint8_t* row = img + (size_t)gy * pitch;
+    uint32_t v;
+    if (gx >= 0 && gx + 3 < w) {
+      v = *reinterpret_cast<const uint32_t*>(row + gx);
+    } else {
+      uint32_t b0 = row[reflect101c(gx, w)], b1 = row[reflect101c(gx + 1, w)], b2 = row[reflect101c(gx + 2, w)],
+               b3 = row[reflect101c(gx + 3, w)];
+      v = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+    *reinterpret_cast<uint32_t*>(tile + r * TS + 4 * c) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ equalizeHist
+__global__ __launch_bounds__(256) void k_hist256(ImgSel src, int w, int h, int pitch, size_t sstride,
+                                                 unsigned* __restrict__ hist, const int* __restrict__ active) {
+  const int s = blockIdx.y;
+  if (active && !active[s]) return;
+  __shared__ unsigned lh[4][256];
+  for (int i = threadIdx.x; i < 1024; i += 256) (&lh[0][0])[i] = 0;
+  __syncthreads();
+  const uint8_t* img = src.ptr(s, sstride);
+  const int wv = threadIdx.x >> 6;
+  const int dwords_per_row = w >> 2;  // w % 4 == 0 (checked on host)
+  const long total = (long)dwords_per_row * h;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int y = (int)(i / dwords_per_row), x4 = (int)(i - (long)y * dwords_per_row);
+    uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * pitch + 4 * x4);
+    atomicAdd(&lh[wv][v & 255], 1u);
+    atomicAdd(&lh[wv][(v >> 8) & 255], 1u);
+    atomicAdd(&lh[wv][(v >> 16) & 255], 1u);
+    atomicAdd(&lh[wv][v >> 24], 1u);
+  }
+  __syncthreads();
+  unsigned t = lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
+  if (t) atomicAdd(&hist[s * 256 + threadIdx.x], t);
+}
+
+// one workgroup of 256 threads per stream: hist -> LUT (OpenCV: first non-zero bin -> 0, scale = 255/(total-hist[i0]))
+__global__ __launch_bounds__(256) void k_equalize_lut(unsigned* __restrict__ hist, uint8_t* __restrict__ lut, int total,
+                                                      const int* __restrict__ active) {
+  const int s = blockIdx.x;
+  if (active && !active[s]) return;
+  __shared__ unsigned hs[256];
+  __shared__ unsigned cs[256];
+  __shared__ int first;
+  const int t = threadIdx.x;
+  hs[t] = hist[s * 256 + t];
+  hist[s * 256 + t] = 0;  // ready for the next frame
+  if (t == 0) first = 256;
+  __syncthreads();
+  if (hs[t]) atomicMin(&first, t);
+  cs[t] = hs[t];
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {  // inclusive scan
+    unsigned v = (t >= o) ? cs[t - o] : 0;
+    __syncthreads();
+    cs[t] += v;
+    __syncthreads();
+  }
+  const int i0 = first;
+  uint8_t out;
+  if ((int)hs[i0] == total) {
+    out = (uint8_t)i0;  // constant image: dst filled with that value (only bin i0 is ever looked up)
+  } else if (t <= i0) {
+    out = 0;
+  } else {
+    float scale = (256 - 1.f) / (float)(total - (int)hs[i0]);
+    int sum = (int)(cs[t] - cs[i0]);
+    int v = __float2int_rn((float)sum * scale);
+    out = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+  }
+  lut[s * 256 + t] = out;
+}
+
+__global__ __launch_bounds__(256) void k_lut_apply(ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch,
+                                                   size_t sstride, size_t dstride, const uint8_t* __restrict__ lut,
+                                                   const int* __restrict__ active) {
+  const int s = blockIdx.y;
+  if (active && !active[s]) return;
+  __shared__ uint8_t l[256];
+  l[threadIdx.x] = lut ? lut[s * 256 + threadIdx.x] : (uint8_t)threadIdx.x;
+  __syncthreads();
+  const uint8_t* in = src.ptr(s, sstride);
+  uint8_t* out = const_cast<uint8_t*>(dst.ptr(s, dstride));
+  const int dpr = w >> 2;
+  const long total = (long)dpr * h;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int y = (int)(i / dpr), x4 = (int)(i - (long)y * dpr);
+    uint32_t v = *reinterpret_cast<const uint32_t*>(in + (size_t)y * spitch + 4 * x4);
+    uint32_t o = (uint32_t)l[v & 255] | ((uint32_t)l[(v >> 8) & 255] << 8) | ((uint32_t)l[(v >> 16) & 255] << 16) |
+                 ((uint32_t)l[v >> 24] << 24);
+    *reinterpret_cast<uint32_t*>(out + (size_t)y * dpitch + 4 * x4) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pyrDown
+// One workgroup -> PD_TH x PD_TW destination pixels.  Source tile (2*TH+3) x (2*TW+4(+pad)) staged in LDS.
+constexpr int PD_TW = 64, PD_TH = 16;
+constexpr int PD_SW = 2 * PD_TW + 8;  // 136: starts at 2*x0-4 (dword aligned), covers 2*x0-2 .. 2*x0+2*TW
+constexpr int PD_SH = 2 * PD_TH + 3;  // 35
+
+__global__ __launch_bounds__(256) void k_pyr_down(ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst,
+                                                  int dpitch, size_t dstride, const int* __restrict__ active) {
+  const int s = blockIdx.z;
+  if (active && !active[s]) return;
+  const int dw = (sw + 1) >> 1, dh = (sh + 1) >> 1;
+  const int x0 = blockIdx.x * PD_TW, y0 = blockIdx.y * PD_TH;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[PD_SH * PD_SW];
+  __shared__ uint16_t hrow[PD_SH * PD_TW];
+  const uint8_t* img = src.ptr(s, sstride);
+  load_tile_u8<PD_SH, PD_SW, PD_SW>(img, sw, sh, spitch, 2 * x0 - 4, 2 * y0 - 2, tile);
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD_SH * PD_TW; i += 256) {
+    int r = i / PD_TW, c = i - r * PD_TW;
+    const uint8_t* p = tile + r * PD_SW + 2 * c + 2;  // tile col of image x = 2*(x0+c)-2
+    hrow[i] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+  }
+  __syncthreads();
+  uint8_t* out = const_cast<uint8_t*>(dst.ptr(s, dstride));
+  for (int i = threadIdx.x; i < PD_TH * PD_TW; i += 256) {
+    int r = i / PD_TW, c = i - r * PD_TW;
+    int x = x0 + c, y = y0 + r;
+    if (x < dw && y < dh) {
+      const uint16_t* q = hrow + (2 * r) * PD_TW + c;
+      int v = q[0] + 4 * q[PD_TW] + 6 * q[2 * PD_TW] + 4 * q[3 * PD_TW] + q[4 * PD_TW];
+      out[(size_t)y * dpitch + x] = (uint8_t)((v + 128) >> 8);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ min-eigenvalue map
+// Tile of EG_TH x EG_TW outputs (+HALO ring when HALO=1).  Needs cov on a +1 ring and image on a +2 ring beyond that.
+constexpr int EG_TW = 64, EG_TH = 16;
+
+template <int HALO>
+struct EigTile {
+  static constexpr int OW = EG_TW + 2 * HALO, OH = EG_TH + 2 * HALO;  // eig region
+  static constexpr int CW = OW + 2, CH = OH + 2;                      // cov (sobel) region
+  static constexpr int IW_ = CW + 2, IH = CH + 2;                     // image region
+  static constexpr int IPAD = 4;                                      // left pad so the tile starts dword aligned
+  static constexpr int IW = ((IW_ + IPAD + 3) / 4) * 4;               // LDS tile width (bytes)
+};
+
+// Computes the eig values of one tile into LDS `eig` (OH x OW floats).  Float op order is fixed (raster 3x3 sums) so results are reproducible bit-for-bit.
+template <int HALO>
+__device__ __forceinline__ void eig_tile(const uint8_t* __restrict__ img, int w, int h, int pitch, int x0, int y0,
+                                         uint8_t* tile, float* sfx, float* sfy, float* eig) {
+  using T = EigTile<HALO>;
+  // image tile origin: (x0 - HALO - 2 - IPAD, y0 - HALO - 2); x0 is a multiple of 64, IPAD chosen so origin % 4 == 0
+  constexpr int XOFF = HALO + 2 + (4 - ((HALO + 2) & 3)) % 4;  // HALO=0 -> 4 ; HALO=1 -> 4
+  static_assert(XOFF % 4 == 0 && XOFF <= T::IPAD + 3, "alignment");
+  const int ix0 = x0 - XOFF, iy0 = y0 - HALO - 2;
+  load_tile_u8<T::IH, T::IW, T::IW>(img, w, h, pitch, ix0, iy0, tile);
+  __syncthreads();
+  const float scale = (float)(1.0 / (255.0 * 4.0 * 3.0));
+  // sobel on the cov region; position (X,Y) is first reflected into the image (boxFilter REFLECT_101 on cov)
+  for (int i = threadIdx.x; i < T::CH * T::CW; i += blockDim.x) {
+    int r = i / T::CW, c = i - r * T::CW;
+    int X = x0 - HALO - 1 + c, Y = y0 - HALO - 1 + r;
+    int Xr = reflect101(X, w), Yr = reflect101(Y, h);
+    // clamp for tiles that hang over the right/bottom edge far beyond the image (values unused there)
+    int tx = Xr - ix0, ty = Yr - iy0;
+    float fx = 0.f, fy = 0.f;
+    if (tx >= 1 && tx < T::IW - 1 && ty >= 1 && ty < T::IH - 1) {
+      const uint8_t* p = tile + ty * T::IW + tx;
+      int a = p[-T::IW - 1], b = p[-T::IW], cc = p[-T::IW + 1];
+      int d = p[-1], f = p[1];
+      int g = p[T::IW - 1], hh = p[T::IW], k = p[T::IW + 1];
+      int dx = (cc + 2 * f + k) - (a + 2 * d + g);
+      int dy = (g + 2 * hh + k) - (a + 2 * b + cc);
+      fx = (float)dx * scale;
+      fy = (float)dy * scale;
+    }
+    sfx[i] = fx;
+    sfy[i] = fy;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T::OH * T::OW; i += blockDim.x) {
+    int r = i / T::OW, c = i - r * T::OW;
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        float fx = sfx[(r + j) * T::CW + c + k], fy = sfy[(r + j) * T::CW + c + k];
+        sa += fx * fx;
+        sb += fx * fy;
+        sc += fy * fy;
+      }
+    float a = sa * 0.5f, b = sb, cc = sc * 0.5f;
+    eig[i] = (a + cc) - __fsqrt_rn((a - cc) * (a - cc) + b * b);
+  }
+  __syncthreads();
+}
+
+// pass 1: per-stream maximum of the eig map (minMaxLoc).  maxenc[s] must be zeroed before launch.
+__global__ __launch_bounds__(256) void k_eig_max(ImgSel src, int w, int h, int pitch, size_t sstride,
+                                                 unsigned* __restrict__ maxenc, const int* __restrict__ active) {
+  const int s = blockIdx.z;
+  if (active && !active[s]) return;
+  using T = EigTile<0>;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[T::IH * T::IW];
+  __shared__ float sfx[T::CH * T::CW], sfy[T::CH * T::CW], eig[T::OH * T::OW];
+  __shared__ unsigned wmax[4];
+  const int x0 = blockIdx.x * EG_TW, y0 = blockIdx.y * EG_TH;
+  eig_tile<0>(src.ptr(s, sstride), w, h, pitch, x0, y0, tile, sfx, sfy, eig);
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < T::OH * T::OW; i += 256) {
+    int r = i / T::OW, c = i - r * T::OW;
+    if (x0 + c < w && y0 + r < h) {
+      unsigned e = f32_ordered(eig[i]);
+      m = e > m ? e : m;
+    }
+  }
+  m = wave_max_u32(m);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    atomicMax(&maxenc[s], a > b ? a : b);
+  }
+}
+
+// pass 2: recompute eig with a 1-pixel ring, threshold at (float)(max*q), keep 3x3 local maxima, append 64-bit sort keys
+// key = ~((ordered(val) << 32) | pixel_offset)  -> ascending key order == (val desc, offset desc)
+__global__ __launch_bounds__(256) void k_eig_nms(ImgSel src, int w, int h, int pitch, size_t sstride,
+                                                 const unsigned* __restrict__ maxenc, const double* __restrict__ qual,
+                                                 double quality, unsigned long long* __restrict__ keys,
+                                                 int* __restrict__ nkeys, int cap, const int* __restrict__ active) {
+  const int s = blockIdx.z;
+  if (active && !active[s]) return;
+  using T = EigTile<1>;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[T::IH * T::IW];
+  __shared__ float sfx[T::CH * T::CW], sfy[T::CH * T::CW], eig[T::OH * T::OW];
+  const int x0 = blockIdx.x * EG_TW, y0 = blockIdx.y * EG_TH;
+  eig_tile<1>(src.ptr(s, sstride), w, h, pitch, x0, y0, tile, sfx, sfy, eig);
+  const float maxv = f32_unordered(maxenc[s]);
+  const double q = qual ? qual[s] : quality;
+  const float thr = (float)((double)maxv * q);
+  for (int i = threadIdx.x; i < EG_TH * EG_TW; i += 256) {
+    int r = i / EG_TW, c = i - r * EG_TW;
+    int x = x0 + c, y = y0 + r;
+    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
+    const float* e = eig + (r + 1) * T::OW + (c + 1);
+    float v = e[0];
+    if (!(v > thr) || v == 0.f) continue;
+    bool ismax = true;
+#pragma unroll
+    for (int j = -1; j <= 1; j++)
+#pragma unroll
+      for (int k = -1; k <= 1; k++) {
+        float nv = e[j * T::OW + k];
+        float tv = nv > thr ? nv : 0.f;
+        if (tv > v) ismax = false;
+      }
+    if (ismax) {
+      int slot = atomicAdd(&nkeys[s], 1);
+      if (slot < cap) {
+        unsigned long long key = ((unsigned long long)f32_ordered(v) << 32) | (unsigned)(y * w + x);
+        keys[(size_t)s * cap + slot] = ~key;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ key sort
+// One workgroup (1024 threads) per stream sorts its keys ascending with a bitonic network; sub-sequences that fit the
+// 32 KB LDS window (4096 keys) are finished in LDS, wider strides go through L2.
+constexpr int SORT_T = 1024;
+constexpr int SORT_LDS = 4096;
+
+__global__ __launch_bounds__(SORT_T) void k_sort_keys(unsigned long long* __restrict__ keys, int* __restrict__ nkeys,
+                                                      int cap, const int* __restrict__ active) {
+  const int s = blockIdx.x;
+  if (active && !active[s]) return;
+  __shared__ unsigned long long sk[SORT_LDS];
+  unsigned long long* K = keys + (size_t)s * cap;
+  int n = nkeys[s];
+  if (n > cap) n = cap;
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  if (np2 > cap) np2 = cap;  // cap is a power of two
+  for (int i = n + threadIdx.x; i < np2; i += SORT_T) K[i] = ~0ull;  // pad (sorts last)
+  __syncthreads();
+  if (np2 <= 1) return;
+  const int chunk = np2 < SORT_LDS ? np2 : SORT_LDS;
+  // phase A: sort each chunk completely in LDS (direction alternates by chunk index for the global network)
+  for (int base = 0; base < np2; base += chunk) {
+    for (int i = threadIdx.x; i < chunk; i += SORT_T) sk[i] = K[base + i];
+    __syncthreads();
+    for (int k = 2; k <= chunk; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < chunk / 2; t += SORT_T) {
+          int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          int l = i | j;
+          bool up = (((base + i) & k) == 0);
+          unsigned long long a = sk[i], b = sk[l];
+          if ((a > b) == up) {
+            sk[i] = b;
+            sk[l] = a;
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = threadIdx.x; i < chunk; i += SORT_T) K[base + i] = sk[i];
+    __syncthreads();
+  }
+  // phase B: remaining merge stages k > chunk
+  for (int k = chunk << 1; k <= np2; k <<= 1) {
+    int j = k >> 1;
+    for (; j >= chunk; j >>= 1) {  // global strides
+      for (int t = threadIdx.x; t < np2 / 2; t += SORT_T) {
+        int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        int l = i | j;
+        bool up = ((i & k) == 0);
+        unsigned long long a = K[i], b = K[l];
+        if ((a > b) == up) {
+          K[i] = b;
+          K[l] = a;
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    for (int base = 0; base < np2; base += chunk) {  // strides < chunk in LDS
+      for (int i = threadIdx.x; i < chunk; i += SORT_T) sk[i] = K[base + i];
+      __syncthreads();
+      for (int jj = chunk >> 1; jj > 0; jj >>= 1) {
+        for (int t = threadIdx.x; t < chunk / 2; t += SORT_T) {
+          int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+          int l = i | jj;
+          bool up = (((base + i) & k) == 0);
+          unsigned long long a = sk[i], b = sk[l];
+          if ((a > b) == up) {
+            sk[i] = b;
+            sk[l] = a;
+          }
+        }
+        __syncthreads();
+      }
+      for (int i = threadIdx.x; i < chunk; i += SORT_T) K[base + i] = sk[i];
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ min-distance selection
+// One wave per stream walks the sorted candidates in batches of 64 and reproduces goodFeaturesToTrack's greedy
+// grid rejection exactly: a candidate is dropped iff an already accepted corner lies at squared distance < minDist^2.
+// Accepted corners are kept in an LDS bitmap (w*h bits <= 46 KB); corners of one batch are resolved lane by lane.
+__global__ __launch_bounds__(64) void k_select_mindist(const unsigned long long* __restrict__ keys,
+                                                       const int* __restrict__ nkeys, int cap, int w, int h,
+                                                       const int* __restrict__ max_corners_s, int max_corners,
+                                                       double min_distance, float* __restrict__ out_xy,
+                                                       int* __restrict__ out_n, int out_cap,
+                                                       const int* __restrict__ active) {
+  const int s = blockIdx.x;
+  if (active && !active[s]) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned bitmap[];  // ceil(w/32) words per row
+  const int wpr = (w + 31) >> 5;
+  for (int i = threadIdx.x; i < wpr * h; i += 64) bitmap[i] = 0;
+  __syncthreads();
+  int n = nkeys[s];
+  if (n > cap) n = cap;
+  const int maxc = max_corners_s ? max_corners_s[s] : max_corners;
+  const unsigned long long* K = keys + (size_t)s * cap;
+  float* out = out_xy + (size_t)s * out_cap * 2;
+  const int lane = threadIdx.x;
+  const bool use_dist = min_distance >= 1.0;
+  const float md2 = (float)(min_distance * min_distance);
+  const int R = use_dist ? (int)__double2int_rn(min_distance) : 0;  // cell size; |dx|,|dy| < minDistance <= R (+0.5)
+  int accepted = 0;
+  for (int base = 0; base < n && (maxc <= 0 || accepted < maxc); base += 64) {
+    const int i = base + lane;
+    bool valid = i < n;
+    int x = 0, y = 0;
+    if (valid) {
+      unsigned off = (unsigned)(~K[i]);
+      y = off / (unsigned)w;
+      x = off - y * w;
+    }
+    bool good = valid;
+    if (good && use_dist) {
+      for (int dy = -R; dy <= R && good; dy++) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        for (int dx = -R; dx <= R; dx++) {
+          int xx = x + dx;
+          if (xx < 0 || xx >= w) continue;
+          float fdx = (float)dx, fdy = (float)dy;
+          if (fdx * fdx + fdy * fdy < md2) {
+            if (bitmap[yy * wpr + (xx >> 5)] & (1u << (xx & 31))) {
+              good = false;
+              break;
+            }
+          }
+        }
+      }
+    }
+    // resolve conflicts inside the batch in rank order
+    unsigned long long pending = __ballot(good);
+    if (use_dist) {
+      unsigned long long todo = pending;
+      while (todo) {
+        int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        // lane k's decision is final now
+        int kg = __shfl((int)good, k, 64);
+        if (!kg) continue;
+        int kx = __shfl(x, k, 64), ky = __shfl(y, k, 64);
+        if (lane > k && good) {
+          float fdx = (float)(x - kx), fdy = (float)(y - ky);
+          if (fdx * fdx + fdy * fdy < md2) good = false;
+        }
+      }
+      pending = __ballot(good);
+    }
+    int pos = accepted + lane_prefix(pending);
+    if (good && (maxc <= 0 || pos < maxc) && pos < out_cap) {
+      out[2 * pos] = (float)x;
+      out[2 * pos + 1] = (float)y;
+      atomicOr(&bitmap[y * wpr + (x >> 5)], 1u << (x & 31));
+    }
+    accepted += __popcll(pending);
+    __syncthreads();
+  }
+  if (maxc > 0 && accepted > maxc) accepted = maxc;
+  if (accepted > out_cap) accepted = out_cap;
+  if (lane == 0) out_n[s] = accepted;
+}
+
+// ------------------------------------------------------------------------------------------------ FeatureDEM
+// One wave per stream.  mode[s]==1: detect (init), mode[s]==2: redetect (existing landmark positions seed the regions).
+// Reproduces feature_dem.cpp including calHarrisR's quirks, integer cv::Point rounding in redetect, the cross-shaped
+// spacing test and the "push then check size" region cap.  std::sort ties are resolved stably (GFTT rank order).
+constexpr int DEM_MAXC = 2048;   // max GFTT corners per call (2*gftt_num)
+constexpr int DEM_MAXR = 192;    // max entries kept per region (existing + new)
+
+__device__ __forceinline__ float dem_harris(const uint8_t* __restrict__ img, int pitch, float ptx, float pty) {
+  int xx = (int)ptx, yy = (int)pty;
+  const uint8_t* p = img + (size_t)yy * pitch + xx;
+  int p0 = p[-pitch - 1], p1 = p[-pitch], p2 = p[-pitch + 1];
+  int p3 = p[-1];
+  int p5 = p[pitch + 1];  // quirk (feature_dem.cpp:71)
+  int p6 = p[pitch - 1], p7 = p[pitch], p8 = p[pitch + 1];
+  float IX = (float)((p0 + p3 + p6 - (p2 + p5 + p8)) / 3);
+  float IY = (float)((p0 + p1 + p2 - (p6 + p7 + p8)) / 3);
+  float X2 = IX * IX, Y2 = IY * IX, XY = IX * IX;
+  return (X2 * Y2) - (XY * XY) - 0.05f * (X2 + Y2) * (X2 + Y2);
+}
+
+__global__ __launch_bounds__(64) void k_feature_dem(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
+                                                    const float* __restrict__ corners, const int* __restrict__ ncorners,
+                                                    int corner_cap, const int* __restrict__ mode,
+                                                    const double* __restrict__ exist_xy, const int* __restrict__ nexist,
+                                                    int exist_cap, float* __restrict__ out_xy, int* __restrict__ out_n,
+                                                    int out_cap) {
+  const int s = blockIdx.x;
+  const int md = mode ? mode[s] : 1;
+  if (md == 0) return;
+  const int lane = threadIdx.x;
+  __shared__ float cx[DEM_MAXC], cy[DEM_MAXC], cscore[DEM_MAXC];
+  __shared__ short creg[DEM_MAXC];
+  __shared__ short sorted_idx[DEM_MAXC];  // candidate indices grouped by region, sorted by score desc (stable)
+  __shared__ int rcount[16], roff[17];
+  __shared__ float kx[16][DEM_MAXR], ky[16][DEM_MAXR];
+  __shared__ int kcount[16], knew0[16];
+  const uint8_t* img = src.ptr(s, sstride);
+  int nc = ncorners[s];
+  if (nc > corner_cap) nc = corner_cap;
+  if (nc > DEM_MAXC) nc = DEM_MAXC;
+  const float* C = corners + (size_t)s * corner_cap * 2;
+  if (lane < 16) {
+    rcount[lane] = 0;
+    kcount[lane] = 0;
+  }
+  __syncthreads();
+  // existing features (redetect): fill regions in landmark order (sequential to keep order) -- lane 0
+  if (md == 2 && lane == 0) {
+    int ne = nexist[s];
+    if (ne > exist_cap) ne = exist_cap;
+    const double* E = exist_xy + (size_t)s * exist_cap * 2;
+    for (int i = 0; i < ne; i++) {
+      float px = (float)E[2 * i], py = (float)E[2 * i + 1];
+      if (px >= 3 && px < (w - 3) && py >= 3 && py < (h - 3)) {
+        int r = (int)(4.f * floorf(py / (float)prm.regionHeight) + px / (float)prm.regionWidth);
+        int k = kcount[r];
+        if (k < DEM_MAXR) {
+          kx[r][k] = px;
+          ky[r][k] = py;
+          kcount[r] = k + 1;
+        }
+      }
+    }
+  }
+  // candidates: region + score
+  for (int i = lane; i < nc; i += 64) {
+    float px = C[2 * i], py = C[2 * i + 1];
+    int r = -1;
+    float sc = 0.f;
+    if (px >= 3 && px < (w - 3) && py >= 3 && py < (h - 3)) {
+      r = (int)(4.f * floorf(py / (float)prm.regionHeight) + px / (float)prm.regionWidth);
+      sc = dem_harris(img, pitch, px, py);
+      atomicAdd(&rcount[r], 1);
+    }
+    cx[i] = px;
+    cy[i] = py;
+    cscore[i] = sc;
+    creg[i] = (short)r;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int o = 0;
+    for (int r = 0; r < 16; r++) {
+      roff[r] = o;
+      o += rcount[r];
+    }
+    roff[16] = o;
+  }
+  __syncthreads();
+  // stable rank inside the region: #(same region, score greater) + #(same region, equal score, earlier index)
+  for (int i = lane; i < nc; i += 64) {
+    int r = creg[i];
+    if (r < 0) continue;
+    float sc = cscore[i];
+    int pos = 0;
+    for (int j = 0; j < nc; j++) {
+      if (creg[j] != r) continue;
+      float sj = cscore[j];
+      pos += (sj > sc) || (sj == sc && j < i);
+    }
+    sorted_idx[roff[r] + pos] = (short)i;
+  }
+  __syncthreads();
+  if (lane < 16) knew0[lane] = kcount[lane];
+  __syncthreads();
+  // greedy spacing per region (16 lanes, one region each)
+  if (lane < 16) {
+    const int r = lane;
+    const int bd = prm.boundary_dis;
+    int kept = kcount[r];
+    unsigned count = 0;
+    for (int j = roff[r]; j < roff[r + 1]; j++) {
+      int ci = sorted_idx[j];
+      float px = cx[ci], py = cy[ci];
+      if (md == 2) {  // cv::Point pt = Point2f (rounds), feature_dem.cpp:174
+        px = (float)__float2int_rn(px);
+        py = (float)__float2int_rn(py);
+      }
+      int ok = 1;
+      for (int k = 0; k < kept; k++) {
+        float dis_x = fabsf(px - kx[r][k]);
+        float dis_y = fabsf(py - ky[r][k]);
+        if (dis_x <= (float)bd || dis_y <= (float)bd) ok = 0;
+      }
+      if (ok) {
+        if (kept < DEM_MAXR) {
+          kx[r][kept] = px;
+          ky[r][kept] = py;
+        }
+        kept++;
+        count++;
+        if (md == 1) {
+          if (count >= prm.max_region_feature_num) break;
+        } else {
+          if ((unsigned)kept >= prm.max_region_feature_num) break;
+        }
+      }
+    }
+    kcount[r] = kept < DEM_MAXR ? kept : DEM_MAXR;
+  }
+  __syncthreads();
+  // output: new points, regions in order 0..15, per region in acceptance order
+  if (lane == 0) {
+    float* O = out_xy + (size_t)s * out_cap * 2;
+    int o = 0;
+    for (int r = 0; r < 16; r++)
+      for (int k = knew0[r]; k < kcount[r]; k++) {
+        if (o < out_cap) {
+          O[2 * o] = kx[r][k];
+          O[2 * o + 1] = ky[r][k];
+        }
+        o++;
+      }
+    out_n[s] = o < out_cap ? o : out_cap;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+void launch_equalize_hist(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
+                          size_t dstride, int S, unsigned* hist, uint8_t* lut, const int* active) {
+  int blocks = div_up((w / 4) * h, 256 * 8);
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(k_hist256, dim3(blocks, S), dim3(256), 0, st, src, w, h, spitch, sstride, hist, active);
+  hipLaunchKernelGGL(k_equalize_lut, dim3(S), dim3(256), 0, st, hist, lut, w * h, active);
+  int ablocks = div_up((w / 4) * h, 256 * 4);
+  hipLaunchKernelGGL(k_lut_apply, dim3(ablocks, S), dim3(256), 0, st, src, dst, w, h, spitch, dpitch, sstride, dstride,
+                     (const uint8_t*)lut, active);
+}
+
+void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
+                       size_t dstride, int S, const int* active) {
+  int ablocks = div_up((w / 4) * h, 256 * 4);
+  hipLaunchKernelGGL(k_lut_apply, dim3(ablocks, S), dim3(256), 0, st, src, dst, w, h, spitch, dpitch, sstride, dstride,
+                     (const uint8_t*)nullptr, active);
+}
+
+void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,
+                     size_t dstride, int S, const int* active) {
+  int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+  hipLaunchKernelGGL(k_pyr_down, dim3(div_up(dw, PD_TW), div_up(dh, PD_TH), S), dim3(256), 0, st, src, sw, sh, spitch,
+                     sstride, dst, dpitch, dstride, active);
+}
+
+void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, GfttScratch sc,
+                 const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
+                 float* out_xy, int* out_n, int out_cap, const int* active) {
+  hipMemsetAsync(sc.maxenc, 0, sizeof(unsigned) * S, st);
+  hipMemsetAsync(sc.nkeys, 0, sizeof(int) * S, st);
+  dim3 grid(div_up(w, EG_TW), div_up(h, EG_TH), S);
+  hipLaunchKernelGGL(k_eig_max, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, active);
+  hipLaunchKernelGGL(k_eig_nms, grid, dim3(256), 0, st, src, w, h, pitch, sstride, (const unsigned*)sc.maxenc, qual_s,
+                     quality, sc.keys, sc.nkeys, sc.cap, active);
+  hipLaunchKernelGGL(k_sort_keys, dim3(S), dim3(SORT_T), 0, st, sc.keys, sc.nkeys, sc.cap, active);
+  size_t bm = (size_t)((w + 31) / 32) * h * sizeof(unsigned);
+  hipLaunchKernelGGL(k_select_mindist, dim3(S), dim3(64), bm, st, (const unsigned long long*)sc.keys,
+                     (const int*)sc.nkeys, sc.cap, w, h, maxc_s, max_corners, min_distance, out_xy, out_n, out_cap,
+                     active);
+}
+
+void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
+                        const float* corners, const int* ncorners, int corner_cap, const int* mode,
+                        const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,
+                        int out_cap) {
+  hipLaunchKernelGGL(k_feature_dem, dim3(S), dim3(64), 0, st, src, w, h, pitch, sstride, prm, corners, ncorners,
+                     corner_cap, mode, exist_xy, nexist, exist_cap, out_xy, out_n, out_cap);
+}
+
+hipError_t img_kernels_init() {
+  // the selection bitmap may exceed the default 64 KB dynamic LDS window only for images > 512K pixels
+  return hipFuncSetAttribute((const void*)k_select_mindist, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
+
+}  // namespace flvis

@@ -1,0 +1,66 @@
+// flvis_amd: host-visible declarations for the image / LK kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flvis {
+
+// Selects, per stream, one of two image slots (frame ping-pong: reference F2FTracking swaps last_frame/curr_frame,
+// src/frontend/f2f_tracking.cpp:70; the swap is per stream here because streams fail/recover independently).
+struct ImgSel {
+  const uint8_t* b[2];
+  const int* cur;  // device array [S] with the stream's current slot, or nullptr (always slot 0)
+  int flip;        // 0 -> current slot, 1 -> the other one (last frame)
+  __host__ __device__ const uint8_t* ptr(int s, size_t stride) const {
+    int k = cur ? (cur[s] ^ flip) : 0;
+    return b[k] + (size_t)s * stride;
+  }
+};
+static inline ImgSel img_plain(const uint8_t* p) { return ImgSel{{p, p}, nullptr, 0}; }
+
+constexpr int LK_MAX_LEVELS = 6;
+struct PyrSel {
+  ImgSel lvl[LK_MAX_LEVELS];
+  int w[LK_MAX_LEVELS], h[LK_MAX_LEVELS], pitch[LK_MAX_LEVELS];
+  size_t stride[LK_MAX_LEVELS];  // bytes between consecutive streams
+  int levels;                    // highest level index (0..levels)
+};
+
+struct LKParams {
+  int max_iter;     // clamped to [0,100] like cv::calcOpticalFlowPyrLK
+  double eps2;      // epsilon^2
+  float min_eig;    // minEigThreshold (1e-4)
+  int use_initial;  // OPTFLOW_USE_INITIAL_FLOW
+};
+
+struct DemParams {
+  int regionWidth, regionHeight, boundary_dis;
+  unsigned max_region_feature_num;
+};
+
+struct GfttScratch {
+  unsigned* maxenc;          // [S]
+  int* nkeys;                // [S]
+  unsigned long long* keys;  // [S][cap]
+  int cap;                   // power of two
+};
+
+hipError_t img_kernels_init();
+void launch_equalize_hist(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
+                          size_t dstride, int S, unsigned* hist, uint8_t* lut, const int* active);
+void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
+                       size_t dstride, int S, const int* active);
+void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,
+                     size_t dstride, int S, const int* active);
+void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, GfttScratch sc,
+                 const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
+                 float* out_xy, int* out_n, int out_cap, const int* active);
+void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
+                        const float* corners, const int* ncorners, int corner_cap, const int* mode,
+                        const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,
+                        int out_cap);
+// pyramidal LK, 31x31 window: one wave per (stream, point)
+void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
+                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active);
+
+}  // namespace flvis

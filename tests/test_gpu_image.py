@@ -1,0 +1,150 @@
+"""GPU parity tests (run with -m gpu on MI355X): HIP image kernels vs the CPU oracle, bit-exact, through the C ABI."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import _synth as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import flvis_amd
+    c = flvis_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("h,w,n", [(48, 64, 3), (480, 640, 2), (480, 752, 2)])
+def test_equalize_hist_parity(ctx, h, w, n):
+    rng = np.random.default_rng(h * w)
+    imgs = np.stack([(S.value_noise(h, w, 20 + i) * 170 + rng.integers(0, 60, (h, w))).astype(np.uint8)
+                     for i in range(n)])
+    imgs[0, :, :] = np.clip(imgs[0].astype(int) // 3 + 90, 0, 255)  # narrow histogram
+    out = ctx.equalize_hist(_cuda(imgs)).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[i], O.equalize_hist(imgs[i]))
+
+
+def test_equalize_hist_constant(ctx):
+    imgs = np.full((2, 32, 64), 9, np.uint8)
+    imgs[1] = 250
+    out = ctx.equalize_hist(_cuda(imgs)).cpu().numpy()
+    assert np.array_equal(out, imgs)
+
+
+@pytest.mark.parametrize("h,w,n", [(480, 640, 2), (240, 320, 3), (120, 160, 1), (60, 80, 2), (480, 752, 1), (62, 92, 2)])
+def test_pyr_down_parity(ctx, h, w, n):
+    imgs = np.stack([S.texture_u8(h, w, 30 + i) for i in range(n)])
+    out = ctx.pyr_down(_cuda(imgs)).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[i], O.pyr_down(imgs[i]))
+
+
+@pytest.mark.parametrize("h,w,maxc,q,md", [(96, 128, 50, 0.01, 5), (480, 640, 500, 0.001, 5), (480, 640, 1000, 0.001, 5),
+                                          (480, 752, 1000, 0.01, 10), (100, 132, 40, 0.05, 3)])
+def test_gftt_parity(ctx, h, w, maxc, q, md):
+    n = 3
+    imgs = np.stack([S.texture_u8(h, w, 40 + i) for i in range(n)])
+    imgs[2, : h // 2] = 128  # half flat image: few corners
+    xy, cnt = ctx.gftt(_cuda(imgs), maxc, q, md)
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(n):
+        want = O.gftt(imgs[i], maxc, q, md)
+        assert cnt[i] == len(want), (i, cnt[i], len(want))
+        assert np.array_equal(xy[i, :cnt[i]], want)
+
+
+def test_gftt_flat_image_has_no_corners(ctx):
+    imgs = np.full((1, 64, 64), 100, np.uint8)
+    xy, cnt = ctx.gftt(_cuda(imgs), 10, 0.01, 5)
+    assert int(cnt[0]) == 0
+
+
+@pytest.mark.parametrize("h,w,fp", [(480, 640, [15, 30, 5, 500, 0.001, 5]), (480, 752, [30, 20, 5, 1000, 0.01, 10])])
+def test_feature_dem_detect_parity(ctx, h, w, fp):
+    n = 2
+    imgs = np.stack([S.texture_u8(h, w, 50 + i) for i in range(n)])
+    xy, cnt = ctx.feature_dem_detect(_cuda(imgs), fp)
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(n):
+        want = O.dem_detect(imgs[i], fp)
+        assert cnt[i] == len(want)
+        assert np.array_equal(xy[i, :cnt[i]], want)
+
+
+@pytest.mark.parametrize("h,w,fp", [(480, 640, [15, 30, 5, 500, 0.001, 5]), (480, 752, [30, 20, 5, 1000, 0.01, 10])])
+def test_feature_dem_redetect_parity(ctx, h, w, fp):
+    import torch
+    n = 3
+    imgs = np.stack([S.texture_u8(h, w, 60 + i) for i in range(n)])
+    cap = 512
+    ex = np.zeros((n, cap, 2), np.float64)
+    nex = np.zeros(n, np.int32)
+    for i in range(n):
+        first = O.dem_detect(imgs[i], fp)
+        sel = first[:: (i + 2)].astype(np.float64) + np.array([0.37, -0.21]) * (i + 1)
+        ex[i, :len(sel)] = sel
+        nex[i] = len(sel)
+    nex[2] = 0  # no existing points at all
+    xy, cnt = ctx.feature_dem_redetect(_cuda(imgs), fp, _cuda(ex), _cuda(nex))
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(n):
+        want = O.dem_redetect(imgs[i], fp, ex[i, :nex[i]])
+        assert cnt[i] == len(want), (i, cnt[i], len(want))
+        assert np.array_equal(xy[i, :cnt[i]], want)
+
+
+def _lk_case(h, w, n, seed, shifts, npts, max_level=10):
+    prev = np.zeros((n, h, w), np.uint8)
+    nxt = np.zeros((n, h, w), np.uint8)
+    nmax = npts + 7
+    pp = np.zeros((n, nmax, 2), np.float32)
+    init = np.zeros((n, nmax, 2), np.float32)
+    cnt = np.zeros(n, np.int32)
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        dx, dy = shifts[i % len(shifts)]
+        prev[i], nxt[i] = S.shifted_pair(h, w, seed + i, dx, dy)
+        pts = O.gftt(prev[i], npts, 0.01, 6)
+        extra = np.array([[1.5, 2.5], [w - 2.25, h - 3.5], [w / 2 + 0.123, 0.75], [-8.0, 20.0], [w + 40.0, 10.0]],
+                         np.float32)  # border / outside points
+        pts = np.concatenate([pts[: npts - len(extra)], extra])
+        k = len(pts) - (i % 3)
+        pp[i, :k] = pts[:k]
+        init[i, :k] = pts[:k] + np.array([dx, dy], np.float32) * 0.6 + rng.normal(0, 0.7, (k, 2)).astype(np.float32)
+        cnt[i] = k
+    return prev, nxt, pp, init, cnt
+
+
+@pytest.mark.parametrize("h,w,n,seed,max_level,use_initial", [
+    (480, 640, 2, 100, 10, True), (480, 640, 2, 110, 5, True), (240, 320, 3, 120, 10, False),
+    (480, 752, 1, 130, 10, True), (120, 160, 2, 140, 1, True)])
+def test_lk_parity_bit_exact(ctx, h, w, n, seed, max_level, use_initial):
+    shifts = [(3.3, -2.1), (-7.6, 5.2), (0.3, 0.2)]
+    prev, nxt, pp, init, cnt = _lk_case(h, w, n, seed, shifts, 120)
+    out, st = ctx.lk_track(_cuda(prev), _cuda(nxt), _cuda(pp), _cuda(init), _cuda(cnt), max_level=max_level,
+                           use_initial=use_initial)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    for i in range(n):
+        k = cnt[i]
+        want, wst = O.lk(prev[i], nxt[i], pp[i, :k], init[i, :k], max_level=max_level, use_initial=use_initial)
+        assert np.array_equal(st[i, :k], wst), (i, np.nonzero(st[i, :k] != wst))
+        assert np.array_equal(out[i, :k].view(np.uint32), want.view(np.uint32)), (
+            i, np.abs(out[i, :k] - want).max())
+
+
+def test_lk_empty_and_ragged(ctx):
+    prev, nxt, pp, init, cnt = _lk_case(120, 160, 3, 200, [(1.0, 0.5)], 30)
+    cnt[1] = 0
+    out, st = ctx.lk_track(_cuda(prev), _cuda(nxt), _cuda(pp), _cuda(init), _cuda(cnt))
+    out = out.cpu().numpy()
+    assert np.array_equal(out[1], init[1])          # untouched
+    want, wst = O.lk(prev[2], nxt[2], pp[2, :cnt[2]], init[2, :cnt[2]])
+    assert np.array_equal(out[2, :cnt[2]], want)
