@@ -27,6 +27,9 @@ def load_library(rebuild_if_stale=True):
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import it FIRST so that libflvis_hip.so binds
+    # to the HIP runtime torch already loaded; two runtimes in one process cannot both own the device.
+    import torch  # noqa: F401
     if rebuild_if_stale and os.path.exists(_build.HIPCC):
         try:
             if _build.stale():

@@ -52,14 +52,14 @@ int flvis_hip_create(int device, void* hip_stream, flvis_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return FLVIS_ERR_NO_DEVICE;
   flvis_ctx* c = new flvis_ctx();
   c->device = device;
-  if (hip_stream) {
-    c->stream = (hipStream_t)hip_stream;
-  } else {
+  if (hip_stream == (void*)(intptr_t)-1) {  // FLVIS_STREAM_NEW: private non-blocking stream
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
       delete c;
       return FLVIS_ERR_HIP;
     }
     c->own_stream = true;
+  } else {
+    c->stream = (hipStream_t)hip_stream;  // NULL == the device's default (null) stream, as in HIP itself
   }
   if (img_kernels_init() != hipSuccess) {
     (void)hipGetLastError();

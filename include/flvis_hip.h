@@ -40,8 +40,9 @@ typedef enum flvis_status {
 const char* flvis_version(void);
 
 /* Creates a context bound to HIP device `device`.  `hip_stream` is an existing hipStream_t (e.g. torch's current
- * stream) or NULL to let the library create its own non-blocking stream.  Fails with FLVIS_ERR_NO_DEVICE when no GPU
- * is visible. */
+ * stream); NULL means the device's default (null) stream exactly as in HIP; FLVIS_STREAM_NEW asks the library to
+ * create a private non-blocking stream.  Fails with FLVIS_ERR_NO_DEVICE when no GPU is visible. */
+#define FLVIS_STREAM_NEW ((void*)(intptr_t)-1)
 int flvis_hip_create(int device, void* hip_stream, flvis_ctx** out);
 void flvis_hip_destroy(flvis_ctx* ctx);
 const char* flvis_last_error(const flvis_ctx* ctx);
