@@ -110,6 +110,7 @@ class Context:
         """prev/nxt uint8 [n,h,w]; prev_pts/next_pts float32 [n,nmax,2]; count int32 [n].
         Returns (next_pts_out, status uint8 [n,nmax])."""
         import torch
+        prev, nxt = prev.contiguous(), nxt.contiguous()
         n, h, w = prev.shape
         nmax = prev_pts.shape[1]
         assert prev_pts.dtype == torch.float32 and next_pts.dtype == torch.float32 and count.dtype == torch.int32
@@ -122,6 +123,7 @@ class Context:
 
     def gftt(self, img, max_corners, quality, min_distance):
         import torch
+        img = img.contiguous()
         n, h, w = img.shape
         out = torch.zeros((n, max_corners, 2), dtype=torch.float32, device=img.device)
         cnt = torch.zeros((n,), dtype=torch.int32, device=img.device)
@@ -131,6 +133,7 @@ class Context:
 
     def feature_dem_detect(self, img, f_para, out_cap=1024):
         import torch
+        img = img.contiguous()
         n, h, w = img.shape
         fp = (C.c_double * 6)(*[float(x) for x in f_para])
         out = torch.zeros((n, out_cap, 2), dtype=torch.float32, device=img.device)
@@ -141,6 +144,7 @@ class Context:
 
     def feature_dem_redetect(self, img, f_para, exist_xy, exist_count, out_cap=1024):
         import torch
+        img = img.contiguous()
         n, h, w = img.shape
         fp = (C.c_double * 6)(*[float(x) for x in f_para])
         assert exist_xy.dtype == torch.float64 and exist_count.dtype == torch.int32

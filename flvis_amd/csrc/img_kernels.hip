@@ -219,7 +219,7 @@ __device__ __forceinline__ void eig_tile(const uint8_t* __restrict__ img, int w,
         sc += fy * fy;
       }
     float a = sa * 0.5f, b = sb, cc = sc * 0.5f;
-    eig[i] = (a + cc) - __fsqrt_rn((a - cc) * (a - cc) + b * b);
+    eig[i] = (a + cc) - sqrtf((a - cc) * (a - cc) + b * b);
   }
   __syncthreads();
 }

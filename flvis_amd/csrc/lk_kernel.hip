@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const
                       iA22 = wave_sum_i64((long long)a22);
       const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
       float D = A11 * A22 - A12 * A12;
-      const float minEig = __fdiv_rn(A22 + A11 - __fsqrt_rn((A11 - A22) * (A11 - A22) + 4.f * A12 * A12),
+      const float minEig = __fdiv_rn(A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12),
                                      (float)(2 * LK_WIN * LK_WIN));
       if (minEig < prm.min_eig || D < 1.1920929e-07f) {
         if (level == 0) st = 0;

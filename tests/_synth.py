@@ -54,6 +54,6 @@ def shifted_pair(h, w, seed, dx, dy, margin=64):
         d = big[y0 + 1][:, x0 + 1]
         return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
 
-    i0 = np.clip(np.round(sample(0.0, 0.0)), 0, 255).astype(np.uint8)
-    i1 = np.clip(np.round(sample(-dx, -dy)), 0, 255).astype(np.uint8)
+    i0 = np.ascontiguousarray(np.clip(np.round(sample(0.0, 0.0)), 0, 255).astype(np.uint8))
+    i1 = np.ascontiguousarray(np.clip(np.round(sample(-dx, -dy)), 0, 255).astype(np.uint8))
     return i0, i1
