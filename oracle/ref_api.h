@@ -43,4 +43,115 @@ class FeatureDEM {
                       bool existed) const;
 };
 
+
+}  // namespace ref
+
+#include "ref_math.hpp"
+namespace ref {
+int poly_real_roots(const double* a, int deg, double* roots);
+void project_points(const float* p3d, int n, const SE3& T, const double K[4], const double D[4], float* out);
+void undistort_points(const float* src, int n, const double K[4], const double D[4], const Mat3& R, const double P[12],
+                      float* dst);
+Vec3 triangulate_dlt(Vec2 pt1, Vec2 pt2, const double P1[12], const double P2[12]);
+Vec3 triangulate_two_view(Vec2 pt1, Vec2 pt2, const SE3& T1, const SE3& T2, double fx, double fy, double cx, double cy);
+int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
+bool ransac_subset(uint64_t seed, uint32_t hyp, int count, int m, int* idx);
+int seven_point(const double x1[][2], const double x2[][2], double F[3][9]);
+int find_fundamental_ransac(const float* m1, const float* m2, int n, double thr, double conf, uint64_t seed,
+                            uint8_t* mask);
+int p3p_grunert(const Vec3 P[3], const Vec3 f[3], Mat3 Rs[4], Vec3 ts[4]);
+bool solve_spd6(const double H[36], const double b[6], double x[6]);
+int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, double fy, double cx, double cy,
+                     bool iterative_flag, int iterations, double reproj_err, double conf, uint64_t seed, SE3& T,
+                     uint8_t* mask);
+bool optimize_in_frame(SE3& T_c_w, const Vec3* lm_3d_w, const Vec2* lm_2d, const int64_t* lm_id, int n, double fx,
+                       double fy, double cx, double cy);
+}  // namespace ref
+
+#include <deque>
+#include <map>
+namespace ref {
+
+// ---- wire structs (msg/KeyFrame.msg, msg/CorrectionInf.msg; src/utils/include/keyframe_msg.h, correction_inf_msg.h)
+struct KeyFrameStruct {
+  int64_t frame_id = 0;
+  int lm_count = 0;
+  std::vector<int64_t> lm_id;
+  std::vector<Vec2> lm_2d;
+  std::vector<Vec3> lm_3d;
+  SE3 T_c_w = se3_identity();
+};
+struct CorrectionInfStruct {
+  int64_t frame_id = 0;
+  SE3 T_c_w = se3_identity();
+  int lm_count = 0;
+  std::vector<int64_t> lm_id;
+  std::vector<Vec3> lm_3d;
+  int lm_outlier_count = 0;
+  std::vector<int64_t> lm_outlier_id;
+};
+
+// src/backend/include/poselmbag.h
+struct LM_ITEM {
+  int64_t id;
+  int count;
+  Vec3 p3d_w;
+};
+struct POSE_ITEM {
+  int64_t relevent_frame_id;
+  int64_t pose_id;
+  SE3 pose;
+};
+class PoseLMBag {
+ public:
+  std::vector<LM_ITEM> lm_sub_bag;
+  std::vector<POSE_ITEM> pose_sub_bag;
+  int pose_buffer_size, newest, oldest, wp_init;
+  bool pose_sub_bag_initialized;
+  explicit PoseLMBag(int pose_buffer_size_in);
+  void reset();
+  bool hasTheLM(int64_t id_in, int& idx) const;
+  bool addLMObservation(int64_t id_in, Vec3 p3d_w_in);
+  bool addLMObservationSlidingWindow(int64_t id_in, Vec3 p3d_w_in);
+  bool removeLMObservation(int64_t id_in);
+  void addPose(int64_t id_in, const SE3& pose_in);
+  int64_t getPoseIdByReleventFrameId(int64_t frame_id) const;
+};
+
+// the part of g2o::SparseOptimizer the local map uses: pose vertices (ring slots), landmark vertices, projection edges
+struct BAGraph {
+  struct PoseV {
+    SE3 est;
+    bool fixed;
+    bool present;
+  };
+  struct Edge {
+    int64_t id;
+    int64_t lm;
+    int pose;
+    Vec2 z;
+  };
+  double K[4];
+  std::vector<PoseV> poses;
+  std::map<int64_t, Vec3> lms;
+  std::map<int64_t, Edge> edges;  // by edge id
+  void optimize(int iterations);
+  void remove_pose(int slot);
+  void remove_lm(int64_t id);
+};
+
+class LocalMap {
+ public:
+  enum State { UN_INITIALIZED, SLIDING_WINDOW, OPTIMIZING, FAIL };
+  LocalMap(int window, double fx, double fy, double cx, double cy);
+  bool frame_callback(const KeyFrameStruct& kf, CorrectionInfStruct& out);
+  void reset();
+  PoseLMBag bag;
+  BAGraph graph;
+  std::deque<KeyFrameStruct> kfs;
+  int window_size;
+  State state;
+  int64_t edge_id;
+};
+
 }  // namespace ref

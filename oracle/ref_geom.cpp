@@ -1,0 +1,837 @@
+// ORACLE (test infrastructure, NOT product code) -- point geometry of the FLVIS front-end.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
+//
+//   project_points       cv::projectPoints call sites   src/processing/lkorb_tracking.cpp:55-61, camera_frame.cpp:113-122
+//   undistort_points     cv::undistortPoints            src/frontend/f2f_tracking.cpp:301,425; lkorb_tracking.cpp:87; camera_frame.cpp:130
+//   triangulate_dlt      Triangulation::triangulationPt src/processing/triangulation.cpp:9-39 (Eigen::JacobiSVD -> one-sided Jacobi)
+//   find_fundamental_ransac  cv::findFundamentalMat(FM_RANSAC, 5.0, 0.99)   lkorb_tracking.cpp:133-135
+//   solve_pnp_ransac     cv::solvePnPRansac(...,100,3.0,0.99,ITERATIVE|P3P) lkorb_tracking.cpp:170-177
+//   optimize_in_frame    OptimizeInFrame::optimize      src/processing/optimize_in_frame.cpp:10-91 + g2o LM
+//                        (3rdPartLib/g2o/g2o/core/optimization_algorithm_levenberg.cpp:58-175, base_binary_edge.hpp:61-134,
+//                         robust_kernel_impl.cpp:65-78, types/sba/types_six_dof_expmap.cpp:389-433)
+//
+// **parity unpinned** for the OpenCV-resident steps (no OpenCV here, no golden vectors in the reference).
+// Where OpenCV's internals cannot be matched (RNG stream, EPnP/DLT initialisers) this file DEFINES the algorithm:
+//   * both RANSACs keep OpenCV's control flow (RANSACPointSetRegistrator: subset draw with duplicate rejection, best model =
+//     strictly more inliers, adaptive iteration count RANSACUpdateNumIters) but draw from a counter-based RNG (ref_math.hpp);
+//   * 7-point F: Hartley-normalised points, null space by Gauss-Jordan with full pivoting, cubic by bracketing + bisection;
+//   * PnP hypotheses: Grunert P3P on the first 3 sample points, remaining sample points disambiguate (OpenCV: EPnP on 5
+//     points for ITERATIVE, P3P on 4 for P3P); refinement on the RANSAC inliers: 10 Gauss-Newton steps on reprojection error.
+// Tests pin these against synthetic ground truth and scipy.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ref_api.h"
+#include "ref_math.hpp"
+
+namespace ref {
+
+// ------------------------------------------------------------------------------------------ polynomial real roots
+static double poly_eval(const double* a, int deg, double x) {
+  double r = a[deg];
+  for (int i = deg - 1; i >= 0; i--) r = r * x + a[i];
+  return r;
+}
+
+// Real roots of a[0] + a[1]x + ... + a[deg]x^deg (deg <= 4), ascending.  Deterministic: only + - * / sqrt and compares.
+// Roots of even multiplicity (no sign change) are not reported.
+int poly_real_roots(const double* a_in, int deg, double* roots) {
+  double a[5];
+  double amax = 0;
+  for (int i = 0; i <= deg; i++) {
+    a[i] = a_in[i];
+    amax = std::max(amax, std::fabs(a[i]));
+  }
+  if (amax == 0) return 0;
+  while (deg > 0 && std::fabs(a[deg]) <= 1e-14 * amax) deg--;
+  if (deg == 0) return 0;
+  if (deg == 1) {
+    roots[0] = -a[0] / a[1];
+    return 1;
+  }
+  if (deg == 2) {
+    double disc = a[1] * a[1] - 4 * a[2] * a[0];
+    if (disc < 0) return 0;
+    double sq = std::sqrt(disc);
+    double q = -0.5 * (a[1] + (a[1] >= 0 ? sq : -sq));
+    double r0 = q / a[2];
+    double r1 = (q != 0) ? a[0] / q : r0;
+    if (disc == 0) {
+      roots[0] = r0;
+      return 1;
+    }
+    roots[0] = std::min(r0, r1);
+    roots[1] = std::max(r0, r1);
+    return 2;
+  }
+  double d[5];
+  for (int i = 1; i <= deg; i++) d[i - 1] = a[i] * i;
+  double crit[4];
+  int nc = poly_real_roots(d, deg - 1, crit);
+  double B = 0;
+  for (int i = 0; i < deg; i++) B = std::max(B, std::fabs(a[i] / a[deg]));
+  B += 1.0;
+  double knots[6];
+  int nk = 0;
+  knots[nk++] = -B;
+  for (int i = 0; i < nc; i++)
+    if (crit[i] > -B && crit[i] < B) knots[nk++] = crit[i];
+  knots[nk++] = B;
+  int nr = 0;
+  for (int i = 0; i + 1 < nk; i++) {
+    double lo = knots[i], hi = knots[i + 1];
+    double flo = poly_eval(a, deg, lo), fhi = poly_eval(a, deg, hi);
+    if (flo == 0) {
+      if (nr == 0 || roots[nr - 1] != lo) roots[nr++] = lo;
+      continue;
+    }
+    if (fhi == 0) {
+      if (i + 2 == nk) roots[nr++] = hi;  // interior knots are picked up as `lo` of the next interval
+      continue;
+    }
+    if ((flo < 0) == (fhi < 0)) continue;
+    for (int it = 0; it < 200; it++) {
+      double mid = 0.5 * (lo + hi);
+      if (mid == lo || mid == hi) break;
+      double fm = poly_eval(a, deg, mid);
+      if (fm == 0) {
+        lo = hi = mid;
+        break;
+      }
+      if ((fm < 0) == (flo < 0)) {
+        lo = mid;
+        flo = fm;
+      } else {
+        hi = mid;
+      }
+    }
+    roots[nr++] = 0.5 * (lo + hi);
+  }
+  return nr;
+}
+
+// ------------------------------------------------------------------------------------------ camera maps
+// cv::projectPoints(Point3f, rvec, tvec, K, D[k1 k2 p1 p2]) -> Point2f.  R is taken from the pose quaternion directly
+// (the reference goes SE3 -> Rodrigues -> rvec -> Rodrigues, an identity up to rounding).
+void project_points(const float* p3d, int n, const SE3& T, const double K[4], const double D[4], float* out) {
+  Mat3 R = quat_to_mat(T.q);
+  for (int i = 0; i < n; i++) {
+    Vec3 P{(double)p3d[3 * i], (double)p3d[3 * i + 1], (double)p3d[3 * i + 2]};
+    Vec3 X = R * P + T.t;
+    double z = X.z ? 1. / X.z : 1;
+    double x = X.x * z, y = X.y * z;
+    double r2 = x * x + y * y, r4 = r2 * r2;
+    double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    double cdist = 1 + D[0] * r2 + D[1] * r4;
+    double xd = x * cdist + D[2] * a1 + D[3] * a2;
+    double yd = y * cdist + D[2] * a3 + D[3] * a1;
+    out[2 * i] = (float)(xd * K[0] + K[2]);
+    out[2 * i + 1] = (float)(yd * K[1] + K[3]);
+  }
+}
+
+// cv::undistortPoints(src, dst, K, D, R, P): 5 fixed-point iterations of the distortion model, then R and P.
+void undistort_points(const float* src, int n, const double K[4], const double D[4], const Mat3& R, const double P[12],
+                      float* dst) {
+  for (int i = 0; i < n; i++) {
+    double x = (src[2 * i] - K[2]) / K[0], y = (src[2 * i + 1] - K[3]) / K[1];
+    double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      double r2 = x * x + y * y;
+      double icdist = 1. / (1 + (D[1] * r2 + D[0]) * r2);
+      double deltaX = 2 * D[2] * x * y + D[3] * (r2 + 2 * x * x);
+      double deltaY = D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    double xx = R.m[0][0] * x + R.m[0][1] * y + R.m[0][2];
+    double yy = R.m[1][0] * x + R.m[1][1] * y + R.m[1][2];
+    double ww = 1. / (R.m[2][0] * x + R.m[2][1] * y + R.m[2][2]);
+    x = xx * ww;
+    y = yy * ww;
+    dst[2 * i] = (float)(x * P[0] + P[2]);       // fx' = P(0,0), cx' = P(0,2)
+    dst[2 * i + 1] = (float)(y * P[5] + P[6]);   // fy' = P(1,1), cy' = P(1,2)
+  }
+}
+
+// ------------------------------------------------------------------------------------------ DLT triangulation
+// Smallest right singular vector of the 4x4 A by one-sided (Hestenes) Jacobi; X = V[:,min] / V[3,min].
+Vec3 triangulate_dlt(Vec2 pt1, Vec2 pt2, const double P1[12], const double P2[12]) {
+  double A[4][4], V[4][4];
+  for (int j = 0; j < 4; j++) {
+    A[0][j] = pt1.y * P1[8 + j] - P1[4 + j];
+    A[1][j] = P1[j] - pt1.x * P1[8 + j];
+    A[2][j] = pt2.y * P2[8 + j] - P2[4 + j];
+    A[3][j] = P2[j] - pt2.x * P2[8 + j];
+  }
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) V[i][j] = (i == j);
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0;
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 4; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < 4; i++) {
+          alpha += A[i][p] * A[i][p];
+          beta += A[i][q] * A[i][q];
+          gamma += A[i][p] * A[i][q];
+        }
+        if (gamma * gamma <= 1e-32 * (alpha * beta)) continue;  // already orthogonal to working precision
+        off = 1;
+        double zeta = (beta - alpha) / (2.0 * gamma);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 4; i++) {
+          double ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - s * aq;
+          A[i][q] = s * ap + c * aq;
+          double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq;
+          V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (off == 0) break;
+  }
+  int best = 0;
+  double bn = DBL_MAX;
+  for (int j = 0; j < 4; j++) {
+    double nn = 0;
+    for (int i = 0; i < 4; i++) nn += A[i][j] * A[i][j];
+    if (nn < bn) {
+      bn = nn;
+      best = j;
+    }
+  }
+  return {V[0][best] / V[3][best], V[1][best] / V[3][best], V[2][best] / V[3][best]};
+}
+
+// Triangulation::triangulationPt(pt1, pt2, T_c_w1, T_c_w2, fx,fy,cx,cy)  triangulation.cpp:80-97
+Vec3 triangulate_two_view(Vec2 pt1, Vec2 pt2, const SE3& T1, const SE3& T2, double fx, double fy, double cx, double cy) {
+  double P1[12], P2[12];
+  const SE3* Ts[2] = {&T1, &T2};
+  double* Ps[2] = {P1, P2};
+  for (int k = 0; k < 2; k++) {
+    Mat3 R = quat_to_mat(Ts[k]->q);
+    Vec3 t = Ts[k]->t;
+    double T34[3][4] = {{R.m[0][0], R.m[0][1], R.m[0][2], t.x}, {R.m[1][0], R.m[1][1], R.m[1][2], t.y},
+                        {R.m[2][0], R.m[2][1], R.m[2][2], t.z}};
+    for (int j = 0; j < 4; j++) {
+      Ps[k][j] = fx * T34[0][j] + 0 * T34[1][j] + cx * T34[2][j];
+      Ps[k][4 + j] = 0 * T34[0][j] + fy * T34[1][j] + cy * T34[2][j];
+      Ps[k][8 + j] = 0 * T34[0][j] + 0 * T34[1][j] + 1 * T34[2][j];
+    }
+  }
+  return triangulate_dlt(pt1, pt2, P1, P2);
+}
+
+// ------------------------------------------------------------------------------------------ RANSAC plumbing
+// cv::RANSACUpdateNumIters
+int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+  p = std::max(p, 0.);
+  p = std::min(p, 1.);
+  ep = std::max(ep, 0.);
+  ep = std::min(ep, 1.);
+  double num = std::max(1. - p, DBL_MIN);
+  double denom = 1. - std::pow(1. - ep, modelPoints);
+  if (denom < DBL_MIN) return 0;
+  num = std::log(num);
+  denom = std::log(denom);
+  return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)lrint(num / denom);
+}
+
+// draws `m` distinct indices in [0,count) for hypothesis `hyp`; false if it cannot (count too small)
+bool ransac_subset(uint64_t seed, uint32_t hyp, int count, int m, int* idx) {
+  int got = 0;
+  for (uint32_t k = 0; k < 256 && got < m; k++) {
+    int c = (int)(rng_draw(seed, hyp, k) % (uint32_t)count);
+    bool dup = false;
+    for (int j = 0; j < got; j++) dup |= (idx[j] == c);
+    if (!dup) idx[got++] = c;
+  }
+  return got == m;
+}
+
+// ------------------------------------------------------------------------------------------ 7-point fundamental matrix
+static double det3(const double* r0, const double* r1, const double* r2) {
+  return r0[0] * (r1[1] * r2[2] - r1[2] * r2[1]) - r0[1] * (r1[0] * r2[2] - r1[2] * r2[0]) +
+         r0[2] * (r1[0] * r2[1] - r1[1] * r2[0]);
+}
+
+// Returns up to 3 fundamental matrices (row-major 3x3, x2^T F x1 = 0).
+int seven_point(const double x1[][2], const double x2[][2], double F[3][9]) {
+  // Hartley normalisation of the 7 points
+  double c1[2] = {0, 0}, c2[2] = {0, 0};
+  for (int i = 0; i < 7; i++) {
+    c1[0] += x1[i][0];
+    c1[1] += x1[i][1];
+    c2[0] += x2[i][0];
+    c2[1] += x2[i][1];
+  }
+  for (int k = 0; k < 2; k++) {
+    c1[k] /= 7;
+    c2[k] /= 7;
+  }
+  double d1 = 0, d2 = 0;
+  for (int i = 0; i < 7; i++) {
+    d1 += std::sqrt((x1[i][0] - c1[0]) * (x1[i][0] - c1[0]) + (x1[i][1] - c1[1]) * (x1[i][1] - c1[1]));
+    d2 += std::sqrt((x2[i][0] - c2[0]) * (x2[i][0] - c2[0]) + (x2[i][1] - c2[1]) * (x2[i][1] - c2[1]));
+  }
+  if (d1 < 1e-12 || d2 < 1e-12) return 0;
+  const double s1 = std::sqrt(2.0) * 7 / d1, s2 = std::sqrt(2.0) * 7 / d2;
+  double A[7][9];
+  for (int i = 0; i < 7; i++) {
+    double u1 = (x1[i][0] - c1[0]) * s1, v1 = (x1[i][1] - c1[1]) * s1;
+    double u2 = (x2[i][0] - c2[0]) * s2, v2 = (x2[i][1] - c2[1]) * s2;
+    double row[9] = {u2 * u1, u2 * v1, u2, v2 * u1, v2 * v1, v2, u1, v1, 1};
+    memcpy(A[i], row, sizeof(row));
+  }
+  // Gauss-Jordan with full pivoting
+  int pivcol[7];
+  bool used[9] = {false};
+  for (int r = 0; r < 7; r++) {
+    int br = -1, bc = -1;
+    double bv = 0;
+    for (int i = r; i < 7; i++)
+      for (int j = 0; j < 9; j++)
+        if (!used[j] && std::fabs(A[i][j]) > bv) {
+          bv = std::fabs(A[i][j]);
+          br = i;
+          bc = j;
+        }
+    if (bv < 1e-12) return 0;  // rank deficient sample
+    if (br != r)
+      for (int j = 0; j < 9; j++) std::swap(A[r][j], A[br][j]);
+    used[bc] = true;
+    pivcol[r] = bc;
+    double inv = 1.0 / A[r][bc];
+    for (int j = 0; j < 9; j++) A[r][j] *= inv;
+    for (int i = 0; i < 7; i++)
+      if (i != r) {
+        double f = A[i][bc];
+        if (f != 0)
+          for (int j = 0; j < 9; j++) A[i][j] -= f * A[r][j];
+      }
+  }
+  int freec[2], nf = 0;
+  for (int j = 0; j < 9; j++)
+    if (!used[j]) freec[nf++] = j;
+  double f1[9], f2[9];
+  double* fs[2] = {f1, f2};
+  for (int k = 0; k < 2; k++) {
+    for (int j = 0; j < 9; j++) fs[k][j] = 0;
+    fs[k][freec[k]] = 1;
+    for (int r = 0; r < 7; r++) fs[k][pivcol[r]] = -A[r][freec[k]];
+  }
+  // det(f2 + lambda (f1 - f2)) = 0
+  double Bm[9];
+  for (int j = 0; j < 9; j++) Bm[j] = f1[j] - f2[j];
+  const double *a0 = f2, *a1 = f2 + 3, *a2 = f2 + 6, *b0 = Bm, *b1 = Bm + 3, *b2 = Bm + 6;
+  double c[4];
+  c[0] = det3(a0, a1, a2);
+  c[1] = det3(b0, a1, a2) + det3(a0, b1, a2) + det3(a0, a1, b2);
+  c[2] = det3(b0, b1, a2) + det3(b0, a1, b2) + det3(a0, b1, b2);
+  c[3] = det3(b0, b1, b2);
+  double roots[4];
+  int nr = poly_real_roots(c, 3, roots);
+  int nm = 0;
+  for (int k = 0; k < nr && nm < 3; k++) {
+    double Fh[9];
+    for (int j = 0; j < 9; j++) Fh[j] = f2[j] + roots[k] * Bm[j];
+    // F = T2^T Fh T1 with T = [s 0 -s cx; 0 s -s cy; 0 0 1]
+    double T1[9] = {s1, 0, -s1 * c1[0], 0, s1, -s1 * c1[1], 0, 0, 1};
+    double T2[9] = {s2, 0, -s2 * c2[0], 0, s2, -s2 * c2[1], 0, 0, 1};
+    double tmp[9], Fo[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int m = 0; m < 3; m++) s += Fh[3 * i + m] * T1[3 * m + j];
+        tmp[3 * i + j] = s;
+      }
+    double nn = 0;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int m = 0; m < 3; m++) s += T2[3 * m + i] * tmp[3 * m + j];
+        Fo[3 * i + j] = s;
+        nn += s * s;
+      }
+    if (!(nn > 0) || !std::isfinite(nn)) continue;
+    double inv = 1.0 / std::sqrt(nn);
+    for (int j = 0; j < 9; j++) F[nm][j] = Fo[j] * inv;
+    nm++;
+  }
+  return nm;
+}
+
+// OpenCV FMEstimatorCallback::computeError: max of the two squared point-line distances, as float
+static inline float f_error(const double* F, double x1, double y1, double x2, double y2) {
+  double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+  double s2 = 1. / (a * a + b * b);
+  double dd2 = x2 * a + y2 * b + c;
+  a = F[0] * x2 + F[3] * y2 + F[6];
+  b = F[1] * x2 + F[4] * y2 + F[7];
+  c = F[2] * x2 + F[5] * y2 + F[8];
+  double s1 = 1. / (a * a + b * b);
+  double dd1 = x1 * a + y1 * b + c;
+  return (float)std::max(dd1 * dd1 * s1, dd2 * dd2 * s2);
+}
+
+// cv::findFundamentalMat(m1, m2, FM_RANSAC, thr, conf, mask) -> mask only (the reference discards F).  Returns #inliers.
+int find_fundamental_ransac(const float* m1, const float* m2, int n, double thr, double conf, uint64_t seed,
+                            uint8_t* mask) {
+  for (int i = 0; i < n; i++) mask[i] = 0;
+  if (n < 7) return 0;
+  const int modelPoints = 7;
+  int niters = 1000;
+  const float t = (float)(thr * thr);
+  int maxGood = 0;
+  std::vector<uint8_t> cur(n);
+  if (n == 7) {  // OpenCV: exactly 7 points -> no RANSAC, all points kept
+    for (int i = 0; i < n; i++) mask[i] = 1;
+    return n;
+  }
+  for (int iter = 0; iter < niters; iter++) {
+    int idx[7];
+    if (!ransac_subset(seed, (uint32_t)iter, n, modelPoints, idx)) break;
+    double x1[7][2], x2[7][2];
+    for (int k = 0; k < 7; k++) {
+      x1[k][0] = m1[2 * idx[k]];
+      x1[k][1] = m1[2 * idx[k] + 1];
+      x2[k][0] = m2[2 * idx[k]];
+      x2[k][1] = m2[2 * idx[k] + 1];
+    }
+    double F[3][9];
+    int nm = seven_point(x1, x2, F);
+    for (int m = 0; m < nm; m++) {
+      int good = 0;
+      for (int i = 0; i < n; i++) {
+        float e = f_error(F[m], m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]);
+        cur[i] = (e <= t);
+        good += cur[i];
+      }
+      if (good > std::max(maxGood, modelPoints - 1)) {
+        memcpy(mask, cur.data(), n);
+        maxGood = good;
+        niters = ransac_update_num_iters(conf, (double)(n - good) / n, modelPoints, niters);
+      }
+    }
+  }
+  return maxGood;
+}
+
+// ------------------------------------------------------------------------------------------ P3P (Grunert)
+// World points P[3], unit bearings f[3] -> up to 4 poses (R, t) with X_cam = R P + t.
+int p3p_grunert(const Vec3 P[3], const Vec3 f[3], Mat3 Rs[4], Vec3 ts[4]) {
+  double a2 = dot(P[1] - P[2], P[1] - P[2]), b2 = dot(P[0] - P[2], P[0] - P[2]), c2 = dot(P[0] - P[1], P[0] - P[1]);
+  if (b2 < 1e-20 || a2 < 1e-20 || c2 < 1e-20) return 0;
+  double ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
+  double A = (a2 - c2) / b2, C = c2 / b2;
+  double q[5];
+  q[4] = A * A - 2 * A - 4 * C * ca * ca + 1;
+  q[3] = -4 * A * A * cb + 4 * A * ca * cg + 4 * A * cb + 8 * C * ca * ca * cb + 8 * C * ca * cg - 4 * ca * cg;
+  q[2] = 4 * A * A * cb * cb + 2 * A * A - 8 * A * ca * cb * cg - 4 * A * cg * cg - 4 * C * ca * ca - 16 * C * ca * cb * cg -
+         4 * C * cg * cg + 4 * ca * ca + 4 * cg * cg - 2;
+  q[1] = -4 * A * A * cb + 4 * A * ca * cg + 8 * A * cb * cg * cg - 4 * A * cb + 8 * C * ca * cg + 8 * C * cb * cg * cg -
+         4 * ca * cg;
+  q[0] = A * A - 4 * A * cg * cg + 2 * A - 4 * C * cg * cg + 1;
+  double roots[4];
+  int nr = poly_real_roots(q, 4, roots);
+  int ns = 0;
+  for (int k = 0; k < nr && ns < 4; k++) {
+    double v = roots[k];
+    if (!(v > 0)) continue;
+    double den = 2 * (cg - v * ca);
+    if (std::fabs(den) < 1e-12) continue;
+    double u = ((A - 1) * v * v - 2 * A * cb * v + 1 + A) / den;
+    if (!(u > 0)) continue;
+    double dd = 1 + v * v - 2 * v * cb;
+    if (!(dd > 0)) continue;
+    double s1 = std::sqrt(b2 / dd), s2 = u * s1, s3 = v * s1;
+    Vec3 X[3] = {s1 * f[0], s2 * f[1], s3 * f[2]};
+    // rigid alignment by orthonormal triads
+    Vec3 e1w = P[1] - P[0], e1c = X[1] - X[0];
+    double n1w = norm(e1w), n1c = norm(e1c);
+    if (n1w < 1e-12 || n1c < 1e-12) continue;
+    e1w = (1 / n1w) * e1w;
+    e1c = (1 / n1c) * e1c;
+    Vec3 e3w = cross(e1w, P[2] - P[0]), e3c = cross(e1c, X[2] - X[0]);
+    double n3w = norm(e3w), n3c = norm(e3c);
+    if (n3w < 1e-12 || n3c < 1e-12) continue;
+    e3w = (1 / n3w) * e3w;
+    e3c = (1 / n3c) * e3c;
+    Vec3 e2w = cross(e3w, e1w), e2c = cross(e3c, e1c);
+    Mat3 R;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) R.m[i][j] = e1c[i] * e1w[j] + e2c[i] * e2w[j] + e3c[i] * e3w[j];
+    Rs[ns] = R;
+    ts[ns] = X[0] - R * P[0];
+    ns++;
+  }
+  return ns;
+}
+
+static inline bool reproj(const Mat3& R, Vec3 t, Vec3 P, double fx, double fy, double cx, double cy, double& u, double& v) {
+  Vec3 X = R * P + t;
+  double z = X.z ? 1. / X.z : 1;  // cv::projectPoints convention
+  u = fx * X.x * z + cx;
+  v = fy * X.y * z + cy;
+  return true;
+}
+
+// 6x6 SPD solve (Cholesky); false if not positive definite
+bool solve_spd6(const double H[36], const double b[6], double x[6]) {
+  double L[36] = {0};
+  for (int j = 0; j < 6; j++) {
+    double s = H[6 * j + j];
+    for (int k = 0; k < j; k++) s -= L[6 * j + k] * L[6 * j + k];
+    if (!(s > 0)) return false;
+    L[6 * j + j] = std::sqrt(s);
+    for (int i = j + 1; i < 6; i++) {
+      double v = H[6 * i + j];
+      for (int k = 0; k < j; k++) v -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = v / L[6 * j + j];
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) {
+    double v = b[i];
+    for (int k = 0; k < i; k++) v -= L[6 * i + k] * y[k];
+    y[i] = v / L[6 * i + i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double v = y[i];
+    for (int k = i + 1; k < 6; k++) v -= L[6 * k + i] * x[k];
+    x[i] = v / L[6 * i + i];
+  }
+  return true;
+}
+
+// g2o EdgeSE3ProjectXYZ: error and pose Jacobian (types_six_dof_expmap.cpp:389-433), tangent = (omega, upsilon)
+static inline void proj_edge(const SE3& T, Vec3 pw, Vec2 z, double fx, double fy, double cx, double cy, double e[2],
+                             double J[2][6]) {
+  Vec3 X = g2o_map(T, pw);
+  double x = X.x, y = X.y, zz = X.z, z2 = zz * zz;
+  e[0] = z.x - (x / zz * fx + cx);
+  e[1] = z.y - (y / zz * fy + cy);
+  if (J) {
+    J[0][0] = x * y / z2 * fx;
+    J[0][1] = -(1 + (x * x / z2)) * fx;
+    J[0][2] = y / zz * fx;
+    J[0][3] = -1. / zz * fx;
+    J[0][4] = 0;
+    J[0][5] = x / z2 * fx;
+    J[1][0] = (1 + y * y / z2) * fy;
+    J[1][1] = -x * y / z2 * fy;
+    J[1][2] = -x / zz * fy;
+    J[1][3] = 0;
+    J[1][4] = -1. / zz * fy;
+    J[1][5] = y / z2 * fy;
+  }
+}
+
+// Gauss-Newton refinement of T on the given correspondences (stand-in for OpenCV's final solvePnP on the inliers)
+static void pnp_refine(SE3& T, const std::vector<Vec3>& pw, const std::vector<Vec2>& z, double fx, double fy, double cx,
+                       double cy) {
+  for (int it = 0; it < 10; it++) {
+    double H[36] = {0}, b[6] = {0};
+    for (size_t i = 0; i < pw.size(); i++) {
+      double e[2], J[2][6];
+      proj_edge(T, pw[i], z[i], fx, fy, cx, cy, e, J);
+      for (int r = 0; r < 6; r++) {
+        b[r] -= J[0][r] * e[0] + J[1][r] * e[1];
+        for (int c = 0; c < 6; c++) H[6 * r + c] += J[0][r] * J[0][c] + J[1][r] * J[1][c];
+      }
+    }
+    double dx[6];
+    if (!solve_spd6(H, b, dx)) break;
+    T = g2o_mul(g2o_exp(dx), T);
+    double nn = 0;
+    for (int k = 0; k < 6; k++) nn += dx[k] * dx[k];
+    if (nn < 1e-20) break;
+  }
+}
+
+// cv::solvePnPRansac(p3d, p2d, K_rect, D=0, r, t, false, iters, reprojErr, conf, inliers, ITERATIVE|P3P).
+// p3d/p2d are the float-cast values (camera_frame.cpp:415-427).  Returns #inliers (0 = no model: T untouched).
+int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, double fy, double cx, double cy,
+                     bool iterative_flag, int iterations, double reproj_err, double conf, uint64_t seed, SE3& T,
+                     uint8_t* mask) {
+  for (int i = 0; i < n; i++) mask[i] = 0;
+  const int modelPoints = iterative_flag ? 5 : 4;
+  if (n < modelPoints) return 0;
+  int niters = iterations;
+  const float t2 = (float)(reproj_err * reproj_err);
+  int maxGood = 0;
+  Mat3 bestR = mat3_identity();
+  Vec3 bestt{0, 0, 0};
+  std::vector<uint8_t> cur(n);
+  for (int iter = 0; iter < niters; iter++) {
+    int idx[5];
+    if (!ransac_subset(seed, (uint32_t)iter, n, modelPoints, idx)) break;
+    Vec3 P[3], f[3];
+    for (int k = 0; k < 3; k++) {
+      P[k] = {(double)p3d[3 * idx[k]], (double)p3d[3 * idx[k] + 1], (double)p3d[3 * idx[k] + 2]};
+      Vec3 d{((double)p2d[2 * idx[k]] - cx) / fx, ((double)p2d[2 * idx[k] + 1] - cy) / fy, 1.0};
+      f[k] = (1.0 / norm(d)) * d;
+    }
+    Mat3 Rs[4];
+    Vec3 ts[4];
+    int ns = p3p_grunert(P, f, Rs, ts);
+    if (ns == 0) continue;
+    int bk = -1;
+    double be = DBL_MAX;
+    for (int k = 0; k < ns; k++) {
+      double e = 0;
+      for (int m = 3; m < modelPoints; m++) {
+        Vec3 Pm{(double)p3d[3 * idx[m]], (double)p3d[3 * idx[m] + 1], (double)p3d[3 * idx[m] + 2]};
+        double u, v;
+        reproj(Rs[k], ts[k], Pm, fx, fy, cx, cy, u, v);
+        double du = u - (double)p2d[2 * idx[m]], dv = v - (double)p2d[2 * idx[m] + 1];
+        e += du * du + dv * dv;
+      }
+      if (e < be) {
+        be = e;
+        bk = k;
+      }
+    }
+    if (bk < 0) continue;
+    int good = 0;
+    for (int i = 0; i < n; i++) {
+      Vec3 Pi{(double)p3d[3 * i], (double)p3d[3 * i + 1], (double)p3d[3 * i + 2]};
+      double u, v;
+      reproj(Rs[bk], ts[bk], Pi, fx, fy, cx, cy, u, v);
+      float du = (float)u - p2d[2 * i], dv = (float)v - p2d[2 * i + 1];  // projectPoints -> Point2f, then L2SQR in float
+      float e = du * du + dv * dv;
+      cur[i] = (e <= t2);
+      good += cur[i];
+    }
+    if (good > std::max(maxGood, modelPoints - 1)) {
+      memcpy(mask, cur.data(), n);
+      maxGood = good;
+      bestR = Rs[bk];
+      bestt = ts[bk];
+      niters = ransac_update_num_iters(conf, (double)(n - good) / n, modelPoints, niters);
+    }
+  }
+  if (maxGood == 0) return 0;
+  SE3 Tb = g2o_from_mat(bestR, bestt);
+  std::vector<Vec3> pw;
+  std::vector<Vec2> z;
+  for (int i = 0; i < n; i++)
+    if (mask[i]) {
+      pw.push_back({(double)p3d[3 * i], (double)p3d[3 * i + 1], (double)p3d[3 * i + 2]});
+      z.push_back({(double)p2d[2 * i], (double)p2d[2 * i + 1]});
+    }
+  pnp_refine(Tb, pw, z, fx, fy, cx, cy);
+  // SE3_from_rvec_tvec: Rodrigues(rvec) -> R -> SE3(R,t)   (common.h:151-158)
+  T = se3_from_mat(quat_to_mat(Tb.q), Tb.t);
+  return maxGood;
+}
+
+// ------------------------------------------------------------------------------------------ pose-only LM (g2o)
+// One g2o optimize(n_iter) call on a single free VertexSE3Expmap with fixed landmarks; edges given in active order.
+struct PoseEdge {
+  Vec3 pw;
+  Vec2 z;
+  int64_t id;
+  bool alive;
+};
+
+static double robust_chi2(const SE3& T, const std::vector<PoseEdge>& E, double fx, double fy, double cx, double cy) {
+  double chi = 0;
+  for (auto& e : E) {
+    if (!e.alive) continue;
+    double er[2];
+    proj_edge(T, e.pw, e.z, fx, fy, cx, cy, er, nullptr);
+    double c2 = er[0] * er[0] + er[1] * er[1];
+    if (c2 <= 1.0)
+      chi += c2;
+    else
+      chi += 2 * std::sqrt(c2) * 1.0 - 1.0;
+  }
+  return chi;
+}
+
+static void g2o_pose_optimize(SE3& T, const std::vector<PoseEdge>& E, int iterations, double fx, double fy, double cx,
+                              double cy) {
+  double lambda = -1, ni = 2;
+  for (int iteration = 0; iteration < iterations; iteration++) {
+    double currentChi = robust_chi2(T, E, fx, fy, cx, cy);
+    double H[36] = {0}, b[6] = {0};
+    for (auto& e : E) {
+      if (!e.alive) continue;
+      double er[2], J[2][6];
+      proj_edge(T, e.pw, e.z, fx, fy, cx, cy, er, J);
+      double c2 = er[0] * er[0] + er[1] * er[1];
+      double w = (c2 <= 1.0) ? 1.0 : 1.0 / std::sqrt(c2);  // rho'
+      double o0 = -er[0] * w, o1 = -er[1] * w;               // omega_r * rho[1]
+      for (int r = 0; r < 6; r++) {
+        b[r] += J[0][r] * o0 + J[1][r] * o1;
+        for (int c = 0; c < 6; c++) H[6 * r + c] += (J[0][r] * w) * J[0][c] + (J[1][r] * w) * J[1][c];
+      }
+    }
+    if (iteration == 0) {
+      double maxDiag = 0;
+      for (int j = 0; j < 6; j++) maxDiag = std::max(std::fabs(H[7 * j]), maxDiag);
+      lambda = 1e-5 * maxDiag;
+      ni = 2;
+    }
+    double rho = 0;
+    int qmax = 0;
+    bool lambda_bad = false;
+    do {
+      SE3 backup = T;
+      double Hl[36];
+      memcpy(Hl, H, sizeof(Hl));
+      for (int j = 0; j < 6; j++) Hl[7 * j] += lambda;
+      double x[6] = {0};
+      bool ok2 = solve_spd6(Hl, b, x);
+      if (ok2) T = g2o_mul(g2o_exp(x), T);
+      double tempChi = robust_chi2(T, E, fx, fy, cx, cy);
+      if (!ok2) tempChi = DBL_MAX;
+      rho = currentChi - tempChi;
+      double scale = 0;
+      for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        double scaleFactor = std::max(1. / 3., alpha);
+        lambda *= scaleFactor;
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        T = backup;
+        if (!std::isfinite(lambda)) {
+          lambda_bad = true;
+          break;
+        }
+      }
+      qmax++;
+    } while (rho < 0 && qmax < 10);
+    if (qmax == 10 || rho == 0 || lambda_bad) break;  // Terminate
+  }
+}
+
+// OptimizeInFrame::optimize.  lm arrays are the valid inlier pairs in frame order.  Returns false if <10 edges.
+bool optimize_in_frame(SE3& T_c_w, const Vec3* lm_3d_w, const Vec2* lm_2d, const int64_t* lm_id, int n, double fx,
+                       double fy, double cx, double cy) {
+  if (n < 10) return false;
+  std::vector<PoseEdge> E(n);
+  for (int i = 0; i < n; i++) E[i] = {lm_3d_w[i], lm_2d[i], lm_id[i], true};
+  // active edges are processed in edge-id order (sparse_optimizer.cpp:493-498); edge id = lm_id
+  std::stable_sort(E.begin(), E.end(), [](const PoseEdge& a, const PoseEdge& b) { return a.id < b.id; });
+  SE3 T = g2o_from_mat(quat_to_mat(T_c_w.q), T_c_w.t);
+  g2o_pose_optimize(T, E, 2, fx, fy, cx, cy);
+  int alive = 0;
+  for (auto& e : E) {
+    double er[2];
+    proj_edge(T, e.pw, e.z, fx, fy, cx, cy, er, nullptr);
+    if (er[0] * er[0] + er[1] * er[1] > 3.0) e.alive = false;
+    alive += e.alive;
+  }
+  if (alive < 10) return false;
+  g2o_pose_optimize(T, E, 2, fx, fy, cx, cy);
+  T_c_w = se3_from_mat(quat_to_mat(T.q), T.t);
+  return true;
+}
+
+}  // namespace ref
+
+// ------------------------------------------------------------------------------------------ C entry points (ctypes)
+extern "C" {
+int ref_poly_real_roots(const double* a, int deg, double* roots) { return ref::poly_real_roots(a, deg, roots); }
+
+void ref_project_points(const float* p3d, int n, const double* pose7 /*tx ty tz qx qy qz qw*/, const double* K,
+                        const double* D, float* out) {
+  ref::SE3 T{{pose7[6], pose7[3], pose7[4], pose7[5]}, {pose7[0], pose7[1], pose7[2]}};
+  ref::project_points(p3d, n, T, K, D, out);
+}
+void ref_undistort_points(const float* src, int n, const double* K, const double* D, const double* R9, const double* P12,
+                          float* dst) {
+  ref::Mat3 R;
+  for (int i = 0; i < 9; i++) R.m[i / 3][i % 3] = R9[i];
+  ref::undistort_points(src, n, K, D, R, P12, dst);
+}
+void ref_triangulate_dlt(const double* pt1, const double* pt2, const double* P1, const double* P2, double* out) {
+  ref::Vec3 X = ref::triangulate_dlt({pt1[0], pt1[1]}, {pt2[0], pt2[1]}, P1, P2);
+  out[0] = X.x;
+  out[1] = X.y;
+  out[2] = X.z;
+}
+int ref_seven_point(const double* x1, const double* x2, double* F27) {
+  double a[7][2], b[7][2], F[3][9];
+  for (int i = 0; i < 7; i++) {
+    a[i][0] = x1[2 * i];
+    a[i][1] = x1[2 * i + 1];
+    b[i][0] = x2[2 * i];
+    b[i][1] = x2[2 * i + 1];
+  }
+  int n = ref::seven_point(a, b, F);
+  memcpy(F27, F, sizeof(F));
+  return n;
+}
+int ref_find_fundamental_ransac(const float* m1, const float* m2, int n, double thr, double conf, uint64_t seed,
+                                uint8_t* mask) {
+  return ref::find_fundamental_ransac(m1, m2, n, thr, conf, seed, mask);
+}
+int ref_p3p(const double* P9, const double* f9, double* R36, double* t12) {
+  ref::Vec3 P[3], f[3];
+  for (int i = 0; i < 3; i++) {
+    P[i] = {P9[3 * i], P9[3 * i + 1], P9[3 * i + 2]};
+    f[i] = {f9[3 * i], f9[3 * i + 1], f9[3 * i + 2]};
+  }
+  ref::Mat3 Rs[4];
+  ref::Vec3 ts[4];
+  int n = ref::p3p_grunert(P, f, Rs, ts);
+  for (int k = 0; k < n; k++) {
+    for (int i = 0; i < 9; i++) R36[9 * k + i] = Rs[k].m[i / 3][i % 3];
+    t12[3 * k] = ts[k].x;
+    t12[3 * k + 1] = ts[k].y;
+    t12[3 * k + 2] = ts[k].z;
+  }
+  return n;
+}
+int ref_solve_pnp_ransac(const float* p3d, const float* p2d, int n, const double* K4, int iterative_flag, int iterations,
+                         double reproj_err, double conf, uint64_t seed, double* pose7_inout, uint8_t* mask) {
+  ref::SE3 T{{pose7_inout[6], pose7_inout[3], pose7_inout[4], pose7_inout[5]},
+             {pose7_inout[0], pose7_inout[1], pose7_inout[2]}};
+  int r = ref::solve_pnp_ransac(p3d, p2d, n, K4[0], K4[1], K4[2], K4[3], iterative_flag != 0, iterations, reproj_err,
+                                conf, seed, T, mask);
+  pose7_inout[0] = T.t.x;
+  pose7_inout[1] = T.t.y;
+  pose7_inout[2] = T.t.z;
+  pose7_inout[3] = T.q.x;
+  pose7_inout[4] = T.q.y;
+  pose7_inout[5] = T.q.z;
+  pose7_inout[6] = T.q.w;
+  return r;
+}
+int ref_optimize_in_frame(double* pose7_inout, const double* lm3d, const double* lm2d, const int64_t* ids, int n,
+                          const double* K4) {
+  ref::SE3 T{{pose7_inout[6], pose7_inout[3], pose7_inout[4], pose7_inout[5]},
+             {pose7_inout[0], pose7_inout[1], pose7_inout[2]}};
+  std::vector<ref::Vec3> p3(n);
+  std::vector<ref::Vec2> p2(n);
+  for (int i = 0; i < n; i++) {
+    p3[i] = {lm3d[3 * i], lm3d[3 * i + 1], lm3d[3 * i + 2]};
+    p2[i] = {lm2d[2 * i], lm2d[2 * i + 1]};
+  }
+  bool ok = ref::optimize_in_frame(T, p3.data(), p2.data(), ids, n, K4[0], K4[1], K4[2], K4[3]);
+  pose7_inout[0] = T.t.x;
+  pose7_inout[1] = T.t.y;
+  pose7_inout[2] = T.t.z;
+  pose7_inout[3] = T.q.x;
+  pose7_inout[4] = T.q.y;
+  pose7_inout[5] = T.q.z;
+  pose7_inout[6] = T.q.w;
+  return ok ? 1 : 0;
+}
+}

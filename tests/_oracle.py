@@ -90,3 +90,216 @@ def dem_redetect(img, f_para, existed, cap=4096):
     n = lib().ref_feature_dem_redetect(_p(img, C.c_uint8), img.shape[1], img.shape[0], _p(fp, C.c_double),
                                        _p(ex, C.c_double), ex.shape[0], _p(out, C.c_float), cap)
     return out[:n].copy()
+
+
+# ---------------------------------------------------------------------------------------------- geometry
+def _d(a):
+    return _p(np.ascontiguousarray(a, np.float64), C.c_double)
+
+
+def poly_real_roots(coeffs):
+    a = np.ascontiguousarray(coeffs, np.float64)
+    r = np.zeros(4, np.float64)
+    n = lib().ref_poly_real_roots(_p(a, C.c_double), len(a) - 1, _p(r, C.c_double))
+    return r[:n].copy()
+
+
+def project_points(p3d, pose7, K, D):
+    p = np.ascontiguousarray(p3d, np.float32).reshape(-1, 3)
+    out = np.zeros((len(p), 2), np.float32)
+    lib().ref_project_points(_p(p, C.c_float), len(p), _d(pose7), _d(K), _d(D), _p(out, C.c_float))
+    return out
+
+
+def undistort_points(src, K, D, R, P):
+    s = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    out = np.zeros_like(s)
+    lib().ref_undistort_points(_p(s, C.c_float), len(s), _d(K), _d(D), _d(np.asarray(R).reshape(9)),
+                               _d(np.asarray(P).reshape(12)), _p(out, C.c_float))
+    return out
+
+
+def triangulate_dlt(pt1, pt2, P1, P2):
+    out = np.zeros(3)
+    lib().ref_triangulate_dlt(_d(pt1), _d(pt2), _d(np.asarray(P1).reshape(12)), _d(np.asarray(P2).reshape(12)),
+                              _p(out, C.c_double))
+    return out
+
+
+def seven_point(x1, x2):
+    F = np.zeros((3, 9))
+    n = lib().ref_seven_point(_d(x1), _d(x2), _p(F, C.c_double))
+    return F[:n].reshape(n, 3, 3)
+
+
+def find_fundamental_ransac(m1, m2, thr=5.0, conf=0.99, seed=1):
+    a = np.ascontiguousarray(m1, np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(m2, np.float32).reshape(-1, 2)
+    mask = np.zeros(len(a), np.uint8)
+    f = lib().ref_find_fundamental_ransac
+    f.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_double, C.c_double, C.c_uint64,
+                  C.POINTER(C.c_uint8)]
+    n = f(_p(a, C.c_float), _p(b, C.c_float), len(a), thr, conf, seed, _p(mask, C.c_uint8))
+    return n, mask
+
+
+def p3p(P, f):
+    R = np.zeros((4, 3, 3))
+    t = np.zeros((4, 3))
+    n = lib().ref_p3p(_d(P), _d(f), _p(R, C.c_double), _p(t, C.c_double))
+    return R[:n], t[:n]
+
+
+def solve_pnp_ransac(p3d, p2d, K4, iterative, pose7=None, iterations=100, reproj=3.0, conf=0.99, seed=1):
+    a = np.ascontiguousarray(p3d, np.float32).reshape(-1, 3)
+    b = np.ascontiguousarray(p2d, np.float32).reshape(-1, 2)
+    pose = np.array([0, 0, 0, 0, 0, 0, 1.0]) if pose7 is None else np.ascontiguousarray(pose7, np.float64).copy()
+    mask = np.zeros(len(a), np.uint8)
+    f = lib().ref_solve_pnp_ransac
+    f.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int,
+                  C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]
+    n = f(_p(a, C.c_float), _p(b, C.c_float), len(a), _d(K4), int(iterative), iterations, reproj, conf, seed,
+          _p(pose, C.c_double), _p(mask, C.c_uint8))
+    return n, pose, mask
+
+
+def optimize_in_frame(pose7, lm3d, lm2d, ids, K4):
+    pose = np.ascontiguousarray(pose7, np.float64).copy()
+    a = np.ascontiguousarray(lm3d, np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(lm2d, np.float64).reshape(-1, 2)
+    i = np.ascontiguousarray(ids, np.int64)
+    ok = lib().ref_optimize_in_frame(_p(pose, C.c_double), _p(a, C.c_double), _p(b, C.c_double), _p(i, C.c_int64),
+                                     len(a), _d(K4))
+    return bool(ok), pose
+
+
+class LocalMap:
+    def __init__(self, window, K4):
+        self.window = window
+        lib().ref_localmap_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().ref_localmap_create(window, _d(K4)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().ref_localmap_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def push(self, frame_id, pose7, lm_id, lm_2d, lm_3d, cap=8192):
+        ids = np.ascontiguousarray(lm_id, np.int64)
+        n = len(ids)
+        ofid = C.c_int64(0)
+        opose = np.zeros(7)
+        ocnt = C.c_int(0)
+        oid = np.zeros(cap, np.int64)
+        o3d = np.zeros((cap, 3))
+        oocnt = C.c_int(0)
+        ooid = np.zeros(cap, np.int64)
+        r = lib().ref_localmap_push(self.h, C.c_int64(frame_id), _d(pose7), n, _p(ids, C.c_int64), _d(lm_2d), _d(lm_3d),
+                                    C.byref(ofid), _p(opose, C.c_double), C.byref(ocnt), _p(oid, C.c_int64),
+                                    _p(o3d, C.c_double), cap, C.byref(oocnt), _p(ooid, C.c_int64), cap)
+        if not r:
+            return None
+        return dict(frame_id=ofid.value, pose7=opose, lm_id=oid[:ocnt.value].copy(), lm_3d=o3d[:ocnt.value].copy(),
+                    outlier_id=ooid[:oocnt.value].copy())
+
+    def poses(self):
+        p = np.zeros((self.window, 7))
+        f = np.zeros(self.window, np.int32)
+        pr = np.zeros(self.window, np.int32)
+        lib().ref_localmap_poses(self.h, _p(p, C.c_double), _p(f, C.c_int32), _p(pr, C.c_int32))
+        return p, f, pr
+
+
+def ba_solve(poses7, fixed, lms3, e_pose, e_lm, e_uv, K4, it1=12, cull=True, it2=8):
+    p = np.ascontiguousarray(poses7, np.float64).copy()
+    l = np.ascontiguousarray(lms3, np.float64).copy()
+    fx = np.ascontiguousarray(fixed, np.int32)
+    ep = np.ascontiguousarray(e_pose, np.int32)
+    el = np.ascontiguousarray(e_lm, np.int32)
+    uv = np.ascontiguousarray(e_uv, np.float64)
+    alive = np.zeros(len(ep), np.uint8)
+    tr = np.zeros(3)
+    f = lib().ref_ba_solve
+    f.restype = C.c_double
+    chi = f(len(p), _p(p, C.c_double), _p(fx, C.c_int32), len(l), _p(l, C.c_double), len(ep), _p(ep, C.c_int32),
+            _p(el, C.c_int32), _p(uv, C.c_double), _d(K4), it1, int(cull), it2, _p(alive, C.c_uint8), _p(tr, C.c_double))
+    return dict(poses7=p, lms3=l, alive=alive, chi2=chi, trace=tr)
+
+
+# ---------------------------------------------------------------------------------------------- tracker / config
+class RefConfig(C.Structure):
+    _fields_ = [("type_of_vi", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int),
+                ("cam0_intrinsics", C.c_double * 4), ("cam0_distortion", C.c_double * 4),
+                ("cam1_intrinsics", C.c_double * 4), ("cam1_distortion", C.c_double * 4),
+                ("T_imu_cam0", C.c_double * 16), ("T_cam0_cam1", C.c_double * 16),
+                ("vifusion_para", C.c_double * 6), ("feature_para", C.c_double * 6), ("dr_para", C.c_double * 3),
+                ("window_size", C.c_int),
+                ("cam_type", C.c_int), ("has_imu_type", C.c_int), ("skip_first_n_imgs", C.c_int),
+                ("need_equal_hist", C.c_int),
+                ("R0", C.c_double * 9), ("R1", C.c_double * 9), ("P0", C.c_double * 12), ("P1", C.c_double * 12)]
+
+
+def load_config(path):
+    cfg = RefConfig()
+    assert lib().ref_config_sizeof() == C.sizeof(RefConfig), (lib().ref_config_sizeof(), C.sizeof(RefConfig))
+    err = C.create_string_buffer(256)
+    ok = lib().ref_config_load_yaml(path.encode(), C.byref(cfg), err, 256)
+    if not ok:
+        raise RuntimeError(err.value.decode())
+    return cfg
+
+
+class Tracker:
+    def __init__(self, cfg, seed=0xF1715):
+        lib().ref_tracker_create.restype = C.c_void_p
+        lib().ref_tracker_create.argtypes = [C.POINTER(RefConfig), C.c_uint64]
+        self.h = C.c_void_p(lib().ref_tracker_create(C.byref(cfg), seed))
+        self.cfg = cfg
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().ref_tracker_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def imu(self, t, acc, gyro):
+        out = np.zeros(10)
+        lib().ref_tracker_imu(self.h, C.c_double(t), _d(acc), _d(gyro), _p(out, C.c_double))
+        return out
+
+    def image(self, t, img0, img1):
+        img0 = np.ascontiguousarray(img0, np.uint8)
+        img1 = np.ascontiguousarray(img1, np.uint8)
+        st = C.c_int(0)
+        pose = np.zeros(7)
+        n = C.c_int(0)
+        dbg = np.zeros(3, np.int32)
+        fl = lib().ref_tracker_image(self.h, C.c_double(t), _p(img0, C.c_uint8), _p(img1, C.c_uint8), C.byref(st),
+                                     _p(pose, C.c_double), C.byref(n), _p(dbg, C.c_int32))
+        return dict(new_keyframe=bool(fl & 1), reset_cmd=bool(fl & 2), state=st.value, pose7=pose, n_landmarks=n.value,
+                    dbg=dbg)
+
+    def landmarks(self, cap=2048):
+        ids = np.zeros(cap, np.int64)
+        p2d = np.zeros((cap, 2))
+        p2u = np.zeros((cap, 2))
+        p3w = np.zeros((cap, 3))
+        fl = np.zeros(cap, np.uint8)
+        n = lib().ref_tracker_landmarks(self.h, cap, _p(ids, C.c_int64), _p(p2d, C.c_double), _p(p2u, C.c_double),
+                                        _p(p3w, C.c_double), _p(fl, C.c_uint8))
+        return dict(ids=ids[:n].copy(), p2d=p2d[:n].copy(), p2u=p2u[:n].copy(), p3w=p3w[:n].copy(), flags=fl[:n].copy())
+
+    def keyframe(self, cap=2048):
+        fid = C.c_int64(0)
+        pose = np.zeros(7)
+        ids = np.zeros(cap, np.int64)
+        p2u = np.zeros((cap, 2))
+        p3w = np.zeros((cap, 3))
+        n = lib().ref_tracker_keyframe(self.h, cap, C.byref(fid), _p(pose, C.c_double), _p(ids, C.c_int64),
+                                       _p(p2u, C.c_double), _p(p3w, C.c_double))
+        return dict(frame_id=fid.value, pose7=pose, lm_id=ids[:n].copy(), lm_2d=p2u[:n].copy(), lm_3d=p3w[:n].copy())
