@@ -154,3 +154,167 @@ class Context:
                                                              _ptr(exist_count), exist_xy.shape[1], _ptr(out), _ptr(cnt),
                                                              out_cap), "feature_dem_redetect")
         return out, cnt
+
+
+# ---------------------------------------------------------------------------------------------------- pipeline level
+class FlvisCfg(C.Structure):
+    """flvis_cfg of include/flvis_hip.h."""
+    _fields_ = [("type_of_vi", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int),
+                ("cam0_intrinsics", C.c_double * 4), ("cam0_distortion", C.c_double * 4),
+                ("cam1_intrinsics", C.c_double * 4), ("cam1_distortion", C.c_double * 4),
+                ("T_imu_cam0", C.c_double * 16), ("T_cam0_cam1", C.c_double * 16),
+                ("vifusion_para", C.c_double * 6), ("feature_para", C.c_double * 6), ("dr_para", C.c_double * 3),
+                ("window_size", C.c_int),
+                ("cam_type", C.c_int), ("imu_type", C.c_int), ("skip_first_n_imgs", C.c_int),
+                ("need_equal_hist", C.c_int),
+                ("R0", C.c_double * 9), ("R1", C.c_double * 9), ("P0", C.c_double * 12), ("P1", C.c_double * 12)]
+
+
+class FrameOut(C.Structure):
+    """flvis_frame_out of include/flvis_hip.h."""
+    _fields_ = [("state", C.c_int), ("new_keyframe", C.c_int), ("reset_cmd", C.c_int), ("n_landmarks", C.c_int),
+                ("frame_id", C.c_int64), ("T_c_w", C.c_double * 7),
+                ("of_inliers", C.c_int), ("f_inliers", C.c_int), ("pnp_inliers", C.c_int), ("pad_", C.c_int),
+                ("reprojection_error", C.c_double)]
+
+
+def load_config(yaml_path):
+    """flvis_config_load: accepts the reference's yaml files unchanged.  Host-only (no GPU needed)."""
+    lib = load_library()
+    cfg = FlvisCfg()
+    err = C.create_string_buffer(256)
+    rc = lib.flvis_config_load(yaml_path.encode(), C.byref(cfg), err, 256)
+    if rc != FLVIS_OK:
+        raise FlvisError("flvis_config_load(%s) failed (%d): %s" % (yaml_path, rc, err.value.decode()))
+    return cfg
+
+
+def _P(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Tracker:
+    """Batched F2FTracking + LocalMap for n_streams independent streams on one GPU (flvis_tracker_create)."""
+
+    def __init__(self, ctx, cfg, n_streams, seed_base=0xF1715, traj_capacity=0):
+        import numpy as np
+        self.ctx = ctx
+        self.lib = ctx._lib
+        self.S = n_streams
+        self.cfg = cfg
+        self.np = np
+        self.lib.flvis_tracker_create.argtypes = [C.c_void_p, C.POINTER(FlvisCfg), C.c_int, C.c_uint64, C.c_int]
+        ctx._check(self.lib.flvis_tracker_create(ctx._h, C.byref(cfg), n_streams, seed_base, traj_capacity),
+                   "tracker_create")
+        self._out = (FrameOut * n_streams)()
+
+    def imu_feed_flvis(self, stream, samples7):
+        np = self.np
+        a = np.ascontiguousarray(samples7, np.float64).reshape(-1, 7)
+        if len(a):
+            self.ctx._check(self.lib.flvis_imu_feed_flvis_frame(self.ctx._h, stream, len(a), _P(a, C.c_double)),
+                            "imu_feed")
+
+    def imu_feed_sensor(self, stream, t, acc, gyro):
+        a = (C.c_double * 3)(*[float(x) for x in acc])
+        g = (C.c_double * 3)(*[float(x) for x in gyro])
+        self.ctx._check(self.lib.flvis_imu_feed(self.ctx._h, stream, C.c_double(t), a, g), "imu_feed")
+
+    def image_feed(self, img0, img1, times, want_out=True, with_local_map=True):
+        """img0/img1: uint8 cuda tensors [S,H,W]; times: sequence of S floats."""
+        np = self.np
+        assert img0.is_cuda and img0.is_contiguous() and img1.is_contiguous() and img0.shape[0] == self.S
+        t = np.ascontiguousarray(times, np.float64)
+        out = C.cast(self._out, C.c_void_p) if want_out else C.c_void_p(0)
+        self.ctx._check(self.lib.flvis_image_feed(self.ctx._h, _ptr(img0), _ptr(img1), _P(t, C.c_double), out,
+                                                  int(with_local_map)), "image_feed")
+        if not want_out:
+            return None
+        res = []
+        for o in self._out:
+            res.append(dict(state=o.state, new_keyframe=bool(o.new_keyframe), reset_cmd=bool(o.reset_cmd),
+                            n_landmarks=o.n_landmarks, frame_id=o.frame_id, pose7=np.array(o.T_c_w[:]),
+                            dbg=np.array([o.of_inliers, o.f_inliers, o.pnp_inliers]),
+                            reprojection_error=o.reprojection_error))
+        return res
+
+    def landmarks(self, stream, cap=2048):
+        np = self.np
+        ids = np.zeros(cap, np.int64)
+        p2d = np.zeros((cap, 2))
+        p2u = np.zeros((cap, 2))
+        p3w = np.zeros((cap, 3))
+        fl = np.zeros(cap, np.uint8)
+        n = self.lib.flvis_get_landmarks(self.ctx._h, stream, cap, _P(ids, C.c_int64), _P(p2d, C.c_double),
+                                         _P(p2u, C.c_double), _P(p3w, C.c_double), _P(fl, C.c_uint8))
+        if n < 0:
+            self.ctx._check(n, "get_landmarks")
+        return dict(ids=ids[:n].copy(), p2d=p2d[:n].copy(), p2u=p2u[:n].copy(), p3w=p3w[:n].copy(), flags=fl[:n].copy())
+
+    def keyframe(self, stream, cap=2048):
+        np = self.np
+        fid = C.c_int64(0)
+        pose = np.zeros(7)
+        ids = np.zeros(cap, np.int64)
+        p2u = np.zeros((cap, 2))
+        p3w = np.zeros((cap, 3))
+        n = self.lib.flvis_get_keyframe(self.ctx._h, stream, cap, C.byref(fid), _P(pose, C.c_double), _P(ids, C.c_int64),
+                                        _P(p2u, C.c_double), _P(p3w, C.c_double))
+        if n < 0:
+            self.ctx._check(n, "get_keyframe")
+        return dict(frame_id=fid.value, pose7=pose, lm_id=ids[:n].copy(), lm_2d=p2u[:n].copy(), lm_3d=p3w[:n].copy())
+
+    def correction(self, stream, cap=8192):
+        np = self.np
+        fid = C.c_int64(0)
+        pose = np.zeros(7)
+        cnt = C.c_int(0)
+        ids = np.zeros(cap, np.int64)
+        p3 = np.zeros((cap, 3))
+        oc = C.c_int(0)
+        oid = np.zeros(cap, np.int64)
+        r = self.lib.flvis_get_correction(self.ctx._h, stream, cap, C.byref(fid), _P(pose, C.c_double), C.byref(cnt),
+                                          _P(ids, C.c_int64), _P(p3, C.c_double), C.byref(oc), _P(oid, C.c_int64))
+        if r < 0:
+            self.ctx._check(r, "get_correction")
+        if r == 0:
+            return None
+        return dict(frame_id=fid.value, pose7=pose, lm_id=ids[:cnt.value].copy(), lm_3d=p3[:cnt.value].copy(),
+                    outlier_id=oid[:oc.value].copy())
+
+    def ba_push_keyframe(self, stream, frame_id, pose7, lm_id, lm_2d, lm_3d, cap=8192):
+        np = self.np
+        p7 = np.ascontiguousarray(pose7, np.float64)
+        ids = np.ascontiguousarray(lm_id, np.int64)
+        l2 = np.ascontiguousarray(lm_2d, np.float64)
+        l3 = np.ascontiguousarray(lm_3d, np.float64)
+        fid = C.c_int64(0)
+        pose = np.zeros(7)
+        cnt = C.c_int(0)
+        oid_ = np.zeros(cap, np.int64)
+        o3 = np.zeros((cap, 3))
+        oc = C.c_int(0)
+        ooid = np.zeros(cap, np.int64)
+        r = self.lib.flvis_ba_push_keyframe(self.ctx._h, stream, C.c_int64(frame_id), _P(p7, C.c_double), len(ids),
+                                            _P(ids, C.c_int64), _P(l2, C.c_double), _P(l3, C.c_double), cap,
+                                            C.byref(fid), _P(pose, C.c_double), C.byref(cnt), _P(oid_, C.c_int64),
+                                            _P(o3, C.c_double), C.byref(oc), _P(ooid, C.c_int64))
+        if r < 0:
+            self.ctx._check(r, "ba_push_keyframe")
+        if r == 0:
+            return None
+        return dict(frame_id=fid.value, pose7=pose, lm_id=oid_[:cnt.value].copy(), lm_3d=o3[:cnt.value].copy(),
+                    outlier_id=ooid[:oc.value].copy())
+
+    def trajectory(self, stream, first, n):
+        np = self.np
+        rows = np.zeros((n, 9))
+        r = self.lib.flvis_get_trajectory(self.ctx._h, stream, first, n, _P(rows, C.c_double))
+        if r < 0:
+            self.ctx._check(r, "get_trajectory")
+        return rows
+
+    def counters(self):
+        c = (C.c_int64 * 3)()
+        self.ctx._check(self.lib.flvis_get_counters(self.ctx._h, c), "get_counters")
+        return list(c)

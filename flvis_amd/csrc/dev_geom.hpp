@@ -1,0 +1,367 @@
+// flvis_amd: device-side point geometry (fp64): camera maps, DLT triangulation, 7-point F, Grunert P3P, projection
+// edge + small SPD solves.  Reference call sites: src/processing/lkorb_tracking.cpp:55-61,87,133-135,170-177;
+// src/processing/camera_frame.cpp:113-131; src/processing/triangulation.cpp:9-97;
+// 3rdPartLib/g2o/g2o/types/sba/types_six_dof_expmap.cpp:389-433.
+#pragma once
+#include "dev_math.hpp"
+
+namespace flvis {
+
+// cv::projectPoints for one Point3f (k1 k2 p1 p2 model) -> Point2f
+FD void project_point(const float* p3, const M3& R, V3 t, const double* K, const double* D, float* out) {
+  V3 P{(double)p3[0], (double)p3[1], (double)p3[2]};
+  V3 X = R * P + t;
+  double z = X.z ? 1. / X.z : 1;
+  double x = X.x * z, y = X.y * z;
+  double r2 = x * x + y * y, r4 = r2 * r2;
+  double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+  double cdist = 1 + D[0] * r2 + D[1] * r4;
+  double xd = x * cdist + D[2] * a1 + D[3] * a2;
+  double yd = y * cdist + D[2] * a3 + D[3] * a1;
+  out[0] = (float)(xd * K[0] + K[2]);
+  out[1] = (float)(yd * K[1] + K[3]);
+}
+
+// cv::undistortPoints for one Point2f with (K, D, R, P)
+FD void undistort_point(const float* src, const double* K, const double* D, const double* R9, const double* P12,
+                        float* dst) {
+  double x = (src[0] - K[2]) / K[0], y = (src[1] - K[3]) / K[1];
+  double x0 = x, y0 = y;
+  for (int j = 0; j < 5; j++) {
+    double r2 = x * x + y * y;
+    double icdist = 1. / (1 + (D[1] * r2 + D[0]) * r2);
+    double deltaX = 2 * D[2] * x * y + D[3] * (r2 + 2 * x * x);
+    double deltaY = D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  double xx = R9[0] * x + R9[1] * y + R9[2];
+  double yy = R9[3] * x + R9[4] * y + R9[5];
+  double ww = 1. / (R9[6] * x + R9[7] * y + R9[8]);
+  x = xx * ww;
+  y = yy * ww;
+  dst[0] = (float)(x * P12[0] + P12[2]);
+  dst[1] = (float)(y * P12[5] + P12[6]);
+}
+
+// Triangulation::triangulationPt: smallest right singular vector of the 4x4 DLT matrix (one-sided Jacobi)
+__device__ inline V3 triangulate_dlt(double u1, double v1, double u2, double v2, const double* P1, const double* P2) {
+  double A[4][4], V[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    A[0][j] = v1 * P1[8 + j] - P1[4 + j];
+    A[1][j] = P1[j] - u1 * P1[8 + j];
+    A[2][j] = v2 * P2[8 + j] - P2[4 + j];
+    A[3][j] = P2[j] - u2 * P2[8 + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; sweep++) {
+    int off = 0;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int q = p + 1; q < 4; q++) {
+        double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          alpha += A[i][p] * A[i][p];
+          beta += A[i][q] * A[i][q];
+          gamma += A[i][p] * A[i][q];
+        }
+        if (gamma * gamma <= 1e-32 * (alpha * beta)) continue;
+        off = 1;
+        double zeta = (beta - alpha) / (2.0 * gamma);
+        double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          double ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - s * aq;
+          A[i][q] = s * ap + c * aq;
+          double vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq;
+          V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (!off) break;
+  }
+  int best = 0;
+  double bn = 1.7976931348623157e308;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    double nn = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) nn += A[i][j] * A[i][j];
+    if (nn < bn) {
+      bn = nn;
+      best = j;
+    }
+  }
+  double vx = 0, vy = 0, vz = 0, vw = 1;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (j == best) {
+      vx = V[0][j];
+      vy = V[1][j];
+      vz = V[2][j];
+      vw = V[3][j];
+    }
+  return V3{vx / vw, vy / vw, vz / vw};
+}
+
+__device__ inline V3 triangulate_two_view(double u1, double v1, double u2, double v2, const SE3d& T1, const SE3d& T2,
+                                          double fx, double fy, double cx, double cy) {
+  double P1[12], P2[12];
+  for (int k = 0; k < 2; k++) {
+    const SE3d& T = k == 0 ? T1 : T2;
+    double* P = k == 0 ? P1 : P2;
+    M3 R = q_to_mat(T.q);
+    double T34[3][4] = {{R.m[0][0], R.m[0][1], R.m[0][2], T.t.x}, {R.m[1][0], R.m[1][1], R.m[1][2], T.t.y},
+                        {R.m[2][0], R.m[2][1], R.m[2][2], T.t.z}};
+    for (int j = 0; j < 4; j++) {
+      P[j] = fx * T34[0][j] + 0 * T34[1][j] + cx * T34[2][j];
+      P[4 + j] = 0 * T34[0][j] + fy * T34[1][j] + cy * T34[2][j];
+      P[8 + j] = 0 * T34[0][j] + 0 * T34[1][j] + 1 * T34[2][j];
+    }
+  }
+  return triangulate_dlt(u1, v1, u2, v2, P1, P2);
+}
+
+// 7-point fundamental matrix: Hartley-normalised, Gauss-Jordan null space, cubic by bracketing.  x1/x2: [7][2]
+__device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], double (*F)[9]) {
+  double c1[2] = {0, 0}, c2[2] = {0, 0};
+  for (int i = 0; i < 7; i++) {
+    c1[0] += x1[i][0];
+    c1[1] += x1[i][1];
+    c2[0] += x2[i][0];
+    c2[1] += x2[i][1];
+  }
+  for (int k = 0; k < 2; k++) {
+    c1[k] /= 7;
+    c2[k] /= 7;
+  }
+  double d1 = 0, d2 = 0;
+  for (int i = 0; i < 7; i++) {
+    d1 += sqrt((x1[i][0] - c1[0]) * (x1[i][0] - c1[0]) + (x1[i][1] - c1[1]) * (x1[i][1] - c1[1]));
+    d2 += sqrt((x2[i][0] - c2[0]) * (x2[i][0] - c2[0]) + (x2[i][1] - c2[1]) * (x2[i][1] - c2[1]));
+  }
+  if (d1 < 1e-12 || d2 < 1e-12) return 0;
+  const double s1 = sqrt(2.0) * 7 / d1, s2 = sqrt(2.0) * 7 / d2;
+  double A[7][9];
+  for (int i = 0; i < 7; i++) {
+    double u1 = (x1[i][0] - c1[0]) * s1, v1 = (x1[i][1] - c1[1]) * s1;
+    double u2 = (x2[i][0] - c2[0]) * s2, v2 = (x2[i][1] - c2[1]) * s2;
+    A[i][0] = u2 * u1;
+    A[i][1] = u2 * v1;
+    A[i][2] = u2;
+    A[i][3] = v2 * u1;
+    A[i][4] = v2 * v1;
+    A[i][5] = v2;
+    A[i][6] = u1;
+    A[i][7] = v1;
+    A[i][8] = 1;
+  }
+  int pivcol[7];
+  bool used[9];
+  for (int j = 0; j < 9; j++) used[j] = false;
+  for (int r = 0; r < 7; r++) {
+    int br = -1, bc = -1;
+    double bv = 0;
+    for (int i = r; i < 7; i++)
+      for (int j = 0; j < 9; j++)
+        if (!used[j] && fabs(A[i][j]) > bv) {
+          bv = fabs(A[i][j]);
+          br = i;
+          bc = j;
+        }
+    if (bv < 1e-12) return 0;
+    if (br != r)
+      for (int j = 0; j < 9; j++) {
+        double tmp = A[r][j];
+        A[r][j] = A[br][j];
+        A[br][j] = tmp;
+      }
+    used[bc] = true;
+    pivcol[r] = bc;
+    double inv = 1.0 / A[r][bc];
+    for (int j = 0; j < 9; j++) A[r][j] *= inv;
+    for (int i = 0; i < 7; i++)
+      if (i != r) {
+        double f = A[i][bc];
+        if (f != 0)
+          for (int j = 0; j < 9; j++) A[i][j] -= f * A[r][j];
+      }
+  }
+  int freec[2], nf = 0;
+  for (int j = 0; j < 9; j++)
+    if (!used[j] && nf < 2) freec[nf++] = j;
+  double f1[9], f2[9];
+  for (int k = 0; k < 2; k++) {
+    double* fs = k == 0 ? f1 : f2;
+    for (int j = 0; j < 9; j++) fs[j] = 0;
+    fs[freec[k]] = 1;
+    for (int r = 0; r < 7; r++) fs[pivcol[r]] = -A[r][freec[k]];
+  }
+  double Bm[9];
+  for (int j = 0; j < 9; j++) Bm[j] = f1[j] - f2[j];
+  const double *a0 = f2, *a1 = f2 + 3, *a2 = f2 + 6, *b0 = Bm, *b1 = Bm + 3, *b2 = Bm + 6;
+  double c[4];
+  c[0] = det3(a0, a1, a2);
+  c[1] = det3(b0, a1, a2) + det3(a0, b1, a2) + det3(a0, a1, b2);
+  c[2] = det3(b0, b1, a2) + det3(b0, a1, b2) + det3(a0, b1, b2);
+  c[3] = det3(b0, b1, b2);
+  double roots[4];
+  int nr = poly_real_roots(c, 3, roots);
+  int nm = 0;
+  for (int k = 0; k < nr && nm < 3; k++) {
+    double Fh[9];
+    for (int j = 0; j < 9; j++) Fh[j] = f2[j] + roots[k] * Bm[j];
+    double T1[9] = {s1, 0, -s1 * c1[0], 0, s1, -s1 * c1[1], 0, 0, 1};
+    double T2[9] = {s2, 0, -s2 * c2[0], 0, s2, -s2 * c2[1], 0, 0, 1};
+    double tmp[9], Fo[9];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int m = 0; m < 3; m++) s += Fh[3 * i + m] * T1[3 * m + j];
+        tmp[3 * i + j] = s;
+      }
+    double nn = 0;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int m = 0; m < 3; m++) s += T2[3 * m + i] * tmp[3 * m + j];
+        Fo[3 * i + j] = s;
+        nn += s * s;
+      }
+    if (!(nn > 0) || !isfinite(nn)) continue;
+    double inv = 1.0 / sqrt(nn);
+    for (int j = 0; j < 9; j++) F[nm][j] = Fo[j] * inv;
+    nm++;
+  }
+  return nm;
+}
+
+// OpenCV FMEstimatorCallback::computeError (max of the two squared point-line distances, float)
+FD float f_error(const double* F, double x1, double y1, double x2, double y2) {
+  double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
+  double s2 = 1. / (a * a + b * b);
+  double dd2 = x2 * a + y2 * b + c;
+  a = F[0] * x2 + F[3] * y2 + F[6];
+  b = F[1] * x2 + F[4] * y2 + F[7];
+  c = F[2] * x2 + F[5] * y2 + F[8];
+  double s1 = 1. / (a * a + b * b);
+  double dd1 = x1 * a + y1 * b + c;
+  return (float)fmax(dd1 * dd1 * s1, dd2 * dd2 * s2);
+}
+
+// Grunert P3P: up to 4 (R, t) with X_cam = R P + t
+__device__ inline int p3p_grunert(const V3* P, const V3* f, M3* Rs, V3* ts) {
+  double a2 = dot(P[1] - P[2], P[1] - P[2]), b2 = dot(P[0] - P[2], P[0] - P[2]), c2 = dot(P[0] - P[1], P[0] - P[1]);
+  if (b2 < 1e-20 || a2 < 1e-20 || c2 < 1e-20) return 0;
+  double ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
+  double A = (a2 - c2) / b2, C = c2 / b2;
+  double q[5];
+  q[4] = A * A - 2 * A - 4 * C * ca * ca + 1;
+  q[3] = -4 * A * A * cb + 4 * A * ca * cg + 4 * A * cb + 8 * C * ca * ca * cb + 8 * C * ca * cg - 4 * ca * cg;
+  q[2] = 4 * A * A * cb * cb + 2 * A * A - 8 * A * ca * cb * cg - 4 * A * cg * cg - 4 * C * ca * ca - 16 * C * ca * cb * cg -
+         4 * C * cg * cg + 4 * ca * ca + 4 * cg * cg - 2;
+  q[1] = -4 * A * A * cb + 4 * A * ca * cg + 8 * A * cb * cg * cg - 4 * A * cb + 8 * C * ca * cg + 8 * C * cb * cg * cg -
+         4 * ca * cg;
+  q[0] = A * A - 4 * A * cg * cg + 2 * A - 4 * C * cg * cg + 1;
+  double roots[4];
+  int nr = poly_real_roots(q, 4, roots);
+  int ns = 0;
+  for (int k = 0; k < nr && ns < 4; k++) {
+    double v = roots[k];
+    if (!(v > 0)) continue;
+    double den = 2 * (cg - v * ca);
+    if (fabs(den) < 1e-12) continue;
+    double u = ((A - 1) * v * v - 2 * A * cb * v + 1 + A) / den;
+    if (!(u > 0)) continue;
+    double dd = 1 + v * v - 2 * v * cb;
+    if (!(dd > 0)) continue;
+    double s1 = sqrt(b2 / dd), s2 = u * s1, s3 = v * s1;
+    V3 X0 = s1 * f[0], X1 = s2 * f[1], X2 = s3 * f[2];
+    V3 e1w = P[1] - P[0], e1c = X1 - X0;
+    double n1w = norm(e1w), n1c = norm(e1c);
+    if (n1w < 1e-12 || n1c < 1e-12) continue;
+    e1w = (1 / n1w) * e1w;
+    e1c = (1 / n1c) * e1c;
+    V3 e3w = cross(e1w, P[2] - P[0]), e3c = cross(e1c, X2 - X0);
+    double n3w = norm(e3w), n3c = norm(e3c);
+    if (n3w < 1e-12 || n3c < 1e-12) continue;
+    e3w = (1 / n3w) * e3w;
+    e3c = (1 / n3c) * e3c;
+    V3 e2w = cross(e3w, e1w), e2c = cross(e3c, e1c);
+    M3 R;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        R.m[i][j] = vget(e1c, i) * vget(e1w, j) + vget(e2c, i) * vget(e2w, j) + vget(e3c, i) * vget(e3w, j);
+    Rs[ns] = R;
+    ts[ns] = X0 - R * P[0];
+    ns++;
+  }
+  return ns;
+}
+
+// g2o EdgeSE3ProjectXYZ error + pose Jacobian (tangent = omega, upsilon)
+FD void proj_edge(const SE3d& T, V3 pw, double zu, double zv, double fx, double fy, double cx, double cy, double* e,
+                  double (*J)[6]) {
+  V3 X = g2o_map(T, pw);
+  double x = X.x, y = X.y, zz = X.z, z2 = zz * zz;
+  e[0] = zu - (x / zz * fx + cx);
+  e[1] = zv - (y / zz * fy + cy);
+  if (J) {
+    J[0][0] = x * y / z2 * fx;
+    J[0][1] = -(1 + (x * x / z2)) * fx;
+    J[0][2] = y / zz * fx;
+    J[0][3] = -1. / zz * fx;
+    J[0][4] = 0;
+    J[0][5] = x / z2 * fx;
+    J[1][0] = (1 + y * y / z2) * fy;
+    J[1][1] = -x * y / z2 * fy;
+    J[1][2] = -x / zz * fy;
+    J[1][3] = 0;
+    J[1][4] = -1. / zz * fy;
+    J[1][5] = y / z2 * fy;
+  }
+}
+
+// 6x6 SPD solve by Cholesky; false if not positive definite
+__device__ inline bool solve_spd6(const double* H, const double* b, double* x) {
+  double L[36];
+  for (int i = 0; i < 36; i++) L[i] = 0;
+  for (int j = 0; j < 6; j++) {
+    double s = H[6 * j + j];
+    for (int k = 0; k < j; k++) s -= L[6 * j + k] * L[6 * j + k];
+    if (!(s > 0)) return false;
+    L[6 * j + j] = sqrt(s);
+    for (int i = j + 1; i < 6; i++) {
+      double v = H[6 * i + j];
+      for (int k = 0; k < j; k++) v -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = v / L[6 * j + j];
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; i++) {
+    double v = b[i];
+    for (int k = 0; k < i; k++) v -= L[6 * i + k] * y[k];
+    y[i] = v / L[6 * i + i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double v = y[i];
+    for (int k = i + 1; k < 6; k++) v -= L[6 * k + i] * x[k];
+    x[i] = v / L[6 * i + i];
+  }
+  return true;
+}
+
+FD double huber_rho(double e) { return e <= 1.0 ? e : 2 * sqrt(e) - 1.0; }
+FD double huber_w(double e) { return e <= 1.0 ? 1.0 : 1.0 / sqrt(e); }
+
+}  // namespace flvis

@@ -1,0 +1,560 @@
+// flvis_amd: host orchestration of the batched front-end + local map behind the C ABI (include/flvis_hip.h).
+// Host-side mirror of the reference's F2FTracking / TrackingNodeletClass::process / LocalMapNodeletClass call sequence
+// (src/frontend/f2f_tracking.cpp:59-400, src/frontend/vo_tracking.cpp:326-371,396-430, src/backend/vo_localmap.cpp:87-380):
+// the host only stages IMU samples and enqueues a FIXED kernel sequence per frame on one HIP stream; every decision the
+// reference takes per frame is taken on the device by the kernels in track_kernels.hip / ba_kernels.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/flvis_hip.h"
+#include "ctx.hpp"
+#include "track_kernels.hpp"
+
+namespace flvis {
+
+struct Pipeline {
+  int S = 0;
+  flvis_cfg cfg;
+  Pipe pipe;
+  int levels_t = 0, levels_s = 0, levels = 0;
+  // images
+  uint8_t* pyr0[2][LK_MAX_LEVELS] = {};
+  uint8_t* pyr1[LK_MAX_LEVELS] = {};
+  int lw[LK_MAX_LEVELS], lh[LK_MAX_LEVELS], lpitch[LK_MAX_LEVELS];
+  size_t lstride[LK_MAX_LEVELS];
+  GfttScratch gftt;
+  float* gftt_xy = nullptr;
+  int* gftt_n = nullptr;
+  unsigned* eq_hist = nullptr;
+  uint8_t* eq_lut = nullptr;
+  double* d_time = nullptr;
+  // host staging
+  std::vector<double> h_imu;  // [S][IMU_MAX][7]
+  std::vector<int> h_nimu;
+  void* pinned = nullptr;  // [S] times + imu + counts
+  size_t pinned_bytes = 0;
+  long long frames_fed = 0;
+  std::vector<void*> allocs;
+};
+
+}  // namespace flvis
+
+using namespace flvis;
+
+namespace {
+
+template <typename T>
+T* dalloc(Pipeline* pl, size_t n, bool zero = true) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+  if (zero) hipMemset(p, 0, n * sizeof(T));
+  pl->allocs.push_back(p);
+  return (T*)p;
+}
+
+int lk_levels(int w, int h, int win, int max_level) {
+  int level = 0;
+  for (; level <= max_level; ++level) {
+    w = (w + 1) / 2;
+    h = (h + 1) / 2;
+    if (w <= win || h <= win) return level;
+  }
+  return max_level;
+}
+
+void pose7_from_mat44(const double* m, double* out7, bool inverse) {
+  // rotation matrix -> quaternion (Eigen convention), host side
+  double R[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
+  double t[3] = {m[3], m[7], m[11]};
+  if (inverse) {
+    double Rt[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Rt[i][j] = R[j][i];
+    double ti[3];
+    for (int i = 0; i < 3; i++) ti[i] = -(Rt[i][0] * t[0] + Rt[i][1] * t[1] + Rt[i][2] * t[2]);
+    memcpy(R, Rt, sizeof(R));
+    memcpy(t, ti, sizeof(t));
+  }
+  double q[4];  // w x y z
+  double tr = R[0][0] + R[1][1] + R[2][2];
+  if (tr > 0) {
+    double s = std::sqrt(tr + 1.0);
+    q[0] = 0.5 * s;
+    s = 0.5 / s;
+    q[1] = (R[2][1] - R[1][2]) * s;
+    q[2] = (R[0][2] - R[2][0]) * s;
+    q[3] = (R[1][0] - R[0][1]) * s;
+  } else {
+    int i = 0;
+    if (R[1][1] > R[0][0]) i = 1;
+    if (R[2][2] > R[i][i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+    double v[3];
+    v[i] = 0.5 * s;
+    s = 0.5 / s;
+    q[0] = (R[k][j] - R[j][k]) * s;
+    v[j] = (R[j][i] + R[i][j]) * s;
+    v[k] = (R[k][i] + R[i][k]) * s;
+    q[1] = v[0];
+    q[2] = v[1];
+    q[3] = v[2];
+  }
+  if (inverse) {  // Sophus SO3::inverse() renormalises
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= n;
+  }
+  out7[0] = t[0];
+  out7[1] = t[1];
+  out7[2] = t[2];
+  out7[3] = q[1];
+  out7[4] = q[2];
+  out7[5] = q[3];
+  out7[6] = q[0];
+}
+
+void glibc_seed(unsigned s, int* r34) {
+  std::vector<int> v(344);
+  v[0] = (int)s;
+  for (int i = 1; i < 31; i++) {
+    long long w = (16807LL * v[i - 1]) % 2147483647;
+    if (w < 0) w += 2147483647;
+    v[i] = (int)w;
+  }
+  for (int i = 31; i < 34; i++) v[i] = v[i - 31];
+  for (int i = 34; i < 344; i++) v[i] = (int)((unsigned)v[i - 31] + (unsigned)v[i - 3]);
+  for (int i = 0; i < 34; i++) r34[i] = v[344 - 34 + i];
+}
+
+}  // namespace
+
+void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
+  if (!ctx || !ctx->pipe) return;
+  Pipeline* pl = ctx->pipe;
+  for (void* p : pl->allocs) hipFree(p);
+  if (pl->pinned) hipHostFree(pl->pinned);
+  delete pl;
+  ctx->pipe = nullptr;
+}
+
+extern "C" {
+
+int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, uint64_t seed_base, int traj_capacity) {
+  if (!ctx || !cfg || n_streams <= 0) return FLVIS_ERR_INVALID_ARG;
+  if (ctx->pipe) flvis_pipeline_destroy_internal(ctx);
+  const int w = cfg->image_width, h = cfg->image_height;
+  if (w < 64 || h < 64 || (w & 15)) return ctx->fail(FLVIS_ERR_CONFIG, "image width must be a multiple of 16 and >= 64");
+  if (cfg->window_size > BA_WMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "window_size exceeds the LDS-resident solver (16)");
+  if ((int)cfg->feature_para[3] * 2 > 2048) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para4 (gftt_num) must be <= 1024");
+  if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "image too large for the GFTT LDS bitmap");
+  hipSetDevice(ctx->device);
+  Pipeline* pl = new Pipeline();
+  ctx->pipe = pl;
+  const int S = n_streams;
+  pl->S = S;
+  pl->cfg = *cfg;
+  Pipe& p = pl->pipe;
+  memset(&p, 0, sizeof(p));
+  p.S = S;
+  CamParams& c = p.cam;
+  c.cam_type = cfg->cam_type;
+  c.w = w;
+  c.h = h;
+  c.fx = cfg->P0[0];
+  c.fy = cfg->P0[5];
+  c.cx = cfg->P0[2];
+  c.cy = cfg->P0[6];
+  memcpy(c.K0, cfg->cam0_intrinsics, 32);
+  memcpy(c.D0, cfg->cam0_distortion, 32);
+  memcpy(c.K1, cfg->cam1_intrinsics, 32);
+  memcpy(c.D1, cfg->cam1_distortion, 32);
+  memcpy(c.R0, cfg->R0, 72);
+  memcpy(c.R1, cfg->R1, 72);
+  memcpy(c.P0, cfg->P0, 96);
+  memcpy(c.P1, cfg->P1, 96);
+  pose7_from_mat44(cfg->T_cam0_cam1, c.T_c1_c0, true);
+  pose7_from_mat44(cfg->T_imu_cam0, c.T_i_c, false);
+  pose7_from_mat44(cfg->T_imu_cam0, c.T_c_i, true);
+  c.iir_ratio = (float)cfg->dr_para[0];
+  c.range = (float)cfg->dr_para[1];
+  c.enable_dummy = !(cfg->dr_para[2] < 0.5);
+  c.need_equal_hist = cfg->need_equal_hist;
+  c.skip_first_n = cfg->skip_first_n_imgs;
+  for (int i = 0; i < 4; i++) c.vi_para[i] = cfg->vifusion_para[i];
+  c.dem.regionWidth = (int)std::floor(w / 4.0);
+  c.dem.regionHeight = (int)std::floor(h / 4.0);
+  c.dem.boundary_dis = (int)std::floor(cfg->feature_para[2] / 2.0);
+  c.dem.max_region_feature_num = (unsigned)cfg->feature_para[0];
+  c.gftt_num = (int)cfg->feature_para[3];
+  c.gftt_ql = cfg->feature_para[4];
+  c.gftt_dis = (int)cfg->feature_para[5];
+  c.window = cfg->window_size;
+  c.seed = seed_base;
+
+  bool ok = true;
+#define DA(field, T, n) ok = ok && ((p.field = dalloc<T>(pl, (n))) != nullptr)
+  DA(st, StreamState, S);
+  DA(lm, Landmark, (size_t)2 * S * NMAX);
+  DA(vi, MotionState, (size_t)S * VI_QUEUE);
+  DA(imu_in, double, (size_t)S * IMU_MAX * 7);
+  DA(n_imu, int, S);
+  DA(prev_pts, float, (size_t)S * NMAX * 2);
+  DA(next_pts, float, (size_t)S * NMAX * 2);
+  DA(lk_status, uint8_t, (size_t)S * NMAX);
+  DA(lk_count, int, S);
+  DA(m1, float, (size_t)S * NMAX * 2);
+  DA(m2, float, (size_t)S * NMAX * 2);
+  DA(tri, double, (size_t)S * NMAX * 3);
+  DA(tri_mask, uint8_t, (size_t)S * NMAX);
+  DA(new_xy, float, (size_t)S * NEW_MAX * 2);
+  DA(n_new, int, S);
+  DA(exist_xy, double, (size_t)S * NMAX * 2);
+  DA(n_exist, int, S);
+  DA(act_img, int, S);
+  DA(act_track, int, S);
+  DA(det_mode, int, S);
+  DA(det_maxc, int, S);
+  DA(img_slot, int, S);
+  DA(out, FrameOut, S);
+  DA(kf, KeyFrameDev, S);
+  DA(win, WindowDev, S);
+  DA(kfs_ring, KeyFrameDev, (size_t)S * BA_WMAX);
+  DA(corr, CorrectionDev, S);
+  DA(counters, long long, 8);
+  p.ba_scratch_stride = ba_scratch_doubles();
+  DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
+  unsigned long long* seeds = dalloc<unsigned long long>(pl, S);
+  ok = ok && seeds;
+  p.seeds = seeds;
+  p.traj_cap = traj_capacity > 0 ? traj_capacity : 0;
+  if (p.traj_cap) DA(traj, double, (size_t)S * p.traj_cap * 9);
+  // image pyramids
+  pl->levels_t = lk_levels(w, h, 31, 10);
+  pl->levels_s = lk_levels(w, h, 31, 5);
+  pl->levels = std::max(pl->levels_t, pl->levels_s);
+  if (pl->levels >= LK_MAX_LEVELS) pl->levels = LK_MAX_LEVELS - 1;
+  int lw = w, lh = h;
+  for (int l = 0; l <= pl->levels; l++) {
+    pl->lw[l] = lw;
+    pl->lh[l] = lh;
+    pl->lpitch[l] = align_up(lw, 16);
+    pl->lstride[l] = (size_t)pl->lpitch[l] * lh + 64;
+    pl->lstride[l] = (pl->lstride[l] + 63) / 64 * 64;
+    for (int k = 0; k < 2; k++) ok = ok && ((pl->pyr0[k][l] = dalloc<uint8_t>(pl, pl->lstride[l] * S + 256)) != nullptr);
+    ok = ok && ((pl->pyr1[l] = dalloc<uint8_t>(pl, pl->lstride[l] * S + 256)) != nullptr);
+    lw = (lw + 1) / 2;
+    lh = (lh + 1) / 2;
+  }
+  // GFTT scratch
+  int cap = 1;
+  while (cap < (w / 2 + 1) * (h / 2 + 1)) cap <<= 1;
+  pl->gftt.cap = cap;
+  ok = ok && ((pl->gftt.maxenc = dalloc<unsigned>(pl, S)) != nullptr);
+  ok = ok && ((pl->gftt.nkeys = dalloc<int>(pl, S)) != nullptr);
+  ok = ok && ((pl->gftt.keys = dalloc<unsigned long long>(pl, (size_t)cap * S, false)) != nullptr);
+  ok = ok && ((pl->gftt_xy = dalloc<float>(pl, (size_t)S * 2 * c.gftt_num * 2)) != nullptr);
+  ok = ok && ((pl->gftt_n = dalloc<int>(pl, S)) != nullptr);
+  ok = ok && ((pl->eq_hist = dalloc<unsigned>(pl, (size_t)S * 256)) != nullptr);
+  ok = ok && ((pl->eq_lut = dalloc<uint8_t>(pl, (size_t)S * 256)) != nullptr);
+  ok = ok && ((pl->d_time = dalloc<double>(pl, S)) != nullptr);
+#undef DA
+  if (!ok) {
+    flvis_pipeline_destroy_internal(ctx);
+    return ctx->fail(FLVIS_ERR_HIP, "tracker_create: device allocation failed");
+  }
+  // initial per-stream state (F2FTracking::init, VIMOTION ctor, landmark id counter 100, glibc rand seed 1)
+  std::vector<StreamState> hs(S);
+  memset(hs.data(), 0, sizeof(StreamState) * S);
+  std::vector<unsigned long long> hseed(S);
+  for (int s = 0; s < S; s++) {
+    StreamState& st = hs[s];
+    st.state = ST_UNINIT;
+    st.cur = 0;
+    st.skip_n = cfg->skip_first_n_imgs;
+    st.lm_id_counter = 100;
+    st.vi_first = 1;
+    for (int k = 0; k < 2; k++) st.T_c_w[k][6] = 1.0;
+    st.T_kf[6] = 1.0;
+    st.guess[6] = 1.0;
+    glibc_seed(1, st.rnd_r);
+    st.rnd_pos = 0;
+    hseed[s] = seed_base + (unsigned long long)s;
+  }
+  hipMemcpy(p.st, hs.data(), sizeof(StreamState) * S, hipMemcpyHostToDevice);
+  hipMemcpy(seeds, hseed.data(), sizeof(unsigned long long) * S, hipMemcpyHostToDevice);
+  pl->h_imu.assign((size_t)S * IMU_MAX * 7, 0.0);
+  pl->h_nimu.assign(S, 0);
+  pl->pinned_bytes = sizeof(double) * S + sizeof(double) * (size_t)S * IMU_MAX * 7 + sizeof(int) * S;
+  if (hipHostMalloc(&pl->pinned, pl->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+    flvis_pipeline_destroy_internal(ctx);
+    return ctx->fail(FLVIS_ERR_HIP, "tracker_create: pinned allocation failed");
+  }
+  if (ba_kernels_init() != hipSuccess) {
+    (void)hipGetLastError();
+    flvis_pipeline_destroy_internal(ctx);
+    return ctx->fail(FLVIS_ERR_HIP, "tracker_create: cannot reserve LDS for the BA kernel");
+  }
+  hipDeviceSynchronize();
+  return FLVIS_OK;
+}
+
+int flvis_imu_feed_flvis_frame(flvis_ctx* ctx, int stream, int n, const double* samples7) {
+  if (!ctx || !ctx->pipe || !samples7) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S || n < 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "imu_feed: bad stream");
+  int& cnt = pl->h_nimu[stream];
+  if (cnt + n > IMU_MAX) return ctx->fail(FLVIS_ERR_CAPACITY, "imu_feed: more than 64 IMU samples between two frames");
+  memcpy(&pl->h_imu[((size_t)stream * IMU_MAX + cnt) * 7], samples7, sizeof(double) * 7 * n);
+  cnt += n;
+  return FLVIS_OK;
+}
+
+int flvis_imu_feed(flvis_ctx* ctx, int stream, double t, const double* a, const double* g) {
+  if (!ctx || !ctx->pipe || !a || !g) return FLVIS_ERR_INVALID_ARG;
+  double s[7];
+  s[0] = t;
+  switch (ctx->pipe->cfg.imu_type) {  // src/frontend/vo_tracking.cpp:331-357
+    case 0:                            // D435I
+      s[1] = -a[2]; s[2] = a[0]; s[3] = a[1];
+      s[4] = g[2]; s[5] = -g[0]; s[6] = -g[1];
+      break;
+    case 1:  // EuRoC_MAV
+      s[1] = -a[2]; s[2] = a[1]; s[3] = -a[0];
+      s[4] = g[2]; s[5] = -g[1]; s[6] = g[0];
+      break;
+    default:  // PIXHAWK
+      s[1] = -a[0]; s[2] = -a[1]; s[3] = -a[2];
+      s[4] = g[0]; s[5] = g[1]; s[6] = g[2];
+      break;
+  }
+  return flvis_imu_feed_flvis_frame(ctx, stream, 1, s);
+}
+
+static void fill_pyr(Pipeline* pl, PyrSel& ps, uint8_t* const* l0, uint8_t* const* l1, const int* cur, int flip, int levels) {
+  ps.levels = levels;
+  for (int l = 0; l <= levels; l++) {
+    ps.lvl[l] = ImgSel{{l0[l], l1 ? l1[l] : l0[l]}, cur, flip};
+    ps.w[l] = pl->lw[l];
+    ps.h[l] = pl->lh[l];
+    ps.pitch[l] = pl->lpitch[l];
+    ps.stride[l] = pl->lstride[l];
+  }
+}
+
+static int run_local_map(flvis_ctx* ctx) {
+  Pipeline* pl = ctx->pipe;
+  launch_ba_update(ctx->stream, pl->pipe);
+  launch_ba_solve(ctx->stream, pl->pipe);
+  return FLVIS_OK;
+}
+
+int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
+                     flvis_frame_out* h_out, int with_local_map) {
+  if (!ctx || !ctx->pipe || !d_img0 || !d_img1 || !h_times) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  Pipe& p = pl->pipe;
+  const int S = pl->S;
+  hipStream_t st = ctx->stream;
+  const int w = pl->cfg.image_width, h = pl->cfg.image_height;
+  // ---- stage host inputs (pinned) and upload
+  double* pt = (double*)pl->pinned;
+  double* pi = pt + S;
+  int* pn = (int*)(pi + (size_t)S * IMU_MAX * 7);
+  hipStreamSynchronize(st);  // the previous frame's async copies read the pinned buffer
+  memcpy(pt, h_times, sizeof(double) * S);
+  memcpy(pi, pl->h_imu.data(), sizeof(double) * (size_t)S * IMU_MAX * 7);
+  memcpy(pn, pl->h_nimu.data(), sizeof(int) * S);
+  std::fill(pl->h_nimu.begin(), pl->h_nimu.end(), 0);
+  hipMemcpyAsync(pl->d_time, pt, sizeof(double) * S, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(p.imu_in, pi, sizeof(double) * (size_t)S * IMU_MAX * 7, hipMemcpyHostToDevice, st);
+  hipMemcpyAsync(p.n_imu, pn, sizeof(int) * S, hipMemcpyHostToDevice, st);
+  // ---- fixed kernel sequence
+  launch_imu_feed(st, p);
+  launch_frame_begin(st, p, pl->d_time);
+  // images -> level 0 of the stream's current slot (copy, or equalizeHist for EuRoC), then the pyramids
+  ImgSel in0 = img_plain(d_img0), in1 = img_plain(d_img1);
+  ImgSel l0cur{{pl->pyr0[0][0], pl->pyr0[1][0]}, p.img_slot, 0};
+  ImgSel l1cur = img_plain(pl->pyr1[0]);
+  if (pl->cfg.need_equal_hist) {
+    launch_equalize_hist(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
+    launch_equalize_hist(st, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
+  } else {
+    launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
+    launch_copy_image(st, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
+  }
+  for (int l = 1; l <= pl->levels; l++) {
+    ImgSel s0{{pl->pyr0[0][l - 1], pl->pyr0[1][l - 1]}, p.img_slot, 0}, d0{{pl->pyr0[0][l], pl->pyr0[1][l]}, p.img_slot, 0};
+    launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
+    launch_pyr_down(st, img_plain(pl->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1],
+                    img_plain(pl->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
+  }
+  // temporal tracking
+  launch_track_prepare(st, p);
+  {
+    PyrSel prev, next;
+    fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 1, pl->levels_t);
+    fill_pyr(pl, next, pl->pyr0[0], pl->pyr0[1], p.img_slot, 0, pl->levels_t);
+    LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
+    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track);
+  }
+  launch_track_collect(st, p);
+  launch_ransac_f(st, p);
+  launch_ransac_pnp(st, p);
+  launch_track_post(st, p);
+  launch_pose_lm(st, p);
+  launch_reproj_filter(st, p);
+  // detection (init: detect, tracking: redetect)
+  launch_gftt(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, pl->gftt, nullptr, p.cam.gftt_ql, p.det_maxc, p.cam.gftt_num,
+              (double)p.cam.gftt_dis, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num, p.det_mode);
+  launch_feature_dem(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num,
+                     p.det_mode, p.exist_xy, p.n_exist, NMAX, p.new_xy, p.n_new, NEW_MAX);
+  launch_add_new(st, p);
+  // depth innovation: stereo LK img0 -> img1 + DLT + IIR
+  launch_depth_prepare(st, p);
+  {
+    PyrSel prev, next;
+    fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 0, pl->levels_s);
+    fill_pyr(pl, next, pl->pyr1, nullptr, nullptr, 0, pl->levels_s);
+    LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
+    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode);
+  }
+  launch_depth_innovate(st, p);
+  launch_frame_end(st, p, (int)pl->frames_fed);
+  if (with_local_map) run_local_map(ctx);
+  pl->frames_fed++;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ctx->hip_fail(e, "image_feed launch");
+  if (h_out) {
+    static_assert(sizeof(flvis_frame_out) == sizeof(FrameOut), "FrameOut layout");
+    e = hipMemcpyAsync(h_out, p.out, sizeof(FrameOut) * S, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return ctx->hip_fail(e, "image_feed readback");
+  }
+  return FLVIS_OK;
+}
+
+int flvis_get_landmarks(flvis_ctx* ctx, int stream, int cap, int64_t* h_id, double* h_2d, double* h_2du, double* h_3d,
+                        uint8_t* h_flags) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  hipStreamSynchronize(ctx->stream);
+  StreamState st;
+  hipMemcpy(&st, pl->pipe.st + stream, sizeof(st), hipMemcpyDeviceToHost);
+  int n = st.n_lm[st.cur];
+  std::vector<Landmark> lm(n);
+  if (n) hipMemcpy(lm.data(), pl->pipe.lm + ((size_t)st.cur * pl->S + stream) * NMAX, sizeof(Landmark) * n, hipMemcpyDeviceToHost);
+  for (int i = 0; i < n && i < cap; i++) {
+    h_id[i] = lm[i].id;
+    h_2d[2 * i] = lm[i].p2d[0];
+    h_2d[2 * i + 1] = lm[i].p2d[1];
+    h_2du[2 * i] = lm[i].p2u[0];
+    h_2du[2 * i + 1] = lm[i].p2u[1];
+    for (int j = 0; j < 3; j++) h_3d[3 * i + j] = lm[i].p3w[j];
+    h_flags[i] = (uint8_t)((lm[i].has3d ? 1 : 0) | (lm[i].inlier ? 2 : 0));
+  }
+  return n;
+}
+
+int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T7, int64_t* h_id, double* h_2d,
+                       double* h_3d) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  hipStreamSynchronize(ctx->stream);
+  std::vector<KeyFrameDev> kfv(1);
+  KeyFrameDev& kf = kfv[0];
+  hipMemcpy(&kf, pl->pipe.kf + stream, sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
+  if (!kf.valid) return 0;
+  *frame_id = kf.frame_id;
+  memcpy(T7, kf.T_c_w, 56);
+  for (int i = 0; i < kf.lm_count && i < cap; i++) {
+    h_id[i] = kf.lm_id[i];
+    h_2d[2 * i] = kf.lm_2d[i][0];
+    h_2d[2 * i + 1] = kf.lm_2d[i][1];
+    for (int j = 0; j < 3; j++) h_3d[3 * i + j] = kf.lm_3d[i][j];
+  }
+  return kf.lm_count;
+}
+
+static int read_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T7, int* lm_count, int64_t* h_id,
+                           double* h_3d, int* oc, int64_t* h_oid) {
+  Pipeline* pl = ctx->pipe;
+  std::vector<CorrectionDev> cv(1);
+  CorrectionDev& c = cv[0];
+  hipMemcpy(&c, pl->pipe.corr + stream, sizeof(CorrectionDev), hipMemcpyDeviceToHost);
+  if (!c.valid) return 0;
+  *frame_id = c.frame_id;
+  memcpy(T7, c.T_c_w, 56);
+  *lm_count = c.lm_count;
+  for (int i = 0; i < c.lm_count && i < cap; i++) {
+    h_id[i] = c.lm_id[i];
+    for (int j = 0; j < 3; j++) h_3d[3 * i + j] = c.lm_3d[i][j];
+  }
+  *oc = c.lm_outlier_count;
+  for (int i = 0; i < c.lm_outlier_count && i < cap; i++) h_oid[i] = c.lm_outlier_id[i];
+  return 1;
+}
+
+int flvis_get_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T7, int* lm_count, int64_t* h_id,
+                         double* h_3d, int* oc, int64_t* h_oid) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  if (stream < 0 || stream >= ctx->pipe->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  hipStreamSynchronize(ctx->stream);
+  return read_correction(ctx, stream, cap, frame_id, T7, lm_count, h_id, h_3d, oc, h_oid);
+}
+
+int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first, int n, double* h_rows9) {
+  if (!ctx || !ctx->pipe || !h_rows9) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S || first < 0 || n < 0 || first + n > pl->pipe.traj_cap)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "get_trajectory: out of range");
+  hipStreamSynchronize(ctx->stream);
+  hipMemcpy(h_rows9, pl->pipe.traj + ((size_t)stream * pl->pipe.traj_cap + first) * 9, sizeof(double) * 9 * n, hipMemcpyDeviceToHost);
+  return n;
+}
+
+int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) {
+  if (!ctx || !ctx->pipe || !h3) return FLVIS_ERR_INVALID_ARG;
+  hipStreamSynchronize(ctx->stream);
+  long long c[8];
+  hipMemcpy(c, ctx->pipe->pipe.counters, sizeof(c), hipMemcpyDeviceToHost);
+  h3[0] = ctx->pipe->frames_fed * ctx->pipe->S;
+  h3[1] = c[1];
+  h3[2] = c[2];
+  return FLVIS_OK;
+}
+
+int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, int lm_count, const int64_t* h_id,
+                           const double* h_2d, const double* h_3d, int cap, int64_t* out_frame_id, double* out_T7,
+                           int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid) {
+  if (!ctx || !ctx->pipe || !T7 || lm_count < 0 || lm_count > KF_MAXLM) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  std::vector<KeyFrameDev> kfv(1);
+  KeyFrameDev& kf = kfv[0];
+  memset(&kf, 0, sizeof(kf));
+  kf.frame_id = frame_id;
+  kf.lm_count = lm_count;
+  kf.valid = 1;
+  memcpy(kf.T_c_w, T7, 56);
+  for (int i = 0; i < lm_count; i++) {
+    kf.lm_id[i] = h_id[i];
+    kf.lm_2d[i][0] = h_2d[2 * i];
+    kf.lm_2d[i][1] = h_2d[2 * i + 1];
+    for (int j = 0; j < 3; j++) kf.lm_3d[i][j] = h_3d[3 * i + j];
+  }
+  hipStreamSynchronize(ctx->stream);
+  hipMemcpy(pl->pipe.kf + stream, &kf, sizeof(kf), hipMemcpyHostToDevice);
+  int one = 1, zero = 0;
+  hipMemcpy(&pl->pipe.st[stream].kf_pending, &one, sizeof(int), hipMemcpyHostToDevice);
+  hipMemcpy(&pl->pipe.corr[stream].valid, &zero, sizeof(int), hipMemcpyHostToDevice);
+  run_local_map(ctx);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ctx->hip_fail(e, "ba_push_keyframe");
+  return read_correction(ctx, stream, cap, out_frame_id, out_T7, out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid);
+}
+
+}  // extern "C"

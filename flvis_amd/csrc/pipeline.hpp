@@ -1,0 +1,141 @@
+// flvis_amd: device-resident state of the batched front-end (F2FTracking mirror) and local map (LocalMap mirror).
+//
+// One context tracks S independent streams.  All per-stream state lives in HBM; the host only enqueues a fixed
+// sequence of kernels per frame step (no host round trip unless the caller asks for outputs), every kernel masks
+// itself by the stream's state machine flags.  Reference anchors: src/frontend/f2f_tracking.cpp (state machine),
+// src/processing/camera_frame.cpp / landmark.cpp (frame + landmark records), src/processing/vi_motion.cpp (IMU filter),
+// src/backend/vo_localmap.cpp + poselmbag.cpp (sliding window).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "img_kernels.hpp"
+
+namespace flvis {
+
+constexpr int NMAX = 1024;        // landmark capacity per stream and frame slot
+constexpr int IMU_MAX = 64;       // IMU samples accepted per stream between two frames
+constexpr int VI_QUEUE = 400;     // STATES_QUEUE_SIZE (src/processing/include/vi_motion.h:10)
+constexpr int KF_MAXLM = 1024;    // landmarks per keyframe payload
+constexpr int BA_WMAX = 16;       // window sizes supported by the LDS-resident solver
+constexpr int BA_LMAX = 4096;     // landmarks in the window
+constexpr int BA_EMAX = 8192;     // observations (edges) in the window
+
+enum { ST_UNINIT = 0, ST_TRACKING = 1, ST_TRACKFAIL = 2 };
+enum { PH_IDLE = 0, PH_TRACK = 1, PH_INIT = 2 };
+enum { CAM_STEREO_RECT = 0, CAM_STEREO_UNRECT = 1 };
+
+// LandMarkInFrame (src/processing/include/landmark.h:8-35), AoS so that a frame-to-frame copy is one record move
+struct Landmark {
+  long long id;
+  double p3w[3];
+  double p2d[2];
+  double p2u[2];
+  double p3c[3];
+  double first2d[2];
+  double first_pose[7];  // tx ty tz qx qy qz qw
+  unsigned char has3d, inlier, pad[6];
+};
+
+struct MotionState {  // MOTION_STATE (vi_motion.h:12-17)
+  double pos[3], vel[3], q[4] /*w x y z*/, acc[3], gyro[3], t;
+};
+
+struct CamParams {
+  int cam_type, w, h;
+  double fx, fy, cx, cy;  // rectified (from P0)
+  double K0[4], D0[4], K1[4], D1[4];
+  double R0[9], R1[9], P0[12], P1[12];
+  double T_c1_c0[7];  // pose7
+  double T_i_c[7], T_c_i[7];
+  float iir_ratio, range;
+  int enable_dummy, need_equal_hist, skip_first_n;
+  double vi_para[4];
+  DemParams dem;
+  int gftt_num;
+  double gftt_ql;
+  int gftt_dis;
+  int window;
+  unsigned long long seed;
+};
+
+struct StreamState {
+  int state, phase, ok, cur;
+  int skip_n, has_imu, cont_fail, tf_cnt;
+  long long frameCount, lm_id_counter;
+  int n_lm[2];
+  long long frame_id[2];
+  double frame_time[2];
+  double T_c_w[2][7];
+  double T_kf[7];
+  int use_guess;
+  double guess[7];
+  int new_kf, reset_cmd;
+  int n_surv, of_cnt, f_cnt, pnp_cnt;
+  int orig_size, n_new;
+  double reproj_err;
+  int rnd_r[34], rnd_pos;
+  // VIMOTION scalars
+  int vi_initialized, vi_first, vi_head, vi_count;  // ring: oldest at head, count entries
+  double acc_bias[3], gyro_bias[3];
+  // local map
+  int lm_state;  // 0 UN_INITIALIZED, 1 SLIDING_WINDOW
+  int kf_pending;
+};
+
+struct FrameOut {  // per stream, per image_feed
+  int state, new_keyframe, reset_cmd, n_landmarks;
+  long long frame_id;
+  double T_c_w[7];
+  int of_cnt, f_cnt, pnp_cnt, pad;
+  double reproj_err;
+};
+
+// KeyFrame payload (msg/KeyFrame.msg without the images): what KeyFrameMsg::pub packs (src/utils/keyframe_msg.cpp:30-124)
+struct KeyFrameDev {
+  long long frame_id;
+  int lm_count, valid;
+  double T_c_w[7];
+  long long lm_id[KF_MAXLM];
+  double lm_2d[KF_MAXLM][2];
+  double lm_3d[KF_MAXLM][3];
+};
+
+// CorrectionInf (msg/CorrectionInf.msg)
+struct CorrectionDev {
+  long long frame_id;
+  int lm_count, lm_outlier_count, valid, pad;
+  double T_c_w[7];
+  long long lm_id[BA_LMAX];
+  double lm_3d[BA_LMAX][3];
+  long long lm_outlier_id[BA_EMAX];
+};
+
+// sliding-window graph of one stream (PoseLMBag + the g2o graph the callback maintains)
+struct WindowDev {
+  // PoseLMBag
+  int newest, oldest, wp_init, initialized;
+  long long pose_frame_id[BA_WMAX];
+  double bag_pose[BA_WMAX][7];
+  int n_lm;
+  long long lm_id[BA_LMAX];
+  int lm_count[BA_LMAX];
+  double lm_p3d[BA_LMAX][3];  // bag's p3d_w (running mean during init / first seen)
+  // graph
+  double pose_est[BA_WMAX][7];
+  int pose_fixed[BA_WMAX], pose_present[BA_WMAX];
+  double lm_est[BA_LMAX][3];  // vertex estimate, parallel to lm_id (vertex exists iff bag entry exists)
+  int n_edge;
+  long long edge_next_id;
+  long long e_id[BA_EMAX];
+  long long e_lm[BA_EMAX];  // landmark id
+  int e_pose[BA_EMAX];
+  double e_uv[BA_EMAX][2];
+  // keyframe queue (the `kfs` deque of vo_localmap.cpp:55): ring of the last `window` payloads, storage in Pipe::kfs_ring
+  int kfs_head, kfs_size;
+  int solve;        // set by the bookkeeping kernel when this keyframe triggers an optimisation
+  int overflow;     // a capacity (BA_LMAX / BA_EMAX) was exceeded; the window stops accepting work
+  long long ba_runs;
+};
+
+}  // namespace flvis

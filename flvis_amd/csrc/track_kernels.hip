@@ -1,0 +1,1146 @@
+// flvis_amd: batched front-end state machine kernels (gfx950).  Device-resident mirror of
+//   F2FTracking::image_feed / init_frame        src/frontend/f2f_tracking.cpp:59-453
+//   LKORBTracking::tracking (stages around LK)  src/processing/lkorb_tracking.cpp:9-202
+//   OptimizeInFrame::optimize                   src/processing/optimize_in_frame.cpp:10-91 (+ g2o LM)
+//   CameraFrame::{calReprjInlierOutlier, eraseReprjOutlier, depthInnovation, eraseNoDepthPoint, getKeyFrameInf}
+//                                               src/processing/camera_frame.cpp:18-91,93-180,236-330,515-528
+// Every kernel handles all S streams of the batch and masks itself with the stream's phase flags, so the host enqueues
+// the same kernel sequence every frame (no host decisions, graph-capturable).  Latency-bound stages use one wave (or
+// one thread) per stream; the J^T J / J^T r assemblies are wave reductions (DPP/shuffle butterflies).
+#include "dev_common.hpp"
+#include "dev_geom.hpp"
+#include "track_kernels.hpp"
+#include "vi_motion.hpp"
+
+namespace flvis {
+
+FD Landmark* lm_ptr(const Pipe& p, int slot, int s) { return p.lm + ((size_t)slot * p.S + s) * NMAX; }
+
+// glibc rand() (TYPE_3): next output from the stream's ring
+FD int glibc_rand_next(StreamState& st) {
+  int pos = st.rnd_pos;
+  int a = st.rnd_r[(pos + 34 - 31) % 34], b = st.rnd_r[(pos + 34 - 3) % 34];
+  int n = (int)((unsigned)a + (unsigned)b);
+  st.rnd_r[pos] = n;
+  st.rnd_pos = (pos + 1) % 34;
+  return (int)(((unsigned)n) >> 1);
+}
+
+FD void track_fail(StreamState& st) {  // f2f_tracking.cpp:235-247 / 257-269
+  st.cont_fail++;
+  st.cur ^= 1;  // last_frame.swap(curr_frame): escape this frame
+  if (st.cont_fail >= 2) {
+    st.state = ST_TRACKFAIL;
+    st.cont_fail = 0;
+  }
+  st.phase = PH_IDLE;
+  st.ok = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ IMU
+__global__ void k_imu_feed(Pipe p) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.S) return;
+  StreamState& st = p.st[s];
+  ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
+  int n = p.n_imu[s];
+  if (n > IMU_MAX) n = IMU_MAX;
+  const double* in = p.imu_in + (size_t)s * IMU_MAX * 7;
+  for (int i = 0; i < n; i++)
+    vi_imu_feed(p.cam, st, ring, in[7 * i], V3{in[7 * i + 1], in[7 * i + 2], in[7 * i + 3]},
+                V3{in[7 * i + 4], in[7 * i + 5], in[7 * i + 6]});
+  p.n_imu[s] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ frame begin
+__global__ void k_frame_begin(Pipe p, const double* __restrict__ frame_time) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.S) return;
+  StreamState& st = p.st[s];
+  ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
+  const double time = frame_time[s];
+  st.frameCount++;
+  st.cur ^= 1;
+  const int c = st.cur;
+  st.n_lm[c] = 0;
+  store_pose7(st.T_c_w[c], se3_identity());
+  st.frame_id[c] = st.frameCount;
+  st.frame_time[c] = time;
+  st.new_kf = 0;
+  st.reset_cmd = 0;
+  st.phase = PH_IDLE;
+  st.ok = 1;
+  st.use_guess = 0;
+  st.of_cnt = st.f_cnt = st.pnp_cnt = 0;
+  st.n_new = 0;
+  int det_mode = 0;
+  if (st.skip_n > 0) {
+    st.skip_n--;
+  } else {
+    switch (st.state) {
+      case ST_UNINIT: {
+        M3 R_w_c;
+        R_w_c.m[0][0] = 0; R_w_c.m[0][1] = 0; R_w_c.m[0][2] = 1;
+        R_w_c.m[1][0] = -1; R_w_c.m[1][1] = 0; R_w_c.m[1][2] = 0;
+        R_w_c.m[2][0] = 0; R_w_c.m[2][1] = -1; R_w_c.m[2][2] = 0;
+        SE3d T = se3_inverse(se3_from_mat(R_w_c, V3{0, 0, 0}));
+        bool go = true;
+        if (st.has_imu) {
+          if (st.vi_initialized) {
+            Q4 q_init;
+            vi_vision_trigger(ring, q_init);
+            M3 R = q_to_mat(q_init) * q_to_mat(load_pose7(p.cam.T_i_c).q);
+            T = se3_inverse(se3_from_mat(R, V3{0, 0, 0}));
+          } else {
+            go = false;
+          }
+        }
+        store_pose7(st.T_c_w[c], T);
+        if (go) {
+          st.phase = PH_INIT;
+          det_mode = 1;
+        }
+        break;
+      }
+      case ST_TRACKING: {
+        SE3d g = se3_identity();
+        if (st.has_imu) st.use_guess = vi_get_corr_frame_state(p.cam, ring, time, g) ? 1 : 0;
+        store_pose7(st.guess, g);
+        st.phase = PH_TRACK;
+        break;
+      }
+      case ST_TRACKFAIL: {
+        st.tf_cnt++;
+        if ((st.tf_cnt % 3) == 0) {
+          SE3d T;
+          if (vi_get_corr_frame_state(p.cam, ring, time, T)) {
+            store_pose7(st.T_c_w[c], T);
+            st.phase = PH_INIT;
+            det_mode = 1;
+          } else {
+            st.cur ^= 1;
+          }
+          st.tf_cnt = 0;
+        } else {
+          st.cur ^= 1;
+          if ((st.tf_cnt % 2) == 0) st.reset_cmd = 1;
+        }
+        break;
+      }
+    }
+  }
+  p.act_img[s] = st.phase != PH_IDLE;
+  p.act_track[s] = st.phase == PH_TRACK;
+  p.det_mode[s] = det_mode;
+  p.det_maxc[s] = det_mode == 1 ? 2 * p.cam.gftt_num : p.cam.gftt_num;
+  p.n_exist[s] = 0;
+  p.img_slot[s] = c;  // image slot written this frame (stays valid even if the frame is escaped later)
+  p.lk_count[s] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ temporal LK inputs
+__global__ __launch_bounds__(256) void k_track_prepare(Pipe p) {
+  const int s = blockIdx.y;
+  const StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK) return;
+  const int last = st.cur ^ 1;
+  const int n = st.n_lm[last];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) p.lk_count[s] = n;
+  if (i >= n) return;
+  const Landmark& lm = lm_ptr(p, last, s)[i];
+  float px = (float)lm.p2d[0], py = (float)lm.p2d[1];
+  float* pp = p.prev_pts + ((size_t)s * NMAX + i) * 2;
+  float* np = p.next_pts + ((size_t)s * NMAX + i) * 2;
+  pp[0] = px;
+  pp[1] = py;
+  if (st.use_guess) {
+    SE3d g = load_pose7(st.guess);
+    float p3[3] = {(float)lm.p3w[0], (float)lm.p3w[1], (float)lm.p3w[2]};
+    project_point(p3, q_to_mat(g.q), g.t, p.cam.K0, p.cam.D0, np);
+  } else {
+    np[0] = px;
+    np[1] = py;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LK survivors
+// lkorb_tracking.cpp:93-125: survivors are appended in DESCENDING index order (quirk A1); the parallel from_* arrays
+// keep ascending order.  One wave per stream.
+__global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK) return;
+  const int lane = threadIdx.x;
+  const int cur = st.cur, last = cur ^ 1;
+  const int n = st.n_lm[last];
+  const Landmark* from = lm_ptr(p, last, s);
+  Landmark* to = lm_ptr(p, cur, s);
+  const float* tr = p.next_pts + (size_t)s * NMAX * 2;
+  const uint8_t* status = p.lk_status + (size_t)s * NMAX;
+  const int w = p.cam.w - 1, h = p.cam.h - 1;
+  // total survivors
+  int total = 0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool pass = i < n && status[i] == 1 && tr[2 * i] > 0 && tr[2 * i + 1] > 0 && tr[2 * i] < (float)w && tr[2 * i + 1] < (float)h;
+    total += __popcll(__ballot(pass));
+  }
+  int before = 0;  // survivors with smaller index than this chunk
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool pass = i < n && status[i] == 1 && tr[2 * i] > 0 && tr[2 * i + 1] > 0 && tr[2 * i] < (float)w && tr[2 * i + 1] < (float)h;
+    unsigned long long b = __ballot(pass);
+    if (pass) {
+      int k = before + lane_prefix(b);  // ascending rank
+      int j = total - 1 - k;            // position in to.landmarks (descending)
+      Landmark lm = from[i];
+      float tx = tr[2 * i], ty = tr[2 * i + 1];
+      float und[2] = {tx, ty};
+      float fu[2];
+      if (p.cam.cam_type == CAM_STEREO_RECT) {
+        fu[0] = (float)lm.p2d[0];  // from_p2d_undistort = from_p2d_plane
+        fu[1] = (float)lm.p2d[1];
+      } else {
+        float src[2] = {tx, ty};
+        undistort_point(src, p.cam.K0, p.cam.D0, p.cam.R0, p.cam.P0, und);
+        fu[0] = (float)lm.p2u[0];
+        fu[1] = (float)lm.p2u[1];
+      }
+      lm.p2d[0] = (double)tx;
+      lm.p2d[1] = (double)ty;
+      lm.p2u[0] = (double)und[0];
+      lm.p2u[1] = (double)und[1];
+      to[j] = lm;
+      float* m1 = p.m1 + ((size_t)s * NMAX + k) * 2;
+      float* m2 = p.m2 + ((size_t)s * NMAX + k) * 2;
+      m1[0] = fu[0];
+      m1[1] = fu[1];
+      m2[0] = und[0];
+      m2[1] = und[1];
+    }
+    before += __popcll(b);
+  }
+  if (lane == 0) {
+    st.n_lm[cur] = total;
+    st.n_surv = total;
+    st.of_cnt = total;
+    if (total < 10) st.ok = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ F-matrix RANSAC
+// cv::findFundamentalMat(FM_RANSAC, 5.0, 0.99) control flow with the counter RNG; 64 hypotheses per batch (one per lane),
+// the adaptive stop is replayed sequentially over the batch.  Only the mask is used (lkorb_tracking.cpp:133-158).
+__global__ __launch_bounds__(64) void k_ransac_f(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK || !st.ok) return;
+  const int lane = threadIdx.x;
+  const int n = st.n_surv;
+  __shared__ float sm1[NMAX * 2], sm2[NMAX * 2];
+  __shared__ int hcnt[64], hmodel[64];
+  __shared__ double bestF[9];
+  __shared__ int ctl[4];  // niters, maxGood, best_iter, best_model
+  const float* gm1 = p.m1 + (size_t)s * NMAX * 2;
+  const float* gm2 = p.m2 + (size_t)s * NMAX * 2;
+  for (int i = lane; i < 2 * n; i += 64) {
+    sm1[i] = gm1[i];
+    sm2[i] = gm2[i];
+  }
+  if (lane == 0) {
+    ctl[0] = 1000;
+    ctl[1] = 0;
+    ctl[2] = -1;
+    ctl[3] = 0;
+  }
+  __syncthreads();
+  const unsigned long long seed = mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[st.cur]));
+  const float thr2 = 25.0f;
+  Landmark* to = lm_ptr(p, st.cur, s);
+  if (n > 7) {
+    for (int base = 0; base < ctl[0]; base += 64) {
+      const int iter = base + lane;
+      int cnt = -1, model = 0;
+      if (iter < ctl[0]) {
+        int idx[7];
+        if (ransac_subset(seed, (unsigned)iter, n, 7, idx)) {
+          double x1[7][2], x2[7][2];
+          for (int k = 0; k < 7; k++) {
+            x1[k][0] = sm1[2 * idx[k]];
+            x1[k][1] = sm1[2 * idx[k] + 1];
+            x2[k][0] = sm2[2 * idx[k]];
+            x2[k][1] = sm2[2 * idx[k] + 1];
+          }
+          double F[3][9];
+          int nm = seven_point(x1, x2, F);
+          cnt = 0;
+          for (int m = 0; m < nm; m++) {
+            int good = 0;
+            for (int i = 0; i < n; i++)
+              good += (f_error(F[m], sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1]) <= thr2);
+            if (good > cnt) {
+              cnt = good;
+              model = m;
+            }
+          }
+        } else {
+          cnt = -2;  // subset impossible: the reference loop stops
+        }
+      }
+      hcnt[lane] = cnt;
+      hmodel[lane] = model;
+      __syncthreads();
+      if (lane == 0) {
+        int niters = ctl[0], maxGood = ctl[1];
+        for (int k = 0; k < 64; k++) {
+          if (base + k >= niters) break;
+          if (hcnt[k] == -2) {
+            niters = 0;
+            break;
+          }
+          int good = hcnt[k];
+          int lim = maxGood > 6 ? maxGood : 6;
+          if (good > lim) {
+            maxGood = good;
+            ctl[2] = base + k;
+            ctl[3] = hmodel[k];
+            niters = ransac_update_num_iters(0.99, (double)(n - good) / n, 7, niters);
+          }
+        }
+        ctl[0] = niters;
+        ctl[1] = maxGood;
+      }
+      __syncthreads();
+    }
+    // regenerate the winning model and apply its mask with the reference's mirrored index
+    if (ctl[2] >= 0) {
+      if (lane == 0) {
+        int idx[7];
+        ransac_subset(seed, (unsigned)ctl[2], n, 7, idx);
+        double x1[7][2], x2[7][2];
+        for (int k = 0; k < 7; k++) {
+          x1[k][0] = sm1[2 * idx[k]];
+          x1[k][1] = sm1[2 * idx[k] + 1];
+          x2[k][0] = sm2[2 * idx[k]];
+          x2[k][1] = sm2[2 * idx[k] + 1];
+        }
+        double F[3][9];
+        seven_point(x1, x2, F);
+        for (int j = 0; j < 9; j++) bestF[j] = F[ctl[3]][j];
+      }
+      __syncthreads();
+      for (int i = lane; i < n; i += 64) {
+        bool in = f_error(bestF, sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1]) <= thr2;
+        if (!in) to[i].inlier = 0;  // mask index i applied to to.landmarks[i] (descending order): quirk A1
+      }
+    } else {
+      for (int i = lane; i < n; i += 64) to[i].inlier = 0;  // no model: all-zero mask
+    }
+  }
+  __syncthreads();
+  int fc = 0;
+  for (int i = lane; i < n; i += 64) fc += to[i].inlier ? 1 : 0;
+  fc = wave_sum_i32(fc);
+  if (lane == 0) {
+    st.f_cnt = fc;
+    if (fc < 10) st.ok = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ PnP RANSAC
+// cv::solvePnPRansac(p3d, p2d, K_rect, 0, r, t, false, 100, 3.0, 0.99, inliers, ITERATIVE|P3P) control flow; hypotheses
+// by Grunert P3P (first 3 sample points, the rest disambiguate), Gauss-Newton refinement on the inliers.
+__global__ __launch_bounds__(64) void k_ransac_pnp(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK || !st.ok) return;
+  const int lane = threadIdx.x;
+  const int cur = st.cur;
+  Landmark* to = lm_ptr(p, cur, s);
+  const int nl = st.n_lm[cur];
+  __shared__ float s2d[NMAX * 2], s3d[NMAX * 3];
+  __shared__ short sidx[NMAX];
+  __shared__ unsigned char smask[NMAX];
+  __shared__ int hcnt[64];
+  __shared__ double hpose[64][12];
+  __shared__ int ctl[4];
+  __shared__ double bpose[12];
+  // gather (has3d && inlier) in order
+  int np = 0;
+  for (int base = 0; base < nl; base += 64) {
+    int i = base + lane;
+    bool sel = i < nl && to[i].has3d && to[i].inlier;
+    unsigned long long b = __ballot(sel);
+    if (sel) {
+      int k = np + lane_prefix(b);
+      s2d[2 * k] = (float)to[i].p2u[0];
+      s2d[2 * k + 1] = (float)to[i].p2u[1];
+      s3d[3 * k] = (float)to[i].p3w[0];
+      s3d[3 * k + 1] = (float)to[i].p3w[1];
+      s3d[3 * k + 2] = (float)to[i].p3w[2];
+      sidx[k] = (short)i;
+    }
+    np += __popcll(b);
+  }
+  const bool iterative = st.use_guess != 0;
+  const int modelPoints = iterative ? 5 : 4;
+  if (lane == 0) {
+    ctl[0] = 100;
+    ctl[1] = 0;
+    ctl[2] = -1;
+  }
+  __syncthreads();
+  const double fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
+  const unsigned long long seed = mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[cur] + 1));
+  const float t2 = 9.0f;
+  if (np >= modelPoints) {
+    for (int base = 0; base < ctl[0]; base += 64) {
+      const int iter = base + lane;
+      int cnt = -1;
+      if (iter < ctl[0]) {
+        int idx[5];
+        if (ransac_subset(seed, (unsigned)iter, np, modelPoints, idx)) {
+          V3 P[3], f[3];
+          for (int k = 0; k < 3; k++) {
+            P[k] = V3{(double)s3d[3 * idx[k]], (double)s3d[3 * idx[k] + 1], (double)s3d[3 * idx[k] + 2]};
+            V3 d{((double)s2d[2 * idx[k]] - cx) / fx, ((double)s2d[2 * idx[k] + 1] - cy) / fy, 1.0};
+            f[k] = (1.0 / norm(d)) * d;
+          }
+          M3 Rs[4];
+          V3 ts[4];
+          int ns = p3p_grunert(P, f, Rs, ts);
+          int bk = -1;
+          double be = 1.7976931348623157e308;
+          for (int k = 0; k < ns; k++) {
+            double e = 0;
+            for (int m = 3; m < modelPoints; m++) {
+              V3 Pm{(double)s3d[3 * idx[m]], (double)s3d[3 * idx[m] + 1], (double)s3d[3 * idx[m] + 2]};
+              V3 X = Rs[k] * Pm + ts[k];
+              double z = X.z ? 1. / X.z : 1;
+              double du = fx * X.x * z + cx - (double)s2d[2 * idx[m]], dv = fy * X.y * z + cy - (double)s2d[2 * idx[m] + 1];
+              e += du * du + dv * dv;
+            }
+            if (e < be) {
+              be = e;
+              bk = k;
+            }
+          }
+          if (bk >= 0) {
+            M3 R = Rs[0];
+            V3 t = ts[0];
+            for (int k = 1; k < 4; k++)
+              if (k == bk) {
+                R = Rs[k];
+                t = ts[k];
+              }
+            int good = 0;
+            for (int i = 0; i < np; i++) {
+              V3 Pi{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]};
+              V3 X = R * Pi + t;
+              double z = X.z ? 1. / X.z : 1;
+              float du = (float)(fx * X.x * z + cx) - s2d[2 * i], dv = (float)(fy * X.y * z + cy) - s2d[2 * i + 1];
+              good += (du * du + dv * dv <= t2);
+            }
+            cnt = good;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+              for (int c = 0; c < 3; c++) hpose[lane][3 * r + c] = R.m[r][c];
+            hpose[lane][9] = t.x;
+            hpose[lane][10] = t.y;
+            hpose[lane][11] = t.z;
+          } else {
+            cnt = -1;  // no model from this sample: continue
+          }
+        } else {
+          cnt = -2;
+        }
+      }
+      hcnt[lane] = cnt;
+      __syncthreads();
+      if (lane == 0) {
+        int niters = ctl[0], maxGood = ctl[1];
+        for (int k = 0; k < 64; k++) {
+          if (base + k >= niters) break;
+          if (hcnt[k] == -2) {
+            niters = 0;
+            break;
+          }
+          int good = hcnt[k];
+          int lim = maxGood > modelPoints - 1 ? maxGood : modelPoints - 1;
+          if (good > lim) {
+            maxGood = good;
+            ctl[2] = base + k;
+            for (int j = 0; j < 12; j++) bpose[j] = hpose[k][j];
+            niters = ransac_update_num_iters(0.99, (double)(np - good) / np, modelPoints, niters);
+          }
+        }
+        ctl[0] = niters;
+        ctl[1] = maxGood;
+      }
+      __syncthreads();
+    }
+  }
+  SE3d T = iterative ? load_pose7(st.guess) : se3_identity();
+  if (iterative) T = se3_from_mat(q_to_mat(T.q), T.t);
+  int inliers = 0;
+  if (ctl[2] >= 0) {
+    M3 R;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) R.m[r][c] = bpose[3 * r + c];
+    V3 t{bpose[9], bpose[10], bpose[11]};
+    for (int i = lane; i < np; i += 64) {
+      V3 Pi{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]};
+      V3 X = R * Pi + t;
+      double z = X.z ? 1. / X.z : 1;
+      float du = (float)(fx * X.x * z + cx) - s2d[2 * i], dv = (float)(fy * X.y * z + cy) - s2d[2 * i + 1];
+      smask[i] = (du * du + dv * dv <= t2) ? 1 : 0;
+    }
+    __syncthreads();
+    inliers = ctl[1];
+    // Gauss-Newton refinement on the inliers (stand-in for OpenCV's final solvePnP)
+    SE3d Tb = g2o_from_mat(R, t);
+    for (int it = 0; it < 10; it++) {
+      double acc[27];
+#pragma unroll
+      for (int k = 0; k < 27; k++) acc[k] = 0;
+      for (int i = lane; i < np; i += 64) {
+        if (!smask[i]) continue;
+        double e[2], J[2][6];
+        proj_edge(Tb, V3{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]}, (double)s2d[2 * i],
+                  (double)s2d[2 * i + 1], fx, fy, cx, cy, e, J);
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          acc[21 + r] -= J[0][r] * e[0] + J[1][r] * e[1];
+#pragma unroll
+          for (int c = r; c < 6; c++) acc[q++] += J[0][r] * J[0][c] + J[1][r] * J[1][c];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 27; k++) acc[k] = wave_sum_f64(acc[k]);
+      double H[36], b[6], dx[6];
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        b[r] = acc[21 + r];
+#pragma unroll
+        for (int c = r; c < 6; c++) {
+          H[6 * r + c] = acc[q];
+          H[6 * c + r] = acc[q];
+          q++;
+        }
+      }
+      if (!solve_spd6(H, b, dx)) break;
+      Tb = g2o_mul(g2o_exp(dx), Tb);
+      double nn = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) nn += dx[k] * dx[k];
+      if (nn < 1e-20) break;
+    }
+    T = se3_from_mat(q_to_mat(Tb.q), Tb.t);
+  } else {
+    for (int i = lane; i < np; i += 64) smask[i] = 0;
+  }
+  __syncthreads();
+  for (int i = lane; i < np; i += 64)
+    if (smask[i] == 0) to[sidx[i]].inlier = 0;  // CameraFrame::updateLMState
+  if (lane == 0) {
+    store_pose7(st.T_c_w[cur], T);
+    st.pnp_cnt = inliers;
+    if (inliers < 10) st.ok = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ after tracking
+__global__ void k_track_post(Pipe p) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.S) return;
+  StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK) return;
+  if (!st.ok) {
+    track_fail(st);
+    return;
+  }
+  st.cont_fail = 0;
+  if (st.has_imu) {
+    ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
+    SE3d T = load_pose7(st.T_c_w[st.cur]);
+    vi_vision_rp_compensation(p.cam, ring, st.frame_time[st.cur], T);
+    store_pose7(st.T_c_w[st.cur], T);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pose-only LM
+// OptimizeInFrame::optimize: g2o Levenberg on one free pose, Huber(1), optimize(2), drop chi2 > 3, optimize(2).
+// One wave per stream: lanes stride the edges, 21+6 sums by wave butterflies, lane-uniform 6x6 Cholesky.
+struct PoseLMShared {
+  double pw[NMAX][3];
+  double z[NMAX][2];
+  unsigned char alive[NMAX];
+};
+
+__device__ inline double pose_robust_chi2(const SE3d& T, const PoseLMShared& sh, int n, double fx, double fy, double cx,
+                                          double cy) {
+  double chi = 0;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    if (!sh.alive[i]) continue;
+    double e[2];
+    proj_edge(T, V3{sh.pw[i][0], sh.pw[i][1], sh.pw[i][2]}, sh.z[i][0], sh.z[i][1], fx, fy, cx, cy, e, nullptr);
+    chi += huber_rho(e[0] * e[0] + e[1] * e[1]);
+  }
+  return wave_sum_f64(chi);
+}
+
+__device__ inline void pose_lm_optimize(SE3d& T, const PoseLMShared& sh, int n, int iterations, double fx, double fy,
+                                        double cx, double cy) {
+  double lambda = -1, ni = 2;
+  for (int iteration = 0; iteration < iterations; iteration++) {
+    double currentChi = pose_robust_chi2(T, sh, n, fx, fy, cx, cy);
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) acc[k] = 0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+      if (!sh.alive[i]) continue;
+      double e[2], J[2][6];
+      proj_edge(T, V3{sh.pw[i][0], sh.pw[i][1], sh.pw[i][2]}, sh.z[i][0], sh.z[i][1], fx, fy, cx, cy, e, J);
+      double c2 = e[0] * e[0] + e[1] * e[1];
+      double w = huber_w(c2);
+      double o0 = -e[0] * w, o1 = -e[1] * w;
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        acc[21 + r] += J[0][r] * o0 + J[1][r] * o1;
+#pragma unroll
+        for (int c = r; c < 6; c++) acc[q++] += (J[0][r] * w) * J[0][c] + (J[1][r] * w) * J[1][c];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) acc[k] = wave_sum_f64(acc[k]);
+    double H[36], b[6];
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      b[r] = acc[21 + r];
+#pragma unroll
+      for (int c = r; c < 6; c++) {
+        H[6 * r + c] = acc[q];
+        H[6 * c + r] = acc[q];
+        q++;
+      }
+    }
+    if (iteration == 0) {
+      double maxDiag = 0;
+#pragma unroll
+      for (int j = 0; j < 6; j++) maxDiag = fmax(fabs(H[7 * j]), maxDiag);
+      lambda = 1e-5 * maxDiag;
+      ni = 2;
+    }
+    double rho = 0;
+    int qmax = 0;
+    bool lambda_bad = false;
+    do {
+      SE3d backup = T;
+      double Hl[36], x[6];
+#pragma unroll
+      for (int k = 0; k < 36; k++) Hl[k] = H[k];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        Hl[7 * j] += lambda;
+        x[j] = 0;
+      }
+      bool ok2 = solve_spd6(Hl, b, x);
+      if (ok2) T = g2o_mul(g2o_exp(x), T);
+      double tempChi = pose_robust_chi2(T, sh, n, fx, fy, cx, cy);
+      if (!ok2) tempChi = 1.7976931348623157e308;
+      rho = currentChi - tempChi;
+      double scale = 0;
+#pragma unroll
+      for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3.0);
+        alpha = fmin(alpha, 2. / 3.);
+        double scaleFactor = fmax(1. / 3., alpha);
+        lambda *= scaleFactor;
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        T = backup;
+        if (!isfinite(lambda)) {
+          lambda_bad = true;
+          break;
+        }
+      }
+      qmax++;
+    } while (rho < 0 && qmax < 10);
+    if (qmax == 10 || rho == 0 || lambda_bad) break;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_pose_lm(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK) return;
+  const int lane = threadIdx.x;
+  const int cur = st.cur;
+  Landmark* lms = lm_ptr(p, cur, s);
+  const int nl = st.n_lm[cur];
+  __shared__ PoseLMShared sh;
+  int n = 0;
+  for (int base = 0; base < nl; base += 64) {
+    int i = base + lane;
+    bool sel = i < nl && lms[i].has3d && lms[i].inlier;
+    unsigned long long b = __ballot(sel);
+    if (sel) {
+      int k = n + lane_prefix(b);
+      sh.pw[k][0] = lms[i].p3w[0];
+      sh.pw[k][1] = lms[i].p3w[1];
+      sh.pw[k][2] = lms[i].p3w[2];
+      sh.z[k][0] = lms[i].p2u[0];
+      sh.z[k][1] = lms[i].p2u[1];
+      sh.alive[k] = 1;
+    }
+    n += __popcll(b);
+  }
+  __syncthreads();
+  bool ok = n >= 10;
+  if (ok) {
+    const double fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
+    SE3d T0 = load_pose7(st.T_c_w[cur]);
+    SE3d T = g2o_from_mat(q_to_mat(T0.q), T0.t);
+    pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
+    int alive = 0;
+    for (int i = lane; i < n; i += 64) {
+      double e[2];
+      proj_edge(T, V3{sh.pw[i][0], sh.pw[i][1], sh.pw[i][2]}, sh.z[i][0], sh.z[i][1], fx, fy, cx, cy, e, nullptr);
+      if (e[0] * e[0] + e[1] * e[1] > 3.0) sh.alive[i] = 0;
+      alive += sh.alive[i];
+    }
+    alive = wave_sum_i32(alive);
+    __syncthreads();
+    if (alive < 10) {
+      ok = false;
+    } else {
+      pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
+      if (lane == 0) store_pose7(st.T_c_w[cur], se3_from_mat(q_to_mat(T.q), T.t));
+    }
+  }
+  if (!ok && lane == 0) track_fail(st);
+}
+
+// ------------------------------------------------------------------------------------------------ reprojection filter
+// calReprjInlierOutlier(1.5) + eraseReprjOutlier + viCorrectionFromVision; prepares the redetect inputs.
+__global__ __launch_bounds__(64) void k_reproj_filter(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK) return;
+  const int lane = threadIdx.x;
+  const int cur = st.cur;
+  Landmark* lms = lm_ptr(p, cur, s);
+  const int n = st.n_lm[cur];
+  __shared__ double dist[NMAX];
+  __shared__ double valid[NMAX];
+  __shared__ double sh_thr;
+  const SE3d T = load_pose7(st.T_c_w[cur]);
+  int nv = 0;
+  double sum = 0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    double d = 0;
+    bool v = false;
+    if (i < n) {
+      V3 pc = se3_act(T, V3{lms[i].p3w[0], lms[i].p3w[1], lms[i].p3w[2]});
+      double u = p.cam.fx * pc.x / pc.z + p.cam.cx, vv = p.cam.fy * pc.y / pc.z + p.cam.cy;
+      double ex = lms[i].p2u[0] - u, ey = lms[i].p2u[1] - vv;
+      d = sqrt(ex * ex + ey * ey);
+      dist[i] = d;
+      v = d < 3.0;
+    }
+    unsigned long long b = __ballot(v);
+    if (v) valid[nv + lane_prefix(b)] = d;
+    nv += __popcll(b);
+  }
+  __syncthreads();
+  // mean over the valid distances in index order (sequential sum like the reference, lane 0)
+  if (lane == 0) {
+    for (int i = 0; i < nv; i++) sum += valid[i];
+    st.reproj_err = sum / (double)nv;
+  }
+  // median: element of rank nv/2 in ascending order (ties: any equal value)
+  if (nv > 0) {
+    const int target = nv / 2;
+    for (int i = lane; i < nv; i += 64) {
+      double v = valid[i];
+      int less = 0, eq = 0;
+      for (int j = 0; j < nv; j++) {
+        less += valid[j] < v;
+        eq += valid[j] == v;
+      }
+      if (less <= target && target < less + eq) sh_thr = 1.5 * v;
+    }
+  } else if (lane == 0) {
+    sh_thr = 3.0;
+  }
+  __syncthreads();
+  double sh = sh_thr;
+  if (sh >= 3.0) sh = 3.0;
+  // flag + erase outliers (order preserving, in place)
+  int kept = 0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool keep = i < n && !(dist[i] > sh);
+    Landmark lm;
+    if (keep) {
+      lm = lms[i];
+      lm.inlier = 1;
+    }
+    unsigned long long b = __ballot(keep);
+    __syncthreads();
+    if (keep) lms[kept + lane_prefix(b)] = lm;
+    kept += __popcll(b);
+    __syncthreads();
+  }
+  // existing points for FeatureDEM::redetect
+  double* ex = p.exist_xy + (size_t)s * NMAX * 2;
+  for (int i = lane; i < kept; i += 64) {
+    ex[2 * i] = lms[i].p2d[0];
+    ex[2 * i + 1] = lms[i].p2d[1];
+  }
+  if (lane == 0) {
+    st.n_lm[cur] = kept;
+    st.orig_size = kept;
+    p.n_exist[s] = kept;
+    p.det_mode[s] = 2;
+    p.det_maxc[s] = p.cam.gftt_num;
+    if (st.has_imu) {
+      ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
+      vi_correction_from_vision(p.cam, st, ring, st.frame_time[cur], T, st.frame_time[cur ^ 1],
+                                load_pose7(st.T_c_w[cur ^ 1]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ new landmarks
+__global__ __launch_bounds__(64) void k_add_new(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  const int mode = p.det_mode[s];
+  if (mode == 0) return;
+  const int lane = threadIdx.x;
+  const int cur = st.cur;
+  Landmark* lms = lm_ptr(p, cur, s);
+  int n0 = st.n_lm[cur];
+  int nn = p.n_new[s];
+  if (n0 + nn > NMAX) nn = NMAX - n0;
+  const float* xy = p.new_xy + (size_t)s * NEW_MAX * 2;
+  const bool as_inlier = (mode == 1) ? true : (st.orig_size < 60);
+  for (int k = lane; k < nn; k += 64) {
+    float src[2] = {xy[2 * k], xy[2 * k + 1]};
+    float und[2] = {src[0], src[1]};
+    if (mode == 1 || p.cam.cam_type == CAM_STEREO_UNRECT) undistort_point(src, p.cam.K0, p.cam.D0, p.cam.R0, p.cam.P0, und);
+    Landmark lm;
+    lm.id = st.lm_id_counter + k;
+    lm.p3w[0] = lm.p3w[1] = lm.p3w[2] = 0;
+    lm.p3c[0] = lm.p3c[1] = lm.p3c[2] = 0;
+    lm.p2d[0] = (double)src[0];
+    lm.p2d[1] = (double)src[1];
+    lm.p2u[0] = (double)und[0];
+    lm.p2u[1] = (double)und[1];
+    lm.first2d[0] = lm.p2u[0];
+    lm.first2d[1] = lm.p2u[1];
+    for (int j = 0; j < 7; j++) lm.first_pose[j] = st.T_c_w[cur][j];
+    lm.has3d = 0;
+    lm.inlier = as_inlier ? 1 : 0;
+    for (int j = 0; j < 6; j++) lm.pad[j] = 0;
+    lms[n0 + k] = lm;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    st.lm_id_counter += p.n_new[s];  // ids are consumed even for points that do not fit (never happens below NMAX)
+    st.n_lm[cur] = n0 + nn;
+    st.n_new = nn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depth: inputs
+__global__ __launch_bounds__(256) void k_depth_prepare(Pipe p) {
+  const int s = blockIdx.y;
+  const StreamState& st = p.st[s];
+  if (p.det_mode[s] == 0) return;
+  const int cur = st.cur;
+  const int n = st.n_lm[cur];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) p.lk_count[s] = n;
+  if (i >= n) return;
+  const Landmark& lm = lm_ptr(p, cur, s)[i];
+  const SE3d T = load_pose7(st.T_c_w[cur]);
+  // recover3DPts_c_FromTriangulation (camera_frame.cpp:236-270)
+  SE3d T1 = load_pose7(lm.first_pose);
+  V3 baseline = T1.t - T.t;
+  double* tri = p.tri + ((size_t)s * NMAX + i) * 3;
+  unsigned char tm = 0;
+  tri[0] = tri[1] = tri[2] = 0;
+  if (norm(baseline) >= 0.2) {
+    V3 pw = triangulate_two_view(lm.first2d[0], lm.first2d[1], lm.p2u[0], lm.p2u[1], T1, T, p.cam.fx, p.cam.fy, p.cam.cx,
+                                 p.cam.cy);
+    V3 pc = se3_act(T, pw);
+    if (pc.z >= 0.5 && pc.z <= (double)p.cam.range) {
+      tri[0] = pc.x;
+      tri[1] = pc.y;
+      tri[2] = pc.z;
+      tm = 1;
+    }
+  }
+  p.tri_mask[(size_t)s * NMAX + i] = tm;
+  // stereo LK seeds (camera_frame.cpp:108-122)
+  float* p0 = p.prev_pts + ((size_t)s * NMAX + i) * 2;
+  float* p1 = p.next_pts + ((size_t)s * NMAX + i) * 2;
+  p0[0] = (float)lm.p2d[0];
+  p0[1] = (float)lm.p2d[1];
+  if (lm.has3d) {
+    SE3d T1c = se3_mul(load_pose7(p.cam.T_c1_c0), T);
+    float p3[3] = {(float)lm.p3w[0], (float)lm.p3w[1], (float)lm.p3w[2]};
+    project_point(p3, q_to_mat(T1c.q), T1c.t, p.cam.K1, p.cam.D1, p1);
+  } else {
+    p1[0] = p0[0];
+    p1[1] = p0[1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depth innovation
+// recover3DPts_c_FromStereo (after LK) + depthInnovation + eraseNoDepthPoint.  One wave per stream; the rand()-drawn
+// dummy depths (quirk A11) are consumed in landmark order: failures are ranked by ballot prefix, lane 0 advances the
+// stream's glibc generator by the number of failures.
+__global__ __launch_bounds__(64) void k_depth_innovate(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  if (p.det_mode[s] == 0) return;
+  const int lane = threadIdx.x;
+  const int cur = st.cur;
+  Landmark* lms = lm_ptr(p, cur, s);
+  const int n = st.n_lm[cur];
+  __shared__ double meas[NMAX][3];
+  __shared__ unsigned char mok[NMAX];
+  __shared__ short frank[NMAX];
+  __shared__ float rnd[NMAX];
+  const float* p1 = p.next_pts + (size_t)s * NMAX * 2;
+  const uint8_t* status = p.lk_status + (size_t)s * NMAX;
+  const double range = (double)p.cam.range;
+  int nfail = 0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool fail = false;
+    if (i < n) {
+      bool ok = false;
+      if (status[i] == 1) {
+        float src[2] = {p1[2 * i], p1[2 * i + 1]}, u1[2];
+        undistort_point(src, p.cam.K1, p.cam.D1, p.cam.R1, p.cam.P1, u1);
+        float u0x = (float)lms[i].p2u[0], u0y = (float)lms[i].p2u[1];
+        V3 pc = triangulate_dlt((double)u0x, (double)u0y, (double)u1[0], (double)u1[1], p.cam.P0, p.cam.P1);
+        if (!(pc.z < 0 || pc.z > range)) {
+          meas[i][0] = pc.x;
+          meas[i][1] = pc.y;
+          meas[i][2] = pc.z;
+          ok = true;
+        }
+      }
+      mok[i] = ok;
+      fail = !ok;
+    }
+    unsigned long long b = __ballot(fail);
+    if (fail) frank[i] = (short)(nfail + lane_prefix(b));
+    nfail += __popcll(b);
+  }
+  __syncthreads();
+  if (lane == 0)
+    for (int k = 0; k < nfail; k++)
+      rnd[k] = (float)(0.3 + (double)((float)glibc_rand_next(st) / ((float)(2147483647 / (0.4)))));
+  __syncthreads();
+  const SE3d T = load_pose7(st.T_c_w[cur]);
+  const SE3d Tinv = se3_inverse(T);
+  const unsigned char* tmask = p.tri_mask + (size_t)s * NMAX;
+  const double* tri = p.tri + (size_t)s * NMAX * 3;
+  const float iir = p.cam.iir_ratio;
+  for (int i = lane; i < n; i += 64) {
+    Landmark& lm = lms[i];
+    if (!mok[i]) {
+      double depth = (double)rnd[frank[i]];
+      float u0x = (float)lm.p2u[0], u0y = (float)lm.p2u[1];
+      meas[i][0] = ((double)u0x - p.cam.cx) * depth / p.cam.fx;
+      meas[i][1] = ((double)u0y - p.cam.cy) * depth / p.cam.fy;
+      meas[i][2] = depth;
+    }
+    V3 m;
+    if (!mok[i] && !tmask[i]) {
+      if (!lm.has3d && p.cam.enable_dummy) {
+        m = V3{meas[i][0], meas[i][1], meas[i][2]};
+        V3 pw = se3_act(Tinv, m);
+        lm.p3c[0] = m.x; lm.p3c[1] = m.y; lm.p3c[2] = m.z;
+        lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;
+        lm.has3d = 1;
+      }
+      continue;
+    }
+    if (mok[i])
+      m = V3{meas[i][0], meas[i][1], meas[i][2]};
+    else
+      m = V3{tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]};
+    if (lm.has3d) {
+      V3 lc = se3_act(T, V3{lm.p3w[0], lm.p3w[1], lm.p3w[2]});
+      V3 upd = lc * (double)iir + m * (double)(1 - iir);
+      V3 pw = se3_act(Tinv, upd);
+      lm.p3c[0] = upd.x; lm.p3c[1] = upd.y; lm.p3c[2] = upd.z;
+      lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;
+    } else {
+      V3 pw = se3_act(Tinv, m);
+      lm.p3c[0] = m.x; lm.p3c[1] = m.y; lm.p3c[2] = m.z;
+      lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;
+      lm.has3d = 1;
+    }
+  }
+  __syncthreads();
+  // eraseNoDepthPoint (order preserving)
+  int kept = 0;
+  for (int base = 0; base < n; base += 64) {
+    int i = base + lane;
+    bool keep = i < n && lms[i].has3d;
+    Landmark lm;
+    if (keep) lm = lms[i];
+    unsigned long long b = __ballot(keep);
+    __syncthreads();
+    if (keep) lms[kept + lane_prefix(b)] = lm;
+    kept += __popcll(b);
+    __syncthreads();
+  }
+  if (lane == 0) st.n_lm[cur] = kept;
+}
+
+// ------------------------------------------------------------------------------------------------ frame end
+// init_frame's success test, keyframe decision (f2f_tracking.cpp:329-354,442-452), outputs, KeyFrame payload.
+__global__ __launch_bounds__(64) void k_frame_end(Pipe p, int frame_slot) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  const int lane = threadIdx.x;
+  __shared__ int s_newkf;
+  if (lane == 0) s_newkf = 0;
+  __syncthreads();
+  if (st.phase == PH_INIT) {
+    const int cur = st.cur;
+    Landmark* lms = lm_ptr(p, cur, s);
+    int valid = 0;
+    for (int i = lane; i < st.n_lm[cur]; i += 64) valid += (lms[i].has3d && lms[i].inlier) ? 1 : 0;
+    valid = wave_sum_i32(valid);
+    if (lane == 0) {
+      if (valid > 30) {
+        for (int j = 0; j < 7; j++) st.T_kf[j] = st.T_c_w[cur][j];
+        st.new_kf = 1;
+        st.state = ST_TRACKING;
+      } else if (st.state == ST_TRACKFAIL) {
+        st.cur ^= 1;  // "Recover failure": last_frame.swap(curr_frame)
+      }
+    }
+  } else if (st.phase == PH_TRACK && lane == 0) {
+    const int cur = st.cur;
+    SE3d Tkf = load_pose7(st.T_kf), Tc = load_pose7(st.T_c_w[cur]);
+    SE3d Td = se3_mul(Tkf, se3_inverse(Tc));
+    V3 r = so3_log(Td.q);
+    double t_norm = fabs(Td.t.x) + fabs(Td.t.y) + fabs(Td.t.z);
+    double r_norm = fabs(r.x) + fabs(r.y) + fabs(r.z);
+    bool kf = false;
+    if (st.frameCount < 40 && (st.frameCount % 5) == 0) kf = true;
+    if (t_norm >= 0.05 || r_norm >= 0.2) kf = true;
+    if (kf) {
+      st.new_kf = 1;
+      for (int j = 0; j < 7; j++) st.T_kf[j] = st.T_c_w[cur][j];
+    }
+  }
+  __syncthreads();
+  const int cur = st.cur;  // curr_frame as the caller sees it after image_feed
+  if (lane == 0) {
+    s_newkf = st.new_kf;
+    FrameOut& o = p.out[s];
+    o.state = st.state;
+    o.new_keyframe = st.new_kf;
+    o.reset_cmd = st.reset_cmd;
+    o.n_landmarks = st.n_lm[cur];
+    o.frame_id = st.frame_id[cur];
+    for (int j = 0; j < 7; j++) o.T_c_w[j] = st.T_c_w[cur][j];
+    o.of_cnt = st.of_cnt;
+    o.f_cnt = st.f_cnt;
+    o.pnp_cnt = st.pnp_cnt;
+    o.reproj_err = st.reproj_err;
+    if (p.traj && frame_slot >= 0 && frame_slot < p.traj_cap) {
+      double* t = p.traj + ((size_t)s * p.traj_cap + frame_slot) * 9;
+      t[0] = st.frame_time[cur];
+      for (int j = 0; j < 7; j++) t[1 + j] = st.T_c_w[cur][j];
+      t[8] = (double)(st.state | (st.new_kf << 4));
+    }
+  }
+  __syncthreads();
+  if (s_newkf) {
+    KeyFrameDev& kf = p.kf[s];
+    Landmark* lms = lm_ptr(p, cur, s);
+    const int n = st.n_lm[cur];
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+      int i = base + lane;
+      bool sel = i < n && lms[i].has3d && lms[i].inlier;
+      unsigned long long b = __ballot(sel);
+      if (sel) {
+        int k = cnt + lane_prefix(b);
+        if (k < KF_MAXLM) {
+          kf.lm_id[k] = lms[i].id;
+          kf.lm_2d[k][0] = lms[i].p2u[0];
+          kf.lm_2d[k][1] = lms[i].p2u[1];
+          kf.lm_3d[k][0] = lms[i].p3w[0];
+          kf.lm_3d[k][1] = lms[i].p3w[1];
+          kf.lm_3d[k][2] = lms[i].p3w[2];
+        }
+      }
+      cnt += __popcll(b);
+    }
+    if (lane == 0) {
+      kf.frame_id = st.frame_id[cur];
+      kf.lm_count = cnt < KF_MAXLM ? cnt : KF_MAXLM;
+      for (int j = 0; j < 7; j++) kf.T_c_w[j] = st.T_c_w[cur][j];
+      kf.valid = 1;
+      st.kf_pending = 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void launch_imu_feed(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_imu_feed, dim3((p.S + 63) / 64), dim3(64), 0, st, p);
+}
+void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time) {
+  hipLaunchKernelGGL(k_frame_begin, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time);
+}
+void launch_track_prepare(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_track_prepare, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
+}
+void launch_track_collect(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_track_collect, dim3(p.S), dim3(64), 0, st, p); }
+void launch_ransac_f(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_f, dim3(p.S), dim3(64), 0, st, p); }
+void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_pnp, dim3(p.S), dim3(64), 0, st, p); }
+void launch_track_post(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_track_post, dim3((p.S + 63) / 64), dim3(64), 0, st, p);
+}
+void launch_pose_lm(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_pose_lm, dim3(p.S), dim3(64), 0, st, p); }
+void launch_reproj_filter(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_reproj_filter, dim3(p.S), dim3(64), 0, st, p); }
+void launch_add_new(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_add_new, dim3(p.S), dim3(64), 0, st, p); }
+void launch_depth_prepare(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_depth_prepare, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
+}
+void launch_depth_innovate(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_depth_innovate, dim3(p.S), dim3(64), 0, st, p); }
+void launch_frame_end(hipStream_t st, const Pipe& p, int frame_slot) {
+  hipLaunchKernelGGL(k_frame_end, dim3(p.S), dim3(64), 0, st, p, frame_slot);
+}
+
+}  // namespace flvis

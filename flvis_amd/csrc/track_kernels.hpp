@@ -1,0 +1,67 @@
+// flvis_amd: kernel-argument bundle and launch prototypes of the batched front-end / local-map kernels.
+#pragma once
+#include "pipeline.hpp"
+
+namespace flvis {
+
+constexpr int NEW_MAX = 1024;  // capacity of FeatureDEM's output per stream and frame
+
+struct Pipe {
+  int S;
+  CamParams cam;
+  StreamState* st;          // [S]
+  Landmark* lm;             // [2][S][NMAX]
+  MotionState* vi;          // [S][VI_QUEUE]
+  const unsigned long long* seeds;  // [S] RANSAC seeds
+  double* imu_in;           // [S][IMU_MAX][7]  (t, acc, gyro) in the FLVIS IMU frame
+  int* n_imu;               // [S]
+  float* prev_pts;          // [S][NMAX][2]
+  float* next_pts;          // [S][NMAX][2]
+  uint8_t* lk_status;       // [S][NMAX]
+  int* lk_count;            // [S]
+  float* m1;                // [S][NMAX][2]  F-RANSAC inputs (ascending survivors)
+  float* m2;
+  double* tri;              // [S][NMAX][3]
+  uint8_t* tri_mask;        // [S][NMAX]
+  float* new_xy;            // [S][NEW_MAX][2]
+  int* n_new;               // [S]
+  double* exist_xy;         // [S][NMAX][2]
+  int* n_exist;             // [S]
+  int* act_img;             // [S]
+  int* act_track;           // [S]
+  int* det_mode;            // [S] 0 none, 1 detect (init), 2 redetect
+  int* det_maxc;            // [S]
+  int* img_slot;            // [S] image slot of the current frame
+  FrameOut* out;            // [S]
+  double* traj;             // [S][traj_cap][9]  (t, pose7, state|kf<<4) or nullptr
+  int traj_cap;
+  KeyFrameDev* kf;          // [S] latest keyframe payload
+  // local map
+  WindowDev* win;           // [S]
+  KeyFrameDev* kfs_ring;    // [S][BA_WMAX]
+  CorrectionDev* corr;      // [S]
+  double* ba_scratch;       // [S][ba_scratch_stride]
+  size_t ba_scratch_stride;
+  long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
+};
+
+void launch_imu_feed(hipStream_t st, const Pipe& p);
+void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time);
+void launch_track_prepare(hipStream_t st, const Pipe& p);
+void launch_track_collect(hipStream_t st, const Pipe& p);
+void launch_ransac_f(hipStream_t st, const Pipe& p);
+void launch_ransac_pnp(hipStream_t st, const Pipe& p);
+void launch_track_post(hipStream_t st, const Pipe& p);
+void launch_pose_lm(hipStream_t st, const Pipe& p);
+void launch_reproj_filter(hipStream_t st, const Pipe& p);
+void launch_add_new(hipStream_t st, const Pipe& p);
+void launch_depth_prepare(hipStream_t st, const Pipe& p);
+void launch_depth_innovate(hipStream_t st, const Pipe& p);
+void launch_frame_end(hipStream_t st, const Pipe& p, int frame_slot);
+// local map
+void launch_ba_update(hipStream_t st, const Pipe& p);
+void launch_ba_solve(hipStream_t st, const Pipe& p);
+hipError_t ba_kernels_init();
+size_t ba_scratch_doubles();
+
+}  // namespace flvis

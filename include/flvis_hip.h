@@ -85,6 +85,83 @@ int flvis_hip_feature_dem_redetect(flvis_ctx* ctx, const uint8_t* d_img, int w, 
                                    const double* d_exist_xy, const int* d_exist_count, int exist_cap, float* d_out_xy,
                                    int* d_out_count, int out_cap);
 
+/* ---- pipeline-level entry points: F2FTracking + LocalMap for a batch of independent streams ------------------------
+ *
+ * Mirrors the reference's class surface (include/f2f_tracking.h:51-73, src/backend/vo_localmap.cpp:87-380):
+ *   flvis_config_load        <- TrackingNodeletClass::onInit yaml handling      src/frontend/vo_tracking.cpp:103-306
+ *                                (accepts the reference's yaml files unchanged; src/utils/include/yamlRead.h)
+ *   flvis_tracker_create     <- F2FTracking::init                               src/frontend/f2f_tracking.cpp:5-38
+ *   flvis_imu_feed           <- TrackingNodeletClass::imu_callback + F2FTracking::imu_feed
+ *                                                                               src/frontend/vo_tracking.cpp:326-371, f2f_tracking.cpp:46-57
+ *   flvis_image_feed         <- F2FTracking::image_feed (+ KeyFrameMsg::pub + LocalMapNodeletClass::frame_callback when
+ *                                with_local_map != 0)                           f2f_tracking.cpp:59-400, vo_tracking.cpp:396-430
+ *   flvis_get_keyframe       <- flvis/KeyFrame message payload                  msg/KeyFrame.msg, src/utils/keyframe_msg.cpp:30-124
+ *   flvis_get_correction     <- flvis/CorrectionInf message payload             msg/CorrectionInf.msg, src/utils/correction_inf_msg.cpp:13-64
+ *   flvis_ba_push_keyframe   <- LocalMapNodeletClass::frame_callback alone      src/backend/vo_localmap.cpp:87-380
+ */
+typedef struct flvis_cfg {
+  int type_of_vi;                 /* 1 EuRoC (stereo unrectified + IMU), 3 D435i stereo, 5 D435 stereo + pixhawk */
+  int image_width, image_height;
+  double cam0_intrinsics[4], cam0_distortion[4], cam1_intrinsics[4], cam1_distortion[4];
+  double T_imu_cam0[16];          /* row-major 4x4 (EuRoC: T_imu_mavimu * T_mavimu_cam0) */
+  double T_cam0_cam1[16];
+  double vifusion_para[6], feature_para[6], dr_para[3];
+  int window_size;
+  /* derived by flvis_config_finalize (cv::stereoRectify restated, CALIB_ZERO_DISPARITY, alpha 0) */
+  int cam_type, imu_type, skip_first_n_imgs, need_equal_hist;
+  double R0[9], R1[9], P0[12], P1[12];
+} flvis_cfg;
+
+typedef struct flvis_frame_out {
+  int state;            /* 0 UnInit, 1 Tracking, 2 TrackingFail (enum TRACKINGSTATE) */
+  int new_keyframe, reset_cmd, n_landmarks;
+  int64_t frame_id;
+  double T_c_w[7];      /* tx ty tz qx qy qz qw of curr_frame */
+  int of_inliers, f_inliers, pnp_inliers, pad_;   /* the counts lkorb_tracking.cpp:191 prints */
+  double reprojection_error;
+} flvis_frame_out;
+
+int flvis_config_load(const char* yaml_path, flvis_cfg* cfg, char* err, int errlen);
+int flvis_config_finalize(flvis_cfg* cfg);
+
+/* Creates the batched tracker (and local map) for n_streams independent streams inside `ctx`.  seed_base + stream is the
+ * RANSAC seed of each stream.  traj_capacity > 0 keeps a device-side trajectory of that many frames per stream. */
+int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, uint64_t seed_base, int traj_capacity);
+
+/* One IMU sample of stream `stream` in the SENSOR frame; remapped per type_of_vi like imu_callback does.  Samples are
+ * staged on the host and consumed by the next flvis_image_feed (feed samples with t <= image time before the image). */
+int flvis_imu_feed(flvis_ctx* ctx, int stream, double t, const double* acc3, const double* gyro3);
+/* Same, n samples already in the FLVIS IMU frame: rows of 7 doubles (t, acc xyz, gyro xyz). */
+int flvis_imu_feed_flvis_frame(flvis_ctx* ctx, int stream, int n, const double* samples7);
+
+/* One stereo frame for every stream of the batch.  d_img0/d_img1: device [n_streams][h][w] mono8; h_times: host
+ * [n_streams] seconds.  h_out (host, [n_streams], may be NULL): results; when NULL nothing is copied back and the call
+ * does not synchronise.  with_local_map != 0 also runs the sliding-window BA for streams that emit a keyframe. */
+int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
+                     flvis_frame_out* h_out, int with_local_map);
+
+/* Landmarks of curr_frame of one stream (host arrays of capacity cap): ids, raw pixel, rectified pixel, world point,
+ * flags (bit0 has_3d, bit1 is_tracking_inlier).  Returns the landmark count (or <0). */
+int flvis_get_landmarks(flvis_ctx* ctx, int stream, int cap, int64_t* h_id, double* h_2d, double* h_2d_undist,
+                        double* h_3d_w, uint8_t* h_flags);
+/* Last KeyFrame payload of a stream: returns lm_count (or <0); arrays of capacity cap. */
+int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T_c_w7, int64_t* h_lm_id,
+                       double* h_lm_2d, double* h_lm_3d);
+/* Last CorrectionInf of a stream: returns 1 if one exists (0 if not yet, <0 error). */
+int flvis_get_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T_c_w7, int* lm_count,
+                         int64_t* h_lm_id, double* h_lm_3d, int* lm_outlier_count, int64_t* h_outlier_id);
+/* Device-side trajectory of one stream: rows of 9 doubles (t, tx ty tz qx qy qz qw, state | new_kf<<4). */
+int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_frames, double* h_rows9);
+/* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */
+int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
+
+/* LocalMapNodeletClass::frame_callback for one stream with a caller-supplied KeyFrame (host arrays).  Returns 1 and fills
+ * the outputs when an optimisation ran, 0 while the window is still filling. */
+int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T_c_w7, int lm_count,
+                           const int64_t* h_lm_id, const double* h_lm_2d, const double* h_lm_3d, int cap,
+                           int64_t* out_frame_id, double* out_T_c_w7, int* out_lm_count, int64_t* out_lm_id,
+                           double* out_lm_3d, int* out_outlier_count, int64_t* out_outlier_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""GPU parity tests of the full hot path through the C ABI: batched HIP front-end (F2FTracking mirror) and sliding-window
+BA (LocalMap mirror) against the CPU oracle on identical synthetic inputs.
+Bar: landmark ids / counts / inlier flags / tracked float pixel positions bit-exact; fp64 geometry within the tolerance
+written next to each check."""
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import _ba_synth as B
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import flvis_amd
+    c = flvis_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _cfgs():
+    import flvis_amd
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_d435_stereo.yaml")
+    open(p, "w").write(synth.D435I_STEREO_YAML)
+    cfg = flvis_amd.load_config(p)
+    ocfg = O.RefConfig()
+    assert C.sizeof(ocfg) == C.sizeof(cfg)
+    C.memmove(C.byref(ocfg), C.byref(cfg), C.sizeof(cfg))  # identical layout: both sides get the SAME numbers
+    return cfg, ocfg
+
+
+def test_frontend_parity_two_streams(ctx):
+    import flvis_amd
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs()
+    S, nframes = 2, 75
+    streams = [3, 140]
+    trajs = [synth.Trajectory(s) for s in streams]
+    rnd = synth.Renderer("cuda")
+    seed_base = 0xF1715
+    trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=seed_base, traj_capacity=nframes)
+    refs = [O.Tracker(ocfg, seed_base + i) for i in range(S)]
+    t_prev = -1.0
+    n_kf = 0
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        for i, s in enumerate(streams):
+            smp = synth.imu_samples(trajs[i], s, t_prev, t)
+            trk.imu_feed_flvis(i, smp)
+            for r in smp:
+                refs[i].imu(r[0], r[1:4], r[4:7])
+        t_prev = t
+        i0, i1 = rnd.stereo_frame(trajs, t, f)
+        outs = trk.image_feed(i0, i1, [t] * S, with_local_map=False)
+        h0, h1 = i0.cpu().numpy(), i1.cpu().numpy()
+        for i in range(S):
+            want = refs[i].image(t, h0[i], h1[i])
+            got = outs[i]
+            where = "frame %d stream %d" % (f, i)
+            assert got["state"] == want["state"], where
+            assert got["new_keyframe"] == want["new_keyframe"], where
+            assert got["n_landmarks"] == want["n_landmarks"], (where, got["n_landmarks"], want["n_landmarks"])
+            assert np.array_equal(got["dbg"], want["dbg"]), (where, got["dbg"], want["dbg"])
+            # pose: fp64 chain with wave-reduced sums vs sequential sums -> tolerance 1e-9 (m / unit quaternion)
+            assert np.allclose(got["pose7"], want["pose7"], atol=1e-9, rtol=0), (where, got["pose7"] - want["pose7"])
+            if want["state"] == 1 and f % 6 == 0:
+                gl, wl = trk.landmarks(i), refs[i].landmarks()
+                assert np.array_equal(gl["ids"], wl["ids"]), where
+                assert np.array_equal(gl["flags"], wl["flags"]), where
+                assert np.array_equal(gl["p2d"], wl["p2d"]), where           # float LK output, bit-exact
+                assert np.allclose(gl["p3w"], wl["p3w"], atol=1e-8, rtol=0), where
+            if want["new_keyframe"]:
+                n_kf += 1
+                gk, wk = trk.keyframe(i), refs[i].keyframe()
+                assert gk["frame_id"] == wk["frame_id"] and np.array_equal(gk["lm_id"], wk["lm_id"]), where
+                assert np.allclose(gk["lm_3d"], wk["lm_3d"], atol=1e-8, rtol=0), where
+    assert n_kf >= 4
+    rows = trk.trajectory(0, 0, nframes)
+    assert np.allclose(rows[:, 0], np.arange(nframes) / synth.FRAME_HZ)
+
+
+def test_local_map_parity(ctx):
+    import flvis_amd
+    cfg, _ = _cfgs()
+    trk = flvis_amd.Tracker(ctx, cfg, 2, seed_base=1)
+    K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
+    for stream, seed in ((0, 11), (1, 12)):
+        seq = B.make_sequence(seed, n_kf=14, n_lm=260, outlier_frac=0.03)
+        ref = O.LocalMap(cfg.window_size, K4)
+        produced = 0
+        for k, kf in enumerate(seq["kfs"]):
+            want = ref.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
+            got = trk.ba_push_keyframe(stream, kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
+            assert (want is None) == (got is None), k
+            if want is None:
+                continue
+            produced += 1
+            assert got["frame_id"] == want["frame_id"]
+            assert np.array_equal(got["lm_id"], want["lm_id"]), k                      # index work: exact
+            assert np.array_equal(got["outlier_id"], want["outlier_id"]), k            # descending edge-id order
+            # fp64 LM chain (20 iterations, different summation order): tolerance 1e-6 m on pose and landmarks
+            assert np.allclose(got["pose7"], want["pose7"], atol=1e-6, rtol=0), (k, got["pose7"] - want["pose7"])
+            assert np.allclose(got["lm_3d"], want["lm_3d"], atol=1e-6, rtol=0), (
+                k, np.abs(got["lm_3d"] - want["lm_3d"]).max())
+        assert produced == len(seq["kfs"]) - cfg.window_size + 1
