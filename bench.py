@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the MI355X-native FLVIS hot path (front-end tracking + sliding-window BA).
+
+Workload (BASELINE.json configs[3]): one GPU tracks a batch of 64 independent synthetic 640x480 stereo + 200 Hz IMU
+streams; a "step" is one stereo frame for every stream of the batch: full HIP front-end (copy, 2x3-level pyramids,
+temporal LK, F-RANSAC, PnP-RANSAC, pose LM, reprojection filter, GFTT + FeatureDEM redetect, stereo LK, DLT depth
+innovation, keyframe decision) plus the batched Schur BA for every stream that emits a keyframe.  Inputs (rendered
+frames, IMU samples) are resident in HBM / host memory before the timed region starts.
+With --gpus N (torchrun, one rank per GPU) every rank tracks its own 64 streams (weak scaling, no data-path collective);
+the only exchange is one RCCL all-gather of the final poses + all-reduce of counters after the timed region.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
+
+# algorithmic HBM bytes per launch of the image-scan kernels for ONE stream, 640x480:
+PYR_BYTES = 307200 + 76800 + 19200 + 4800          # one pyramid (levels 0..3)
+ALG_BYTES = {
+    "lk_track(temporal)": 2 * PYR_BYTES,           # one pass over the previous and the current pyramid
+    "lk_track(stereo)": 2 * PYR_BYTES,             # one pass over the img0 and img1 pyramids
+    "gftt(eig,nms,sort,select)": 2 * 307200,       # corner response reads img0 twice (max pass + threshold/NMS pass)
+    "ingest(copy/equalize)": 4 * 307200,           # read + write both images
+    "pyr_down x6": 2 * (307200 + 76800 + 19200) + 2 * (76800 + 19200 + 4800),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=70)
+    ap.add_argument("--streams", type=int, default=64, help="independent streams per GPU")
+    ap.add_argument("--cpu-frames", type=int, default=80, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-local-map", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import flvis_amd
+    from flvis_amd import synth
+
+    S, K, Wm = args.streams, args.steps, args.warmup
+    ypath = os.path.join(tempfile.gettempdir(), "flvis_bench_d435_stereo_%d.yaml" % rank)
+    open(ypath, "w").write(synth.D435I_STEREO_YAML)
+    cfg = flvis_amd.load_config(ypath)
+    skip = cfg.skip_first_n_imgs
+    ctx = flvis_amd.Context(local_rank)
+    nsteps = Wm + K
+    trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715 + rank * S, traj_capacity=nsteps)
+    lib = ctx._lib
+
+    # ---- synthetic inputs, resident before the timed region
+    stream_ids = [rank * S + i for i in range(S)]
+    trajs = [synth.Trajectory(s) for s in stream_ids]
+    rnd = synth.Renderer(dev)
+    t_render = time.time()
+    frames = {}
+    for f in range(skip, nsteps):  # the first `skip` frames are dropped by the reference before any processing
+        frames[f] = rnd.stereo_frame(trajs, f / synth.FRAME_HZ, f)
+    for f in range(0, min(skip, nsteps)):
+        frames[f] = frames.get(skip, None) or rnd.stereo_frame(trajs, f / synth.FRAME_HZ, f)
+    torch.cuda.synchronize()
+    t_render = time.time() - t_render
+    SPF = 16
+    imu = np.zeros((nsteps, S, SPF, 7))
+    imu_cnt = np.zeros((nsteps, S), np.int32)
+    for i, s in enumerate(stream_ids):
+        t_prev = -1.0 / synth.FRAME_HZ
+        for f in range(nsteps):
+            t = f / synth.FRAME_HZ
+            smp = synth.imu_samples(trajs[i], s, t_prev, t)
+            imu[f, i, :len(smp)] = smp
+            imu_cnt[f, i] = len(smp)
+            t_prev = t
+    times = np.array([[f / synth.FRAME_HZ] * S for f in range(nsteps)])
+    wlm = 0 if args.no_local_map else 1
+
+    def step(f):
+        rc = lib.flvis_imu_feed_all(ctx._h, imu_cnt[f].ctypes.data_as(C.POINTER(C.c_int)),
+                                    imu[f].ctypes.data_as(C.POINTER(C.c_double)), SPF)
+        if rc:
+            ctx._check(rc, "imu_feed_all")
+        i0, i1 = frames[f]
+        rc = lib.flvis_image_feed(ctx._h, C.c_void_p(i0.data_ptr()), C.c_void_p(i1.data_ptr()),
+                                  times[f].ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(0), wlm)
+        if rc:
+            ctx._check(rc, "image_feed")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for f in range(Wm):
+        step(f)
+    torch.cuda.synchronize()
+    ctx._check(lib.flvis_prof_enable(ctx._h, K), "prof_enable")
+    barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for f in range(Wm, Wm + K):
+        step(f)
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- results: per-stage HIP-event times, tracker health, final poses
+    nst = lib.flvis_prof_stage_count()
+    lib.flvis_prof_stage_name.restype = C.c_char_p
+    ms = (C.c_double * nst)()
+    nrec = C.c_int(0)
+    ctx._check(lib.flvis_prof_read(ctx._h, ms, C.byref(nrec)), "prof_read")
+    stages = {lib.flvis_prof_stage_name(i).decode(): ms[i] / max(nrec.value, 1) for i in range(nst)}
+    cnt = trk.counters()
+    rows = np.stack([trk.trajectory(i, Wm + K - 1, 1)[0] for i in range(S)])
+    tracking = int((rows[:, 8].astype(int) & 15 == 1).sum())
+    kfs_total = cnt[1]
+    if world > 1:  # the path's only exchange: results, after the timed region
+        poses = torch.from_numpy(rows[:, 1:8].copy()).to(dev)
+        gathered = [torch.empty_like(poses) for _ in range(world)]
+        dist.all_gather(gathered, poses)
+        c = torch.tensor([cnt[0], cnt[1], cnt[2], tracking], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        cnt = [int(x) for x in c[:3].tolist()]
+        tracking = int(c[3].item())
+
+    out = None
+    if rank == 0:
+        total_frames = world * S * K
+        value = total_frames / elapsed
+        dom = max(ALG_BYTES.keys(), key=lambda k: stages.get(k, 0.0))
+        dom_ms = stages[dom]
+        achieved = ALG_BYTES[dom] * S / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "frames/sec/node (640x480 stereo+IMU)", "value": round(value, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32 LK+GFTT, f64 geometry+BA",
+            "data": "synthetic",
+            "config": {"workload": "1xMI355X: batch of %d independent 640x480 synthetic stereo+IMU streams, full HIP "
+                                   "front-end + batched Schur BA (BASELINE.json configs[3])" % S,
+                       "streams_per_gpu": S, "window_size": cfg.window_size, "local_map": bool(wlm),
+                       "streams_tracking_at_end": tracking, "keyframes_in_run": int(kfs_total),
+                       "ba_runs_in_run": int(cnt[2]), "gpu_ms_per_step_events": round(gpu_ms / K, 4)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES[dom] * S},
+            "stages_ms_per_step": {k: round(v, 4) for k, v in stages.items()},
+        }
+        # ---- CPU baseline: the oracle (port of the reference path) on a bounded sample of the same workload, 1 core
+        if args.cpu_frames > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _oracle as O
+            ocfg = O.RefConfig()
+            C.memmove(C.byref(ocfg), C.byref(cfg), C.sizeof(cfg))
+            ref = O.Tracker(ocfg, 0xF1715)
+            lm = O.LocalMap(cfg.window_size, np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]]))
+            n_cpu = min(args.cpu_frames, nsteps - skip)
+            host = [(frames[skip + j][0][0].cpu().numpy(), frames[skip + j][1][0].cpu().numpy()) for j in range(n_cpu)]
+            for f in range(skip):  # IMU-only prefix (untimed): the skipped frames carry no vision work
+                for r in imu[f, 0, :imu_cnt[f, 0]]:
+                    ref.imu(r[0], r[1:4], r[4:7])
+                ref.image(f / synth.FRAME_HZ, host[0][0], host[0][1])
+            tc = time.perf_counter()
+            for j in range(n_cpu):
+                f = skip + j
+                for r in imu[f, 0, :imu_cnt[f, 0]]:
+                    ref.imu(r[0], r[1:4], r[4:7])
+                res = ref.image(f / synth.FRAME_HZ, host[j][0], host[j][1])
+                if res["new_keyframe"] and wlm:
+                    kf = ref.keyframe()
+                    lm.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
+            tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": round(n_cpu / tc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "stream 0, %d frames after the %d skipped start-up frames of the same synthetic "
+                                             "workload, oracle front-end + local-map BA, single thread (%d host cores "
+                                             "present)" % (n_cpu, skip, os.cpu_count())}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

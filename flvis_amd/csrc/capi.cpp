@@ -69,6 +69,7 @@ int flvis_hip_create(int device, void* hip_stream, flvis_ctx** out) {
 }
 
 void flvis_pipeline_destroy_internal(flvis_ctx* ctx);  // pipeline.cpp
+void flvis_pipeline_sync_internal(flvis_ctx* ctx);
 
 void flvis_hip_destroy(flvis_ctx* ctx) {
   if (!ctx) return;
@@ -87,6 +88,7 @@ int flvis_hip_synchronize(flvis_ctx* ctx) {
   CHECK_CTX(ctx);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) return ctx->hip_fail(e, "hipStreamSynchronize");
+  flvis_pipeline_sync_internal(ctx);
   return FLVIS_OK;
 }
 
@@ -261,5 +263,3 @@ int flvis_hip_feature_dem_redetect(flvis_ctx* ctx, const uint8_t* d_img, int w, 
 
 }  // extern "C"
 
-// until pipeline.cpp exists
-__attribute__((weak)) void flvis_pipeline_destroy_internal(flvis_ctx*) {}

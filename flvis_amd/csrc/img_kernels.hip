@@ -268,6 +268,12 @@ __global__ __launch_bounds__(256) void k_eig_nms(ImgSel src, int w, int h, int p
   const float maxv = f32_unordered(maxenc[s]);
   const double q = qual ? qual[s] : quality;
   const float thr = (float)((double)maxv * q);
+  // candidates are collected per workgroup in LDS and appended with ONE global atomic per workgroup (the per-stream
+  // counter would otherwise serialise ~10^4 atomics per image); their order is irrelevant, the keys are sorted next
+  __shared__ unsigned long long lkeys[EG_TH * EG_TW];
+  __shared__ int lcount, lbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
   for (int i = threadIdx.x; i < EG_TH * EG_TW; i += 256) {
     int r = i / EG_TW, c = i - r * EG_TW;
     int x = x0 + c, y = y0 + r;
@@ -285,12 +291,18 @@ __global__ __launch_bounds__(256) void k_eig_nms(ImgSel src, int w, int h, int p
         if (tv > v) ismax = false;
       }
     if (ismax) {
-      int slot = atomicAdd(&nkeys[s], 1);
-      if (slot < cap) {
-        unsigned long long key = ((unsigned long long)f32_ordered(v) << 32) | (unsigned)(y * w + x);
-        keys[(size_t)s * cap + slot] = ~key;
-      }
+      int slot = atomicAdd(&lcount, 1);
+      unsigned long long key = ((unsigned long long)f32_ordered(v) << 32) | (unsigned)(y * w + x);
+      lkeys[slot] = ~key;
     }
+  }
+  __syncthreads();
+  const int n = lcount;
+  if (threadIdx.x == 0 && n > 0) lbase = atomicAdd(&nkeys[s], n);
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int slot = lbase + i;
+    if (slot < cap) keys[(size_t)s * cap + slot] = lkeys[i];
   }
 }
 

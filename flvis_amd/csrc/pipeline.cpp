@@ -37,7 +37,21 @@ struct Pipeline {
   size_t pinned_bytes = 0;
   long long frames_fed = 0;
   std::vector<void*> allocs;
+  // optional per-stage HIP-event timing (flvis_prof_enable)
+  std::vector<hipEvent_t> prof_ev;
+  int prof_cap = 0, prof_step = 0;
+  // local map on its own HIP stream: the BA of frame N overlaps the front-end of frame N+1 (its output is never fed
+  // back into the tracker in the reference, src/frontend/vo_tracking.cpp:373-385).  Keyframe payloads are double-buffered.
+  hipStream_t ba_stream = nullptr;
+  hipEvent_t ev_fe[2] = {nullptr, nullptr}, ev_ba[2] = {nullptr, nullptr};
+  bool ev_ba_armed[2] = {false, false};
+  KeyFrameDev* kfbuf[2] = {nullptr, nullptr};
 };
+constexpr int PROF_STAGES = 18;
+static const char* kStageNames[PROF_STAGES] = {
+    "imu_feed+frame_begin", "ingest(copy/equalize)", "pyr_down x6", "track_prepare", "lk_track(temporal)", "track_collect",
+    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt(eig,nms,sort,select)", "feature_dem+add_new",
+    "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end", "ba_update", "ba_solve"};
 
 }  // namespace flvis
 
@@ -130,10 +144,23 @@ void glibc_seed(unsigned s, int* r34) {
 
 }  // namespace
 
-void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
+extern "C" void flvis_pipeline_sync_internal(flvis_ctx* ctx) {
+  if (ctx && ctx->pipe && ctx->pipe->ba_stream) hipStreamSynchronize(ctx->pipe->ba_stream);
+}
+
+extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   if (!ctx || !ctx->pipe) return;
   Pipeline* pl = ctx->pipe;
+  if (pl->ba_stream) {
+    hipStreamSynchronize(pl->ba_stream);
+    hipStreamDestroy(pl->ba_stream);
+  }
+  for (int k = 0; k < 2; k++) {
+    if (pl->ev_fe[k]) hipEventDestroy(pl->ev_fe[k]);
+    if (pl->ev_ba[k]) hipEventDestroy(pl->ev_ba[k]);
+  }
   for (void* p : pl->allocs) hipFree(p);
+  for (hipEvent_t e : pl->prof_ev) hipEventDestroy(e);
   if (pl->pinned) hipHostFree(pl->pinned);
   delete pl;
   ctx->pipe = nullptr;
@@ -218,7 +245,9 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   DA(det_maxc, int, S);
   DA(img_slot, int, S);
   DA(out, FrameOut, S);
-  DA(kf, KeyFrameDev, S);
+  ok = ok && ((pl->kfbuf[0] = dalloc<KeyFrameDev>(pl, S)) != nullptr);
+  ok = ok && ((pl->kfbuf[1] = dalloc<KeyFrameDev>(pl, S)) != nullptr);
+  p.kf = pl->kfbuf[0];
   DA(win, WindowDev, S);
   DA(kfs_ring, KeyFrameDev, (size_t)S * BA_WMAX);
   DA(corr, CorrectionDev, S);
@@ -291,6 +320,14 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     flvis_pipeline_destroy_internal(ctx);
     return ctx->fail(FLVIS_ERR_HIP, "tracker_create: pinned allocation failed");
   }
+  bool evok = hipStreamCreateWithFlags(&pl->ba_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int k = 0; k < 2 && evok; k++)
+    evok = hipEventCreateWithFlags(&pl->ev_fe[k], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&pl->ev_ba[k], hipEventDisableTiming) == hipSuccess;
+  if (!evok) {
+    flvis_pipeline_destroy_internal(ctx);
+    return ctx->fail(FLVIS_ERR_HIP, "tracker_create: cannot create the local-map stream/events");
+  }
   if (ba_kernels_init() != hipSuccess) {
     (void)hipGetLastError();
     flvis_pipeline_destroy_internal(ctx);
@@ -343,11 +380,19 @@ static void fill_pyr(Pipeline* pl, PyrSel& ps, uint8_t* const* l0, uint8_t* cons
   }
 }
 
+int flvis_prof_stage_count(void);
+// synchronous local-map step on keyframe buffer 0 (flvis_ba_push_keyframe)
 static int run_local_map(flvis_ctx* ctx) {
   Pipeline* pl = ctx->pipe;
-  launch_ba_update(ctx->stream, pl->pipe);
-  launch_ba_solve(ctx->stream, pl->pipe);
+  Pipe p = pl->pipe;
+  p.kf = pl->kfbuf[0];
+  launch_ba_update(ctx->stream, p);
+  launch_ba_solve(ctx->stream, p);
   return FLVIS_OK;
+}
+static void sync_all(flvis_ctx* ctx) {
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->pipe && ctx->pipe->ba_stream) hipStreamSynchronize(ctx->pipe->ba_stream);
 }
 
 int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
@@ -371,8 +416,14 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   hipMemcpyAsync(p.imu_in, pi, sizeof(double) * (size_t)S * IMU_MAX * 7, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(p.n_imu, pn, sizeof(int) * S, hipMemcpyHostToDevice, st);
   // ---- fixed kernel sequence
+  const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
+  hipEvent_t* pev = prof ? &pl->prof_ev[(size_t)pl->prof_step * (PROF_STAGES + 1)] : nullptr;
+#define MARK(i) \
+  if (prof) hipEventRecord(pev[i], st)
+  MARK(0);
   launch_imu_feed(st, p);
   launch_frame_begin(st, p, pl->d_time);
+  MARK(1);
   // images -> level 0 of the stream's current slot (copy, or equalizeHist for EuRoC), then the pyramids
   ImgSel in0 = img_plain(d_img0), in1 = img_plain(d_img1);
   ImgSel l0cur{{pl->pyr0[0][0], pl->pyr0[1][0]}, p.img_slot, 0};
@@ -384,6 +435,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
     launch_copy_image(st, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
   }
+  MARK(2);
   for (int l = 1; l <= pl->levels; l++) {
     ImgSel s0{{pl->pyr0[0][l - 1], pl->pyr0[1][l - 1]}, p.img_slot, 0}, d0{{pl->pyr0[0][l], pl->pyr0[1][l]}, p.img_slot, 0};
     launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
@@ -391,7 +443,9 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
                     img_plain(pl->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
   }
   // temporal tracking
+  MARK(3);
   launch_track_prepare(st, p);
+  MARK(4);
   {
     PyrSel prev, next;
     fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 1, pl->levels_t);
@@ -399,20 +453,29 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track);
   }
+  MARK(5);
   launch_track_collect(st, p);
+  MARK(6);
   launch_ransac_f(st, p);
+  MARK(7);
   launch_ransac_pnp(st, p);
+  MARK(8);
   launch_track_post(st, p);
   launch_pose_lm(st, p);
+  MARK(9);
   launch_reproj_filter(st, p);
+  MARK(10);
   // detection (init: detect, tracking: redetect)
   launch_gftt(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, pl->gftt, nullptr, p.cam.gftt_ql, p.det_maxc, p.cam.gftt_num,
               (double)p.cam.gftt_dis, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num, p.det_mode);
+  MARK(11);
   launch_feature_dem(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num,
                      p.det_mode, p.exist_xy, p.n_exist, NMAX, p.new_xy, p.n_new, NEW_MAX);
   launch_add_new(st, p);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
+  MARK(12);
   launch_depth_prepare(st, p);
+  MARK(13);
   {
     PyrSel prev, next;
     fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 0, pl->levels_s);
@@ -420,9 +483,31 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode);
   }
+  MARK(14);
   launch_depth_innovate(st, p);
+  MARK(15);
+  const int par = (int)(pl->frames_fed & 1);
+  p.kf = pl->kfbuf[par];  // this frame's keyframe slot; the local map may still be reading the other one
+  if (pl->ev_ba_armed[par]) hipStreamWaitEvent(st, pl->ev_ba[par], 0);  // BA of frame N-2 has released this slot
   launch_frame_end(st, p, (int)pl->frames_fed);
-  if (with_local_map) run_local_map(ctx);
+  if (with_local_map) {
+    hipStream_t bs = pl->ba_stream;
+    hipEventRecord(pl->ev_fe[par], st);
+    hipStreamWaitEvent(bs, pl->ev_fe[par], 0);
+    if (prof) hipEventRecord(pev[16], bs);
+    launch_ba_update(bs, p);
+    if (prof) hipEventRecord(pev[17], bs);
+    launch_ba_solve(bs, p);
+    if (prof) hipEventRecord(pev[18], bs);
+    hipEventRecord(pl->ev_ba[par], bs);
+    pl->ev_ba_armed[par] = true;
+  } else if (prof) {
+    MARK(16);
+    MARK(17);
+    MARK(18);
+  }
+#undef MARK
+  if (prof) pl->prof_step++;
   pl->frames_fed++;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ctx->hip_fail(e, "image_feed launch");
@@ -435,12 +520,56 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   return FLVIS_OK;
 }
 
+int flvis_imu_feed_all(flvis_ctx* ctx, const int* h_counts, const double* h_samples, int samples_per_stream) {
+  if (!ctx || !ctx->pipe || !h_counts || !h_samples || samples_per_stream <= 0) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  for (int s = 0; s < pl->S; s++) {
+    int n = h_counts[s];
+    if (n < 0 || n > samples_per_stream) return ctx->fail(FLVIS_ERR_INVALID_ARG, "imu_feed_all: bad count");
+    int rc = flvis_imu_feed_flvis_frame(ctx, s, n, h_samples + (size_t)s * samples_per_stream * 7);
+    if (rc) return rc;
+  }
+  return FLVIS_OK;
+}
+
+int flvis_prof_enable(flvis_ctx* ctx, int max_steps) {
+  if (!ctx || !ctx->pipe || max_steps < 0) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  sync_all(ctx);
+  for (hipEvent_t e : pl->prof_ev) hipEventDestroy(e);
+  pl->prof_ev.clear();
+  pl->prof_cap = max_steps;
+  pl->prof_step = 0;
+  pl->prof_ev.resize((size_t)max_steps * (PROF_STAGES + 1));
+  for (auto& e : pl->prof_ev)
+    if (hipEventCreate(&e) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
+  return FLVIS_OK;
+}
+
+int flvis_prof_stage_count(void) { return PROF_STAGES; }
+const char* flvis_prof_stage_name(int i) { return (i >= 0 && i < PROF_STAGES) ? kStageNames[i] : ""; }
+
+int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps) {
+  if (!ctx || !ctx->pipe || !h_ms_per_stage || !n_steps) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  sync_all(ctx);
+  for (int i = 0; i < PROF_STAGES; i++) h_ms_per_stage[i] = 0;
+  for (int k = 0; k < pl->prof_step; k++)
+    for (int i = 0; i < PROF_STAGES; i++) {
+      float ms = 0;
+      hipEventElapsedTime(&ms, pl->prof_ev[(size_t)k * (PROF_STAGES + 1) + i], pl->prof_ev[(size_t)k * (PROF_STAGES + 1) + i + 1]);
+      h_ms_per_stage[i] += ms;
+    }
+  *n_steps = pl->prof_step;
+  return FLVIS_OK;
+}
+
 int flvis_get_landmarks(flvis_ctx* ctx, int stream, int cap, int64_t* h_id, double* h_2d, double* h_2du, double* h_3d,
                         uint8_t* h_flags) {
   if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
-  hipStreamSynchronize(ctx->stream);
+  sync_all(ctx);
   StreamState st;
   hipMemcpy(&st, pl->pipe.st + stream, sizeof(st), hipMemcpyDeviceToHost);
   int n = st.n_lm[st.cur];
@@ -463,10 +592,10 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
   if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
-  hipStreamSynchronize(ctx->stream);
+  sync_all(ctx);
   std::vector<KeyFrameDev> kfv(1);
   KeyFrameDev& kf = kfv[0];
-  hipMemcpy(&kf, pl->pipe.kf + stream, sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
+  hipMemcpy(&kf, pl->kfbuf[(pl->frames_fed > 0 ? (pl->frames_fed - 1) : 0) & 1] + stream, sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
   if (!kf.valid) return 0;
   *frame_id = kf.frame_id;
   memcpy(T7, kf.T_c_w, 56);
@@ -502,7 +631,7 @@ int flvis_get_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id,
                          double* h_3d, int* oc, int64_t* h_oid) {
   if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
   if (stream < 0 || stream >= ctx->pipe->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
-  hipStreamSynchronize(ctx->stream);
+  sync_all(ctx);
   return read_correction(ctx, stream, cap, frame_id, T7, lm_count, h_id, h_3d, oc, h_oid);
 }
 
@@ -511,14 +640,14 @@ int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first, int n, double* h
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S || first < 0 || n < 0 || first + n > pl->pipe.traj_cap)
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "get_trajectory: out of range");
-  hipStreamSynchronize(ctx->stream);
+  sync_all(ctx);
   hipMemcpy(h_rows9, pl->pipe.traj + ((size_t)stream * pl->pipe.traj_cap + first) * 9, sizeof(double) * 9 * n, hipMemcpyDeviceToHost);
   return n;
 }
 
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) {
   if (!ctx || !ctx->pipe || !h3) return FLVIS_ERR_INVALID_ARG;
-  hipStreamSynchronize(ctx->stream);
+  sync_all(ctx);
   long long c[8];
   hipMemcpy(c, ctx->pipe->pipe.counters, sizeof(c), hipMemcpyDeviceToHost);
   h3[0] = ctx->pipe->frames_fed * ctx->pipe->S;
@@ -546,14 +675,19 @@ int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const d
     kf.lm_2d[i][1] = h_2d[2 * i + 1];
     for (int j = 0; j < 3; j++) kf.lm_3d[i][j] = h_3d[3 * i + j];
   }
-  hipStreamSynchronize(ctx->stream);
-  hipMemcpy(pl->pipe.kf + stream, &kf, sizeof(kf), hipMemcpyHostToDevice);
-  int one = 1, zero = 0;
-  hipMemcpy(&pl->pipe.st[stream].kf_pending, &one, sizeof(int), hipMemcpyHostToDevice);
+  sync_all(ctx);
+  const int zero = 0;
+  for (int i = 0; i < pl->S; i++)  // only `stream` carries a keyframe in this call
+    hipMemcpy(&pl->kfbuf[0][i].valid, &zero, sizeof(int), hipMemcpyHostToDevice);
+  hipMemcpy(pl->kfbuf[0] + stream, &kf, sizeof(kf), hipMemcpyHostToDevice);
   hipMemcpy(&pl->pipe.corr[stream].valid, &zero, sizeof(int), hipMemcpyHostToDevice);
   run_local_map(ctx);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) return ctx->hip_fail(e, "ba_push_keyframe");
+  {
+    const int z = 0;
+    hipMemcpy(&pl->kfbuf[0][stream].valid, &z, sizeof(int), hipMemcpyHostToDevice);
+  }
   return read_correction(ctx, stream, cap, out_frame_id, out_T7, out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid);
 }
 

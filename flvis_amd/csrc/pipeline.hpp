@@ -130,6 +130,7 @@ struct WindowDev {
   long long e_id[BA_EMAX];
   long long e_lm[BA_EMAX];  // landmark id
   int e_pose[BA_EMAX];
+  int e_lidx[BA_EMAX];  // index of e_lm in the bag arrays (kept consistent across bag compaction)
   double e_uv[BA_EMAX][2];
   // keyframe queue (the `kfs` deque of vo_localmap.cpp:55): ring of the last `window` payloads, storage in Pipe::kfs_ring
   int kfs_head, kfs_size;

@@ -1029,7 +1029,10 @@ __global__ __launch_bounds__(64) void k_frame_end(Pipe p, int frame_slot) {
   StreamState& st = p.st[s];
   const int lane = threadIdx.x;
   __shared__ int s_newkf;
-  if (lane == 0) s_newkf = 0;
+  if (lane == 0) {
+    s_newkf = 0;
+    p.kf[s].valid = 0;  // this frame's keyframe slot: filled below only if the frame becomes a keyframe
+  }
   __syncthreads();
   if (st.phase == PH_INIT) {
     const int cur = st.cur;
@@ -1110,8 +1113,7 @@ __global__ __launch_bounds__(64) void k_frame_end(Pipe p, int frame_slot) {
       kf.frame_id = st.frame_id[cur];
       kf.lm_count = cnt < KF_MAXLM ? cnt : KF_MAXLM;
       for (int j = 0; j < 7; j++) kf.T_c_w[j] = st.T_c_w[cur][j];
-      kf.valid = 1;
-      st.kf_pending = 1;
+      kf.valid = 1;  // consumed by k_ba_update (possibly on the local-map stream, overlapped with the next frame)
     }
   }
 }

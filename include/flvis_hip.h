@@ -134,6 +134,16 @@ int flvis_imu_feed(flvis_ctx* ctx, int stream, double t, const double* acc3, con
 /* Same, n samples already in the FLVIS IMU frame: rows of 7 doubles (t, acc xyz, gyro xyz). */
 int flvis_imu_feed_flvis_frame(flvis_ctx* ctx, int stream, int n, const double* samples7);
 
+/* All streams at once: h_counts [n_streams], h_samples [n_streams][samples_per_stream][7] (FLVIS IMU frame). */
+int flvis_imu_feed_all(flvis_ctx* ctx, const int* h_counts, const double* h_samples, int samples_per_stream);
+
+/* Optional per-stage timing of flvis_image_feed with HIP events on the context's stream (for bench.py's roofline).
+ * flvis_prof_enable(max_steps) arms it for the next max_steps frames; flvis_prof_read sums the elapsed ms per stage. */
+int flvis_prof_enable(flvis_ctx* ctx, int max_steps);
+int flvis_prof_stage_count(void);
+const char* flvis_prof_stage_name(int i);
+int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps);
+
 /* One stereo frame for every stream of the batch.  d_img0/d_img1: device [n_streams][h][w] mono8; h_times: host
  * [n_streams] seconds.  h_out (host, [n_streams], may be NULL): results; when NULL nothing is copied back and the call
  * does not synchronise.  with_local_map != 0 also runs the sliding-window BA for streams that emit a keyframe. */
