@@ -74,7 +74,8 @@ def main():
     lib = ctx._lib
 
     # ---- synthetic inputs, resident before the timed region
-    stream_ids = [rank * S + i for i in range(S)]
+    from flvis_amd.dist import shard_streams
+    stream_ids = shard_streams(rank, world, S)
     trajs = [synth.Trajectory(s) for s in stream_ids]
     rnd = synth.Renderer(dev)
     t_render = time.time()
@@ -130,10 +131,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     gpu_ms = e0.elapsed_time(e1)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    from flvis_amd import dist as fdist
+    elapsed = fdist.max_over_ranks(elapsed, dev)
 
     # ---- results: per-stage HIP-event times, tracker health, final poses
     nst = lib.flvis_prof_stage_count()
@@ -146,14 +145,11 @@ def main():
     rows = np.stack([trk.trajectory(i, Wm + K - 1, 1)[0] for i in range(S)])
     tracking = int((rows[:, 8].astype(int) & 15 == 1).sum())
     kfs_total = cnt[1]
-    if world > 1:  # the path's only exchange: results, after the timed region
-        poses = torch.from_numpy(rows[:, 1:8].copy()).to(dev)
-        gathered = [torch.empty_like(poses) for _ in range(world)]
-        dist.all_gather(gathered, poses)
-        c = torch.tensor([cnt[0], cnt[1], cnt[2], tracking], dtype=torch.int64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        cnt = [int(x) for x in c[:3].tolist()]
-        tracking = int(c[3].item())
+    # the path's only exchange: results, after the timed region: all-gather poses, all-reduce counters
+    all_poses, csum = fdist.exchange_results(torch.from_numpy(rows[:, 1:8].copy()).to(dev),
+                                             [cnt[0], cnt[1], cnt[2], tracking], dev)
+    assert all_poses.shape[0] == world * S
+    cnt, tracking, kfs_total = csum[:3], csum[3], csum[1]
 
     out = None
     if rank == 0:

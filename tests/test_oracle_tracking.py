@@ -1,0 +1,57 @@
+"""CPU end-to-end test of the oracle front-end on a synthetic stereo+IMU stream: the state machine initialises after the
+reference's 50 skipped frames, keeps tracking, emits keyframes, and its trajectory follows ground truth."""
+import os
+import tempfile
+
+import numpy as np
+
+import _geom as G
+import _oracle as O
+
+
+def _umeyama_ate(est, gt):
+    mu_e, mu_g = est.mean(0), gt.mean(0)
+    H = (est - mu_e).T @ (gt - mu_g)
+    U, _, Vt = np.linalg.svd(H)
+    D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+    R = Vt.T @ D @ U.T
+    al = (est - mu_e) @ R.T + mu_g
+    return float(np.sqrt(np.mean(np.sum((al - gt) ** 2, axis=1))))
+
+
+def test_oracle_tracks_synthetic_stream():
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_track.yaml")
+    open(p, "w").write(synth.D435I_STEREO_YAML)
+    cfg = O.load_config(p)
+    trk = O.Tracker(cfg, 7)
+    tr = synth.Trajectory(5)
+    rnd = synth.Renderer("cpu")
+    t_prev = -0.05
+    est, gt, states, kfs = [], [], [], 0
+    frame0 = None
+    for f in range(50 + 28):
+        t = f / synth.FRAME_HZ
+        for s in synth.imu_samples(tr, 5, t_prev, t):
+            trk.imu(s[0], s[1:4], s[4:7])
+        t_prev = t
+        if f >= 50 or frame0 is None:
+            i0, i1 = rnd.stereo_frame([tr], t, f)
+            frame0 = (i0[0].numpy(), i1[0].numpy())
+        r = trk.image(t, frame0[0], frame0[1])
+        states.append(r["state"])
+        if f < 50:
+            assert r["state"] == 0 and r["n_landmarks"] == 0         # skip_first_n_imgs (vo_tracking.cpp:171)
+            continue
+        kfs += r["new_keyframe"]
+        R, tt = G.pose7_to_Rt(r["pose7"])
+        Rg, tg = tr.T_c_w(t)
+        est.append(-R.T @ tt)
+        gt.append(-Rg.T @ tg)
+    assert states[50] == 1 and all(s == 1 for s in states[50:])      # init on the first processed frame, never lost
+    assert kfs >= 5
+    lm = trk.landmarks()
+    assert 150 <= len(lm["ids"]) <= 260 and lm["ids"].min() >= 100 and np.all(lm["flags"] & 1)
+    ate = _umeyama_ate(np.array(est), np.array(gt))
+    path = np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum()
+    assert ate < 0.05 * path + 0.01, (ate, path)                     # a few % of the distance travelled
