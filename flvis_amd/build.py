@@ -11,6 +11,7 @@ LIB = os.path.join(HERE, "libflvis_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-result", "-Wno-unused-value"]
+FLAGS += os.environ.get("FLVIS_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():

@@ -251,7 +251,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   DA(win, WindowDev, S);
   DA(kfs_ring, KeyFrameDev, (size_t)S * BA_WMAX);
   DA(corr, CorrectionDev, S);
-  DA(counters, long long, 8);
+  DA(counters, long long, 64);
   p.ba_scratch_stride = ba_scratch_doubles();
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
   unsigned long long* seeds = dalloc<unsigned long long>(pl, S);
@@ -653,6 +653,13 @@ int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) {
   h3[0] = ctx->pipe->frames_fed * ctx->pipe->S;
   h3[1] = c[1];
   h3[2] = c[2];
+  return FLVIS_OK;
+}
+
+int flvis_debug_counters(flvis_ctx* ctx, int64_t* h64) {
+  if (!ctx || !ctx->pipe || !h64) return FLVIS_ERR_INVALID_ARG;
+  sync_all(ctx);
+  hipMemcpy(h64, ctx->pipe->pipe.counters, sizeof(long long) * 64, hipMemcpyDeviceToHost);
   return FLVIS_OK;
 }
 

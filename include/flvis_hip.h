@@ -164,6 +164,9 @@ int flvis_get_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id,
 int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_frames, double* h_rows9);
 /* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
+/* Raw device counter block (64 x int64): [0..7] as above, [8..] per-phase cycle counters of the BA kernel, filled only by
+ * builds with -DFLVIS_BA_PROF (tuning aid, not part of the reference interface). */
+int flvis_debug_counters(flvis_ctx* ctx, int64_t* h_counters64);
 
 /* LocalMapNodeletClass::frame_callback for one stream with a caller-supplied KeyFrame (host arrays).  Returns 1 and fills
  * the outputs when an optimisation ran, 0 while the window is still filling. */

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Phase breakdown of k_ba_solve (needs a build with FLVIS_EXTRA_HIPCC_FLAGS=-DFLVIS_BA_PROF)."""
+import ctypes as C
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+import flvis_amd
+from flvis_amd import synth
+
+S, N = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 110
+dev = torch.device("cuda", 0)
+yp = os.path.join(tempfile.gettempdir(), "baprof.yaml")
+open(yp, "w").write(synth.D435I_STEREO_YAML)
+cfg = flvis_amd.load_config(yp)
+ctx = flvis_amd.Context(0)
+trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715)
+trajs = [synth.Trajectory(s) for s in range(S)]
+rnd = synth.Renderer(dev)
+skip = cfg.skip_first_n_imgs
+fr0 = rnd.stereo_frame(trajs, skip / synth.FRAME_HZ, skip)
+lib = ctx._lib
+tprev = -1.0 / synth.FRAME_HZ
+for f in range(N):
+    t = f / synth.FRAME_HZ
+    imu = np.zeros((S, 16, 7)); cnt = np.zeros(S, np.int32)
+    for i in range(S):
+        smp = synth.imu_samples(trajs[i], i, tprev, t)
+        imu[i, :len(smp)] = smp; cnt[i] = len(smp)
+    tprev = t
+    lib.flvis_imu_feed_all(ctx._h, cnt.ctypes.data_as(C.POINTER(C.c_int)), imu.ctypes.data_as(C.POINTER(C.c_double)), 16)
+    i0, i1 = fr0 if f < skip else rnd.stereo_frame(trajs, t, f)
+    tt = np.full(S, t)
+    rc = lib.flvis_image_feed(ctx._h, C.c_void_p(i0.data_ptr()), C.c_void_p(i1.data_ptr()),
+                              tt.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(0), 1)
+    assert rc == 0
+c = (C.c_int64 * 64)()
+lib.flvis_debug_counters(ctx._h, c)
+c = np.array(c[:])
+names = ["misc", "structure", "-", "linearize_lm", "linearize_pose+chi2", "-", "-", "schur", "cholesky+solve",
+         "update", "chi2_trial", "cull/finish"]
+runs, trials = max(c[8 + 15], 1), max(c[8 + 14], 1)
+print("ba runs %d  trials %d (%.1f/run)  edges/run %.0f  landmarks/run %.0f" % (runs, trials, trials / runs, c[8 + 16] / runs, c[8 + 17] / runs))
+tot = sum(c[8:8 + 12])
+for i, n in enumerate(names):
+    print("%-16s %8.1f us/run  %5.1f%%" % (n, c[8 + i] / runs / 100.0, 100.0 * c[8 + i] / max(tot, 1)))
+print("total %.1f us/run (100 MHz counter assumed)" % (tot / runs / 100.0))
