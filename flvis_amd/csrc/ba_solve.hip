@@ -7,20 +7,24 @@
 //   EdgeSE3ProjectXYZ + RobustKernelHuber               types/sba/types_six_dof_expmap.cpp:389-433, core/robust_kernel_impl.cpp:65-78
 // as ONE kernel launch per keyframe (12 + 8 LM iterations and the chi2 > 3 cull in between, all in-kernel).
 //
-// Mapping (BA_T threads per window, everything landmark-major and structure-of-arrays in HBM so that thread l touches
-// element l of every array -> coalesced):
-//   * observation table: omask[l] (bit per ring slot), uv[slot][l], edge index [slot][l] -- rebuilt when edges change;
-//   * linearisation: thread per landmark walks its <= W observations (fp64 residual, 2x3 / 2x6 Jacobians, Huber weight),
-//     keeps Hll / bl in registers and stores the 6x3 blocks B = w Jp^T Jl to Bd[18][pose][l]; pose blocks Hpp / bp are
-//     RE-computed from the observations by one wave per free pose (butterfly sums) instead of being staged per edge;
-//   * LM trial: (Hll + lambda I) = G G^T per landmark (3x3 Cholesky in registers), Z = B G^-T and c = G^-1 bl are formed
-//     on the way into LDS (double-buffered landmark chunks, one barrier per chunk, next chunk's global loads in flight
-//     during the current chunk's arithmetic).  The reduced system S = Hpp + lambda I - sum_l Z Z^T is accumulated as 6x6
-//     register tiles: thread = (pose pair, landmark slice), fixed slice partition + fixed butterfly order => bit-
-//     reproducible run to run, no atomics.  rhs = bp - sum_l Z c likewise;
+// Mapping (BA_T threads per window).  HBM scratch is structure-of-arrays so that thread l touches element l of every
+// landmark array and thread i element i of every item array -> coalesced:
+//   * observation table: omask[l] (bit per ring slot), uv[slot][l], edge index [slot][l]; the observations by FREE poses
+//     are numbered landmark-major as "items" (ibase[l] = exclusive prefix of their count) -- rebuilt when edges change;
+//   * linearisation: thread per landmark; a wave walks the ring slots together (fp64 residual, 2x3 / 2x6 Jacobians,
+//     Huber weight): Hll / bl stay in registers, the 6x3 blocks B = w Jp^T Jl go to the item arrays, and the 21 + 6
+//     entries of each pose's Hpp / bp are reduced over the wave with a scattered butterfly (fixed order);
+//   * LM trial: (Hll + lambda I) = G G^T per landmark (3x3 Cholesky in registers); Z = B G^-T and c = G^-1 bl are formed
+//     on the way into LDS.  Only OBSERVED (landmark, pose) blocks are staged (compact, item order), in double-buffered
+//     chunks of a few hundred items: one barrier per chunk, the next chunk's global loads are in flight during the
+//     current chunk's arithmetic.  The reduced system S = Hpp + lambda I - sum_l Z Z^T is accumulated as 6x6 register
+//     tiles: thread = (pose pair, landmark slice), fixed slice partition + fixed butterfly order => bit-reproducible
+//     run to run, no atomics.  rhs = bp - sum_l Z c likewise;
 //   * the reduced camera system (6P x 6P, P <= 15) lives in LDS and is factored by ONE wave: left-looking Cholesky over
-//     6x6 blocks (diagonal blocks factored + inverted in registers), block forward / backward substitution;
-//   * back-substitution + trial chi2: thread per landmark, the trial landmark stays in registers between the two.
+//     6x6 blocks (diagonal blocks factored + inverted in registers), block forward / backward substitution; the same wave
+//     then forms the trial poses;
+//   * back-substitution + trial chi2 in one pass: thread per landmark re-linearises its observations (cheaper than
+//     re-reading the B blocks), solves for its step and evaluates the robust error at the trial state.
 // The accepted / trial landmark sets are two SoA buffers whose roles swap on acceptance (no backup copies).
 // This is latency-bound fp64 on a tiny problem (S is at most 90x90): MFMA is deliberately not used.
 #include "dev_common.hpp"
@@ -34,6 +38,7 @@ constexpr int BA_NW = BA_T / 64;
 constexpr int BA_PMAX = BA_WMAX - 1;   // free poses
 constexpr int BA_NRMAX = 6 * BA_PMAX;  // 90
 constexpr int BA_LDS_BUDGET = 160 * 1024;
+constexpr int BA_MAXCHUNK = 160;
 
 // HBM scratch is addressed through explicit global-address-space pointers: inside the non-inlined phase functions the
 // compiler then emits global_load/global_store (vmcnt only) instead of flat_* -- flat loads also tick lgkmcnt and would
@@ -42,39 +47,47 @@ typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) int gint;
 typedef __attribute__((address_space(1))) unsigned guint;
 
-struct BAScratch {  // carved out of Pipe::ba_scratch (doubles) per stream; Lc = landmark stride (multiple of 64)
+struct BAScratch {  // carved out of Pipe::ba_scratch per stream; Lc / Ec = landmark / item strides (multiples of 64)
   gdouble* lmA;     // [3][Lc]  accepted landmark estimates
   gdouble* lmB;     // [3][Lc]  trial estimates (roles swap on acceptance)
   gdouble* Hll;     // [6][Lc]  xx xy xz yy yz zz
   gdouble* bl;      // [3][Lc]
-  gdouble* Bd;      // [18][P][Lc]  w Jp^T Jl (6x3, row-major) by free pose
   gdouble* uv;      // [W][2][Lc]
+  gdouble* BdI;     // [18][Ec]  w Jp^T Jl (6x3, row-major) per item
+  gdouble* HllI;    // [6][Ec]   the owning landmark's Hll, replicated per item (saves the staging a dependent load)
   gint* eid;        // [W][Lc]  edge index or -1
   guint* omask;     // [Lc]  bit slot: landmark has an alive edge to the pose in ring slot `slot`
+  guint* fmask;     // [Lc]  bit h: ... to FREE pose h (hessian index)
+  gint* ibase;      // [Lc + 64]  first item of landmark l (exclusive prefix of popc(fmask)), ibase[L] = item count
   gint* e_alive;    // [E]
-  int Lc;
+  int Lc, Ec;
 };
 
 size_t ba_scratch_doubles() {
-  size_t d = (size_t)BA_LMAX * (3 + 3 + 6 + 3) + (size_t)BA_LMAX * BA_PMAX * 18 + (size_t)BA_LMAX * BA_WMAX * 2;
-  size_t ints = (size_t)BA_LMAX * BA_WMAX + BA_LMAX + BA_EMAX + 64;
+  size_t d = (size_t)BA_LMAX * (3 + 3 + 6 + 3) + (size_t)BA_LMAX * BA_WMAX * 2 + (size_t)BA_EMAX * (18 + 6);
+  size_t ints = (size_t)BA_LMAX * BA_WMAX + (size_t)BA_LMAX * 3 + 64 + BA_EMAX + 64;
   return ((d + (ints + 1) / 2 + 64) + 1) & ~(size_t)1;  // even: 16-byte alignment of every stream's slice
 }
 
-FD BAScratch carve(double* base, int L, int W) {
+FD BAScratch carve(double* base, int L, int E, int W) {
   BAScratch s;
   const int Lc = ((L > 0 ? L : 1) + 63) & ~63;
+  const int Ec = ((E > 0 ? E : 1) + 63) & ~63;
   s.Lc = Lc;
+  s.Ec = Ec;
   gdouble* q = (gdouble*)base;
   s.lmA = q; q += (size_t)3 * Lc;
   s.lmB = q; q += (size_t)3 * Lc;
   s.Hll = q; q += (size_t)6 * Lc;
   s.bl = q; q += (size_t)3 * Lc;
-  s.Bd = q; q += (size_t)18 * (W - 1) * Lc;
   s.uv = q; q += (size_t)2 * W * Lc;
+  s.BdI = q; q += (size_t)18 * Ec;
+  s.HllI = q; q += (size_t)6 * Ec;
   gint* ii = (gint*)q;
   s.eid = ii; ii += (size_t)W * Lc;
   s.omask = (guint*)ii; ii += Lc;
+  s.fmask = (guint*)ii; ii += Lc;
+  s.ibase = ii; ii += Lc + 64;
   s.e_alive = ii;
   return s;
 }
@@ -87,18 +100,22 @@ struct BAShared {
   double Hpp[BA_PMAX][36];
   double b[BA_NRMAX];
   double x[BA_NRMAX];
-  double red[BA_NW];
+  double red[2][BA_NW];
+  double K[4];
+  BAScratch sc;
   int slot_of[BA_PMAX];
   int hidx_of[BA_WMAX];
   int slot_cnt[BA_WMAX];
-  int P, L, E, flag, cnt, W;
-  int NR, LD, off_linv, off_stage;       // reduced system geometry: Hs[NR][LD], Linv, chunk buffers (double offsets)
-  int CH, bufd, npairs, slices, rs;      // landmark chunking / role partition of the Schur phase
-  double K[4];
-  BAScratch sc;
+  int P, L, E, flag, cnt, W, nitems;
+  int NR, LD, off_linv, off_stage;  // reduced system geometry: Hs[NR][LD], Linv, chunk buffers (double offsets)
+  int CI, CL, bufd, nchunk;         // chunk capacities (items, landmarks), doubles per buffer, chunk count
+  int npairs, slices, rs;           // role partition of the Schur phase
+  int wscan[BA_NW];
+  int chunk_l0[BA_MAXCHUNK + 1];    // first landmark / first item of every chunk
+  int chunk_i0[BA_MAXCHUNK + 1];
   long long* prof;  // optional phase timers (FLVIS_BA_PROF builds)
   long long tlast;
-  // followed in dynamic LDS by: Hs[NR][NR+1], Linv[P][36], then the two landmark chunk buffers
+  // followed in dynamic LDS by: Hs[NR][NR+1], Linv[P][36], then the two chunk buffers
 };
 
 // all per-window working state lives in dynamic LDS; the phase functions re-derive it from this symbol so that the
@@ -169,12 +186,24 @@ FD void pose_to_rt(const double* pose7, double* rt) {
   rt[11] = T.t.z;
 }
 
+FD double rsqrt_fwd(double s);
+
+// 1/z: hardware estimate + two Newton steps (~1 ulp).  The projection Jacobians below use ONE reciprocal per observation
+// instead of g2o's fourteen divisions (fp64 division is a ~15-instruction sequence and dominated these phases).
+FD double rcp_nr(double z) {
+  double r = __builtin_amdgcn_rcp(z);
+#pragma unroll
+  for (int it = 0; it < 2; it++) r = fma(r, fma(-z, r, 1.0), r);
+  return r;
+}
+
 // EdgeSE3ProjectXYZ::computeError: squared reprojection error of landmark p in the camera rt = (R | t)
 FD double ba_err2(const double* rt, double px, double py, double pz, double u, double v, const double* K) {
   const double x = rt[0] * px + rt[1] * py + rt[2] * pz + rt[9];
   const double y = rt[3] * px + rt[4] * py + rt[5] * pz + rt[10];
   const double z = rt[6] * px + rt[7] * py + rt[8] * pz + rt[11];
-  const double e0 = u - (x / z * K[0] + K[2]), e1 = v - (y / z * K[1] + K[3]);
+  const double iz = rcp_nr(z);
+  const double e0 = u - (x * iz * K[0] + K[2]), e1 = v - (y * iz * K[1] + K[3]);
   return e0 * e0 + e1 * e1;
 }
 
@@ -184,30 +213,35 @@ FD void ba_linearize(const double* rt, double px, double py, double pz, double u
   const double x = rt[0] * px + rt[1] * py + rt[2] * pz + rt[9];
   const double y = rt[3] * px + rt[4] * py + rt[5] * pz + rt[10];
   const double z = rt[6] * px + rt[7] * py + rt[8] * pz + rt[11];
-  const double z2 = z * z, fx = K[0], fy = K[1];
-  er[0] = u - (x / z * fx + K[2]);
-  er[1] = v - (y / z * fy + K[3]);
-  const double tmp0[3] = {fx, 0, -x / z * fx}, tmp1[3] = {0, fy, -y / z * fy};
+  const double iz = rcp_nr(z), fx = K[0], fy = K[1];
+  const double xn = x * iz, yn = y * iz;
+  er[0] = u - (xn * fx + K[2]);
+  er[1] = v - (yn * fy + K[3]);
   if (Ji) {
+    const double ax = -iz * fx, ay = -iz * fy;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      Ji[0][c] = -1. / z * (tmp0[0] * rt[c] + tmp0[1] * rt[3 + c] + tmp0[2] * rt[6 + c]);
-      Ji[1][c] = -1. / z * (tmp1[0] * rt[c] + tmp1[1] * rt[3 + c] + tmp1[2] * rt[6 + c]);
+      Ji[0][c] = ax * (rt[c] - xn * rt[6 + c]);
+      Ji[1][c] = ay * (rt[3 + c] - yn * rt[6 + c]);
     }
   }
-  Jj[0][0] = x * y / z2 * fx;
-  Jj[0][1] = -(1 + (x * x / z2)) * fx;
-  Jj[0][2] = y / z * fx;
-  Jj[0][3] = -1. / z * fx;
+  Jj[0][0] = xn * yn * fx;
+  Jj[0][1] = -(1 + xn * xn) * fx;
+  Jj[0][2] = yn * fx;
+  Jj[0][3] = -iz * fx;
   Jj[0][4] = 0;
-  Jj[0][5] = x / z2 * fx;
-  Jj[1][0] = (1 + y * y / z2) * fy;
-  Jj[1][1] = -x * y / z2 * fy;
-  Jj[1][2] = -x / z * fy;
+  Jj[0][5] = xn * iz * fx;
+  Jj[1][0] = (1 + yn * yn) * fy;
+  Jj[1][1] = -xn * yn * fy;
+  Jj[1][2] = -xn * fy;
   Jj[1][3] = 0;
-  Jj[1][4] = -1. / z * fy;
-  Jj[1][5] = y / z2 * fy;
+  Jj[1][4] = -iz * fy;
+  Jj[1][5] = yn * iz * fy;
 }
+
+// RobustKernelHuber (delta = 1) on the squared error e: rho(e) and the weight rho'(e)
+FD double ba_huber_rho(double e) { return e <= 1.0 ? e : 2.0 * (e * rsqrt_fwd(e)) - 1.0; }
+FD double ba_huber_w(double e) { return e <= 1.0 ? 1.0 : rsqrt_fwd(e); }
 
 // 1/sqrt(s) for s > 0: hardware estimate + two Newton steps (~1 ulp).  Shorter dependent chain than sqrt + divide,
 // which is what the serial factorisations below are bound by.
@@ -222,6 +256,8 @@ FD double rsqrt_nr(double s) {
 }
 
 // lower Cholesky factor of the 3x3 (H + lambda I), H = xx xy xz yy yz zz; returns the factor with INVERTED diagonal
+FD double rsqrt_fwd(double s) { return rsqrt_nr(s); }
+
 struct Chol3 {
   double i00, g10, g20, i11, g21, i22;
 };
@@ -262,10 +298,13 @@ FD double wave_reduce_scatter32(const double (&v)[32], int& idx) {
   return a1[0] + __shfl_xor(a1[0], 1, 64);
 }
 
-// rebuilds the observation table from the alive edges and the free-pose numbering (hessian order = slot order)
-__device__ __noinline__ void ba_build_structure(BAShared& sh, const WindowDev& w, const BAScratch& sc, int W) {
-  const int t = threadIdx.x;
-  const int E = w.n_edge, L = w.n_lm, Lc = sc.Lc;
+// rebuilds the observation table from the alive edges: free-pose numbering (hessian order = slot order), per-landmark
+// masks, the item numbering and the chunk table of the Schur phase
+__device__ __noinline__ void ba_build_structure(const WindowDev& w) {
+  BAShared& sh = ba_sh();
+  const BAScratch sc = sh.sc;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int E = w.n_edge, L = w.n_lm, Lc = sc.Lc, W = sh.W;
   if (t == 0) {
     sh.E = E;
     sh.L = L;
@@ -300,13 +339,92 @@ __device__ __noinline__ void ba_build_structure(BAShared& sh, const WindowDev& w
       }
     }
     sh.P = P;
+    const int NR = 6 * P, LD = NR + 1;
+    sh.NR = NR;
+    sh.LD = LD;
+    sh.off_linv = NR * LD;
+    sh.off_stage = NR * LD + P * 36;
+    // chunk buffers: per item 18 doubles (Z), per landmark 3 doubles (c) + mask word + local item base
+    const int per_buf = (((int)((BA_LDS_BUDGET - BA_SH_BYTES) / 8) - sh.off_stage) / 2) & ~1;
+    int CL = 256;
+    while (CL > 32 && CL * 4 > per_buf / 4) CL >>= 1;
+    int CI = (per_buf - CL * 4) / 18;
+    if (CI > BA_T) CI = BA_T;  // one staged item per thread
+    sh.CL = CL;
+    sh.CI = CI;
+    sh.bufd = per_buf;
+    const int npairs = P * (P + 1) / 2;
+    int slices = 64;
+    while (slices > 1 && slices * npairs > BA_T) slices >>= 1;
+    int rs = slices;  // <= slices keeps the rhs groups aligned to their butterfly width
+    while (rs > 1 && rs * P > BA_T - slices * npairs) rs >>= 1;
+    sh.npairs = npairs;
+    sh.slices = slices;
+    sh.rs = rs;
   }
+  __syncthreads();
   for (int l = t; l < Lc; l += BA_T) {
-    unsigned m = 0;
+    unsigned m = 0, fm = 0;
     if (l < L)
       for (int slot = 0; slot < W; slot++)
-        if (sc.eid[slot * Lc + l] >= 0) m |= 1u << slot;
+        if (sc.eid[slot * Lc + l] >= 0) {
+          m |= 1u << slot;
+          const int hi = sh.hidx_of[slot];
+          if (hi >= 0) fm |= 1u << hi;
+        }
     sc.omask[l] = m;
+    sc.fmask[l] = fm;
+  }
+  __syncthreads();
+  // item numbering: exclusive scan of popc(fmask) over the landmarks (thread = contiguous run of landmarks)
+  int* lbase = reinterpret_cast<int*>(ba_dyn() + sh.off_stage);  // LDS copy of ibase for the chunk search below
+  {
+    const int per = (L + BA_T - 1) / BA_T;
+    const int la = t * per, lb = (la + per < L) ? la + per : L;
+    int c = 0;
+    for (int l = la; l < lb; l++) c += __popc(sc.fmask[l]);
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) sh.wscan[wv] = inc;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; k++) off += sh.wscan[k];
+    int run = off + inc - c;
+    for (int l = la; l < lb; l++) {
+      sc.ibase[l] = run;
+      lbase[l] = run;
+      run += __popc(sc.fmask[l]);
+    }
+    if (t == BA_T - 1) {
+      sc.ibase[L] = run;  // (the last thread's run ends at L or is empty: run == total either way)
+      lbase[L] = run;
+      sh.nitems = run;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {  // greedy chunking: as many landmarks as fit both capacities
+    const int CI = sh.CI, CL = sh.CL;
+    int c = 0, l0 = 0;
+    while (l0 < L && c < BA_MAXCHUNK) {
+      int lo = l0 + 1, hi = (l0 + CL < L) ? l0 + CL : L;  // invariant: [l0, lo) always fits (one landmark has <= P items)
+      const int i0 = lbase[l0];
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (lbase[mid] - i0 <= CI) lo = mid;
+        else hi = mid - 1;
+      }
+      sh.chunk_l0[c] = l0;
+      sh.chunk_i0[c] = i0;
+      c++;
+      l0 = lo;
+    }
+    sh.chunk_l0[c] = L;
+    sh.chunk_i0[c] = lbase[L];
+    sh.nchunk = c;
   }
   __syncthreads();
 }
@@ -472,44 +590,56 @@ __device__ __noinline__ bool ba_chol_solve() {
 // ---- phases of one LM iteration.  Each is a separate (non-inlined) function so that its register allocation is its own:
 // the phases share state only through LDS (BAShared) and the HBM scratch.
 
-// computeActiveErrors + buildSystem in one pass over the observations (thread per landmark, waves walk the ring slots
-// together): Hll / bl / the B blocks per landmark, and per free pose the 21 + 6 entries of Hpp / bp, reduced over the
-// wave with a scattered butterfly and accumulated per wave in LDS (fixed order -> reproducible).  Returns this thread's
-// share of the robust chi2.  ba_phase_finish_poses() folds the per-wave partials afterwards.
+// computeActiveErrors + buildSystem in one pass over the observations (thread per landmark, a wave walks the ring slots
+// together): Hll / bl per landmark, the B blocks per item, and per free pose the 21 + 6 entries of Hpp / bp, reduced over
+// the wave with a scattered butterfly and accumulated per wave in LDS (fixed order -> reproducible).  Returns this
+// thread's share of the robust chi2.  ba_phase_finish_poses() folds the per-wave partials afterwards.
 __device__ __noinline__ double ba_phase_linearize() {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, L = sh.L, Lc = sc.Lc, W = sh.W, P = sh.P;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, L = sh.L, Lc = sc.Lc, Ec = sc.Ec, W = sh.W, P = sh.P;
   const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
   double* wacc = ba_dyn() + sh.off_stage + (size_t)wv * P * 27;  // [P][27] of this wave (chunk buffers are idle here)
   for (int i = lane; i < P * 27; i += 64) wacc[i] = 0.0;
   wave_lds_fence();
   double chi = 0;
-  const size_t ks = (size_t)P * Lc;
   for (int l0 = wv * 64; l0 < L; l0 += BA_T) {
     const int l = l0 + lane;
     const unsigned m = l < L ? sc.omask[l] : 0u;
     double px = 0, py = 0, pz = 1;
+    unsigned fm = 0;
+    int ib = 0;
     if (m) {
       px = sc.lmA[l];
       py = sc.lmA[Lc + l];
       pz = sc.lmA[2 * Lc + l];
+      fm = sc.fmask[l];
+      ib = sc.ibase[l];
     }
     double h[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+    // the loop body is deliberately NOT unrolled (instruction-cache footprint); the next slot's observation is loaded
+    // while the current one is processed
+    double un = (m & 1u) ? sc.uv[l] : 0.0, vn = (m & 1u) ? sc.uv[(size_t)Lc + l] : 0.0;
+#pragma unroll 1
     for (int slot = 0; slot < W; slot++) {
+      const double u = un, v = vn;
       const bool has = (m >> slot) & 1u;
+      if (slot + 1 < W) {
+        const bool hn = (m >> (slot + 1)) & 1u;
+        un = hn ? sc.uv[(size_t)(2 * slot + 2) * Lc + l] : 0.0;
+        vn = hn ? sc.uv[(size_t)(2 * slot + 3) * Lc + l] : 0.0;
+      }
       if (__ballot(has) == 0ull) continue;
       const int hi = sh.hidx_of[slot];
       double pv[32];
 #pragma unroll
       for (int k = 0; k < 32; k++) pv[k] = 0;
       if (has) {
-        const double u = sc.uv[(size_t)(2 * slot) * Lc + l], v = sc.uv[(size_t)(2 * slot + 1) * Lc + l];
         double er[2], Ji[2][3], Jj[2][6];
         ba_linearize(sh.RT[slot], px, py, pz, u, v, K, er, Ji, Jj);
         const double e2 = er[0] * er[0] + er[1] * er[1];
-        chi += huber_rho(e2);
-        const double wgt = huber_w(e2);
+        chi += ba_huber_rho(e2);
+        const double wgt = ba_huber_w(e2);
         const double o0 = -er[0] * wgt, o1 = -er[1] * wgt;
         int q = 0;
 #pragma unroll
@@ -519,7 +649,7 @@ __device__ __noinline__ double ba_phase_linearize() {
           for (int c = r; c < 3; c++) h[q++] += (Ji[0][r] * wgt) * Ji[0][c] + (Ji[1][r] * wgt) * Ji[1][c];
         }
         if (hi >= 0) {
-          gdouble* dst = sc.Bd + (size_t)hi * Lc + l;
+          gdouble* dst = sc.BdI + ib + __popc(fm & ((1u << hi) - 1u));
           q = 0;
 #pragma unroll
           for (int r = 0; r < 6; r++) {
@@ -527,7 +657,8 @@ __device__ __noinline__ double ba_phase_linearize() {
 #pragma unroll
             for (int c = r; c < 6; c++) pv[q++] = (Jj[0][r] * wgt) * Jj[0][c] + (Jj[1][r] * wgt) * Jj[1][c];
 #pragma unroll
-            for (int c = 0; c < 3; c++) dst[(3 * r + c) * ks] = (Jj[0][r] * wgt) * Ji[0][c] + (Jj[1][r] * wgt) * Ji[1][c];
+            for (int c = 0; c < 3; c++)
+              dst[(size_t)(3 * r + c) * Ec] = (Jj[0][r] * wgt) * Ji[0][c] + (Jj[1][r] * wgt) * Ji[1][c];
           }
         }
       }
@@ -543,6 +674,11 @@ __device__ __noinline__ double ba_phase_linearize() {
       for (int j = 0; j < 6; j++) sc.Hll[(size_t)j * Lc + l] = h[j];
 #pragma unroll
       for (int j = 0; j < 3; j++) sc.bl[(size_t)j * Lc + l] = bb[j];
+      const int ni = __popc(fm);
+      for (int r = 0; r < ni; r++) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) sc.HllI[(size_t)j * Ec + ib + r] = h[j];
+      }
     }
   }
   return chi;
@@ -587,12 +723,13 @@ __device__ __noinline__ double ba_phase_max_diag() {
 }
 
 // reduced camera system S = Hpp + lambda I - sum_l Z Z^T (lower triangle into Hs) and rhs = bp - sum_l Z c (into sh.x),
-// streaming the landmarks through double-buffered LDS chunks
+// streaming the observed blocks through double-buffered LDS chunks
 __device__ __noinline__ void ba_phase_schur(double lambda) {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
-  const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, P = sh.P;
-  const int CH = sh.CH, bufd = sh.bufd, slices = sh.slices, rs = sh.rs, npairs = sh.npairs, LD = sh.LD;
+  const int t = threadIdx.x, Lc = sc.Lc, Ec = sc.Ec, P = sh.P;
+  const int CI = sh.CI, CL = sh.CL, bufd = sh.bufd, slices = sh.slices, rs = sh.rs, npairs = sh.npairs, LD = sh.LD;
+  const int nchunk = sh.nchunk;
   double* Hs = ba_dyn();
   double* stage = Hs + sh.off_stage;
   // this thread's role in the accumulation
@@ -617,49 +754,41 @@ __device__ __noinline__ void ba_phase_schur(double lambda) {
   for (int k = 0; k < 36; k++) acc[k] = 0;
 #pragma unroll
   for (int k = 0; k < 6; k++) accr[k] = 0;
-  const int nchunk = (L + CH - 1) / CH;
-  // staging item of this thread: (h, ll); h == P is the landmark's c vector + mask word
-  const int st_h = t / CH, st_ll = t - st_h * CH;
-  const bool st_on = t < CH * (P + 1);
-  const int st_slot = (st_on && st_h < P) ? sh.slot_of[st_h] : 0;
-  const size_t ks = (size_t)P * Lc;
-  double rB[18], rH[6], rb[3];
-  int rkind = 0;
+  // staging registers: one item (B block + its landmark's Hll) and one landmark entry (Hll, bl, mask, item base)
+  double rB[18], rH[6], rH2[6], rb[3];
+  bool it_on = false, lm_on = false;
   unsigned rmask = 0;
+  int rbase = 0;
   auto prefetch = [&](int c) {
-    rkind = 0;
-    rmask = 0;
-    if (!st_on) return;
-    const int l = c * CH + st_ll;
-    if (l >= L) return;
-    const unsigned m = sc.omask[l];
-    if (st_h < P) {
-      if (!((m >> st_slot) & 1u)) return;
-      rkind = 1;
-      const gdouble* src = sc.Bd + (size_t)st_h * Lc + l;
+    const int l0 = sh.chunk_l0[c], nl = sh.chunk_l0[c + 1] - l0;
+    const int i0 = sh.chunk_i0[c], ni = sh.chunk_i0[c + 1] - i0;
+    it_on = t < ni;
+    lm_on = t < nl;
+    if (it_on) {
+      const gdouble* src = sc.BdI + i0 + t;
 #pragma unroll
-      for (int k = 0; k < 18; k++) rB[k] = src[k * ks];
-    } else {
-      if (!m) return;
-      rkind = 2;
-      for (int h = 0; h < P; h++) rmask |= ((m >> sh.slot_of[h]) & 1u) << h;
+      for (int k = 0; k < 18; k++) rB[k] = src[(size_t)k * Ec];
+      const gdouble* hs = sc.HllI + i0 + t;
+#pragma unroll
+      for (int k = 0; k < 6; k++) rH[k] = hs[(size_t)k * Ec];
+    }
+    if (lm_on) {
+      const int l = l0 + t;
+      rmask = sc.fmask[l];
+      rbase = sc.ibase[l] - i0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) rH2[k] = sc.Hll[(size_t)k * Lc + l];
 #pragma unroll
       for (int k = 0; k < 3; k++) rb[k] = sc.bl[(size_t)k * Lc + l];
     }
-#pragma unroll
-    for (int k = 0; k < 6; k++) rH[k] = sc.Hll[(size_t)k * Lc + l];
   };
   auto commit = [&](int buf) {
-    if (!st_on) return;
     double* zb = stage + (size_t)buf * bufd;
-    double* cb = zb + (size_t)CH * P * 18;
-    unsigned* mb = reinterpret_cast<unsigned*>(cb + (size_t)CH * 3);
-    if (rkind == 0) {  // blocks of unobserved (landmark, pose) pairs are never read: the mask word gates them
-      if (st_h == P) mb[st_ll] = 0u;
-      return;
-    }
-    const Chol3 g = chol3(rH, lambda);
-    if (rkind == 1) {
+    double* cb = zb + (size_t)CI * 18;
+    unsigned* mb = reinterpret_cast<unsigned*>(cb + (size_t)CL * 3);
+    int* lb = reinterpret_cast<int*>(mb + CL);
+    if (it_on) {
+      const Chol3 g = chol3(rH, lambda);
       double zz[18];
 #pragma unroll
       for (int r = 0; r < 6; r++) {  // Z G^T = B, row by row
@@ -667,44 +796,55 @@ __device__ __noinline__ void ba_phase_schur(double lambda) {
         zz[3 * r + 1] = (rB[3 * r + 1] - zz[3 * r] * g.g10) * g.i11;
         zz[3 * r + 2] = (rB[3 * r + 2] - zz[3 * r] * g.g20 - zz[3 * r + 1] * g.g21) * g.i22;
       }
-      double2* z = reinterpret_cast<double2*>(zb) + (size_t)st_h * 9 * CH + st_ll;  // element pairs: 16-byte LDS accesses
+      double2* z = reinterpret_cast<double2*>(zb) + t;  // element pairs [9][CI]: 16-byte LDS accesses
 #pragma unroll
-      for (int kp = 0; kp < 9; kp++) z[kp * CH] = double2{zz[2 * kp], zz[2 * kp + 1]};
-    } else {  // c = G^-1 bl
-      const double c0 = rb[0] * g.i00;
-      const double c1 = (rb[1] - g.g10 * c0) * g.i11;
-      const double c2 = (rb[2] - g.g20 * c0 - g.g21 * c1) * g.i22;
-      cb[st_ll] = c0;
-      cb[CH + st_ll] = c1;
-      cb[2 * CH + st_ll] = c2;
-      mb[st_ll] = rmask;
+      for (int kp = 0; kp < 9; kp++) z[kp * CI] = double2{zz[2 * kp], zz[2 * kp + 1]};
+    }
+    if (lm_on) {
+      mb[t] = rmask;
+      lb[t] = rbase;
+      if (rmask) {  // c = G^-1 bl
+        const Chol3 g = chol3(rH2, lambda);
+        const double c0 = rb[0] * g.i00;
+        const double c1 = (rb[1] - g.g10 * c0) * g.i11;
+        const double c2 = (rb[2] - g.g20 * c0 - g.g21 * c1) * g.i22;
+        cb[t] = c0;
+        cb[CL + t] = c1;
+        cb[2 * CL + t] = c2;
+      }
     }
   };
-  prefetch(0);
+  if (nchunk > 0) prefetch(0);
   for (int c = 0; c < nchunk; c++) {
     const int buf = c & 1;
     commit(buf);
     __syncthreads();
     if (c + 1 < nchunk) prefetch(c + 1);
+    const int nl = sh.chunk_l0[c + 1] - sh.chunk_l0[c];
     const double* zb = stage + (size_t)buf * bufd;
-    const double* cb = zb + (size_t)CH * P * 18;
-    const unsigned* mb = reinterpret_cast<const unsigned*>(cb + (size_t)CH * 3);
+    const double* cb = zb + (size_t)CI * 18;
+    const unsigned* mb = reinterpret_cast<const unsigned*>(cb + (size_t)CL * 3);
+    const int* lb = reinterpret_cast<const int*>(mb + CL);
+    const double2* z2 = reinterpret_cast<const double2*>(zb);
     if (my_i1 >= 0) {
       const unsigned need = (1u << my_i1) | (1u << my_i2);
-      const double2* zi = reinterpret_cast<const double2*>(zb) + (size_t)my_i1 * 9 * CH;
-      const double2* zj = reinterpret_cast<const double2*>(zb) + (size_t)my_i2 * 9 * CH;
-      for (int ll = my_sl; ll < CH; ll += slices) {
-        if ((mb[ll] & need) != need) continue;
+      const unsigned lt1 = (1u << my_i1) - 1u, lt2 = (1u << my_i2) - 1u;
+      for (int ll = my_sl; ll < nl; ll += slices) {
+        const unsigned m = mb[ll];
+        if ((m & need) != need) continue;
+        const int base = lb[ll];
+        const double2* zi = z2 + base + __popc(m & lt1);
+        const double2* zj = z2 + base + __popc(m & lt2);
         double a[18];
 #pragma unroll
         for (int kp = 0; kp < 9; kp++) {
-          const double2 v2 = zi[kp * CH + ll];
+          const double2 v2 = zi[kp * CI];
           a[2 * kp] = v2.x;
           a[2 * kp + 1] = v2.y;
         }
 #pragma unroll
         for (int cp = 0; cp < 3; cp++) {  // two columns of the tile (6 elements of Z_i2) per step
-          const double2 q0 = zj[(3 * cp) * CH + ll], q1 = zj[(3 * cp + 1) * CH + ll], q2 = zj[(3 * cp + 2) * CH + ll];
+          const double2 q0 = zj[(3 * cp) * CI], q1 = zj[(3 * cp + 1) * CI], q2 = zj[(3 * cp + 2) * CI];
           const double bq[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
 #pragma unroll
           for (int h2 = 0; h2 < 2; h2++) {
@@ -716,14 +856,16 @@ __device__ __noinline__ void ba_phase_schur(double lambda) {
         }
       }
     } else if (my_rp >= 0) {
-      const double2* zi = reinterpret_cast<const double2*>(zb) + (size_t)my_rp * 9 * CH;
-      for (int ll = my_rsl; ll < CH; ll += rs) {
-        if (!((mb[ll] >> my_rp) & 1u)) continue;
-        const double c0 = cb[ll], c1 = cb[CH + ll], c2 = cb[2 * CH + ll];
+      const unsigned ltp = (1u << my_rp) - 1u;
+      for (int ll = my_rsl; ll < nl; ll += rs) {
+        const unsigned m = mb[ll];
+        if (!((m >> my_rp) & 1u)) continue;
+        const double2* zi = z2 + lb[ll] + __popc(m & ltp);
+        const double c0 = cb[ll], c1 = cb[CL + ll], c2 = cb[2 * CL + ll];
         double a[18];
 #pragma unroll
         for (int kp = 0; kp < 9; kp++) {
-          const double2 v2 = zi[kp * CH + ll];
+          const double2 v2 = zi[kp * CI];
           a[2 * kp] = v2.x;
           a[2 * kp + 1] = v2.y;
         }
@@ -757,44 +899,71 @@ __device__ __noinline__ void ba_phase_schur(double lambda) {
   }
 }
 
-// trial update x (+) : poses by threads < W, landmarks by back-substitution (thread per landmark) into the trial buffer;
-// returns this thread's share of the gain-ratio denominator
-__device__ __noinline__ double ba_phase_update(double lambda, int ok2) {
+// wave 0: factor + solve the reduced system, then form the trial poses x (+) pose (unchanged poses if the factorisation
+// failed) and their (R | t) tables
+__device__ __noinline__ void ba_phase_solve_poses() {
+  BAShared& sh = ba_sh();
+  const int lane = threadIdx.x & 63;
+  const bool okc = ba_chol_solve();
+  wave_lds_fence();
+  if (lane == 0) sh.flag = okc ? 1 : 0;
+  if (lane < sh.W) {
+#pragma unroll
+    for (int j = 0; j < 7; j++) sh.poseT[lane][j] = sh.pose[lane][j];
+    const int hi = sh.hidx_of[lane];
+    if (okc && hi >= 0) {
+      SE3d T = load_pose7(sh.pose[lane]);
+      T = g2o_mul(g2o_exp(sh.x + 6 * hi), T);
+      store_pose7(sh.poseT[lane], T);
+    }
+    pose_to_rt(sh.poseT[lane], sh.RTt[lane]);
+  }
+}
+
+// landmark back-substitution and the robust chi2 of the trial state in one pass (thread per landmark): the observations
+// are re-linearised at the accepted state (B^T dx_pose = w Jl^T (Jp dx_pose) needs no stored block), the step is solved
+// with the landmark's 3x3 factor, the trial landmark goes to lmB and its reprojection errors against the trial poses
+// are summed.  out[0] = share of the gain-ratio denominator, out[1] = share of the trial chi2.
+__device__ __noinline__ void ba_phase_update_chi2(double lambda, int ok2, double* out) {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
-  const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, P = sh.P, W = sh.W;
-  if (t < W) {
-#pragma unroll
-    for (int j = 0; j < 7; j++) sh.poseT[t][j] = sh.pose[t][j];
-    const int hi = sh.hidx_of[t];
-    if (ok2 && hi >= 0) {
-      SE3d T = load_pose7(sh.pose[t]);
-      T = g2o_mul(g2o_exp(sh.x + 6 * hi), T);
-      store_pose7(sh.poseT[t], T);
-    }
-    pose_to_rt(sh.poseT[t], sh.RTt[t]);
-  }
-  double scale_part = 0;
-  const size_t ks = (size_t)P * Lc;
+  const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, W = sh.W;
+  const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
+  double scale_part = 0, chit = 0;
   for (int l = t; l < L; l += BA_T) {
     const unsigned m = sc.omask[l];
     double p[3] = {sc.lmA[l], sc.lmA[Lc + l], sc.lmA[2 * Lc + l]};
     if (m && ok2) {
       const double bl[3] = {sc.bl[l], sc.bl[Lc + l], sc.bl[2 * Lc + l]};
-      double v[3] = {bl[0], bl[1], bl[2]};
       double H[6];
 #pragma unroll
       for (int k = 0; k < 6; k++) H[k] = sc.Hll[(size_t)k * Lc + l];
-      for (int h = 0; h < P; h++) {
-        if (!((m >> sh.slot_of[h]) & 1u)) continue;
-        const gdouble* src = sc.Bd + (size_t)h * Lc + l;
-        const double* xp = sh.x + 6 * h;
+      double v[3] = {bl[0], bl[1], bl[2]};
+      double un = (m & 1u) ? sc.uv[l] : 0.0, vn = (m & 1u) ? sc.uv[(size_t)Lc + l] : 0.0;
+#pragma unroll 1
+      for (int slot = 0; slot < W; slot++) {  // (not unrolled: instruction-cache footprint; next observation in flight)
+        const double uu = un, vv = vn;
+        if (slot + 1 < W) {
+          const bool hn = (m >> (slot + 1)) & 1u;
+          un = hn ? sc.uv[(size_t)(2 * slot + 2) * Lc + l] : 0.0;
+          vn = hn ? sc.uv[(size_t)(2 * slot + 3) * Lc + l] : 0.0;
+        }
+        const int hi = sh.hidx_of[slot];
+        if (!((m >> slot) & 1u) || hi < 0) continue;
+        double er[2], Ji[2][3], Jj[2][6];
+        ba_linearize(sh.RT[slot], p[0], p[1], p[2], uu, vv, K, er, Ji, Jj);
+        const double wgt = ba_huber_w(er[0] * er[0] + er[1] * er[1]);
+        const double* xp = sh.x + 6 * hi;
+        double j0 = 0, j1 = 0;
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-          const double xr = xp[r];
-#pragma unroll
-          for (int c = 0; c < 3; c++) v[c] -= src[(3 * r + c) * ks] * xr;
+          j0 += Jj[0][r] * xp[r];
+          j1 += Jj[1][r] * xp[r];
         }
+        j0 *= wgt;
+        j1 *= wgt;
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] -= Ji[0][c] * j0 + Ji[1][c] * j1;
       }
       const Chol3 g = chol3(H, lambda);
       const double y0 = v[0] * g.i00;
@@ -811,30 +980,47 @@ __device__ __noinline__ double ba_phase_update(double lambda, int ok2) {
     sc.lmB[l] = p[0];
     sc.lmB[Lc + l] = p[1];
     sc.lmB[2 * Lc + l] = p[2];
-  }
-  if (ok2)
-    for (int i = t; i < 6 * P; i += BA_T) scale_part += sh.x[i] * (lambda * sh.x[i] + sh.b[i]);
-  return scale_part;
-}
-
-// robust chi2 of the trial state (lmB, RTt); the same thread owns a landmark here and in ba_phase_update
-__device__ __noinline__ double ba_phase_trial_chi2() {
-  BAShared& sh = ba_sh();
-  const BAScratch sc = sh.sc;
-  const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, W = sh.W;
-  const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
-  double chit = 0;
-  for (int l = t; l < L; l += BA_T) {
-    const unsigned m = sc.omask[l];
-    if (!m) continue;
-    const double px = sc.lmB[l], py = sc.lmB[Lc + l], pz = sc.lmB[2 * Lc + l];
-    for (int slot = 0; slot < W; slot++) {
-      if (!((m >> slot) & 1u)) continue;
-      const double u = sc.uv[(size_t)(2 * slot) * Lc + l], v = sc.uv[(size_t)(2 * slot + 1) * Lc + l];
-      chit += huber_rho(ba_err2(sh.RTt[slot], px, py, pz, u, v, K));
+    if (m) {
+      double un = (m & 1u) ? sc.uv[l] : 0.0, vn = (m & 1u) ? sc.uv[(size_t)Lc + l] : 0.0;
+#pragma unroll 1
+      for (int slot = 0; slot < W; slot++) {
+        const double uu = un, vv = vn;
+        if (slot + 1 < W) {
+          const bool hn = (m >> (slot + 1)) & 1u;
+          un = hn ? sc.uv[(size_t)(2 * slot + 2) * Lc + l] : 0.0;
+          vn = hn ? sc.uv[(size_t)(2 * slot + 3) * Lc + l] : 0.0;
+        }
+        if (!((m >> slot) & 1u)) continue;
+        chit += ba_huber_rho(ba_err2(sh.RTt[slot], p[0], p[1], p[2], uu, vv, K));
+      }
     }
   }
-  return chit;
+  if (ok2)
+    for (int i = t; i < 6 * sh.P; i += BA_T) scale_part += sh.x[i] * (lambda * sh.x[i] + sh.b[i]);
+  out[0] = scale_part;
+  out[1] = chit;
+}
+
+// two block sums with one set of barriers
+__device__ inline void block_sum2(double& a, double& b, double (*red)[BA_NW]) {
+  a = wave_sum_f64(a);
+  b = wave_sum_f64(b);
+  const int t = threadIdx.x;
+  __syncthreads();
+  if ((t & 63) == 0) {
+    red[0][t >> 6] = a;
+    red[1][t >> 6] = b;
+  }
+  __syncthreads();
+  double ra = 0, rb = 0;
+#pragma unroll
+  for (int i = 0; i < BA_NW; i++) {
+    ra += red[0][i];
+    rb += red[1][i];
+  }
+  __syncthreads();
+  a = ra;
+  b = rb;
 }
 
 // one g2o optimize(iterations) call
@@ -842,46 +1028,20 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
   BAShared& sh = ba_sh();
   const int t = threadIdx.x;
   BAPROF(0);
-  ba_build_structure(sh, w, sh.sc, sh.W);
+  ba_build_structure(w);
   BAPROF(1);
   if (sh.cnt == 0) return;
-  if (t == 0) {
-    const int P = sh.P;
-    const int NR = 6 * P, LD = NR + 1;
-    sh.NR = NR;
-    sh.LD = LD;
-    sh.off_linv = NR * LD;
-    sh.off_stage = NR * LD + P * 36;
-    const int stage_doubles = (int)((BA_LDS_BUDGET - BA_SH_BYTES) / 8) - sh.off_stage;
-    // landmark chunk: per landmark P*18 (Z) + 3 (c) doubles + one mask word, two buffers
-    int CH = (stage_doubles / 2 - 8) / (P * 18 + 4);
-    if (CH > 128) CH = 128;
-    CH &= ~15;
-    if (CH < 16) CH = 16;
-    if (CH * (P + 1) > BA_T) CH = (BA_T / (P + 1)) & ~15;
-    sh.CH = CH;
-    sh.bufd = CH * (P * 18 + 4);
-    const int npairs = P * (P + 1) / 2;
-    int slices = 64;
-    while (slices > 1 && slices * npairs > BA_T) slices >>= 1;
-    int rs = slices;  // <= slices keeps the rhs groups aligned to their butterfly width
-    while (rs > 1 && rs * P > BA_T - slices * npairs) rs >>= 1;
-    sh.npairs = npairs;
-    sh.slices = slices;
-    sh.rs = rs;
-  }
-  __syncthreads();
   double lambda = -1, ni = 2;
   for (int iteration = 0; iteration < iterations; iteration++) {
     BAPROF(0);
     const double chi = ba_phase_linearize();
     BAPROF(3);
-    double currentChi = block_sum(chi, sh.red);  // (its barriers also publish the per-wave partials / Hll / bl / Bd)
+    double currentChi = block_sum(chi, sh.red[0]);  // (its barriers also publish the per-wave partials / Hll / bl / B)
     ba_phase_finish_poses();
     __syncthreads();
     BAPROF(4);
     if (iteration == 0) {
-      lambda = 1e-5 * block_max(ba_phase_max_diag(), sh.red);
+      lambda = 1e-5 * block_max(ba_phase_max_diag(), sh.red[0]);
       ni = 2;
     }
     double rho = 0;
@@ -892,17 +1052,16 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
       ba_phase_schur(lambda);
       __syncthreads();
       BAPROF(7);
-      if (t < 64) {
-        const bool okc = ba_chol_solve();
-        if (t == 0) sh.flag = okc ? 1 : 0;
-      }
+      if (t < 64) ba_phase_solve_poses();
       __syncthreads();
       BAPROF(8);
       const int ok2 = sh.flag;
-      const double scale = block_sum(ba_phase_update(lambda, ok2), sh.red) + 1e-3;  // (barriers publish poseT / RTt)
+      double parts[2];
+      ba_phase_update_chi2(lambda, ok2, parts);
+      double scale = parts[0], tempChi = parts[1];
+      block_sum2(scale, tempChi, sh.red);
+      scale += 1e-3;
       BAPROF(9);
-      double tempChi = block_sum(ba_phase_trial_chi2(), sh.red);
-      BAPROF(10);
 #ifdef FLVIS_BA_PROF
       if (t == 0 && sh.prof) atomicAdd((unsigned long long*)&sh.prof[14], 1ull);
 #endif
@@ -951,7 +1110,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p) {
   const int L = w.n_lm, E = w.n_edge;
   const int t = threadIdx.x, lane = t & 63;
   if (t == 0) {
-    sh.sc = carve(p.ba_scratch + (size_t)s * p.ba_scratch_stride, L, W);
+    sh.sc = carve(p.ba_scratch + (size_t)s * p.ba_scratch_stride, L, E, W);
     sh.W = W;
     sh.K[0] = p.cam.fx;
     sh.K[1] = p.cam.fy;

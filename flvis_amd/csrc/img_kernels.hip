@@ -313,9 +313,11 @@ constexpr int SORT_T = 1024;
 constexpr int SORT_LDS = 4096;
 
 __global__ __launch_bounds__(SORT_T) void k_sort_keys(unsigned long long* __restrict__ keys, int* __restrict__ nkeys,
-                                                      int cap, const int* __restrict__ active) {
+                                                      int cap, const int* __restrict__ active,
+                                                      unsigned* __restrict__ maxenc) {
   const int s = blockIdx.x;
   if (active && !active[s]) return;
+  if (threadIdx.x == 0) maxenc[s] = 0;  // both eig passes are done with it: hand it back zeroed
   __shared__ unsigned long long sk[SORT_LDS];
   unsigned long long* K = keys + (size_t)s * cap;
   int n = nkeys[s];
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(SORT_T) void k_sort_keys(unsigned long long* __rest
 // grid rejection exactly: a candidate is dropped iff an already accepted corner lies at squared distance < minDist^2.
 // Accepted corners are kept in an LDS bitmap (w*h bits <= 46 KB); corners of one batch are resolved lane by lane.
 __global__ __launch_bounds__(64) void k_select_mindist(const unsigned long long* __restrict__ keys,
-                                                       const int* __restrict__ nkeys, int cap, int w, int h,
+                                                       int* __restrict__ nkeys, int cap, int w, int h,
                                                        const int* __restrict__ max_corners_s, int max_corners,
                                                        double min_distance, float* __restrict__ out_xy,
                                                        int* __restrict__ out_n, int out_cap,
@@ -469,7 +471,10 @@ __global__ __launch_bounds__(64) void k_select_mindist(const unsigned long long*
   }
   if (maxc > 0 && accepted > maxc) accepted = maxc;
   if (accepted > out_cap) accepted = out_cap;
-  if (lane == 0) out_n[s] = accepted;
+  if (lane == 0) {
+    out_n[s] = accepted;
+    nkeys[s] = 0;  // last consumer: hand the candidate counter back zeroed
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ FeatureDEM
@@ -657,20 +662,29 @@ void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, siz
                      sstride, dst, dpitch, dstride, active);
 }
 
+// stage_events (optional): 8 events = (begin, end) for eig_max, eig_nms, sort_keys, select_mindist.
+// reset_counters: zero maxenc / nkeys first; a caller that allocated them zeroed and always runs the full chain can pass
+// false -- k_sort_keys / k_select_mindist hand them back zeroed.
 void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, GfttScratch sc,
                  const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
-                 float* out_xy, int* out_n, int out_cap, const int* active) {
-  hipMemsetAsync(sc.maxenc, 0, sizeof(unsigned) * S, st);
-  hipMemsetAsync(sc.nkeys, 0, sizeof(int) * S, st);
+                 float* out_xy, int* out_n, int out_cap, const int* active, hipEvent_t* ev, bool reset_counters) {
+  if (reset_counters) {
+    hipMemsetAsync(sc.maxenc, 0, sizeof(unsigned) * S, st);
+    hipMemsetAsync(sc.nkeys, 0, sizeof(int) * S, st);
+  }
   dim3 grid(div_up(w, EG_TW), div_up(h, EG_TH), S);
+  if (ev) hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(k_eig_max, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, active);
+  if (ev) hipEventRecord(ev[1], st), hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(k_eig_nms, grid, dim3(256), 0, st, src, w, h, pitch, sstride, (const unsigned*)sc.maxenc, qual_s,
                      quality, sc.keys, sc.nkeys, sc.cap, active);
-  hipLaunchKernelGGL(k_sort_keys, dim3(S), dim3(SORT_T), 0, st, sc.keys, sc.nkeys, sc.cap, active);
+  if (ev) hipEventRecord(ev[3], st), hipEventRecord(ev[4], st);
+  hipLaunchKernelGGL(k_sort_keys, dim3(S), dim3(SORT_T), 0, st, sc.keys, sc.nkeys, sc.cap, active, sc.maxenc);
+  if (ev) hipEventRecord(ev[5], st), hipEventRecord(ev[6], st);
   size_t bm = (size_t)((w + 31) / 32) * h * sizeof(unsigned);
-  hipLaunchKernelGGL(k_select_mindist, dim3(S), dim3(64), bm, st, (const unsigned long long*)sc.keys,
-                     (const int*)sc.nkeys, sc.cap, w, h, maxc_s, max_corners, min_distance, out_xy, out_n, out_cap,
-                     active);
+  hipLaunchKernelGGL(k_select_mindist, dim3(S), dim3(64), bm, st, (const unsigned long long*)sc.keys, sc.nkeys, sc.cap, w, h,
+                     maxc_s, max_corners, min_distance, out_xy, out_n, out_cap, active);
+  if (ev) hipEventRecord(ev[7], st);
 }
 
 void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,

@@ -54,7 +54,8 @@ void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, siz
                      size_t dstride, int S, const int* active);
 void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, GfttScratch sc,
                  const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
-                 float* out_xy, int* out_n, int out_cap, const int* active);
+                 float* out_xy, int* out_n, int out_cap, const int* active, hipEvent_t* stage_events = nullptr,
+                 bool reset_counters = true);
 void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
                         const float* corners, const int* ncorners, int corner_cap, const int* mode,
                         const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,

@@ -43,15 +43,20 @@ struct Pipeline {
   // local map on its own HIP stream: the BA of frame N overlaps the front-end of frame N+1 (its output is never fed
   // back into the tracker in the reference, src/frontend/vo_tracking.cpp:373-385).  Keyframe payloads are double-buffered.
   hipStream_t ba_stream = nullptr;
+  // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
+  // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
+  hipStream_t det_stream = nullptr;
+  hipEvent_t ev_img = nullptr, ev_det = nullptr;
   hipEvent_t ev_fe[2] = {nullptr, nullptr}, ev_ba[2] = {nullptr, nullptr};
   bool ev_ba_armed[2] = {false, false};
   KeyFrameDev* kfbuf[2] = {nullptr, nullptr};
 };
-constexpr int PROF_STAGES = 18;
+constexpr int PROF_STAGES = 21;  // every stage has its own (begin, end) event pair on the stream it runs on
 static const char* kStageNames[PROF_STAGES] = {
     "imu_feed+frame_begin", "ingest(copy/equalize)", "pyr_down x6", "track_prepare", "lk_track(temporal)", "track_collect",
-    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt(eig,nms,sort,select)", "feature_dem+add_new",
-    "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end", "ba_update", "ba_solve"};
+    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_max", "gftt:eig_nms", "gftt:sort_keys",
+    "gftt:select_mindist", "feature_dem+add_new", "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end",
+    "ba_update", "ba_solve"};
 
 }  // namespace flvis
 
@@ -155,6 +160,12 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
     hipStreamSynchronize(pl->ba_stream);
     hipStreamDestroy(pl->ba_stream);
   }
+  if (pl->det_stream) {
+    hipStreamSynchronize(pl->det_stream);
+    hipStreamDestroy(pl->det_stream);
+  }
+  if (pl->ev_img) hipEventDestroy(pl->ev_img);
+  if (pl->ev_det) hipEventDestroy(pl->ev_det);
   for (int k = 0; k < 2; k++) {
     if (pl->ev_fe[k]) hipEventDestroy(pl->ev_fe[k]);
     if (pl->ev_ba[k]) hipEventDestroy(pl->ev_ba[k]);
@@ -243,6 +254,8 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   DA(act_track, int, S);
   DA(det_mode, int, S);
   DA(det_maxc, int, S);
+  DA(gftt_act, int, S);
+  DA(gftt_maxc, int, S);
   DA(img_slot, int, S);
   DA(out, FrameOut, S);
   ok = ok && ((pl->kfbuf[0] = dalloc<KeyFrameDev>(pl, S)) != nullptr);
@@ -320,7 +333,10 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     flvis_pipeline_destroy_internal(ctx);
     return ctx->fail(FLVIS_ERR_HIP, "tracker_create: pinned allocation failed");
   }
-  bool evok = hipStreamCreateWithFlags(&pl->ba_stream, hipStreamNonBlocking) == hipSuccess;
+  bool evok = hipStreamCreateWithFlags(&pl->ba_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&pl->det_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&pl->ev_img, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&pl->ev_det, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < 2 && evok; k++)
     evok = hipEventCreateWithFlags(&pl->ev_fe[k], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&pl->ev_ba[k], hipEventDisableTiming) == hipSuccess;
@@ -393,6 +409,7 @@ static int run_local_map(flvis_ctx* ctx) {
 static void sync_all(flvis_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   if (ctx->pipe && ctx->pipe->ba_stream) hipStreamSynchronize(ctx->pipe->ba_stream);
+  if (ctx->pipe && ctx->pipe->det_stream) hipStreamSynchronize(ctx->pipe->det_stream);
 }
 
 int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
@@ -417,35 +434,51 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   hipMemcpyAsync(p.n_imu, pn, sizeof(int) * S, hipMemcpyHostToDevice, st);
   // ---- fixed kernel sequence
   const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
-  hipEvent_t* pev = prof ? &pl->prof_ev[(size_t)pl->prof_step * (PROF_STAGES + 1)] : nullptr;
-#define MARK(i) \
-  if (prof) hipEventRecord(pev[i], st)
-  MARK(0);
+  hipEvent_t* pev = prof ? &pl->prof_ev[(size_t)pl->prof_step * (2 * PROF_STAGES)] : nullptr;
+#define PB(i, strm) \
+  if (prof) hipEventRecord(pev[2 * (i)], strm)
+#define PE(i, strm) \
+  if (prof) hipEventRecord(pev[2 * (i) + 1], strm)
+  PB(0, st);
   launch_imu_feed(st, p);
   launch_frame_begin(st, p, pl->d_time);
-  MARK(1);
+  PE(0, st);
   // images -> level 0 of the stream's current slot (copy, or equalizeHist for EuRoC), then the pyramids
   ImgSel in0 = img_plain(d_img0), in1 = img_plain(d_img1);
   ImgSel l0cur{{pl->pyr0[0][0], pl->pyr0[1][0]}, p.img_slot, 0};
   ImgSel l1cur = img_plain(pl->pyr1[0]);
+  PB(1, st);
   if (pl->cfg.need_equal_hist) {
     launch_equalize_hist(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
-    launch_equalize_hist(st, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
   } else {
     launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
+  }
+  // fork: corner detection of the new left image (speculative for tracking frames: used only if tracking succeeds)
+  hipStream_t ds = pl->det_stream;
+  hipEventRecord(pl->ev_img, st);
+  hipStreamWaitEvent(ds, pl->ev_img, 0);
+  launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, pl->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
+              (double)p.cam.gftt_dis, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num, p.gftt_act, prof ? &pev[2 * 10] : nullptr, false);
+  hipEventRecord(pl->ev_det, ds);
+  if (pl->cfg.need_equal_hist) {
+    launch_equalize_hist(st, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
+  } else {
     launch_copy_image(st, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
   }
-  MARK(2);
+  PE(1, st);
+  PB(2, st);
   for (int l = 1; l <= pl->levels; l++) {
     ImgSel s0{{pl->pyr0[0][l - 1], pl->pyr0[1][l - 1]}, p.img_slot, 0}, d0{{pl->pyr0[0][l], pl->pyr0[1][l]}, p.img_slot, 0};
     launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
     launch_pyr_down(st, img_plain(pl->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1],
                     img_plain(pl->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
   }
+  PE(2, st);
   // temporal tracking
-  MARK(3);
+  PB(3, st);
   launch_track_prepare(st, p);
-  MARK(4);
+  PE(3, st);
+  PB(4, st);
   {
     PyrSel prev, next;
     fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 1, pl->levels_t);
@@ -453,29 +486,35 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track);
   }
-  MARK(5);
+  PE(4, st);
+  PB(5, st);
   launch_track_collect(st, p);
-  MARK(6);
+  PE(5, st);
+  PB(6, st);
   launch_ransac_f(st, p);
-  MARK(7);
+  PE(6, st);
+  PB(7, st);
   launch_ransac_pnp(st, p);
-  MARK(8);
+  PE(7, st);
+  PB(8, st);
   launch_track_post(st, p);
   launch_pose_lm(st, p);
-  MARK(9);
+  PE(8, st);
+  PB(9, st);
   launch_reproj_filter(st, p);
-  MARK(10);
-  // detection (init: detect, tracking: redetect)
-  launch_gftt(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, pl->gftt, nullptr, p.cam.gftt_ql, p.det_maxc, p.cam.gftt_num,
-              (double)p.cam.gftt_dis, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num, p.det_mode);
-  MARK(11);
+  PE(9, st);
+  // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners
+  hipStreamWaitEvent(st, pl->ev_det, 0);
+  PB(14, st);
   launch_feature_dem(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num,
                      p.det_mode, p.exist_xy, p.n_exist, NMAX, p.new_xy, p.n_new, NEW_MAX);
   launch_add_new(st, p);
+  PE(14, st);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
-  MARK(12);
+  PB(15, st);
   launch_depth_prepare(st, p);
-  MARK(13);
+  PE(15, st);
+  PB(16, st);
   {
     PyrSel prev, next;
     fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 0, pl->levels_s);
@@ -483,30 +522,36 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode);
   }
-  MARK(14);
+  PE(16, st);
+  PB(17, st);
   launch_depth_innovate(st, p);
-  MARK(15);
+  PE(17, st);
   const int par = (int)(pl->frames_fed & 1);
   p.kf = pl->kfbuf[par];  // this frame's keyframe slot; the local map may still be reading the other one
   if (pl->ev_ba_armed[par]) hipStreamWaitEvent(st, pl->ev_ba[par], 0);  // BA of frame N-2 has released this slot
+  PB(18, st);
   launch_frame_end(st, p, (int)pl->frames_fed);
+  PE(18, st);
   if (with_local_map) {
     hipStream_t bs = pl->ba_stream;
     hipEventRecord(pl->ev_fe[par], st);
     hipStreamWaitEvent(bs, pl->ev_fe[par], 0);
-    if (prof) hipEventRecord(pev[16], bs);
+    PB(19, bs);
     launch_ba_update(bs, p);
-    if (prof) hipEventRecord(pev[17], bs);
+    PE(19, bs);
+    PB(20, bs);
     launch_ba_solve(bs, p);
-    if (prof) hipEventRecord(pev[18], bs);
+    PE(20, bs);
     hipEventRecord(pl->ev_ba[par], bs);
     pl->ev_ba_armed[par] = true;
   } else if (prof) {
-    MARK(16);
-    MARK(17);
-    MARK(18);
+    for (int i = 19; i <= 20; i++) {
+      PB(i, st);
+      PE(i, st);
+    }
   }
-#undef MARK
+#undef PB
+#undef PE
   if (prof) pl->prof_step++;
   pl->frames_fed++;
   hipError_t e = hipGetLastError();
@@ -540,7 +585,7 @@ int flvis_prof_enable(flvis_ctx* ctx, int max_steps) {
   pl->prof_ev.clear();
   pl->prof_cap = max_steps;
   pl->prof_step = 0;
-  pl->prof_ev.resize((size_t)max_steps * (PROF_STAGES + 1));
+  pl->prof_ev.resize((size_t)max_steps * (2 * PROF_STAGES));
   for (auto& e : pl->prof_ev)
     if (hipEventCreate(&e) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
   return FLVIS_OK;
@@ -557,7 +602,7 @@ int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps) {
   for (int k = 0; k < pl->prof_step; k++)
     for (int i = 0; i < PROF_STAGES; i++) {
       float ms = 0;
-      hipEventElapsedTime(&ms, pl->prof_ev[(size_t)k * (PROF_STAGES + 1) + i], pl->prof_ev[(size_t)k * (PROF_STAGES + 1) + i + 1]);
+      hipEventElapsedTime(&ms, pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i], pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i + 1]);
       h_ms_per_stage[i] += ms;
     }
   *n_steps = pl->prof_step;

@@ -133,6 +133,10 @@ __global__ void k_frame_begin(Pipe p, const double* __restrict__ frame_time) {
   p.act_track[s] = st.phase == PH_TRACK;
   p.det_mode[s] = det_mode;
   p.det_maxc[s] = det_mode == 1 ? 2 * p.cam.gftt_num : p.cam.gftt_num;
+  // goodFeaturesToTrack runs beside the tracking chain: planned here for init frames (detect, 2x corners) and for
+  // tracking frames (redetect); the result of a frame whose tracking fails is simply not consumed
+  p.gftt_act[s] = (det_mode == 1 || st.phase == PH_TRACK) ? 1 : 0;
+  p.gftt_maxc[s] = det_mode == 1 ? 2 * p.cam.gftt_num : p.cam.gftt_num;
   p.n_exist[s] = 0;
   p.img_slot[s] = c;  // image slot written this frame (stays valid even if the frame is escaped later)
   p.lk_count[s] = 0;

@@ -31,6 +31,8 @@ struct Pipe {
   int* act_track;           // [S]
   int* det_mode;            // [S] 0 none, 1 detect (init), 2 redetect
   int* det_maxc;            // [S]
+  int* gftt_act;            // [S] corner detection planned at frame begin (init frames; tracking frames speculatively)
+  int* gftt_maxc;           // [S] its maxCorners
   int* img_slot;            // [S] image slot of the current frame
   FrameOut* out;            // [S]
   double* traj;             // [S][traj_cap][9]  (t, pose7, state|kf<<4) or nullptr
