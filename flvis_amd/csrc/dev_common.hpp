@@ -60,4 +60,30 @@ __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
   return __popcll(mask & ((1ull << lane_id()) - 1ull));
 }
 
+// sum over the 64 lanes of 32 values per lane, scattered: returns the total of value `idx` (idx as returned, < 32) in
+// every lane; each exchange step halves the values a lane carries (63 shuffles instead of 32 x 6).  Fixed order.
+template <int N, int O>
+__device__ __forceinline__ void wave_rs_step(const double (&in)[2 * N], double (&out)[N], int lane, int& base) {
+  const bool up = (lane & O) != 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const double send = up ? in[i] : in[i + N];
+    const double keep = up ? in[i + N] : in[i];
+    out[i] = keep + __shfl_xor(send, O, 64);
+  }
+  base += up ? N : 0;
+}
+__device__ __forceinline__ double wave_reduce_scatter32(const double (&v)[32], int& idx) {
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  double a16[16], a8[8], a4[4], a2[2], a1[1];
+  wave_rs_step<16, 32>(v, a16, lane, base);
+  wave_rs_step<8, 16>(a16, a8, lane, base);
+  wave_rs_step<4, 8>(a8, a4, lane, base);
+  wave_rs_step<2, 4>(a4, a2, lane, base);
+  wave_rs_step<1, 2>(a2, a1, lane, base);
+  idx = base;
+  return a1[0] + __shfl_xor(a1[0], 1, 64);
+}
+
 }  // namespace flvis

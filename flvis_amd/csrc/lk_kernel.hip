@@ -6,18 +6,27 @@
 //
 // Mapping: ONE WAVE (64 lanes) per (stream, point); the wave walks the pyramid levels top-down and runs the <=30
 // Gauss-Newton iterations in-kernel.  Lane l owns window row (l>>1) and the 16-column half (l&1) of the 31x31 window:
-// the interpolated template (I, Ix, Iy as int16) lives in that lane's registers for the whole level, so LDS only
-// holds the 34x36-byte source patch / 32x36-byte search patch, staged with dword loads + v_alignbyte so that each
-// lane then reads 5 aligned dwords per row.  Scharr derivatives are computed on the fly from the staged patch (no
-// derivative image in HBM).  Sums are exact integers (int32 per lane, int64 across the wave) -> bit-exact vs oracle.
+// the interpolated template (I, Ix, Iy as packed int16 pairs) lives in that lane's registers for the whole level.
+// Scharr derivatives are computed on the fly from the staged source patch (no derivative image in HBM).
+// The search image is cached per level as a 41-row x 52-byte REGION around the current position (window + 4 px margin,
+// dword-aligned columns): iterations read their 32x32 window from LDS and only a move of more than the margin re-stages
+// it -- no global load and no barrier in a steady-state iteration.  The bilinear interpolation + residual run on packed
+// 16-bit pairs (v_perm_b32 to widen two bytes, v_dot2c_i32_i16 for the weights and for the b1/b2 accumulation): ~8
+// instructions per pixel.  Sums are exact integers (int32 per lane; the wave total is reduced as 16-bit halves with DPP
+// row reductions + 4 readlanes) -> bit-exact vs the oracle.
 #include "dev_common.hpp"
 #include "img_kernels.hpp"
 
 namespace flvis {
 
 constexpr int LK_WIN = 31;
-constexpr int LK_PS = 40;     // LDS patch row stride (bytes); 36 used
+constexpr int LK_PS = 40;     // template-source patch row stride (bytes); 36 used
 constexpr int LK_PROWS = 34;  // rows of the template-source patch
+constexpr int LK_RM = 4;      // search-region margin (pixels)
+constexpr int LK_RS = 52;     // search-region row stride (bytes): 13 dwords (odd -> conflict-free row walks)
+constexpr int LK_RROWS = 33 + 2 * LK_RM;
+
+typedef short lk_s2 __attribute__((ext_vector_type(2)));
 
 // patch[r][c] = img(X0 + c, Y0 + r) for r < nrows, c < 36, REFLECT_101 outside the image
 __device__ __forceinline__ void lk_load_patch(const uint8_t* __restrict__ img, int w, int h, int pitch, int X0, int Y0,
@@ -42,9 +51,48 @@ __device__ __forceinline__ void lk_load_patch(const uint8_t* __restrict__ img, i
   }
 }
 
+// region[r][c] = img(X0 + c, Y0 + r), r < LK_RROWS, c < 52, X0 a multiple of 4 (aligned dword loads), REFLECT_101 outside
+__device__ __forceinline__ void lk_load_region(const uint8_t* __restrict__ img, int w, int h, int pitch, int X0, int Y0,
+                                               uint8_t* region) {
+  for (int i = threadIdx.x; i < LK_RROWS * 13; i += 64) {
+    int r = i / 13, k = i - r * 13;
+    int Y = Y0 + r, X = X0 + 4 * k;
+    uint32_t v;
+    if (Y >= 0 && Y < h && X >= 0 && X + 3 < w) {
+      v = *reinterpret_cast<const uint32_t*>(img + (size_t)Y * pitch + X);
+    } else {
+      const uint8_t* row = img + (size_t)reflect101c(Y, h) * pitch;
+      uint32_t b0 = row[reflect101c(X, w)], b1 = row[reflect101c(X + 1, w)], b2 = row[reflect101c(X + 2, w)],
+               b3 = row[reflect101c(X + 3, w)];
+      v = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+    *reinterpret_cast<uint32_t*>(region + r * LK_RS + 4 * k) = v;
+  }
+}
+
 __device__ __forceinline__ int descale_i(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 #define LK_BYTE(D, K) ((int)(((D)[(K) >> 2] >> (((K)&3) * 8)) & 255u))
+
+// bytes K and K+1 of the dword array D, widened to a pair of 16-bit lanes (one v_perm_b32; K is a compile-time constant)
+#define LK_PAIR(D, K)                                                                                              \
+  ((((K)&3) == 3) ? __builtin_amdgcn_perm((D)[((K) >> 2) + 1], (D)[(K) >> 2], 0x0c040c03u)                         \
+                  : __builtin_amdgcn_perm(0u, (D)[(K) >> 2], 0x0c000c00u | (uint32_t)((K)&3) | ((uint32_t)(((K)&3) + 1) << 16)))
+
+// sum of v over the wave as a wave-uniform value: 4 DPP steps give every lane its row-of-16 total, 4 readlanes add the rows
+__device__ __forceinline__ int lk_wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+// exact 64-bit total of a per-lane int32: 16-bit halves cannot overflow 32 bits over 64 lanes
+__device__ __forceinline__ long long lk_wave_sum_wide(int v) {
+  const int lo = lk_wave_sum_i32(v & 0xffff), hi = lk_wave_sum_i32(v >> 16);
+  return ((long long)hi << 16) + (long long)lo;
+}
 
 __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const float* __restrict__ prev_pts,
                                                  float* __restrict__ next_pts, uint8_t* __restrict__ status,
@@ -54,7 +102,7 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const
   if (active && !active[s]) return;
   int n = count[s];
   if (n > nmax) n = nmax;
-  __shared__ __attribute__((aligned(16))) uint8_t patch[LK_PROWS * LK_PS];
+  __shared__ __attribute__((aligned(16))) uint8_t patch[LK_RROWS * LK_RS + 12];  // template patch, then search region
   const int lane = threadIdx.x;
   const int r = lane >> 1;
   const int c0 = (lane & 1) * 16;
@@ -104,7 +152,7 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const
       lk_load_patch(prev.lvl[level].ptr(s, prev.stride[level]), W, H, prev.pitch[level], ipx - 1, ipy - 1, LK_PROWS,
                     patch);
       __syncthreads();
-      short tI[16], tX[16], tY[16];
+      lk_s2 tI[8], tX[8], tY[8];  // pixel pairs (c, c+1)
       int a11 = 0, a12 = 0, a22 = 0;
       if (r < LK_WIN) {
         uint32_t d[4][5];
@@ -133,6 +181,7 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const
             dy[dr][c] = in ? ((t1[c + 2] + t1[c]) * 3 + t1[c + 1] * 10) : 0;
           }
         }
+        short sI[16], sX[16], sY[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) {
           if (c0 + c < LK_WIN) {
@@ -141,24 +190,30 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const
             int ival = descale_i(i00 * iw00 + i01 * iw01 + i10 * iw10 + i11 * iw11, W_BITS - 5);
             int ixval = descale_i(dx[0][c] * iw00 + dx[0][c + 1] * iw01 + dx[1][c] * iw10 + dx[1][c + 1] * iw11, W_BITS);
             int iyval = descale_i(dy[0][c] * iw00 + dy[0][c + 1] * iw01 + dy[1][c] * iw10 + dy[1][c + 1] * iw11, W_BITS);
-            tI[c] = (short)ival;
-            tX[c] = (short)ixval;
-            tY[c] = (short)iyval;
+            sI[c] = (short)ival;
+            sX[c] = (short)ixval;
+            sY[c] = (short)iyval;
             a11 += ixval * ixval;
             a12 += ixval * iyval;
             a22 += iyval * iyval;
           } else {
-            tI[c] = 0;
-            tX[c] = 0;
-            tY[c] = 0;
+            sI[c] = 0;
+            sX[c] = 0;
+            sY[c] = 0;
           }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          tI[c] = lk_s2{sI[2 * c], sI[2 * c + 1]};
+          tX[c] = lk_s2{sX[2 * c], sX[2 * c + 1]};
+          tY[c] = lk_s2{sY[2 * c], sY[2 * c + 1]};
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-          tI[c] = 0;
-          tX[c] = 0;
-          tY[c] = 0;
+        for (int c = 0; c < 8; c++) {
+          tI[c] = lk_s2{0, 0};
+          tX[c] = lk_s2{0, 0};
+          tY[c] = lk_s2{0, 0};
         }
       }
       const long long iA11 = wave_sum_i64((long long)a11), iA12 = wave_sum_i64((long long)a12),
@@ -177,6 +232,8 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const
       float pdx = 0.f, pdy = 0.f;
       const int JW = next.w[level], JH = next.h[level];
       const uint8_t* Jimg = next.lvl[level].ptr(s, next.stride[level]);
+      bool region_ok = false;
+      int RX0 = 0, RY0 = 0;
       for (int j = 0; j < prm.max_iter; j++) {
         const int inx = (int)floorf(npx), iny = (int)floorf(npy);
         if (inx < -LK_WIN || inx >= JW || iny < -LK_WIN || iny >= JH) {
@@ -189,26 +246,48 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const
         iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
         iw10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-        __syncthreads();
-        lk_load_patch(Jimg, JW, JH, next.pitch[level], inx, iny, 32, patch);
-        __syncthreads();
+        if (!region_ok || inx < RX0 || inx - RX0 > 15 || iny < RY0 || iny - RY0 > 2 * LK_RM) {
+          RX0 = (inx - LK_RM) & ~3;
+          RY0 = iny - LK_RM;
+          __syncthreads();
+          lk_load_region(Jimg, JW, JH, next.pitch[level], RX0, RY0, patch);
+          __syncthreads();
+          region_ok = true;
+        }
         int b1 = 0, b2 = 0;
         if (r < LK_WIN) {
+          const int bx = inx - RX0 + c0, sh = bx & 3;
+          const uint8_t* rp = patch + (iny - RY0 + r) * LK_RS + (bx & ~3);
           uint32_t e[2][5];
 #pragma unroll
-          for (int q = 0; q < 2; q++)
+          for (int q = 0; q < 2; q++) {
+            uint32_t dd[6];
 #pragma unroll
-            for (int k = 0; k < 5; k++) e[q][k] = *reinterpret_cast<const uint32_t*>(patch + (r + q) * LK_PS + c0 + 4 * k);
+            for (int k = 0; k < 6; k++) dd[k] = *reinterpret_cast<const uint32_t*>(rp + q * LK_RS + 4 * k);
 #pragma unroll
-          for (int c = 0; c < 16; c++) {
-            int j00 = LK_BYTE(e[0], c), j01 = LK_BYTE(e[0], c + 1), j10 = LK_BYTE(e[1], c), j11 = LK_BYTE(e[1], c + 1);
-            int diff = descale_i(j00 * iw00 + j01 * iw01 + j10 * iw10 + j11 * iw11, W_BITS - 5) - (int)tI[c];
+            for (int k = 0; k < 5; k++) e[q][k] = __builtin_amdgcn_alignbyte(dd[k + 1], dd[k], sh);
+          }
+          const lk_s2 wT = lk_s2{(short)iw00, (short)iw01}, wB = lk_s2{(short)iw10, (short)iw11};
+#pragma unroll
+          for (int c2 = 0; c2 < 8; c2++) {
+            int iv[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+              const int c = 2 * c2 + hh;
+              const uint32_t pt = LK_PAIR(e[0], c), pb = LK_PAIR(e[1], c);
+              int acc = 1 << (W_BITS - 5 - 1);
+              acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, pt), wT, acc, false);
+              acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, pb), wB, acc, false);
+              iv[hh] = acc >> (W_BITS - 5);
+            }
+            const lk_s2 ivp = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iv[1], (uint32_t)iv[0], 0x05040100u));
+            const lk_s2 diff = ivp - tI[c2];
             // columns >= 31 have tX = tY = 0, so they add nothing
-            b1 += diff * (int)tX[c];
-            b2 += diff * (int)tY[c];
+            b1 = __builtin_amdgcn_sdot2(diff, tX[c2], b1, false);
+            b2 = __builtin_amdgcn_sdot2(diff, tY[c2], b2, false);
           }
         }
-        const long long ib1 = wave_sum_i64((long long)b1), ib2 = wave_sum_i64((long long)b2);
+        const long long ib1 = lk_wave_sum_wide(b1), ib2 = lk_wave_sum_wide(b2);
         const float fb1 = (float)ib1 * FLT_SCALE, fb2 = (float)ib2 * FLT_SCALE;
         const float ddx = (A12 * fb2 - A22 * fb1) * D;
         const float ddy = (A12 * fb1 - A11 * fb2) * D;

@@ -234,25 +234,31 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
 }
 
 // ------------------------------------------------------------------------------------------------ F-matrix RANSAC
-// cv::findFundamentalMat(FM_RANSAC, 5.0, 0.99) control flow with the counter RNG; 64 hypotheses per batch (one per lane),
-// the adaptive stop is replayed sequentially over the batch.  Only the mask is used (lkorb_tracking.cpp:133-158).
-__global__ __launch_bounds__(64) void k_ransac_f(Pipe p) {
+// cv::findFundamentalMat(FM_RANSAC, 5.0, 0.99) control flow with the counter RNG.  One workgroup of RF_T threads per
+// stream, 64 hypotheses per batch: wave 0 solves the 7-point systems (one per lane, up to 3 models each -> LDS), then ALL
+// waves score the <= 192 models (a wave takes a model, its lanes stride the correspondences, ballot-popcount counts the
+// inliers) and the adaptive stop is replayed sequentially over the batch.  Only the mask is used
+// (lkorb_tracking.cpp:133-158).
+constexpr int RF_T = 1024;
+__global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK || !st.ok) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = st.n_surv;
   __shared__ float sm1[NMAX * 2], sm2[NMAX * 2];
+  __shared__ double Fm[64 * 3][9];
+  __shared__ int hnm[64], mcnt[64 * 3];
   __shared__ int hcnt[64], hmodel[64];
   __shared__ double bestF[9];
   __shared__ int ctl[4];  // niters, maxGood, best_iter, best_model
   const float* gm1 = p.m1 + (size_t)s * NMAX * 2;
   const float* gm2 = p.m2 + (size_t)s * NMAX * 2;
-  for (int i = lane; i < 2 * n; i += 64) {
+  for (int i = tid; i < 2 * n; i += RF_T) {
     sm1[i] = gm1[i];
     sm2[i] = gm2[i];
   }
-  if (lane == 0) {
+  if (tid == 0) {
     ctl[0] = 1000;
     ctl[1] = 0;
     ctl[2] = -1;
@@ -264,38 +270,60 @@ __global__ __launch_bounds__(64) void k_ransac_f(Pipe p) {
   Landmark* to = lm_ptr(p, st.cur, s);
   if (n > 7) {
     for (int base = 0; base < ctl[0]; base += 64) {
-      const int iter = base + lane;
-      int cnt = -1, model = 0;
-      if (iter < ctl[0]) {
-        int idx[7];
-        if (ransac_subset(seed, (unsigned)iter, n, 7, idx)) {
-          double x1[7][2], x2[7][2];
-          for (int k = 0; k < 7; k++) {
-            x1[k][0] = sm1[2 * idx[k]];
-            x1[k][1] = sm1[2 * idx[k] + 1];
-            x2[k][0] = sm2[2 * idx[k]];
-            x2[k][1] = sm2[2 * idx[k] + 1];
-          }
-          double F[3][9];
-          int nm = seven_point(x1, x2, F);
-          cnt = 0;
-          for (int m = 0; m < nm; m++) {
-            int good = 0;
-            for (int i = 0; i < n; i++)
-              good += (f_error(F[m], sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1]) <= thr2);
-            if (good > cnt) {
-              cnt = good;
-              model = m;
+      if (wv == 0) {  // hypotheses of this batch
+        const int iter = base + lane;
+        int nm = -1;  // -1: beyond niters, -2: subset impossible (the reference loop stops)
+        if (iter < ctl[0]) {
+          int idx[7];
+          if (ransac_subset(seed, (unsigned)iter, n, 7, idx)) {
+            double x1[7][2], x2[7][2];
+            for (int k = 0; k < 7; k++) {
+              x1[k][0] = sm1[2 * idx[k]];
+              x1[k][1] = sm1[2 * idx[k] + 1];
+              x2[k][0] = sm2[2 * idx[k]];
+              x2[k][1] = sm2[2 * idx[k] + 1];
             }
+            double F[3][9];
+            nm = seven_point(x1, x2, F);
+            for (int m = 0; m < nm; m++)
+              for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
+          } else {
+            nm = -2;
           }
-        } else {
-          cnt = -2;  // subset impossible: the reference loop stops
         }
+        hnm[lane] = nm;
       }
-      hcnt[lane] = cnt;
-      hmodel[lane] = model;
       __syncthreads();
-      if (lane == 0) {
+      for (int mi = wv; mi < 64 * 3; mi += RF_T / 64) {  // score the models
+        const int hyp = mi / 3, m = mi - 3 * hyp;
+        if (m >= hnm[hyp]) continue;
+        double F[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) F[j] = Fm[mi][j];
+        int good = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+          const int i = i0 + lane;
+          const bool in = i < n && f_error(F, sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1]) <= thr2;
+          good += __popcll(__ballot(in));
+        }
+        if (lane == 0) mcnt[mi] = good;
+      }
+      __syncthreads();
+      if (tid < 64) {  // best model of each hypothesis: first maximum in model order
+        const int nm = hnm[tid];
+        int cnt = nm == -2 ? -2 : (nm < 0 ? -1 : 0), model = 0;
+        for (int m = 0; m < nm; m++) {
+          const int good = mcnt[tid * 3 + m];
+          if (good > cnt) {
+            cnt = good;
+            model = m;
+          }
+        }
+        hcnt[tid] = cnt;
+        hmodel[tid] = model;
+      }
+      __syncthreads();
+      if (tid == 0) {
         int niters = ctl[0], maxGood = ctl[1];
         for (int k = 0; k < 64; k++) {
           if (base + k >= niters) break;
@@ -309,6 +337,7 @@ __global__ __launch_bounds__(64) void k_ransac_f(Pipe p) {
             maxGood = good;
             ctl[2] = base + k;
             ctl[3] = hmodel[k];
+            for (int j = 0; j < 9; j++) bestF[j] = Fm[k * 3 + hmodel[k]][j];
             niters = ransac_update_num_iters(0.99, (double)(n - good) / n, 7, niters);
           }
         }
@@ -317,49 +346,37 @@ __global__ __launch_bounds__(64) void k_ransac_f(Pipe p) {
       }
       __syncthreads();
     }
-    // regenerate the winning model and apply its mask with the reference's mirrored index
+    // apply the winning model's mask with the reference's mirrored index
     if (ctl[2] >= 0) {
-      if (lane == 0) {
-        int idx[7];
-        ransac_subset(seed, (unsigned)ctl[2], n, 7, idx);
-        double x1[7][2], x2[7][2];
-        for (int k = 0; k < 7; k++) {
-          x1[k][0] = sm1[2 * idx[k]];
-          x1[k][1] = sm1[2 * idx[k] + 1];
-          x2[k][0] = sm2[2 * idx[k]];
-          x2[k][1] = sm2[2 * idx[k] + 1];
-        }
-        double F[3][9];
-        seven_point(x1, x2, F);
-        for (int j = 0; j < 9; j++) bestF[j] = F[ctl[3]][j];
-      }
-      __syncthreads();
-      for (int i = lane; i < n; i += 64) {
+      for (int i = tid; i < n; i += RF_T) {
         bool in = f_error(bestF, sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1]) <= thr2;
         if (!in) to[i].inlier = 0;  // mask index i applied to to.landmarks[i] (descending order): quirk A1
       }
     } else {
-      for (int i = lane; i < n; i += 64) to[i].inlier = 0;  // no model: all-zero mask
+      for (int i = tid; i < n; i += RF_T) to[i].inlier = 0;  // no model: all-zero mask
     }
   }
   __syncthreads();
-  int fc = 0;
-  for (int i = lane; i < n; i += 64) fc += to[i].inlier ? 1 : 0;
-  fc = wave_sum_i32(fc);
-  if (lane == 0) {
-    st.f_cnt = fc;
-    if (fc < 10) st.ok = 0;
+  if (wv == 0) {
+    int fc = 0;
+    for (int i = lane; i < n; i += 64) fc += to[i].inlier ? 1 : 0;
+    fc = wave_sum_i32(fc);
+    if (lane == 0) {
+      st.f_cnt = fc;
+      if (fc < 10) st.ok = 0;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ PnP RANSAC
 // cv::solvePnPRansac(p3d, p2d, K_rect, 0, r, t, false, 100, 3.0, 0.99, inliers, ITERATIVE|P3P) control flow; hypotheses
 // by Grunert P3P (first 3 sample points, the rest disambiguate), Gauss-Newton refinement on the inliers.
-__global__ __launch_bounds__(64) void k_ransac_pnp(Pipe p) {
+constexpr int RP_T = 512;
+__global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK || !st.ok) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cur = st.cur;
   Landmark* to = lm_ptr(p, cur, s);
   const int nl = st.n_lm[cur];
@@ -370,100 +387,121 @@ __global__ __launch_bounds__(64) void k_ransac_pnp(Pipe p) {
   __shared__ double hpose[64][12];
   __shared__ int ctl[4];
   __shared__ double bpose[12];
-  // gather (has3d && inlier) in order
-  int np = 0;
-  for (int base = 0; base < nl; base += 64) {
-    int i = base + lane;
-    bool sel = i < nl && to[i].has3d && to[i].inlier;
-    unsigned long long b = __ballot(sel);
-    if (sel) {
-      int k = np + lane_prefix(b);
-      s2d[2 * k] = (float)to[i].p2u[0];
-      s2d[2 * k + 1] = (float)to[i].p2u[1];
-      s3d[3 * k] = (float)to[i].p3w[0];
-      s3d[3 * k + 1] = (float)to[i].p3w[1];
-      s3d[3 * k + 2] = (float)to[i].p3w[2];
-      sidx[k] = (short)i;
+  __shared__ int snp;
+  // gather (has3d && inlier) in order (wave 0)
+  if (wv == 0) {
+    int np0 = 0;
+    for (int base = 0; base < nl; base += 64) {
+      int i = base + lane;
+      bool sel = i < nl && to[i].has3d && to[i].inlier;
+      unsigned long long b = __ballot(sel);
+      if (sel) {
+        int k = np0 + lane_prefix(b);
+        s2d[2 * k] = (float)to[i].p2u[0];
+        s2d[2 * k + 1] = (float)to[i].p2u[1];
+        s3d[3 * k] = (float)to[i].p3w[0];
+        s3d[3 * k + 1] = (float)to[i].p3w[1];
+        s3d[3 * k + 2] = (float)to[i].p3w[2];
+        sidx[k] = (short)i;
+      }
+      np0 += __popcll(b);
     }
-    np += __popcll(b);
-  }
-  const bool iterative = st.use_guess != 0;
-  const int modelPoints = iterative ? 5 : 4;
-  if (lane == 0) {
-    ctl[0] = 100;
-    ctl[1] = 0;
-    ctl[2] = -1;
+    if (lane == 0) {
+      snp = np0;
+      ctl[0] = 100;
+      ctl[1] = 0;
+      ctl[2] = -1;
+    }
   }
   __syncthreads();
+  const int np = snp;
+  const bool iterative = st.use_guess != 0;
+  const int modelPoints = iterative ? 5 : 4;
   const double fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
   const unsigned long long seed = mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[cur] + 1));
   const float t2 = 9.0f;
   if (np >= modelPoints) {
     for (int base = 0; base < ctl[0]; base += 64) {
-      const int iter = base + lane;
-      int cnt = -1;
-      if (iter < ctl[0]) {
-        int idx[5];
-        if (ransac_subset(seed, (unsigned)iter, np, modelPoints, idx)) {
-          V3 P[3], f[3];
-          for (int k = 0; k < 3; k++) {
-            P[k] = V3{(double)s3d[3 * idx[k]], (double)s3d[3 * idx[k] + 1], (double)s3d[3 * idx[k] + 2]};
-            V3 d{((double)s2d[2 * idx[k]] - cx) / fx, ((double)s2d[2 * idx[k] + 1] - cy) / fy, 1.0};
-            f[k] = (1.0 / norm(d)) * d;
-          }
-          M3 Rs[4];
-          V3 ts[4];
-          int ns = p3p_grunert(P, f, Rs, ts);
-          int bk = -1;
-          double be = 1.7976931348623157e308;
-          for (int k = 0; k < ns; k++) {
-            double e = 0;
-            for (int m = 3; m < modelPoints; m++) {
-              V3 Pm{(double)s3d[3 * idx[m]], (double)s3d[3 * idx[m] + 1], (double)s3d[3 * idx[m] + 2]};
-              V3 X = Rs[k] * Pm + ts[k];
-              double z = X.z ? 1. / X.z : 1;
-              double du = fx * X.x * z + cx - (double)s2d[2 * idx[m]], dv = fy * X.y * z + cy - (double)s2d[2 * idx[m] + 1];
-              e += du * du + dv * dv;
+      if (wv == 0) {  // hypotheses of this batch: P3P on the first 3 sample points, the rest disambiguate
+        const int iter = base + lane;
+        int cnt = -1;  // -1: no model / beyond niters, -2: subset impossible, -3: model in hpose[lane], to be scored
+        if (iter < ctl[0]) {
+          int idx[5];
+          if (ransac_subset(seed, (unsigned)iter, np, modelPoints, idx)) {
+            V3 P[3], f[3];
+            for (int k = 0; k < 3; k++) {
+              P[k] = V3{(double)s3d[3 * idx[k]], (double)s3d[3 * idx[k] + 1], (double)s3d[3 * idx[k] + 2]};
+              V3 d{((double)s2d[2 * idx[k]] - cx) / fx, ((double)s2d[2 * idx[k] + 1] - cy) / fy, 1.0};
+              f[k] = (1.0 / norm(d)) * d;
             }
-            if (e < be) {
-              be = e;
-              bk = k;
-            }
-          }
-          if (bk >= 0) {
-            M3 R = Rs[0];
-            V3 t = ts[0];
-            for (int k = 1; k < 4; k++)
-              if (k == bk) {
-                R = Rs[k];
-                t = ts[k];
+            M3 Rs[4];
+            V3 ts[4];
+            int ns = p3p_grunert(P, f, Rs, ts);
+            int bk = -1;
+            double be = 1.7976931348623157e308;
+            for (int k = 0; k < ns; k++) {
+              double e = 0;
+              for (int m = 3; m < modelPoints; m++) {
+                V3 Pm{(double)s3d[3 * idx[m]], (double)s3d[3 * idx[m] + 1], (double)s3d[3 * idx[m] + 2]};
+                V3 X = Rs[k] * Pm + ts[k];
+                double z = X.z ? 1. / X.z : 1;
+                double du = fx * X.x * z + cx - (double)s2d[2 * idx[m]], dv = fy * X.y * z + cy - (double)s2d[2 * idx[m] + 1];
+                e += du * du + dv * dv;
               }
-            int good = 0;
-            for (int i = 0; i < np; i++) {
-              V3 Pi{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]};
-              V3 X = R * Pi + t;
-              double z = X.z ? 1. / X.z : 1;
-              float du = (float)(fx * X.x * z + cx) - s2d[2 * i], dv = (float)(fy * X.y * z + cy) - s2d[2 * i + 1];
-              good += (du * du + dv * dv <= t2);
+              if (e < be) {
+                be = e;
+                bk = k;
+              }
             }
-            cnt = good;
+            if (bk >= 0) {
+              M3 R = Rs[0];
+              V3 t = ts[0];
+              for (int k = 1; k < 4; k++)
+                if (k == bk) {
+                  R = Rs[k];
+                  t = ts[k];
+                }
 #pragma unroll
-            for (int r = 0; r < 3; r++)
+              for (int r = 0; r < 3; r++)
 #pragma unroll
-              for (int c = 0; c < 3; c++) hpose[lane][3 * r + c] = R.m[r][c];
-            hpose[lane][9] = t.x;
-            hpose[lane][10] = t.y;
-            hpose[lane][11] = t.z;
+                for (int c = 0; c < 3; c++) hpose[lane][3 * r + c] = R.m[r][c];
+              hpose[lane][9] = t.x;
+              hpose[lane][10] = t.y;
+              hpose[lane][11] = t.z;
+              cnt = -3;
+            }
           } else {
-            cnt = -1;  // no model from this sample: continue
+            cnt = -2;
           }
-        } else {
-          cnt = -2;
         }
+        hcnt[lane] = cnt;
       }
-      hcnt[lane] = cnt;
       __syncthreads();
-      if (lane == 0) {
+      for (int hy = wv; hy < 64; hy += RP_T / 64) {  // score the models: lanes stride the correspondences
+        if (hcnt[hy] != -3) continue;
+        M3 R;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) R.m[r][c] = hpose[hy][3 * r + c];
+        const V3 t{hpose[hy][9], hpose[hy][10], hpose[hy][11]};
+        int good = 0;
+        for (int i0 = 0; i0 < np; i0 += 64) {
+          const int i = i0 + lane;
+          bool in = false;
+          if (i < np) {
+            V3 Pi{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]};
+            V3 X = R * Pi + t;
+            double z = X.z ? 1. / X.z : 1;
+            float du = (float)(fx * X.x * z + cx) - s2d[2 * i], dv = (float)(fy * X.y * z + cy) - s2d[2 * i + 1];
+            in = du * du + dv * dv <= t2;
+          }
+          good += __popcll(__ballot(in));
+        }
+        if (lane == 0) hcnt[hy] = good;
+      }
+      __syncthreads();
+      if (tid == 0) {
         int niters = ctl[0], maxGood = ctl[1];
         for (int k = 0; k < 64; k++) {
           if (base + k >= niters) break;
@@ -486,6 +524,7 @@ __global__ __launch_bounds__(64) void k_ransac_pnp(Pipe p) {
       __syncthreads();
     }
   }
+  if (wv != 0) return;  // mask + final refinement: one wave
   SE3d T = iterative ? load_pose7(st.guess) : se3_identity();
   if (iterative) T = se3_from_mat(q_to_mat(T.q), T.t);
   int inliers = 0;
@@ -506,11 +545,12 @@ __global__ __launch_bounds__(64) void k_ransac_pnp(Pipe p) {
     __syncthreads();
     inliers = ctl[1];
     // Gauss-Newton refinement on the inliers (stand-in for OpenCV's final solvePnP)
+    __shared__ double gn[32];
     SE3d Tb = g2o_from_mat(R, t);
     for (int it = 0; it < 10; it++) {
-      double acc[27];
+      double acc[32];
 #pragma unroll
-      for (int k = 0; k < 27; k++) acc[k] = 0;
+      for (int k = 0; k < 32; k++) acc[k] = 0;
       for (int i = lane; i < np; i += 64) {
         if (!smask[i]) continue;
         double e[2], J[2][6];
@@ -524,20 +564,27 @@ __global__ __launch_bounds__(64) void k_ransac_pnp(Pipe p) {
           for (int c = r; c < 6; c++) acc[q++] += J[0][r] * J[0][c] + J[1][r] * J[1][c];
         }
       }
-#pragma unroll
-      for (int k = 0; k < 27; k++) acc[k] = wave_sum_f64(acc[k]);
+      {
+        int idx;
+        const double tot = wave_reduce_scatter32(acc, idx);
+        __builtin_amdgcn_wave_barrier();
+        if (!(lane & 1)) gn[idx] = tot;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+      }
       double H[36], b[6], dx[6];
       int q = 0;
 #pragma unroll
       for (int r = 0; r < 6; r++) {
-        b[r] = acc[21 + r];
+        b[r] = gn[21 + r];
 #pragma unroll
         for (int c = r; c < 6; c++) {
-          H[6 * r + c] = acc[q];
-          H[6 * c + r] = acc[q];
+          H[6 * r + c] = gn[q];
+          H[6 * c + r] = gn[q];
           q++;
         }
       }
+      asm volatile("" ::: "memory");
       if (!solve_spd6(H, b, dx)) break;
       Tb = g2o_mul(g2o_exp(dx), Tb);
       double nn = 0;
@@ -1133,8 +1180,8 @@ void launch_track_prepare(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_track_prepare, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
 }
 void launch_track_collect(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_track_collect, dim3(p.S), dim3(64), 0, st, p); }
-void launch_ransac_f(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_f, dim3(p.S), dim3(64), 0, st, p); }
-void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_pnp, dim3(p.S), dim3(64), 0, st, p); }
+void launch_ransac_f(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_f, dim3(p.S), dim3(RF_T), 0, st, p); }
+void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_pnp, dim3(p.S), dim3(RP_T), 0, st, p); }
 void launch_track_post(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_track_post, dim3((p.S + 63) / 64), dim3(64), 0, st, p);
 }
