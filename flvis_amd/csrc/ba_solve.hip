@@ -503,6 +503,7 @@ __device__ __noinline__ bool ba_chol_solve() {
     }
     wave_lds_fence();
   }
+  BAPROF(5);
   // forward substitution L y = rhs (block-wise)
   for (int jb = 0; jb < P; jb++) {
     const int c0 = 6 * jb;
@@ -880,6 +881,7 @@ __device__ __noinline__ void ba_phase_solve_poses() {
   const int lane = threadIdx.x & 63;
   const bool okc = ba_chol_solve();
   wave_lds_fence();
+  BAPROF(6);
   if (lane == 0) sh.flag = okc ? 1 : 0;
   if (lane < sh.W) {
 #pragma unroll

@@ -60,6 +60,26 @@ __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
   return __popcll(mask & ((1ull << lane_id()) - 1ull));
 }
 
+// Exclusive rank of `flag` among the threads of the workgroup (thread order) and the workgroup total.
+// blockDim.x == 64 * NW; s_cnt: int[NW] in LDS.  Two barriers; every thread of the workgroup must call it.
+template <int NW>
+__device__ __forceinline__ int block_rank(bool flag, int* s_cnt, int& total) {
+  const unsigned long long b = __ballot(flag);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_cnt[wv] = __popcll(b);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) {
+    const int cc = s_cnt[k];
+    tot += cc;
+    if (k < wv) off += cc;
+  }
+  __syncthreads();
+  total = tot;
+  return off + lane_prefix(b);
+}
+
 // sum over the 64 lanes of 32 values per lane, scattered: returns the total of value `idx` (idx as returned, < 32) in
 // every lane; each exchange step halves the values a lane carries (63 shuffles instead of 32 x 6).  Fixed order.
 template <int N, int O>

@@ -497,52 +497,77 @@ __device__ __forceinline__ float dem_harris(const uint8_t* __restrict__ img, int
   return (X2 * Y2) - (XY * XY) - 0.05f * (X2 + Y2) * (X2 + Y2);
 }
 
-__global__ __launch_bounds__(64) void k_feature_dem(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
-                                                    const float* __restrict__ corners, const int* __restrict__ ncorners,
-                                                    int corner_cap, const int* __restrict__ mode,
-                                                    const double* __restrict__ exist_xy, const int* __restrict__ nexist,
-                                                    int exist_cap, float* __restrict__ out_xy, int* __restrict__ out_n,
-                                                    int out_cap) {
+constexpr int DEM_T = 256;
+__global__ __launch_bounds__(DEM_T) void k_feature_dem(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
+                                                       const float* __restrict__ corners, const int* __restrict__ ncorners,
+                                                       int corner_cap, const int* __restrict__ mode,
+                                                       const double* __restrict__ exist_xy, const int* __restrict__ nexist,
+                                                       int exist_cap, float* __restrict__ out_xy, int* __restrict__ out_n,
+                                                       int out_cap) {
   const int s = blockIdx.x;
   const int md = mode ? mode[s] : 1;
   if (md == 0) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   __shared__ float cx[DEM_MAXC], cy[DEM_MAXC], cscore[DEM_MAXC];
   __shared__ short creg[DEM_MAXC];
-  __shared__ short sorted_idx[DEM_MAXC];  // candidate indices grouped by region, sorted by score desc (stable)
+  __shared__ short bucket[DEM_MAXC];      // candidate indices grouped by region, index order inside a region
+  __shared__ short sorted_idx[DEM_MAXC];  // ... sorted by score desc (stable)
   __shared__ int rcount[16], roff[17];
   __shared__ float kx[16][DEM_MAXR], ky[16][DEM_MAXR];
-  __shared__ int kcount[16], knew0[16];
+  __shared__ int kcount[16], knew0[16], ooff[17];
+  __shared__ int wcnt[DEM_T / 64][16];
   const uint8_t* img = src.ptr(s, sstride);
   int nc = ncorners[s];
   if (nc > corner_cap) nc = corner_cap;
   if (nc > DEM_MAXC) nc = DEM_MAXC;
   const float* C = corners + (size_t)s * corner_cap * 2;
-  if (lane < 16) {
-    rcount[lane] = 0;
-    kcount[lane] = 0;
+  if (tid < 16) {
+    rcount[tid] = 0;
+    kcount[tid] = 0;
   }
   __syncthreads();
-  // existing features (redetect): fill regions in landmark order (sequential to keep order) -- lane 0
-  if (md == 2 && lane == 0) {
+  // existing features (redetect) fill their regions in landmark order: ordered per-region ranks by ballots, chunk by chunk
+  if (md == 2) {
     int ne = nexist[s];
     if (ne > exist_cap) ne = exist_cap;
     const double* E = exist_xy + (size_t)s * exist_cap * 2;
-    for (int i = 0; i < ne; i++) {
-      float px = (float)E[2 * i], py = (float)E[2 * i + 1];
-      if (px >= 3 && px < (w - 3) && py >= 3 && py < (h - 3)) {
-        int r = (int)(4.f * floorf(py / (float)prm.regionHeight) + px / (float)prm.regionWidth);
-        int k = kcount[r];
+    for (int base = 0; base < ne; base += DEM_T) {
+      const int i = base + tid;
+      int r = -1;
+      float px = 0.f, py = 0.f;
+      if (i < ne) {
+        px = (float)E[2 * i];
+        py = (float)E[2 * i + 1];
+        if (px >= 3 && px < (w - 3) && py >= 3 && py < (h - 3))
+          r = (int)(4.f * floorf(py / (float)prm.regionHeight) + px / (float)prm.regionWidth);
+      }
+      int myrank = 0;
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const unsigned long long bq = __ballot(r == q);
+        if (lane == 0) wcnt[wv][q] = __popcll(bq);
+        if (r == q) myrank = lane_prefix(bq);
+      }
+      __syncthreads();
+      if (r >= 0) {
+        int k = kcount[r] + myrank;
+        for (int v = 0; v < wv; v++) k += wcnt[v][r];
         if (k < DEM_MAXR) {
           kx[r][k] = px;
           ky[r][k] = py;
-          kcount[r] = k + 1;
         }
       }
+      __syncthreads();
+      if (tid < 16) {
+        int k = kcount[tid];
+        for (int v = 0; v < DEM_T / 64; v++) k += wcnt[v][tid];
+        kcount[tid] = k < DEM_MAXR ? k : DEM_MAXR;
+      }
+      __syncthreads();
     }
   }
   // candidates: region + score
-  for (int i = lane; i < nc; i += 64) {
+  for (int i = tid; i < nc; i += DEM_T) {
     float px = C[2 * i], py = C[2 * i + 1];
     int r = -1;
     float sc = 0.f;
@@ -557,7 +582,7 @@ __global__ __launch_bounds__(64) void k_feature_dem(ImgSel src, int w, int h, in
     creg[i] = (short)r;
   }
   __syncthreads();
-  if (lane == 0) {
+  if (tid == 0) {
     int o = 0;
     for (int r = 0; r < 16; r++) {
       roff[r] = o;
@@ -566,48 +591,66 @@ __global__ __launch_bounds__(64) void k_feature_dem(ImgSel src, int w, int h, in
     roff[16] = o;
   }
   __syncthreads();
-  // stable rank inside the region: #(same region, score greater) + #(same region, equal score, earlier index)
-  for (int i = lane; i < nc; i += 64) {
-    int r = creg[i];
-    if (r < 0) continue;
-    float sc = cscore[i];
+  // bucket the candidates by region keeping index order: wave q handles regions q, q+4, ...: ballots over the candidates
+  for (int r = wv; r < 16; r += DEM_T / 64) {
+    int o = roff[r];
+    for (int base = 0; base < nc; base += 64) {
+      const int i = base + lane;
+      const bool in = i < nc && creg[i] == r;
+      const unsigned long long bq = __ballot(in);
+      if (in) bucket[o + lane_prefix(bq)] = (short)i;
+      o += __popcll(bq);
+    }
+  }
+  __syncthreads();
+  // stable rank inside the region: #(score greater) + #(equal score, earlier index); only region members are compared
+  for (int j = tid; j < roff[16]; j += DEM_T) {
+    const int i = bucket[j];
+    const int r = creg[i];
+    const float sc = cscore[i];
     int pos = 0;
-    for (int j = 0; j < nc; j++) {
-      if (creg[j] != r) continue;
-      float sj = cscore[j];
-      pos += (sj > sc) || (sj == sc && j < i);
+    for (int q = roff[r]; q < roff[r + 1]; q++) {
+      const float sj = cscore[bucket[q]];
+      pos += (sj > sc) || (sj == sc && q < j);
     }
     sorted_idx[roff[r] + pos] = (short)i;
   }
+  if (tid < 16) knew0[tid] = kcount[tid];
   __syncthreads();
-  if (lane < 16) knew0[lane] = kcount[lane];
-  __syncthreads();
-  // greedy spacing per region (16 lanes, one region each)
-  if (lane < 16) {
-    const int r = lane;
+  // greedy spacing per region: 16 lanes per region, the lanes split the already kept points of the region
+  {
+    const int r = tid >> 4, sub = tid & 15;  // 256 threads = 16 regions x 16 lanes (a quarter wave each)
     const int bd = prm.boundary_dis;
     int kept = kcount[r];
     unsigned count = 0;
-    for (int j = roff[r]; j < roff[r + 1]; j++) {
+    const int j0 = roff[r], j1 = roff[r + 1];
+    for (int j = j0; j < j1; j++) {
       int ci = sorted_idx[j];
       float px = cx[ci], py = cy[ci];
       if (md == 2) {  // cv::Point pt = Point2f (rounds), feature_dem.cpp:174
         px = (float)__float2int_rn(px);
         py = (float)__float2int_rn(py);
       }
-      int ok = 1;
-      for (int k = 0; k < kept; k++) {
+      int bad = 0;
+      for (int k = sub; k < kept; k += 16) {
         float dis_x = fabsf(px - kx[r][k]);
         float dis_y = fabsf(py - ky[r][k]);
-        if (dis_x <= (float)bd || dis_y <= (float)bd) ok = 0;
+        if (dis_x <= (float)bd || dis_y <= (float)bd) bad = 1;
       }
-      if (ok) {
-        if (kept < DEM_MAXR) {
+      // OR over the 16 lanes of this region (they sit in one row of 16 lanes of the wave)
+      bad |= __shfl_xor(bad, 1, 64);
+      bad |= __shfl_xor(bad, 2, 64);
+      bad |= __shfl_xor(bad, 4, 64);
+      bad |= __shfl_xor(bad, 8, 64);
+      if (!bad) {
+        if (kept < DEM_MAXR && sub == 0) {
           kx[r][kept] = px;
           ky[r][kept] = py;
         }
         kept++;
         count++;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
         if (md == 1) {
           if (count >= prm.max_region_feature_num) break;
         } else {
@@ -615,22 +658,30 @@ __global__ __launch_bounds__(64) void k_feature_dem(ImgSel src, int w, int h, in
         }
       }
     }
-    kcount[r] = kept < DEM_MAXR ? kept : DEM_MAXR;
+    if (sub == 0) kcount[r] = kept < DEM_MAXR ? kept : DEM_MAXR;
   }
   __syncthreads();
   // output: new points, regions in order 0..15, per region in acceptance order
-  if (lane == 0) {
-    float* O = out_xy + (size_t)s * out_cap * 2;
+  if (tid == 0) {
     int o = 0;
-    for (int r = 0; r < 16; r++)
-      for (int k = knew0[r]; k < kcount[r]; k++) {
-        if (o < out_cap) {
-          O[2 * o] = kx[r][k];
-          O[2 * o + 1] = ky[r][k];
-        }
-        o++;
-      }
+    for (int r = 0; r < 16; r++) {
+      ooff[r] = o;
+      o += kcount[r] - knew0[r];
+    }
+    ooff[16] = o;
     out_n[s] = o < out_cap ? o : out_cap;
+  }
+  __syncthreads();
+  {
+    float* O = out_xy + (size_t)s * out_cap * 2;
+    const int r = tid >> 4, sub = tid & 15;
+    for (int k = knew0[r] + sub; k < kcount[r]; k += 16) {
+      const int o = ooff[r] + (k - knew0[r]);
+      if (o < out_cap) {
+        O[2 * o] = kx[r][k];
+        O[2 * o + 1] = ky[r][k];
+      }
+    }
   }
 }
 
@@ -691,7 +742,7 @@ void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, siz
                         const float* corners, const int* ncorners, int corner_cap, const int* mode,
                         const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,
                         int out_cap) {
-  hipLaunchKernelGGL(k_feature_dem, dim3(S), dim3(64), 0, st, src, w, h, pitch, sstride, prm, corners, ncorners,
+  hipLaunchKernelGGL(k_feature_dem, dim3(S), dim3(DEM_T), 0, st, src, w, h, pitch, sstride, prm, corners, ncorners,
                      corner_cap, mode, exist_xy, nexist, exist_cap, out_xy, out_n, out_cap);
 }
 

@@ -453,27 +453,29 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   } else {
     launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
   }
-  // fork: corner detection of the new left image (speculative for tracking frames: used only if tracking succeeds)
+  PE(1, st);
+  PB(2, st);
+  for (int l = 1; l <= pl->levels; l++) {  // left pyramid: needed by the temporal tracker right away
+    ImgSel s0{{pl->pyr0[0][l - 1], pl->pyr0[1][l - 1]}, p.img_slot, 0}, d0{{pl->pyr0[0][l], pl->pyr0[1][l]}, p.img_slot, 0};
+    launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
+  }
+  PE(2, st);
+  // fork: the right image (ingest + pyramid, first used by the stereo matcher) and the corner detection of the new left
+  // image (speculative for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain
   hipStream_t ds = pl->det_stream;
   hipEventRecord(pl->ev_img, st);
   hipStreamWaitEvent(ds, pl->ev_img, 0);
+  if (pl->cfg.need_equal_hist) {
+    launch_equalize_hist(ds, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
+  } else {
+    launch_copy_image(ds, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
+  }
+  for (int l = 1; l <= pl->levels; l++)
+    launch_pyr_down(ds, img_plain(pl->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1],
+                    img_plain(pl->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
   launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, pl->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
               (double)p.cam.gftt_dis, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num, p.gftt_act, prof ? &pev[2 * 10] : nullptr, false);
   hipEventRecord(pl->ev_det, ds);
-  if (pl->cfg.need_equal_hist) {
-    launch_equalize_hist(st, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
-  } else {
-    launch_copy_image(st, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
-  }
-  PE(1, st);
-  PB(2, st);
-  for (int l = 1; l <= pl->levels; l++) {
-    ImgSel s0{{pl->pyr0[0][l - 1], pl->pyr0[1][l - 1]}, p.img_slot, 0}, d0{{pl->pyr0[0][l], pl->pyr0[1][l]}, p.img_slot, 0};
-    launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
-    launch_pyr_down(st, img_plain(pl->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1],
-                    img_plain(pl->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
-  }
-  PE(2, st);
   // temporal tracking
   PB(3, st);
   launch_track_prepare(st, p);

@@ -627,59 +627,98 @@ __global__ void k_track_post(Pipe p) {
 
 // ------------------------------------------------------------------------------------------------ pose-only LM
 // OptimizeInFrame::optimize: g2o Levenberg on one free pose, Huber(1), optimize(2), drop chi2 > 3, optimize(2).
-// One wave per stream: lanes stride the edges, 21+6 sums by wave butterflies, lane-uniform 6x6 Cholesky.
+// One workgroup of PL_T threads per stream, NMAX / PL_T edges per thread (point, measurement and alive flag in registers
+// -- 512 threads keep the 256-VGPR budget the 6x6 normal equations need); the
+// 21+6 normal-equation sums are reduced per wave with the scattered butterfly and folded over the waves through LDS in
+// wave order (reproducible); every thread then solves the same 6x6 system, so the pose needs no broadcast.
+constexpr int PL_T = 512;
+constexpr int PL_NW = PL_T / 64;
+constexpr int PL_EPT = NMAX / PL_T;
 struct PoseLMShared {
-  double pw[NMAX][3];
-  double z[NMAX][2];
-  unsigned char alive[NMAX];
+  double part[PL_NW][32];
+  double tot[32];
+  double red[PL_NW];
+  int s_cnt[PL_NW];
 };
 
-__device__ inline double pose_robust_chi2(const SE3d& T, const PoseLMShared& sh, int n, double fx, double fy, double cx,
-                                          double cy) {
-  double chi = 0;
-  for (int i = threadIdx.x; i < n; i += 64) {
-    if (!sh.alive[i]) continue;
-    double e[2];
-    proj_edge(T, V3{sh.pw[i][0], sh.pw[i][1], sh.pw[i][2]}, sh.z[i][0], sh.z[i][1], fx, fy, cx, cy, e, nullptr);
-    chi += huber_rho(e[0] * e[0] + e[1] * e[1]);
-  }
-  return wave_sum_f64(chi);
+struct PoseEdge {
+  V3 pw;
+  double zu, zv;
+  bool alive;
+};
+
+__device__ inline double pose_block_sum(double v, PoseLMShared& sh) {
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0;
+#pragma unroll
+  for (int k = 0; k < PL_NW; k++) r += sh.red[k];
+  return r;
 }
 
-__device__ inline void pose_lm_optimize(SE3d& T, const PoseLMShared& sh, int n, int iterations, double fx, double fy,
+__device__ inline double pose_robust_chi2(const SE3d& T, const PoseEdge* ed, PoseLMShared& sh, double fx, double fy,
+                                          double cx, double cy) {
+  double chi = 0;
+#pragma unroll
+  for (int k = 0; k < PL_EPT; k++)
+    if (ed[k].alive) {
+      double e[2];
+      proj_edge(T, ed[k].pw, ed[k].zu, ed[k].zv, fx, fy, cx, cy, e, nullptr);
+      chi += huber_rho(e[0] * e[0] + e[1] * e[1]);
+    }
+  return pose_block_sum(chi, sh);
+}
+
+__device__ inline void pose_lm_optimize(SE3d& T, const PoseEdge* ed, PoseLMShared& sh, int iterations, double fx, double fy,
                                         double cx, double cy) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double lambda = -1, ni = 2;
   for (int iteration = 0; iteration < iterations; iteration++) {
-    double currentChi = pose_robust_chi2(T, sh, n, fx, fy, cx, cy);
-    double acc[27];
+    double currentChi = pose_robust_chi2(T, ed, sh, fx, fy, cx, cy);
+    double acc[32];
 #pragma unroll
-    for (int k = 0; k < 27; k++) acc[k] = 0;
-    for (int i = threadIdx.x; i < n; i += 64) {
-      if (!sh.alive[i]) continue;
-      double e[2], J[2][6];
-      proj_edge(T, V3{sh.pw[i][0], sh.pw[i][1], sh.pw[i][2]}, sh.z[i][0], sh.z[i][1], fx, fy, cx, cy, e, J);
-      double c2 = e[0] * e[0] + e[1] * e[1];
-      double w = huber_w(c2);
-      double o0 = -e[0] * w, o1 = -e[1] * w;
-      int q = 0;
+    for (int k = 0; k < 32; k++) acc[k] = 0;
 #pragma unroll
-      for (int r = 0; r < 6; r++) {
-        acc[21 + r] += J[0][r] * o0 + J[1][r] * o1;
+    for (int k = 0; k < PL_EPT; k++)
+      if (ed[k].alive) {
+        double e[2], J[2][6];
+        proj_edge(T, ed[k].pw, ed[k].zu, ed[k].zv, fx, fy, cx, cy, e, J);
+        double c2 = e[0] * e[0] + e[1] * e[1];
+        double w = huber_w(c2);
+        double o0 = -e[0] * w, o1 = -e[1] * w;
+        int q = 0;
 #pragma unroll
-        for (int c = r; c < 6; c++) acc[q++] += (J[0][r] * w) * J[0][c] + (J[1][r] * w) * J[1][c];
+        for (int r = 0; r < 6; r++) {
+          acc[21 + r] += J[0][r] * o0 + J[1][r] * o1;
+#pragma unroll
+          for (int c = r; c < 6; c++) acc[q++] += (J[0][r] * w) * J[0][c] + (J[1][r] * w) * J[1][c];
+        }
       }
-    }
+    {
+      int idx;
+      const double tot = wave_reduce_scatter32(acc, idx);
+      __syncthreads();  // (previous readers of part / tot are done)
+      if (!(lane & 1)) sh.part[wv][idx] = tot;
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        double a = 0;
 #pragma unroll
-    for (int k = 0; k < 27; k++) acc[k] = wave_sum_f64(acc[k]);
+        for (int k = 0; k < PL_NW; k++) a += sh.part[k][threadIdx.x];
+        sh.tot[threadIdx.x] = a;
+      }
+      __syncthreads();
+    }
     double H[36], b[6];
     int q = 0;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      b[r] = acc[21 + r];
+      b[r] = sh.tot[21 + r];
 #pragma unroll
       for (int c = r; c < 6; c++) {
-        H[6 * r + c] = acc[q];
-        H[6 * c + r] = acc[q];
+        H[6 * r + c] = sh.tot[q];
+        H[6 * c + r] = sh.tot[q];
         q++;
       }
     }
@@ -705,7 +744,7 @@ __device__ inline void pose_lm_optimize(SE3d& T, const PoseLMShared& sh, int n, 
       }
       bool ok2 = solve_spd6(Hl, b, x);
       if (ok2) T = g2o_mul(g2o_exp(x), T);
-      double tempChi = pose_robust_chi2(T, sh, n, fx, fy, cx, cy);
+      double tempChi = pose_robust_chi2(T, ed, sh, fx, fy, cx, cy);
       if (!ok2) tempChi = 1.7976931348623157e308;
       rho = currentChi - tempChi;
       double scale = 0;
@@ -735,136 +774,128 @@ __device__ inline void pose_lm_optimize(SE3d& T, const PoseLMShared& sh, int n, 
   }
 }
 
-__global__ __launch_bounds__(64) void k_pose_lm(Pipe p) {
+__global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   const int cur = st.cur;
   Landmark* lms = lm_ptr(p, cur, s);
   const int nl = st.n_lm[cur];
   __shared__ PoseLMShared sh;
+  // the edges are the (has3d && inlier) landmarks; their order does not enter any result except through summation order,
+  // which is fixed by the thread index
+  PoseEdge ed[PL_EPT];
   int n = 0;
-  for (int base = 0; base < nl; base += 64) {
-    int i = base + lane;
-    bool sel = i < nl && lms[i].has3d && lms[i].inlier;
-    unsigned long long b = __ballot(sel);
-    if (sel) {
-      int k = n + lane_prefix(b);
-      sh.pw[k][0] = lms[i].p3w[0];
-      sh.pw[k][1] = lms[i].p3w[1];
-      sh.pw[k][2] = lms[i].p3w[2];
-      sh.z[k][0] = lms[i].p2u[0];
-      sh.z[k][1] = lms[i].p2u[1];
-      sh.alive[k] = 1;
+#pragma unroll
+  for (int k = 0; k < PL_EPT; k++) {
+    const int i = tid + k * PL_T;
+    ed[k].alive = false;
+    ed[k].pw = V3{0, 0, 1};
+    ed[k].zu = ed[k].zv = 0;
+    if (i < nl && lms[i].has3d && lms[i].inlier) {
+      ed[k].pw = V3{lms[i].p3w[0], lms[i].p3w[1], lms[i].p3w[2]};
+      ed[k].zu = lms[i].p2u[0];
+      ed[k].zv = lms[i].p2u[1];
+      ed[k].alive = true;
     }
-    n += __popcll(b);
+    int tot;
+    block_rank<PL_NW>(ed[k].alive, sh.s_cnt, tot);
+    n += tot;
   }
-  __syncthreads();
   bool ok = n >= 10;
   if (ok) {
     const double fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
     SE3d T0 = load_pose7(st.T_c_w[cur]);
     SE3d T = g2o_from_mat(q_to_mat(T0.q), T0.t);
-    pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
+    pose_lm_optimize(T, ed, sh, 2, fx, fy, cx, cy);
     int alive = 0;
-    for (int i = lane; i < n; i += 64) {
-      double e[2];
-      proj_edge(T, V3{sh.pw[i][0], sh.pw[i][1], sh.pw[i][2]}, sh.z[i][0], sh.z[i][1], fx, fy, cx, cy, e, nullptr);
-      if (e[0] * e[0] + e[1] * e[1] > 3.0) sh.alive[i] = 0;
-      alive += sh.alive[i];
+#pragma unroll
+    for (int k = 0; k < PL_EPT; k++) {
+      if (ed[k].alive) {
+        double e[2];
+        proj_edge(T, ed[k].pw, ed[k].zu, ed[k].zv, fx, fy, cx, cy, e, nullptr);
+        if (e[0] * e[0] + e[1] * e[1] > 3.0) ed[k].alive = false;
+      }
+      int tot;
+      block_rank<PL_NW>(ed[k].alive, sh.s_cnt, tot);
+      alive += tot;
     }
-    alive = wave_sum_i32(alive);
-    __syncthreads();
     if (alive < 10) {
       ok = false;
     } else {
-      pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
-      if (lane == 0) store_pose7(st.T_c_w[cur], se3_from_mat(q_to_mat(T.q), T.t));
+      pose_lm_optimize(T, ed, sh, 2, fx, fy, cx, cy);
+      if (tid == 0) store_pose7(st.T_c_w[cur], se3_from_mat(q_to_mat(T.q), T.t));
     }
   }
-  if (!ok && lane == 0) track_fail(st);
+  if (!ok && tid == 0) track_fail(st);
 }
 
 // ------------------------------------------------------------------------------------------------ reprojection filter
 // calReprjInlierOutlier(1.5) + eraseReprjOutlier + viCorrectionFromVision; prepares the redetect inputs.
-__global__ __launch_bounds__(64) void k_reproj_filter(Pipe p) {
+// One workgroup of NMAX threads per stream, one landmark per thread.
+__global__ __launch_bounds__(NMAX) void k_reproj_filter(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK) return;
-  const int lane = threadIdx.x;
+  const int i = threadIdx.x;
   const int cur = st.cur;
   Landmark* lms = lm_ptr(p, cur, s);
   const int n = st.n_lm[cur];
-  __shared__ double dist[NMAX];
   __shared__ double valid[NMAX];
   __shared__ double sh_thr;
+  __shared__ int s_cnt[NMAX / 64];
   const SE3d T = load_pose7(st.T_c_w[cur]);
-  int nv = 0;
-  double sum = 0;
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    double d = 0;
-    bool v = false;
-    if (i < n) {
-      V3 pc = se3_act(T, V3{lms[i].p3w[0], lms[i].p3w[1], lms[i].p3w[2]});
-      double u = p.cam.fx * pc.x / pc.z + p.cam.cx, vv = p.cam.fy * pc.y / pc.z + p.cam.cy;
-      double ex = lms[i].p2u[0] - u, ey = lms[i].p2u[1] - vv;
-      d = sqrt(ex * ex + ey * ey);
-      dist[i] = d;
-      v = d < 3.0;
-    }
-    unsigned long long b = __ballot(v);
-    if (v) valid[nv + lane_prefix(b)] = d;
-    nv += __popcll(b);
+  Landmark lm;
+  double d = 0;
+  bool v = false;
+  if (i < n) {
+    lm = lms[i];
+    V3 pc = se3_act(T, V3{lm.p3w[0], lm.p3w[1], lm.p3w[2]});
+    double u = p.cam.fx * pc.x / pc.z + p.cam.cx, vv = p.cam.fy * pc.y / pc.z + p.cam.cy;
+    double ex = lm.p2u[0] - u, ey = lm.p2u[1] - vv;
+    d = sqrt(ex * ex + ey * ey);
+    v = d < 3.0;
   }
+  int nv;
+  const int vr = block_rank<NMAX / 64>(v, s_cnt, nv);
+  if (v) valid[vr] = d;
+  if (i == 0 && nv == 0) sh_thr = 3.0;
   __syncthreads();
-  // mean over the valid distances in index order (sequential sum like the reference, lane 0)
-  if (lane == 0) {
-    for (int i = 0; i < nv; i++) sum += valid[i];
+  // mean over the valid distances in index order (sequential sum like the reference, thread 0)
+  if (i == 0) {
+    double sum = 0;
+    for (int k = 0; k < nv; k++) sum += valid[k];
     st.reproj_err = sum / (double)nv;
   }
   // median: element of rank nv/2 in ascending order (ties: any equal value)
-  if (nv > 0) {
+  if (i < nv) {
     const int target = nv / 2;
-    for (int i = lane; i < nv; i += 64) {
-      double v = valid[i];
-      int less = 0, eq = 0;
-      for (int j = 0; j < nv; j++) {
-        less += valid[j] < v;
-        eq += valid[j] == v;
-      }
-      if (less <= target && target < less + eq) sh_thr = 1.5 * v;
+    const double vi = valid[i];
+    int less = 0, eq = 0;
+    for (int j = 0; j < nv; j++) {
+      const double vj = valid[j];
+      less += vj < vi;
+      eq += vj == vi;
     }
-  } else if (lane == 0) {
-    sh_thr = 3.0;
+    if (less <= target && target < less + eq) sh_thr = 1.5 * vi;
   }
   __syncthreads();
   double sh = sh_thr;
   if (sh >= 3.0) sh = 3.0;
-  // flag + erase outliers (order preserving, in place)
-  int kept = 0;
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    bool keep = i < n && !(dist[i] > sh);
-    Landmark lm;
-    if (keep) {
-      lm = lms[i];
-      lm.inlier = 1;
-    }
-    unsigned long long b = __ballot(keep);
-    __syncthreads();
-    if (keep) lms[kept + lane_prefix(b)] = lm;
-    kept += __popcll(b);
-    __syncthreads();
+  // flag + erase outliers (order preserving; every landmark was read above)
+  const bool keep = i < n && !(d > sh);
+  int kept;
+  const int k = block_rank<NMAX / 64>(keep, s_cnt, kept);
+  if (keep) {
+    lm.inlier = 1;
+    lms[k] = lm;
+    // existing points for FeatureDEM::redetect
+    double* ex = p.exist_xy + ((size_t)s * NMAX + k) * 2;
+    ex[0] = lm.p2d[0];
+    ex[1] = lm.p2d[1];
   }
-  // existing points for FeatureDEM::redetect
-  double* ex = p.exist_xy + (size_t)s * NMAX * 2;
-  for (int i = lane; i < kept; i += 64) {
-    ex[2 * i] = lms[i].p2d[0];
-    ex[2 * i + 1] = lms[i].p2d[1];
-  }
-  if (lane == 0) {
+  if (i == 0) {
     st.n_lm[cur] = kept;
     st.orig_size = kept;
     p.n_exist[s] = kept;
@@ -966,120 +997,101 @@ __global__ __launch_bounds__(256) void k_depth_prepare(Pipe p) {
 }
 
 // ------------------------------------------------------------------------------------------------ depth innovation
-// recover3DPts_c_FromStereo (after LK) + depthInnovation + eraseNoDepthPoint.  One wave per stream; the rand()-drawn
-// dummy depths (quirk A11) are consumed in landmark order: failures are ranked by ballot prefix, lane 0 advances the
+// recover3DPts_c_FromStereo (after LK) + depthInnovation + eraseNoDepthPoint.  One workgroup of NMAX threads per stream,
+// one landmark per thread (read once, updated in registers, written to its compacted position).  The rand()-drawn dummy
+// depths (quirk A11) are consumed in landmark order: failures are ranked with a workgroup prefix, thread 0 advances the
 // stream's glibc generator by the number of failures.
-__global__ __launch_bounds__(64) void k_depth_innovate(Pipe p) {
+__global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (p.det_mode[s] == 0) return;
-  const int lane = threadIdx.x;
+  const int i = threadIdx.x;
   const int cur = st.cur;
   Landmark* lms = lm_ptr(p, cur, s);
   const int n = st.n_lm[cur];
-  __shared__ double meas[NMAX][3];
-  __shared__ unsigned char mok[NMAX];
-  __shared__ short frank[NMAX];
   __shared__ float rnd[NMAX];
+  __shared__ int s_cnt[NMAX / 64];
   const float* p1 = p.next_pts + (size_t)s * NMAX * 2;
   const uint8_t* status = p.lk_status + (size_t)s * NMAX;
   const double range = (double)p.cam.range;
-  int nfail = 0;
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    bool fail = false;
-    if (i < n) {
-      bool ok = false;
-      if (status[i] == 1) {
-        float src[2] = {p1[2 * i], p1[2 * i + 1]}, u1[2];
-        undistort_point(src, p.cam.K1, p.cam.D1, p.cam.R1, p.cam.P1, u1);
-        float u0x = (float)lms[i].p2u[0], u0y = (float)lms[i].p2u[1];
-        V3 pc = triangulate_dlt((double)u0x, (double)u0y, (double)u1[0], (double)u1[1], p.cam.P0, p.cam.P1);
-        if (!(pc.z < 0 || pc.z > range)) {
-          meas[i][0] = pc.x;
-          meas[i][1] = pc.y;
-          meas[i][2] = pc.z;
-          ok = true;
-        }
+  const bool valid = i < n;
+  Landmark lm;
+  bool ok = false;
+  V3 meas{0, 0, 0};
+  if (valid) {
+    lm = lms[i];
+    if (status[i] == 1) {
+      float src[2] = {p1[2 * i], p1[2 * i + 1]}, u1[2];
+      undistort_point(src, p.cam.K1, p.cam.D1, p.cam.R1, p.cam.P1, u1);
+      float u0x = (float)lm.p2u[0], u0y = (float)lm.p2u[1];
+      V3 pc = triangulate_dlt((double)u0x, (double)u0y, (double)u1[0], (double)u1[1], p.cam.P0, p.cam.P1);
+      if (!(pc.z < 0 || pc.z > range)) {
+        meas = pc;
+        ok = true;
       }
-      mok[i] = ok;
-      fail = !ok;
     }
-    unsigned long long b = __ballot(fail);
-    if (fail) frank[i] = (short)(nfail + lane_prefix(b));
-    nfail += __popcll(b);
   }
-  __syncthreads();
-  if (lane == 0)
+  int nfail;
+  const int frank = block_rank<NMAX / 64>(valid && !ok, s_cnt, nfail);
+  if (i == 0)
     for (int k = 0; k < nfail; k++)
       rnd[k] = (float)(0.3 + (double)((float)glibc_rand_next(st) / ((float)(2147483647 / (0.4)))));
   __syncthreads();
-  const SE3d T = load_pose7(st.T_c_w[cur]);
-  const SE3d Tinv = se3_inverse(T);
-  const unsigned char* tmask = p.tri_mask + (size_t)s * NMAX;
-  const double* tri = p.tri + (size_t)s * NMAX * 3;
-  const float iir = p.cam.iir_ratio;
-  for (int i = lane; i < n; i += 64) {
-    Landmark& lm = lms[i];
-    if (!mok[i]) {
-      double depth = (double)rnd[frank[i]];
+  if (valid) {
+    const SE3d T = load_pose7(st.T_c_w[cur]);
+    const SE3d Tinv = se3_inverse(T);
+    const float iir = p.cam.iir_ratio;
+    const bool tm = p.tri_mask[(size_t)s * NMAX + i] != 0;
+    if (!ok) {
+      double depth = (double)rnd[frank];
       float u0x = (float)lm.p2u[0], u0y = (float)lm.p2u[1];
-      meas[i][0] = ((double)u0x - p.cam.cx) * depth / p.cam.fx;
-      meas[i][1] = ((double)u0y - p.cam.cy) * depth / p.cam.fy;
-      meas[i][2] = depth;
+      meas = V3{((double)u0x - p.cam.cx) * depth / p.cam.fx, ((double)u0y - p.cam.cy) * depth / p.cam.fy, depth};
     }
-    V3 m;
-    if (!mok[i] && !tmask[i]) {
+    if (!ok && !tm) {
       if (!lm.has3d && p.cam.enable_dummy) {
-        m = V3{meas[i][0], meas[i][1], meas[i][2]};
+        V3 pw = se3_act(Tinv, meas);
+        lm.p3c[0] = meas.x; lm.p3c[1] = meas.y; lm.p3c[2] = meas.z;
+        lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;
+        lm.has3d = 1;
+      }
+    } else {
+      V3 m = meas;
+      if (!ok) {
+        const double* tri = p.tri + ((size_t)s * NMAX + i) * 3;
+        m = V3{tri[0], tri[1], tri[2]};
+      }
+      if (lm.has3d) {
+        V3 lc = se3_act(T, V3{lm.p3w[0], lm.p3w[1], lm.p3w[2]});
+        V3 upd = lc * (double)iir + m * (double)(1 - iir);
+        V3 pw = se3_act(Tinv, upd);
+        lm.p3c[0] = upd.x; lm.p3c[1] = upd.y; lm.p3c[2] = upd.z;
+        lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;
+      } else {
         V3 pw = se3_act(Tinv, m);
         lm.p3c[0] = m.x; lm.p3c[1] = m.y; lm.p3c[2] = m.z;
         lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;
         lm.has3d = 1;
       }
-      continue;
-    }
-    if (mok[i])
-      m = V3{meas[i][0], meas[i][1], meas[i][2]};
-    else
-      m = V3{tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]};
-    if (lm.has3d) {
-      V3 lc = se3_act(T, V3{lm.p3w[0], lm.p3w[1], lm.p3w[2]});
-      V3 upd = lc * (double)iir + m * (double)(1 - iir);
-      V3 pw = se3_act(Tinv, upd);
-      lm.p3c[0] = upd.x; lm.p3c[1] = upd.y; lm.p3c[2] = upd.z;
-      lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;
-    } else {
-      V3 pw = se3_act(Tinv, m);
-      lm.p3c[0] = m.x; lm.p3c[1] = m.y; lm.p3c[2] = m.z;
-      lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;
-      lm.has3d = 1;
     }
   }
-  __syncthreads();
-  // eraseNoDepthPoint (order preserving)
-  int kept = 0;
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    bool keep = i < n && lms[i].has3d;
-    Landmark lm;
-    if (keep) lm = lms[i];
-    unsigned long long b = __ballot(keep);
-    __syncthreads();
-    if (keep) lms[kept + lane_prefix(b)] = lm;
-    kept += __popcll(b);
-    __syncthreads();
-  }
-  if (lane == 0) st.n_lm[cur] = kept;
+  // eraseNoDepthPoint (order preserving): every landmark was read above, the barriers inside block_rank separate the
+  // reads from the compacted writes
+  int kept;
+  const bool keep = valid && lm.has3d;
+  const int k = block_rank<NMAX / 64>(keep, s_cnt, kept);
+  if (keep) lms[k] = lm;
+  if (i == 0) st.n_lm[cur] = kept;
 }
 
 // ------------------------------------------------------------------------------------------------ frame end
 // init_frame's success test, keyframe decision (f2f_tracking.cpp:329-354,442-452), outputs, KeyFrame payload.
-__global__ __launch_bounds__(64) void k_frame_end(Pipe p, int frame_slot) {
+constexpr int FE_T = 256;
+__global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;  // (first wave does the scalar bookkeeping)
   __shared__ int s_newkf;
+  __shared__ int s_cnt[FE_T / 64];
   if (lane == 0) {
     s_newkf = 0;
     p.kf[s].valid = 0;  // this frame's keyframe slot: filled below only if the frame becomes a keyframe
@@ -1089,8 +1101,12 @@ __global__ __launch_bounds__(64) void k_frame_end(Pipe p, int frame_slot) {
     const int cur = st.cur;
     Landmark* lms = lm_ptr(p, cur, s);
     int valid = 0;
-    for (int i = lane; i < st.n_lm[cur]; i += 64) valid += (lms[i].has3d && lms[i].inlier) ? 1 : 0;
-    valid = wave_sum_i32(valid);
+    for (int base = 0; base < st.n_lm[cur]; base += FE_T) {
+      const int i = base + lane;
+      int tot;
+      block_rank<FE_T / 64>(i < st.n_lm[cur] && lms[i].has3d && lms[i].inlier, s_cnt, tot);
+      valid += tot;
+    }
     if (lane == 0) {
       if (valid > 30) {
         for (int j = 0; j < 7; j++) st.T_kf[j] = st.T_c_w[cur][j];
@@ -1143,12 +1159,13 @@ __global__ __launch_bounds__(64) void k_frame_end(Pipe p, int frame_slot) {
     Landmark* lms = lm_ptr(p, cur, s);
     const int n = st.n_lm[cur];
     int cnt = 0;
-    for (int base = 0; base < n; base += 64) {
+    for (int base = 0; base < n; base += FE_T) {
       int i = base + lane;
       bool sel = i < n && lms[i].has3d && lms[i].inlier;
-      unsigned long long b = __ballot(sel);
+      int tot;
+      const int rk = block_rank<FE_T / 64>(sel, s_cnt, tot);
       if (sel) {
-        int k = cnt + lane_prefix(b);
+        int k = cnt + rk;
         if (k < KF_MAXLM) {
           kf.lm_id[k] = lms[i].id;
           kf.lm_2d[k][0] = lms[i].p2u[0];
@@ -1158,7 +1175,7 @@ __global__ __launch_bounds__(64) void k_frame_end(Pipe p, int frame_slot) {
           kf.lm_3d[k][2] = lms[i].p3w[2];
         }
       }
-      cnt += __popcll(b);
+      cnt += tot;
     }
     if (lane == 0) {
       kf.frame_id = st.frame_id[cur];
@@ -1185,15 +1202,15 @@ void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ran
 void launch_track_post(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_track_post, dim3((p.S + 63) / 64), dim3(64), 0, st, p);
 }
-void launch_pose_lm(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_pose_lm, dim3(p.S), dim3(64), 0, st, p); }
-void launch_reproj_filter(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_reproj_filter, dim3(p.S), dim3(64), 0, st, p); }
+void launch_pose_lm(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_pose_lm, dim3(p.S), dim3(PL_T), 0, st, p); }
+void launch_reproj_filter(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_reproj_filter, dim3(p.S), dim3(NMAX), 0, st, p); }
 void launch_add_new(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_add_new, dim3(p.S), dim3(64), 0, st, p); }
 void launch_depth_prepare(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_depth_prepare, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
 }
-void launch_depth_innovate(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_depth_innovate, dim3(p.S), dim3(64), 0, st, p); }
+void launch_depth_innovate(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_depth_innovate, dim3(p.S), dim3(NMAX), 0, st, p); }
 void launch_frame_end(hipStream_t st, const Pipe& p, int frame_slot) {
-  hipLaunchKernelGGL(k_frame_end, dim3(p.S), dim3(64), 0, st, p, frame_slot);
+  hipLaunchKernelGGL(k_frame_end, dim3(p.S), dim3(FE_T), 0, st, p, frame_slot);
 }
 
 }  // namespace flvis

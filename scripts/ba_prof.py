@@ -42,7 +42,7 @@ for f in range(N):
 c = (C.c_int64 * 64)()
 lib.flvis_debug_counters(ctx._h, c)
 c = np.array(c[:])
-names = ["misc", "structure", "-", "linearize_lm", "linearize_pose+chi2", "-", "-", "schur", "cholesky+solve",
+names = ["misc", "structure", "-", "linearize_lm", "linearize_pose+chi2", "chol_factor", "tri_solves", "schur", "trial_poses",
          "update", "chi2_trial", "cull/finish"]
 runs, trials = max(c[8 + 15], 1), max(c[8 + 14], 1)
 print("ba runs %d  trials %d (%.1f/run)  edges/run %.0f  landmarks/run %.0f" % (runs, trials, trials / runs, c[8 + 16] / runs, c[8 + 17] / runs))
