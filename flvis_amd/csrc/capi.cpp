@@ -202,6 +202,7 @@ int flvis_hip_gftt(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img
   if (!d_img || !d_out_xy || !d_out_count || w < 8 || h < 8 || (w & 3) || n_img <= 0 || max_corners <= 0)
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "gftt: bad args");
   if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "gftt: image too large for the LDS bitmap");
+  if (min_distance > 64.0) return ctx->fail(FLVIS_ERR_CAPACITY, "gftt: minDistance > 64 is not supported");
   GfttScratch sc;
   int rc = gftt_scratch(ctx, w, h, n_img, sc);
   if (rc) return rc;

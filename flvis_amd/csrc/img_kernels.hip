@@ -4,7 +4,7 @@
 //   k_pyr_down                                 -> cv::pyrDown levels of calcOpticalFlowPyrLK's pyramids
 //                                                 (reference: src/processing/lkorb_tracking.cpp:64-73, camera_frame.cpp:124-128)
 //   k_eig<0> (max) / k_eig<1> (threshold+NMS)  -> cornerMinEigenVal + minMaxLoc + threshold + dilate==val
-//   k_sort_keys / k_select_mindist             -> sort by response + min-distance selection of cv::goodFeaturesToTrack
+//   k_gftt_pick                                -> ranked min-distance selection of cv::goodFeaturesToTrack (tiered top-K)
 //                                                 (reference: src/processing/feature_dem.cpp:160,221)
 //   k_feature_dem                              -> FeatureDEM::detect / ::redetect (feature_dem.cpp:92-266, quirks kept)
 //
@@ -306,22 +306,25 @@ __global__ __launch_bounds__(256) void k_eig_nms(ImgSel src, int w, int h, int p
   }
 }
 
-// ------------------------------------------------------------------------------------------------ key sort
-// One workgroup (1024 threads) per stream sorts its keys ascending with a bitonic network; sub-sequences that fit the
-// 32 KB LDS window (4096 keys) are finished in LDS, wider strides go through L2.
+// ------------------------------------------------------------------------------------------------ ranked selection
+// cv::goodFeaturesToTrack's tail: sort the candidates by (response desc, offset desc) and walk them greedily, dropping a
+// candidate iff an already accepted corner lies at squared distance < minDist^2, until maxCorners are accepted.
+// With qualityLevel ~1e-3 an image yields tens of thousands of candidates but the walk stops after a few hundred, so the
+// candidates are NOT sorted as a whole: one workgroup per stream builds a 4096-bin histogram of the top 12 bits of the
+// (order-preserving) response, takes the highest bins that fit a 4096-key LDS tier, sorts only that tier (bitonic, in
+// LDS) and walks it; further tiers follow only while maxCorners is not reached.  Keys of one bin always travel together,
+// so the walk order is exactly the fully sorted order.  A single bin that overflows a tier (degenerate images) falls
+// back to the full bitonic sort through L2.  The accepted corners live in an LDS bitmap (w*h bits); a candidate tests
+// its 2R+1 rows against per-row chord masks of the disc (two 32-bit windows per row), the candidates of one 64-wide
+// batch are resolved against each other in rank order by a short fixed-point iteration over ballots.
 constexpr int SORT_T = 1024;
 constexpr int SORT_LDS = 4096;
+constexpr int PICK_BINS = 4096;
+constexpr int PICK_MAXR = 64;  // largest minDistance handled by the chord-mask walk (checked by the callers)
 
-__global__ __launch_bounds__(SORT_T) void k_sort_keys(unsigned long long* __restrict__ keys, int* __restrict__ nkeys,
-                                                      int cap, const int* __restrict__ active,
-                                                      unsigned* __restrict__ maxenc) {
-  const int s = blockIdx.x;
-  if (active && !active[s]) return;
-  if (threadIdx.x == 0) maxenc[s] = 0;  // both eig passes are done with it: hand it back zeroed
-  __shared__ unsigned long long sk[SORT_LDS];
-  unsigned long long* K = keys + (size_t)s * cap;
-  int n = nkeys[s];
-  if (n > cap) n = cap;
+// full ascending bitonic sort of K[0..np2) (np2 = n rounded up to a power of two, padded with ~0) using the 4096-key LDS
+// window sk; sub-sequences that fit the window are finished in LDS, wider strides go through L2
+__device__ void sort_keys_global(unsigned long long* __restrict__ K, int n, int cap, unsigned long long* sk) {
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
   if (np2 > cap) np2 = cap;  // cap is a power of two
@@ -329,7 +332,6 @@ __global__ __launch_bounds__(SORT_T) void k_sort_keys(unsigned long long* __rest
   __syncthreads();
   if (np2 <= 1) return;
   const int chunk = np2 < SORT_LDS ? np2 : SORT_LDS;
-  // phase A: sort each chunk completely in LDS (direction alternates by chunk index for the global network)
   for (int base = 0; base < np2; base += chunk) {
     for (int i = threadIdx.x; i < chunk; i += SORT_T) sk[i] = K[base + i];
     __syncthreads();
@@ -350,7 +352,6 @@ __global__ __launch_bounds__(SORT_T) void k_sort_keys(unsigned long long* __rest
     for (int i = threadIdx.x; i < chunk; i += SORT_T) K[base + i] = sk[i];
     __syncthreads();
   }
-  // phase B: remaining merge stages k > chunk
   for (int k = chunk << 1; k <= np2; k <<= 1) {
     int j = k >> 1;
     for (; j >= chunk; j >>= 1) {  // global strides
@@ -389,89 +390,249 @@ __global__ __launch_bounds__(SORT_T) void k_sort_keys(unsigned long long* __rest
   }
 }
 
-// ------------------------------------------------------------------------------------------------ min-distance selection
-// One wave per stream walks the sorted candidates in batches of 64 and reproduces goodFeaturesToTrack's greedy
-// grid rejection exactly: a candidate is dropped iff an already accepted corner lies at squared distance < minDist^2.
-// Accepted corners are kept in an LDS bitmap (w*h bits <= 46 KB); corners of one batch are resolved lane by lane.
-__global__ __launch_bounds__(64) void k_select_mindist(const unsigned long long* __restrict__ keys,
-                                                       int* __restrict__ nkeys, int cap, int w, int h,
-                                                       const int* __restrict__ max_corners_s, int max_corners,
-                                                       double min_distance, float* __restrict__ out_xy,
-                                                       int* __restrict__ out_n, int out_cap,
-                                                       const int* __restrict__ active) {
-  const int s = blockIdx.x;
-  if (active && !active[s]) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned bitmap[];  // ceil(w/32) words per row
-  const int wpr = (w + 31) >> 5;
-  for (int i = threadIdx.x; i < wpr * h; i += 64) bitmap[i] = 0;
+// ascending bitonic sort of the first m keys of sk (LDS), m <= SORT_LDS
+__device__ void sort_keys_lds(unsigned long long* sk, int m) {
+  int np2 = 1;
+  while (np2 < m) np2 <<= 1;
+  for (int i = m + threadIdx.x; i < np2; i += SORT_T) sk[i] = ~0ull;
   __syncthreads();
-  int n = nkeys[s];
-  if (n > cap) n = cap;
-  const int maxc = max_corners_s ? max_corners_s[s] : max_corners;
-  const unsigned long long* K = keys + (size_t)s * cap;
-  float* out = out_xy + (size_t)s * out_cap * 2;
-  const int lane = threadIdx.x;
-  const bool use_dist = min_distance >= 1.0;
-  const float md2 = (float)(min_distance * min_distance);
-  const int R = use_dist ? (int)__double2int_rn(min_distance) : 0;  // cell size; |dx|,|dy| < minDistance <= R (+0.5)
-  int accepted = 0;
-  for (int base = 0; base < n && (maxc <= 0 || accepted < maxc); base += 64) {
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < np2 / 2; t += SORT_T) {
+        int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        int l = i | j;
+        bool up = ((i & k) == 0);
+        unsigned long long a = sk[i], b = sk[l];
+        if ((a > b) == up) {
+          sk[i] = b;
+          sk[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+}
+
+struct PickState {
+  int accepted;
+  int chord[PICK_MAXR + 1];  // largest |dx| inside the disc at |dy|, -1: none
+};
+
+// greedy walk of m sorted keys (ascending = best first) by ONE wave; returns with ps.accepted updated
+__device__ void pick_walk(const unsigned long long* keys, int m, int w, int h, int wpr, unsigned* bitmap, int maxc, float md2,
+                          int R, bool use_dist, float* __restrict__ out, int out_cap, PickState& ps) {
+  const int lane = threadIdx.x & 63;
+  int accepted = ps.accepted;
+  for (int base = 0; base < m && (maxc <= 0 || accepted < maxc); base += 64) {
     const int i = base + lane;
-    bool valid = i < n;
+    const bool valid = i < m;
     int x = 0, y = 0;
     if (valid) {
-      unsigned off = (unsigned)(~K[i]);
+      unsigned off = (unsigned)(~keys[i]);
       y = off / (unsigned)w;
       x = off - y * w;
     }
     bool good = valid;
     if (good && use_dist) {
       for (int dy = -R; dy <= R && good; dy++) {
-        int yy = y + dy;
+        const int yy = y + dy;
         if (yy < 0 || yy >= h) continue;
-        for (int dx = -R; dx <= R; dx++) {
-          int xx = x + dx;
-          if (xx < 0 || xx >= w) continue;
-          float fdx = (float)dx, fdy = (float)dy;
-          if (fdx * fdx + fdy * fdy < md2) {
-            if (bitmap[yy * wpr + (xx >> 5)] & (1u << (xx & 31))) {
-              good = false;
-              break;
-            }
+        const int cw = ps.chord[dy < 0 ? -dy : dy];
+        if (cw < 0) continue;
+        int xa = x - cw, xb = x + cw;  // inclusive column range of the disc in this row
+        if (xa < 0) xa = 0;
+        if (xb >= w) xb = w - 1;
+        const unsigned* row = bitmap + yy * wpr;
+        for (int wd = xa >> 5; wd <= (xb >> 5); wd++) {
+          const int lo = (wd << 5) > xa ? 0 : (xa & 31), hi = ((wd << 5) + 31) < xb ? 31 : (xb & 31);
+          const unsigned mask = (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo);
+          if (row[wd] & mask) {
+            good = false;
+            break;
           }
         }
       }
     }
-    // resolve conflicts inside the batch in rank order
-    unsigned long long pending = __ballot(good);
+    // resolve the batch in rank order: cm = earlier lanes of the batch inside my disc; a lane is decided once all lanes
+    // of its cm are, and is accepted iff none of them was accepted
+    unsigned long long accmask = __ballot(good);
     if (use_dist) {
-      unsigned long long todo = pending;
-      while (todo) {
-        int k = __ffsll((long long)todo) - 1;
+      unsigned long long cm = 0;
+      const unsigned long long cand = accmask;
+      for (unsigned long long todo = cand; todo;) {
+        const int k = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        // lane k's decision is final now
-        int kg = __shfl((int)good, k, 64);
-        if (!kg) continue;
-        int kx = __shfl(x, k, 64), ky = __shfl(y, k, 64);
-        if (lane > k && good) {
+        const int kx = __builtin_amdgcn_readlane(x, k), ky = __builtin_amdgcn_readlane(y, k);
+        if (lane > k) {
           float fdx = (float)(x - kx), fdy = (float)(y - ky);
-          if (fdx * fdx + fdy * fdy < md2) good = false;
+          if (fdx * fdx + fdy * fdy < md2) cm |= 1ull << k;
         }
       }
-      pending = __ballot(good);
+      unsigned long long decided = ~cand;  // lanes without a candidate are decided (rejected)
+      unsigned long long acc = 0;
+      bool mine = !good;
+      while (true) {
+        bool now = false, a = false;
+        if (!mine && (cm & ~decided) == 0ull) {
+          now = true;
+          a = (cm & acc) == 0ull;
+        }
+        const unsigned long long bn = __ballot(now), ba = __ballot(now && a);
+        if (bn == 0ull) break;
+        decided |= bn;
+        acc |= ba;
+        if (now) {
+          mine = true;
+          good = a;
+        }
+      }
+      accmask = acc;
     }
-    int pos = accepted + lane_prefix(pending);
+    const int pos = accepted + lane_prefix(accmask);
     if (good && (maxc <= 0 || pos < maxc) && pos < out_cap) {
       out[2 * pos] = (float)x;
       out[2 * pos + 1] = (float)y;
       atomicOr(&bitmap[y * wpr + (x >> 5)], 1u << (x & 31));
     }
-    accepted += __popcll(pending);
+    accepted += __popcll(accmask);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+  ps.accepted = accepted;
+}
+
+__global__ __launch_bounds__(SORT_T) void k_gftt_pick(unsigned long long* __restrict__ keys, int* __restrict__ nkeys, int cap,
+                                                      int w, int h, const int* __restrict__ max_corners_s, int max_corners,
+                                                      double min_distance, float* __restrict__ out_xy,
+                                                      int* __restrict__ out_n, int out_cap, const int* __restrict__ active,
+                                                      unsigned* __restrict__ maxenc) {
+  const int s = blockIdx.x;
+  if (active && !active[s]) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char pick_smem[];
+  unsigned long long* sk = reinterpret_cast<unsigned long long*>(pick_smem);          // [SORT_LDS] tier
+  int* hist = reinterpret_cast<int*>(sk + SORT_LDS);                                   // [PICK_BINS + 1] suffix counts
+  unsigned* bitmap = reinterpret_cast<unsigned*>(hist + PICK_BINS + 8);                // ceil(w/32) words per row
+  __shared__ PickState ps;
+  __shared__ int s_lo, s_hi, s_m, s_full, s_fill;
+  const int tid = threadIdx.x;
+  if (tid == 0) maxenc[s] = 0;  // both eig passes are done with it: hand it back zeroed
+  int n = nkeys[s];
+  if (n > cap) n = cap;
+  const int maxc = max_corners_s ? max_corners_s[s] : max_corners;
+  unsigned long long* K = keys + (size_t)s * cap;
+  float* out = out_xy + (size_t)s * out_cap * 2;
+  const bool use_dist = min_distance >= 1.0;
+  const float md2 = (float)(min_distance * min_distance);
+  int R = use_dist ? (int)__double2int_rn(min_distance) : 0;  // |dx|,|dy| < minDistance <= R (+0.5)
+  if (R > PICK_MAXR) R = PICK_MAXR;  // (callers reject minDistance > PICK_MAXR)
+  const int wpr = (w + 31) >> 5;
+  for (int i = tid; i < wpr * h; i += SORT_T) bitmap[i] = 0;
+  for (int i = tid; i <= PICK_BINS; i += SORT_T) hist[i] = 0;
+  if (tid <= PICK_MAXR) {
+    int cw = -1;
+    if (tid <= R)
+      for (int dx = 0; dx <= R; dx++) {
+        float fdx = (float)dx, fdy = (float)tid;
+        if (fdx * fdx + fdy * fdy < md2) cw = dx;
+      }
+    ps.chord[tid] = cw;
+  }
+  if (tid == 0) {
+    ps.accepted = 0;
+    s_full = 0;
+  }
+  __syncthreads();
+  // histogram of the top 12 bits of the ordered response (bin 4095 = best)
+  for (int i = tid; i < n; i += SORT_T) atomicAdd(&hist[(unsigned)((~K[i]) >> 52)], 1);
+  __syncthreads();
+  // suffix sums: hist[b] <- number of keys with bin >= b (hist[PICK_BINS] = 0); 4 bins per thread + workgroup scan
+  {
+    const int b0 = PICK_BINS - 4 * (tid + 1);  // this thread's bins b0..b0+3, thread 0 owns the top four
+    const int c3 = hist[b0 + 3], c2 = hist[b0 + 2], c1 = hist[b0 + 1], c0 = hist[b0];
+    int mysum = c0 + c1 + c2 + c3, inc = mysum;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    __shared__ int wtot[SORT_T / 64];
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    int before = inc - mysum;  // keys in better bins
+    for (int k = 0; k < wv; k++) before += wtot[k];
+    hist[b0 + 3] = before + c3;
+    hist[b0 + 2] = before + c3 + c2;
+    hist[b0 + 1] = before + c3 + c2 + c1;
+    hist[b0] = before + mysum;
+  }
+  __syncthreads();
+  int hi = PICK_BINS;  // bins >= hi are consumed
+  bool sorted_all = false;
+  while (true) {
+    if (tid == 0) {
+      int lo = hi, m = 0;
+      if (!s_full && hi > 0) {
+        // lowest lo with count(lo..hi-1) <= SORT_LDS: binary search on the monotone suffix counts
+        const int basec = hist[hi];
+        int a = 0, b = hi - 1;  // answer in [a, hi-1] if bin hi-1 alone fits
+        if (hist[hi - 1] - basec > SORT_LDS) {
+          s_full = 1;
+        } else {
+          while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (hist[mid] - basec <= SORT_LDS) b = mid;
+            else a = mid + 1;
+          }
+          lo = a;
+          m = hist[lo] - basec;
+        }
+      }
+      s_lo = lo;
+      s_hi = hi;
+      s_m = m;
+    }
+    __syncthreads();
+    if (s_full) break;
+    const int lo = s_lo, m = s_m;
+    if (lo == hi) break;  // nothing left
+    // gather the tier (order irrelevant: sorted next)
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += SORT_T) {
+      const unsigned long long k = K[i];
+      const int bin = (int)((~k) >> 52);
+      if (bin >= lo && bin < hi) sk[atomicAdd(&s_fill, 1)] = k;
+    }
+    __syncthreads();
+    sort_keys_lds(sk, m);
+    if (tid < 64) pick_walk(sk, m, w, h, wpr, bitmap, maxc, md2, R, use_dist, out, out_cap, ps);
+    __syncthreads();
+    hi = lo;
+    if ((maxc > 0 && ps.accepted >= maxc) || hi == 0) {
+      sorted_all = true;
+      break;
+    }
+  }
+  if (!sorted_all && s_full) {
+    // degenerate response distribution (or a very large minDistance): full sort, then walk the sorted array; corners
+    // accepted by earlier tiers stay (their keys come first again and are re-walked against an emptied bitmap)
+    for (int i = tid; i < wpr * h; i += SORT_T) bitmap[i] = 0;
+    if (tid == 0) ps.accepted = 0;
+    __syncthreads();
+    sort_keys_global(K, n, cap, sk);
+    __syncthreads();
+    if (tid < 64) {
+      for (int base = 0; base < n && (maxc <= 0 || ps.accepted < maxc); base += SORT_LDS) {
+        const int m = (n - base) < SORT_LDS ? (n - base) : SORT_LDS;
+        pick_walk(K + base, m, w, h, wpr, bitmap, maxc, md2, R, use_dist, out, out_cap, ps);
+      }
+    }
     __syncthreads();
   }
-  if (maxc > 0 && accepted > maxc) accepted = maxc;
-  if (accepted > out_cap) accepted = out_cap;
-  if (lane == 0) {
+  if (tid == 0) {
+    int accepted = ps.accepted;
+    if (maxc > 0 && accepted > maxc) accepted = maxc;
+    if (accepted > out_cap) accepted = out_cap;
     out_n[s] = accepted;
     nkeys[s] = 0;  // last consumer: hand the candidate counter back zeroed
   }
@@ -713,9 +874,9 @@ void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, siz
                      sstride, dst, dpitch, dstride, active);
 }
 
-// stage_events (optional): 8 events = (begin, end) for eig_max, eig_nms, sort_keys, select_mindist.
+// stage_events (optional): 6 events = (begin, end) for eig_max, eig_nms, gftt_pick.
 // reset_counters: zero maxenc / nkeys first; a caller that allocated them zeroed and always runs the full chain can pass
-// false -- k_sort_keys / k_select_mindist hand them back zeroed.
+// false -- k_gftt_pick hands them back zeroed.
 void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, GfttScratch sc,
                  const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
                  float* out_xy, int* out_n, int out_cap, const int* active, hipEvent_t* ev, bool reset_counters) {
@@ -730,12 +891,11 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
   hipLaunchKernelGGL(k_eig_nms, grid, dim3(256), 0, st, src, w, h, pitch, sstride, (const unsigned*)sc.maxenc, qual_s,
                      quality, sc.keys, sc.nkeys, sc.cap, active);
   if (ev) hipEventRecord(ev[3], st), hipEventRecord(ev[4], st);
-  hipLaunchKernelGGL(k_sort_keys, dim3(S), dim3(SORT_T), 0, st, sc.keys, sc.nkeys, sc.cap, active, sc.maxenc);
-  if (ev) hipEventRecord(ev[5], st), hipEventRecord(ev[6], st);
-  size_t bm = (size_t)((w + 31) / 32) * h * sizeof(unsigned);
-  hipLaunchKernelGGL(k_select_mindist, dim3(S), dim3(64), bm, st, (const unsigned long long*)sc.keys, sc.nkeys, sc.cap, w, h,
-                     maxc_s, max_corners, min_distance, out_xy, out_n, out_cap, active);
-  if (ev) hipEventRecord(ev[7], st);
+  const size_t lds = sizeof(unsigned long long) * SORT_LDS + sizeof(int) * (PICK_BINS + 8) +
+                     (size_t)((w + 31) / 32) * h * sizeof(unsigned);
+  hipLaunchKernelGGL(k_gftt_pick, dim3(S), dim3(SORT_T), lds, st, sc.keys, sc.nkeys, sc.cap, w, h, maxc_s, max_corners,
+                     min_distance, out_xy, out_n, out_cap, active, sc.maxenc);
+  if (ev) hipEventRecord(ev[5], st);
 }
 
 void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
@@ -748,7 +908,7 @@ void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, siz
 
 hipError_t img_kernels_init() {
   // the selection bitmap may exceed the default 64 KB dynamic LDS window only for images > 512K pixels
-  return hipFuncSetAttribute((const void*)k_select_mindist, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  return hipFuncSetAttribute((const void*)k_gftt_pick, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }
 
 }  // namespace flvis

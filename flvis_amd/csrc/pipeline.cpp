@@ -51,11 +51,11 @@ struct Pipeline {
   bool ev_ba_armed[2] = {false, false};
   KeyFrameDev* kfbuf[2] = {nullptr, nullptr};
 };
-constexpr int PROF_STAGES = 21;  // every stage has its own (begin, end) event pair on the stream it runs on
+constexpr int PROF_STAGES = 20;  // every stage has its own (begin, end) event pair on the stream it runs on
 static const char* kStageNames[PROF_STAGES] = {
     "imu_feed+frame_begin", "ingest(copy/equalize)", "pyr_down x6", "track_prepare", "lk_track(temporal)", "track_collect",
-    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_max", "gftt:eig_nms", "gftt:sort_keys",
-    "gftt:select_mindist", "feature_dem+add_new", "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end",
+    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_max", "gftt:eig_nms", "gftt:pick",
+    "feature_dem+add_new", "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end",
     "ba_update", "ba_solve"};
 
 }  // namespace flvis
@@ -184,6 +184,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   if (ctx->pipe) flvis_pipeline_destroy_internal(ctx);
   const int w = cfg->image_width, h = cfg->image_height;
   if (w < 64 || h < 64 || (w & 15)) return ctx->fail(FLVIS_ERR_CONFIG, "image width must be a multiple of 16 and >= 64");
+  if (cfg->feature_para[5] > 64.0) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para6 (GFTT minDistance) > 64 is not supported");
   if (cfg->window_size > BA_WMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "window_size exceeds the LDS-resident solver (16)");
   if ((int)cfg->feature_para[3] * 2 > 2048) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para4 (gftt_num) must be <= 1024");
   if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "image too large for the GFTT LDS bitmap");
@@ -507,16 +508,16 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PE(9, st);
   // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners
   hipStreamWaitEvent(st, pl->ev_det, 0);
-  PB(14, st);
+  PB(13, st);
   launch_feature_dem(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num,
                      p.det_mode, p.exist_xy, p.n_exist, NMAX, p.new_xy, p.n_new, NEW_MAX);
   launch_add_new(st, p);
-  PE(14, st);
+  PE(13, st);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
-  PB(15, st);
+  PB(14, st);
   launch_depth_prepare(st, p);
-  PE(15, st);
-  PB(16, st);
+  PE(14, st);
+  PB(15, st);
   {
     PyrSel prev, next;
     fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 0, pl->levels_s);
@@ -524,30 +525,30 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode);
   }
-  PE(16, st);
-  PB(17, st);
+  PE(15, st);
+  PB(16, st);
   launch_depth_innovate(st, p);
-  PE(17, st);
+  PE(16, st);
   const int par = (int)(pl->frames_fed & 1);
   p.kf = pl->kfbuf[par];  // this frame's keyframe slot; the local map may still be reading the other one
   if (pl->ev_ba_armed[par]) hipStreamWaitEvent(st, pl->ev_ba[par], 0);  // BA of frame N-2 has released this slot
-  PB(18, st);
+  PB(17, st);
   launch_frame_end(st, p, (int)pl->frames_fed);
-  PE(18, st);
+  PE(17, st);
   if (with_local_map) {
     hipStream_t bs = pl->ba_stream;
     hipEventRecord(pl->ev_fe[par], st);
     hipStreamWaitEvent(bs, pl->ev_fe[par], 0);
-    PB(19, bs);
+    PB(18, bs);
     launch_ba_update(bs, p);
-    PE(19, bs);
-    PB(20, bs);
+    PE(18, bs);
+    PB(19, bs);
     launch_ba_solve(bs, p);
-    PE(20, bs);
+    PE(19, bs);
     hipEventRecord(pl->ev_ba[par], bs);
     pl->ev_ba_armed[par] = true;
   } else if (prof) {
-    for (int i = 19; i <= 20; i++) {
+    for (int i = 18; i <= 19; i++) {
       PB(i, st);
       PE(i, st);
     }
