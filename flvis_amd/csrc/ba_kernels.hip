@@ -169,11 +169,16 @@ FD void pose_to_g2o(const double* pose7, double* out7) {
 }
 
 // LocalMapNodeletClass::frame_callback up to (not including) the optimisation; one wave per stream
-__global__ __launch_bounds__(64) void k_ba_update(Pipe p) {
+__global__ __launch_bounds__(64) void k_ba_update(Pipe p, long long seq) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   WindowDev& w = p.win[s];
   const int lane = threadIdx.x;
+  // per-stream ordering across the two local-map streams: wait until launch seq-1 has released this window
+  if (lane == 0)
+    while (__hip_atomic_load(&p.ba_seq[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq - 1) __builtin_amdgcn_s_sleep(8);
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   if (lane == 0) w.solve = 0;
   if (!p.kf[s].valid) return;
   __syncthreads();
@@ -298,6 +303,8 @@ __global__ __launch_bounds__(64) void k_ba_update(Pipe p) {
 }
 
 
-void launch_ba_update(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ba_update, dim3(p.S), dim3(64), 0, st, p); }
+void launch_ba_update(hipStream_t st, const Pipe& p, long long seq) {
+  hipLaunchKernelGGL(k_ba_update, dim3(p.S), dim3(64), 0, st, p, seq);
+}
 
 }  // namespace flvis

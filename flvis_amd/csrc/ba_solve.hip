@@ -1077,10 +1077,20 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
   }
 }
 
-__global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p) {
+// releases the stream's window to the next local-map launch (see Pipeline::ba_stream)
+FD void ba_release(const Pipe& p, int s, long long seq) {
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&p.ba_seq[s], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p, long long seq) {
   const int s = blockIdx.x;
   WindowDev& w = p.win[s];
-  if (!w.solve) return;
+  if (!w.solve) {
+    ba_release(p, s, seq);
+    return;
+  }
   BAShared& sh = ba_sh();
   const int W = p.cam.window;
   const int L = w.n_lm, E = w.n_edge;
@@ -1231,10 +1241,11 @@ __global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p) {
     }
   }
   BAPROF(11);
+  ba_release(p, s, seq);
 }
 
-void launch_ba_solve(hipStream_t st, const Pipe& p) {
-  hipLaunchKernelGGL(k_ba_solve, dim3(p.S), dim3(BA_T), BA_LDS_BUDGET, st, p);
+void launch_ba_solve(hipStream_t st, const Pipe& p, long long seq) {
+  hipLaunchKernelGGL(k_ba_solve, dim3(p.S), dim3(BA_T), BA_LDS_BUDGET, st, p, seq);
 }
 hipError_t ba_kernels_init() {
   return hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);

@@ -42,7 +42,12 @@ struct Pipeline {
   int prof_cap = 0, prof_step = 0;
   // local map on its own HIP stream: the BA of frame N overlaps the front-end of frame N+1 (its output is never fed
   // back into the tracker in the reference, src/frontend/vo_tracking.cpp:373-385).  Keyframe payloads are double-buffered.
-  hipStream_t ba_stream = nullptr;
+  // Two local-map streams alternate by frame parity so that the BA kernels of consecutive frames can be in flight
+  // together; the per-stream order (a window is updated strictly keyframe after keyframe) is enforced ON THE DEVICE by a
+  // sequence number per stream (Pipe::ba_seq): the bookkeeping kernel of launch q waits until launch q-1 has released
+  // that stream.  The launches are enqueued in order on independent hardware queues, so the wait always terminates.
+  hipStream_t ba_stream[2] = {nullptr, nullptr};
+  long long ba_launches = 0;
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
@@ -150,16 +155,18 @@ void glibc_seed(unsigned s, int* r34) {
 }  // namespace
 
 extern "C" void flvis_pipeline_sync_internal(flvis_ctx* ctx) {
-  if (ctx && ctx->pipe && ctx->pipe->ba_stream) hipStreamSynchronize(ctx->pipe->ba_stream);
+  for (int k = 0; k < 2; k++)
+    if (ctx && ctx->pipe && ctx->pipe->ba_stream[k]) hipStreamSynchronize(ctx->pipe->ba_stream[k]);
 }
 
 extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   if (!ctx || !ctx->pipe) return;
   Pipeline* pl = ctx->pipe;
-  if (pl->ba_stream) {
-    hipStreamSynchronize(pl->ba_stream);
-    hipStreamDestroy(pl->ba_stream);
-  }
+  for (int k = 0; k < 2; k++)
+    if (pl->ba_stream[k]) {
+      hipStreamSynchronize(pl->ba_stream[k]);
+      hipStreamDestroy(pl->ba_stream[k]);
+    }
   if (pl->det_stream) {
     hipStreamSynchronize(pl->det_stream);
     hipStreamDestroy(pl->det_stream);
@@ -266,6 +273,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   DA(kfs_ring, KeyFrameDev, (size_t)S * BA_WMAX);
   DA(corr, CorrectionDev, S);
   DA(counters, long long, 64);
+  DA(ba_seq, long long, S);
   p.ba_scratch_stride = ba_scratch_doubles();
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
   unsigned long long* seeds = dalloc<unsigned long long>(pl, S);
@@ -334,7 +342,8 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     flvis_pipeline_destroy_internal(ctx);
     return ctx->fail(FLVIS_ERR_HIP, "tracker_create: pinned allocation failed");
   }
-  bool evok = hipStreamCreateWithFlags(&pl->ba_stream, hipStreamNonBlocking) == hipSuccess &&
+  bool evok = hipStreamCreateWithFlags(&pl->ba_stream[0], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&pl->ba_stream[1], hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&pl->det_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&pl->ev_img, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&pl->ev_det, hipEventDisableTiming) == hipSuccess;
@@ -403,13 +412,15 @@ static int run_local_map(flvis_ctx* ctx) {
   Pipeline* pl = ctx->pipe;
   Pipe p = pl->pipe;
   p.kf = pl->kfbuf[0];
-  launch_ba_update(ctx->stream, p);
-  launch_ba_solve(ctx->stream, p);
+  const long long seq = ++pl->ba_launches;
+  launch_ba_update(ctx->stream, p, seq);
+  launch_ba_solve(ctx->stream, p, seq);
   return FLVIS_OK;
 }
 static void sync_all(flvis_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
-  if (ctx->pipe && ctx->pipe->ba_stream) hipStreamSynchronize(ctx->pipe->ba_stream);
+  for (int k = 0; k < 2; k++)
+    if (ctx->pipe && ctx->pipe->ba_stream[k]) hipStreamSynchronize(ctx->pipe->ba_stream[k]);
   if (ctx->pipe && ctx->pipe->det_stream) hipStreamSynchronize(ctx->pipe->det_stream);
 }
 
@@ -536,14 +547,15 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   launch_frame_end(st, p, (int)pl->frames_fed);
   PE(17, st);
   if (with_local_map) {
-    hipStream_t bs = pl->ba_stream;
+    hipStream_t bs = pl->ba_stream[par];
+    const long long seq = ++pl->ba_launches;
     hipEventRecord(pl->ev_fe[par], st);
     hipStreamWaitEvent(bs, pl->ev_fe[par], 0);
     PB(18, bs);
-    launch_ba_update(bs, p);
+    launch_ba_update(bs, p, seq);
     PE(18, bs);
     PB(19, bs);
-    launch_ba_solve(bs, p);
+    launch_ba_solve(bs, p, seq);
     PE(19, bs);
     hipEventRecord(pl->ev_ba[par], bs);
     pl->ev_ba_armed[par] = true;

@@ -45,6 +45,7 @@ struct Pipe {
   double* ba_scratch;       // [S][ba_scratch_stride]
   size_t ba_scratch_stride;
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
+  long long* ba_seq;        // [S] number of the last local-map launch that has released the stream's window
 };
 
 void launch_imu_feed(hipStream_t st, const Pipe& p);
@@ -61,8 +62,8 @@ void launch_depth_prepare(hipStream_t st, const Pipe& p);
 void launch_depth_innovate(hipStream_t st, const Pipe& p);
 void launch_frame_end(hipStream_t st, const Pipe& p, int frame_slot);
 // local map
-void launch_ba_update(hipStream_t st, const Pipe& p);
-void launch_ba_solve(hipStream_t st, const Pipe& p);
+void launch_ba_update(hipStream_t st, const Pipe& p, long long seq);
+void launch_ba_solve(hipStream_t st, const Pipe& p, long long seq);
 hipError_t ba_kernels_init();
 size_t ba_scratch_doubles();
 
