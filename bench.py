@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--streams", type=int, default=64, help="independent streams per GPU")
     ap.add_argument("--cpu-frames", type=int, default=80, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-local-map", action="store_true")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="split the GPU's streams over this many independent tracker contexts (own HIP streams each): the "
+                         "per-stream kernels are latency-bound, so sub-batches fed round-robin overlap on the GPU")
     args = ap.parse_args()
 
     import torch
@@ -69,9 +72,13 @@ def main():
     open(ypath, "w").write(synth.D435I_STEREO_YAML)
     cfg = flvis_amd.load_config(ypath)
     skip = cfg.skip_first_n_imgs
-    ctx = flvis_amd.Context(local_rank)
+    G = args.groups
+    assert S % G == 0, "--streams must be a multiple of --groups"
+    Sg = S // G
     nsteps = Wm + K
-    trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715 + rank * S, traj_capacity=nsteps)
+    ctxs = [flvis_amd.Context(local_rank, own_stream=(G > 1)) for _ in range(G)]
+    trks = [flvis_amd.Tracker(ctxs[g], cfg, Sg, seed_base=0xF1715 + rank * S + g * Sg, traj_capacity=nsteps) for g in range(G)]
+    ctx, trk = ctxs[0], trks[0]
     lib = ctx._lib
 
     # ---- synthetic inputs, resident before the timed region
@@ -102,15 +109,17 @@ def main():
     wlm = 0 if args.no_local_map else 1
 
     def step(f):
-        rc = lib.flvis_imu_feed_all(ctx._h, imu_cnt[f].ctypes.data_as(C.POINTER(C.c_int)),
-                                    imu[f].ctypes.data_as(C.POINTER(C.c_double)), SPF)
-        if rc:
-            ctx._check(rc, "imu_feed_all")
         i0, i1 = frames[f]
-        rc = lib.flvis_image_feed(ctx._h, C.c_void_p(i0.data_ptr()), C.c_void_p(i1.data_ptr()),
-                                  times[f].ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(0), wlm)
-        if rc:
-            ctx._check(rc, "image_feed")
+        for g in range(G):
+            a, b = g * Sg, (g + 1) * Sg
+            rc = lib.flvis_imu_feed_all(ctxs[g]._h, imu_cnt[f, a:b].ctypes.data_as(C.POINTER(C.c_int)),
+                                        imu[f, a:b].ctypes.data_as(C.POINTER(C.c_double)), SPF)
+            if rc:
+                ctxs[g]._check(rc, "imu_feed_all")
+            rc = lib.flvis_image_feed(ctxs[g]._h, C.c_void_p(i0[a:b].data_ptr()), C.c_void_p(i1[a:b].data_ptr()),
+                                      times[f, a:b].ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(0), wlm)
+            if rc:
+                ctxs[g]._check(rc, "image_feed")
 
     def barrier():
         if world > 1:
@@ -119,7 +128,8 @@ def main():
     for f in range(Wm):
         step(f)
     torch.cuda.synchronize()
-    ctx._check(lib.flvis_prof_enable(ctx._h, K), "prof_enable")
+    for g in range(G):
+        ctxs[g]._check(lib.flvis_prof_enable(ctxs[g]._h, K), "prof_enable")
     barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -142,8 +152,8 @@ def main():
     nrec = C.c_int(0)
     ctx._check(lib.flvis_prof_read(ctx._h, ms, C.byref(nrec)), "prof_read")
     stages = {lib.flvis_prof_stage_name(i).decode(): ms[i] / max(nrec.value, 1) for i in range(nst)}
-    cnt = trk.counters()
-    rows = np.stack([trk.trajectory(i, Wm + K - 1, 1)[0] for i in range(S)])
+    cnt = [sum(c) for c in zip(*[t.counters() for t in trks])]
+    rows = np.stack([trks[i // Sg].trajectory(i % Sg, Wm + K - 1, 1)[0] for i in range(S)])
     tracking = int((rows[:, 8].astype(int) & 15 == 1).sum())
     kfs_total = cnt[1]
     # the path's only exchange: results, after the timed region: all-gather poses, all-reduce counters
@@ -166,7 +176,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "1xMI355X: batch of %d independent 640x480 synthetic stereo+IMU streams, full HIP "
                                    "front-end + batched Schur BA (BASELINE.json configs[3])" % S,
-                       "streams_per_gpu": S, "window_size": cfg.window_size, "local_map": bool(wlm),
+                       "streams_per_gpu": S, "contexts_per_gpu": G, "window_size": cfg.window_size, "local_map": bool(wlm),
                        "streams_tracking_at_end": tracking, "keyframes_in_run": int(kfs_total),
                        "ba_runs_in_run": int(cnt[2]), "gpu_ms_per_step_events": round(gpu_ms / K, 4)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -206,7 +216,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

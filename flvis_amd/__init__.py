@@ -53,9 +53,11 @@ def _ptr(t):
 
 
 class Context:
-    """Owns a flvis_ctx bound to one GPU and one HIP stream (torch's current stream by default)."""
+    """Owns a flvis_ctx bound to one GPU and one HIP stream: torch's current stream by default, the default stream with
+    use_torch_stream=False, or a private non-blocking stream with own_stream=True (several contexts then run concurrently;
+    inputs produced on torch's stream must be synchronised by the caller)."""
 
-    def __init__(self, device=0, use_torch_stream=True):
+    def __init__(self, device=0, use_torch_stream=True, own_stream=False):
         import torch
         self._lib = load_library()
         if not torch.cuda.is_available():
@@ -63,6 +65,8 @@ class Context:
         torch.cuda.set_device(device)
         self.device = torch.device("cuda", device)
         stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream) if use_torch_stream else C.c_void_p(0)
+        if own_stream:
+            stream = C.c_void_p(-1 & (2 ** 64 - 1))  # FLVIS_STREAM_NEW
         h = C.c_void_p(0)
         rc = self._lib.flvis_hip_create(C.c_int(device), stream, C.byref(h))
         if rc != FLVIS_OK:

@@ -94,7 +94,8 @@ __device__ __forceinline__ long long lk_wave_sum_wide(int v) {
   return ((long long)hi << 16) + (long long)lo;
 }
 
-__global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const float* __restrict__ prev_pts,
+// 4 waves per SIMD (<= 128 VGPRs): this kernel is latency-bound (PMC: VALU busy ~20%), occupancy is what pays
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lk_track(PyrSel prev, PyrSel next, const float* __restrict__ prev_pts,
                                                  float* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                  const int* __restrict__ count, int nmax, LKParams prm,
                                                  const int* __restrict__ active) {
@@ -216,8 +217,7 @@ __global__ __launch_bounds__(64) void k_lk_track(PyrSel prev, PyrSel next, const
           tY[c] = lk_s2{0, 0};
         }
       }
-      const long long iA11 = wave_sum_i64((long long)a11), iA12 = wave_sum_i64((long long)a12),
-                      iA22 = wave_sum_i64((long long)a22);
+      const long long iA11 = lk_wave_sum_wide(a11), iA12 = lk_wave_sum_wide(a12), iA22 = lk_wave_sum_wide(a22);
       const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
       float D = A11 * A22 - A12 * A12;
       const float minEig = __fdiv_rn(A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12),
