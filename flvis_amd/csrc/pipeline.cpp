@@ -455,6 +455,31 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   launch_imu_feed(st, p);
   launch_frame_begin(st, p, pl->d_time);
   PE(0, st);
+  if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {
+    // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
+    // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
+    p.kf = pl->kfbuf[(int)(pl->frames_fed & 1)];
+    PB(17, st);
+    launch_frame_end(st, p, (int)pl->frames_fed);
+    PE(17, st);
+    if (prof) {
+      for (int i = 1; i < PROF_STAGES; i++)
+        if (i != 17) {
+          PB(i, st);
+          PE(i, st);
+        }
+      pl->prof_step++;
+    }
+    pl->frames_fed++;
+    hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return ctx->hip_fail(e0, "image_feed launch");
+    if (h_out) {
+      e0 = hipMemcpyAsync(h_out, p.out, sizeof(FrameOut) * S, hipMemcpyDeviceToHost, st);
+      if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
+      if (e0 != hipSuccess) return ctx->hip_fail(e0, "image_feed readback");
+    }
+    return FLVIS_OK;
+  }
   // images -> level 0 of the stream's current slot (copy, or equalizeHist for EuRoC), then the pyramids
   ImgSel in0 = img_plain(d_img0), in1 = img_plain(d_img1);
   ImgSel l0cur{{pl->pyr0[0][0], pl->pyr0[1][0]}, p.img_slot, 0};
