@@ -155,13 +155,76 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       __syncthreads();
       lk_s2 tI[8], tX[8], tY[8];  // pixel pairs (c, c+1)
       int a11 = 0, a12 = 0, a22 = 0;
-      if (r < LK_WIN) {
+      // every pixel the Scharr stencil is evaluated at lies inside the image -> no border masks (wave-uniform test)
+      const bool interior = ipx >= 0 && ipx + 32 <= W - 1 && ipy >= 0 && ipy + 31 <= H - 1;
+      if (r < LK_WIN && interior) {
+        // packed 16-bit path: two columns per instruction (v_pk_*), weights applied with v_dot2c_i32_i16
         uint32_t d[4][5];
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
           for (int k = 0; k < 5; k++) d[j][k] = *reinterpret_cast<const uint32_t*>(patch + (r + j) * LK_PS + c0 + 4 * k);
-        // Scharr derivatives on window rows r (dr=0) and r+1 (dr=1), window cols c0..c0+16
+        const lk_s2 wT = lk_s2{(short)iw00, (short)iw01}, wB = lk_s2{(short)iw10, (short)iw11};
+        lk_s2 DX[2][9], DY[2][9];  // (v[2j], v[2j+1]) of window row r + dr
+#pragma unroll
+        for (int dr = 0; dr < 2; dr++) {
+          lk_s2 T0[10], T1[10];
+#pragma unroll
+          for (int j = 0; j < 10; j++) {
+            const lk_s2 A = __builtin_bit_cast(lk_s2, LK_PAIR(d[dr], 2 * j)), B = __builtin_bit_cast(lk_s2, LK_PAIR(d[dr + 1], 2 * j)),
+                        Cc = __builtin_bit_cast(lk_s2, LK_PAIR(d[dr + 2], 2 * j));
+            T0[j] = (A + Cc) * (short)3 + B * (short)10;
+            T1[j] = Cc - A;
+          }
+#pragma unroll
+          for (int j = 0; j < 9; j++) {
+            DX[dr][j] = T0[j + 1] - T0[j];
+            const lk_s2 T1o = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, T1[j + 1]),
+                                                                             __builtin_bit_cast(uint32_t, T1[j]), 0x05040302u));
+            DY[dr][j] = (T1[j + 1] + T1[j]) * (short)3 + T1o * (short)10;
+          }
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 8; c2++) {
+          int iv[2], ix[2], iy[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; hh++) {
+            const int c = 2 * c2 + hh;
+            lk_s2 x0, x1, y0, y1;  // (v[c], v[c+1]) of rows r, r+1
+            if (hh == 0) {
+              x0 = DX[0][c2]; x1 = DX[1][c2]; y0 = DY[0][c2]; y1 = DY[1][c2];
+            } else {
+              x0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[0][c2 + 1]), __builtin_bit_cast(uint32_t, DX[0][c2]), 0x05040302u));
+              x1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[1][c2 + 1]), __builtin_bit_cast(uint32_t, DX[1][c2]), 0x05040302u));
+              y0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[0][c2 + 1]), __builtin_bit_cast(uint32_t, DY[0][c2]), 0x05040302u));
+              y1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[1][c2 + 1]), __builtin_bit_cast(uint32_t, DY[1][c2]), 0x05040302u));
+            }
+            int ax = 1 << (W_BITS - 1), ay = 1 << (W_BITS - 1), ai = 1 << (W_BITS - 5 - 1);
+            ax = __builtin_amdgcn_sdot2(x0, wT, ax, false);
+            ax = __builtin_amdgcn_sdot2(x1, wB, ax, false);
+            ay = __builtin_amdgcn_sdot2(y0, wT, ay, false);
+            ay = __builtin_amdgcn_sdot2(y1, wB, ay, false);
+            ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[1], c + 1)), wT, ai, false);
+            ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[2], c + 1)), wB, ai, false);
+            const bool on = c0 + c < LK_WIN;  // window column 31 of the second half does not exist
+            ix[hh] = on ? (ax >> W_BITS) : 0;
+            iy[hh] = on ? (ay >> W_BITS) : 0;
+            iv[hh] = on ? (ai >> (W_BITS - 5)) : 0;
+          }
+          tI[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iv[1], (uint32_t)iv[0], 0x05040100u));
+          tX[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)ix[1], (uint32_t)ix[0], 0x05040100u));
+          tY[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iy[1], (uint32_t)iy[0], 0x05040100u));
+          a11 = __builtin_amdgcn_sdot2(tX[c2], tX[c2], a11, false);
+          a12 = __builtin_amdgcn_sdot2(tX[c2], tY[c2], a12, false);
+          a22 = __builtin_amdgcn_sdot2(tY[c2], tY[c2], a22, false);
+        }
+      } else if (r < LK_WIN) {
+        uint32_t d[4][5];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int k = 0; k < 5; k++) d[j][k] = *reinterpret_cast<const uint32_t*>(patch + (r + j) * LK_PS + c0 + 4 * k);
+        // Scharr derivatives on window rows r (dr=0) and r+1 (dr=1), window cols c0..c0+16; zero outside the image
         int dx[2][17], dy[2][17];
 #pragma unroll
         for (int dr = 0; dr < 2; dr++) {
@@ -188,15 +251,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           if (c0 + c < LK_WIN) {
             int i00 = LK_BYTE(d[1], c + 1), i01 = LK_BYTE(d[1], c + 2), i10 = LK_BYTE(d[2], c + 1),
                 i11 = LK_BYTE(d[2], c + 2);
-            int ival = descale_i(i00 * iw00 + i01 * iw01 + i10 * iw10 + i11 * iw11, W_BITS - 5);
-            int ixval = descale_i(dx[0][c] * iw00 + dx[0][c + 1] * iw01 + dx[1][c] * iw10 + dx[1][c + 1] * iw11, W_BITS);
-            int iyval = descale_i(dy[0][c] * iw00 + dy[0][c + 1] * iw01 + dy[1][c] * iw10 + dy[1][c + 1] * iw11, W_BITS);
+            // all factors fit 24 bits (pixels 8, weights 15, Scharr sums 13): full-rate 24-bit multiplies
+            int ival = descale_i(__mul24(i00, iw00) + __mul24(i01, iw01) + __mul24(i10, iw10) + __mul24(i11, iw11), W_BITS - 5);
+            int ixval = descale_i(__mul24(dx[0][c], iw00) + __mul24(dx[0][c + 1], iw01) + __mul24(dx[1][c], iw10) +
+                                      __mul24(dx[1][c + 1], iw11), W_BITS);
+            int iyval = descale_i(__mul24(dy[0][c], iw00) + __mul24(dy[0][c + 1], iw01) + __mul24(dy[1][c], iw10) +
+                                      __mul24(dy[1][c + 1], iw11), W_BITS);
             sI[c] = (short)ival;
             sX[c] = (short)ixval;
             sY[c] = (short)iyval;
-            a11 += ixval * ixval;
-            a12 += ixval * iyval;
-            a22 += iyval * iyval;
+            a11 += __mul24(ixval, ixval);
+            a12 += __mul24(ixval, iyval);
+            a22 += __mul24(iyval, iyval);
           } else {
             sI[c] = 0;
             sX[c] = 0;

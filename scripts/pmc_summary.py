@@ -9,14 +9,16 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 names = []
 for r in rows:
-    k = r["Kernel_Name"].split("(")[0][-34:]
+    if "flvis::" not in r["Kernel_Name"]:
+        continue
+    k = r["Kernel_Name"].split("flvis::")[1].split("(")[0]
     c = r["Counter_Name"]
     if c not in names:
         names.append(c)
     acc[k][c] += float(r["Counter_Value"])
     if c == names[0]:
         cnt[k] += 1
-print("%-36s %5s " % ("kernel", "n") + " ".join("%14s" % n[-14:] for n in names))
+print("%-20s %5s " % ("kernel", "n") + " ".join("%16s" % n[-16:] for n in names))
 for k in sorted(acc, key=lambda k: -acc[k].get(names[0], 0)):
     n = max(cnt[k], 1)
-    print("%-36s %5d " % (k, n) + " ".join("%14.0f" % (acc[k][c] / n) for c in names))
+    print("%-20s %5d " % (k, n) + " ".join("%16.0f" % (acc[k][c] / n) for c in names))
