@@ -63,6 +63,105 @@ window_size:       8
 """
 
 
+# EuRoC-MAV-like rig (type_of_vi 1: unrectified stereo with radial-tangential distortion, 752x480, equalizeHist): the
+# public sensor calibration of the EuRoC VI sensor (cam0/cam1 sensor.yaml of the dataset) in FLVIS's parameter names.
+_EUROC_T_IMU_MAVIMU = np.array([[0.0, 0.0, 1.0, 0.0], [0.0, -1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+_EUROC_T_B_C0 = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975],
+                          [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
+                          [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949],
+                          [0.0, 0.0, 0.0, 1.0]])
+_EUROC_T_B_C1 = np.array([[0.0125552670891, -0.999755099723, 0.0182237714554, -0.0198435579556],
+                          [0.999598781151, 0.0130119051815, 0.0251588363115, 0.0453689425024],
+                          [-0.0253898008918, 0.0179005838253, 0.999517347078, 0.00786212447038],
+                          [0.0, 0.0, 0.0, 1.0]])
+_EUROC_K0 = (458.654, 457.296, 367.215, 248.375)
+_EUROC_D0 = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+_EUROC_K1 = (457.587, 456.134, 379.999, 255.238)
+_EUROC_D1 = (-0.28368365, 0.07451284, -0.00010473, -3.55590700e-05)
+
+
+def _fmt44(m):
+    return "[" + ",\n ".join(", ".join("%.16g" % v for v in row) for row in m) + "]"
+
+
+EUROC_LIKE_YAML = """type_of_vi: 1
+image_width: 752
+image_height: 480
+T_imu_mavimu:
+%s
+cam0_intrinsics: [%s]
+cam0_distortion_coeffs: [%s]
+T_mavimu_cam0:
+%s
+cam1_intrinsics: [%s]
+cam1_distortion_coeffs: [%s]
+T_mavimu_cam1:
+%s
+is_lite_version:   False
+vifusion_para1: 0.1
+vifusion_para2: 0.01
+vifusion_para3: 0.001
+vifusion_para4: 0.001
+vifusion_para5: 0.3
+vifusion_para6: 0.1
+feature_para1: 30
+feature_para2: 20
+feature_para3: 5
+feature_para4: 1000
+feature_para5: 0.01
+feature_para6: 10
+dr_para1: 0.90
+dr_para2: 50
+dr_para3: 1.0
+output_sparse_map: True
+window_size:       10
+""" % (_fmt44(_EUROC_T_IMU_MAVIMU), ", ".join("%.16g" % v for v in _EUROC_K0), ", ".join("%.16g" % v for v in _EUROC_D0),
+       _fmt44(_EUROC_T_B_C0), ", ".join("%.16g" % v for v in _EUROC_K1), ", ".join("%.16g" % v for v in _EUROC_D1),
+       _fmt44(_EUROC_T_B_C1))
+
+
+class Rig:
+    """Stereo rig geometry for the renderer: intrinsics + radtan distortion per camera, camera0 -> body (R_i_c, t_i_c) and
+    camera1 in camera0 coordinates (R_c0_c1, t_c0_c1)."""
+
+    def __init__(self, width, height, K0, D0, K1, D1, T_i_c0, T_c0_c1):
+        self.width, self.height = width, height
+        self.K0, self.D0, self.K1, self.D1 = K0, D0, K1, D1
+        self.R_i_c, self.t_i_c = T_i_c0[:3, :3].copy(), T_i_c0[:3, 3].copy()
+        self.R_c0_c1, self.t_c0_c1 = T_c0_c1[:3, :3].copy(), T_c0_c1[:3, 3].copy()
+
+
+def d435_rig():
+    T_i_c = np.eye(4)
+    T_i_c[:3, :3] = R_I_C
+    T01 = np.eye(4)
+    T01[0, 3] = BASELINE
+    return Rig(W, H, (FX, FY, CX, CY), (0.0, 0.0, 0.0, 0.0), (FX, FY, CX, CY), (0.0, 0.0, 0.0, 0.0), T_i_c, T01)
+
+
+def euroc_rig():
+    T_i_c0 = _EUROC_T_IMU_MAVIMU @ _EUROC_T_B_C0
+    T01 = np.linalg.inv(_EUROC_T_B_C0) @ _EUROC_T_B_C1
+    return Rig(752, 480, _EUROC_K0, _EUROC_D0, _EUROC_K1, _EUROC_D1, T_i_c0, T01)
+
+
+def _pixel_rays(width, height, K, D):
+    """Unit-depth rays of every pixel of a radtan camera: inverts the distortion by fixed-point iteration (as
+    cv::undistortPoints does) so that the rendered image IS what the distorted camera would see."""
+    ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float64), torch.arange(width, dtype=torch.float64), indexing="ij")
+    xd, yd = (xs - K[2]) / K[0], (ys - K[3]) / K[1]
+    k1, k2, p1, p2 = D
+    x, y = xd.clone(), yd.clone()
+    if any(abs(v) > 0 for v in D):
+        for _ in range(40):
+            r2 = x * x + y * y
+            rad = 1 + k1 * r2 + k2 * r2 * r2
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x, y = (xd - dx) / rad, (yd - dy) / rad
+    return torch.stack([x, y, torch.ones_like(x)], -1)
+
+
 def make_textures(n_planes=5, seed=0xF1715000):
     """[n_planes, TEX, TEX] float32 in [0,255], periodic, band-limited (sum of octaves of bicubic value noise)."""
     out = []
@@ -139,11 +238,14 @@ class Trajectory:
         return np.array([rd - yd * np.sin(p), pd * np.cos(r) + yd * np.sin(r) * np.cos(p),
                          -pd * np.sin(r) + yd * np.cos(r) * np.cos(p)])
 
-    def T_c_w(self, t):
+    def T_c_w(self, t, rig=None):
         """Ground-truth world->camera0 (R, t)."""
-        R_w_c = self.R_w_i(t) @ R_I_C
+        R_i_c = R_I_C if rig is None else rig.R_i_c
+        t_i_c = np.zeros(3) if rig is None else rig.t_i_c
+        R_w_c = self.R_w_i(t) @ R_i_c
+        c = self.pos(t) + self.R_w_i(t) @ t_i_c
         R_c_w = R_w_c.T
-        return R_c_w, -R_c_w @ self.pos(t)
+        return R_c_w, -R_c_w @ c
 
 
 def imu_samples(traj, s, t0, t1, noise=True):
@@ -175,17 +277,20 @@ def flvis_to_d435i_sensor(acc_f, gyro_f):
 
 
 class Renderer:
-    def __init__(self, device="cpu", noise_sigma=2.0):
+    def __init__(self, device="cpu", noise_sigma=2.0, rig=None):
         self.dev = torch.device(device)
         self.tex = make_textures().to(self.dev)
-        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
-        self.rays_c = torch.stack([(xs - CX) / FX, (ys - CY) / FY, torch.ones_like(xs)], -1).to(self.dev)  # [H,W,3]
+        self.rig = rig if rig is not None else d435_rig()
+        g = self.rig
+        self.rays = [_pixel_rays(g.width, g.height, g.K0, g.D0).to(self.dev), _pixel_rays(g.width, g.height, g.K1, g.D1).to(self.dev)]
+        self.rays_c = self.rays[0]  # [H,W,3]
         self.noise_sigma = noise_sigma
 
-    def render(self, R_w_c, c_w, seed=None):
-        """R_w_c [S,3,3], c_w [S,3] (float64 tensors on device) -> uint8 [S,H,W]."""
+    def render(self, R_w_c, c_w, seed=None, cam=0):
+        """R_w_c [S,3,3], c_w [S,3] (float64 tensors on device) -> uint8 [S,H,W] as seen by camera `cam` of the rig."""
         S = R_w_c.shape[0]
-        d = torch.einsum("sij,hwj->shwi", R_w_c, self.rays_c)  # [S,H,W,3]
+        H, W = self.rig.height, self.rig.width
+        d = torch.einsum("sij,hwj->shwi", R_w_c, self.rays[cam])  # [S,H,W,3]
         best = torch.full((S, H, W), 1e30, dtype=torch.float64, device=self.dev)
         val = torch.full((S, H, W), 128.0, dtype=torch.float32, device=self.dev)
         for pi, (n, off, a, b) in enumerate(_PLANES):
@@ -218,14 +323,16 @@ class Renderer:
 
     def stereo_frame(self, trajs, t, frame_idx=0):
         """Renders img0, img1 ([S,H,W] uint8 each) for all trajectories at time t."""
-        Rs, c0, c1 = [], [], []
+        g = self.rig
+        R0, R1, c0, c1 = [], [], [], []
         for tr in trajs:
-            R_w_c = tr.R_w_i(t) @ R_I_C
-            p = tr.pos(t)
-            Rs.append(R_w_c)
-            c0.append(p)
-            c1.append(p + R_w_c @ np.array([BASELINE, 0.0, 0.0]))
-        Rw = torch.from_numpy(np.stack(Rs)).to(self.dev)
-        i0 = self.render(Rw, torch.from_numpy(np.stack(c0)).to(self.dev), seed=2 * frame_idx)
-        i1 = self.render(Rw, torch.from_numpy(np.stack(c1)).to(self.dev), seed=2 * frame_idx + 1)
+            R_w_i = tr.R_w_i(t)
+            R_w_c0 = R_w_i @ g.R_i_c
+            p0 = tr.pos(t) + R_w_i @ g.t_i_c
+            R0.append(R_w_c0)
+            c0.append(p0)
+            R1.append(R_w_c0 @ g.R_c0_c1)
+            c1.append(p0 + R_w_c0 @ g.t_c0_c1)
+        i0 = self.render(torch.from_numpy(np.stack(R0)).to(self.dev), torch.from_numpy(np.stack(c0)).to(self.dev), seed=2 * frame_idx, cam=0)
+        i1 = self.render(torch.from_numpy(np.stack(R1)).to(self.dev), torch.from_numpy(np.stack(c1)).to(self.dev), seed=2 * frame_idx + 1, cam=1)
         return i0, i1

@@ -35,27 +35,23 @@ def _cfgs():
     return cfg, ocfg
 
 
-def test_frontend_parity_two_streams(ctx):
-    """Closed-loop parity of the whole front-end against the oracle, two streams, 90 frames.
+def _cfgs_yaml(text, tag):
+    import flvis_amd
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_%s.yaml" % tag)
+    open(p, "w").write(text)
+    cfg = flvis_amd.load_config(p)
+    ocfg = O.RefConfig()
+    assert C.sizeof(ocfg) == C.sizeof(cfg)
+    C.memmove(C.byref(ocfg), C.byref(cfg), C.sizeof(cfg))  # identical layout: both sides get the SAME numbers
+    return cfg, ocfg
 
-    Two regimes, both asserted:
-      * LOCKSTEP -- every discrete decision is compared every frame (state, keyframe flag, landmark count, LK / F / PnP
-        inlier counts, landmark ids + flags, keyframe id lists) and must be identical, with poses within 1e-6, until the
-        first single-landmark disagreement;
-      * after the first float-ulp flip of an LK start point (a float cast of an fp64 projection: a 1e-12 pose difference
-        can move it by one ulp, LK then converges to a pixel position ~1e-4 px away) the two runs are two valid roundings
-        of the same computation: borderline threshold tests (1.5 x median reprojection error, depth range) may then differ
-        for single landmarks (and every later landmark id is shifted once the number of new features differs), so the
-        comparison becomes: same state / keyframe decisions, landmark and inlier counts within 10%, poses within 1e-3
-        (1 mm; the runs then track slightly different landmark sets).
-    LOCKSTEP must hold for at least 12 tracked frames on every stream (it holds for 20+)."""
+
+def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf):
     import flvis_amd
     from flvis_amd import synth
-    cfg, ocfg = _cfgs()
-    S, nframes = 2, 90
-    streams = [3, 140]
+    S = len(streams)
     trajs = [synth.Trajectory(s) for s in streams]
-    rnd = synth.Renderer("cuda")
+    rnd = synth.Renderer("cuda", rig=rig)
     seed_base = 0xF1715
     trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=seed_base, traj_capacity=nframes)
     refs = [O.Tracker(ocfg, seed_base + i) for i in range(S)]
@@ -113,10 +109,41 @@ def test_frontend_parity_two_streams(ctx):
                     assert np.allclose(gk["lm_3d"], wk["lm_3d"], atol=2e-3, rtol=0), where
                 else:
                     assert abs(len(gk["lm_id"]) - len(wk["lm_id"])) <= max(10, 0.1 * len(wk["lm_id"])), where
-    assert n_kf >= 4
-    assert min(lock_frames) >= 12, lock_frames
+    assert n_kf >= min_kf
+    assert min(lock_frames) >= min_lock, lock_frames
     rows = trk.trajectory(0, 0, nframes)
     assert np.allclose(rows[:, 0], np.arange(nframes) / synth.FRAME_HZ)
+
+
+
+
+def test_frontend_parity_two_streams(ctx):
+    """Closed-loop parity of the whole front-end against the oracle, two streams, 90 frames.
+
+    Two regimes, both asserted:
+      * LOCKSTEP -- every discrete decision is compared every frame (state, keyframe flag, landmark count, LK / F / PnP
+        inlier counts, landmark ids + flags, keyframe id lists) and must be identical, with poses within 1e-6, until the
+        first single-landmark disagreement;
+      * after the first float-ulp flip of an LK start point (a float cast of an fp64 projection: a 1e-12 pose difference
+        can move it by one ulp, LK then converges to a pixel position ~1e-4 px away) the two runs are two valid roundings
+        of the same computation: borderline threshold tests (1.5 x median reprojection error, depth range) may then differ
+        for single landmarks (and every later landmark id is shifted once the number of new features differs), so the
+        comparison becomes: same state / keyframe decisions, landmark and inlier counts within 10%, poses within 1e-3
+        (1 mm; the runs then track slightly different landmark sets).
+    LOCKSTEP must hold for at least 12 tracked frames on every stream (it holds for 20+)."""
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs()
+    _run_frontend_parity(ctx, cfg, ocfg, None, [3, 140], 90, 12, 4)
+
+
+def test_frontend_parity_euroc_mode(ctx):
+    """Same closed-loop comparison in EuRoC mode (type_of_vi 1): 752x480, equalizeHist on both images, unrectified stereo
+    with radial-tangential distortion (undistortPoints + stereoRectify'd projection matrices), no skipped frames, the
+    EuRoC feature parameters (1000 corners, quality 0.01, minDistance 10)."""
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
+    assert cfg.cam_type == 1 and cfg.need_equal_hist == 1 and cfg.image_width == 752
+    _run_frontend_parity(ctx, cfg, ocfg, synth.euroc_rig(), [9], 45, 8, 2)
 
 
 def test_local_map_parity(ctx):

@@ -55,3 +55,40 @@ def test_oracle_tracks_synthetic_stream():
     ate = _umeyama_ate(np.array(est), np.array(gt))
     path = np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum()
     assert ate < 0.05 * path + 0.01, (ate, path)                     # a few % of the distance travelled
+
+
+def test_oracle_tracks_euroc_like_stream():
+    """EuRoC mode (type_of_vi 1): unrectified stereo with radial-tangential distortion, 752x480, equalizeHist, no skipped
+    frames, window 10 -- the oracle initialises once the IMU filter is ready and follows ground truth."""
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_track_euroc.yaml")
+    open(p, "w").write(synth.EUROC_LIKE_YAML)
+    cfg = O.load_config(p)
+    assert cfg.cam_type == 1 and cfg.need_equal_hist == 1 and cfg.skip_first_n_imgs == 0 and cfg.image_width == 752
+    rig = synth.euroc_rig()
+    trk = O.Tracker(cfg, 11)
+    tr = synth.Trajectory(9)
+    rnd = synth.Renderer("cpu", rig=rig)
+    t_prev = -0.05
+    est, gt, states, kfs = [], [], [], 0
+    for f in range(40):
+        t = f / synth.FRAME_HZ
+        for s in synth.imu_samples(tr, 9, t_prev, t):
+            trk.imu(s[0], s[1:4], s[4:7])
+        t_prev = t
+        i0, i1 = rnd.stereo_frame([tr], t, f)
+        r = trk.image(t, i0[0].numpy(), i1[0].numpy())
+        states.append(r["state"])
+        if r["state"] != 1:
+            continue
+        kfs += r["new_keyframe"]
+        R, tt = G.pose7_to_Rt(r["pose7"])
+        Rg, tg = tr.T_c_w(t, rig)
+        est.append(-R.T @ tt)
+        gt.append(-Rg.T @ tg)
+    first = states.index(1)
+    assert first <= 12 and all(s == 1 for s in states[first:]), states
+    assert kfs >= 3
+    ate = _umeyama_ate(np.array(est), np.array(gt))
+    path = np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum()
+    assert ate < 0.05 * path + 0.01, (ate, path)
