@@ -131,81 +131,140 @@ __device__ inline V3 triangulate_two_view(double u1, double v1, double u2, doubl
 }
 
 // 7-point fundamental matrix: Hartley-normalised, Gauss-Jordan null space, cubic by bracketing.  x1/x2: [7][2]
-__device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], double (*F)[9]) {
+// 7-point fundamental matrix (Hartley normalisation, Gauss-Jordan null space with full pivoting, cubic in the pencil
+// parameter).  The 7x9 system lives in a per-lane LDS workspace `wk` (element (i,j) at wk[(9*i+j)*WS]): pivoting indexes
+// rows and columns dynamically, and a dynamically indexed local array would be placed in scratch memory (the elimination
+// then runs at memory latency: it was 85% of k_ransac_f).  Column bookkeeping uses bit masks / selects.
+#ifndef SP_STAMP
+#define SP_STAMP(i) do { } while (0)
+#endif
+template <int WS>
+__device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], double (*F)[9], double* wk) {
+#define SP_A(i, j) wk[(9 * (i) + (j)) * WS]
   double c1[2] = {0, 0}, c2[2] = {0, 0};
+#pragma unroll
   for (int i = 0; i < 7; i++) {
     c1[0] += x1[i][0];
     c1[1] += x1[i][1];
     c2[0] += x2[i][0];
     c2[1] += x2[i][1];
   }
+#pragma unroll
   for (int k = 0; k < 2; k++) {
     c1[k] /= 7;
     c2[k] /= 7;
   }
   double d1 = 0, d2 = 0;
+#pragma unroll
   for (int i = 0; i < 7; i++) {
     d1 += sqrt((x1[i][0] - c1[0]) * (x1[i][0] - c1[0]) + (x1[i][1] - c1[1]) * (x1[i][1] - c1[1]));
     d2 += sqrt((x2[i][0] - c2[0]) * (x2[i][0] - c2[0]) + (x2[i][1] - c2[1]) * (x2[i][1] - c2[1]));
   }
   if (d1 < 1e-12 || d2 < 1e-12) return 0;
   const double s1 = sqrt(2.0) * 7 / d1, s2 = sqrt(2.0) * 7 / d2;
-  double A[7][9];
+#pragma unroll
   for (int i = 0; i < 7; i++) {
     double u1 = (x1[i][0] - c1[0]) * s1, v1 = (x1[i][1] - c1[1]) * s1;
     double u2 = (x2[i][0] - c2[0]) * s2, v2 = (x2[i][1] - c2[1]) * s2;
-    A[i][0] = u2 * u1;
-    A[i][1] = u2 * v1;
-    A[i][2] = u2;
-    A[i][3] = v2 * u1;
-    A[i][4] = v2 * v1;
-    A[i][5] = v2;
-    A[i][6] = u1;
-    A[i][7] = v1;
-    A[i][8] = 1;
+    SP_A(i, 0) = u2 * u1;
+    SP_A(i, 1) = u2 * v1;
+    SP_A(i, 2) = u2;
+    SP_A(i, 3) = v2 * u1;
+    SP_A(i, 4) = v2 * v1;
+    SP_A(i, 5) = v2;
+    SP_A(i, 6) = u1;
+    SP_A(i, 7) = v1;
+    SP_A(i, 8) = 1;
   }
+  SP_STAMP(0);
   int pivcol[7];
-  bool used[9];
-  for (int j = 0; j < 9; j++) used[j] = false;
+  unsigned used = 0;
+#pragma unroll
   for (int r = 0; r < 7; r++) {
     int br = -1, bc = -1;
     double bv = 0;
-    for (int i = r; i < 7; i++)
+#pragma unroll
+    for (int i = r; i < 7; i++) {
+      double av[9];  // (all loads of a row are issued before the compare chain)
+#pragma unroll
+      for (int j = 0; j < 9; j++) av[j] = fabs(SP_A(i, j));
+#pragma unroll
       for (int j = 0; j < 9; j++)
-        if (!used[j] && fabs(A[i][j]) > bv) {
-          bv = fabs(A[i][j]);
+        if (!((used >> j) & 1u) && av[j] > bv) {
+          bv = av[j];
           br = i;
           bc = j;
         }
+    }
     if (bv < 1e-12) return 0;
-    if (br != r)
+    if (br != r) {
+      double ra[9], rb[9];
+#pragma unroll
       for (int j = 0; j < 9; j++) {
-        double tmp = A[r][j];
-        A[r][j] = A[br][j];
-        A[br][j] = tmp;
+        ra[j] = SP_A(r, j);
+        rb[j] = SP_A(br, j);
       }
-    used[bc] = true;
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        SP_A(r, j) = rb[j];
+        SP_A(br, j) = ra[j];
+      }
+    }
+    used |= 1u << bc;
     pivcol[r] = bc;
-    double inv = 1.0 / A[r][bc];
-    for (int j = 0; j < 9; j++) A[r][j] *= inv;
+    double inv = 1.0 / SP_A(r, bc);
+    double prow[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      prow[j] = SP_A(r, j) * inv;
+      SP_A(r, j) = prow[j];
+    }
+    double fcol[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) fcol[i] = SP_A(i, bc);
+#pragma unroll
     for (int i = 0; i < 7; i++)
       if (i != r) {
-        double f = A[i][bc];
-        if (f != 0)
-          for (int j = 0; j < 9; j++) A[i][j] -= f * A[r][j];
+        const double f = fcol[i];
+        if (f != 0) {
+          double row[9];
+#pragma unroll
+          for (int j = 0; j < 9; j++) row[j] = SP_A(i, j);
+#pragma unroll
+          for (int j = 0; j < 9; j++) SP_A(i, j) = row[j] - f * prow[j];
+        }
       }
   }
-  int freec[2], nf = 0;
+  SP_STAMP(1);
+  int freec[2] = {0, 0}, nf = 0;
+#pragma unroll
   for (int j = 0; j < 9; j++)
-    if (!used[j] && nf < 2) freec[nf++] = j;
+    if (!((used >> j) & 1u) && nf < 2) {
+      if (nf == 0) freec[0] = j;
+      else freec[1] = j;
+      nf++;
+    }
   double f1[9], f2[9];
+#pragma unroll
   for (int k = 0; k < 2; k++) {
-    double* fs = k == 0 ? f1 : f2;
-    for (int j = 0; j < 9; j++) fs[j] = 0;
-    fs[freec[k]] = 1;
-    for (int r = 0; r < 7; r++) fs[pivcol[r]] = -A[r][freec[k]];
+    double fs[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) fs[j] = (j == freec[k]) ? 1.0 : 0.0;
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+      const double v = -SP_A(r, freec[k]);
+#pragma unroll
+      for (int j = 0; j < 9; j++) fs[j] = (pivcol[r] == j) ? v : fs[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      if (k == 0) f1[j] = fs[j];
+      else f2[j] = fs[j];
+    }
   }
+#undef SP_A
   double Bm[9];
+#pragma unroll
   for (int j = 0; j < 9; j++) Bm[j] = f1[j] - f2[j];
   const double *a0 = f2, *a1 = f2 + 3, *a2 = f2 + 6, *b0 = Bm, *b1 = Bm + 3, *b2 = Bm + 6;
   double c[4];
@@ -213,32 +272,50 @@ __device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], 
   c[1] = det3(b0, a1, a2) + det3(a0, b1, a2) + det3(a0, a1, b2);
   c[2] = det3(b0, b1, a2) + det3(b0, a1, b2) + det3(a0, b1, b2);
   c[3] = det3(b0, b1, b2);
+  SP_STAMP(2);
   double roots[4];
   int nr = poly_real_roots(c, 3, roots);
+  SP_STAMP(3);
   int nm = 0;
-  for (int k = 0; k < nr && nm < 3; k++) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (k >= nr) break;
     double Fh[9];
+#pragma unroll
     for (int j = 0; j < 9; j++) Fh[j] = f2[j] + roots[k] * Bm[j];
     double T1[9] = {s1, 0, -s1 * c1[0], 0, s1, -s1 * c1[1], 0, 0, 1};
     double T2[9] = {s2, 0, -s2 * c2[0], 0, s2, -s2 * c2[1], 0, 0, 1};
     double tmp[9], Fo[9];
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
       for (int j = 0; j < 3; j++) {
         double s = 0;
+#pragma unroll
         for (int m = 0; m < 3; m++) s += Fh[3 * i + m] * T1[3 * m + j];
         tmp[3 * i + j] = s;
       }
     double nn = 0;
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
       for (int j = 0; j < 3; j++) {
         double s = 0;
+#pragma unroll
         for (int m = 0; m < 3; m++) s += T2[3 * m + i] * tmp[3 * m + j];
         Fo[3 * i + j] = s;
         nn += s * s;
       }
     if (!(nn > 0) || !isfinite(nn)) continue;
     double inv = 1.0 / sqrt(nn);
-    for (int j = 0; j < 9; j++) F[nm][j] = Fo[j] * inv;
+    // (static destination index: nm is 0, 1 or 2)
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const double v = Fo[j] * inv;
+      if (nm == 0) F[0][j] = v;
+      else if (nm == 1) F[1][j] = v;
+      else F[2][j] = v;
+    }
     nm++;
   }
   return nm;
@@ -258,7 +335,10 @@ FD float f_error(const double* F, double x1, double y1, double x2, double y2) {
 }
 
 // Grunert P3P: up to 4 (R, t) with X_cam = R P + t
-__device__ inline int p3p_grunert(const V3* P, const V3* f, M3* Rs, V3* ts) {
+// Calls fn(R, t) for every solution (X_cam = R P + t), in root order; returns their number.  Everything is statically
+// indexed (no solution arrays): indexed local arrays would live in scratch memory.
+template <class Fn>
+__device__ inline int p3p_grunert_each(const V3* P, const V3* f, Fn&& fn) {
   double a2 = dot(P[1] - P[2], P[1] - P[2]), b2 = dot(P[0] - P[2], P[0] - P[2]), c2 = dot(P[0] - P[1], P[0] - P[1]);
   if (b2 < 1e-20 || a2 < 1e-20 || c2 < 1e-20) return 0;
   double ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
@@ -274,7 +354,9 @@ __device__ inline int p3p_grunert(const V3* P, const V3* f, M3* Rs, V3* ts) {
   double roots[4];
   int nr = poly_real_roots(q, 4, roots);
   int ns = 0;
-  for (int k = 0; k < nr && ns < 4; k++) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (k >= nr) break;
     double v = roots[k];
     if (!(v > 0)) continue;
     double den = 2 * (cg - v * ca);
@@ -302,8 +384,7 @@ __device__ inline int p3p_grunert(const V3* P, const V3* f, M3* Rs, V3* ts) {
 #pragma unroll
       for (int j = 0; j < 3; j++)
         R.m[i][j] = vget(e1c, i) * vget(e1w, j) + vget(e2c, i) * vget(e2w, j) + vget(e3c, i) * vget(e3w, j);
-    Rs[ns] = R;
-    ts[ns] = X0 - R * P[0];
+    fn(R, X0 - R * P[0]);
     ns++;
   }
   return ns;

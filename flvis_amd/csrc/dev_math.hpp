@@ -327,46 +327,121 @@ __device__ inline int poly_roots_quadratic(const double* a, double* roots) {
   roots[1] = fmax(r0, r1);
   return 2;
 }
-// one bracketing level: roots of `a` (degree deg >= 3) given the real roots `crit` of its derivative
+// Horner on five register-resident coefficients; coefficients above the degree are 0, which leaves every intermediate
+// bit-identical to the degree-limited Horner (0 * x + a = a exactly for finite x)
+FD double poly_eval5(double a0, double a1, double a2, double a3, double a4, double x) {
+  double r = a4;
+  r = r * x + a3;
+  r = r * x + a2;
+  r = r * x + a1;
+  r = r * x + a0;
+  return r;
+}
+// one bracketing level: roots of `a` (degree deg >= 3) given the real roots `crit` of its derivative.
+// The coefficients and the knots live in registers (selects instead of indexed local arrays: indexed arrays end up in
+// scratch memory, and the ~60-step bisections of every root then run at memory latency).
 __device__ inline int poly_roots_bracket(const double* a, int deg, const double* crit, int nc, double* roots) {
+  const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = deg >= 4 ? a[4] : 0.0;
+  const double alead = deg >= 4 ? a4 : a3;
   double B = 0;
-  for (int i = 0; i < deg; i++) B = fmax(B, fabs(a[i] / a[deg]));
+  B = fmax(B, fabs(a0 / alead));
+  B = fmax(B, fabs(a1 / alead));
+  B = fmax(B, fabs(a2 / alead));
+  if (deg >= 4) B = fmax(B, fabs(a3 / alead));
   B += 1.0;
-  double knots[6];
-  int nk = 0;
-  knots[nk++] = -B;
-  for (int i = 0; i < nc; i++)
-    if (crit[i] > -B && crit[i] < B) knots[nk++] = crit[i];
-  knots[nk++] = B;
+  // knots: -B, the critical points inside (-B, B) in order, +B  (at most 5 values)
+  double k0 = -B, k1 = B, k2 = B, k3 = B, k4 = B;
+  int nk = 1;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (i < nc) {
+      const double c = crit[i];
+      if (c > -B && c < B) {
+        if (nk == 1) k1 = c;
+        else if (nk == 2) k2 = c;
+        else k3 = c;
+        nk++;
+      }
+    }
+  }
+  if (nk == 1) k1 = B;
+  else if (nk == 2) k2 = B;
+  else if (nk == 3) k3 = B;
+  else k4 = B;
+  nk++;
+  // the (up to 4) sign-change intervals are bisected TOGETHER: the chains are independent, so interleaving them hides the
+  // fp64 dependency latency of one chain behind the others; every chain performs exactly the sequential arithmetic
+  double lo[4], hi[4], flo[4], fhi[4];
+  bool bis[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    lo[i] = i == 0 ? k0 : (i == 1 ? k1 : (i == 2 ? k2 : k3));
+    hi[i] = i == 0 ? k1 : (i == 1 ? k2 : (i == 2 ? k3 : k4));
+    const bool on = i + 1 < nk;
+    flo[i] = on ? poly_eval5(a0, a1, a2, a3, a4, lo[i]) : 1.0;
+    fhi[i] = on ? poly_eval5(a0, a1, a2, a3, a4, hi[i]) : 1.0;
+    bis[i] = on && flo[i] != 0 && fhi[i] != 0 && ((flo[i] < 0) != (fhi[i] < 0));
+  }
+  {
+    bool run[4] = {bis[0], bis[1], bis[2], bis[3]};
+    for (int it = 0; it < 200 && (run[0] || run[1] || run[2] || run[3]); it++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (run[i]) {
+          const double mid = 0.5 * (lo[i] + hi[i]);
+          if (mid == lo[i] || mid == hi[i]) {
+            run[i] = false;
+          } else {
+            const double fm = poly_eval5(a0, a1, a2, a3, a4, mid);
+            if (fm == 0) {
+              lo[i] = hi[i] = mid;
+              run[i] = false;
+            } else if ((fm < 0) == (flo[i] < 0)) {
+              lo[i] = mid;
+              flo[i] = fm;
+            } else {
+              hi[i] = mid;
+            }
+          }
+        }
+      }
+    }
+  }
   int nr = 0;
-  for (int i = 0; i + 1 < nk; i++) {
-    double lo = knots[i], hi = knots[i + 1];
-    double flo = poly_eval(a, deg, lo), fhi = poly_eval(a, deg, hi);
-    if (flo == 0) {
-      if (nr == 0 || roots[nr - 1] != lo) roots[nr++] = lo;
-      continue;
-    }
-    if (fhi == 0) {
-      if (i + 2 == nk) roots[nr++] = hi;
-      continue;
-    }
-    if ((flo < 0) == (fhi < 0)) continue;
-    for (int it = 0; it < 200; it++) {
-      double mid = 0.5 * (lo + hi);
-      if (mid == lo || mid == hi) break;
-      double fm = poly_eval(a, deg, mid);
-      if (fm == 0) {
-        lo = hi = mid;
-        break;
-      }
-      if ((fm < 0) == (flo < 0)) {
-        lo = mid;
-        flo = fm;
+  double rprev = 0;  // roots[nr - 1]
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i + 1 < nk) {
+      const double klo = i == 0 ? k0 : (i == 1 ? k1 : (i == 2 ? k2 : k3));
+      const double khi = i == 0 ? k1 : (i == 1 ? k2 : (i == 2 ? k3 : k4));
+      bool emit = false;
+      double rv = 0;
+      if (bis[i]) {
+        emit = true;
+        rv = 0.5 * (lo[i] + hi[i]);
       } else {
-        hi = mid;
+        const double f0 = poly_eval5(a0, a1, a2, a3, a4, klo), f1 = poly_eval5(a0, a1, a2, a3, a4, khi);
+        if (f0 == 0) {
+          if (nr == 0 || rprev != klo) {
+            emit = true;
+            rv = klo;
+          }
+        } else if (f1 == 0) {
+          if (i + 2 == nk) {
+            emit = true;
+            rv = khi;
+          }
+        }
+      }
+      if (emit) {
+        if (nr == 0) roots[0] = rv;
+        else if (nr == 1) roots[1] = rv;
+        else if (nr == 2) roots[2] = rv;
+        else roots[3] = rv;
+        rprev = rv;
+        nr++;
       }
     }
-    roots[nr++] = 0.5 * (lo + hi);
   }
   return nr;
 }

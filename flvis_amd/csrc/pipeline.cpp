@@ -40,6 +40,7 @@ struct Pipeline {
   // optional per-stage HIP-event timing (flvis_prof_enable)
   std::vector<hipEvent_t> prof_ev;
   int prof_cap = 0, prof_step = 0;
+  unsigned long long prof_mask = ~0ull;  // stages that record events (an event record costs a few us on the GPU queue)
   // local map on its own HIP stream: the BA of frame N overlaps the front-end of frame N+1 (its output is never fed
   // back into the tracker in the reference, src/frontend/vo_tracking.cpp:373-385).  Keyframe payloads are double-buffered.
   // Two local-map streams alternate by frame parity so that the BA kernels of consecutive frames can be in flight
@@ -448,9 +449,9 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
   hipEvent_t* pev = prof ? &pl->prof_ev[(size_t)pl->prof_step * (2 * PROF_STAGES)] : nullptr;
 #define PB(i, strm) \
-  if (prof) hipEventRecord(pev[2 * (i)], strm)
+  if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i)], strm)
 #define PE(i, strm) \
-  if (prof) hipEventRecord(pev[2 * (i) + 1], strm)
+  if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i) + 1], strm)
   PB(0, st);
   launch_imu_feed(st, p);
   launch_frame_begin(st, p, pl->d_time);
@@ -511,7 +512,8 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     launch_pyr_down(ds, img_plain(pl->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1],
                     img_plain(pl->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
   launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, pl->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
-              (double)p.cam.gftt_dis, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num, p.gftt_act, prof ? &pev[2 * 10] : nullptr, false);
+              (double)p.cam.gftt_dis, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
+              (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
   hipEventRecord(pl->ev_det, ds);
   // temporal tracking
   PB(3, st);
@@ -617,9 +619,12 @@ int flvis_imu_feed_all(flvis_ctx* ctx, const int* h_counts, const double* h_samp
   return FLVIS_OK;
 }
 
-int flvis_prof_enable(flvis_ctx* ctx, int max_steps) {
+int flvis_prof_enable(flvis_ctx* ctx, int max_steps) { return flvis_prof_enable_stages(ctx, max_steps, ~0ull); }
+
+int flvis_prof_enable_stages(flvis_ctx* ctx, int max_steps, uint64_t stage_mask) {
   if (!ctx || !ctx->pipe || max_steps < 0) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
+  pl->prof_mask = stage_mask;
   sync_all(ctx);
   for (hipEvent_t e : pl->prof_ev) hipEventDestroy(e);
   pl->prof_ev.clear();
@@ -642,6 +647,8 @@ int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps) {
   for (int k = 0; k < pl->prof_step; k++)
     for (int i = 0; i < PROF_STAGES; i++) {
       float ms = 0;
+      if (!((pl->prof_mask >> i) & 1ull)) continue;
+      if (i >= 10 && i <= 12 && ((pl->prof_mask >> 10) & 7ull) != 7ull) continue;  // the GFTT chain is timed as a whole
       hipEventElapsedTime(&ms, pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i], pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i + 1]);
       h_ms_per_stage[i] += ms;
     }

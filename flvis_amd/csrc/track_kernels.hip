@@ -8,6 +8,21 @@
 // the same kernel sequence every frame (no host decisions, graph-capturable).  Latency-bound stages use one wave (or
 // one thread) per stream; the J^T J / J^T r assemblies are wave reductions (DPP/shuffle butterflies).
 #include "dev_common.hpp"
+#ifdef FLVIS_RANSAC_PROF
+// sub-phase stamps of the 7-point solver (lane 0 of the hypothesis wave), counters[40..]
+#define SP_STAMP(i)                                                                                      \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && g_sp_prof) {                                                                 \
+      long long now_ = (long long)wall_clock64();                                                        \
+      atomicAdd((unsigned long long*)&g_sp_prof[i], (unsigned long long)(now_ - g_sp_last));            \
+      g_sp_last = now_;                                                                                  \
+    }                                                                                                    \
+  } while (0)
+namespace flvis {
+static __device__ long long* g_sp_prof = nullptr;
+static __device__ long long g_sp_last = 0;
+}
+#endif
 #include "dev_geom.hpp"
 #include "track_kernels.hpp"
 #include "vi_motion.hpp"
@@ -239,15 +254,33 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
 // waves score the <= 192 models (a wave takes a model, its lanes stride the correspondences, ballot-popcount counts the
 // inliers) and the adaptive stop is replayed sequentially over the batch.  Only the mask is used
 // (lkorb_tracking.cpp:133-158).
+#ifdef FLVIS_RANSAC_PROF
+#define RPROF(base, i)                                                                                   \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && p.counters) {                                                                \
+      long long now_ = (long long)wall_clock64();                                                        \
+      atomicAdd((unsigned long long*)&p.counters[(base) + (i)], (unsigned long long)(now_ - tlast_));   \
+      tlast_ = now_;                                                                                     \
+    }                                                                                                    \
+  } while (0)
+#else
+#define RPROF(base, i) do { } while (0)
+#endif
+
 constexpr int RF_T = 1024;
 __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK || !st.ok) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef FLVIS_RANSAC_PROF
+  long long tlast_ = (long long)wall_clock64();
+  if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[24 + 7], 1ull);
+#endif
   const int n = st.n_surv;
   __shared__ float sm1[NMAX * 2], sm2[NMAX * 2];
   __shared__ double Fm[64 * 3][9];
+  __shared__ double spw[63 * 64];  // 7-point workspaces of the 64 hypothesis lanes (element-major: conflict-free)
   __shared__ int hnm[64], mcnt[64 * 3];
   __shared__ int hcnt[64], hmodel[64];
   __shared__ double bestF[9];
@@ -268,12 +301,22 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
   const unsigned long long seed = mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[st.cur]));
   const float thr2 = 25.0f;
   Landmark* to = lm_ptr(p, st.cur, s);
+  RPROF(24, 0);
   if (n > 7) {
     for (int base = 0; base < ctl[0]; base += 64) {
+#ifdef FLVIS_RANSAC_PROF
+      if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[24 + 6], 1ull);
+#endif
       if (wv == 0) {  // hypotheses of this batch
         const int iter = base + lane;
         int nm = -1;  // -1: beyond niters, -2: subset impossible (the reference loop stops)
         if (iter < ctl[0]) {
+#ifdef FLVIS_RANSAC_PROF
+          if (tid == 0) {
+            g_sp_prof = p.counters ? p.counters + 40 : nullptr;
+            g_sp_last = (long long)wall_clock64();
+          }
+#endif
           int idx[7];
           if (ransac_subset(seed, (unsigned)iter, n, 7, idx)) {
             double x1[7][2], x2[7][2];
@@ -284,7 +327,8 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
               x2[k][1] = sm2[2 * idx[k] + 1];
             }
             double F[3][9];
-            nm = seven_point(x1, x2, F);
+            nm = seven_point<64>(x1, x2, F, spw + lane);
+            SP_STAMP(4);
             for (int m = 0; m < nm; m++)
               for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
           } else {
@@ -294,6 +338,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
         hnm[lane] = nm;
       }
       __syncthreads();
+      RPROF(24, 1);
       for (int mi = wv; mi < 64 * 3; mi += RF_T / 64) {  // score the models
         const int hyp = mi / 3, m = mi - 3 * hyp;
         if (m >= hnm[hyp]) continue;
@@ -309,6 +354,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
         if (lane == 0) mcnt[mi] = good;
       }
       __syncthreads();
+      RPROF(24, 2);
       if (tid < 64) {  // best model of each hypothesis: first maximum in model order
         const int nm = hnm[tid];
         int cnt = nm == -2 ? -2 : (nm < 0 ? -1 : 0), model = 0;
@@ -345,6 +391,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
         ctl[1] = maxGood;
       }
       __syncthreads();
+      RPROF(24, 3);
     }
     // apply the winning model's mask with the reference's mirrored index
     if (ctl[2] >= 0) {
@@ -366,6 +413,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
       if (fc < 10) st.ok = 0;
     }
   }
+  RPROF(24, 4);
 }
 
 // ------------------------------------------------------------------------------------------------ PnP RANSAC
@@ -377,6 +425,10 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK || !st.ok) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef FLVIS_RANSAC_PROF
+  long long tlast_ = (long long)wall_clock64();
+  if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[32 + 7], 1ull);
+#endif
   const int cur = st.cur;
   Landmark* to = lm_ptr(p, cur, s);
   const int nl = st.n_lm[cur];
@@ -420,8 +472,12 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   const double fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
   const unsigned long long seed = mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[cur] + 1));
   const float t2 = 9.0f;
+  RPROF(32, 0);
   if (np >= modelPoints) {
     for (int base = 0; base < ctl[0]; base += 64) {
+#ifdef FLVIS_RANSAC_PROF
+      if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[32 + 6], 1ull);
+#endif
       if (wv == 0) {  // hypotheses of this batch: P3P on the first 3 sample points, the rest disambiguate
         const int iter = base + lane;
         int cnt = -1;  // -1: no model / beyond niters, -2: subset impossible, -3: model in hpose[lane], to be scored
@@ -434,33 +490,40 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
               V3 d{((double)s2d[2 * idx[k]] - cx) / fx, ((double)s2d[2 * idx[k] + 1] - cy) / fy, 1.0};
               f[k] = (1.0 / norm(d)) * d;
             }
-            M3 Rs[4];
-            V3 ts[4];
-            int ns = p3p_grunert(P, f, Rs, ts);
+            // the first solution with the smallest reprojection error on the remaining sample points wins
             int bk = -1;
             double be = 1.7976931348623157e308;
-            for (int k = 0; k < ns; k++) {
+            M3 R;
+            V3 t;
+            V3 Pm[2];
+            double zm[2][2];
+#pragma unroll
+            for (int m = 3; m < 5; m++) {
+              const int im = m < modelPoints ? idx[m] : idx[3];
+              Pm[m - 3] = V3{(double)s3d[3 * im], (double)s3d[3 * im + 1], (double)s3d[3 * im + 2]};
+              zm[m - 3][0] = (double)s2d[2 * im];
+              zm[m - 3][1] = (double)s2d[2 * im + 1];
+            }
+            int kk = 0;
+            p3p_grunert_each(P, f, [&](const M3& Rk, const V3& tk) {
               double e = 0;
-              for (int m = 3; m < modelPoints; m++) {
-                V3 Pm{(double)s3d[3 * idx[m]], (double)s3d[3 * idx[m] + 1], (double)s3d[3 * idx[m] + 2]};
-                V3 X = Rs[k] * Pm + ts[k];
+#pragma unroll
+              for (int m = 3; m < 5; m++) {
+                if (m >= modelPoints) break;
+                V3 X = Rk * Pm[m - 3] + tk;
                 double z = X.z ? 1. / X.z : 1;
-                double du = fx * X.x * z + cx - (double)s2d[2 * idx[m]], dv = fy * X.y * z + cy - (double)s2d[2 * idx[m] + 1];
+                double du = fx * X.x * z + cx - zm[m - 3][0], dv = fy * X.y * z + cy - zm[m - 3][1];
                 e += du * du + dv * dv;
               }
               if (e < be) {
                 be = e;
-                bk = k;
+                bk = kk;
+                R = Rk;
+                t = tk;
               }
-            }
+              kk++;
+            });
             if (bk >= 0) {
-              M3 R = Rs[0];
-              V3 t = ts[0];
-              for (int k = 1; k < 4; k++)
-                if (k == bk) {
-                  R = Rs[k];
-                  t = ts[k];
-                }
 #pragma unroll
               for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -477,6 +540,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
         hcnt[lane] = cnt;
       }
       __syncthreads();
+      RPROF(32, 1);
       for (int hy = wv; hy < 64; hy += RP_T / 64) {  // score the models: lanes stride the correspondences
         if (hcnt[hy] != -3) continue;
         M3 R;
@@ -501,6 +565,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
         if (lane == 0) hcnt[hy] = good;
       }
       __syncthreads();
+      RPROF(32, 2);
       if (tid == 0) {
         int niters = ctl[0], maxGood = ctl[1];
         for (int k = 0; k < 64; k++) {
@@ -524,6 +589,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
       __syncthreads();
     }
   }
+  RPROF(32, 3);
   if (wv != 0) return;  // mask + final refinement: one wave
   SE3d T = iterative ? load_pose7(st.guess) : se3_identity();
   if (iterative) T = se3_from_mat(q_to_mat(T.q), T.t);
@@ -604,6 +670,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
     st.pnp_cnt = inliers;
     if (inliers < 10) st.ok = 0;
   }
+  RPROF(32, 4);
 }
 
 // ------------------------------------------------------------------------------------------------ after tracking

@@ -140,6 +140,9 @@ int flvis_imu_feed_all(flvis_ctx* ctx, const int* h_counts, const double* h_samp
 /* Optional per-stage timing of flvis_image_feed with HIP events on the context's stream (for bench.py's roofline).
  * flvis_prof_enable(max_steps) arms it for the next max_steps frames; flvis_prof_read sums the elapsed ms per stage. */
 int flvis_prof_enable(flvis_ctx* ctx, int max_steps);
+/* Same, but only the stages whose bit is set in stage_mask record events (an event record costs a few microseconds on
+ * the GPU queue; timing all ~20 stages inflates a frame by ~10%). */
+int flvis_prof_enable_stages(flvis_ctx* ctx, int max_steps, uint64_t stage_mask);
 int flvis_prof_stage_count(void);
 const char* flvis_prof_stage_name(int i);
 int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps);

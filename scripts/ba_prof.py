@@ -50,3 +50,14 @@ tot = sum(c[8:8 + 12])
 for i, n in enumerate(names):
     print("%-16s %8.1f us/run  %5.1f%%" % (n, c[8 + i] / runs / 100.0, 100.0 * c[8 + i] / max(tot, 1)))
 print("total %.1f us/run (100 MHz counter assumed)" % (tot / runs / 100.0))
+
+if c[24 + 7] or c[32 + 7]:
+    for base, name, ph in ((24, "ransac_f", ["load", "generate", "score", "replay", "mask+count"]),
+                           (32, "ransac_pnp", ["gather", "generate", "score", "replay(+prev)", "mask+refine"])):
+        n = max(c[base + 7], 1)
+        print("%s: %d calls, %.2f batches/call: " % (name, c[base + 7], c[base + 6] / n) +
+              "  ".join("%s=%.1fus" % (nm, c[base + i] / n / 100.0) for i, nm in enumerate(ph)))
+
+if c[24 + 7]:
+    n = max(c[24 + 7], 1)
+    print("seven_point (thread 0): " + "  ".join("%s=%.1fus" % (nm, c[40 + i] / n / 100.0) for i, nm in enumerate(["subset+normalise", "eliminate", "nullspace+cubic coeffs", "cubic roots", "denormalise"])))
