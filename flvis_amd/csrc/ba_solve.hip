@@ -33,6 +33,11 @@
 
 namespace flvis {
 
+// g2o optimize(12) / optimize(8) of vo_localmap.cpp:296,345 (overridable for timing experiments only)
+#ifndef FLVIS_BA_IT1
+#define FLVIS_BA_IT1 12
+#define FLVIS_BA_IT2 8
+#endif
 constexpr int BA_T = 512;
 constexpr int BA_NW = BA_T / 64;
 constexpr int BA_PMAX = BA_WMAX - 1;   // free poses
@@ -1131,7 +1136,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p, long long seq) {
     for (int e = t; e < E; e += BA_T) sc.e_alive[e] = 1;
   }
   __syncthreads();
-  ba_optimize(w, 12);
+  ba_optimize(w, FLVIS_BA_IT1);
   __syncthreads();
   BAPROF(0);
   // chi2 > 3 cull (vo_localmap.cpp:301-317): reverse edge order => outlier ids by descending edge id
@@ -1168,7 +1173,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p, long long seq) {
   }
   __syncthreads();
   BAPROF(11);
-  ba_optimize(w, 8);
+  ba_optimize(w, FLVIS_BA_IT2);
   __syncthreads();
   BAPROF(0);
   const BAScratch sc = sh.sc;

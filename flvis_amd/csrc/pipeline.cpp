@@ -33,7 +33,13 @@ struct Pipeline {
   // host staging
   std::vector<double> h_imu;  // [S][IMU_MAX][7]
   std::vector<int> h_nimu;
-  void* pinned = nullptr;  // [S] times + imu + counts
+  // Host staging for the per-frame inputs (times, IMU samples, counts): a ring of pinned slots, each guarded by an event
+  // recorded after its upload, so that image_feed never has to wait for the previous frame -- the host then runs several
+  // frames ahead of the GPU and the ~45 launches of a frame are already queued when the GPU gets to them (with a per-frame
+  // stream synchronisation every short kernel was followed by a ~11 us launch bubble).
+  static constexpr int PIN_RING = 4;
+  void* pinned[PIN_RING] = {};
+  hipEvent_t ev_pin[PIN_RING] = {};
   size_t pinned_bytes = 0;
   long long frames_fed = 0;
   std::vector<void*> allocs;
@@ -43,19 +49,20 @@ struct Pipeline {
   unsigned long long prof_mask = ~0ull;  // stages that record events (an event record costs a few us on the GPU queue)
   // local map on its own HIP stream: the BA of frame N overlaps the front-end of frame N+1 (its output is never fed
   // back into the tracker in the reference, src/frontend/vo_tracking.cpp:373-385).  Keyframe payloads are double-buffered.
-  // Two local-map streams alternate by frame parity so that the BA kernels of consecutive frames can be in flight
+  // NBA local-map streams are used round-robin so that the BA kernels of consecutive frames can be in flight
   // together; the per-stream order (a window is updated strictly keyframe after keyframe) is enforced ON THE DEVICE by a
   // sequence number per stream (Pipe::ba_seq): the bookkeeping kernel of launch q waits until launch q-1 has released
   // that stream.  The launches are enqueued in order on independent hardware queues, so the wait always terminates.
-  hipStream_t ba_stream[2] = {nullptr, nullptr};
+  static constexpr int NBA = 4;  // local-map launches in flight
+  hipStream_t ba_stream[NBA] = {};
   long long ba_launches = 0;
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
   hipEvent_t ev_img = nullptr, ev_det = nullptr;
-  hipEvent_t ev_fe[2] = {nullptr, nullptr}, ev_ba[2] = {nullptr, nullptr};
-  bool ev_ba_armed[2] = {false, false};
-  KeyFrameDev* kfbuf[2] = {nullptr, nullptr};
+  hipEvent_t ev_fe[NBA] = {}, ev_ba[NBA] = {};
+  bool ev_ba_armed[NBA] = {};
+  KeyFrameDev* kfbuf[NBA] = {};
 };
 constexpr int PROF_STAGES = 20;  // every stage has its own (begin, end) event pair on the stream it runs on
 static const char* kStageNames[PROF_STAGES] = {
@@ -156,14 +163,14 @@ void glibc_seed(unsigned s, int* r34) {
 }  // namespace
 
 extern "C" void flvis_pipeline_sync_internal(flvis_ctx* ctx) {
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < Pipeline::NBA; k++)
     if (ctx && ctx->pipe && ctx->pipe->ba_stream[k]) hipStreamSynchronize(ctx->pipe->ba_stream[k]);
 }
 
 extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   if (!ctx || !ctx->pipe) return;
   Pipeline* pl = ctx->pipe;
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < Pipeline::NBA; k++)
     if (pl->ba_stream[k]) {
       hipStreamSynchronize(pl->ba_stream[k]);
       hipStreamDestroy(pl->ba_stream[k]);
@@ -174,13 +181,16 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   }
   if (pl->ev_img) hipEventDestroy(pl->ev_img);
   if (pl->ev_det) hipEventDestroy(pl->ev_det);
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < Pipeline::NBA; k++) {
     if (pl->ev_fe[k]) hipEventDestroy(pl->ev_fe[k]);
     if (pl->ev_ba[k]) hipEventDestroy(pl->ev_ba[k]);
   }
   for (void* p : pl->allocs) hipFree(p);
   for (hipEvent_t e : pl->prof_ev) hipEventDestroy(e);
-  if (pl->pinned) hipHostFree(pl->pinned);
+  for (int k = 0; k < Pipeline::PIN_RING; k++) {
+    if (pl->pinned[k]) hipHostFree(pl->pinned[k]);
+    if (pl->ev_pin[k]) hipEventDestroy(pl->ev_pin[k]);
+  }
   delete pl;
   ctx->pipe = nullptr;
 }
@@ -267,8 +277,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   DA(gftt_maxc, int, S);
   DA(img_slot, int, S);
   DA(out, FrameOut, S);
-  ok = ok && ((pl->kfbuf[0] = dalloc<KeyFrameDev>(pl, S)) != nullptr);
-  ok = ok && ((pl->kfbuf[1] = dalloc<KeyFrameDev>(pl, S)) != nullptr);
+  for (int k = 0; k < Pipeline::NBA; k++) ok = ok && ((pl->kfbuf[k] = dalloc<KeyFrameDev>(pl, S)) != nullptr);
   p.kf = pl->kfbuf[0];
   DA(win, WindowDev, S);
   DA(kfs_ring, KeyFrameDev, (size_t)S * BA_WMAX);
@@ -339,16 +348,21 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   pl->h_imu.assign((size_t)S * IMU_MAX * 7, 0.0);
   pl->h_nimu.assign(S, 0);
   pl->pinned_bytes = sizeof(double) * S + sizeof(double) * (size_t)S * IMU_MAX * 7 + sizeof(int) * S;
-  if (hipHostMalloc(&pl->pinned, pl->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+  bool pinok = true;
+  for (int k = 0; k < Pipeline::PIN_RING && pinok; k++)
+    pinok = hipHostMalloc(&pl->pinned[k], pl->pinned_bytes, hipHostMallocDefault) == hipSuccess &&
+            hipEventCreateWithFlags(&pl->ev_pin[k], hipEventDisableTiming) == hipSuccess;
+  if (!pinok) {
     flvis_pipeline_destroy_internal(ctx);
     return ctx->fail(FLVIS_ERR_HIP, "tracker_create: pinned allocation failed");
   }
-  bool evok = hipStreamCreateWithFlags(&pl->ba_stream[0], hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&pl->ba_stream[1], hipStreamNonBlocking) == hipSuccess &&
+  bool evok = true;
+  for (int k = 0; k < Pipeline::NBA && evok; k++) evok = hipStreamCreateWithFlags(&pl->ba_stream[k], hipStreamNonBlocking) == hipSuccess;
+  evok = evok &&
               hipStreamCreateWithFlags(&pl->det_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&pl->ev_img, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&pl->ev_det, hipEventDisableTiming) == hipSuccess;
-  for (int k = 0; k < 2 && evok; k++)
+  for (int k = 0; k < Pipeline::NBA && evok; k++)
     evok = hipEventCreateWithFlags(&pl->ev_fe[k], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&pl->ev_ba[k], hipEventDisableTiming) == hipSuccess;
   if (!evok) {
@@ -420,7 +434,7 @@ static int run_local_map(flvis_ctx* ctx) {
 }
 static void sync_all(flvis_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < Pipeline::NBA; k++)
     if (ctx->pipe && ctx->pipe->ba_stream[k]) hipStreamSynchronize(ctx->pipe->ba_stream[k]);
   if (ctx->pipe && ctx->pipe->det_stream) hipStreamSynchronize(ctx->pipe->det_stream);
 }
@@ -434,10 +448,11 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   hipStream_t st = ctx->stream;
   const int w = pl->cfg.image_width, h = pl->cfg.image_height;
   // ---- stage host inputs (pinned) and upload
-  double* pt = (double*)pl->pinned;
+  const int pslot = (int)(pl->frames_fed % Pipeline::PIN_RING);
+  double* pt = (double*)pl->pinned[pslot];
   double* pi = pt + S;
   int* pn = (int*)(pi + (size_t)S * IMU_MAX * 7);
-  hipStreamSynchronize(st);  // the previous frame's async copies read the pinned buffer
+  if (pl->frames_fed >= Pipeline::PIN_RING) hipEventSynchronize(pl->ev_pin[pslot]);  // upload of frame N-PIN_RING is done
   memcpy(pt, h_times, sizeof(double) * S);
   memcpy(pi, pl->h_imu.data(), sizeof(double) * (size_t)S * IMU_MAX * 7);
   memcpy(pn, pl->h_nimu.data(), sizeof(int) * S);
@@ -445,6 +460,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   hipMemcpyAsync(pl->d_time, pt, sizeof(double) * S, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(p.imu_in, pi, sizeof(double) * (size_t)S * IMU_MAX * 7, hipMemcpyHostToDevice, st);
   hipMemcpyAsync(p.n_imu, pn, sizeof(int) * S, hipMemcpyHostToDevice, st);
+  hipEventRecord(pl->ev_pin[pslot], st);
   // ---- fixed kernel sequence
   const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
   hipEvent_t* pev = prof ? &pl->prof_ev[(size_t)pl->prof_step * (2 * PROF_STAGES)] : nullptr;
@@ -459,7 +475,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
-    p.kf = pl->kfbuf[(int)(pl->frames_fed & 1)];
+    p.kf = pl->kfbuf[(int)(pl->frames_fed % Pipeline::NBA)];
     PB(17, st);
     launch_frame_end(st, p, (int)pl->frames_fed);
     PE(17, st);
@@ -567,9 +583,9 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PB(16, st);
   launch_depth_innovate(st, p);
   PE(16, st);
-  const int par = (int)(pl->frames_fed & 1);
+  const int par = (int)(pl->frames_fed % Pipeline::NBA);
   p.kf = pl->kfbuf[par];  // this frame's keyframe slot; the local map may still be reading the other one
-  if (pl->ev_ba_armed[par]) hipStreamWaitEvent(st, pl->ev_ba[par], 0);  // BA of frame N-2 has released this slot
+  if (pl->ev_ba_armed[par]) hipStreamWaitEvent(st, pl->ev_ba[par], 0);  // BA of frame N-NBA has released this slot
   PB(17, st);
   launch_frame_end(st, p, (int)pl->frames_fed);
   PE(17, st);
@@ -687,7 +703,7 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
   sync_all(ctx);
   std::vector<KeyFrameDev> kfv(1);
   KeyFrameDev& kf = kfv[0];
-  hipMemcpy(&kf, pl->kfbuf[(pl->frames_fed > 0 ? (pl->frames_fed - 1) : 0) & 1] + stream, sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
+  hipMemcpy(&kf, pl->kfbuf[(pl->frames_fed > 0 ? (pl->frames_fed - 1) : 0) % Pipeline::NBA] + stream, sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
   if (!kf.valid) return 0;
   *frame_id = kf.frame_id;
   memcpy(T7, kf.T_c_w, 56);
