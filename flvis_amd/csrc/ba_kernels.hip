@@ -49,15 +49,18 @@ FD void bag_add_pose(WindowDev& w, int W, long long frame_id, const double* pose
   }
 }
 
-// removes edges flagged by pred (order preserving); one wave
+constexpr int BU_T = 1024;  // threads of the bookkeeping workgroup
+constexpr int BU_NW = BU_T / 64;
+
+// removes edges flagged by pred (order preserving, in place); whole workgroup
 template <typename Pred>
-__device__ inline void edges_remove_if(WindowDev& w, Pred pred) {
-  const int lane = threadIdx.x;
+__device__ inline void edges_remove_if(WindowDev& w, int* s_cnt, Pred pred) {
+  const int tid = threadIdx.x;
   const int n = w.n_edge;
   int kept = 0;
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    bool keep = i < n && !pred(i);
+  for (int base = 0; base < n; base += BU_T) {
+    const int i = base + tid;
+    const bool keep = i < n && !pred(i);
     long long id = 0, lm = 0;
     int ps = 0, li = 0;
     double u = 0, v = 0;
@@ -69,10 +72,10 @@ __device__ inline void edges_remove_if(WindowDev& w, Pred pred) {
       u = w.e_uv[i][0];
       v = w.e_uv[i][1];
     }
-    unsigned long long b = __ballot(keep);
-    __syncthreads();
+    int tot;
+    const int rk = block_rank<BU_NW>(keep, s_cnt, tot);  // (its barriers separate this pass's reads from its writes)
     if (keep) {
-      int k = kept + lane_prefix(b);
+      const int k = kept + rk;
       w.e_id[k] = id;
       w.e_lm[k] = lm;
       w.e_pose[k] = ps;
@@ -80,85 +83,83 @@ __device__ inline void edges_remove_if(WindowDev& w, Pred pred) {
       w.e_uv[k][0] = u;
       w.e_uv[k][1] = v;
     }
-    kept += __popcll(b);
-    __syncthreads();
+    kept += tot;
   }
-  if (lane == 0) w.n_edge = kept;
+  __syncthreads();
+  if (tid == 0) w.n_edge = kept;
   __syncthreads();
 }
 
 // adds the observations of one keyframe to the bag (init: running mean, sliding: count only) and, if slot >= 0, the
-// projection edges to that pose slot.  New landmarks are appended in keyframe order.
-__device__ inline void bag_add_keyframe(WindowDev& w, long long* sid, const KeyFrameDev& kf, bool sliding, int slot) {
-  const int lane = threadIdx.x;
-  const int n = kf.lm_count;
-  const int e0 = w.n_edge;
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    int found = -1;
-    bool isnew = false;
-    if (i < n) {
-      found = bag_find(sid, w.n_lm, kf.lm_id[i]);
-      isnew = found < 0;
-    }
-    unsigned long long b = __ballot(isnew);
-    __syncthreads();
-    if (i < n) {
-      int li;
-      if (isnew) {
-        int k = w.n_lm + lane_prefix(b);
-        li = k;
-        if (k < BA_LMAX) {
-          w.lm_id[k] = kf.lm_id[i];
-          sid[k] = kf.lm_id[i];
-          w.lm_count[k] = 1;
-          for (int j = 0; j < 3; j++) {
-            w.lm_p3d[k][j] = kf.lm_3d[i][j];
-            w.lm_est[k][j] = kf.lm_3d[i][j];
-          }
-        }
-      } else {
-        li = found;
-        int cnt = w.lm_count[found];
-        if (!sliding) {  // PoseLMBag::addLMObservation: running mean (poselmbag.cpp:69-91)
-          for (int j = 0; j < 3; j++) {
-            double pj = (double)cnt * w.lm_p3d[found][j] + kf.lm_3d[i][j];
-            w.lm_p3d[found][j] = (1.0 / (double)(cnt + 1)) * pj;
-          }
-        }
-        w.lm_count[found] = cnt + 1;
-      }
-      if (slot >= 0) {
-        int k = e0 + i;
-        if (k < BA_EMAX) {
-          w.e_id[k] = w.edge_next_id + i;
-          w.e_lm[k] = kf.lm_id[i];
-          w.e_pose[k] = slot;
-          w.e_lidx[k] = li < BA_LMAX ? li : 0;
-          w.e_uv[k][0] = kf.lm_2d[i][0];
-          w.e_uv[k][1] = kf.lm_2d[i][1];
-        }
-      }
-    }
-    __syncthreads();
-    if (lane == 0) {
-      int nn = w.n_lm + __popcll(b);
-      if (nn > BA_LMAX) {
-        nn = BA_LMAX;
-        w.overflow = 1;
-      }
-      w.n_lm = nn;
-    }
-    __syncthreads();
+// projection edges to that pose slot.  New landmarks are appended in keyframe order.  One keyframe landmark per thread.
+__device__ inline void bag_add_keyframe(WindowDev& w, long long* sid, int* s_cnt, const KeyFrameDev& kf, bool sliding, int slot) {
+  const int tid = threadIdx.x;
+  const int n = kf.lm_count;  // <= KF_MAXLM == BU_T
+  const int e0 = w.n_edge, nl0 = w.n_lm;
+  int found = -1;
+  bool isnew = false;
+  long long id = 0;
+  if (tid < n) {
+    id = kf.lm_id[tid];
+    found = bag_find(sid, nl0, id);  // (ids are unique inside a keyframe: entries appended below cannot match)
+    isnew = found < 0;
   }
-  if (slot >= 0 && lane == 0) {
-    int ne = e0 + n;
-    if (ne > BA_EMAX) {
-      ne = BA_EMAX;
+  int nnew;
+  const int rk = block_rank<BU_NW>(isnew, s_cnt, nnew);
+  if (tid < n) {
+    int li;
+    if (isnew) {
+      const int k = nl0 + rk;
+      li = k;
+      if (k < BA_LMAX) {
+        w.lm_id[k] = id;
+        sid[k] = id;
+        w.lm_count[k] = 1;
+        for (int j = 0; j < 3; j++) {
+          w.lm_p3d[k][j] = kf.lm_3d[tid][j];
+          w.lm_est[k][j] = kf.lm_3d[tid][j];
+        }
+      }
+    } else {
+      li = found;
+      const int cnt = w.lm_count[found];
+      if (!sliding) {  // PoseLMBag::addLMObservation: running mean (poselmbag.cpp:69-91)
+        for (int j = 0; j < 3; j++) {
+          double pj = (double)cnt * w.lm_p3d[found][j] + kf.lm_3d[tid][j];
+          w.lm_p3d[found][j] = (1.0 / (double)(cnt + 1)) * pj;
+        }
+      }
+      w.lm_count[found] = cnt + 1;
+    }
+    if (slot >= 0) {
+      const int k = e0 + tid;
+      if (k < BA_EMAX) {
+        w.e_id[k] = w.edge_next_id + tid;
+        w.e_lm[k] = id;
+        w.e_pose[k] = slot;
+        w.e_lidx[k] = li < BA_LMAX ? li : 0;
+        w.e_uv[k][0] = kf.lm_2d[tid][0];
+        w.e_uv[k][1] = kf.lm_2d[tid][1];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int nn = nl0 + nnew;
+    if (nn > BA_LMAX) {
+      nn = BA_LMAX;
       w.overflow = 1;
     }
-    w.n_edge = ne;
-    w.edge_next_id += n;
+    w.n_lm = nn;
+    if (slot >= 0) {
+      int ne = e0 + n;
+      if (ne > BA_EMAX) {
+        ne = BA_EMAX;
+        w.overflow = 1;
+      }
+      w.n_edge = ne;
+      w.edge_next_id += n;
+    }
   }
   __syncthreads();
 }
@@ -168,29 +169,31 @@ FD void pose_to_g2o(const double* pose7, double* out7) {
   store_pose7(out7, g2o_from_mat(q_to_mat(T.q), T.t));
 }
 
-// LocalMapNodeletClass::frame_callback up to (not including) the optimisation; one wave per stream
-__global__ __launch_bounds__(64) void k_ba_update(Pipe p, long long seq) {
+// LocalMapNodeletClass::frame_callback up to (not including) the optimisation; one workgroup per stream (keyframe
+// landmarks, bag landmarks and edges are handled one per thread; all compactions are order preserving)
+__global__ __launch_bounds__(BU_T) void k_ba_update(Pipe p, long long seq) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   WindowDev& w = p.win[s];
-  const int lane = threadIdx.x;
-  // per-stream ordering across the two local-map streams: wait until launch seq-1 has released this window
-  if (lane == 0)
+  const int tid = threadIdx.x;
+  // per-stream ordering across the local-map streams: wait until launch seq-1 has released this window
+  if (tid == 0)
     while (__hip_atomic_load(&p.ba_seq[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq - 1) __builtin_amdgcn_s_sleep(8);
   __syncthreads();
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  if (lane == 0) w.solve = 0;
+  if (tid == 0) w.solve = 0;
   if (!p.kf[s].valid) return;
   __syncthreads();
   const int W = p.cam.window;
   KeyFrameDev* ring = p.kfs_ring + (size_t)s * BA_WMAX;
   __shared__ long long sid[BA_LMAX];  // bag landmark ids (32 KB): all id lookups of this callback scan LDS, not HBM
-  for (int i = lane; i < w.n_lm; i += 64) sid[i] = w.lm_id[i];
+  __shared__ int s_cnt[BU_NW];
+  for (int i = tid; i < w.n_lm; i += BU_T) sid[i] = w.lm_id[i];
   {  // kfs.push_back(kf)
     const KeyFrameDev& src = p.kf[s];
     KeyFrameDev& dst = ring[(w.kfs_head + w.kfs_size) % W];
     const int n = src.lm_count;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = tid; i < n; i += BU_T) {
       dst.lm_id[i] = src.lm_id[i];
       dst.lm_2d[i][0] = src.lm_2d[i][0];
       dst.lm_2d[i][1] = src.lm_2d[i][1];
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(64) void k_ba_update(Pipe p, long long seq) {
       dst.lm_3d[i][1] = src.lm_3d[i][1];
       dst.lm_3d[i][2] = src.lm_3d[i][2];
     }
-    if (lane == 0) {
+    __syncthreads();
+    if (tid == 0) {
       dst.frame_id = src.frame_id;
       dst.lm_count = n;
       dst.valid = 1;
@@ -211,49 +215,48 @@ __global__ __launch_bounds__(64) void k_ba_update(Pipe p, long long seq) {
   if (w.overflow) return;
   if (st.lm_state == 0) {  // UN_INITIALIZED (vo_localmap.cpp:122-216)
     if (w.kfs_size < W) return;  // returns before pop_front (quirk A22)
-    if (lane == 0) {
+    if (tid == 0) {
       w.n_edge = 0;
       w.edge_next_id = 0;
     }
     __syncthreads();
     for (int f = 0; f < W; f++) {
       const KeyFrameDev& kf = ring[(w.kfs_head + f) % W];
-      if (lane == 0) bag_add_pose(w, W, kf.frame_id, kf.T_c_w);
+      if (tid == 0) bag_add_pose(w, W, kf.frame_id, kf.T_c_w);
       __syncthreads();
       // pose vertex id = ring slot of the frame (getPoseIdByReleventFrameId): slot f during initialisation; edge ids
       // are assigned keyframe by keyframe in the reference (after all vertices exist), same order here
-      bag_add_keyframe(w, sid, kf, false, f);
+      bag_add_keyframe(w, sid, s_cnt, kf, false, f);
     }
-    if (lane < W) {
-      w.pose_present[lane] = 1;
-      w.pose_fixed[lane] = (lane == w.oldest) ? 1 : 0;
-      pose_to_g2o(w.bag_pose[lane], w.pose_est[lane]);
+    if (tid < W) {
+      w.pose_present[tid] = 1;
+      w.pose_fixed[tid] = (tid == w.oldest) ? 1 : 0;
+      pose_to_g2o(w.bag_pose[tid], w.pose_est[tid]);
     }
-    for (int i = lane; i < w.n_lm; i += 64)
+    for (int i = tid; i < w.n_lm; i += BU_T)
       for (int j = 0; j < 3; j++) w.lm_est[i][j] = w.lm_p3d[i][j];  // vertex estimate = running mean (quirk A23)
   } else {  // SLIDING_WINDOW (vo_localmap.cpp:218-284)
     const int old = w.oldest;
-    edges_remove_if(w, [&](int i) { return w.e_pose[i] == old; });
-    if (lane == 0) w.pose_present[old] = 0;
-    __syncthreads();
+    edges_remove_if(w, s_cnt, [&](int i) { return w.e_pose[i] == old; });
+    if (tid == 0) w.pose_present[old] = 0;
     {  // for(auto id : kfs.at(0).lm_id) if(bag->removeLMObservation(id)) optimizer.removeVertex(lm)
       const KeyFrameDev& k0 = ring[w.kfs_head % W];
-      for (int i = lane; i < k0.lm_count; i += 64) {
+      for (int i = tid; i < k0.lm_count; i += BU_T) {
         int f = bag_find(sid, w.n_lm, k0.lm_id[i]);
         if (f >= 0) w.lm_count[f]--;
       }
       __syncthreads();
-      edges_remove_if(w, [&](int i) { return w.lm_count[w.e_lidx[i]] == 0; });  // edges vanish with the vertex
+      edges_remove_if(w, s_cnt, [&](int i) { return w.lm_count[w.e_lidx[i]] == 0; });  // edges vanish with the vertex
       // erase those landmarks from the bag (order preserving) and remap the edges' bag indices
       const int n = w.n_lm;
       int* remap = reinterpret_cast<int*>(p.ba_scratch + (size_t)s * p.ba_scratch_stride);
       int kept = 0;
-      for (int base = 0; base < n; base += 64) {
-        int i = base + lane;
-        bool keep = i < n && w.lm_count[i] != 0;
+      for (int base = 0; base < n; base += BU_T) {
+        const int i = base + tid;
+        const bool keep = i < n && w.lm_count[i] != 0;
         long long id = 0;
         int cnt = 0;
-        double a[3], b[3];
+        double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
         if (keep) {
           id = w.lm_id[i];
           cnt = w.lm_count[i];
@@ -262,11 +265,11 @@ __global__ __launch_bounds__(64) void k_ba_update(Pipe p, long long seq) {
             b[j] = w.lm_est[i][j];
           }
         }
-        unsigned long long bal = __ballot(keep);
-        __syncthreads();
-        if (i < n) remap[i] = keep ? kept + lane_prefix(bal) : 0;
+        int tot;
+        const int rk = block_rank<BU_NW>(keep, s_cnt, tot);
+        if (i < n) remap[i] = keep ? kept + rk : 0;
         if (keep) {
-          int k = kept + lane_prefix(bal);
+          const int k = kept + rk;
           w.lm_id[k] = id;
           sid[k] = id;
           w.lm_count[k] = cnt;
@@ -275,15 +278,16 @@ __global__ __launch_bounds__(64) void k_ba_update(Pipe p, long long seq) {
             w.lm_est[k][j] = b[j];
           }
         }
-        kept += __popcll(bal);
-        __syncthreads();
+        kept += tot;
       }
-      for (int e = lane; e < w.n_edge; e += 64) w.e_lidx[e] = remap[w.e_lidx[e]];
-      if (lane == 0) w.n_lm = kept;
+      __syncthreads();
+      for (int e = tid; e < w.n_edge; e += BU_T) w.e_lidx[e] = remap[w.e_lidx[e]];
+      __syncthreads();
+      if (tid == 0) w.n_lm = kept;
       __syncthreads();
     }
     const KeyFrameDev& kn = ring[(w.kfs_head + w.kfs_size - 1) % W];
-    if (lane == 0) {
+    if (tid == 0) {
       bag_add_pose(w, W, kn.frame_id, kn.T_c_w);
       w.pose_present[w.newest] = 1;
       w.pose_fixed[w.newest] = 0;
@@ -291,10 +295,10 @@ __global__ __launch_bounds__(64) void k_ba_update(Pipe p, long long seq) {
       w.pose_fixed[w.oldest] = 1;
     }
     __syncthreads();
-    bag_add_keyframe(w, sid, kn, true, w.newest);
+    bag_add_keyframe(w, sid, s_cnt, kn, true, w.newest);
   }
   __syncthreads();
-  if (lane == 0) {
+  if (tid == 0) {
     w.solve = w.overflow ? 0 : 1;
     // kfs.pop_front() happens after the optimisation in the reference; nothing reads kfs in between
     w.kfs_head = (w.kfs_head + 1) % W;
@@ -302,9 +306,8 @@ __global__ __launch_bounds__(64) void k_ba_update(Pipe p, long long seq) {
   }
 }
 
-
 void launch_ba_update(hipStream_t st, const Pipe& p, long long seq) {
-  hipLaunchKernelGGL(k_ba_update, dim3(p.S), dim3(64), 0, st, p, seq);
+  hipLaunchKernelGGL(k_ba_update, dim3(p.S), dim3(BU_T), 0, st, p, seq);
 }
 
 }  // namespace flvis

@@ -799,6 +799,7 @@ __device__ __noinline__ void ba_phase_schur(double lambda) {
     const int buf = c & 1;
     commit(buf);
     __syncthreads();
+    BAPROF(2);
     if (c + 1 < nchunk) prefetch(c + 1);
     const int nl = sh.chunk_l0[c + 1] - sh.chunk_l0[c];
     const double* zb = stage + (size_t)buf * bufd;
@@ -809,29 +810,42 @@ __device__ __noinline__ void ba_phase_schur(double lambda) {
     if (my_i1 >= 0) {
       const unsigned need = (1u << my_i1) | (1u << my_i2);
       const unsigned lt1 = (1u << my_i1) - 1u, lt2 = (1u << my_i2) - 1u;
-      for (int ll = my_sl; ll < nl; ll += slices) {
-        const unsigned m = mb[ll];
-        if ((m & need) != need) continue;
-        const int base = lb[ll];
-        const double2* zi = z2 + base + __popc(m & lt1);
-        const double2* zj = z2 + base + __popc(m & lt2);
-        double a[18];
+      // the masks / item bases of this thread's landmarks are fetched 8 at a time before the arithmetic: a dependent LDS
+      // read per landmark (most of them only to find the pair unobserved) was a large part of this loop
+      for (int g0 = my_sl; g0 < nl; g0 += 8 * slices) {
+        unsigned mk[8];
+        int bs[8];
 #pragma unroll
-        for (int kp = 0; kp < 9; kp++) {
-          const double2 v2 = zi[kp * CI];
-          a[2 * kp] = v2.x;
-          a[2 * kp + 1] = v2.y;
+        for (int q = 0; q < 8; q++) {
+          const int ll = g0 + q * slices;
+          mk[q] = ll < nl ? mb[ll] : 0u;
+          bs[q] = ll < nl ? lb[ll] : 0;
         }
 #pragma unroll
-        for (int cp = 0; cp < 3; cp++) {  // two columns of the tile (6 elements of Z_i2) per step
-          const double2 q0 = zj[(3 * cp) * CI], q1 = zj[(3 * cp + 1) * CI], q2 = zj[(3 * cp + 2) * CI];
-          const double bq[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+        for (int q = 0; q < 8; q++) {
+          const unsigned m = mk[q];
+          if ((m & need) != need) continue;
+          const int base = bs[q];
+          const double2* zi = z2 + base + __popc(m & lt1);
+          const double2* zj = z2 + base + __popc(m & lt2);
+          double a[18];
 #pragma unroll
-          for (int h2 = 0; h2 < 2; h2++) {
-            const int cc = 2 * cp + h2;
+          for (int kp = 0; kp < 9; kp++) {
+            const double2 v2 = zi[kp * CI];
+            a[2 * kp] = v2.x;
+            a[2 * kp + 1] = v2.y;
+          }
 #pragma unroll
-            for (int r = 0; r < 6; r++)
-              acc[6 * r + cc] = fma(a[3 * r + 2], bq[3 * h2 + 2], fma(a[3 * r + 1], bq[3 * h2 + 1], fma(a[3 * r], bq[3 * h2], acc[6 * r + cc])));
+          for (int cp = 0; cp < 3; cp++) {  // two columns of the tile (6 elements of Z_i2) per step
+            const double2 q0 = zj[(3 * cp) * CI], q1 = zj[(3 * cp + 1) * CI], q2 = zj[(3 * cp + 2) * CI];
+            const double bq[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {
+              const int cc = 2 * cp + h2;
+#pragma unroll
+              for (int r = 0; r < 6; r++)
+                acc[6 * r + cc] = fma(a[3 * r + 2], bq[3 * h2 + 2], fma(a[3 * r + 1], bq[3 * h2 + 1], fma(a[3 * r], bq[3 * h2], acc[6 * r + cc])));
+            }
           }
         }
       }
@@ -853,6 +867,7 @@ __device__ __noinline__ void ba_phase_schur(double lambda) {
         for (int r = 0; r < 6; r++) accr[r] = fma(a[3 * r + 2], c2, fma(a[3 * r + 1], c1, fma(a[3 * r], c0, accr[r])));
       }
     }
+    BAPROF(12);
   }
   // combine the slices (fixed butterfly order) and write S / rhs
   for (int off = slices >> 1; off > 0; off >>= 1) {

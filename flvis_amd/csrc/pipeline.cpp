@@ -5,6 +5,7 @@
 // reference takes per frame is taken on the device by the kernels in track_kernels.hip / ba_kernels.hip.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -53,7 +54,9 @@ struct Pipeline {
   // together; the per-stream order (a window is updated strictly keyframe after keyframe) is enforced ON THE DEVICE by a
   // sequence number per stream (Pipe::ba_seq): the bookkeeping kernel of launch q waits until launch q-1 has released
   // that stream.  The launches are enqueued in order on independent hardware queues, so the wait always terminates.
-  static constexpr int NBA = 4;  // local-map launches in flight
+  static constexpr int NBA = 4;  // local-map streams (upper bound of launches in flight)
+  int nba = 2;                   // streams in use (FLVIS_BA_STREAMS, tuning knob)
+  bool sync_each_frame = false;  // FLVIS_SYNC_EACH_FRAME=1: image_feed waits for the previous frame (tuning knob)
   hipStream_t ba_stream[NBA] = {};
   long long ba_launches = 0;
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
@@ -356,6 +359,11 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     flvis_pipeline_destroy_internal(ctx);
     return ctx->fail(FLVIS_ERR_HIP, "tracker_create: pinned allocation failed");
   }
+  if (const char* e = getenv("FLVIS_BA_STREAMS")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= Pipeline::NBA) pl->nba = v;
+  }
+  if (const char* e = getenv("FLVIS_SYNC_EACH_FRAME")) pl->sync_each_frame = atoi(e) != 0;
   bool evok = true;
   for (int k = 0; k < Pipeline::NBA && evok; k++) evok = hipStreamCreateWithFlags(&pl->ba_stream[k], hipStreamNonBlocking) == hipSuccess;
   evok = evok &&
@@ -452,6 +460,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   double* pt = (double*)pl->pinned[pslot];
   double* pi = pt + S;
   int* pn = (int*)(pi + (size_t)S * IMU_MAX * 7);
+  if (pl->sync_each_frame) hipStreamSynchronize(st);
   if (pl->frames_fed >= Pipeline::PIN_RING) hipEventSynchronize(pl->ev_pin[pslot]);  // upload of frame N-PIN_RING is done
   memcpy(pt, h_times, sizeof(double) * S);
   memcpy(pi, pl->h_imu.data(), sizeof(double) * (size_t)S * IMU_MAX * 7);
@@ -475,7 +484,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
-    p.kf = pl->kfbuf[(int)(pl->frames_fed % Pipeline::NBA)];
+    p.kf = pl->kfbuf[(int)(pl->frames_fed % pl->nba)];
     PB(17, st);
     launch_frame_end(st, p, (int)pl->frames_fed);
     PE(17, st);
@@ -583,7 +592,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PB(16, st);
   launch_depth_innovate(st, p);
   PE(16, st);
-  const int par = (int)(pl->frames_fed % Pipeline::NBA);
+  const int par = (int)(pl->frames_fed % pl->nba);
   p.kf = pl->kfbuf[par];  // this frame's keyframe slot; the local map may still be reading the other one
   if (pl->ev_ba_armed[par]) hipStreamWaitEvent(st, pl->ev_ba[par], 0);  // BA of frame N-NBA has released this slot
   PB(17, st);
@@ -703,7 +712,7 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
   sync_all(ctx);
   std::vector<KeyFrameDev> kfv(1);
   KeyFrameDev& kf = kfv[0];
-  hipMemcpy(&kf, pl->kfbuf[(pl->frames_fed > 0 ? (pl->frames_fed - 1) : 0) % Pipeline::NBA] + stream, sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
+  hipMemcpy(&kf, pl->kfbuf[(pl->frames_fed > 0 ? (pl->frames_fed - 1) : 0) % pl->nba] + stream, sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
   if (!kf.valid) return 0;
   *frame_id = kf.frame_id;
   memcpy(T7, kf.T_c_w, 56);
