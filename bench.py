@@ -51,6 +51,9 @@ def main():
                          "per-stream kernels are latency-bound, so sub-batches fed round-robin overlap on the GPU")
     args = ap.parse_args()
 
+    # the pipeline uses 4-6 HIP streams per tracker context; with the default of 4 hardware queues the long local-map kernels
+    # share a queue with the front-end chain (must be set before the HIP runtime initialises)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,6 +155,8 @@ def main():
     for f in range(Wm, Wm + K):
         step(f)
     e1.record()
+    for g in range(G):  # everything enqueued AND every queued keyframe consumed by the local map
+        ctxs[g]._check(lib.flvis_hip_synchronize(ctxs[g]._h), "synchronize")
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

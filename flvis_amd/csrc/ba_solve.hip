@@ -42,7 +42,7 @@ constexpr int BA_T = 512;
 constexpr int BA_NW = BA_T / 64;
 constexpr int BA_PMAX = BA_WMAX - 1;   // free poses
 constexpr int BA_NRMAX = 6 * BA_PMAX;  // 90
-constexpr int BA_LDS_BUDGET = 160 * 1024;
+constexpr int BA_LDS_BUDGET = 159 * 1024;  // dynamic LDS of the worker (1 KB left for its static words)
 constexpr int BA_MAXCHUNK = 160;
 
 // HBM scratch is addressed through explicit global-address-space pointers: inside the non-inlined phase functions the
@@ -1097,20 +1097,11 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
   }
 }
 
-// releases the stream's window to the next local-map launch (see Pipeline::ba_stream)
-FD void ba_release(const Pipe& p, int s, long long seq) {
-  __atomic_thread_fence(__ATOMIC_RELEASE);
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&p.ba_seq[s], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
+#include "ba_update.hpp"
 
-__global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p, long long seq) {
-  const int s = blockIdx.x;
+// the OPTIMIZING block for the window of stream s (w.solve set by ba_update_dev); frame_id = the keyframe that triggered it
+__device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_id) {
   WindowDev& w = p.win[s];
-  if (!w.solve) {
-    ba_release(p, s, seq);
-    return;
-  }
   BAShared& sh = ba_sh();
   const int W = p.cam.window;
   const int L = w.n_lm, E = w.n_edge;
@@ -1249,7 +1240,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p, long long seq) {
     }
     if (lane == 0) {
       w.n_edge = kept;
-      out.frame_id = p.kf[s].frame_id;
+      out.frame_id = frame_id;
       SE3d Tn = load_pose7(sh.pose[w.newest]);
       store_pose7(out.T_c_w, se3_from_mat(q_to_mat(Tn.q), Tn.t));
       out.lm_count = c;
@@ -1261,14 +1252,79 @@ __global__ __launch_bounds__(BA_T) void k_ba_solve(Pipe p, long long seq) {
     }
   }
   BAPROF(11);
-  ba_release(p, s, seq);
 }
 
-void launch_ba_solve(hipStream_t st, const Pipe& p, long long seq) {
-  hipLaunchKernelGGL(k_ba_solve, dim3(p.S), dim3(BA_T), BA_LDS_BUDGET, st, p, seq);
+// Local-map worker: one workgroup per stream drains the stream's keyframe queue (bookkeeping + optimisation per keyframe,
+// strictly in order).  It is launched after every frame on one of the local-map HIP streams; a workgroup that finds the
+// stream's window owned by a workgroup of an earlier launch leaves at once -- the owner re-checks the queue before and
+// after releasing the window, so a keyframe is picked up at the latest by the launch that follows it.  The tracker
+// therefore never waits for the optimiser unless the queue (KFQ keyframes) is full.
+__global__ __launch_bounds__(BA_T) void k_ba_worker(Pipe p) {
+  const int s = blockIdx.x;
+  const int t = threadIdx.x;
+  __shared__ int s_go;
+  __shared__ unsigned s_head, s_tail;
+  __shared__ int s_cnt[BA_NW];
+#ifdef FLVIS_BA_DEBUG
+#define BADBG(code) do { if (t == 0 && p.counters) { p.counters[48] = (code); atomicAdd((unsigned long long*)&p.counters[49], 1ull); } } while (0)
+  int guard_ = 0;
+#else
+#define BADBG(code) do { } while (0)
+#endif
+  while (true) {
+#ifdef FLVIS_BA_DEBUG
+    if (++guard_ > 100) { BADBG(999); return; }
+#endif
+    BADBG(1);
+    if (t == 0) {
+      s_go = 0;
+      const unsigned tl = __hip_atomic_load(&p.kfq_tail[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned hd = __hip_atomic_load(&p.kfq_head[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if (tl != hd && atomicCAS(&p.ba_busy[s], 0, 1) == 0) s_go = 1;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    // only the owner advances the head: it is read once (after the acquire above) and then kept in a register
+    unsigned my_head = __hip_atomic_load(&p.kfq_head[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+      if (t == 0) {
+        s_head = my_head;
+        s_tail = __hip_atomic_load(&p.kfq_tail[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      const unsigned hd = s_head, tl = s_tail;
+      __syncthreads();
+      BADBG(2);
+      if (hd == tl) break;
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      const KeyFrameDev& kf = p.kfq[(size_t)s * KFQ + (hd % KFQ)];
+      const long long frame_id = kf.frame_id;
+      BADBG(3);
+      ba_update_dev(p, s, kf, reinterpret_cast<long long*>(ba_dyn()), s_cnt);
+      BADBG(4);
+      __syncthreads();
+      if (p.win[s].solve) ba_solve_dev(p, s, frame_id);
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      __syncthreads();
+      if (t == 0) __hip_atomic_store(&p.kfq_head[s], hd + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      my_head = hd + 1u;
+      BADBG(5);
+    }
+    BADBG(6);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&p.ba_busy[s], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // a keyframe may have arrived between the emptiness test and the release: look again
+  }
+}
+
+void launch_ba_worker(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_ba_worker, dim3(p.S), dim3(BA_T), BA_LDS_BUDGET, st, p);
 }
 hipError_t ba_kernels_init() {
-  return hipFuncSetAttribute((const void*)k_ba_solve, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
+  return hipFuncSetAttribute((const void*)k_ba_worker, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
 }
 
 }  // namespace flvis

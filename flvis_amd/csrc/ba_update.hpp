@@ -1,26 +1,10 @@
-// flvis_amd: batched sliding-window bundle adjustment for gfx950 (one workgroup per stream-window).
+// flvis_amd: local-map bookkeeping in front of the optimiser (included by ba_solve.hip inside namespace flvis).
 //
-// Replaces the OPTIMIZING block of LocalMapNodeletClass::frame_callback (src/backend/vo_localmap.cpp:292-366) and the
-// graph bookkeeping in front of it (:114-284, PoseLMBag src/backend/poselmbag.cpp), i.e. g2o's
-//   SparseOptimizer::initializeOptimization/optimize    core/sparse_optimizer.cpp:208-272,366-431
-//   OptimizationAlgorithmLevenberg::solve               core/optimization_algorithm_levenberg.cpp:58-175
-//   BlockSolver<6,3>::buildSystem/setLambda/solve       core/block_solver.hpp:314-565   (Schur complement on the landmarks)
-//   EdgeSE3ProjectXYZ + RobustKernelHuber               types/sba/types_six_dof_expmap.cpp:389-433, core/robust_kernel_impl.cpp:65-78
-// as ONE kernel launch per keyframe (12 + 8 LM iterations and the chi2 > 3 cull in between, all in-kernel).
-//
-// Layout / mapping (1024 threads = 16 waves per window):
-//   * edges are processed one thread each (fp64 residual, 2x3 / 2x6 Jacobians, Huber weight);
-//   * per-landmark data is DENSE by (landmark, pose): Hpl[l][p] (6x3) and B*Dinv[l][p], plus a pose bit mask, so the Schur
-//     complement streams contiguous landmark chunks through LDS and every reduced-system element (i1,r,i2,c) is owned by
-//     ONE thread that sums its landmarks in index order -> no atomics, bit-reproducible run to run;
-//   * per-pose 6x6 blocks / rhs: one wave per free pose, lanes stride that pose's (contiguous) edge range, butterfly sums;
-//   * reduced camera system (6P x 6P, P <= 15) lives in LDS and is factored by an in-LDS Cholesky.
-// The reduced system is tiny (<= 90x90): MFMA is not the bound here, the critical path is the dependent LM trial chain.
-#include "dev_common.hpp"
-#include "dev_geom.hpp"
-#include "track_kernels.hpp"
-
-namespace flvis {
+// LocalMapNodeletClass::frame_callback up to (not including) the optimisation (src/backend/vo_localmap.cpp:114-284) with
+// PoseLMBag (src/backend/poselmbag.cpp): keyframe queue, bag of poses / landmarks, the g2o graph's vertices and edges.
+// Runs on the whole workgroup of the local-map worker: keyframe landmarks, bag landmarks and edges are handled one per
+// thread, every compaction is order preserving (block_rank).  The bag's landmark-id list is staged in LDS.
+#pragma once
 
 // ------------------------------------------------------------------------------------------------ bookkeeping
 // landmark id -> bag index; the id list of the bag is staged in LDS (sid) by k_ba_update and kept in sync with appends
@@ -49,7 +33,7 @@ FD void bag_add_pose(WindowDev& w, int W, long long frame_id, const double* pose
   }
 }
 
-constexpr int BU_T = 1024;  // threads of the bookkeeping workgroup
+constexpr int BU_T = BA_T;  // the bookkeeping runs on the worker's workgroup
 constexpr int BU_NW = BU_T / 64;
 
 // removes edges flagged by pred (order preserving, in place); whole workgroup
@@ -91,61 +75,67 @@ __device__ inline void edges_remove_if(WindowDev& w, int* s_cnt, Pred pred) {
 }
 
 // adds the observations of one keyframe to the bag (init: running mean, sliding: count only) and, if slot >= 0, the
-// projection edges to that pose slot.  New landmarks are appended in keyframe order.  One keyframe landmark per thread.
+// projection edges to that pose slot.  New landmarks are appended in keyframe order.  One keyframe landmark per thread
+// and pass.
 __device__ inline void bag_add_keyframe(WindowDev& w, long long* sid, int* s_cnt, const KeyFrameDev& kf, bool sliding, int slot) {
   const int tid = threadIdx.x;
-  const int n = kf.lm_count;  // <= KF_MAXLM == BU_T
+  const int n = kf.lm_count;
   const int e0 = w.n_edge, nl0 = w.n_lm;
-  int found = -1;
-  bool isnew = false;
-  long long id = 0;
-  if (tid < n) {
-    id = kf.lm_id[tid];
-    found = bag_find(sid, nl0, id);  // (ids are unique inside a keyframe: entries appended below cannot match)
-    isnew = found < 0;
-  }
-  int nnew;
-  const int rk = block_rank<BU_NW>(isnew, s_cnt, nnew);
-  if (tid < n) {
-    int li;
-    if (isnew) {
-      const int k = nl0 + rk;
-      li = k;
-      if (k < BA_LMAX) {
-        w.lm_id[k] = id;
-        sid[k] = id;
-        w.lm_count[k] = 1;
-        for (int j = 0; j < 3; j++) {
-          w.lm_p3d[k][j] = kf.lm_3d[tid][j];
-          w.lm_est[k][j] = kf.lm_3d[tid][j];
+  int appended = 0;
+  for (int base = 0; base < n; base += BU_T) {
+    const int i = base + tid;
+    int found = -1;
+    bool isnew = false;
+    long long id = 0;
+    if (i < n) {
+      id = kf.lm_id[i];
+      found = bag_find(sid, nl0, id);  // (ids are unique inside a keyframe: entries appended below cannot match)
+      isnew = found < 0;
+    }
+    int nnew;
+    const int rk = block_rank<BU_NW>(isnew, s_cnt, nnew);
+    if (i < n) {
+      int li;
+      if (isnew) {
+        const int k = nl0 + appended + rk;
+        li = k;
+        if (k < BA_LMAX) {
+          w.lm_id[k] = id;
+          sid[k] = id;
+          w.lm_count[k] = 1;
+          for (int j = 0; j < 3; j++) {
+            w.lm_p3d[k][j] = kf.lm_3d[i][j];
+            w.lm_est[k][j] = kf.lm_3d[i][j];
+          }
+        }
+      } else {
+        li = found;
+        const int cnt = w.lm_count[found];
+        if (!sliding) {  // PoseLMBag::addLMObservation: running mean (poselmbag.cpp:69-91)
+          for (int j = 0; j < 3; j++) {
+            double pj = (double)cnt * w.lm_p3d[found][j] + kf.lm_3d[i][j];
+            w.lm_p3d[found][j] = (1.0 / (double)(cnt + 1)) * pj;
+          }
+        }
+        w.lm_count[found] = cnt + 1;
+      }
+      if (slot >= 0) {
+        const int k = e0 + i;
+        if (k < BA_EMAX) {
+          w.e_id[k] = w.edge_next_id + i;
+          w.e_lm[k] = id;
+          w.e_pose[k] = slot;
+          w.e_lidx[k] = li < BA_LMAX ? li : 0;
+          w.e_uv[k][0] = kf.lm_2d[i][0];
+          w.e_uv[k][1] = kf.lm_2d[i][1];
         }
       }
-    } else {
-      li = found;
-      const int cnt = w.lm_count[found];
-      if (!sliding) {  // PoseLMBag::addLMObservation: running mean (poselmbag.cpp:69-91)
-        for (int j = 0; j < 3; j++) {
-          double pj = (double)cnt * w.lm_p3d[found][j] + kf.lm_3d[tid][j];
-          w.lm_p3d[found][j] = (1.0 / (double)(cnt + 1)) * pj;
-        }
-      }
-      w.lm_count[found] = cnt + 1;
     }
-    if (slot >= 0) {
-      const int k = e0 + tid;
-      if (k < BA_EMAX) {
-        w.e_id[k] = w.edge_next_id + tid;
-        w.e_lm[k] = id;
-        w.e_pose[k] = slot;
-        w.e_lidx[k] = li < BA_LMAX ? li : 0;
-        w.e_uv[k][0] = kf.lm_2d[tid][0];
-        w.e_uv[k][1] = kf.lm_2d[tid][1];
-      }
-    }
+    appended += nnew;
   }
   __syncthreads();
   if (tid == 0) {
-    int nn = nl0 + nnew;
+    int nn = nl0 + appended;
     if (nn > BA_LMAX) {
       nn = BA_LMAX;
       w.overflow = 1;
@@ -169,28 +159,18 @@ FD void pose_to_g2o(const double* pose7, double* out7) {
   store_pose7(out7, g2o_from_mat(q_to_mat(T.q), T.t));
 }
 
-// LocalMapNodeletClass::frame_callback up to (not including) the optimisation; one workgroup per stream (keyframe
-// landmarks, bag landmarks and edges are handled one per thread; all compactions are order preserving)
-__global__ __launch_bounds__(BU_T) void k_ba_update(Pipe p, long long seq) {
-  const int s = blockIdx.x;
+// LocalMapNodeletClass::frame_callback up to (not including) the optimisation for the keyframe `src`.  sid: LDS scratch
+// for the bag's landmark ids (BA_LMAX entries), s_cnt: LDS [BU_NW].  Sets w.solve when the optimiser has to run.
+__device__ __noinline__ void ba_update_dev(const Pipe& p, int s, const KeyFrameDev& src, long long* sid, int* s_cnt) {
   StreamState& st = p.st[s];
   WindowDev& w = p.win[s];
   const int tid = threadIdx.x;
-  // per-stream ordering across the local-map streams: wait until launch seq-1 has released this window
-  if (tid == 0)
-    while (__hip_atomic_load(&p.ba_seq[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq - 1) __builtin_amdgcn_s_sleep(8);
-  __syncthreads();
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   if (tid == 0) w.solve = 0;
-  if (!p.kf[s].valid) return;
   __syncthreads();
   const int W = p.cam.window;
   KeyFrameDev* ring = p.kfs_ring + (size_t)s * BA_WMAX;
-  __shared__ long long sid[BA_LMAX];  // bag landmark ids (32 KB): all id lookups of this callback scan LDS, not HBM
-  __shared__ int s_cnt[BU_NW];
   for (int i = tid; i < w.n_lm; i += BU_T) sid[i] = w.lm_id[i];
   {  // kfs.push_back(kf)
-    const KeyFrameDev& src = p.kf[s];
     KeyFrameDev& dst = ring[(w.kfs_head + w.kfs_size) % W];
     const int n = src.lm_count;
     for (int i = tid; i < n; i += BU_T) {
@@ -306,8 +286,3 @@ __global__ __launch_bounds__(BU_T) void k_ba_update(Pipe p, long long seq) {
   }
 }
 
-void launch_ba_update(hipStream_t st, const Pipe& p, long long seq) {
-  hipLaunchKernelGGL(k_ba_update, dim3(p.S), dim3(BU_T), 0, st, p, seq);
-}
-
-}  // namespace flvis

@@ -50,29 +50,25 @@ struct Pipeline {
   unsigned long long prof_mask = ~0ull;  // stages that record events (an event record costs a few us on the GPU queue)
   // local map on its own HIP stream: the BA of frame N overlaps the front-end of frame N+1 (its output is never fed
   // back into the tracker in the reference, src/frontend/vo_tracking.cpp:373-385).  Keyframe payloads are double-buffered.
-  // NBA local-map streams are used round-robin so that the BA kernels of consecutive frames can be in flight
-  // together; the per-stream order (a window is updated strictly keyframe after keyframe) is enforced ON THE DEVICE by a
-  // sequence number per stream (Pipe::ba_seq): the bookkeeping kernel of launch q waits until launch q-1 has released
-  // that stream.  The launches are enqueued in order on independent hardware queues, so the wait always terminates.
+  // The local-map worker (k_ba_worker) is launched after every frame on one of NBA HIP streams (round-robin); it drains
+  // the per-stream keyframe queues (Pipe::kfq) that frame_end fills.  Launches overlap freely: a stream's window is owned
+  // by one workgroup at a time (Pipe::ba_busy), later launches leave it to the owner.
   static constexpr int NBA = 4;  // local-map streams (upper bound of launches in flight)
   int nba = 2;                   // streams in use (FLVIS_BA_STREAMS, tuning knob)
   bool sync_each_frame = false;  // FLVIS_SYNC_EACH_FRAME=1: image_feed waits for the previous frame (tuning knob)
   hipStream_t ba_stream[NBA] = {};
-  long long ba_launches = 0;
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
   hipEvent_t ev_img = nullptr, ev_det = nullptr;
-  hipEvent_t ev_fe[NBA] = {}, ev_ba[NBA] = {};
-  bool ev_ba_armed[NBA] = {};
-  KeyFrameDev* kfbuf[NBA] = {};
+  hipEvent_t ev_fe[NBA] = {};
 };
-constexpr int PROF_STAGES = 20;  // every stage has its own (begin, end) event pair on the stream it runs on
+constexpr int PROF_STAGES = 19;  // every stage has its own (begin, end) event pair on the stream it runs on
 static const char* kStageNames[PROF_STAGES] = {
     "imu_feed+frame_begin", "ingest(copy/equalize)", "pyr_down x6", "track_prepare", "lk_track(temporal)", "track_collect",
     "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_max", "gftt:eig_nms", "gftt:pick",
     "feature_dem+add_new", "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end",
-    "ba_update", "ba_solve"};
+    "ba_worker(launch)"};
 
 }  // namespace flvis
 
@@ -165,9 +161,9 @@ void glibc_seed(unsigned s, int* r34) {
 
 }  // namespace
 
+static void sync_all(flvis_ctx* ctx);
 extern "C" void flvis_pipeline_sync_internal(flvis_ctx* ctx) {
-  for (int k = 0; k < Pipeline::NBA; k++)
-    if (ctx && ctx->pipe && ctx->pipe->ba_stream[k]) hipStreamSynchronize(ctx->pipe->ba_stream[k]);
+  if (ctx && ctx->pipe) sync_all(ctx);
 }
 
 extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
@@ -186,7 +182,6 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   if (pl->ev_det) hipEventDestroy(pl->ev_det);
   for (int k = 0; k < Pipeline::NBA; k++) {
     if (pl->ev_fe[k]) hipEventDestroy(pl->ev_fe[k]);
-    if (pl->ev_ba[k]) hipEventDestroy(pl->ev_ba[k]);
   }
   for (void* p : pl->allocs) hipFree(p);
   for (hipEvent_t e : pl->prof_ev) hipEventDestroy(e);
@@ -280,13 +275,14 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   DA(gftt_maxc, int, S);
   DA(img_slot, int, S);
   DA(out, FrameOut, S);
-  for (int k = 0; k < Pipeline::NBA; k++) ok = ok && ((pl->kfbuf[k] = dalloc<KeyFrameDev>(pl, S)) != nullptr);
-  p.kf = pl->kfbuf[0];
+  DA(kfq, KeyFrameDev, (size_t)S * KFQ);
+  DA(kfq_tail, unsigned, S);
+  DA(kfq_head, unsigned, S);
+  DA(ba_busy, int, S);
   DA(win, WindowDev, S);
   DA(kfs_ring, KeyFrameDev, (size_t)S * BA_WMAX);
   DA(corr, CorrectionDev, S);
   DA(counters, long long, 64);
-  DA(ba_seq, long long, S);
   p.ba_scratch_stride = ba_scratch_doubles();
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
   unsigned long long* seeds = dalloc<unsigned long long>(pl, S);
@@ -371,8 +367,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
               hipEventCreateWithFlags(&pl->ev_img, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&pl->ev_det, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < Pipeline::NBA && evok; k++)
-    evok = hipEventCreateWithFlags(&pl->ev_fe[k], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&pl->ev_ba[k], hipEventDisableTiming) == hipSuccess;
+    evok = hipEventCreateWithFlags(&pl->ev_fe[k], hipEventDisableTiming) == hipSuccess;
   if (!evok) {
     flvis_pipeline_destroy_internal(ctx);
     return ctx->fail(FLVIS_ERR_HIP, "tracker_create: cannot create the local-map stream/events");
@@ -430,21 +425,28 @@ static void fill_pyr(Pipeline* pl, PyrSel& ps, uint8_t* const* l0, uint8_t* cons
 }
 
 int flvis_prof_stage_count(void);
-// synchronous local-map step on keyframe buffer 0 (flvis_ba_push_keyframe)
-static int run_local_map(flvis_ctx* ctx) {
-  Pipeline* pl = ctx->pipe;
-  Pipe p = pl->pipe;
-  p.kf = pl->kfbuf[0];
-  const long long seq = ++pl->ba_launches;
-  launch_ba_update(ctx->stream, p, seq);
-  launch_ba_solve(ctx->stream, p, seq);
-  return FLVIS_OK;
-}
-static void sync_all(flvis_ctx* ctx) {
+static void sync_streams(flvis_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < Pipeline::NBA; k++)
     if (ctx->pipe && ctx->pipe->ba_stream[k]) hipStreamSynchronize(ctx->pipe->ba_stream[k]);
   if (ctx->pipe && ctx->pipe->det_stream) hipStreamSynchronize(ctx->pipe->det_stream);
+}
+// waits for everything that was enqueued AND for the local map to have consumed every queued keyframe (a keyframe that
+// slipped in while a worker workgroup was releasing its window is picked up by one more worker launch)
+static void sync_all(flvis_ctx* ctx) {
+  sync_streams(ctx);
+  Pipeline* pl = ctx->pipe;
+  if (!pl) return;
+  std::vector<unsigned> hd(pl->S), tl(pl->S);
+  for (int guard = 0; guard < 64; guard++) {
+    hipMemcpy(hd.data(), pl->pipe.kfq_head, sizeof(unsigned) * pl->S, hipMemcpyDeviceToHost);
+    hipMemcpy(tl.data(), pl->pipe.kfq_tail, sizeof(unsigned) * pl->S, hipMemcpyDeviceToHost);
+    bool pending = false;
+    for (int i = 0; i < pl->S; i++) pending = pending || hd[i] != tl[i];
+    if (!pending) break;
+    launch_ba_worker(pl->ba_stream[0], pl->pipe);
+    hipStreamSynchronize(pl->ba_stream[0]);
+  }
 }
 
 int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
@@ -484,7 +486,6 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
-    p.kf = pl->kfbuf[(int)(pl->frames_fed % pl->nba)];
     PB(17, st);
     launch_frame_end(st, p, (int)pl->frames_fed);
     PE(17, st);
@@ -593,28 +594,22 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   launch_depth_innovate(st, p);
   PE(16, st);
   const int par = (int)(pl->frames_fed % pl->nba);
-  p.kf = pl->kfbuf[par];  // this frame's keyframe slot; the local map may still be reading the other one
-  if (pl->ev_ba_armed[par]) hipStreamWaitEvent(st, pl->ev_ba[par], 0);  // BA of frame N-NBA has released this slot
   PB(17, st);
   launch_frame_end(st, p, (int)pl->frames_fed);
   PE(17, st);
   if (with_local_map) {
     hipStream_t bs = pl->ba_stream[par];
-    const long long seq = ++pl->ba_launches;
     hipEventRecord(pl->ev_fe[par], st);
     hipStreamWaitEvent(bs, pl->ev_fe[par], 0);
     PB(18, bs);
-    launch_ba_update(bs, p, seq);
+    launch_ba_worker(bs, p);
     PE(18, bs);
-    PB(19, bs);
-    launch_ba_solve(bs, p, seq);
-    PE(19, bs);
-    hipEventRecord(pl->ev_ba[par], bs);
-    pl->ev_ba_armed[par] = true;
-  } else if (prof) {
-    for (int i = 18; i <= 19; i++) {
-      PB(i, st);
-      PE(i, st);
+  } else {
+    // without a local map nobody consumes the keyframe queue: drop what frame_end appended
+    hipMemcpyAsync(p.kfq_head, p.kfq_tail, sizeof(unsigned) * S, hipMemcpyDeviceToDevice, st);
+    if (prof) {
+      PB(18, st);
+      PE(18, st);
     }
   }
 #undef PB
@@ -712,8 +707,13 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
   sync_all(ctx);
   std::vector<KeyFrameDev> kfv(1);
   KeyFrameDev& kf = kfv[0];
-  hipMemcpy(&kf, pl->kfbuf[(pl->frames_fed > 0 ? (pl->frames_fed - 1) : 0) % pl->nba] + stream, sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
-  if (!kf.valid) return 0;
+  FrameOut fo;
+  hipMemcpy(&fo, pl->pipe.out + stream, sizeof(FrameOut), hipMemcpyDeviceToHost);
+  if (!fo.new_keyframe) return 0;  // the last frame of this stream did not become a keyframe
+  unsigned tl = 0;
+  hipMemcpy(&tl, pl->pipe.kfq_tail + stream, sizeof(unsigned), hipMemcpyDeviceToHost);
+  if (tl == 0) return 0;
+  hipMemcpy(&kf, pl->pipe.kfq + (size_t)stream * KFQ + ((tl - 1) % KFQ), sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
   *frame_id = kf.frame_id;
   memcpy(T7, kf.T_c_w, 56);
   for (int i = 0; i < kf.lm_count && i < cap; i++) {
@@ -801,17 +801,16 @@ int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const d
   }
   sync_all(ctx);
   const int zero = 0;
-  for (int i = 0; i < pl->S; i++)  // only `stream` carries a keyframe in this call
-    hipMemcpy(&pl->kfbuf[0][i].valid, &zero, sizeof(int), hipMemcpyHostToDevice);
-  hipMemcpy(pl->kfbuf[0] + stream, &kf, sizeof(kf), hipMemcpyHostToDevice);
+  unsigned tl = 0;
+  hipMemcpy(&tl, pl->pipe.kfq_tail + stream, sizeof(unsigned), hipMemcpyDeviceToHost);
+  hipMemcpy(pl->pipe.kfq + (size_t)stream * KFQ + (tl % KFQ), &kf, sizeof(kf), hipMemcpyHostToDevice);
+  tl++;
+  hipMemcpy(pl->pipe.kfq_tail + stream, &tl, sizeof(unsigned), hipMemcpyHostToDevice);
   hipMemcpy(&pl->pipe.corr[stream].valid, &zero, sizeof(int), hipMemcpyHostToDevice);
-  run_local_map(ctx);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  launch_ba_worker(pl->ba_stream[0], pl->pipe);
+  hipError_t e = hipStreamSynchronize(pl->ba_stream[0]);
   if (e != hipSuccess) return ctx->hip_fail(e, "ba_push_keyframe");
-  {
-    const int z = 0;
-    hipMemcpy(&pl->kfbuf[0][stream].valid, &z, sizeof(int), hipMemcpyHostToDevice);
-  }
+  sync_all(ctx);
   return read_correction(ctx, stream, cap, out_frame_id, out_T7, out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid);
 }
 

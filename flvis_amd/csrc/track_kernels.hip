@@ -1159,10 +1159,7 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
   const int lane = threadIdx.x;  // (first wave does the scalar bookkeeping)
   __shared__ int s_newkf;
   __shared__ int s_cnt[FE_T / 64];
-  if (lane == 0) {
-    s_newkf = 0;
-    p.kf[s].valid = 0;  // this frame's keyframe slot: filled below only if the frame becomes a keyframe
-  }
+  if (lane == 0) s_newkf = 0;
   __syncthreads();
   if (st.phase == PH_INIT) {
     const int cur = st.cur;
@@ -1222,7 +1219,17 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
   }
   __syncthreads();
   if (s_newkf) {
-    KeyFrameDev& kf = p.kf[s];
+    // append the KeyFrame payload to the stream's queue (the local map consumes it on its own HIP streams); a full queue
+    // means the local map is KFQ keyframes behind: wait for it (its worker is running, it was launched after every frame)
+    __shared__ unsigned s_tail;
+    if (lane == 0) {
+      const unsigned tl = p.kfq_tail[s];
+      while (tl - __hip_atomic_load(&p.kfq_head[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)KFQ)
+        __builtin_amdgcn_s_sleep(16);
+      s_tail = tl;
+    }
+    __syncthreads();
+    KeyFrameDev& kf = p.kfq[(size_t)s * KFQ + (s_tail % KFQ)];
     Landmark* lms = lm_ptr(p, cur, s);
     const int n = st.n_lm[cur];
     int cnt = 0;
@@ -1248,8 +1255,11 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
       kf.frame_id = st.frame_id[cur];
       kf.lm_count = cnt < KF_MAXLM ? cnt : KF_MAXLM;
       for (int j = 0; j < 7; j++) kf.T_c_w[j] = st.T_c_w[cur][j];
-      kf.valid = 1;  // consumed by k_ba_update (possibly on the local-map stream, overlapped with the next frame)
+      kf.valid = 1;
     }
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&p.kfq_tail[s], s_tail + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

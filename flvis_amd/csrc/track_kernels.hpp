@@ -37,7 +37,12 @@ struct Pipe {
   FrameOut* out;            // [S]
   double* traj;             // [S][traj_cap][9]  (t, pose7, state|kf<<4) or nullptr
   int traj_cap;
-  KeyFrameDev* kf;          // [S] latest keyframe payload
+  // keyframe queue tracker -> local map (the `/vo_kf` topic of the reference): frame_end appends, the local-map worker
+  // consumes at its own pace (monotonic counters, slot = counter % KFQ)
+  KeyFrameDev* kfq;         // [S][KFQ]
+  unsigned* kfq_tail;       // [S] keyframes produced
+  unsigned* kfq_head;       // [S] keyframes consumed
+  int* ba_busy;             // [S] a worker workgroup owns the stream's window
   // local map
   WindowDev* win;           // [S]
   KeyFrameDev* kfs_ring;    // [S][BA_WMAX]
@@ -45,7 +50,6 @@ struct Pipe {
   double* ba_scratch;       // [S][ba_scratch_stride]
   size_t ba_scratch_stride;
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
-  long long* ba_seq;        // [S] number of the last local-map launch that has released the stream's window
 };
 
 void launch_imu_feed(hipStream_t st, const Pipe& p);
@@ -62,8 +66,7 @@ void launch_depth_prepare(hipStream_t st, const Pipe& p);
 void launch_depth_innovate(hipStream_t st, const Pipe& p);
 void launch_frame_end(hipStream_t st, const Pipe& p, int frame_slot);
 // local map
-void launch_ba_update(hipStream_t st, const Pipe& p, long long seq);
-void launch_ba_solve(hipStream_t st, const Pipe& p, long long seq);
+void launch_ba_worker(hipStream_t st, const Pipe& p);
 hipError_t ba_kernels_init();
 size_t ba_scratch_doubles();
 
