@@ -1265,17 +1265,7 @@ __global__ __launch_bounds__(BA_T) void k_ba_worker(Pipe p) {
   __shared__ int s_go;
   __shared__ unsigned s_head, s_tail;
   __shared__ int s_cnt[BA_NW];
-#ifdef FLVIS_BA_DEBUG
-#define BADBG(code) do { if (t == 0 && p.counters) { p.counters[48] = (code); atomicAdd((unsigned long long*)&p.counters[49], 1ull); } } while (0)
-  int guard_ = 0;
-#else
-#define BADBG(code) do { } while (0)
-#endif
   while (true) {
-#ifdef FLVIS_BA_DEBUG
-    if (++guard_ > 100) { BADBG(999); return; }
-#endif
-    BADBG(1);
     if (t == 0) {
       s_go = 0;
       const unsigned tl = __hip_atomic_load(&p.kfq_tail[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1295,23 +1285,18 @@ __global__ __launch_bounds__(BA_T) void k_ba_worker(Pipe p) {
       __syncthreads();
       const unsigned hd = s_head, tl = s_tail;
       __syncthreads();
-      BADBG(2);
       if (hd == tl) break;
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       const KeyFrameDev& kf = p.kfq[(size_t)s * KFQ + (hd % KFQ)];
       const long long frame_id = kf.frame_id;
-      BADBG(3);
       ba_update_dev(p, s, kf, reinterpret_cast<long long*>(ba_dyn()), s_cnt);
-      BADBG(4);
       __syncthreads();
       if (p.win[s].solve) ba_solve_dev(p, s, frame_id);
       __atomic_thread_fence(__ATOMIC_RELEASE);
       __syncthreads();
       if (t == 0) __hip_atomic_store(&p.kfq_head[s], hd + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       my_head = hd + 1u;
-      BADBG(5);
     }
-    BADBG(6);
     __atomic_thread_fence(__ATOMIC_RELEASE);
     __syncthreads();
     if (t == 0) __hip_atomic_store(&p.ba_busy[s], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
