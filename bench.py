@@ -195,6 +195,15 @@ def main():
         dom_ms = sum(lk_ms) / 2.0
         dom_bytes = ALG_BYTES["lk_track(temporal)"] * Sg
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM traffic of the same kernel from the committed PMC passes (profiles/r01_lk_pmc.json, scripts/pmc_to_json.py);
+        # PMC collection needs rocprofv3 around the process, so it cannot be measured from inside this script
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_lk_pmc.json")))
+            if S == 64 and pmc.get("traffic_bytes_per_launch"):
+                traffic = int(pmc["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
         out = {
             "metric": "frames/sec/node (640x480 stereo+IMU) + ATE vs CPU ref", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(elapsed / K * 1e3, 4),
@@ -206,7 +215,7 @@ def main():
                        "streams_tracking_at_end": tracking, "keyframes_in_run": int(kfs_total),
                        "ba_runs_in_run": int(cnt[2]), "gpu_ms_per_step_events": round(gpu_ms / K, 4)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
                          "launches_per_step": 2},
             "stages_ms_per_step": {k: round(v, 4) for k, v in stages.items()},

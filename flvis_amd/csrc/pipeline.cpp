@@ -361,7 +361,12 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   }
   if (const char* e = getenv("FLVIS_SYNC_EACH_FRAME")) pl->sync_each_frame = atoi(e) != 0;
   bool evok = true;
-  for (int k = 0; k < Pipeline::NBA && evok; k++) evok = hipStreamCreateWithFlags(&pl->ba_stream[k], hipStreamNonBlocking) == hipSuccess;
+  // the local map must not displace the tracking chain: its streams get the lowest queue priority
+  int prio_least = 0, prio_greatest = 0;
+  hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (const char* e = getenv("FLVIS_BA_PRIORITY")) prio_least = atoi(e);  // tuning knob
+  for (int k = 0; k < Pipeline::NBA && evok; k++)
+    evok = hipStreamCreateWithPriority(&pl->ba_stream[k], hipStreamNonBlocking, prio_least) == hipSuccess;
   evok = evok &&
               hipStreamCreateWithFlags(&pl->det_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&pl->ev_img, hipEventDisableTiming) == hipSuccess &&
