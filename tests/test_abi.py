@@ -51,3 +51,46 @@ def test_product_does_not_reference_oracle():
             if re.search(r"oracle/|libflvis_ref|ref_api\.h|ref_math\.hpp", txt):
                 bad.append(path)
     assert not bad, "product sources must not use the oracle: %s" % bad
+
+
+def test_config_loader_matches_oracle_on_both_rigs():
+    """Host logic of the boundary: the product's yaml loader + stereoRectify (csrc/config.cpp, no GPU involved) and the
+    oracle's are independent implementations; they must produce the same flvis_cfg for the rectified D435i rig and the
+    unrectified EuRoC-like rig: integers exactly, doubles to 1e-9 (4x4 products / inverses and the Rodrigues steps of stereoRectify are associated
+    differently).  The one field with a different meaning on the two sides (IMU axis-remap selector vs. an unused flag)
+    is skipped."""
+    import tempfile
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    import flvis_amd
+    from flvis_amd import synth
+    for tag, text in (("d435", synth.D435I_STEREO_YAML), ("euroc", synth.EUROC_LIKE_YAML)):
+        p = os.path.join(tempfile.gettempdir(), "flvis_cfgpar_%s.yaml" % tag)
+        open(p, "w").write(text)
+        a, b = flvis_amd.load_config(p), O.load_config(p)
+        assert C.sizeof(a) == C.sizeof(b)
+        fb = {getattr(type(b), n).offset: n for n, _ in b._fields_}
+        for name, _ in a._fields_:
+            if name == "imu_type":
+                continue
+            va, vb = getattr(a, name), getattr(b, fb[getattr(type(a), name).offset])
+            if hasattr(va, "__len__"):
+                assert np.allclose(np.array(list(va), float), np.array(list(vb), float), atol=1e-9, rtol=0), (tag, name)
+            elif isinstance(va, float):
+                assert abs(va - vb) <= 1e-9, (tag, name)
+            else:
+                assert va == vb, (tag, name, va, vb)
+        assert a.image_width in (640, 752) and a.window_size in (8, 10)
+
+
+def test_config_loader_rejects_bad_files():
+    import tempfile
+    import flvis_amd
+    p = os.path.join(tempfile.gettempdir(), "flvis_cfg_bad.yaml")
+    open(p, "w").write("type_of_vi: 3\nimage_width: 640\n")
+    with pytest.raises(flvis_amd.FlvisError):
+        flvis_amd.load_config(p)
+    with pytest.raises(flvis_amd.FlvisError):
+        flvis_amd.load_config(os.path.join(tempfile.gettempdir(), "flvis_does_not_exist.yaml"))
