@@ -56,6 +56,8 @@ struct Pipeline {
   static constexpr int NBA = 4;  // local-map streams (upper bound of launches in flight)
   int nba = 2;                   // streams in use (FLVIS_BA_STREAMS, tuning knob)
   bool sync_each_frame = false;  // FLVIS_SYNC_EACH_FRAME=1: image_feed waits for the previous frame (tuning knob)
+  int ba_every = 1;              // launch the local-map worker every n-th frame (FLVIS_BA_EVERY): its workgroups need an
+                                 // empty CU each, also the ones that find nothing to do
   hipStream_t ba_stream[NBA] = {};
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
@@ -360,6 +362,10 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     if (v >= 1 && v <= Pipeline::NBA) pl->nba = v;
   }
   if (const char* e = getenv("FLVIS_SYNC_EACH_FRAME")) pl->sync_each_frame = atoi(e) != 0;
+  if (const char* e = getenv("FLVIS_BA_EVERY")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= KFQ / 2) pl->ba_every = v;
+  }
   bool evok = true;
   // the local map must not displace the tracking chain: its streams get the lowest queue priority
   int prio_least = 0, prio_greatest = 0;
@@ -598,18 +604,18 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PB(16, st);
   launch_depth_innovate(st, p);
   PE(16, st);
-  const int par = (int)(pl->frames_fed % pl->nba);
+  const int par = (int)((pl->frames_fed / pl->ba_every) % pl->nba);
   PB(17, st);
   launch_frame_end(st, p, (int)pl->frames_fed);
   PE(17, st);
-  if (with_local_map) {
+  if (with_local_map && (pl->frames_fed % pl->ba_every) == 0) {
     hipStream_t bs = pl->ba_stream[par];
     hipEventRecord(pl->ev_fe[par], st);
     hipStreamWaitEvent(bs, pl->ev_fe[par], 0);
     PB(18, bs);
     launch_ba_worker(bs, p);
     PE(18, bs);
-  } else {
+  } else if (!with_local_map) {
     // without a local map nobody consumes the keyframe queue: drop what frame_end appended
     hipMemcpyAsync(p.kfq_head, p.kfq_tail, sizeof(unsigned) * S, hipMemcpyDeviceToDevice, st);
     if (prof) {
