@@ -318,6 +318,14 @@ class Tracker:
             self.ctx._check(r, "get_trajectory")
         return rows
 
+    def write_trajectory(self, stream, first, n, path, fmt=0, min_dt=0.0):
+        """flvis_write_trajectory: fmt 0 = `stamp x y z qw qx qy qz`, 1 = KITTI 12 columns.  Returns lines written."""
+        self.lib.flvis_write_trajectory.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_double]
+        r = self.lib.flvis_write_trajectory(self.ctx._h, stream, first, n, path.encode(), fmt, C.c_double(min_dt))
+        if r < 0:
+            self.ctx._check(r, "write_trajectory")
+        return r
+
     def counters(self):
         c = (C.c_int64 * 3)()
         self.ctx._check(self.lib.flvis_get_counters(self.ctx._h, c), "get_counters")

@@ -773,6 +773,51 @@ int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first, int n, double* h
   return n;
 }
 
+int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first, int n, const char* path, int format, double min_dt) {
+  if (!ctx || !ctx->pipe || !path || (format != 0 && format != 1)) return FLVIS_ERR_INVALID_ARG;
+  std::vector<double> rows((size_t)(n > 0 ? n : 0) * 9);
+  int got = flvis_get_trajectory(ctx, stream, first, n, rows.data());
+  if (got < 0) return got;
+  FILE* f = fopen(path, "w");
+  if (!f) return ctx->fail(FLVIS_ERR_INVALID_ARG, "write_trajectory: cannot open the output file");
+  int written = 0;
+  bool have_last = false;
+  double last_t = 0;
+  for (int i = 0; i < got; i++) {
+    const double* r = &rows[(size_t)i * 9];
+    if (((int)r[8] & 15) != 1) continue;  // only frames of a TRACKING stream carry a pose
+    const double t = r[0];
+    if (min_dt > 0) {
+      if (!have_last) {  // the reference's throttle starts its clock at the first call
+        have_last = true;
+        last_t = t;
+        continue;
+      }
+      if (!(t - last_t > min_dt)) continue;
+    }
+    last_t = t;
+    // T_c_w = (t, q) -> T_w_c: R_w_c = R^T, centre = -R^T t
+    double qx = r[4], qy = r[5], qz = r[6], qw = r[7];
+    const double qn = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+    qx /= qn; qy /= qn; qz /= qn; qw /= qn;
+    const double R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)},
+                            {2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)},
+                            {2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)}};
+    double c[3];
+    for (int k = 0; k < 3; k++) c[k] = -(R[0][k] * r[1] + R[1][k] * r[2] + R[2][k] * r[3]);
+    if (format == 0) {
+      // operator<< with setprecision(6) (default float notation) == %.6g; the stamp prints like ros::Time (sec.nsec)
+      fprintf(f, "%.9f %.6g %.6g %.6g %.6g %.6g %.6g %.6g\n", t, c[0], c[1], c[2], qw, -qx, -qy, -qz);
+    } else {
+      fprintf(f, "%.6g %.6g %.6g %.6g %.6g %.6g %.6g %.6g %.6g %.6g %.6g %.6g\n", R[0][0], R[1][0], R[2][0], c[0], R[0][1], R[1][1],
+              R[2][1], c[1], R[0][2], R[1][2], R[2][2], c[2]);
+    }
+    written++;
+  }
+  fclose(f);
+  return written;
+}
+
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) {
   if (!ctx || !ctx->pipe || !h3) return FLVIS_ERR_INVALID_ARG;
   sync_all(ctx);

@@ -1,0 +1,189 @@
+"""Trajectory / dataset I/O and the ATE tool (harness code, CPU only).
+
+Formats:
+  * recorder format of the reference (src/independ_modules/vo_repub_rec.cpp:82-91): `stamp x y z qw qx qy qz`
+    (what `evo_traj tum` is fed in results/1_readme, with qw first as the recorder writes it);
+  * KITTI odometry poses (vo_repub_rec.cpp:100-111, bag/KITTI/dataset/poses.zip): 12 row-major entries of [R | t] per line;
+  * EuRoC ASL ground truth (`state_groundtruth_estimate0/data.csv`): `#timestamp [ns], p_RS_R_x, p_RS_R_y, p_RS_R_z,
+    q_RS_w, q_RS_x, q_RS_y, q_RS_z, ...`.
+ATE = RMSE of the translation error after a least-squares rigid (optionally similarity) alignment (Umeyama 1991), on poses
+associated by nearest timestamp -- the metric BASELINE.json quotes.
+"""
+import io
+import zipfile
+
+import numpy as np
+
+
+def quat_to_rot(qw, qx, qy, qz):
+    n = np.sqrt(qw * qw + qx * qx + qy * qy + qz * qz)
+    qw, qx, qy, qz = qw / n, qx / n, qy / n, qz / n
+    return np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                     [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                     [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+
+
+def rot_to_quat(R):
+    """-> (qw, qx, qy, qz), qw >= 0."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q if q[0] >= 0 else -q
+
+
+# ---------------------------------------------------------------------------------------------- recorder format
+def write_stamped(path, stamps, positions, quats_wxyz):
+    """`stamp x y z qw qx qy qz`, 6 significant digits like the reference's recorder (setprecision(6))."""
+    with open(path, "w") as f:
+        for t, p, q in zip(stamps, positions, quats_wxyz):
+            f.write("%.9f %.6g %.6g %.6g %.6g %.6g %.6g %.6g\n" % (t, p[0], p[1], p[2], q[0], q[1], q[2], q[3]))
+
+
+def read_stamped(path):
+    """-> (stamps [n], positions [n,3], quats_wxyz [n,4])."""
+    a = np.loadtxt(path, ndmin=2)
+    if a.size == 0:
+        return np.zeros(0), np.zeros((0, 3)), np.zeros((0, 4))
+    return a[:, 0], a[:, 1:4], a[:, 4:8]
+
+
+def throttle(stamps, min_dt=0.1):
+    """Indices the reference's recorder would keep (vo_repub_rec.cpp:77-79): its clock starts at the first call, a pose
+    is written when more than min_dt has passed since the last written one."""
+    keep, last = [], None
+    for i, t in enumerate(stamps):
+        if last is None:
+            last = t
+            continue
+        if t - last > min_dt:
+            keep.append(i)
+            last = t
+    return np.array(keep, dtype=int)
+
+
+# ---------------------------------------------------------------------------------------------- KITTI
+def write_kitti(path, rotations, positions):
+    with open(path, "w") as f:
+        for R, t in zip(rotations, positions):
+            f.write(" ".join("%.6g" % v for v in (R[0, 0], R[0, 1], R[0, 2], t[0], R[1, 0], R[1, 1], R[1, 2], t[1],
+                                                  R[2, 0], R[2, 1], R[2, 2], t[2])) + "\n")
+
+
+def _kitti_rows(text):
+    a = np.loadtxt(io.StringIO(text), ndmin=2)
+    assert a.shape[1] == 12, "KITTI pose files have 12 columns"
+    M = a.reshape(-1, 3, 4)
+    return M[:, :, :3].copy(), M[:, :, 3].copy()
+
+
+def read_kitti(path, member=None):
+    """-> (rotations [n,3,3], positions [n,3]).  `path` may be a poses.zip (give the member, e.g. 'poses/00.txt')."""
+    if str(path).endswith(".zip"):
+        with zipfile.ZipFile(path) as z:
+            names = [n for n in z.namelist() if n.endswith(".txt")]
+            name = member if member is not None else sorted(names)[0]
+            return _kitti_rows(z.read(name).decode())
+    return _kitti_rows(open(path).read())
+
+
+# ---------------------------------------------------------------------------------------------- EuRoC ASL
+def read_euroc_groundtruth(csv_path):
+    """state_groundtruth_estimate0/data.csv -> (stamps [s], positions [n,3], quats_wxyz [n,4])."""
+    rows = []
+    for line in open(csv_path):
+        if line.startswith("#") or not line.strip():
+            continue
+        v = line.split(",")
+        rows.append([float(x) for x in v[:8]])
+    a = np.array(rows).reshape(-1, 8)
+    return a[:, 0] * 1e-9, a[:, 1:4], a[:, 4:8]
+
+
+def read_euroc_image_list(csv_path):
+    """mav0/cam*/data.csv -> [(stamp_s, filename)]."""
+    out = []
+    for line in open(csv_path):
+        if line.startswith("#") or not line.strip():
+            continue
+        ts, name = line.strip().split(",")[:2]
+        out.append((int(ts) * 1e-9, name.strip()))
+    return out
+
+
+def read_euroc_imu(csv_path):
+    """mav0/imu0/data.csv -> [n,7] (t, gyro xyz, acc xyz) in the sensor frame (the reference remaps axes per type_of_vi)."""
+    rows = []
+    for line in open(csv_path):
+        if line.startswith("#") or not line.strip():
+            continue
+        v = [float(x) for x in line.split(",")[:7]]
+        rows.append([v[0] * 1e-9] + v[1:])
+    return np.array(rows).reshape(-1, 7)
+
+
+# ---------------------------------------------------------------------------------------------- ATE
+def associate(stamps_a, stamps_b, max_dt=0.02):
+    """Nearest-timestamp association (each stamp of b used at most once) -> (idx_a, idx_b)."""
+    stamps_a, stamps_b = np.asarray(stamps_a, float), np.asarray(stamps_b, float)
+    if len(stamps_a) == 0 or len(stamps_b) == 0:
+        return np.zeros(0, int), np.zeros(0, int)
+    order = np.argsort(stamps_b)
+    sb = stamps_b[order]
+    pos = np.searchsorted(sb, stamps_a)
+    ia, ib, used = [], [], set()
+    for i, p in enumerate(pos):
+        best, bd = -1, max_dt
+        for c in (p - 1, p):
+            if 0 <= c < len(sb):
+                d = abs(sb[c] - stamps_a[i])
+                if d <= bd and order[c] not in used:
+                    best, bd = order[c], d
+        if best >= 0:
+            used.add(best)
+            ia.append(i)
+            ib.append(best)
+    return np.array(ia, int), np.array(ib, int)
+
+
+def umeyama(src, dst, with_scale=False):
+    """Least-squares similarity/rigid transform dst ~ s R src + t (Umeyama 1991) -> (s, R, t)."""
+    src, dst = np.asarray(src, float), np.asarray(dst, float)
+    mu_s, mu_d = src.mean(0), dst.mean(0)
+    xs, xd = src - mu_s, dst - mu_d
+    cov = xd.T @ xs / len(src)
+    U, D, Vt = np.linalg.svd(cov)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vt
+    s = float(np.trace(np.diag(D) @ S) / (xs ** 2).sum() * len(src)) if with_scale else 1.0
+    t = mu_d - s * R @ mu_s
+    return s, R, t
+
+
+def ate_rmse(est_pos, ref_pos, align=True, with_scale=False):
+    """RMSE of ||ref - (s R est + t)|| over associated positions."""
+    est_pos, ref_pos = np.asarray(est_pos, float), np.asarray(ref_pos, float)
+    if len(est_pos) < 3 and align:
+        raise ValueError("need at least 3 poses to align")
+    if align:
+        s, R, t = umeyama(est_pos, ref_pos, with_scale)
+        est_pos = (s * (R @ est_pos.T)).T + t
+    return float(np.sqrt(np.mean(np.sum((est_pos - ref_pos) ** 2, axis=1))))
+
+
+def ate_from_files(est_path, ref_path, max_dt=0.02, with_scale=False):
+    te, pe, _ = read_stamped(est_path)
+    tr, pr, _ = read_stamped(ref_path)
+    ia, ib = associate(te, tr, max_dt)
+    return ate_rmse(pe[ia], pr[ib], True, with_scale), len(ia)

@@ -165,6 +165,14 @@ int flvis_get_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id,
                          int64_t* h_lm_id, double* h_lm_3d, int* lm_outlier_count, int64_t* h_outlier_id);
 /* Device-side trajectory of one stream: rows of 9 doubles (t, tx ty tz qx qy qz qw, state | new_kf<<4). */
 int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_frames, double* h_rows9);
+/* Trajectory recorder (replaces src/independ_modules/vo_repub_rec.cpp:74-124 for offline runs): writes the recorded
+ * camera poses T_w_c (inverse of T_c_w) of frames [first_frame, first_frame + n_frames) whose state is TRACKING to a
+ * text file.  format 0: `stamp x y z qw qx qy qz` per line (vo_repub_rec.cpp:82-91, the TUM order with qw first);
+ * format 1: KITTI, 12 row-major entries of [R | t] per line (:100-111).  min_dt > 0 emulates the recorder's throttle
+ * (a pose is written only if its stamp is more than min_dt after the last written one; the reference uses 0.1 s of
+ * wall-clock).  Returns the number of lines written or a negative error code. */
+int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_frames, const char* path, int format,
+                           double min_dt);
 /* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
 /* Raw device counter block (64 x int64): [0..7] as above, [8..] per-phase cycle counters of the BA kernel, filled only by

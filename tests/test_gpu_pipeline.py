@@ -146,6 +146,47 @@ def test_frontend_parity_euroc_mode(ctx):
     _run_frontend_parity(ctx, cfg, ocfg, synth.euroc_rig(), [9], 45, 8, 2)
 
 
+def test_trajectory_recorder(ctx):
+    """flvis_write_trajectory (the recorder of vo_repub_rec.cpp:74-124): both file formats agree with the device
+    trajectory, only TRACKING frames are written, the throttle rule holds."""
+    import flvis_amd
+    from flvis_amd import synth, traj_io
+    cfg, _ = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
+    rig = synth.euroc_rig()
+    nframes = 30
+    trk = flvis_amd.Tracker(ctx, cfg, 1, seed_base=5, traj_capacity=nframes)
+    tr = synth.Trajectory(9)
+    rnd = synth.Renderer("cuda", rig=rig)
+    t_prev = -0.05
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        trk.imu_feed_flvis(0, synth.imu_samples(tr, 9, t_prev, t))
+        t_prev = t
+        i0, i1 = rnd.stereo_frame([tr], t, f)
+        trk.image_feed(i0, i1, [t], with_local_map=False)
+    rows = trk.trajectory(0, 0, nframes)
+    tracked = [i for i in range(nframes) if (int(rows[i, 8]) & 15) == 1]
+    assert len(tracked) >= 15
+    p0 = os.path.join(tempfile.gettempdir(), "flvis_rec_tum.txt")
+    p1 = os.path.join(tempfile.gettempdir(), "flvis_rec_kitti.txt")
+    assert trk.write_trajectory(0, 0, nframes, p0, 0) == len(tracked)
+    assert trk.write_trajectory(0, 0, nframes, p1, 1) == len(tracked)
+    ts, pos, quat = traj_io.read_stamped(p0)
+    Rk, tk = traj_io.read_kitti(p1)
+    for k, i in enumerate(tracked):
+        R = traj_io.quat_to_rot(rows[i, 7], rows[i, 4], rows[i, 5], rows[i, 6])      # T_c_w rotation
+        centre = -R.T @ rows[i, 1:4]
+        assert abs(ts[k] - rows[i, 0]) < 1e-8
+        assert np.allclose(pos[k], centre, rtol=1e-5, atol=1e-6) and np.allclose(tk[k], centre, rtol=1e-5, atol=1e-6)
+        assert np.allclose(Rk[k], R.T, atol=1e-5)
+        assert np.allclose(traj_io.quat_to_rot(*quat[k]), R.T, atol=1e-5)           # written orientation is q_w_c
+    n_thr = trk.write_trajectory(0, 0, nframes, p0, 0, 0.1)
+    assert n_thr == len(traj_io.throttle(rows[tracked, 0], 0.1))
+    # the estimate follows the synthetic ground truth (camera centres, rigid alignment)
+    gt = np.array([-(tr.T_c_w(rows[i, 0], rig)[0]).T @ tr.T_c_w(rows[i, 0], rig)[1] for i in tracked])
+    assert traj_io.ate_rmse(pos, gt) < 0.02
+
+
 def test_local_map_parity(ctx):
     import flvis_amd
     cfg, _ = _cfgs()

@@ -1,0 +1,150 @@
+"""CPU tests of the trajectory I/O + ATE tool: recorder / KITTI formats, association, Umeyama ATE."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from flvis_amd import traj_io as T
+traj_io = T
+
+
+def _rand_rot(rng):
+    q = rng.normal(size=4)
+    return T.quat_to_rot(*q)
+
+
+def test_quaternion_round_trip_and_recorder_format():
+    rng = np.random.default_rng(1)
+    n = 50
+    stamps = 1403636580.0 + np.arange(n) * 0.05
+    pos = rng.normal(size=(n, 3))
+    quats = []
+    for _ in range(n):
+        R = _rand_rot(rng)
+        q = T.rot_to_quat(R)
+        assert np.allclose(T.quat_to_rot(*q), R, atol=1e-12) and q[0] >= 0
+        quats.append(q)
+    p = os.path.join(tempfile.gettempdir(), "flvis_traj_rt.txt")
+    T.write_stamped(p, stamps, pos, quats)
+    first = open(p).readline().split()
+    assert len(first) == 8 and "." in first[0] and len(first[0].split(".")[1]) == 9      # stamp like ros::Time
+    t2, p2, q2 = T.read_stamped(p)
+    assert np.allclose(t2, stamps, atol=1e-6) and np.allclose(p2, pos, rtol=1e-5, atol=1e-6)   # 6 significant digits
+    assert np.allclose(q2, np.array(quats), atol=1e-5)
+
+
+def test_throttle_matches_the_recorder_rule():
+    stamps = np.arange(40) * 0.0625       # 16 Hz, exactly representable
+    keep = T.throttle(stamps, 0.125)
+    # the clock starts at the first pose; then one pose whenever MORE than min_dt elapsed: every third pose here
+    assert keep[0] == 3 and np.all(np.diff(keep) == 3)
+
+
+def test_kitti_round_trip_and_reference_poses_zip():
+    rng = np.random.default_rng(2)
+    Rs = np.stack([_rand_rot(rng) for _ in range(20)])
+    ts = rng.normal(size=(20, 3)) * 10
+    p = os.path.join(tempfile.gettempdir(), "flvis_kitti_rt.txt")
+    T.write_kitti(p, Rs, ts)
+    assert len(open(p).readline().split()) == 12
+    R2, t2 = T.read_kitti(p)
+    assert np.allclose(R2, Rs, atol=1e-5) and np.allclose(t2, ts, rtol=1e-5, atol=1e-5)
+    ref_zip = "/root/reference/bag/KITTI/dataset/poses.zip"
+    if os.path.exists(ref_zip):           # present in the build container only
+        R, t = T.read_kitti(ref_zip)
+        assert len(R) > 100 and np.allclose(R[0], np.eye(3), atol=1e-9) and np.allclose(t[0], 0, atol=1e-9)
+        dets = np.linalg.det(R)
+        assert np.allclose(dets, 1.0, atol=1e-4)
+        # a trajectory is its own ground truth: ATE 0; shifted/rotated copy: ATE 0 after alignment
+        Rg = _rand_rot(rng)
+        moved = (Rg @ t.T).T + np.array([5.0, -3.0, 1.0])
+        assert T.ate_rmse(moved, t) < 1e-6 * np.abs(t).max()
+
+
+def test_umeyama_recovers_similarity_and_ate_of_noise():
+    rng = np.random.default_rng(3)
+    src = rng.normal(size=(200, 3)) * 3
+    R = _rand_rot(rng)
+    if np.linalg.det(R) < 0:
+        R[:, 0] *= -1
+    t = np.array([1.0, -2.0, 0.5])
+    dst = 1.7 * (R @ src.T).T + t
+    s, R2, t2 = T.umeyama(src, dst, with_scale=True)
+    assert abs(s - 1.7) < 1e-9 and np.allclose(R2, R, atol=1e-9) and np.allclose(t2, t, atol=1e-9)
+    noisy = (R @ src.T).T + t + rng.normal(size=src.shape) * 0.01
+    a = T.ate_rmse(src, noisy)
+    assert 0.012 < a < 0.022                        # sqrt(3) * 0.01 up to the fit
+    with pytest.raises(ValueError):
+        T.ate_rmse(src[:2], dst[:2])
+
+
+def test_association_and_file_level_ate():
+    rng = np.random.default_rng(4)
+    t_ref = np.arange(0, 10, 0.005)                 # 200 Hz ground truth
+    p_ref = np.stack([np.sin(t_ref), np.cos(0.5 * t_ref), 0.1 * t_ref], 1)
+    t_est = np.arange(0.3, 9.5, 0.1) + 0.001        # 10 Hz estimate, 1 ms clock offset
+    p_est = np.stack([np.sin(t_est), np.cos(0.5 * t_est), 0.1 * t_est], 1) + rng.normal(size=(len(t_est), 3)) * 0.002
+    ia, ib = T.associate(t_est, t_ref, 0.003)
+    assert len(ia) == len(t_est) and np.all(np.abs(t_ref[ib] - t_est[ia]) <= 0.003) and len(set(ib)) == len(ib)
+    q = np.tile([1.0, 0, 0, 0], (len(t_ref), 1))
+    pa, pb = os.path.join(tempfile.gettempdir(), "flvis_ate_est.txt"), os.path.join(tempfile.gettempdir(), "flvis_ate_ref.txt")
+    T.write_stamped(pa, t_est, p_est, q[:len(t_est)])
+    T.write_stamped(pb, t_ref, p_ref, q)
+    ate, n = T.ate_from_files(pa, pb, 0.003)
+    assert n == len(t_est) and ate < 0.01
+
+
+def test_euroc_csv_readers():
+    d = tempfile.mkdtemp()
+    gt = os.path.join(d, "gt.csv")
+    open(gt, "w").write("#timestamp, p_RS_R_x [m], p_RS_R_y [m], p_RS_R_z [m], q_RS_w [], q_RS_x [], q_RS_y [], q_RS_z [], v...\n"
+                        "1403636580838555648,4.688319,-1.786938,0.783338,0.534108,-0.153029,-0.827383,-0.082152,0,0,0\n"
+                        "1403636580843555328,4.688177,-1.786770,0.787350,0.534640,-0.152990,-0.826976,-0.082863,0,0,0\n")
+    t, p, q = T.read_euroc_groundtruth(gt)
+    assert len(t) == 2 and abs(t[0] - 1403636580.838555648) < 1e-6 and np.allclose(p[0], [4.688319, -1.786938, 0.783338])
+    assert abs(np.linalg.norm(q[0]) - 1) < 1e-3
+    cam = os.path.join(d, "cam.csv")
+    open(cam, "w").write("#timestamp [ns],filename\n1403636579763555584,1403636579763555584.png\n")
+    lst = T.read_euroc_image_list(cam)
+    assert lst[0][1].endswith(".png") and abs(lst[0][0] - 1403636579.763555584) < 1e-6
+    imu = os.path.join(d, "imu.csv")
+    open(imu, "w").write("#timestamp [ns],w_RS_S_x,w_RS_S_y,w_RS_S_z,a_RS_S_x,a_RS_S_y,a_RS_S_z\n"
+                         "1403636579758555392,-0.0991,0.1473,0.0272,8.1476,-0.3759,-2.4026\n")
+    a = T.read_euroc_imu(imu)
+    assert a.shape == (1, 7) and abs(a[0, 4] - 8.1476) < 1e-9
+
+
+# ---------------------------------------------------------------- KITTI ground truth shipped with the reference (data fixture)
+GOLD_KITTI = os.path.join(os.path.dirname(__file__), "golden", "kitti_poses_04_head.txt")
+
+
+def test_kitti_ground_truth_fixture_roundtrip_and_ate(tmp_path):
+    """tests/golden/kitti_poses_04_head.txt = first 120 poses of KITTI sequence 04 from the reference's
+    bag/KITTI/dataset/poses.zip (scripts/make_kitti_fixture.py)."""
+    R, t = traj_io.read_kitti(GOLD_KITTI)
+    assert R.shape == (120, 3, 3) and t.shape == (120, 3)
+    for k in range(0, 120, 17):
+        assert np.allclose(R[k] @ R[k].T, np.eye(3), atol=1e-5) and abs(np.linalg.det(R[k]) - 1) < 1e-5
+    assert np.linalg.norm(t[0]) < 1e-9 and np.linalg.norm(t[-1]) > 100.0          # a car driving forward
+    p = str(tmp_path / "w.txt")
+    traj_io.write_kitti(p, R, t)
+    R2, t2 = traj_io.read_kitti(p)
+    assert np.allclose(R2, R, atol=6e-6) and np.allclose(t2, t, rtol=6e-6, atol=1e-6)   # %.6g like the recorder
+    # ATE: a rigidly moved copy aligns back to zero; isotropic noise of sigma gives RMSE ~ sigma*sqrt(3)
+    Rg = traj_io.quat_to_rot(0.9, 0.1, -0.3, 0.2)
+    moved = (Rg @ t.T).T + np.array([5.0, -2.0, 1.0])
+    assert traj_io.ate_rmse(moved, t) < 1e-9
+    rng = np.random.default_rng(3)
+    noisy = moved + rng.normal(0, 0.05, moved.shape)
+    a = traj_io.ate_rmse(noisy, t)
+    assert 0.05 * np.sqrt(3) * 0.8 < a < 0.05 * np.sqrt(3) * 1.2
+    assert traj_io.ate_rmse(1.7 * moved, t, with_scale=True) < 1e-8
+    assert traj_io.ate_rmse(1.7 * moved, t, with_scale=False) > 1.0
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/bag/KITTI/dataset/poses.zip"), reason="reference data not present")
+def test_kitti_zip_reader_matches_fixture():
+    R, t = traj_io.read_kitti("/root/reference/bag/KITTI/dataset/poses.zip", "poses/04.txt")
+    Rf, tf = traj_io.read_kitti(GOLD_KITTI)
+    assert len(R) == 271 and np.array_equal(R[:120], Rf) and np.array_equal(t[:120], tf)
