@@ -263,7 +263,7 @@ def main():
                 return -R.T @ p7[0:3]
             grow = trks[0].trajectory(0, skip, n_cpu)
             sel = [j for j in range(n_cpu) if cpu_state[j] == 1 and (int(grow[j, 8]) & 15) == 1]
-            if sel:
+            if len(sel) >= 3:
                 from flvis_amd import traj_io
                 gc = np.array([centre(grow[j, 1:8]) for j in sel])
                 cc = np.array([centre(cpu_pos[j]) for j in sel])

@@ -303,3 +303,136 @@ class Tracker:
         n = lib().ref_tracker_keyframe(self.h, cap, C.byref(fid), _p(pose, C.c_double), _p(ids, C.c_int64),
                                        _p(p2u, C.c_double), _p(p3w, C.c_double))
         return dict(frame_id=fid.value, pose7=pose, lm_id=ids[:n].copy(), lm_2d=p2u[:n].copy(), lm_3d=p3w[:n].copy())
+
+
+# ------------------------------------------------------------------------------------------- ORB (oracle/ref_orb.cpp)
+def resize_linear(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((dh, dw), np.uint8)
+    lib().ref_resize_linear_u8(_p(img, C.c_uint8), img.shape[1], img.shape[0], _p(out, C.c_uint8), int(dw), int(dh))
+    return out
+
+
+def fast_score_map(img, thr):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib().ref_fast_score_map(_p(img, C.c_uint8), img.shape[1], img.shape[0], int(thr), _p(out, C.c_uint8))
+    return out
+
+
+def fast_detect(img, thr, cap=1 << 18):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().ref_fast_detect(_p(img, C.c_uint8), img.shape[1], img.shape[0], int(thr), _p(out, C.c_int), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def gaussian_blur7(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    lib().ref_gaussian_blur7(_p(img, C.c_uint8), img.shape[1], img.shape[0], _p(out, C.c_uint8))
+    return out
+
+
+def gauss_kernel7_fixed():
+    k = np.zeros(7, np.int32)
+    lib().ref_gauss_kernel7_fixed(_p(k, C.c_int))
+    return k
+
+
+def fast_atan2(y, x):
+    f = lib().ref_fast_atan2
+    f.restype = C.c_float
+    f.argtypes = [C.c_float, C.c_float]
+    return f(y, x)
+
+
+def orb_umax(half=15):
+    u = np.zeros(half + 2, np.int32)
+    lib().ref_orb_umax(half, _p(u, C.c_int))
+    return u[:half + 1].copy()
+
+
+def orb_ic_angle(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    f = lib().ref_orb_ic_angle
+    f.restype = C.c_float
+    return f(_p(img, C.c_uint8), img.shape[1], int(x), int(y))
+
+
+def orb_harris(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    f = lib().ref_orb_harris
+    f.restype = C.c_float
+    return f(_p(img, C.c_uint8), img.shape[1], int(x), int(y))
+
+
+def orb_default_pattern():
+    p = np.zeros((512, 2), np.int8)
+    lib().ref_orb_default_pattern(_p(p, C.c_int8))
+    return p
+
+
+def orb_level_sizes(w, h, nlevels=8, sf=1.2):
+    lw, lh, ls = np.zeros(nlevels, np.int32), np.zeros(nlevels, np.int32), np.zeros(nlevels, np.float32)
+    f = lib().ref_orb_level_sizes
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    f(w, h, nlevels, sf, _p(lw, C.c_int), _p(lh, C.c_int), _p(ls, C.c_float))
+    return lw, lh, ls
+
+
+def orb_features_per_level(nfeatures=1000, nlevels=8, sf=1.2):
+    n = np.zeros(nlevels, np.int32)
+    f = lib().ref_orb_features_per_level
+    f.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int)]
+    f(nfeatures, nlevels, sf, _p(n, C.c_int))
+    return n
+
+
+def orb_detect_and_compute(img, nfeatures=1000, sf=1.2, nlevels=8, fast_thr=20, pattern=None, cap=8192, want_pyr=False):
+    """-> kps [n,6] (x, y, size, angle, response, octave), desc [n,32] (, pyramid levels, blurred levels)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    lw, lh, _ = orb_level_sizes(w, h, nlevels, sf)
+    tot = int(np.sum(lw.astype(np.int64) * lh))
+    kps = np.zeros((cap, 6), np.float32)
+    desc = np.zeros((cap, 32), np.uint8)
+    pyr = np.zeros(tot, np.uint8) if want_pyr else None
+    blur = np.zeros(tot, np.uint8) if want_pyr else None
+    pat = None if pattern is None else np.ascontiguousarray(pattern, np.int8)
+    f = lib().ref_orb_detect_and_compute
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p,
+                  C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_int, C.c_void_p, C.c_void_p]
+    n = f(_p(img, C.c_uint8), w, h, nfeatures, sf, nlevels, fast_thr, None if pat is None else pat.ctypes.data,
+          _p(kps, C.c_float), _p(desc, C.c_uint8), cap, None if pyr is None else pyr.ctypes.data,
+          None if blur is None else blur.ctypes.data)
+    assert n >= 0, "oracle ORB: capacity exceeded"
+    if not want_pyr:
+        return kps[:n].copy(), desc[:n].copy()
+    lv, bl, off = [], [], 0
+    for l in range(nlevels):
+        sz = int(lw[l]) * int(lh[l])
+        lv.append(pyr[off:off + sz].reshape(lh[l], lw[l]).copy())
+        bl.append(blur[off:off + sz].reshape(lh[l], lw[l]).copy())
+        off += sz
+    return kps[:n].copy(), desc[:n].copy(), lv, bl
+
+
+def hamming_knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros((len(q), 2), np.int32)
+    dist = np.zeros((len(q), 2), np.int32)
+    lib().ref_hamming_knn2(_p(q, C.c_uint8), len(q), _p(t, C.c_uint8), len(t), _p(idx, C.c_int), _p(dist, C.c_int))
+    return idx, dist
+
+
+def orb_match(a, b, ratio_max):
+    a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+    b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+    pairs = np.zeros((max(len(a), 1), 2), np.int32)
+    f = lib().ref_orb_match_mutual_ratio
+    f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_double, C.POINTER(C.c_int)]
+    n = f(_p(a, C.c_uint8), len(a), _p(b, C.c_uint8), len(b), float(ratio_max), _p(pairs, C.c_int))
+    return pairs[:n].copy()
