@@ -161,6 +161,95 @@ class Context:
 
 
 # ---------------------------------------------------------------------------------------------------- pipeline level
+
+    # ---- ORB extraction + Hamming matching ---------------------------------------------------------
+    def resize_linear(self, img, dw, dh):
+        import torch
+        img = img.contiguous()
+        n, h, w = img.shape
+        out = torch.empty((n, dh, dw), dtype=torch.uint8, device=img.device)
+        self._check(self._lib.flvis_hip_resize_linear(self._h, _ptr(img), w, h, _ptr(out), int(dw), int(dh), n), "resize_linear")
+        return out
+
+    def fast_score(self, img, threshold):
+        import torch
+        img = img.contiguous()
+        n, h, w = img.shape
+        out = torch.empty_like(img)
+        self._check(self._lib.flvis_hip_fast_score(self._h, _ptr(img), w, h, n, int(threshold), _ptr(out)), "fast_score")
+        return out
+
+    def gaussian_blur7(self, img):
+        import torch
+        img = img.contiguous()
+        n, h, w = img.shape
+        out = torch.empty_like(img)
+        self._check(self._lib.flvis_hip_gaussian_blur7(self._h, _ptr(img), _ptr(out), w, h, n), "gaussian_blur7")
+        return out
+
+    def orb_detect_and_compute(self, img, nfeatures=1000, scale_factor=1.2, nlevels=8, fast_threshold=20, pattern=None,
+                               cap=2048):
+        """img uint8 [n,h,w] -> (kps float32 [n,cap,6] (x, y, size, angle, response, octave), desc uint8 [n,cap,32],
+        count int32 [n], overflow int32 [n])."""
+        import numpy as np
+        import torch
+        img = img.contiguous()
+        n, h, w = img.shape
+        kps = torch.zeros((n, cap, 6), dtype=torch.float32, device=img.device)
+        desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device=img.device)
+        cnt = torch.zeros((n,), dtype=torch.int32, device=img.device)
+        ovf = torch.zeros((n,), dtype=torch.int32, device=img.device)
+        prm = OrbParams(int(nfeatures), float(scale_factor), int(nlevels), int(fast_threshold))
+        pat = None
+        if pattern is not None:
+            pat = np.ascontiguousarray(pattern, np.int8)
+            assert pat.size == 1024
+        self._check(self._lib.flvis_hip_orb_detect_and_compute(
+            self._h, _ptr(img), w, h, n, C.byref(prm), C.c_void_p(pat.ctypes.data if pat is not None else 0), _ptr(kps),
+            _ptr(desc), _ptr(cnt), cap, _ptr(ovf)), "orb_detect_and_compute")
+        return kps, desc, cnt, ovf
+
+    def hamming_knn2(self, query, nq, train, nt):
+        """query uint8 [p,qcap,32], nq int32 [p], train uint8 [p,tcap,32], nt int32 [p] -> (idx, dist) int32 [p,qcap,2]."""
+        import torch
+        query, train = query.contiguous(), train.contiguous()
+        p, qcap, _ = query.shape
+        tcap = train.shape[1]
+        idx = torch.full((p, qcap, 2), -7, dtype=torch.int32, device=query.device)
+        dist = torch.full((p, qcap, 2), -7, dtype=torch.int32, device=query.device)
+        self._check(self._lib.flvis_hip_hamming_knn2(self._h, _ptr(query), _ptr(nq), qcap, _ptr(train), _ptr(nt), tcap, p,
+                                                     _ptr(idx), _ptr(dist)), "hamming_knn2")
+        return idx, dist
+
+    def orb_match(self, a, na, b, nb, ratio_max):
+        """mutual-best + ratio test -> (pairs int32 [p,acap,2], npairs int32 [p])."""
+        import torch
+        a, b = a.contiguous(), b.contiguous()
+        p, acap, _ = a.shape
+        bcap = b.shape[1]
+        pairs = torch.full((p, acap, 2), -1, dtype=torch.int32, device=a.device)
+        npairs = torch.zeros((p,), dtype=torch.int32, device=a.device)
+        self._check(self._lib.flvis_hip_orb_match(self._h, _ptr(a), _ptr(na), acap, _ptr(b), _ptr(nb), bcap, p,
+                                                  C.c_double(ratio_max), _ptr(pairs), _ptr(npairs)), "orb_match")
+        return pairs, npairs
+
+
+
+class OrbParams(C.Structure):
+    """flvis_orb_params of include/flvis_hip.h."""
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int), ("fast_threshold", C.c_int)]
+
+
+def orb_default_pattern():
+    """flvis_orb_default_pattern (host only): the built-in 256-pair sampling pattern as int8 [512,2]."""
+    import numpy as np
+    p = np.zeros((512, 2), np.int8)
+    rc = load_library().flvis_orb_default_pattern(C.c_void_p(p.ctypes.data))
+    if rc != FLVIS_OK:
+        raise FlvisError("flvis_orb_default_pattern failed")
+    return p
+
+
 class FlvisCfg(C.Structure):
     """flvis_cfg of include/flvis_hip.h."""
     _fields_ = [("type_of_vi", C.c_int), ("image_width", C.c_int), ("image_height", C.c_int),

@@ -85,6 +85,42 @@ int flvis_hip_feature_dem_redetect(flvis_ctx* ctx, const uint8_t* d_img, int w, 
                                    const double* d_exist_xy, const int* d_exist_count, int exist_cap, float* d_out_xy,
                                    int* d_out_count, int out_cap);
 
+/* ---- ORB extraction + Hamming matching: the keyframe-rate front half of the reference's loop closing.
+ * Replaces cv::ORB::create(nfeatures, scaleFactor, nlevels, 31, 0, 2, cv::ORB::HARRIS_SCORE, 31, fastThreshold)
+ *            ->detectAndCompute(img0, cv::Mat(), keypoints, descriptors)        src/backend/vo_loopclosing.cpp:242-243
+ * (edgeThreshold 31, firstLevel 0, WTA_K 2, HARRIS_SCORE, patchSize 31 are the only values the reference uses and are
+ * fixed here).  Batched over n_img images of one size.  Keypoints come out level-major, raster order within a level
+ * (OpenCV's order is an artefact of std::nth_element); d_kps rows are (x, y, size, angle_deg, response, octave).
+ * h_pattern: host table of the 256 test pairs as int8 [512][2] (x, y), e.g. OpenCV's learned bit_pattern_31_ when the
+ * descriptors must be compatible with a DBoW vocabulary; NULL selects OpenCV's generator makeRandomPattern(31, ., 512)
+ * (flvis_orb_default_pattern).  d_overflow (optional, [n_img]) is set non-zero where a capacity truncated the result. */
+typedef struct flvis_orb_params {
+  int nfeatures;       /* 1000 in the reference */
+  float scale_factor;  /* 1.2f */
+  int nlevels;         /* 8 (<= 12) */
+  int fast_threshold;  /* 20 */
+} flvis_orb_params;
+int flvis_hip_orb_detect_and_compute(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img,
+                                     const flvis_orb_params* prm, const int8_t* h_pattern, float* d_kps, uint8_t* d_desc,
+                                     int* d_count, int cap, int* d_overflow);
+int flvis_orb_default_pattern(int8_t* h_pattern512x2);
+/* building blocks at their OpenCV call shapes (device pointers, [n_img] images, tightly packed):
+ * cv::resize(src, dst, Size(dw, dh), 0, 0, INTER_LINEAR); the FAST-9/16 score map (0 = not a corner) behind
+ * cv::FAST(img, kps, threshold, true); cv::GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101). */
+int flvis_hip_resize_linear(flvis_ctx* ctx, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n_img);
+int flvis_hip_fast_score(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img, int threshold, uint8_t* d_score);
+int flvis_hip_gaussian_blur7(flvis_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n_img);
+/* cv::BFMatcher(cv::NORM_HAMMING, false).knnMatch(query, train, matches, 2) (vo_loopclosing.cpp:601-613) for n_pairs
+ * independent (query, train) sets of 32-byte descriptors: d_query [n_pairs][qcap][32], d_nq [n_pairs], likewise train.
+ * d_idx / d_dist: [n_pairs][qcap][2], ascending distance, ties keep the lower train index; -1 / INT_MAX when absent. */
+int flvis_hip_hamming_knn2(flvis_ctx* ctx, const uint8_t* d_query, const int* d_nq, int qcap, const uint8_t* d_train,
+                           const int* d_nt, int tcap, int n_pairs, int* d_idx, int* d_dist);
+/* the mutual-best + ratio test of vo_loopclosing.cpp:603-639 (knnMatch both ways, keep i when the best match of its best
+ * match is i and d0/d1 < ratio_max), pairs (index in a, index in b) in ascending a order: d_pairs [n_pairs][acap][2]. */
+int flvis_hip_orb_match(flvis_ctx* ctx, const uint8_t* d_a, const int* d_na, int acap, const uint8_t* d_b, const int* d_nb,
+                        int bcap, int n_pairs, double ratio_max, int* d_pairs, int* d_npairs);
+
+
 /* ---- pipeline-level entry points: F2FTracking + LocalMap for a batch of independent streams ------------------------
  *
  * Mirrors the reference's class surface (include/f2f_tracking.h:51-73, src/backend/vo_localmap.cpp:87-380):

@@ -57,3 +57,14 @@ def shifted_pair(h, w, seed, dx, dy, margin=64):
     i0 = np.ascontiguousarray(np.clip(np.round(sample(0.0, 0.0)), 0, 255).astype(np.uint8))
     i1 = np.ascontiguousarray(np.clip(np.round(sample(-dx, -dy)), 0, 255).astype(np.uint8))
     return i0, i1
+
+
+def corner_img(h, w, seed):
+    """texture + random bright/dark rectangles: plenty of FAST corners at every pyramid level."""
+    rng = np.random.default_rng(seed)
+    img = texture_u8(h, w, seed).astype(np.int32)
+    for _ in range(60):
+        x, y = rng.integers(0, w - 8), rng.integers(0, h - 8)
+        ww, hh = rng.integers(6, 60), rng.integers(6, 60)
+        img[y:y + hh, x:x + ww] = np.clip(img[y:y + hh, x:x + ww] + rng.integers(-120, 120), 0, 255)
+    return img.astype(np.uint8)

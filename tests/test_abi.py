@@ -5,6 +5,7 @@ import glob
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -94,3 +95,10 @@ def test_config_loader_rejects_bad_files():
         flvis_amd.load_config(p)
     with pytest.raises(flvis_amd.FlvisError):
         flvis_amd.load_config(os.path.join(tempfile.gettempdir(), "flvis_does_not_exist.yaml"))
+
+
+def test_orb_default_pattern_matches_the_oracle_generator():
+    """host-only entry point: the built-in BRIEF pattern is OpenCV's makeRandomPattern(31, ., 512), as in the oracle."""
+    import flvis_amd
+    import _oracle as O
+    assert np.array_equal(flvis_amd.orb_default_pattern(), O.orb_default_pattern())

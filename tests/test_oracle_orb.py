@@ -11,15 +11,7 @@ CIRCLE = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0,
           (-3, 1), (-2, 2), (-1, 3)]
 
 
-def corner_img(h, w, seed):
-    """texture + random bright/dark rectangles: plenty of FAST corners at every pyramid level."""
-    rng = np.random.default_rng(seed)
-    img = S.texture_u8(h, w, seed).astype(np.int32)
-    for _ in range(60):
-        x, y = rng.integers(0, w - 8), rng.integers(0, h - 8)
-        ww, hh = rng.integers(6, 60), rng.integers(6, 60)
-        img[y:y + hh, x:x + ww] = np.clip(img[y:y + hh, x:x + ww] + rng.integers(-120, 120), 0, 255)
-    return img.astype(np.uint8)
+corner_img = S.corner_img
 
 
 def np_fast_score(img, thr):
