@@ -415,6 +415,29 @@ class Tracker:
             self.ctx._check(r, "write_trajectory")
         return r
 
+    def correction_feed(self, stream, frame_id, pose7, lm_id, lm_3d, outlier_id):
+        """flvis_correction_feed: F2FTracking::correction_feed (opt-in local-map feedback, SURVEY 8f-2)."""
+        np = self.np
+        pose7 = np.ascontiguousarray(pose7, np.float64)
+        lm_id = np.ascontiguousarray(lm_id, np.int64)
+        lm_3d = np.ascontiguousarray(lm_3d, np.float64).reshape(-1, 3)
+        outlier_id = np.ascontiguousarray(outlier_id, np.int64)
+        assert len(lm_id) == len(lm_3d)
+        self.lib.flvis_correction_feed.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_double), C.c_int,
+                                                   C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int64)]
+        self.ctx._check(self.lib.flvis_correction_feed(self.ctx._h, stream, int(frame_id), _P(pose7, C.c_double), len(lm_id),
+                                                       _P(lm_id, C.c_int64), _P(lm_3d, C.c_double), len(outlier_id),
+                                                       _P(outlier_id, C.c_int64)), "correction_feed")
+
+    def pose_records(self, stream, cap=1024):
+        """flvis_get_pose_records -> rows (frame_id, pose7), oldest first."""
+        rows = self.np.zeros((cap, 8))
+        self.lib.flvis_get_pose_records.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        n = self.lib.flvis_get_pose_records(self.ctx._h, stream, cap, _P(rows, C.c_double))
+        if n < 0:
+            self.ctx._check(n, "get_pose_records")
+        return rows[:min(n, cap)].copy()
+
     def counters(self):
         c = (C.c_int64 * 3)()
         self.ctx._check(self.lib.flvis_get_counters(self.ctx._h, c), "get_counters")

@@ -4,6 +4,7 @@
 // the host only stages IMU samples and enqueues a FIXED kernel sequence per frame on one HIP stream; every decision the
 // reference takes per frame is taken on the device by the kernels in track_kernels.hip / ba_kernels.hip.
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,7 @@ struct Pipeline {
   hipStream_t det_stream = nullptr;
   hipEvent_t ev_img = nullptr, ev_det = nullptr;
   hipEvent_t ev_fe[NBA] = {};
+  bool feedback_used = false;  // flvis_correction_feed was called: k_apply_correction runs after every frame_begin
 };
 constexpr int PROF_STAGES = 19;  // every stage has its own (begin, end) event pair on the stream it runs on
 static const char* kStageNames[PROF_STAGES] = {
@@ -284,6 +286,9 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   DA(win, WindowDev, S);
   DA(kfs_ring, KeyFrameDev, (size_t)S * BA_WMAX);
   DA(corr, CorrectionDev, S);
+  DA(rec_id, int, (size_t)S * POSE_REC);
+  DA(rec_T, double, (size_t)S * POSE_REC * 7);
+  p.corr_in = nullptr;  // allocated by the first flvis_correction_feed
   DA(counters, long long, 64);
   p.ba_scratch_stride = ba_scratch_doubles();
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
@@ -493,6 +498,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PB(0, st);
   launch_imu_feed(st, p);
   launch_frame_begin(st, p, pl->d_time);
+  if (pl->feedback_used) launch_apply_correction(st, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
   PE(0, st);
   if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
@@ -868,6 +874,74 @@ int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const d
   if (e != hipSuccess) return ctx->hip_fail(e, "ba_push_keyframe");
   sync_all(ctx);
   return read_correction(ctx, stream, cap, out_frame_id, out_T7, out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid);
+}
+
+// F2FTracking::correction_feed (src/frontend/f2f_tracking.cpp:40-44) -- the sink the reference's
+// correction_feedback_callback (vo_tracking.cpp:373-385) unpacks for and never calls.  Opt-in: nothing changes for a
+// caller that never feeds a correction.  Applied at the stream's next Tracking frame (f2f_tracking.cpp:189-219).
+int flvis_correction_feed(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T_c_w7, int lm_count,
+                          const int64_t* h_lm_id, const double* h_lm_3d, int lm_outlier_count,
+                          const int64_t* h_lm_outlier_id) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S || !T_c_w7 || lm_count < 0 || lm_outlier_count < 0 || (lm_count && (!h_lm_id || !h_lm_3d)) ||
+      (lm_outlier_count && !h_lm_outlier_id))
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "correction_feed: bad args");
+  if (lm_count > BA_LMAX || lm_outlier_count > BA_EMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "correction_feed: too many entries");
+  hipSetDevice(ctx->device);
+  if (!pl->pipe.corr_in) {
+    pl->pipe.corr_in = dalloc<CorrectionDev>(pl, pl->S);
+    if (!pl->pipe.corr_in) return ctx->fail(FLVIS_ERR_HIP, "correction_feed: device allocation failed");
+  }
+  hipStream_t st = ctx->stream;
+  // the previous frame may still be running and reads/clears the slot: order the upload after it on the same stream
+  CorrectionDev* d = pl->pipe.corr_in + stream;
+  struct Head {
+    long long frame_id;
+    int lm_count, lm_outlier_count, valid, pad;
+    double T_c_w[7];
+  } hd;
+  static_assert(offsetof(CorrectionDev, lm_id) == sizeof(Head), "CorrectionDev header layout");
+  hd.frame_id = frame_id;
+  hd.lm_count = lm_count;
+  hd.lm_outlier_count = lm_outlier_count;
+  hd.valid = 1;
+  hd.pad = 0;
+  for (int j = 0; j < 7; j++) hd.T_c_w[j] = T_c_w7[j];
+  hipError_t e = hipSuccess;
+  if (lm_count) {
+    e = hipMemcpyAsync(d->lm_id, h_lm_id, sizeof(int64_t) * lm_count, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d->lm_3d, h_lm_3d, sizeof(double) * 3 * lm_count, hipMemcpyHostToDevice, st);
+  }
+  if (e == hipSuccess && lm_outlier_count)
+    e = hipMemcpyAsync(d->lm_outlier_id, h_lm_outlier_id, sizeof(int64_t) * lm_outlier_count, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d, &hd, sizeof(hd), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // the caller's buffers and `hd` may go away after return
+  if (e != hipSuccess) return ctx->hip_fail(e, "correction_feed");
+  pl->feedback_used = true;
+  return FLVIS_OK;
+}
+
+// pose_records of a stream (f2f_tracking.h:59), oldest first: rows (frame_id, tx ty tz qx qy qz qw); returns the count
+int flvis_get_pose_records(flvis_ctx* ctx, int stream, int cap, double* h_rows8) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S || cap < 0 || (cap && !h_rows8)) return ctx->fail(FLVIS_ERR_INVALID_ARG, "get_pose_records: bad args");
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  StreamState st;
+  std::vector<int> ids(POSE_REC);
+  std::vector<double> T((size_t)POSE_REC * 7);
+  if (hipMemcpy(&st, pl->pipe.st + stream, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(ids.data(), pl->pipe.rec_id + (size_t)stream * POSE_REC, sizeof(int) * POSE_REC, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(T.data(), pl->pipe.rec_T + (size_t)stream * POSE_REC * 7, sizeof(double) * 7 * POSE_REC, hipMemcpyDeviceToHost) != hipSuccess)
+    return ctx->fail(FLVIS_ERR_HIP, "get_pose_records: copy failed");
+  for (int i = 0; i < st.rec_count && i < cap; i++) {
+    const int k = (st.rec_head + i) % POSE_REC;
+    h_rows8[8 * i] = (double)ids[k];
+    for (int j = 0; j < 7; j++) h_rows8[8 * i + 1 + j] = T[(size_t)k * 7 + j];
+  }
+  return st.rec_count;
 }
 
 }  // extern "C"

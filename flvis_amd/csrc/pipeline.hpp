@@ -21,6 +21,7 @@ constexpr int KFQ = 16;            // per-stream keyframe queue between the trac
 constexpr int BA_WMAX = 16;       // window sizes supported by the LDS-resident solver
 constexpr int BA_LMAX = 4096;     // landmarks in the window
 constexpr int BA_EMAX = 8192;     // observations (edges) in the window
+constexpr int POSE_REC = 1024;    // ring behind F2FTracking::pose_records (the reference keeps < 1000, f2f_tracking.cpp:334)
 
 enum { ST_UNINIT = 0, ST_TRACKING = 1, ST_TRACKFAIL = 2 };
 enum { PH_IDLE = 0, PH_TRACK = 1, PH_INIT = 2 };
@@ -82,6 +83,8 @@ struct StreamState {
   // local map
   int lm_state;  // 0 UN_INITIALIZED, 1 SLIDING_WINDOW
   int kf_pending;
+  // pose_records (f2f_tracking.h:59, ID_POSE): ring in Pipe::rec_id / rec_T, oldest at rec_head
+  int rec_head, rec_count;
 };
 
 struct FrameOut {  // per stream, per image_feed

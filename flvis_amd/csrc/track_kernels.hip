@@ -67,6 +67,94 @@ __global__ void k_imu_feed(Pipe p) {
   p.n_imu[s] = 0;
 }
 
+// pose_records.push_back(...) (+ pop_front once 1000 entries are reached on a tracking frame, f2f_tracking.cpp:334-337)
+__device__ inline void pose_record_push(const Pipe& p, int s, StreamState& st, int frame_id, const double* T7, bool pop) {
+  if (st.rec_count == POSE_REC) {  // only reachable after ~25 re-initialisations with a full record: drop the oldest
+    st.rec_head = (st.rec_head + 1) % POSE_REC;
+    st.rec_count--;
+  }
+  const int k = (st.rec_head + st.rec_count) % POSE_REC;
+  p.rec_id[(size_t)s * POSE_REC + k] = frame_id;
+  for (int j = 0; j < 7; j++) p.rec_T[((size_t)s * POSE_REC + k) * 7 + j] = T7[j];
+  st.rec_count++;
+  if (pop && st.rec_count >= 1000) {
+    st.rec_head = (st.rec_head + 1) % POSE_REC;
+    st.rec_count--;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ local-map feedback
+// STEP1 of the Tracking case (f2f_tracking.cpp:189-219), run after frame_begin for streams with a pending correction:
+// re-anchor pose_records and last_frame->T_c_w on the corrected keyframe pose, overwrite lm_3d_w of the landmarks the
+// correction names (forceCorrectLM3DW, camera_frame.cpp:344-360; ids narrowed to int as there) and clear the inlier flag of
+// its outliers (forceMarkOutlier, :362-378).  correctLMP3DWByLMP3DCandT (:332-342) iterates by value: a no-op, as there.
+constexpr int AC_T = 256;
+__global__ __launch_bounds__(AC_T) void k_apply_correction(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  CorrectionDev& c = p.corr_in[s];
+  if (!c.valid || st.phase != PH_TRACK) return;  // has_localmap_feedback stays set until a Tracking frame
+  __shared__ double s_old_inv[7], s_upd[7];
+  __shared__ int s_idx;
+  __shared__ long long s_ids[1024];
+  const int tid = threadIdx.x;
+  const int last = st.cur ^ 1;
+  if (tid == 0) {
+    const int corr_id = (int)c.frame_id;
+    int idx = 0;
+    for (int i = st.rec_count - 1; i >= 0; i--)
+      if (p.rec_id[(size_t)s * POSE_REC + (st.rec_head + i) % POSE_REC] == corr_id) {
+        idx = i;
+        break;
+      }
+    s_idx = idx;
+    const SE3d old = load_pose7(p.rec_T + ((size_t)s * POSE_REC + (st.rec_head + idx) % POSE_REC) * 7);
+    store_pose7(s_old_inv, se3_inverse(old));
+    for (int j = 0; j < 7; j++) s_upd[j] = c.T_c_w[j];
+  }
+  __syncthreads();
+  const SE3d old_inv = load_pose7(s_old_inv), upd = load_pose7(s_upd);
+  for (int i = s_idx + tid; i < st.rec_count; i += AC_T) {
+    double* T = p.rec_T + ((size_t)s * POSE_REC + (st.rec_head + i) % POSE_REC) * 7;
+    store_pose7(T, se3_mul(se3_mul(load_pose7(T), old_inv), upd));
+  }
+  if (tid == 0) store_pose7(st.T_c_w[last], se3_mul(se3_mul(load_pose7(st.T_c_w[last]), old_inv), upd));
+  Landmark* lms = lm_ptr(p, last, s);
+  const int n = st.n_lm[last];
+  // forceCorrectLM3DW: with unique ids on both sides "first landmark with that id" and "last correction entry wins" both
+  // reduce to a plain join; a duplicated correction id resolves to its last entry as in the reference's sequential loop
+  const int nc = min(c.lm_count, BA_LMAX);
+  for (int c0 = 0; c0 < nc; c0 += 1024) {
+    const int m = min(1024, nc - c0);
+    __syncthreads();
+    for (int i = tid; i < m; i += AC_T) s_ids[i] = (long long)(int)c.lm_id[c0 + i];
+    __syncthreads();
+    for (int j = tid; j < n; j += AC_T) {
+      const long long id = lms[j].id;
+      int hit = -1;
+      for (int i = 0; i < m; i++)
+        if (s_ids[i] == id) hit = i;
+      if (hit >= 0)
+        for (int k = 0; k < 3; k++) lms[j].p3w[k] = c.lm_3d[c0 + hit][k];
+    }
+  }
+  const int no = min(c.lm_outlier_count, BA_EMAX);
+  for (int c0 = 0; c0 < no; c0 += 1024) {
+    const int m = min(1024, no - c0);
+    __syncthreads();
+    for (int i = tid; i < m; i += AC_T) s_ids[i] = (long long)(int)c.lm_outlier_id[c0 + i];
+    __syncthreads();
+    for (int j = tid; j < n; j += AC_T) {
+      const long long id = lms[j].id;
+      bool hit = false;
+      for (int i = 0; i < m; i++) hit = hit || (s_ids[i] == id);
+      if (hit) lms[j].inlier = 0;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) c.valid = 0;
+}
+
 // ------------------------------------------------------------------------------------------------ frame begin
 __global__ void k_frame_begin(Pipe p, const double* __restrict__ frame_time) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1173,6 +1261,7 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
     }
     if (lane == 0) {
       if (valid > 30) {
+        pose_record_push(p, s, st, (int)st.frame_id[cur], st.T_c_w[cur], false);  // f2f_tracking.cpp:443-446
         for (int j = 0; j < 7; j++) st.T_kf[j] = st.T_c_w[cur][j];
         st.new_kf = 1;
         st.state = ST_TRACKING;
@@ -1182,6 +1271,7 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
     }
   } else if (st.phase == PH_TRACK && lane == 0) {
     const int cur = st.cur;
+    pose_record_push(p, s, st, (int)st.frame_id[cur], st.T_c_w[cur], true);  // STEP7, f2f_tracking.cpp:329-337
     SE3d Tkf = load_pose7(st.T_kf), Tc = load_pose7(st.T_c_w[cur]);
     SE3d Td = se3_mul(Tkf, se3_inverse(Tc));
     V3 r = so3_log(Td.q);
@@ -1269,6 +1359,9 @@ void launch_imu_feed(hipStream_t st, const Pipe& p) {
 }
 void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time) {
   hipLaunchKernelGGL(k_frame_begin, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time);
+}
+void launch_apply_correction(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_apply_correction, dim3(p.S), dim3(AC_T), 0, st, p);
 }
 void launch_track_prepare(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_track_prepare, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);

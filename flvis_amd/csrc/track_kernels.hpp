@@ -50,10 +50,15 @@ struct Pipe {
   double* ba_scratch;       // [S][ba_scratch_stride]
   size_t ba_scratch_stride;
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
+  // local-map feedback (F2FTracking::correction_feed, dead in the reference's v2)
+  int* rec_id;              // [S][POSE_REC]  ID_POSE::frame_id (an int in the reference)
+  double* rec_T;            // [S][POSE_REC][7]
+  CorrectionDev* corr_in;   // [S] correction waiting for the stream's next Tracking frame (valid flag), or nullptr
 };
 
 void launch_imu_feed(hipStream_t st, const Pipe& p);
 void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time);
+void launch_apply_correction(hipStream_t st, const Pipe& p);
 void launch_track_prepare(hipStream_t st, const Pipe& p);
 void launch_track_collect(hipStream_t st, const Pipe& p);
 void launch_ransac_f(hipStream_t st, const Pipe& p);

@@ -199,6 +199,19 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
 /* Last CorrectionInf of a stream: returns 1 if one exists (0 if not yet, <0 error). */
 int flvis_get_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T_c_w7, int* lm_count,
                          int64_t* h_lm_id, double* h_lm_3d, int* lm_outlier_count, int64_t* h_outlier_id);
+
+/* Local-map feedback into the tracker.  F2FTracking::correction_feed (src/frontend/f2f_tracking.cpp:40-44):
+ * the reference's v2 unpacks CorrectionInf in correction_feedback_callback (vo_tracking.cpp:373-385) and never calls it, so
+ * this is opt-in -- a caller that never feeds a correction gets v2 behaviour.  The correction (e.g. what
+ * flvis_get_correction returned) is applied at the stream's next Tracking frame exactly as f2f_tracking.cpp:189-219 does:
+ * pose_records and last_frame->T_c_w are re-anchored on the corrected keyframe pose, lm_3d_w of the named landmarks is
+ * overwritten, the named outliers lose is_tracking_inlier.  Host buffers; returns after the upload. */
+int flvis_correction_feed(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T_c_w7, int lm_count,
+                          const int64_t* h_lm_id, const double* h_lm_3d, int lm_outlier_count,
+                          const int64_t* h_lm_outlier_id);
+/* F2FTracking::pose_records (f2f_tracking.h:59) of a stream, oldest first: rows (frame_id, tx ty tz qx qy qz qw).
+ * Returns the number of records (< 1000). */
+int flvis_get_pose_records(flvis_ctx* ctx, int stream, int cap, double* h_rows8);
 /* Device-side trajectory of one stream: rows of 9 doubles (t, tx ty tz qx qy qz qw, state | new_kf<<4). */
 int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_frames, double* h_rows9);
 /* Trajectory recorder (replaces src/independ_modules/vo_repub_rec.cpp:74-124 for offline runs): writes the recorded

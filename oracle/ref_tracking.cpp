@@ -546,6 +546,7 @@ F2FTracking::F2FTracking(const Config& cfg_in, uint64_t seed) : cfg(cfg_in) {
   range = (float)cfg.dr_para[1];
   enable_dummy = !(cfg.dr_para[2] < 0.5);
   frameCount = 0;
+  has_localmap_feedback = false;
   vo_tracking_state = UnInit;
   has_imu = false;
   skip_n_imgs = cfg.skip_first_n_imgs;
@@ -703,6 +704,7 @@ bool F2FTracking::init_frame() {
   int valid = 0;
   for (auto& lm : curr_frame->landmarks) valid += (lm.has_3d && lm.is_tracking_inlier);
   if (valid > 30) {
+    pose_records.push_back({(int)curr_frame->frame_id, curr_frame->T_c_w});  // f2f_tracking.cpp:443-446
     T_c_w_last_keyframe = curr_frame->T_c_w;
     return true;
   }
@@ -837,6 +839,42 @@ void F2FTracking::image_feed(double time, const uint8_t* img0_in, const uint8_t*
       break;
     }
     case Tracking: {
+      // STEP1: recover from the local-map feedback (f2f_tracking.cpp:189-219)
+      if (has_localmap_feedback) {
+        int corr_id = (int)correction_inf.frame_id;
+        int old_pose_idx = 0;
+        for (int i = (int)pose_records.size() - 1; i >= 0; i--)
+          if (pose_records[i].frame_id == corr_id) {
+            old_pose_idx = i;
+            break;
+          }
+        SE3 old_T_c_w = pose_records.at(old_pose_idx).T_c_w;
+        SE3 old_T_c_w_inv = se3_inverse(old_T_c_w);
+        SE3 update_T_c_w = correction_inf.T_c_w;
+        for (size_t i = old_pose_idx; i < pose_records.size(); i++) {
+          SE3 T_diff = se3_mul(pose_records[i].T_c_w, old_T_c_w_inv);
+          pose_records[i].T_c_w = se3_mul(T_diff, update_T_c_w);
+        }
+        SE3 T_diff = se3_mul(last_frame->T_c_w, old_T_c_w_inv);
+        last_frame->T_c_w = se3_mul(T_diff, update_T_c_w);
+        // correctLMP3DWByLMP3DCandT (camera_frame.cpp:332-342) iterates `for(auto lm:landmarks)` BY VALUE: a no-op
+        // forceCorrectLM3DW (camera_frame.cpp:344-360): ids narrowed to int, first landmark with that id
+        for (int i = 0; i < correction_inf.lm_count; i++) {
+          int id = (int)correction_inf.lm_id.at(i);
+          for (auto& lm : last_frame->landmarks)
+            if (lm.lm_id == id) {
+              lm.lm_3d_w = correction_inf.lm_3d.at(i);
+              break;
+            }
+        }
+        // forceMarkOutlier (camera_frame.cpp:362-378)
+        for (int i = 0; i < correction_inf.lm_outlier_count; i++) {
+          int id = (int)correction_inf.lm_outlier_id.at(i);
+          for (auto& lm : last_frame->landmarks)
+            if (lm.lm_id == id) lm.is_tracking_inlier = false;
+        }
+        has_localmap_feedback = false;
+      }
       SE3 imu_guess = se3_identity();
       bool has_imu_guess = false;
       if (has_imu) has_imu_guess = vimotion->viGetCorrFrameState(time, imu_guess);
@@ -927,6 +965,8 @@ void F2FTracking::image_feed(double time, const uint8_t* img0_in, const uint8_t*
       }
       depthInnovation(*curr_frame);
       eraseNoDepthPoint(*curr_frame);
+      pose_records.push_back({(int)curr_frame->frame_id, curr_frame->T_c_w});  // STEP7, f2f_tracking.cpp:329-337
+      if (pose_records.size() >= 1000) pose_records.pop_front();
       SE3 T_diff_key_curr = se3_mul(T_c_w_last_keyframe, se3_inverse(curr_frame->T_c_w));
       Vec3 t = T_diff_key_curr.t, r = so3_log(T_diff_key_curr.q);
       double t_norm = std::fabs(t.x) + std::fabs(t.y) + std::fabs(t.z);
@@ -962,6 +1002,11 @@ void F2FTracking::image_feed(double time, const uint8_t* img0_in, const uint8_t*
       break;
     }
   }
+}
+
+void F2FTracking::correction_feed(const CorrectionInfStruct& corr) {  // f2f_tracking.cpp:40-44
+  correction_inf = corr;
+  has_localmap_feedback = true;
 }
 
 void F2FTracking::getKeyFrameInf(KeyFrameStruct& kf) const {
@@ -1057,5 +1102,33 @@ int ref_tracker_keyframe(void* h, int cap, int64_t* frame_id, double* pose7, int
     p3w[3 * i + 2] = kf.lm_3d[i].z;
   }
   return kf.lm_count;
+}
+// F2FTracking::correction_feed (f2f_tracking.cpp:40-44) with the CorrectionInf fields flattened
+void ref_tracker_correction_feed(void* h, int64_t frame_id, const double* pose7, int lm_count, const int64_t* lm_id,
+                                 const double* lm_3d, int outlier_count, const int64_t* outlier_id) {
+  ref::F2FTracking* f = (ref::F2FTracking*)h;
+  ref::CorrectionInfStruct c;
+  c.frame_id = frame_id;
+  c.T_c_w.t = {pose7[0], pose7[1], pose7[2]};
+  c.T_c_w.q.x = pose7[3], c.T_c_w.q.y = pose7[4], c.T_c_w.q.z = pose7[5], c.T_c_w.q.w = pose7[6];
+  c.lm_count = lm_count;
+  for (int i = 0; i < lm_count; i++) {
+    c.lm_id.push_back(lm_id[i]);
+    c.lm_3d.push_back({lm_3d[3 * i], lm_3d[3 * i + 1], lm_3d[3 * i + 2]});
+  }
+  c.lm_outlier_count = outlier_count;
+  for (int i = 0; i < outlier_count; i++) c.lm_outlier_id.push_back(outlier_id[i]);
+  f->correction_feed(c);
+}
+// pose_records dump: rows (frame_id, pose7), oldest first
+int ref_tracker_pose_records(void* h, int cap, double* rows8) {
+  ref::F2FTracking* f = (ref::F2FTracking*)h;
+  int n = (int)f->pose_records.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    const ref::SE3& T = f->pose_records[i].T_c_w;
+    double o[8] = {(double)f->pose_records[i].frame_id, T.t.x, T.t.y, T.t.z, T.q.x, T.q.y, T.q.z, T.q.w};
+    memcpy(rows8 + 8 * i, o, sizeof(o));
+  }
+  return n;
 }
 }

@@ -109,6 +109,16 @@ class F2FTracking {  // src/frontend/f2f_tracking.cpp
   void imu_feed(double time, Vec3 acc, Vec3 gyro, Quat& q_w_i, Vec3& pos_w_i, Vec3& vel_w_i);
   void image_feed(double time, const uint8_t* img0, const uint8_t* img1, bool& new_keyframe, bool& reset_cmd);
   void getKeyFrameInf(KeyFrameStruct& kf) const;  // CameraFrame::getKeyFrameInf + pose (what KeyFrameMsg::pub sends)
+  // local-map feedback (f2f_tracking.cpp:40-44): dead in v2 (vo_tracking.cpp:373-385 unpacks the message and drops it);
+  // restated for the SURVEY 8f-2 row, applied at the next Tracking frame (f2f_tracking.cpp:189-219)
+  void correction_feed(const CorrectionInfStruct& corr);
+  struct ID_POSE {  // f2f_tracking.h:19-22 (frame_id is an int there)
+    int frame_id;
+    SE3 T_c_w;
+  };
+  std::deque<ID_POSE> pose_records;
+  CorrectionInfStruct correction_inf;
+  bool has_localmap_feedback;
 
   Config cfg;
   DepthCamera d_camera;

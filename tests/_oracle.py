@@ -304,6 +304,23 @@ class Tracker:
                                        _p(p2u, C.c_double), _p(p3w, C.c_double))
         return dict(frame_id=fid.value, pose7=pose, lm_id=ids[:n].copy(), lm_2d=p2u[:n].copy(), lm_3d=p3w[:n].copy())
 
+    def correction_feed(self, frame_id, pose7, lm_id, lm_3d, outlier_id):
+        """F2FTracking::correction_feed (dead in v2; SURVEY 8f-2)."""
+        lm_id = np.ascontiguousarray(lm_id, np.int64)
+        lm_3d = np.ascontiguousarray(lm_3d, np.float64).reshape(-1, 3)
+        outlier_id = np.ascontiguousarray(outlier_id, np.int64)
+        pose7 = np.ascontiguousarray(pose7, np.float64)
+        f = lib().ref_tracker_correction_feed
+        f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                      C.c_int, C.POINTER(C.c_int64)]
+        f(self.h, int(frame_id), _p(pose7, C.c_double), len(lm_id), _p(lm_id, C.c_int64), _p(lm_3d, C.c_double),
+          len(outlier_id), _p(outlier_id, C.c_int64))
+
+    def pose_records(self, cap=1024):
+        rows = np.zeros((cap, 8))
+        n = lib().ref_tracker_pose_records(self.h, cap, _p(rows, C.c_double))
+        return rows[:n].copy()
+
 
 # ------------------------------------------------------------------------------------------- ORB (oracle/ref_orb.cpp)
 def resize_linear(img, dw, dh):

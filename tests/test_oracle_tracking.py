@@ -92,3 +92,92 @@ def test_oracle_tracks_euroc_like_stream():
     ate = _umeyama_ate(np.array(est), np.array(gt))
     path = np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum()
     assert ate < 0.05 * path + 0.01, (ate, path)
+
+
+def _run_euroc_like(nframes, feedback):
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_track_euroc.yaml")
+    open(p, "w").write(synth.EUROC_LIKE_YAML)
+    cfg = O.load_config(p)
+    rig = synth.euroc_rig()
+    trk = O.Tracker(cfg, 11)
+    K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
+    lmap = O.LocalMap(cfg.window_size, K4)
+    tr = synth.Trajectory(9)
+    rnd = synth.Renderer("cpu", rig=rig)
+    t_prev = -0.05
+    est, gt, states, n_fed = [], [], [], 0
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        for s in synth.imu_samples(tr, 9, t_prev, t):
+            trk.imu(s[0], s[1:4], s[4:7])
+        t_prev = t
+        i0, i1 = rnd.stereo_frame([tr], t, f)
+        r = trk.image(t, i0[0].numpy(), i1[0].numpy())
+        states.append(r["state"])
+        if r["new_keyframe"]:
+            kf = trk.keyframe()
+            c = lmap.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
+            if c is not None and feedback:
+                trk.correction_feed(c["frame_id"], c["pose7"], c["lm_id"], c["lm_3d"], c["outlier_id"])
+                n_fed += 1
+        if r["state"] == 1:
+            R, tt = G.pose7_to_Rt(r["pose7"])
+            Rg, tg = tr.T_c_w(t, rig)
+            est.append(-R.T @ tt)
+            gt.append(-Rg.T @ tg)
+    return trk, states, np.array(est), np.array(gt), n_fed
+
+
+def test_oracle_local_map_feedback_closed_loop():
+    """the feedback path that is dead in the reference's v2 (f2f_tracking.cpp:40-44,189-219), restated and
+    closed: every CorrectionInf goes back into the tracker.  Tracking survives, stays on ground truth, and the records
+    are re-anchored (the run differs from the open-loop one)."""
+    trk, states, est, gt, n_fed = _run_euroc_like(48, True)
+    trk0, states0, est0, _, _ = _run_euroc_like(48, False)
+    first = states.index(1)
+    assert n_fed >= 2 and all(s == 1 for s in states[first:]), states
+    path = np.linalg.norm(np.diff(gt, axis=0), axis=1).sum()
+    assert _umeyama_ate(est, gt) < 0.05 * path + 0.01
+    assert len(est) == len(est0) and np.abs(est - est0).max() > 1e-6          # the feedback did change the estimate
+    rec = trk.pose_records()
+    assert len(rec) == sum(1 for s in states if s == 1) and np.all(np.diff(rec[:, 0]) == 1)
+
+
+def test_oracle_correction_feed_semantics():
+    """Re-anchoring on a named record, fallback to the oldest record for an unknown frame id, landmark overwrite and
+    outlier marking act on last_frame at the next Tracking frame only."""
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_track_euroc.yaml")
+    open(p, "w").write(synth.EUROC_LIKE_YAML)
+    cfg = O.load_config(p)
+    rig = synth.euroc_rig()
+    trk = O.Tracker(cfg, 11)
+    tr = synth.Trajectory(9)
+    rnd = synth.Renderer("cpu", rig=rig)
+    t_prev = -0.05
+    fed_at = None
+    for f in range(20):
+        t = f / synth.FRAME_HZ
+        for s in synth.imu_samples(tr, 9, t_prev, t):
+            trk.imu(s[0], s[1:4], s[4:7])
+        t_prev = t
+        i0, i1 = rnd.stereo_frame([tr], t, f)
+        r = trk.image(t, i0[0].numpy(), i1[0].numpy())
+        rec = trk.pose_records()
+        if fed_at is not None and f == fed_at + 1:
+            # every record from the named one on moved by the same left-multiplied delta; older ones are untouched
+            assert np.allclose(rec[k, 1:], new_pose, atol=1e-12)
+            assert np.array_equal(rec[:k], before[:k])
+            assert np.abs(rec[k + 1:len(before), 1:4] - before[k + 1:, 1:4]).max() > 1e-3
+            break
+        if r["state"] == 1 and len(rec) >= 4 and fed_at is None:
+            lm = trk.landmarks()
+            k = len(rec) - 3
+            before = rec.copy()
+            new_pose = rec[k, 1:].copy()
+            new_pose[:3] += [0.02, 0.01, -0.03]
+            trk.correction_feed(int(rec[k, 0]), new_pose, lm["ids"][:5], lm["p3w"][:5] + 0.5, lm["ids"][5:8])
+            assert np.array_equal(trk.pose_records(), before)               # nothing happens until the next frame
+            fed_at = f
+    assert fed_at is not None
