@@ -220,7 +220,6 @@ def test_local_map_feedback_parity(ctx):
     tracked = 0
     lock = True
     fed = []
-    hist = {}
     checked_after_feed = 0
     for f in range(nframes):
         t = f / synth.FRAME_HZ
@@ -252,14 +251,14 @@ def test_local_map_feedback_parity(ctx):
             checked_after_feed += 1
             if lock:
                 assert np.allclose(gl["p3w"], wl["p3w"], atol=2e-3, rtol=0), where
-            # ... and must have had an effect (the run without feedback is somewhere else)
-            assert np.abs(want["pose7"] - base["pose7"]).max() > 2e-3, where
+            # ... and must have had an effect: the pose of the next frame comes from PnP on the corrected landmarks
+            # (useExtrinsicGuess=false, so last_frame->T_c_w itself does not enter), 1 cm on a third of them moves it ~0.5 mm
+            assert np.abs(want["pose7"] - base["pose7"]).max() > 1e-4, where
             # re-anchoring: the named record now carries the corrected pose
             k = fed[-1]["rec_index"]
             assert np.allclose(wrec[k, 1:], fed[-1]["pose7"], atol=1e-9), where
         if want["state"] == 1:
             tracked += 1
-            hist[f + 1] = want["pose7"].copy()          # frame_id = frameCount = f + 1
             if tracked in (3, 7):
                 ids = wl["ids"]
                 sel = np.arange(0, len(ids), 3)
