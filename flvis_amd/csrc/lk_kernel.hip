@@ -99,7 +99,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                  float* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                  const int* __restrict__ count, int nmax, LKParams prm,
                                                  const int* __restrict__ active) {
-  const int s = blockIdx.y;
+  // XCD-aware workgroup -> (stream, point) map: workgroup b is observed to run on XCD b % 8 (each XCD has its own 4 MiB
+  // L2), so a stream's workgroups are renumbered onto one XCD and its two pyramids (~0.8 MB) are fetched from HBM once
+  // instead of once per XCD.  A bijection whenever the grid size is a multiple of 8; speed only, never correctness.
+  int s = blockIdx.y, bx = blockIdx.x;
+  {
+    const int G = gridDim.x, N = G * gridDim.y;
+    if ((N & 7) == 0) {
+      const int L = bx + G * s;
+      const int Lp = (L & 7) * (N >> 3) + (L >> 3);
+      s = Lp / G;
+      bx = Lp - s * G;
+    }
+  }
   if (active && !active[s]) return;
   int n = count[s];
   if (n > nmax) n = nmax;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const float FLT_SCALE = 1.f / (1 << 20);
   const float halfWin = (LK_WIN - 1) * 0.5f;
 
-  for (int p = blockIdx.x; p < n; p += gridDim.x) {
+  for (int p = bx; p < n; p += gridDim.x) {
     const size_t pi = ((size_t)s * nmax + p) * 2;
     const float ppx0 = prev_pts[pi], ppy0 = prev_pts[pi + 1];
     float nx = next_pts[pi], ny = next_pts[pi + 1];
