@@ -99,7 +99,41 @@ __global__ void __launch_bounds__(256) k_orb_resize(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------ FAST-9/16
-constexpr int FT_W = 64, FT_H = 16, FT_P = 72;  // LDS tile: (64+6) x (16+6), pitch 72
+#ifndef FLVIS_ORB_TILE_H
+#define FLVIS_ORB_TILE_H 32
+#endif
+constexpr int FT_W = 64, FT_H = FLVIS_ORB_TILE_H, FT_P = 72;  // LDS tile: (64+6) x (FT_H+6), pitch 72
+constexpr int FT_R = FT_H / 4;                                  // rows per thread (256 threads = 4 rows of 64)
+static_assert(FT_H % 4 == 0 && FT_H >= 4 && FT_H <= 64, "tile height");
+
+// cooperative load of the (FT_W+6) x (FT_H+6) neighbourhood of a tile into LDS: all global loads of a thread are issued
+// before the first LDS store (a load -> store loop serialises on the memory latency, ~1 us per trip under load)
+constexpr int TL_TOTAL = (FT_H + 6) * (FT_W + 6);
+constexpr int TL_N = (TL_TOTAL + 255) / 256;
+template <bool REFLECT>
+__device__ __forceinline__ void load_tile_u8(const uint8_t* __restrict__ src, int pitch, int W, int H, int tx0, int ty0,
+                                             uint8_t* tile) {
+  uint8_t v[TL_N];
+#pragma unroll
+  for (int k = 0; k < TL_N; k++) {
+    const int i = threadIdx.x + k * 256;
+    v[k] = 0;
+    if (i < TL_TOTAL) {
+      const int yy = i / (FT_W + 6), xx = i - yy * (FT_W + 6);
+      const int gx = REFLECT ? reflect101c(tx0 + xx - 3, W) : min(max(tx0 + xx - 3, 0), W - 1);
+      const int gy = REFLECT ? reflect101c(ty0 + yy - 3, H) : min(max(ty0 + yy - 3, 0), H - 1);
+      v[k] = src[(size_t)gy * pitch + gx];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < TL_N; k++) {
+    const int i = threadIdx.x + k * 256;
+    if (i < TL_TOTAL) {
+      const int yy = i / (FT_W + 6), xx = i - yy * (FT_W + 6);
+      tile[yy * FT_P + xx] = v[k];
+    }
+  }
+}
 
 __device__ __forceinline__ int fast_score_px(const uint8_t* t /*LDS, centre*/, int thr) {
   // circle of radius 3, clockwise from (0,3) like fast.cpp's makeOffsets; the result does not depend on the start
@@ -170,17 +204,13 @@ __global__ void __launch_bounds__(256) k_fast_score(OrbLevels L, const uint8_t* 
   const int tx0 = (t % tpr) * FT_W, ty0 = (t / tpr) * FT_H;
   int pitch;
   const uint8_t* src = lvl_ptr(L, img0, pyr, l, blockIdx.y, pitch);
-  for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
-    const int yy = i / (FT_W + 6), xx = i - yy * (FT_W + 6);
-    const int gx = min(max(tx0 + xx - 3, 0), W - 1), gy = min(max(ty0 + yy - 3, 0), H - 1);
-    tile[yy * FT_P + xx] = src[(size_t)gy * pitch + gx];
-  }
+  load_tile_u8<false>(src, pitch, W, H, tx0, ty0, tile);
   __syncthreads();
   uint8_t* out = score + (size_t)blockIdx.y * L.stride + L.off[l];
   const int lx = threadIdx.x & 63;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int ly = (threadIdx.x >> 6) * 4 + r;
+#pragma unroll 2
+  for (int r = 0; r < FT_R; r++) {
+    const int ly = (threadIdx.x >> 6) * FT_R + r;
     const int x = tx0 + lx, y = ty0 + ly;
     if (x >= W || y >= H) continue;
     int s = 0;
@@ -195,17 +225,13 @@ __global__ void __launch_bounds__(256) k_fast_score_plain(const uint8_t* __restr
   __shared__ uint8_t tile[(FT_H + 6) * FT_P];
   const int tx0 = blockIdx.x * FT_W, ty0 = blockIdx.y * FT_H;
   const uint8_t* src = img + (size_t)blockIdx.z * W * H;
-  for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
-    const int yy = i / (FT_W + 6), xx = i - yy * (FT_W + 6);
-    const int gx = min(max(tx0 + xx - 3, 0), W - 1), gy = min(max(ty0 + yy - 3, 0), H - 1);
-    tile[yy * FT_P + xx] = src[(size_t)gy * W + gx];
-  }
+  load_tile_u8<false>(src, W, W, H, tx0, ty0, tile);
   __syncthreads();
   uint8_t* out = score + (size_t)blockIdx.z * W * H;
   const int lx = threadIdx.x & 63;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int ly = (threadIdx.x >> 6) * 4 + r;
+#pragma unroll 2
+  for (int r = 0; r < FT_R; r++) {
+    const int ly = (threadIdx.x >> 6) * FT_R + r;
     const int x = tx0 + lx, y = ty0 + ly;
     if (x >= W || y >= H) continue;
     int s = 0;
@@ -215,12 +241,17 @@ __global__ void __launch_bounds__(256) k_fast_score_plain(const uint8_t* __restr
 }
 
 // strict 3x3 maximum (fast.cpp non-max suppression) + KeyPointsFilter::runByImageBorder(edgeThreshold) -> sparse score
-// map `nms` (0 = not a keypoint) and the per-(image, level) histogram of the surviving scores
+// map `nms` of the border box only (row y-31, column x-31, pitch box_pitch = BW rounded up to 16, pad columns zero; 0 = not a
+// keypoint) and the per-(image, level) histogram of the surviving scores
+__device__ __forceinline__ int box_pitch(int W) { return (W - 2 * ORB_EDGE + 15) & ~15; }
+
 __global__ void __launch_bounds__(256) k_fast_nms(OrbLevels L, const uint8_t* __restrict__ score, uint8_t* __restrict__ nms,
                                                   unsigned* __restrict__ hist /*[img][level][256]*/) {
   __shared__ unsigned sh[256];
   const int l = tile_level(L, blockIdx.x);
   const int W = L.w[l], H = L.h[l], P = L.pitch[l];
+  if (W <= 2 * ORB_EDGE || H <= 2 * ORB_EDGE) return;  // uniform: the level has no border box
+  const int BP = box_pitch(W);
   const int tpr = (W + FT_W - 1) / FT_W;
   const int t = blockIdx.x - L.tile0[l];
   const int tx0 = (t % tpr) * FT_W, ty0 = (t / tpr) * FT_H;
@@ -228,21 +259,21 @@ __global__ void __launch_bounds__(256) k_fast_nms(OrbLevels L, const uint8_t* __
   uint8_t* out = nms + (size_t)blockIdx.y * L.stride + L.off[l];
   sh[threadIdx.x] = 0;
   __syncthreads();
-  const bool level_ok = W > 2 * ORB_EDGE && H > 2 * ORB_EDGE;
   const int lx = threadIdx.x & 63;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int x = tx0 + lx, y = ty0 + (threadIdx.x >> 6) * 4 + r;
+#pragma unroll 4
+  for (int r = 0; r < FT_R; r++) {
+    const int x = tx0 + lx, y = ty0 + (threadIdx.x >> 6) * FT_R + r;
     if (x >= W || y >= H) continue;
+    if (y < ORB_EDGE || y >= H - ORB_EDGE || x < ORB_EDGE || x - ORB_EDGE >= BP) continue;
     int keep = 0;
-    if (level_ok && x >= ORB_EDGE && x < W - ORB_EDGE && y >= ORB_EDGE && y < H - ORB_EDGE) {
+    if (x < W - ORB_EDGE) {
       const uint8_t* c = sc + (size_t)y * P + x;
       const int s = c[0];
       if (s > 0 && s > c[-1] && s > c[1] && s > c[-P - 1] && s > c[-P] && s > c[-P + 1] && s > c[P - 1] && s > c[P] &&
           s > c[P + 1])
         keep = s;
     }
-    out[(size_t)y * P + x] = (uint8_t)keep;
+    out[(size_t)(y - ORB_EDGE) * BP + (x - ORB_EDGE)] = (uint8_t)keep;
     if (keep) atomicAdd(&sh[keep], 1u);
   }
   __syncthreads();
@@ -257,30 +288,26 @@ struct GaussK {
 __device__ __forceinline__ void gauss_tile(const uint8_t* __restrict__ src, int W, int H, int spitch,
                                            uint8_t* __restrict__ dst, int dpitch, int tx0, int ty0, const GaussK& g,
                                            uint8_t* tile /*[22][72]*/, int* tmp /*[22][64]*/) {
-  for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
-    const int yy = i / (FT_W + 6), xx = i - yy * (FT_W + 6);
-    const int gx = reflect101c(tx0 + xx - 3, W), gy = reflect101c(ty0 + yy - 3, H);
-    tile[yy * FT_P + xx] = src[(size_t)gy * spitch + gx];
-  }
+  load_tile_u8<true>(src, spitch, W, H, tx0, ty0, tile);
   __syncthreads();
   for (int i = threadIdx.x; i < (FT_H + 6) * FT_W; i += 256) {
     const int yy = i >> 6, xx = i & 63;
     const uint8_t* p = tile + yy * FT_P + xx;
     int s = 0;
 #pragma unroll
-    for (int j = 0; j < 7; j++) s += g.k[j] * p[j];
+    for (int j = 0; j < 7; j++) s += __mul24(g.k[j], (int)p[j]);  // 24-bit multiplies are full rate, 32-bit ones are not
     tmp[yy * FT_W + xx] = s;
   }
   __syncthreads();
   const int lx = threadIdx.x & 63;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int ly = (threadIdx.x >> 6) * 4 + r;
+#pragma unroll 2
+  for (int r = 0; r < FT_R; r++) {
+    const int ly = (threadIdx.x >> 6) * FT_R + r;
     const int x = tx0 + lx, y = ty0 + ly;
     if (x >= W || y >= H) continue;
     int s = 0;
 #pragma unroll
-    for (int j = 0; j < 7; j++) s += g.k[j] * tmp[(ly + j) * FT_W + lx];
+    for (int j = 0; j < 7; j++) s += __mul24(g.k[j], tmp[(ly + j) * FT_W + lx]);  // |tmp| <= 255 * 257 < 2^23
     const int v = (s + (1 << 15)) >> 16;
     dst[(size_t)y * dpitch + x] = (uint8_t)min(255, max(0, v));
   }
@@ -380,20 +407,29 @@ __global__ void __launch_bounds__(SEL_T) k_orb_select(OrbLevels L, const uint8_t
   __syncthreads();
   const int T1 = (int)s_u[0];
   const uint8_t* nm = nms + (size_t)img * L.stride + L.off[l];
-  // raster sweep over the border box, one contiguous segment per wave
-  const int N = BW * BH;
-  const int seg = ((N + SEL_T / 64 - 1) / (SEL_T / 64) + 63) / 64 * 64;
-  const int s0 = wv * seg, s1 = min(N, s0 + seg);
+  // raster sweep over the border-box map in 16-pixel chunks (one aligned 16-byte load per lane), one contiguous run of
+  // chunks per wave: sweep A counts, sweep B emits the survivors' positions in raster order
+  const int BP = box_pitch(W), CPR = BP >> 4;
+  const int NC = CPR * BH;
+  const int seg = ((NC + SEL_T / 64 - 1) / (SEL_T / 64) + 63) / 64 * 64;
+  const int s0 = wv * seg, s1 = min(NC, s0 + seg);
   const int iters = s1 > s0 ? (s1 - s0 + 63) / 64 : 0;  // uniform per wave
+  const unsigned t1 = (unsigned)T1;
+  auto chunk_count = [&](const uint4& q) {
+    int c = 0;
+    const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) c += ((w4[k] >> (8 * b)) & 255u) >= t1 ? 1 : 0;
+    return c;
+  };
   int cnt = 0;
   for (int it = 0; it < iters; it++) {
     const int i = s0 + it * 64 + ln;
-    bool p = false;
-    if (i < s1) {
-      const int y = i / BW, x = i - y * BW;
-      p = nm[(size_t)(y + ORB_EDGE) * P + x + ORB_EDGE] >= T1;
-    }
-    cnt += __popcll(__ballot(p));
+    int c = 0;
+    if (i < s1) c = chunk_count(*reinterpret_cast<const uint4*>(nm + (size_t)i * 16));
+    cnt += wave_sum_i32(c);
   }
   if (ln == 0) s_wcnt[wv] = cnt;
   __syncthreads();
@@ -403,33 +439,44 @@ __global__ void __launch_bounds__(SEL_T) k_orb_select(OrbLevels L, const uint8_t
     if (k < wv) base += c;
     total += c;
   }
-  int plv;
-  const uint8_t* im = lvl_ptr(L, img0, pyr, l, img, plv);
   for (int it = 0; it < iters; it++) {
     const int i = s0 + it * 64 + ln;
-    bool p = false;
-    int x = 0, y = 0;
-    if (i < s1) {
-      y = i / BW;
-      x = i - y * BW;
-      x += ORB_EDGE;
-      y += ORB_EDGE;
-      p = nm[(size_t)y * P + x] >= T1;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (i < s1) q = *reinterpret_cast<const uint4*>(nm + (size_t)i * 16);
+    const int c = i < s1 ? chunk_count(q) : 0;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (ln >= o) incl += t;
     }
-    const unsigned long long b = __ballot(p);
-    if (p) {
-      const int o = base + lane_prefix(b);
-      if (o < ORB_CAND_CAP) {
-        float r = harris7(im, plv, x, y);
-        r = r + 0.0f;  // -0 -> +0 so that the ordered key compares like the float
-        pos[o] = ((unsigned)y << 16) | (unsigned)x;
-        key[o] = f32_ordered(r);
-      }
+    int o = base + incl - c;
+    if (c) {
+      const int y = i / CPR, x0 = (i - y * CPR) * 16;
+      const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (((w4[k] >> (8 * b)) & 255u) >= t1) {
+            if (o < ORB_CAND_CAP) pos[o] = ((unsigned)(y + ORB_EDGE) << 16) | (unsigned)(x0 + 4 * k + b + ORB_EDGE);
+            o++;
+          }
     }
-    base += __popcll(b);
+    base += __shfl(incl, 63, 64);
   }
   if (tid == 0 && total > ORB_CAND_CAP) overflow[img] = 1;
   const int m = min(total, ORB_CAND_CAP);
+  __syncthreads();
+  {  // Harris response of every survivor, one per thread
+    int plv;
+    const uint8_t* im = lvl_ptr(L, img0, pyr, l, img, plv);
+    for (int i = tid; i < m; i += SEL_T) {
+      float r = harris7(im, plv, (int)(pos[i] & 0xFFFFu), (int)(pos[i] >> 16));
+      r = r + 0.0f;  // -0 -> +0 so that the ordered key compares like the float
+      key[i] = f32_ordered(r);
+    }
+  }
   __syncthreads();
   // retainBest(nfeat) on the Harris response: exact n-th largest key by MSB-first radix select
   unsigned thr_key = 0;
