@@ -224,81 +224,64 @@ __device__ __forceinline__ void eig_tile(const uint8_t* __restrict__ img, int w,
   __syncthreads();
 }
 
-// pass 1: per-stream maximum of the eig map (minMaxLoc).  maxenc[s] must be zeroed before launch.
-__global__ __launch_bounds__(256) void k_eig_max(ImgSel src, int w, int h, int pitch, size_t sstride,
-                                                 unsigned* __restrict__ maxenc, const int* __restrict__ active) {
-  const int s = blockIdx.z;
-  if (active && !active[s]) return;
-  using T = EigTile<0>;
-  __shared__ __attribute__((aligned(16))) uint8_t tile[T::IH * T::IW];
-  __shared__ float sfx[T::CH * T::CW], sfy[T::CH * T::CW], eig[T::OH * T::OW];
-  __shared__ unsigned wmax[4];
-  const int x0 = blockIdx.x * EG_TW, y0 = blockIdx.y * EG_TH;
-  eig_tile<0>(src.ptr(s, sstride), w, h, pitch, x0, y0, tile, sfx, sfy, eig);
-  unsigned m = 0;
-  for (int i = threadIdx.x; i < T::OH * T::OW; i += 256) {
-    int r = i / T::OW, c = i - r * T::OW;
-    if (x0 + c < w && y0 + r < h) {
-      unsigned e = f32_ordered(eig[i]);
-      m = e > m ? e : m;
-    }
-  }
-  m = wave_max_u32(m);
-  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
-    atomicMax(&maxenc[s], a > b ? a : b);
-  }
-}
-
-// pass 2: recompute eig with a 1-pixel ring, threshold at (float)(max*q), keep 3x3 local maxima, append 64-bit sort keys
-// key = ~((ordered(val) << 32) | pixel_offset)  -> ascending key order == (val desc, offset desc)
-__global__ __launch_bounds__(256) void k_eig_nms(ImgSel src, int w, int h, int pitch, size_t sstride,
-                                                 const unsigned* __restrict__ maxenc, const double* __restrict__ qual,
-                                                 double quality, unsigned long long* __restrict__ keys,
-                                                 int* __restrict__ nkeys, int cap, const int* __restrict__ active) {
+// One pass over the image: the eig map of the tile (+1 ring), the per-stream maximum (minMaxLoc; maxenc[s] must be zero
+// before the launch) and the 3x3 local maxima as 64-bit sort keys, key = ~((ordered(val) << 32) | pixel_offset), so that
+// ascending key order == (val desc, offset desc).
+// cv::goodFeaturesToTrack thresholds first (THRESH_TOZERO at max*qualityLevel), dilates, and keeps val != 0 && val == dilated.
+// For a pixel above the threshold that is the same as "no raw neighbour is greater": a greater neighbour is itself above
+// the threshold, a neighbour at or below it becomes 0.  So the local-maximum test does not need the threshold, the map is
+// computed ONCE (it used to be computed twice: once for the maximum, once for the thresholded maxima), and the threshold
+// is applied by k_gftt_pick, which runs when the maximum is complete.  (Removing the second pass takes 0.15 ms off a
+// 64-stream step.)
+__global__ __launch_bounds__(256) void k_eig_cand(ImgSel src, int w, int h, int pitch, size_t sstride,
+                                                  unsigned* __restrict__ maxenc, unsigned long long* __restrict__ keys,
+                                                  int* __restrict__ nkeys, int cap, const int* __restrict__ active) {
   const int s = blockIdx.z;
   if (active && !active[s]) return;
   using T = EigTile<1>;
   __shared__ __attribute__((aligned(16))) uint8_t tile[T::IH * T::IW];
   __shared__ float sfx[T::CH * T::CW], sfy[T::CH * T::CW], eig[T::OH * T::OW];
+  __shared__ unsigned wmax[4];
   const int x0 = blockIdx.x * EG_TW, y0 = blockIdx.y * EG_TH;
   eig_tile<1>(src.ptr(s, sstride), w, h, pitch, x0, y0, tile, sfx, sfy, eig);
-  const float maxv = f32_unordered(maxenc[s]);
-  const double q = qual ? qual[s] : quality;
-  const float thr = (float)((double)maxv * q);
   // candidates are collected per workgroup in LDS and appended with ONE global atomic per workgroup (the per-stream
   // counter would otherwise serialise ~10^4 atomics per image); their order is irrelevant, the keys are sorted next
   __shared__ unsigned long long lkeys[EG_TH * EG_TW];
   __shared__ int lcount, lbase;
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
+  unsigned m = 0;
   for (int i = threadIdx.x; i < EG_TH * EG_TW; i += 256) {
     int r = i / EG_TW, c = i - r * EG_TW;
     int x = x0 + c, y = y0 + r;
-    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
+    if (x >= w || y >= h) continue;
     const float* e = eig + (r + 1) * T::OW + (c + 1);
-    float v = e[0];
-    if (!(v > thr) || v == 0.f) continue;
+    const float v = e[0];
+    const unsigned ev = f32_ordered(v);
+    m = ev > m ? ev : m;
+    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
+    if (!(v > 0.f)) continue;
     bool ismax = true;
 #pragma unroll
     for (int j = -1; j <= 1; j++)
 #pragma unroll
-      for (int k = -1; k <= 1; k++) {
-        float nv = e[j * T::OW + k];
-        float tv = nv > thr ? nv : 0.f;
-        if (tv > v) ismax = false;
-      }
+      for (int k = -1; k <= 1; k++)
+        if (e[j * T::OW + k] > v) ismax = false;
     if (ismax) {
       int slot = atomicAdd(&lcount, 1);
-      unsigned long long key = ((unsigned long long)f32_ordered(v) << 32) | (unsigned)(y * w + x);
+      unsigned long long key = ((unsigned long long)ev << 32) | (unsigned)(y * w + x);
       lkeys[slot] = ~key;
     }
   }
+  m = wave_max_u32(m);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
   __syncthreads();
   const int n = lcount;
-  if (threadIdx.x == 0 && n > 0) lbase = atomicAdd(&nkeys[s], n);
+  if (threadIdx.x == 0) {
+    unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    atomicMax(&maxenc[s], a > b ? a : b);
+    if (n > 0) lbase = atomicAdd(&nkeys[s], n);
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += 256) {
     int slot = lbase + i;
@@ -504,7 +487,8 @@ __global__ __launch_bounds__(SORT_T) void k_gftt_pick(unsigned long long* __rest
                                                       int w, int h, const int* __restrict__ max_corners_s, int max_corners,
                                                       double min_distance, float* __restrict__ out_xy,
                                                       int* __restrict__ out_n, int out_cap, const int* __restrict__ active,
-                                                      unsigned* __restrict__ maxenc) {
+                                                      unsigned* __restrict__ maxenc, const double* __restrict__ qual_s,
+                                                      double quality) {
   const int s = blockIdx.x;
   if (active && !active[s]) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char pick_smem[];
@@ -514,7 +498,10 @@ __global__ __launch_bounds__(SORT_T) void k_gftt_pick(unsigned long long* __rest
   __shared__ PickState ps;
   __shared__ int s_lo, s_hi, s_m, s_full, s_fill;
   const int tid = threadIdx.x;
-  if (tid == 0) maxenc[s] = 0;  // both eig passes are done with it: hand it back zeroed
+  // threshold(eig, eig, maxVal * qualityLevel, 0, THRESH_TOZERO): candidates at or below it do not exist for the selection
+  const unsigned thr_ord = f32_ordered((float)((double)f32_unordered(maxenc[s]) * (qual_s ? qual_s[s] : quality)));
+  __syncthreads();
+  if (tid == 0) maxenc[s] = 0;  // the eig pass is done with it: hand it back zeroed
   int n = nkeys[s];
   if (n > cap) n = cap;
   const int maxc = max_corners_s ? max_corners_s[s] : max_corners;
@@ -542,7 +529,10 @@ __global__ __launch_bounds__(SORT_T) void k_gftt_pick(unsigned long long* __rest
   }
   __syncthreads();
   // histogram of the top 12 bits of the ordered response (bin 4095 = best)
-  for (int i = tid; i < n; i += SORT_T) atomicAdd(&hist[(unsigned)((~K[i]) >> 52)], 1);
+  for (int i = tid; i < n; i += SORT_T) {
+    const unsigned long long nk = ~K[i];
+    if ((unsigned)(nk >> 32) > thr_ord) atomicAdd(&hist[(unsigned)(nk >> 52)], 1);
+  }
   __syncthreads();
   // suffix sums: hist[b] <- number of keys with bin >= b (hist[PICK_BINS] = 0); 4 bins per thread + workgroup scan
   {
@@ -601,7 +591,7 @@ __global__ __launch_bounds__(SORT_T) void k_gftt_pick(unsigned long long* __rest
     for (int i = tid; i < n; i += SORT_T) {
       const unsigned long long k = K[i];
       const int bin = (int)((~k) >> 52);
-      if (bin >= lo && bin < hi) sk[atomicAdd(&s_fill, 1)] = k;
+      if (bin >= lo && bin < hi && (unsigned)((~k) >> 32) > thr_ord) sk[atomicAdd(&s_fill, 1)] = k;
     }
     __syncthreads();
     sort_keys_lds(sk, m);
@@ -621,9 +611,10 @@ __global__ __launch_bounds__(SORT_T) void k_gftt_pick(unsigned long long* __rest
     __syncthreads();
     sort_keys_global(K, n, cap, sk);
     __syncthreads();
+    const int nv = hist[0];  // keys above the threshold: a prefix of the sorted array
     if (tid < 64) {
-      for (int base = 0; base < n && (maxc <= 0 || ps.accepted < maxc); base += SORT_LDS) {
-        const int m = (n - base) < SORT_LDS ? (n - base) : SORT_LDS;
+      for (int base = 0; base < nv && (maxc <= 0 || ps.accepted < maxc); base += SORT_LDS) {
+        const int m = (nv - base) < SORT_LDS ? (nv - base) : SORT_LDS;
         pick_walk(K + base, m, w, h, wpr, bitmap, maxc, md2, R, use_dist, out, out_cap, ps);
       }
     }
@@ -886,15 +877,13 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
   }
   dim3 grid(div_up(w, EG_TW), div_up(h, EG_TH), S);
   if (ev) hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_eig_max, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, active);
-  if (ev) hipEventRecord(ev[1], st), hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(k_eig_nms, grid, dim3(256), 0, st, src, w, h, pitch, sstride, (const unsigned*)sc.maxenc, qual_s,
-                     quality, sc.keys, sc.nkeys, sc.cap, active);
-  if (ev) hipEventRecord(ev[3], st), hipEventRecord(ev[4], st);
+  hipLaunchKernelGGL(k_eig_cand, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, sc.keys, sc.nkeys, sc.cap,
+                     active);
+  if (ev) hipEventRecord(ev[1], st), hipEventRecord(ev[2], st), hipEventRecord(ev[3], st), hipEventRecord(ev[4], st);
   const size_t lds = sizeof(unsigned long long) * SORT_LDS + sizeof(int) * (PICK_BINS + 8) +
                      (size_t)((w + 31) / 32) * h * sizeof(unsigned);
   hipLaunchKernelGGL(k_gftt_pick, dim3(S), dim3(SORT_T), lds, st, sc.keys, sc.nkeys, sc.cap, w, h, maxc_s, max_corners,
-                     min_distance, out_xy, out_n, out_cap, active, sc.maxenc);
+                     min_distance, out_xy, out_n, out_cap, active, sc.maxenc, qual_s, quality);
   if (ev) hipEventRecord(ev[5], st);
 }
 
