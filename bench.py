@@ -31,8 +31,7 @@ PYR_BYTES = 307200 + 76800 + 19200 + 4800          # one pyramid (levels 0..3)
 ALG_BYTES = {
     "lk_track(temporal)": 2 * PYR_BYTES,           # one pass over the previous and the current pyramid
     "lk_track(stereo)": 2 * PYR_BYTES,             # one pass over the img0 and img1 pyramids
-    "gftt:eig_max": 307200,                        # corner response pass 1 (per-image maximum) reads img0 once
-    "gftt:eig_nms": 307200,                        # pass 2 (threshold + 3x3 NMS, response recomputed) reads img0 once
+    "gftt:eig_cand": 307200,                       # corner response + maximum + 3x3 local maxima: reads img0 once
     "ingest(copy/equalize)": 4 * 307200,           # read + write both images
     "pyr_down x6": 2 * (307200 + 76800 + 19200) + 2 * (76800 + 19200 + 4800),
 }

@@ -52,9 +52,9 @@ __global__ __launch_bounds__(256) void k_hist256(ImgSel src, int w, int h, int p
   const uint8_t* img = src.ptr(s, sstride);
   const int wv = threadIdx.x >> 6;
   const int dwords_per_row = w >> 2;  // w % 4 == 0 (checked on host)
-  const long total = (long)dwords_per_row * h;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int y = (int)(i / dwords_per_row), x4 = (int)(i - (long)y * dwords_per_row);
+  const int total = dwords_per_row * h;  // 32-bit index math: a 64-bit division per dword dominated this kernel
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int y = i / dwords_per_row, x4 = i - y * dwords_per_row;
     uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)y * pitch + 4 * x4);
     atomicAdd(&lh[wv][v & 255], 1u);
     atomicAdd(&lh[wv][(v >> 8) & 255], 1u);
@@ -114,13 +114,28 @@ __global__ __launch_bounds__(256) void k_lut_apply(ImgSel src, ImgSel dst, int w
   const uint8_t* in = src.ptr(s, sstride);
   uint8_t* out = const_cast<uint8_t*>(dst.ptr(s, dstride));
   const int dpr = w >> 2;
-  const long total = (long)dpr * h;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int y = (int)(i / dpr), x4 = (int)(i - (long)y * dpr);
+  const int total = dpr * h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int y = i / dpr, x4 = i - y * dpr;
     uint32_t v = *reinterpret_cast<const uint32_t*>(in + (size_t)y * spitch + 4 * x4);
     uint32_t o = (uint32_t)l[v & 255] | ((uint32_t)l[(v >> 8) & 255] << 8) | ((uint32_t)l[(v >> 16) & 255] << 16) |
                  ((uint32_t)l[v >> 24] << 24);
     *reinterpret_cast<uint32_t*>(out + (size_t)y * dpitch + 4 * x4) = o;
+  }
+}
+
+// plain image copy into the pyramid's level-0 slot (modes without equalizeHist): 16 bytes per lane, w % 16 == 0
+__global__ __launch_bounds__(256) void k_copy_image16(ImgSel src, ImgSel dst, int w16, int h, int spitch, int dpitch,
+                                                      size_t sstride, size_t dstride, const int* __restrict__ active) {
+  const int s = blockIdx.y;
+  if (active && !active[s]) return;
+  const uint8_t* in = src.ptr(s, sstride);
+  uint8_t* out = const_cast<uint8_t*>(dst.ptr(s, dstride));
+  const int total = w16 * h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int y = i / w16, x = i - y * w16;
+    *reinterpret_cast<uint4*>(out + (size_t)y * dpitch + 16 * x) =
+        *reinterpret_cast<const uint4*>(in + (size_t)y * spitch + 16 * x);
   }
 }
 
@@ -853,6 +868,14 @@ void launch_equalize_hist(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, 
 
 void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
                        size_t dstride, int S, const int* active) {
+  const bool a16 = (w % 16) == 0 && (spitch % 16) == 0 && (dpitch % 16) == 0 && (sstride % 16) == 0 && (dstride % 16) == 0 &&
+                   ((uintptr_t)src.b[0] % 16) == 0 && ((uintptr_t)src.b[1] % 16) == 0 && ((uintptr_t)dst.b[0] % 16) == 0 &&
+                   ((uintptr_t)dst.b[1] % 16) == 0;
+  if (a16) {
+    hipLaunchKernelGGL(k_copy_image16, dim3(div_up((w / 16) * h, 256 * 2), S), dim3(256), 0, st, src, dst, w / 16, h, spitch,
+                       dpitch, sstride, dstride, active);
+    return;
+  }
   int ablocks = div_up((w / 4) * h, 256 * 4);
   hipLaunchKernelGGL(k_lut_apply, dim3(ablocks, S), dim3(256), 0, st, src, dst, w, h, spitch, dpitch, sstride, dstride,
                      (const uint8_t*)nullptr, active);

@@ -70,7 +70,7 @@ struct Pipeline {
 constexpr int PROF_STAGES = 19;  // every stage has its own (begin, end) event pair on the stream it runs on
 static const char* kStageNames[PROF_STAGES] = {
     "imu_feed+frame_begin", "ingest(copy/equalize)", "pyr_down x6", "track_prepare", "lk_track(temporal)", "track_collect",
-    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_max", "gftt:eig_nms", "gftt:pick",
+    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_cand", "gftt:(merged)", "gftt:pick",
     "feature_dem+add_new", "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end",
     "ba_worker(launch)"};
 
