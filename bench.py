@@ -48,6 +48,10 @@ def main():
     ap.add_argument("--groups", type=int, default=1,
                     help="split the GPU's streams over this many independent tracker contexts (own HIP streams each): the "
                          "per-stream kernels are latency-bound, so sub-batches fed round-robin overlap on the GPU")
+    ap.add_argument("--host-threads", type=int, default=-1,
+                    help="1: one host thread per tracker context (ctypes releases the GIL, so the contexts' launch sequences "
+                         "are issued in parallel, like one thread per rig group in a deployment); 0: round-robin from one "
+                         "thread; -1: on when --groups > 1")
     args = ap.parse_args()
 
     # the pipeline uses 4-6 HIP streams per tracker context; with the default of 4 hardware queues the long local-map kernels
@@ -111,25 +115,53 @@ def main():
     times = np.array([[f / synth.FRAME_HZ] * S for f in range(nsteps)])
     wlm = 0 if args.no_local_map else 1
 
-    def step(f):
+    def step_group(f, g):
         i0, i1 = frames[f]
+        a, b = g * Sg, (g + 1) * Sg
+        rc = lib.flvis_imu_feed_all(ctxs[g]._h, imu_cnt[f, a:b].ctypes.data_as(C.POINTER(C.c_int)),
+                                    imu[f, a:b].ctypes.data_as(C.POINTER(C.c_double)), SPF)
+        if rc:
+            ctxs[g]._check(rc, "imu_feed_all")
+        rc = lib.flvis_image_feed(ctxs[g]._h, C.c_void_p(i0[a:b].data_ptr()), C.c_void_p(i1[a:b].data_ptr()),
+                                  times[f, a:b].ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(0), wlm)
+        if rc:
+            ctxs[g]._check(rc, "image_feed")
+
+    def step(f):
         for g in range(G):
-            a, b = g * Sg, (g + 1) * Sg
-            rc = lib.flvis_imu_feed_all(ctxs[g]._h, imu_cnt[f, a:b].ctypes.data_as(C.POINTER(C.c_int)),
-                                        imu[f, a:b].ctypes.data_as(C.POINTER(C.c_double)), SPF)
-            if rc:
-                ctxs[g]._check(rc, "imu_feed_all")
-            rc = lib.flvis_image_feed(ctxs[g]._h, C.c_void_p(i0[a:b].data_ptr()), C.c_void_p(i1[a:b].data_ptr()),
-                                      times[f, a:b].ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(0), wlm)
-            if rc:
-                ctxs[g]._check(rc, "image_feed")
+            step_group(f, g)
+
+    threaded = G > 1 and args.host_threads != 0
+
+    def run_frames(f0, f1):
+        """feed frames [f0, f1) to every context: from one thread round-robin, or one host thread per context"""
+        if not threaded:
+            for f in range(f0, f1):
+                step(f)
+            return
+        import threading
+        errs = []
+
+        def worker(g):
+            try:
+                torch.cuda.set_device(local_rank)
+                for f in range(f0, f1):
+                    step_group(f, g)
+            except Exception as e:  # surfaced after join
+                errs.append(e)
+        ths = [threading.Thread(target=worker, args=(g,)) for g in range(G)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for f in range(Wm):
-        step(f)
+    run_frames(0, Wm)
     torch.cuda.synchronize()
     nst = lib.flvis_prof_stage_count()
     lib.flvis_prof_stage_name.restype = C.c_char_p
@@ -151,8 +183,7 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for f in range(Wm, Wm + K):
-        step(f)
+    run_frames(Wm, Wm + K)
     e1.record()
     for g in range(G):  # everything enqueued AND every queued keyframe consumed by the local map
         ctxs[g]._check(lib.flvis_hip_synchronize(ctxs[g]._h), "synchronize")
@@ -166,8 +197,7 @@ def main():
     # untimed epilogue: all stages
     for g in range(G):
         ctxs[g]._check(lib.flvis_prof_enable_stages(ctxs[g]._h, XTRA, C.c_uint64((1 << 64) - 1)), "prof_enable")
-    for f in range(Wm + K, Wm + K + XTRA):
-        step(f)
+    run_frames(Wm + K, Wm + K + XTRA)
     torch.cuda.synchronize()
     stages = read_stages(ctx)
 
@@ -210,7 +240,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "1xMI355X: batch of %d independent 640x480 synthetic stereo+IMU streams, full HIP "
                                    "front-end + batched Schur BA (BASELINE.json configs[3])" % S,
-                       "streams_per_gpu": S, "contexts_per_gpu": G, "window_size": cfg.window_size, "local_map": bool(wlm),
+                       "streams_per_gpu": S, "contexts_per_gpu": G, "host_threads": (G if threaded else 1), "window_size": cfg.window_size, "local_map": bool(wlm),
                        "streams_tracking_at_end": tracking, "keyframes_in_run": int(kfs_total),
                        "ba_runs_in_run": int(cnt[2]), "gpu_ms_per_step_events": round(gpu_ms / K, 4)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
