@@ -101,6 +101,15 @@ class Context:
         self._check(self._lib.flvis_hip_equalize_hist(self._h, _ptr(img), _ptr(out), w, h, n), "equalize_hist")
         return out
 
+    def cvt_bgr_to_gray(self, img):
+        """img uint8 [n,h,w,3|4] (BGR / BGRA, interleaved) -> gray [n,h,w]."""
+        import torch
+        assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous() and img.dim() == 4
+        n, h, w, c = img.shape
+        out = torch.empty((n, h, w), dtype=torch.uint8, device=img.device)
+        self._check(self._lib.flvis_hip_cvt_bgr_to_gray(self._h, _ptr(img), c, _ptr(out), w, h, n), "cvt_bgr_to_gray")
+        return out
+
     def pyr_down(self, img):
         import torch
         assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous() and img.dim() == 3

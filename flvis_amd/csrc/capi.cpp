@@ -1,6 +1,7 @@
 // flvis_amd: extern "C" shim (include/flvis_hip.h) over the HIP kernels.  No CPU fallback anywhere: without a HIP
 // device every entry point fails with FLVIS_ERR_NO_DEVICE.
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -103,6 +104,18 @@ int flvis_hip_equalize_hist(flvis_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst
   launch_equalize_hist(ctx->stream, img_plain(d_src), img_plain(d_dst), w, h, w, w, (size_t)w * h, (size_t)w * h, n_img,
                        hist, lut, nullptr);
   CHECK_LAUNCH(ctx, "equalize_hist");
+  return FLVIS_OK;
+}
+
+int flvis_hip_cvt_bgr_to_gray(flvis_ctx* ctx, const uint8_t* d_src, int channels, uint8_t* d_dst, int w, int h, int n_img) {
+  CHECK_CTX(ctx);
+  if (!d_src || !d_dst || (channels != 3 && channels != 4) || w <= 0 || h <= 0 || n_img <= 0 || (w & 3) ||
+      ((uintptr_t)d_src & 3) || ((uintptr_t)d_dst & 3))
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "cvt_bgr_to_gray: bad args (3 or 4 channels, w % 4 == 0, 4-byte aligned buffers)");
+  const size_t npx = (size_t)w * h * n_img;
+  if (npx / 4 > 0x7fffffffu) return ctx->fail(FLVIS_ERR_CAPACITY, "cvt_bgr_to_gray: batch too large");
+  launch_bgr_to_gray(ctx->stream, d_src, channels, d_dst, npx);
+  CHECK_LAUNCH(ctx, "cvt_bgr_to_gray");
   return FLVIS_OK;
 }
 

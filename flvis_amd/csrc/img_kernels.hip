@@ -124,6 +124,33 @@ __global__ __launch_bounds__(256) void k_lut_apply(ImgSel src, ImgSel dst, int w
   }
 }
 
+// cv::cvtColor BGR2GRAY / BGRA2GRAY (f2f_tracking.cpp:74-111): 14-bit fixed point, 4 pixels per lane (w % 4 == 0), packed in
+// and out as dwords
+template <int CH>
+__global__ __launch_bounds__(256) void k_bgr_to_gray(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int quads) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= quads) return;
+  const uint32_t* in = reinterpret_cast<const uint32_t*>(src) + (size_t)i * CH;
+  uint32_t o = 0;
+  if (CH == 4) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t v = in[k];
+      const uint32_t y = ((v & 255u) * 1868u + ((v >> 8) & 255u) * 9617u + ((v >> 16) & 255u) * 4899u + (1u << 13)) >> 14;
+      o |= y << (8 * k);
+    }
+  } else {
+    const uint32_t a = in[0], b = in[1], c = in[2];  // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+    const uint32_t px[4][3] = {{a & 255u, (a >> 8) & 255u, (a >> 16) & 255u},
+                               {a >> 24, b & 255u, (b >> 8) & 255u},
+                               {(b >> 16) & 255u, b >> 24, c & 255u},
+                               {(c >> 8) & 255u, (c >> 16) & 255u, c >> 24}};
+#pragma unroll
+    for (int k = 0; k < 4; k++) o |= ((px[k][0] * 1868u + px[k][1] * 9617u + px[k][2] * 4899u + (1u << 13)) >> 14) << (8 * k);
+  }
+  reinterpret_cast<uint32_t*>(dst)[i] = o;
+}
+
 // plain image copy into the pyramid's level-0 slot (modes without equalizeHist): 16 bytes per lane, w % 16 == 0
 __global__ __launch_bounds__(256) void k_copy_image16(ImgSel src, ImgSel dst, int w16, int h, int spitch, int dpitch,
                                                       size_t sstride, size_t dstride, const int* __restrict__ active) {
@@ -864,6 +891,14 @@ void launch_equalize_hist(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, 
   int ablocks = div_up((w / 4) * h, 256 * 4);
   hipLaunchKernelGGL(k_lut_apply, dim3(ablocks, S), dim3(256), 0, st, src, dst, w, h, spitch, dpitch, sstride, dstride,
                      (const uint8_t*)lut, active);
+}
+
+void launch_bgr_to_gray(hipStream_t st, const uint8_t* src, int channels, uint8_t* dst, size_t npixels) {
+  const int quads = (int)(npixels / 4);
+  if (channels == 4)
+    hipLaunchKernelGGL(k_bgr_to_gray<4>, dim3(div_up(quads, 256)), dim3(256), 0, st, src, dst, quads);
+  else
+    hipLaunchKernelGGL(k_bgr_to_gray<3>, dim3(div_up(quads, 256)), dim3(256), 0, st, src, dst, quads);
 }
 
 void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,

@@ -48,6 +48,7 @@ struct GfttScratch {
 hipError_t img_kernels_init();
 void launch_equalize_hist(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
                           size_t dstride, int S, unsigned* hist, uint8_t* lut, const int* active);
+void launch_bgr_to_gray(hipStream_t st, const uint8_t* src, int channels, uint8_t* dst, size_t npixels);
 void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
                        size_t dstride, int S, const int* active);
 void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,

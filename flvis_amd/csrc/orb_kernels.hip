@@ -891,9 +891,16 @@ int flvis_hip_orb_detect_and_compute(flvis_ctx* ctx, const uint8_t* d_img, int w
   else
     default_pattern(hp);
   hipStream_t st = ctx->stream;
-  // pageable source: the copy is staged before the call returns, so the stack buffer may go out of scope
-  if (hipMemcpyAsync(pat, hp, 1024, hipMemcpyHostToDevice, st) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "orb: pattern upload");
-  hipStreamSynchronize(st);
+  if (ctx->orb_pattern.size() != 1024 || std::memcmp(ctx->orb_pattern.data(), hp, 1024) != 0) {
+    // (re)upload only when the pattern changes: steady-state calls stay asynchronous.  The source lives in the context.
+    hipStreamSynchronize(st);  // earlier launches may still read the buffer
+    ctx->orb_pattern.assign(reinterpret_cast<const char*>(hp), 1024);
+    if (hipMemcpyAsync(pat, ctx->orb_pattern.data(), 1024, hipMemcpyHostToDevice, st) != hipSuccess) {
+      ctx->orb_pattern.clear();
+      return ctx->fail(FLVIS_ERR_HIP, "orb: pattern upload");
+    }
+    hipStreamSynchronize(st);
+  }
   int* ovf_out = d_overflow ? d_overflow : ovf;
   hipMemsetAsync(hist, 0, sizeof(unsigned) * 256 * ORB_MAX_LEVELS * n_img, st);
   hipMemsetAsync(ovf_out, 0, sizeof(int) * n_img, st);

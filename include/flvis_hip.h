@@ -55,6 +55,10 @@ void* flvis_hip_stream(flvis_ctx* ctx);
 
 /* cv::equalizeHist on n_img contiguous u8 images of w x h (pitch == w, w % 4 == 0). In place allowed. */
 int flvis_hip_equalize_hist(flvis_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int n_img);
+/* cv::cvtColor(img, gray, CV_BGR2GRAY / CV_BGRA2GRAY) as F2FTracking::image_feed applies it to 3- or 4-channel input
+ * (src/frontend/f2f_tracking.cpp:74-111; mbRGB is constant 0 there): d_src [n_img][h][w][channels] interleaved,
+ * d_dst [n_img][h][w].  w % 4 == 0. */
+int flvis_hip_cvt_bgr_to_gray(flvis_ctx* ctx, const uint8_t* d_src, int channels, uint8_t* d_dst, int w, int h, int n_img);
 
 /* cv::pyrDown (5-tap Gaussian, REFLECT_101, (x+128)>>8): n_img images w x h (pitch src_pitch) ->
  * ((w+1)/2) x ((h+1)/2) images with pitch dst_pitch.  Image i starts at d_src + i*src_pitch*h (resp. dst). */

@@ -11,6 +11,7 @@ struct Pt2f {
 };
 
 void equalize_hist(const uint8_t* src, uint8_t* dst, int w, int h);
+void cvt_bgr_to_gray(const uint8_t* src, int channels, uint8_t* dst, int w, int h);
 void pyr_down(const uint8_t* src, int w, int h, uint8_t* dst);
 int lk_num_levels(int w, int h, int win, int max_level);
 void calc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const float* prev_pts,

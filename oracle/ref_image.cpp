@@ -39,6 +39,17 @@ static inline int reflect101(int i, int n) {
   return i;
 }
 
+// ------------------------------------------------------------------------------------------ cvtColor BGR(A) -> gray
+// cv::cvtColor(img, out, CV_BGR2GRAY / CV_BGRA2GRAY) as F2FTracking::image_feed applies it to 3/4-channel input
+// (src/frontend/f2f_tracking.cpp:74-111, mbRGB is constant 0).  OpenCV 3.x RGB2Gray<uchar> (imgproc/src/color.cpp): 14-bit
+// fixed point, B2Y = 1868, G2Y = 9617, R2Y = 4899, CV_DESCALE = (x + 2^13) >> 14; the alpha channel is ignored.
+void cvt_bgr_to_gray(const uint8_t* src, int channels, uint8_t* dst, int w, int h) {
+  for (size_t i = 0; i < (size_t)w * h; i++) {
+    const uint8_t* p = src + i * channels;
+    dst[i] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ equalizeHist
 void equalize_hist(const uint8_t* src, uint8_t* dst, int w, int h) {
   int hist[256] = {0};
@@ -491,6 +502,9 @@ void FeatureDEM::redetect(const uint8_t* img, const std::vector<Pt2f>& existedPt
 // ------------------------------------------------------------------------------------------ C entry points (ctypes)
 extern "C" {
 void ref_equalize_hist(const uint8_t* src, uint8_t* dst, int w, int h) { ref::equalize_hist(src, dst, w, h); }
+void ref_cvt_bgr_to_gray(const uint8_t* src, int channels, uint8_t* dst, int w, int h) {
+  ref::cvt_bgr_to_gray(src, channels, dst, w, h);
+}
 void ref_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst) { ref::pyr_down(src, w, h, dst); }
 int ref_lk_num_levels(int w, int h, int win, int max_level) { return ref::lk_num_levels(w, h, win, max_level); }
 void ref_calc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int h, const float* prev_pts,

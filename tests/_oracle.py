@@ -33,6 +33,15 @@ def equalize_hist(img):
     return out
 
 
+def cvt_bgr_to_gray(img):
+    """img uint8 [h,w,3|4] (BGR / BGRA) -> gray [h,w]."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, c = img.shape
+    out = np.empty((h, w), np.uint8)
+    lib().ref_cvt_bgr_to_gray(_p(img, C.c_uint8), c, _p(out, C.c_uint8), w, h)
+    return out
+
+
 def pyr_down(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape

@@ -32,6 +32,15 @@ def test_equalize_hist_parity(ctx, h, w, n):
         assert np.array_equal(out[i], O.equalize_hist(imgs[i]))
 
 
+@pytest.mark.parametrize("h,w,c,n", [(480, 640, 3, 2), (480, 640, 4, 2), (37, 52, 3, 3), (5, 4, 4, 1)])
+def test_cvt_bgr_to_gray_parity(ctx, h, w, c, n):
+    rng = np.random.default_rng(h * w + c)
+    imgs = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)
+    out = ctx.cvt_bgr_to_gray(_cuda(imgs)).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(out[i], O.cvt_bgr_to_gray(imgs[i]))
+
+
 def test_equalize_hist_constant(ctx):
     imgs = np.full((2, 32, 64), 9, np.uint8)
     imgs[1] = 250

@@ -188,3 +188,15 @@ def test_feature_dem_redetect_respects_existing():
         same = (existed[:, 1] // 120 == p[1] // 120) & (existed[:, 0] // 160 == p[0] // 160)
         d = np.abs(existed[same].astype(np.float32) - p)
         assert np.all((d[:, 0] > 2) & (d[:, 1] > 2))
+
+
+def test_cvt_bgr_to_gray_matches_the_fixed_point_formula():
+    """cv::cvtColor BGR2GRAY / BGRA2GRAY (f2f_tracking.cpp:74-111): (1868 B + 9617 G + 4899 R + 2^13) >> 14."""
+    rng = np.random.default_rng(1)
+    for c in (3, 4):
+        img = rng.integers(0, 256, (37, 52, c), dtype=np.uint8)
+        want = ((img[..., 0].astype(np.int64) * 1868 + img[..., 1].astype(np.int64) * 9617 + img[..., 2].astype(np.int64) * 4899
+                 + (1 << 13)) >> 14).astype(np.uint8)
+        assert np.array_equal(O.cvt_bgr_to_gray(img), want)
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)       # B = G = R -> unchanged
+    assert np.array_equal(O.cvt_bgr_to_gray(grey)[0], np.arange(256))
