@@ -1,0 +1,83 @@
+"""Pins the yaml loaders (product: flvis_config_load, csrc/config.cpp; oracle: ref_config_load_yaml) on the reference's OWN
+yaml dependency: tests/golden/yaml_*.txt hold what yaml-cpp 0.6.2 (compiled from /root/reference/3rdPartLib by
+oracle/Makefile, read through the accessors of src/utils/include/yamlRead.h) returns for every key -- see
+scripts/make_yaml_fixtures.py.  SURVEY.md §8b: "must accept the reference's yaml files byte-for-byte"."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def read_dump(text):
+    out = {}
+    for line in text.splitlines():
+        f = line.split()
+        if len(f) >= 3 and f[1] != "s":
+            out[f[0]] = np.array([float(x) for x in f[2:2 + int(f[1])]])
+    return out
+
+
+def inv44(m):
+    return np.linalg.inv(np.asarray(m).reshape(4, 4))
+
+
+def check_cfg_against_dump(cfg, d, who):
+    """raw (pre-finalize) fields of flvis_cfg against the yaml-cpp values; exact unless a product of 4x4 matrices is involved"""
+    assert cfg.type_of_vi == int(d["type_of_vi"][0]), who
+    assert cfg.image_width == int(d["image_width"][0]) and cfg.image_height == int(d["image_height"][0]), who
+    for k, name in (("cam0_intrinsics", "cam0_intrinsics"), ("cam0_distortion", "cam0_distortion_coeffs"),
+                    ("cam1_intrinsics", "cam1_intrinsics"), ("cam1_distortion", "cam1_distortion_coeffs")):
+        assert np.array_equal(np.array(list(getattr(cfg, k))), d[name]), (who, k)
+    for k, n in (("vifusion_para", 6), ("feature_para", 6), ("dr_para", 3)):
+        want = np.array([d["%s%d" % (k, i + 1)][0] for i in range(n)])
+        assert np.array_equal(np.array(list(getattr(cfg, k))), want), (who, k)
+    assert cfg.window_size == int(d["window_size"][0]), who
+    T_i_c0 = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)
+    T_c0_c1 = np.array(list(cfg.T_cam0_cam1)).reshape(4, 4)
+    if cfg.type_of_vi == 1:   # vo_tracking.cpp:228-236: T_i_c0 = T_imu_mavimu * T_mavimu_cam0, T_c0_c1 = T_mavimu_cam0^-1 * T_mavimu_cam1
+        a, b, m = d["T_mavimu_cam0"].reshape(4, 4), d["T_mavimu_cam1"].reshape(4, 4), d["T_imu_mavimu"].reshape(4, 4)
+        assert np.allclose(T_i_c0, m @ a, atol=1e-12, rtol=0), who
+        assert np.allclose(T_c0_c1, inv44(a) @ b, atol=1e-12, rtol=0), who
+    else:
+        assert np.array_equal(T_i_c0.reshape(-1), d["T_imu_cam0"]), who
+        assert np.array_equal(T_c0_c1.reshape(-1), d["T_cam0_cam1"]), who
+
+
+@pytest.mark.parametrize("name", ["d435i_stereo", "euroc_like"])
+def test_loaders_match_yaml_cpp_on_the_synthetic_rig_files(name):
+    import flvis_amd
+    from flvis_amd import synth
+    text = {"d435i_stereo": synth.D435I_STEREO_YAML, "euroc_like": synth.EUROC_LIKE_YAML}[name]
+    p = os.path.join(tempfile.gettempdir(), "flvis_yamlcpp_%s.yaml" % name)
+    open(p, "w").write(text)
+    d = read_dump(open(os.path.join(GOLD, "yaml_synth_%s.txt" % name)).read())
+    check_cfg_against_dump(flvis_amd.load_config(p), d, "product")
+    check_cfg_against_dump(O.load_config(p), d, "oracle")
+
+
+REF = {"euroc": "/root/reference/launch/EuRoC_MAV/euroc.yaml",
+       "d435i_stereo": "/root/reference/launch/d435i/sn943222072828_stereo.yaml",
+       "d435_stereo_px4": "/root/reference/launch/d435_pixhawk/sn943222072828_stereo_px4.yaml"}
+
+
+@pytest.mark.parametrize("name", sorted(REF))
+def test_loaders_match_yaml_cpp_on_the_reference_launch_files(name):
+    """the reference's own launch files, read in place (they are not copied into this repo): skipped where /root/reference
+    does not exist (the GPU box)."""
+    if not os.path.exists(REF[name]):
+        pytest.skip("reference not present")
+    import flvis_amd
+    gold = open(os.path.join(GOLD, "yaml_ref_%s.txt" % name)).read()
+    dump = os.path.join(ROOT, "oracle", "_ref", "yaml_dump")
+    if os.path.exists(dump):   # the committed fixture is what the reference's yaml-cpp says today
+        assert subprocess.check_output([dump, REF[name]]).decode() == gold
+    d = read_dump(gold)
+    check_cfg_against_dump(flvis_amd.load_config(REF[name]), d, "product")
+    check_cfg_against_dump(O.load_config(REF[name]), d, "oracle")
