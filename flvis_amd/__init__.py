@@ -269,7 +269,8 @@ class FlvisCfg(C.Structure):
                 ("window_size", C.c_int),
                 ("cam_type", C.c_int), ("imu_type", C.c_int), ("skip_first_n_imgs", C.c_int),
                 ("need_equal_hist", C.c_int),
-                ("R0", C.c_double * 9), ("R1", C.c_double * 9), ("P0", C.c_double * 12), ("P1", C.c_double * 12)]
+                ("R0", C.c_double * 9), ("R1", C.c_double * 9), ("P0", C.c_double * 12), ("P1", C.c_double * 12),
+                ("depth_factor", C.c_double)]
 
 
 class FrameOut(C.Structure):

@@ -207,8 +207,22 @@ extern "C" int flvis_config_finalize(flvis_cfg* c) {
       c->skip_first_n_imgs = 50;
       c->need_equal_hist = 0;
       break;
+    case 0:
+    case 2: {
+      // DEPTH_D435 (vo_tracking.cpp:142-170): pinhole K from cam0_intrinsics, no distortion, no second camera
+      c->cam_type = 2;
+      c->imu_type = c->type_of_vi == 0 ? 0 : 2;
+      c->skip_first_n_imgs = 50;
+      c->need_equal_hist = 0;
+      const double P[12] = {c->cam0_intrinsics[0], 0, c->cam0_intrinsics[2], 0, 0, c->cam0_intrinsics[1], c->cam0_intrinsics[3], 0,
+                            0, 0, 1, 0};
+      memcpy(c->P0, P, sizeof(P));
+      memset(c->P1, 0, sizeof(c->P1));
+      for (int i = 0; i < 9; i++) c->R0[i] = c->R1[i] = (i % 4 == 0) ? 1.0 : 0.0;
+      return c->depth_factor > 0 ? FLVIS_OK : FLVIS_ERR_CONFIG;
+    }
     default:
-      return FLVIS_ERR_CONFIG;  // depth-camera and KITTI modes are not part of this path
+      return FLVIS_ERR_CONFIG;  // KITTI (stereo without IMU) is not part of this path
   }
   double Tinv[16];
   mat44_inverse_rigid(c->T_cam0_cam1, Tinv);  // T_c1_c0
@@ -304,10 +318,19 @@ extern "C" int flvis_config_load(const char* path, flvis_cfg* c, char* err, int 
   c->image_width = (int)v;
   if (!need("image_height", 1, &v)) return fail("yaml key missing: image_height");
   c->image_height = (int)v;
-  if (!need("cam0_intrinsics", 4, c->cam0_intrinsics) || !need("cam0_distortion_coeffs", 4, c->cam0_distortion) ||
-      !need("cam1_intrinsics", 4, c->cam1_intrinsics) || !need("cam1_distortion_coeffs", 4, c->cam1_distortion))
+  const bool depth_mode = c->type_of_vi == 0 || c->type_of_vi == 2;
+  if (!need("cam0_intrinsics", 4, c->cam0_intrinsics) || !need("cam0_distortion_coeffs", 4, c->cam0_distortion))
     return fail("yaml key missing or short: " + missing);
-  if (c->type_of_vi == 1) {
+  if (depth_mode) {  // vo_tracking.cpp:149-154 reads only cam0, depth_factor and T_imu_cam0
+    if (!need("depth_factor", 1, &c->depth_factor) || !need("T_imu_cam0", 16, c->T_imu_cam0))
+      return fail("yaml key missing or short: " + missing);
+    const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(c->T_cam0_cam1, eye, sizeof(eye));
+  } else if (!need("cam1_intrinsics", 4, c->cam1_intrinsics) || !need("cam1_distortion_coeffs", 4, c->cam1_distortion)) {
+    return fail("yaml key missing or short: " + missing);
+  }
+  if (depth_mode) {
+  } else if (c->type_of_vi == 1) {
     double a[16], b[16], m[16], ai[16];
     if (!need("T_mavimu_cam0", 16, a) || !need("T_mavimu_cam1", 16, b) || !need("T_imu_mavimu", 16, m))
       return fail("yaml key missing or short: " + missing);

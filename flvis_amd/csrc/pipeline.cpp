@@ -208,6 +208,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   if (cfg->window_size > BA_WMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "window_size exceeds the LDS-resident solver (16)");
   if ((int)cfg->feature_para[3] * 2 > 2048) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para4 (gftt_num) must be <= 1024");
   if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "image too large for the GFTT LDS bitmap");
+  if (cfg->cam_type == CAM_DEPTH && !(cfg->depth_factor > 0)) return ctx->fail(FLVIS_ERR_CONFIG, "depth mode needs depth_factor > 0");
   hipSetDevice(ctx->device);
   Pipeline* pl = new Pipeline();
   ctx->pipe = pl;
@@ -238,6 +239,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   pose7_from_mat44(cfg->T_imu_cam0, c.T_c_i, true);
   c.iir_ratio = (float)cfg->dr_para[0];
   c.range = (float)cfg->dr_para[1];
+  c.depth_scale = cfg->depth_factor;
   c.enable_dummy = !(cfg->dr_para[2] < 0.5);
   c.need_equal_hist = cfg->need_equal_hist;
   c.skip_first_n = cfg->skip_first_n_imgs;
@@ -546,12 +548,15 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   hipStream_t ds = pl->det_stream;
   hipEventRecord(pl->ev_img, st);
   hipStreamWaitEvent(ds, pl->ev_img, 0);
-  if (pl->cfg.need_equal_hist) {
+  const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
+  p.depth_img = depth_cam ? reinterpret_cast<const uint16_t*>(d_img1) : nullptr;
+  if (depth_cam) {
+  } else if (pl->cfg.need_equal_hist) {
     launch_equalize_hist(ds, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
   } else {
     launch_copy_image(ds, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
   }
-  for (int l = 1; l <= pl->levels; l++)
+  for (int l = 1; l <= pl->levels && !depth_cam; l++)
     launch_pyr_down(ds, img_plain(pl->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1],
                     img_plain(pl->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
   launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, pl->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
@@ -599,7 +604,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   launch_depth_prepare(st, p);
   PE(14, st);
   PB(15, st);
-  {
+  if (!depth_cam) {
     PyrSel prev, next;
     fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 0, pl->levels_s);
     fill_pyr(pl, next, pl->pyr1, nullptr, nullptr, 0, pl->levels_s);

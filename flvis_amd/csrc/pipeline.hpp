@@ -25,7 +25,7 @@ constexpr int POSE_REC = 1024;    // ring behind F2FTracking::pose_records (the 
 
 enum { ST_UNINIT = 0, ST_TRACKING = 1, ST_TRACKFAIL = 2 };
 enum { PH_IDLE = 0, PH_TRACK = 1, PH_INIT = 2 };
-enum { CAM_STEREO_RECT = 0, CAM_STEREO_UNRECT = 1 };
+enum { CAM_STEREO_RECT = 0, CAM_STEREO_UNRECT = 1, CAM_DEPTH = 2 };  // enum TYPEOFCAMERA (depth_camera.h:6-9)
 
 // LandMarkInFrame (src/processing/include/landmark.h:8-35), AoS so that a frame-to-frame copy is one record move
 struct Landmark {
@@ -51,6 +51,7 @@ struct CamParams {
   double T_c1_c0[7];  // pose7
   double T_i_c[7], T_c_i[7];
   float iir_ratio, range;
+  double depth_scale;  // DEPTH_D435: cam_scale_factor (Z16 units per metre)
   int enable_dummy, need_equal_hist, skip_first_n;
   double vi_para[4];
   DemParams dem;

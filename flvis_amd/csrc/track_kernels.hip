@@ -264,7 +264,13 @@ __global__ __launch_bounds__(256) void k_track_prepare(Pipe p) {
   if (st.use_guess) {
     SE3d g = load_pose7(st.guess);
     float p3[3] = {(float)lm.p3w[0], (float)lm.p3w[1], (float)lm.p3w[2]};
-    project_point(p3, q_to_mat(g.q), g.t, p.cam.K0, p.cam.D0, np);
+    if (p.cam.cam_type == CAM_DEPTH) {  // lkorb_tracking.cpp:41-52: pinhole projection of the float-narrowed landmark
+      const V3 pc = se3_act(g, V3{(double)p3[0], (double)p3[1], (double)p3[2]});
+      np[0] = (float)(p.cam.fx * pc.x / pc.z + p.cam.cx);
+      np[1] = (float)(p.cam.fy * pc.y / pc.z + p.cam.cy);
+    } else {
+      project_point(p3, q_to_mat(g.q), g.t, p.cam.K0, p.cam.D0, np);
+    }
   } else {
     np[0] = px;
     np[1] = py;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
       float tx = tr[2 * i], ty = tr[2 * i + 1];
       float und[2] = {tx, ty};
       float fu[2];
-      if (p.cam.cam_type == CAM_STEREO_RECT) {
+      if (p.cam.cam_type != CAM_STEREO_UNRECT) {  // STEREO_RECT and DEPTH_D435 (lkorb_tracking.cpp:76-85)
         fu[0] = (float)lm.p2d[0];  // from_p2d_undistort = from_p2d_plane
         fu[1] = (float)lm.p2d[1];
       } else {
@@ -1081,7 +1087,9 @@ __global__ __launch_bounds__(64) void k_add_new(Pipe p) {
   for (int k = lane; k < nn; k += 64) {
     float src[2] = {xy[2 * k], xy[2 * k + 1]};
     float und[2] = {src[0], src[1]};
-    if (mode == 1 || p.cam.cam_type == CAM_STEREO_UNRECT) undistort_point(src, p.cam.K0, p.cam.D0, p.cam.R0, p.cam.P0, und);
+    // init_frame undistorts in both stereo modes, redetect only in STEREO_UNRECT, DEPTH_D435 never (f2f_tracking.cpp:294-304,410-437)
+    if ((mode == 1 && p.cam.cam_type != CAM_DEPTH) || p.cam.cam_type == CAM_STEREO_UNRECT)
+      undistort_point(src, p.cam.K0, p.cam.D0, p.cam.R0, p.cam.P0, und);
     Landmark lm;
     lm.id = st.lm_id_counter + k;
     lm.p3w[0] = lm.p3w[1] = lm.p3w[2] = 0;
@@ -1136,6 +1144,7 @@ __global__ __launch_bounds__(256) void k_depth_prepare(Pipe p) {
     }
   }
   p.tri_mask[(size_t)s * NMAX + i] = tm;
+  if (p.cam.cam_type == CAM_DEPTH) return;  // the measurement comes from the depth image, no stereo matching
   // stereo LK seeds (camera_frame.cpp:108-122)
   float* p0 = p.prev_pts + ((size_t)s * NMAX + i) * 2;
   float* p1 = p.next_pts + ((size_t)s * NMAX + i) * 2;
@@ -1173,9 +1182,24 @@ __global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
   Landmark lm;
   bool ok = false;
   V3 meas{0, 0, 0};
+  const bool depth_cam = p.cam.cam_type == CAM_DEPTH;
+  float ptx = 0.f, pty = 0.f;
   if (valid) {
     lm = lms[i];
-    if (status[i] == 1) {
+    if (depth_cam) {
+      // recover3DPts_c_FromDepthImg (camera_frame.cpp:182-234): nearest depth pixel (round half away from zero), metres =
+      // Z16 / cam_scale_factor narrowed to float, valid in [0.3, range]
+      ptx = (float)round(lm.p2d[0]);
+      pty = (float)round(lm.p2d[1]);
+      // (landmarks live in the open box (0, W-1) x (0, H-1), lkorb_tracking.cpp:95-102; the clamp only guards the read)
+      const int ix = min(max(__float2int_rn(ptx), 0), p.cam.w - 1), iy = min(max(__float2int_rn(pty), 0), p.cam.h - 1);
+      const uint16_t d16 = p.depth_img[(size_t)s * p.cam.w * p.cam.h + (size_t)iy * p.cam.w + ix];
+      const float z = (float)((double)d16 / p.cam.depth_scale);
+      if ((double)z >= 0.3 && z <= p.cam.range) {
+        meas = V3{((double)ptx - p.cam.cx) * (double)z / p.cam.fx, ((double)pty - p.cam.cy) * (double)z / p.cam.fy, (double)z};
+        ok = true;
+      }
+    } else if (status[i] == 1) {
       float src[2] = {p1[2 * i], p1[2 * i + 1]}, u1[2];
       undistort_point(src, p.cam.K1, p.cam.D1, p.cam.R1, p.cam.P1, u1);
       float u0x = (float)lm.p2u[0], u0y = (float)lm.p2u[1];
@@ -1199,11 +1223,15 @@ __global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
     const bool tm = p.tri_mask[(size_t)s * NMAX + i] != 0;
     if (!ok) {
       double depth = (double)rnd[frank];
-      float u0x = (float)lm.p2u[0], u0y = (float)lm.p2u[1];
-      meas = V3{((double)u0x - p.cam.cx) * depth / p.cam.fx, ((double)u0y - p.cam.cy) * depth / p.cam.fy, depth};
+      if (depth_cam) {  // pixel2camera(lm_2d_plane, ..., d_rand): the double plane position (camera_frame.cpp:200-207)
+        meas = V3{(lm.p2d[0] - p.cam.cx) * depth / p.cam.fx, (lm.p2d[1] - p.cam.cy) * depth / p.cam.fy, depth};
+      } else {
+        float u0x = (float)lm.p2u[0], u0y = (float)lm.p2u[1];
+        meas = V3{((double)u0x - p.cam.cx) * depth / p.cam.fx, ((double)u0y - p.cam.cy) * depth / p.cam.fy, depth};
+      }
     }
     if (!ok && !tm) {
-      if (!lm.has3d && p.cam.enable_dummy) {
+      if (!depth_cam && !lm.has3d && p.cam.enable_dummy) {  // camera_frame.cpp:288-301: stereo types only
         V3 pw = se3_act(Tinv, meas);
         lm.p3c[0] = meas.x; lm.p3c[1] = meas.y; lm.p3c[2] = meas.z;
         lm.p3w[0] = pw.x; lm.p3w[1] = pw.y; lm.p3w[2] = pw.z;

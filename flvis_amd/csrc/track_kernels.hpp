@@ -53,6 +53,7 @@ struct Pipe {
   // local-map feedback (F2FTracking::correction_feed, dead in the reference's v2)
   int* rec_id;              // [S][POSE_REC]  ID_POSE::frame_id (an int in the reference)
   double* rec_T;            // [S][POSE_REC][7]
+  const uint16_t* depth_img;  // [S][h][w] Z16 depth image of the current frame (DEPTH_D435 only), set per image_feed
   CorrectionDev* corr_in;   // [S] correction waiting for the stream's next Tracking frame (valid flag), or nullptr
 };
 

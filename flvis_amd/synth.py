@@ -62,6 +62,39 @@ output_sparse_map: False
 window_size:       8
 """
 
+# depth-camera mode (type_of_vi 0, the key set of launch/d435i/sn943222072828_depth.yaml: cam0 only + depth_factor): the
+# depth image is aligned to cam0, Z16 in millimetres
+D435I_DEPTH_YAML = """type_of_vi: 0
+image_width: 640
+image_height: 480
+cam0_intrinsics: [384.16455078125, 384.16455078125, 320.2144470214844, 238.94403076171875]
+cam0_distortion_coeffs: [0.0, 0.0, 0.0, 0.0]
+depth_factor: 1000.0
+T_imu_cam0:
+[ 0.0,  0.0,  1.0,  0.0,
+ -1.0,  0.0,  0.0,  0.0,
+  0.0, -1.0,  0.0,  0.0,
+  0.0,  0.0,  0.0,  1.0]
+is_lite_version:   True
+vifusion_para1: 0.1
+vifusion_para2: 0.01
+vifusion_para3: 0.001
+vifusion_para4: 0.001
+vifusion_para5: 0.1
+vifusion_para6: 0.1
+feature_para1: 15
+feature_para2: 30
+feature_para3: 5
+feature_para4: 500
+feature_para5: 0.001
+feature_para6: 5
+dr_para1: 0.9
+dr_para2: 8
+dr_para3: 1.0
+output_sparse_map: False
+window_size:       8
+"""
+
 
 # EuRoC-MAV-like rig (type_of_vi 1: unrectified stereo with radial-tangential distortion, 752x480, equalizeHist): the
 # public sensor calibration of the EuRoC VI sensor (cam0/cam1 sensor.yaml of the dataset) in FLVIS's parameter names.
@@ -286,8 +319,9 @@ class Renderer:
         self.rays_c = self.rays[0]  # [H,W,3]
         self.noise_sigma = noise_sigma
 
-    def render(self, R_w_c, c_w, seed=None, cam=0):
-        """R_w_c [S,3,3], c_w [S,3] (float64 tensors on device) -> uint8 [S,H,W] as seen by camera `cam` of the rig."""
+    def render(self, R_w_c, c_w, seed=None, cam=0, want_depth=False):
+        """R_w_c [S,3,3], c_w [S,3] (float64 tensors on device) -> uint8 [S,H,W] as seen by camera `cam` of the rig
+        (and, with want_depth, the z-depth [S,H,W] in metres: the rays have unit z, so the ray parameter IS the depth)."""
         S = R_w_c.shape[0]
         H, W = self.rig.height, self.rig.width
         d = torch.einsum("sij,hwj->shwi", R_w_c, self.rays[cam])  # [S,H,W,3]
@@ -319,7 +353,25 @@ class Renderer:
             g = torch.Generator(device=self.dev)
             g.manual_seed(0x5EED0000 + (seed or 0))
             val = val + self.noise_sigma * torch.randn(val.shape, generator=g, device=self.dev, dtype=torch.float32)
-        return val.round().clamp(0, 255).to(torch.uint8)
+        img = val.round().clamp(0, 255).to(torch.uint8)
+        return (img, best) if want_depth else img
+
+    def depth_frame(self, trajs, t, frame_idx=0, depth_factor=1000.0, max_range=None):
+        """img0 uint8 [S,H,W] and the aligned Z16 depth image [S,H,W] (int16 storage, read as uint16) (depth * depth_factor, rounded; 0 beyond
+        max_range, like a depth sensor's no-return value) -- the input pair of the depth-camera modes."""
+        g = self.rig
+        R0, c0 = [], []
+        for tr in trajs:
+            R_w_i = tr.R_w_i(t)
+            R0.append(R_w_i @ g.R_i_c)
+            c0.append(tr.pos(t) + R_w_i @ g.t_i_c)
+        i0, z = self.render(torch.from_numpy(np.stack(R0)).to(self.dev), torch.from_numpy(np.stack(c0)).to(self.dev),
+                            seed=2 * frame_idx, cam=0, want_depth=True)
+        if max_range is not None:
+            z = torch.where(z <= max_range, z, torch.zeros_like(z))
+        # torch has few uint16 kernels: int16 storage with the same bit pattern (values < 32768, i.e. < 32 m at 1 mm units)
+        d16 = (z * depth_factor).round().clamp(0, 32767).to(torch.int16)
+        return i0, d16
 
     def stereo_frame(self, trajs, t, frame_idx=0):
         """Renders img0, img1 ([S,H,W] uint8 each) for all trajectories at time t."""

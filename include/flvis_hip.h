@@ -140,7 +140,8 @@ int flvis_hip_orb_match(flvis_ctx* ctx, const uint8_t* d_a, const int* d_na, int
  *   flvis_ba_push_keyframe   <- LocalMapNodeletClass::frame_callback alone      src/backend/vo_localmap.cpp:87-380
  */
 typedef struct flvis_cfg {
-  int type_of_vi;                 /* 1 EuRoC (stereo unrectified + IMU), 3 D435i stereo, 5 D435 stereo + pixhawk */
+  int type_of_vi;                 /* 1 EuRoC (stereo unrectified + IMU), 3 D435i stereo, 5 D435 stereo + pixhawk,
+                                     0 D435i depth, 2 D435 depth + pixhawk (the second image is the Z16 depth image) */
   int image_width, image_height;
   double cam0_intrinsics[4], cam0_distortion[4], cam1_intrinsics[4], cam1_distortion[4];
   double T_imu_cam0[16];          /* row-major 4x4 (EuRoC: T_imu_mavimu * T_mavimu_cam0) */
@@ -150,6 +151,7 @@ typedef struct flvis_cfg {
   /* derived by flvis_config_finalize (cv::stereoRectify restated, CALIB_ZERO_DISPARITY, alpha 0) */
   int cam_type, imu_type, skip_first_n_imgs, need_equal_hist;
   double R0[9], R1[9], P0[12], P1[12];
+  double depth_factor;            /* depth modes: Z16 units per metre (yaml key depth_factor, vo_tracking.cpp:153) */
 } flvis_cfg;
 
 typedef struct flvis_frame_out {

@@ -172,8 +172,21 @@ bool config_finalize(Config& c) {
       c.skip_first_n_imgs = 50;
       c.need_equal_hist = 0;
       break;
+    case 0:
+    case 2: {  // vo_tracking.cpp:142-170: DEPTH_D435, pinhole K from cam0_intrinsics, no distortion, 50 skipped frames
+      c.cam_type = DEPTH_D435;
+      c.has_imu_type = 1;
+      c.skip_first_n_imgs = 50;
+      c.need_equal_hist = 0;
+      const double P[12] = {c.cam0_intrinsics[0], 0, c.cam0_intrinsics[2], 0, 0, c.cam0_intrinsics[1], c.cam0_intrinsics[3], 0,
+                            0, 0, 1, 0};
+      memcpy(c.P0, P, sizeof(P));
+      memset(c.P1, 0, sizeof(c.P1));
+      for (int i = 0; i < 9; i++) c.R0[i] = c.R1[i] = (i % 4 == 0) ? 1.0 : 0.0;
+      return true;
+    }
     default:
-      return false;  // depth modes / KITTI are "next" rows
+      return false;  // KITTI (no IMU) is not part of this path
   }
   SE3 T_c0_c1 = se3_from_mat44(c.T_cam0_cam1);
   SE3 T_c1_c0 = se3_inverse(T_c0_c1);
@@ -265,10 +278,17 @@ bool config_load_yaml(const char* path, Config& c, char* err, int errlen) {
   c.image_width = (int)v;
   if (!need("image_height", 1, &v)) return false;
   c.image_height = (int)v;
-  if (!need("cam0_intrinsics", 4, c.cam0_intrinsics) || !need("cam0_distortion_coeffs", 4, c.cam0_distortion) ||
-      !need("cam1_intrinsics", 4, c.cam1_intrinsics) || !need("cam1_distortion_coeffs", 4, c.cam1_distortion))
+  const bool depth_mode = c.type_of_vi == 0 || c.type_of_vi == 2;
+  if (!need("cam0_intrinsics", 4, c.cam0_intrinsics) || !need("cam0_distortion_coeffs", 4, c.cam0_distortion)) return false;
+  if (depth_mode) {  // vo_tracking.cpp:149-154 reads only these
+    if (!need("depth_factor", 1, &c.depth_factor) || !need("T_imu_cam0", 16, c.T_imu_cam0)) return false;
+    double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(c.T_cam0_cam1, eye, sizeof(eye));
+  } else if (!need("cam1_intrinsics", 4, c.cam1_intrinsics) || !need("cam1_distortion_coeffs", 4, c.cam1_distortion)) {
     return false;
-  if (c.type_of_vi == 1) {  // EuRoC: vo_tracking.cpp:218-236
+  }
+  if (depth_mode) {
+  } else if (c.type_of_vi == 1) {  // EuRoC: vo_tracking.cpp:218-236
     double a[16], b[16], m[16];
     if (!need("T_mavimu_cam0", 16, a) || !need("T_mavimu_cam1", 16, b) || !need("T_imu_mavimu", 16, m)) return false;
     SE3 T_mavi_c0 = se3_from_mat44(a), T_mavi_c1 = se3_from_mat44(b), T_i_mavi = se3_from_mat44(m);
@@ -536,6 +556,7 @@ F2FTracking::F2FTracking(const Config& cfg_in, uint64_t seed) : cfg(cfg_in) {
   d_camera.cam0_cy = cfg.P0[6];
   d_camera.T_cam0_cam1 = se3_from_mat44(cfg.T_cam0_cam1);
   d_camera.T_cam1_cam0 = se3_inverse(d_camera.T_cam0_cam1);
+  d_camera.cam_scale_factor = cfg.depth_factor;
   feature_dem = new FeatureDEM(cfg.image_width, cfg.image_height, cfg.feature_para);
   // f2f_tracking.cpp:18-19: only vifusion_para1..4 are forwarded (quirk A19)
   vimotion = new VIMOTION(se3_from_mat44(cfg.T_imu_cam0), 9.81, cfg.vifusion_para[0], cfg.vifusion_para[1],
@@ -610,54 +631,77 @@ void F2FTracking::depthInnovation(CameraFrame& f) {  // camera_frame.cpp:93-180,
       }
     }
   }
-  // recover3DPts_c_FromStereo
-  std::vector<float> p0(2 * n), p1(2 * n), p0u(2 * n), p3(3 * n), proj(2 * n), p1u(2 * n);
-  std::vector<uint8_t> status(n);
-  for (size_t i = 0; i < n; i++) {
-    const LandMarkInFrame& lm = f.landmarks[i];
-    p0[2 * i] = (float)lm.lm_2d_plane.x;
-    p0[2 * i + 1] = (float)lm.lm_2d_plane.y;
-    p0u[2 * i] = (float)lm.lm_2d_undistort.x;
-    p0u[2 * i + 1] = (float)lm.lm_2d_undistort.y;
-    p3[3 * i] = (float)lm.lm_3d_w.x;
-    p3[3 * i + 1] = (float)lm.lm_3d_w.y;
-    p3[3 * i + 2] = (float)lm.lm_3d_w.z;
-  }
-  p1 = p0;
-  if (n) {
-    project_points(p3.data(), (int)n, se3_mul(d_camera.T_cam1_cam0, f.T_c_w), d_camera.K1, d_camera.D1, proj.data());
-    for (size_t i = 0; i < n; i++)
-      if (f.landmarks[i].has_3d) {
-        p1[2 * i] = proj[2 * i];
-        p1[2 * i + 1] = proj[2 * i + 1];
-      }
-    calc_optical_flow_pyr_lk(f.img0.data(), f.img1.data(), d_camera.img_w, d_camera.img_h, p0.data(), p1.data(),
-                             status.data(), (int)n, 31, 5, 30, 0.001, 1, 1e-4f);
-    undistort_points(p1.data(), (int)n, d_camera.K1, d_camera.D1, d_camera.R1, d_camera.P1_, p1u.data());
-  }
-  for (size_t i = 0; i < n; i++) {
-    bool ok = false;
-    if (status[i] == 1) {
-      Vec3 pc = triangulate_dlt({(double)p0u[2 * i], (double)p0u[2 * i + 1]}, {(double)p1u[2 * i], (double)p1u[2 * i + 1]},
-                                d_camera.P0_, d_camera.P1_);
-      if (!(pc.z < 0 || pc.z > range)) {  // quirk A13
-        meas[i] = pc;
+  if (d_camera.cam_type == DEPTH_D435) {
+    // recover3DPts_c_FromDepthImg (camera_frame.cpp:182-234): nearest depth pixel (round half away from zero), metres =
+    // Z16 / cam_scale_factor, valid in [0.3, range]; otherwise a rand()-drawn dummy depth through the PLANE position
+    for (size_t i = 0; i < n; i++) {
+      const LandMarkInFrame& lm = f.landmarks[i];
+      const float ptx = (float)std::round(lm.lm_2d_plane.x), pty = (float)std::round(lm.lm_2d_plane.y);
+      const int ix = (int)std::lrint(ptx), iy = (int)std::lrint(pty);  // Mat::at<ushort>(Point2f) -> Point(cvRound)
+      bool ok = false;
+      const float z = (float)(f.d_img[(size_t)iy * d_camera.img_w + ix] / d_camera.cam_scale_factor);
+      if (z >= 0.3 && z <= range) {
+        meas[i] = {((double)ptx - d_camera.cam0_cx) * (double)z / d_camera.cam0_fx,
+                   ((double)pty - d_camera.cam0_cy) * (double)z / d_camera.cam0_fy, (double)z};
         ok = true;
+      } else {
+        float d_rand = (float)(0.3 + (float)rnd.next() / ((float)(2147483647 / (0.4))));
+        double depth = d_rand;
+        meas[i] = {(lm.lm_2d_plane.x - d_camera.cam0_cx) * depth / d_camera.cam0_fx,
+                   (lm.lm_2d_plane.y - d_camera.cam0_cy) * depth / d_camera.cam0_fy, depth};
       }
+      meas_mask[i] = ok;
     }
-    if (!ok) {  // quirk A11: rand()-drawn dummy depth
-      float d_rand = (float)(0.3 + (float)rnd.next() / ((float)(2147483647 / (0.4))));
-      double depth = d_rand;
-      meas[i] = {((double)p0u[2 * i] - d_camera.cam0_cx) * depth / d_camera.cam0_fx,
-                 ((double)p0u[2 * i + 1] - d_camera.cam0_cy) * depth / d_camera.cam0_fy, depth};
+  } else {
+    // recover3DPts_c_FromStereo
+    std::vector<float> p0(2 * n), p1(2 * n), p0u(2 * n), p3(3 * n), proj(2 * n), p1u(2 * n);
+    std::vector<uint8_t> status(n);
+    for (size_t i = 0; i < n; i++) {
+      const LandMarkInFrame& lm = f.landmarks[i];
+      p0[2 * i] = (float)lm.lm_2d_plane.x;
+      p0[2 * i + 1] = (float)lm.lm_2d_plane.y;
+      p0u[2 * i] = (float)lm.lm_2d_undistort.x;
+      p0u[2 * i + 1] = (float)lm.lm_2d_undistort.y;
+      p3[3 * i] = (float)lm.lm_3d_w.x;
+      p3[3 * i + 1] = (float)lm.lm_3d_w.y;
+      p3[3 * i + 2] = (float)lm.lm_3d_w.z;
     }
-    meas_mask[i] = ok;
+    p1 = p0;
+    if (n) {
+      project_points(p3.data(), (int)n, se3_mul(d_camera.T_cam1_cam0, f.T_c_w), d_camera.K1, d_camera.D1, proj.data());
+      for (size_t i = 0; i < n; i++)
+        if (f.landmarks[i].has_3d) {
+          p1[2 * i] = proj[2 * i];
+          p1[2 * i + 1] = proj[2 * i + 1];
+        }
+      calc_optical_flow_pyr_lk(f.img0.data(), f.img1.data(), d_camera.img_w, d_camera.img_h, p0.data(), p1.data(),
+                               status.data(), (int)n, 31, 5, 30, 0.001, 1, 1e-4f);
+      undistort_points(p1.data(), (int)n, d_camera.K1, d_camera.D1, d_camera.R1, d_camera.P1_, p1u.data());
+    }
+    for (size_t i = 0; i < n; i++) {
+      bool ok = false;
+      if (status[i] == 1) {
+        Vec3 pc = triangulate_dlt({(double)p0u[2 * i], (double)p0u[2 * i + 1]}, {(double)p1u[2 * i], (double)p1u[2 * i + 1]},
+                                  d_camera.P0_, d_camera.P1_);
+        if (!(pc.z < 0 || pc.z > range)) {  // quirk A13
+          meas[i] = pc;
+          ok = true;
+        }
+      }
+      if (!ok) {  // quirk A11: rand()-drawn dummy depth
+        float d_rand = (float)(0.3 + (float)rnd.next() / ((float)(2147483647 / (0.4))));
+        double depth = d_rand;
+        meas[i] = {((double)p0u[2 * i] - d_camera.cam0_cx) * depth / d_camera.cam0_fx,
+                   ((double)p0u[2 * i + 1] - d_camera.cam0_cy) * depth / d_camera.cam0_fy, depth};
+      }
+      meas_mask[i] = ok;
+    }
   }
   for (size_t i = 0; i < n; i++) {
     LandMarkInFrame& lm = f.landmarks[i];
     Vec3 lm_c_measure;
     if (!meas_mask[i] && !tri_mask[i]) {
-      if (!lm.has_3d && enable_dummy) {
+      if (d_camera.cam_type != DEPTH_D435 && !lm.has_3d && enable_dummy) {  // camera_frame.cpp:288-301: stereo types only
         lm_c_measure = meas[i];
         lm.lm_3d_c = lm_c_measure;
         lm.lm_3d_w = camera2worldT_c_w(lm_c_measure, f.T_c_w);
@@ -694,7 +738,8 @@ bool F2FTracking::init_frame() {
     src[2 * i] = pts2d[i].x;
     src[2 * i + 1] = pts2d[i].y;
   }
-  if (!pts2d.empty())  // undistortPoints in both stereo modes (f2f_tracking.cpp:422-437)
+  und = src;  // DEPTH_D435: the undistorted position is the pixel position (f2f_tracking.cpp:410-421)
+  if (!pts2d.empty() && d_camera.cam_type != DEPTH_D435)  // undistortPoints in both stereo modes (f2f_tracking.cpp:422-437)
     undistort_points(src.data(), (int)pts2d.size(), d_camera.K0, d_camera.D0, d_camera.R0, d_camera.P0_, und.data());
   for (size_t i = 0; i < pts2d.size(); i++)
     curr_frame->landmarks.push_back(make_landmark({(double)pts2d[i].x, (double)pts2d[i].y},
@@ -710,6 +755,8 @@ bool F2FTracking::init_frame() {
   }
   return false;
 }
+
+static inline Vec3 world2cameraT_c_w_(Vec3 p, const SE3& T) { return se3_act(T, p); }
 
 bool F2FTracking::lk_tracking(CameraFrame& from, CameraFrame& to, const SE3& guess, bool use_guess) {
   const int n = (int)from.landmarks.size();
@@ -727,11 +774,21 @@ bool F2FTracking::lk_tracking(CameraFrame& from, CameraFrame& to, const SE3& gue
   tracked = from_plane;
   std::vector<uint8_t> mask_tracked(n);
   if (n) {
-    if (use_guess) project_points(from_p3d.data(), n, guess, d_camera.K0, d_camera.D0, tracked.data());
+    if (use_guess) {
+      if (d_camera.cam_type == DEPTH_D435) {  // lkorb_tracking.cpp:41-52: pinhole projection of the float-narrowed landmark
+        for (int i = 0; i < n; i++) {
+          Vec3 pc = world2cameraT_c_w_({(double)from_p3d[3 * i], (double)from_p3d[3 * i + 1], (double)from_p3d[3 * i + 2]}, guess);
+          tracked[2 * i] = (float)(d_camera.cam0_fx * pc.x / pc.z + d_camera.cam0_cx);
+          tracked[2 * i + 1] = (float)(d_camera.cam0_fy * pc.y / pc.z + d_camera.cam0_cy);
+        }
+      } else {
+        project_points(from_p3d.data(), n, guess, d_camera.K0, d_camera.D0, tracked.data());
+      }
+    }
     calc_optical_flow_pyr_lk(from.img0.data(), to.img0.data(), d_camera.img_w, d_camera.img_h, from_plane.data(),
                              tracked.data(), mask_tracked.data(), n, 31, 10, 30, 0.001, 1, 1e-4f);
   }
-  if (d_camera.cam_type == STEREO_RECT) {
+  if (d_camera.cam_type == STEREO_RECT || d_camera.cam_type == DEPTH_D435) {  // lkorb_tracking.cpp:76-85
     from_und = from_plane;
     tracked_und = tracked;
   } else if (n) {
@@ -809,14 +866,20 @@ void F2FTracking::image_feed(double time, const uint8_t* img0_in, const uint8_t*
   curr_frame->frame_time = time;
   const size_t npx = (size_t)cfg.image_width * cfg.image_height;
   curr_frame->img0.assign(img0_in, img0_in + npx);
-  curr_frame->img1.assign(img1_in, img1_in + npx);
+  if (d_camera.cam_type == DEPTH_D435) {  // f2f_tracking.cpp:116-119: the second image is the Z16 depth image
+    const uint16_t* d = reinterpret_cast<const uint16_t*>(img1_in);
+    curr_frame->d_img.assign(d, d + npx);
+  } else {
+    curr_frame->img1.assign(img1_in, img1_in + npx);
+  }
   if (skip_n_imgs > 0) {
     skip_n_imgs--;
     return;
   }
   if (need_equal_hist) {
     equalize_hist(curr_frame->img0.data(), curr_frame->img0.data(), cfg.image_width, cfg.image_height);
-    equalize_hist(curr_frame->img1.data(), curr_frame->img1.data(), cfg.image_width, cfg.image_height);
+    if (d_camera.cam_type != DEPTH_D435)
+      equalize_hist(curr_frame->img1.data(), curr_frame->img1.data(), cfg.image_width, cfg.image_height);
   }
   switch (vo_tracking_state) {
     case UnInit: {

@@ -22,6 +22,7 @@ struct Config {
   // derived
   int cam_type, has_imu_type, skip_first_n_imgs, need_equal_hist;
   double R0[9], R1[9], P0[12], P1[12];
+  double depth_factor;  // depth modes (type_of_vi 0, 2): Z16 units per metre (vo_tracking.cpp:153)
 };
 // fills cam_type/skip/equalize flags and R0,R1,P0,P1 (cv::stereoRectify restated).  false on unsupported type_of_vi.
 bool config_finalize(Config& c);
@@ -36,6 +37,7 @@ struct DepthCamera {  // src/processing/include/depth_camera.h
   Mat3 R0, R1;
   double P0_[12], P1_[12];
   SE3 T_cam0_cam1, T_cam1_cam0;
+  double cam_scale_factor;  // depth_camera.cpp:23
 };
 
 struct LandMarkInFrame {  // src/processing/include/landmark.h
@@ -52,6 +54,7 @@ struct CameraFrame {  // src/processing/include/camera_frame.h
   int64_t frame_id = 0;
   double frame_time = 0;
   std::vector<uint8_t> img0, img1;
+  std::vector<uint16_t> d_img;  // DEPTH_D435: CV_16UC1 aligned to cam0 (f2f_tracking.cpp:116-119)
   std::vector<LandMarkInFrame> landmarks;
   SE3 T_c_w = se3_identity();
   double reprojection_error = 0;

@@ -248,7 +248,8 @@ class RefConfig(C.Structure):
                 ("window_size", C.c_int),
                 ("cam_type", C.c_int), ("has_imu_type", C.c_int), ("skip_first_n_imgs", C.c_int),
                 ("need_equal_hist", C.c_int),
-                ("R0", C.c_double * 9), ("R1", C.c_double * 9), ("P0", C.c_double * 12), ("P1", C.c_double * 12)]
+                ("R0", C.c_double * 9), ("R1", C.c_double * 9), ("P0", C.c_double * 12), ("P1", C.c_double * 12),
+                ("depth_factor", C.c_double)]
 
 
 def load_config(path):
@@ -283,12 +284,13 @@ class Tracker:
 
     def image(self, t, img0, img1):
         img0 = np.ascontiguousarray(img0, np.uint8)
-        img1 = np.ascontiguousarray(img1, np.uint8)
+        # depth modes: the second image is the Z16 depth image (uint16), passed through the same pointer
+        img1 = np.ascontiguousarray(img1) if img1.dtype == np.uint16 else np.ascontiguousarray(img1, np.uint8)
         st = C.c_int(0)
         pose = np.zeros(7)
         n = C.c_int(0)
         dbg = np.zeros(3, np.int32)
-        fl = lib().ref_tracker_image(self.h, C.c_double(t), _p(img0, C.c_uint8), _p(img1, C.c_uint8), C.byref(st),
+        fl = lib().ref_tracker_image(self.h, C.c_double(t), _p(img0, C.c_uint8), C.cast(img1.ctypes.data, C.POINTER(C.c_uint8)), C.byref(st),
                                      _p(pose, C.c_double), C.byref(n), _p(dbg, C.c_int32))
         return dict(new_keyframe=bool(fl & 1), reset_cmd=bool(fl & 2), state=st.value, pose7=pose, n_landmarks=n.value,
                     dbg=dbg)

@@ -32,8 +32,11 @@ def check_cfg_against_dump(cfg, d, who):
     """raw (pre-finalize) fields of flvis_cfg against the yaml-cpp values; exact unless a product of 4x4 matrices is involved"""
     assert cfg.type_of_vi == int(d["type_of_vi"][0]), who
     assert cfg.image_width == int(d["image_width"][0]) and cfg.image_height == int(d["image_height"][0]), who
-    for k, name in (("cam0_intrinsics", "cam0_intrinsics"), ("cam0_distortion", "cam0_distortion_coeffs"),
-                    ("cam1_intrinsics", "cam1_intrinsics"), ("cam1_distortion", "cam1_distortion_coeffs")):
+    depth_mode = cfg.type_of_vi in (0, 2)   # vo_tracking.cpp:149-154 reads cam0, depth_factor and T_imu_cam0 only
+    keys = [("cam0_intrinsics", "cam0_intrinsics"), ("cam0_distortion", "cam0_distortion_coeffs")]
+    if not depth_mode:
+        keys += [("cam1_intrinsics", "cam1_intrinsics"), ("cam1_distortion", "cam1_distortion_coeffs")]
+    for k, name in keys:
         assert np.array_equal(np.array(list(getattr(cfg, k))), d[name]), (who, k)
     for k, n in (("vifusion_para", 6), ("feature_para", 6), ("dr_para", 3)):
         want = np.array([d["%s%d" % (k, i + 1)][0] for i in range(n)])
@@ -41,7 +44,10 @@ def check_cfg_against_dump(cfg, d, who):
     assert cfg.window_size == int(d["window_size"][0]), who
     T_i_c0 = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)
     T_c0_c1 = np.array(list(cfg.T_cam0_cam1)).reshape(4, 4)
-    if cfg.type_of_vi == 1:   # vo_tracking.cpp:228-236: T_i_c0 = T_imu_mavimu * T_mavimu_cam0, T_c0_c1 = T_mavimu_cam0^-1 * T_mavimu_cam1
+    if depth_mode:
+        assert cfg.depth_factor == d["depth_factor"][0] and cfg.cam_type == 2, who
+        assert np.array_equal(T_i_c0.reshape(-1), d["T_imu_cam0"]), who
+    elif cfg.type_of_vi == 1:   # vo_tracking.cpp:228-236: T_i_c0 = T_imu_mavimu * T_mavimu_cam0, T_c0_c1 = T_mavimu_cam0^-1 * T_mavimu_cam1
         a, b, m = d["T_mavimu_cam0"].reshape(4, 4), d["T_mavimu_cam1"].reshape(4, 4), d["T_imu_mavimu"].reshape(4, 4)
         assert np.allclose(T_i_c0, m @ a, atol=1e-12, rtol=0), who
         assert np.allclose(T_c0_c1, inv44(a) @ b, atol=1e-12, rtol=0), who
@@ -50,11 +56,11 @@ def check_cfg_against_dump(cfg, d, who):
         assert np.array_equal(T_c0_c1.reshape(-1), d["T_cam0_cam1"]), who
 
 
-@pytest.mark.parametrize("name", ["d435i_stereo", "euroc_like"])
+@pytest.mark.parametrize("name", ["d435i_stereo", "euroc_like", "d435i_depth"])
 def test_loaders_match_yaml_cpp_on_the_synthetic_rig_files(name):
     import flvis_amd
     from flvis_amd import synth
-    text = {"d435i_stereo": synth.D435I_STEREO_YAML, "euroc_like": synth.EUROC_LIKE_YAML}[name]
+    text = {"d435i_stereo": synth.D435I_STEREO_YAML, "euroc_like": synth.EUROC_LIKE_YAML, "d435i_depth": synth.D435I_DEPTH_YAML}[name]
     p = os.path.join(tempfile.gettempdir(), "flvis_yamlcpp_%s.yaml" % name)
     open(p, "w").write(text)
     d = read_dump(open(os.path.join(GOLD, "yaml_synth_%s.txt" % name)).read())
@@ -64,7 +70,9 @@ def test_loaders_match_yaml_cpp_on_the_synthetic_rig_files(name):
 
 REF = {"euroc": "/root/reference/launch/EuRoC_MAV/euroc.yaml",
        "d435i_stereo": "/root/reference/launch/d435i/sn943222072828_stereo.yaml",
-       "d435_stereo_px4": "/root/reference/launch/d435_pixhawk/sn943222072828_stereo_px4.yaml"}
+       "d435_stereo_px4": "/root/reference/launch/d435_pixhawk/sn943222072828_stereo_px4.yaml",
+       "d435i_depth": "/root/reference/launch/d435i/sn943222072828_depth.yaml",
+       "d435_depth_px4": "/root/reference/launch/d435_pixhawk/sn841512070537_depth_px4.yaml"}
 
 
 @pytest.mark.parametrize("name", sorted(REF))

@@ -46,7 +46,7 @@ def _cfgs_yaml(text, tag):
     return cfg, ocfg
 
 
-def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf):
+def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf, depth_range=None):
     import flvis_amd
     from flvis_amd import synth
     S = len(streams)
@@ -67,9 +67,13 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
             for r in smp:
                 refs[i].imu(r[0], r[1:4], r[4:7])
         t_prev = t
-        i0, i1 = rnd.stereo_frame(trajs, t, f)
+        if depth_range is None:
+            i0, i1 = rnd.stereo_frame(trajs, t, f)
+            h0, h1 = i0.cpu().numpy(), i1.cpu().numpy()
+        else:  # depth-camera mode: the second image is the Z16 depth image aligned to cam0
+            i0, i1 = rnd.depth_frame(trajs, t, f, max_range=depth_range)
+            h0, h1 = i0.cpu().numpy(), i1.cpu().numpy().view(np.uint16)
         outs = trk.image_feed(i0, i1, [t] * S, with_local_map=False)
-        h0, h1 = i0.cpu().numpy(), i1.cpu().numpy()
         for i in range(S):
             want = refs[i].image(t, h0[i], h1[i])
             got = outs[i]
@@ -144,6 +148,17 @@ def test_frontend_parity_euroc_mode(ctx):
     cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
     assert cfg.cam_type == 1 and cfg.need_equal_hist == 1 and cfg.image_width == 752
     _run_frontend_parity(ctx, cfg, ocfg, synth.euroc_rig(), [9], 45, 8, 2)
+
+
+def test_frontend_parity_depth_camera_mode(ctx):
+    """SURVEY 8f-4 (first half): DEPTH_D435 (type_of_vi 0).  Same closed-loop comparison; the depth of a landmark comes from
+    the nearest pixel of the Z16 image (camera_frame.cpp:182-234) instead of stereo LK, pixels beyond 3.3 m carry no
+    depth (0) so the rand()-dummy branch and the "no measurement at all" branch are exercised, LK guesses go through the
+    pinhole projection (lkorb_tracking.cpp:41-52), nothing is undistorted."""
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.D435I_DEPTH_YAML, "d435i_depth")
+    assert cfg.cam_type == 2 and cfg.depth_factor == 1000.0 and cfg.skip_first_n_imgs == 50
+    _run_frontend_parity(ctx, cfg, ocfg, None, [3, 77], 50 + 36, 10, 3, depth_range=3.3)
 
 
 def test_trajectory_recorder(ctx):

@@ -181,3 +181,53 @@ def test_oracle_correction_feed_semantics():
             assert np.array_equal(trk.pose_records(), before)               # nothing happens until the next frame
             fed_at = f
     assert fed_at is not None
+
+
+def test_oracle_tracks_depth_camera_stream():
+    """DEPTH_D435 mode (type_of_vi 0): the second image is the Z16 depth image aligned to cam0; depth comes from
+    the nearest depth pixel instead of stereo matching (camera_frame.cpp:182-234), no undistortion anywhere, LK guesses
+    through the pinhole model (lkorb_tracking.cpp:41-52).  Pixels beyond 3.3 m return 0 (no depth): those landmarks take
+    the rand()-dummy branch and, with no triangulation either, are dropped."""
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_track_depth.yaml")
+    open(p, "w").write(synth.D435I_DEPTH_YAML)
+    cfg = O.load_config(p)
+    assert cfg.cam_type == 2 and cfg.skip_first_n_imgs == 50 and cfg.depth_factor == 1000.0 and cfg.need_equal_hist == 0
+    assert cfg.P0[0] == cfg.cam0_intrinsics[0] and cfg.P0[2] == cfg.cam0_intrinsics[2] and cfg.P0[6] == cfg.cam0_intrinsics[3]
+    trk = O.Tracker(cfg, 7)
+    tr = synth.Trajectory(5)
+    rnd = synth.Renderer("cpu")
+    t_prev = -0.05
+    est, gt, states, kfs = [], [], [], 0
+    frame0 = None
+    for f in range(50 + 26):
+        t = f / synth.FRAME_HZ
+        for s in synth.imu_samples(tr, 5, t_prev, t):
+            trk.imu(s[0], s[1:4], s[4:7])
+        t_prev = t
+        if f >= 50 or frame0 is None:
+            i0, d16 = rnd.depth_frame([tr], t, f, max_range=3.3)
+            frame0 = (i0[0].numpy(), d16[0].numpy().view(np.uint16))
+        r = trk.image(t, frame0[0], frame0[1])
+        states.append(r["state"])
+        if f < 50:
+            assert r["state"] == 0 and r["n_landmarks"] == 0
+            continue
+        kfs += r["new_keyframe"]
+        R, tt = G.pose7_to_Rt(r["pose7"])
+        Rg, tg = tr.T_c_w(t)
+        est.append(-R.T @ tt)
+        gt.append(-Rg.T @ tg)
+        if f == 50:       # init frame: every kept landmark has its depth from the depth image, in [0.3, 3.3] m
+            lm = trk.landmarks()
+            assert len(lm["ids"]) > 40 and np.all(lm["flags"] & 1)
+            Rc, tc = G.pose7_to_Rt(r["pose7"])
+            z = (lm["p3w"] @ Rc.T + tc)[:, 2]
+            assert z.min() >= 0.3 and z.max() <= 3.3 + 1e-6
+            d = frame0[1][np.rint(lm["p2d"][:, 1]).astype(int), np.rint(lm["p2d"][:, 0]).astype(int)] / 1000.0
+            assert np.allclose(z, d.astype(np.float32), atol=1e-6)
+    assert states[50] == 1 and all(s == 1 for s in states[50:]), states[50:]
+    assert kfs >= 4
+    ate = _umeyama_ate(np.array(est), np.array(gt))
+    path = np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum()
+    assert ate < 0.05 * path + 0.01, (ate, path)
