@@ -191,7 +191,9 @@ int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps);
 
 /* One stereo frame for every stream of the batch.  d_img0/d_img1: device [n_streams][h][w] mono8; h_times: host
  * [n_streams] seconds.  h_out (host, [n_streams], may be NULL): results; when NULL nothing is copied back and the call
- * does not synchronise.  with_local_map != 0 also runs the sliding-window BA for streams that emit a keyframe. */
+ * does not synchronise.  with_local_map != 0 also runs the sliding-window BA for streams that emit a keyframe.
+ * Depth-camera rigs (type_of_vi 0 / 2): d_img1 is the Z16 depth image aligned to cam0, [n_streams][h][w] uint16
+ * (F2FTracking::image_feed(time, img0, d_img, ...), src/frontend/vo_tracking.cpp:453, f2f_tracking.cpp:116-119). */
 int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
                      flvis_frame_out* h_out, int with_local_map);
 
