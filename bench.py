@@ -217,7 +217,7 @@ def main():
         total_frames = world * S * K
         value = total_frames / elapsed
         # dominant kernel ON THE CRITICAL PATH: k_lk_track (two launches per step: temporal + stereo).  The kernel with the
-        # largest total time is k_ba_solve, but it runs beside the front-end on the local-map streams and is latency-bound
+        # largest total time is k_ba_worker, but it runs beside the front-end on the local-map streams and is latency-bound
         # fp64 with ~64 KB of algorithmic traffic per keyframe
         lk_ms = [lk_stages["lk_track(temporal)"], lk_stages["lk_track(stereo)"]]
         dom = "k_lk_track"

@@ -7,7 +7,7 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------------ bookkeeping
-// landmark id -> bag index; the id list of the bag is staged in LDS (sid) by k_ba_update and kept in sync with appends
+// landmark id -> bag index; the id list of the bag is staged in LDS (sid) by ba_update_dev and kept in sync with appends
 FD int bag_find(const long long* sid, int n, long long id) {
   for (int i = 0; i < n; i++)
     if (sid[i] == id) return i;

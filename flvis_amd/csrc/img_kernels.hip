@@ -3,13 +3,15 @@
 //   k_hist256 / k_equalize_lut / k_lut_apply   -> cv::equalizeHist        (reference: src/frontend/f2f_tracking.cpp:141-145)
 //   k_pyr_down                                 -> cv::pyrDown levels of calcOpticalFlowPyrLK's pyramids
 //                                                 (reference: src/processing/lkorb_tracking.cpp:64-73, camera_frame.cpp:124-128)
-//   k_eig<0> (max) / k_eig<1> (threshold+NMS)  -> cornerMinEigenVal + minMaxLoc + threshold + dilate==val
+//   k_eig_cand                                 -> cornerMinEigenVal + minMaxLoc + the 3x3 local maxima in ONE pass (the
+//                                                 quality threshold is applied by k_gftt_pick, see k_eig_cand)
+//   k_bgr_to_gray / k_copy_image16             -> cv::cvtColor BGR(A)2GRAY (f2f_tracking.cpp:74-111) / plain ingest
 //   k_gftt_pick                                -> ranked min-distance selection of cv::goodFeaturesToTrack (tiered top-K)
 //                                                 (reference: src/processing/feature_dem.cpp:160,221)
 //   k_feature_dem                              -> FeatureDEM::detect / ::redetect (feature_dem.cpp:92-266, quirks kept)
 //
-// All are HBM-bound streaming passes (u8 images, O(1) flop/byte): tiles are staged in LDS with dword global loads,
-// one workgroup per (tile, stream); blockIdx.z = stream so consecutive workgroups of one stream share an XCD-local L2.
+// Streaming passes over u8 images (O(1) flop/byte): tiles are staged in LDS with dword global loads, one workgroup per
+// (tile, stream).  Measured, they are issue/latency bound rather than HBM bound (DESIGN.md sections 4, 8, 10).
 // Built with -ffp-contract=off: float arithmetic is op-for-op the oracle's (tests compare bit-exactly).
 #include "dev_common.hpp"
 #include "img_kernels.hpp"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase breakdown of k_ba_solve (needs a build with FLVIS_EXTRA_HIPCC_FLAGS=-DFLVIS_BA_PROF)."""
+"""Phase breakdown of the local-map solver (ba_solve_dev, run by k_ba_worker) (needs a build with FLVIS_EXTRA_HIPCC_FLAGS=-DFLVIS_BA_PROF)."""
 import ctypes as C
 import os
 import sys
