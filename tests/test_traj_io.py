@@ -148,3 +148,19 @@ def test_kitti_zip_reader_matches_fixture():
     R, t = traj_io.read_kitti("/root/reference/bag/KITTI/dataset/poses.zip", "poses/04.txt")
     Rf, tf = traj_io.read_kitti(GOLD_KITTI)
     assert len(R) == 271 and np.array_equal(R[:120], Rf) and np.array_equal(t[:120], tf)
+
+
+def test_reads_the_trajectories_the_reference_submitted_to_kitti():
+    """results/flvis_results/*.zip holds FLVIS's own KITTI-benchmark output (sequences 11-21, the recorder's 12-column
+    format, vo_repub_rec.cpp:100-111): the reader must take them as they are.  Skipped where the reference is absent."""
+    import glob
+    zips = glob.glob("/root/reference/results/flvis_results/*.zip")
+    if not zips:
+        pytest.skip("reference not present")
+    R, t = traj_io.read_kitti(zips[0], "17.txt")
+    assert len(R) > 400 and R.shape[1:] == (3, 3) and t.shape == (len(R), 3)
+    for k in range(0, len(R), 97):
+        assert np.allclose(R[k] @ R[k].T, np.eye(3), atol=1e-4) and abs(np.linalg.det(R[k]) - 1) < 1e-4
+    assert np.linalg.norm(t[0]) < 1.0 and np.linalg.norm(t[-1] - t[0]) > 50.0      # a drive, starting near the origin
+    step = np.linalg.norm(np.diff(t, axis=0), axis=1)
+    assert np.median(step) < 3.0                                                    # 10 Hz frames of a car
