@@ -109,15 +109,20 @@ def read_euroc_groundtruth(csv_path):
     return a[:, 0] * 1e-9, a[:, 1:4], a[:, 4:8]
 
 
-def read_euroc_image_list(csv_path):
-    """mav0/cam*/data.csv -> [(stamp_s, filename)]."""
+def read_euroc_image_list_ns(csv_path):
+    """mav0/cam*/data.csv -> [(stamp_ns (int: 19 digits do not fit a double), filename)]."""
     out = []
     for line in open(csv_path):
         if line.startswith("#") or not line.strip():
             continue
         ts, name = line.strip().split(",")[:2]
-        out.append((int(ts) * 1e-9, name.strip()))
+        out.append((int(ts), name.strip()))
     return out
+
+
+def read_euroc_image_list(csv_path):
+    """mav0/cam*/data.csv -> [(stamp_s, filename)]."""
+    return [(ns * 1e-9, name) for ns, name in read_euroc_image_list_ns(csv_path)]
 
 
 def read_euroc_imu(csv_path):
@@ -187,3 +192,66 @@ def ate_from_files(est_path, ref_path, max_dt=0.02, with_scale=False):
     tr, pr, _ = read_stamped(ref_path)
     ia, ib = associate(te, tr, max_dt)
     return ate_rmse(pe[ia], pr[ib], True, with_scale), len(ia)
+
+
+# ---------------------------------------------------------------------------------------------- EuRoC ASL sequences
+def sensor_to_flvis_imu(imu_type, acc, gyro):
+    """The axis remap of TrackingNodeletClass::imu_callback (src/frontend/vo_tracking.cpp:331-357): sensor frame -> the
+    FLVIS IMU frame.  imu_type 0 D435I, 1 EuRoC_MAV, 2 PIXHAWK.  (flvis_imu_feed applies the same remap inside the library;
+    this copy is for feeding the CPU restatement from a dataset.)"""
+    a, g = np.asarray(acc, float), np.asarray(gyro, float)
+    if imu_type == 0:
+        return np.array([-a[2], a[0], a[1]]), np.array([g[2], -g[0], -g[1]])
+    if imu_type == 1:
+        return np.array([-a[2], a[1], -a[0]]), np.array([g[2], -g[1], g[0]])
+    return np.array([-a[0], -a[1], -a[2]]), np.array([g[0], g[1], g[2]])
+
+
+def load_gray(path):
+    """8-bit grayscale image file -> uint8 [h,w] (PIL; EuRoC ships 8-bit PNGs)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("L"), dtype=np.uint8).copy()
+
+
+class EurocSequence:
+    """An EuRoC ASL sequence folder (`<seq>/mav0/{cam0,cam1,imu0,state_groundtruth_estimate0}`): stereo pairs with equal
+    stamps (what the reference's ExactTime synchroniser delivers, vo_tracking.cpp:308-319), the IMU samples between
+    consecutive pairs, the ground truth if present."""
+
+    def __init__(self, root):
+        import os
+        self.mav = os.path.join(root, "mav0") if os.path.isdir(os.path.join(root, "mav0")) else root
+        c0 = dict(read_euroc_image_list_ns(os.path.join(self.mav, "cam0", "data.csv")))
+        c1 = dict(read_euroc_image_list_ns(os.path.join(self.mav, "cam1", "data.csv")))
+        self.stamps_ns = sorted(set(c0) & set(c1))
+        self.files = [(os.path.join(self.mav, "cam0", "data", c0[k]), os.path.join(self.mav, "cam1", "data", c1[k]))
+                      for k in self.stamps_ns]
+        self.imu = read_euroc_imu(os.path.join(self.mav, "imu0", "data.csv"))     # [n,7]: t, gyro xyz, acc xyz (sensor frame)
+        gt = os.path.join(self.mav, "state_groundtruth_estimate0", "data.csv")
+        self.groundtruth = read_euroc_groundtruth(gt) if os.path.exists(gt) else None
+
+    def __len__(self):
+        return len(self.stamps_ns)
+
+    def frames(self, first=0, count=None):
+        """yields (t_seconds, img0, img1, imu_rows) where imu_rows [k,7] = (t, gyro xyz, acc xyz) with t_prev < t <= t_frame."""
+        last = len(self) if count is None else min(len(self), first + count)
+        ti = self.imu[:, 0] if len(self.imu) else np.zeros(0)
+        t_prev = -np.inf if first == 0 else self.stamps_ns[first - 1] * 1e-9
+        for k in range(first, last):
+            t = self.stamps_ns[k] * 1e-9
+            sel = (ti > t_prev) & (ti <= t)
+            yield t, load_gray(self.files[k][0]), load_gray(self.files[k][1]), self.imu[sel]
+            t_prev = t
+
+
+def camera_to_body(positions_w_c, quats_wxyz_w_c, T_imu_cam44):
+    """T_w_i = T_w_c * T_c_i for every pose (EuRoC ground truth is the body frame, the tracker reports the camera)."""
+    T_c_i = np.linalg.inv(np.asarray(T_imu_cam44, float).reshape(4, 4))
+    pos, quat = [], []
+    for p, q in zip(positions_w_c, quats_wxyz_w_c):
+        R = quat_to_rot(*q)
+        pos.append(R @ T_c_i[:3, 3] + p)
+        quat.append(rot_to_quat(R @ T_c_i[:3, :3]))
+    return np.array(pos), np.array(quat)

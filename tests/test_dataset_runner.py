@@ -1,0 +1,97 @@
+"""CPU test of the dataset path: an EuRoC ASL folder (PNG images, imu0/data.csv in the SENSOR frame, ground
+truth csv) is written from the synthetic EuRoC-like rig, read back by flvis_amd.traj_io.EurocSequence and run through
+scripts/run_sequence.py with the CPU backend (BASELINE.json configs[0], "the reference CPU path").  The run must
+reproduce, bit for bit, what the oracle gives when fed the rendered frames directly: PNG is lossless, the sensor->FLVIS IMU
+remap of vo_tracking.cpp:331-357 inverts the one used to write the csv, the stereo pairs are matched by equal stamps."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+import _oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_asl(root, frames, imu_sensor, gt_rows):
+    from PIL import Image
+    for cam in ("cam0", "cam1"):
+        os.makedirs(os.path.join(root, "mav0", cam, "data"), exist_ok=True)
+    os.makedirs(os.path.join(root, "mav0", "imu0"), exist_ok=True)
+    os.makedirs(os.path.join(root, "mav0", "state_groundtruth_estimate0"), exist_ok=True)
+    for c, cam in enumerate(("cam0", "cam1")):
+        with open(os.path.join(root, "mav0", cam, "data.csv"), "w") as f:
+            f.write("#timestamp [ns],filename\n")
+            for ns, imgs in frames:
+                f.write("%d,%d.png\n" % (ns, ns))
+                Image.fromarray(imgs[c]).save(os.path.join(root, "mav0", cam, "data", "%d.png" % ns))
+    with open(os.path.join(root, "mav0", "imu0", "data.csv"), "w") as f:
+        f.write("#timestamp [ns],w_RS_S_x [rad s^-1],w_RS_S_y [rad s^-1],w_RS_S_z [rad s^-1],a_RS_S_x [m s^-2],a_RS_S_y [m s^-2],a_RS_S_z [m s^-2]\n")
+        for r in imu_sensor:
+            f.write("%d,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n" % (r[0], r[1], r[2], r[3], r[4], r[5], r[6]))
+    with open(os.path.join(root, "mav0", "state_groundtruth_estimate0", "data.csv"), "w") as f:
+        f.write("#timestamp, p_RS_R_x [m], p_RS_R_y [m], p_RS_R_z [m], q_RS_w [], q_RS_x [], q_RS_y [], q_RS_z []\n")
+        for r in gt_rows:
+            f.write("%d,%.9f,%.9f,%.9f,1,0,0,0\n" % (r[0], r[1], r[2], r[3]))
+
+
+def test_asl_folder_roundtrip_and_cpu_backend_run():
+    from flvis_amd import synth, traj_io
+    yaml = os.path.join(tempfile.gettempdir(), "flvis_ds_euroc.yaml")
+    open(yaml, "w").write(synth.EUROC_LIKE_YAML)
+    rig = synth.euroc_rig()
+    tr = synth.Trajectory(9)
+    rnd = synth.Renderer("cpu", rig=rig)
+    t0_ns = 1403636579000000000
+    nframes = 17
+    frames, imu_sensor, gt_rows, direct_in = [], [], [], []
+    t_prev = -0.05
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        ns = t0_ns + int(round(t * 1e9))
+        i0, i1 = rnd.stereo_frame([tr], t, f)
+        frames.append((ns, (i0[0].numpy(), i1[0].numpy())))
+        smp = synth.imu_samples(tr, 9, t_prev, t)
+        for r in smp:   # FLVIS frame -> EuRoC sensor frame: the inverse of vo_tracking.cpp:341-348
+            a, g = r[1:4], r[4:7]
+            imu_sensor.append([t0_ns + int(round(r[0] * 1e9)), g[2], -g[1], g[0], -a[2], a[1], -a[0]])
+        direct_in.append((ns * 1e-9, smp))
+        t_prev = t
+        gt_rows.append([ns] + list(tr.pos(t)))
+    root = tempfile.mkdtemp(prefix="flvis_asl_")
+    _write_asl(root, frames, imu_sensor, gt_rows)
+    # the reader
+    seq = traj_io.EurocSequence(root)
+    assert len(seq) == nframes and seq.groundtruth is not None and len(seq.imu) == len(imu_sensor)
+    got = list(seq.frames())
+    for (t, g0, g1, rows), (ns, imgs) in zip(got, frames):
+        assert abs(t - ns * 1e-9) < 1e-6 and np.array_equal(g0, imgs[0]) and np.array_equal(g1, imgs[1])
+    assert sum(len(g[3]) for g in got) == len(imu_sensor)
+    a, g = traj_io.sensor_to_flvis_imu(1, [1.0, 2.0, 3.0], [4.0, 5.0, 6.0])
+    assert list(a) == [-3.0, 2.0, -1.0] and list(g) == [6.0, -5.0, 4.0]
+    # the runner with the CPU backend
+    out = os.path.join(root, "traj_cpu.txt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), root, yaml, out, "--backend", "cpu"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert res["tracked"] >= 6 and res["ate_rmse_m"] < 0.05, res
+    ts, pos, quat = traj_io.read_stamped(out)
+    # the same frames fed to the oracle directly give the same poses (to the 6 significant digits the recorder writes)
+    cfg = O.load_config(yaml)
+    trk = O.Tracker(cfg, 0xF1715)
+    want_t, want_p = [], []
+    for (ns, imgs), (tsec, smp) in zip(frames, direct_in):
+        for s in smp:
+            trk.imu((t0_ns + int(round(s[0] * 1e9))) * 1e-9, s[1:4], s[4:7])   # the stamp the csv carries
+        res = trk.image(ns * 1e-9, imgs[0], imgs[1])
+        if res["state"] == 1:
+            p7 = res["pose7"]
+            R = traj_io.quat_to_rot(p7[6], p7[3], p7[4], p7[5])
+            want_t.append(ns * 1e-9)
+            want_p.append(-R.T @ p7[:3])
+    assert len(want_t) == len(ts) and np.allclose(ts, want_t, atol=1e-6)
+    assert np.allclose(pos, np.array(want_p), rtol=2e-5, atol=1e-6)
