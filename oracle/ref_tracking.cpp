@@ -1194,4 +1194,63 @@ int ref_tracker_pose_records(void* h, int cap, double* rows8) {
   }
   return n;
 }
+// ---- standalone VIMOTION handles (tests/test_oracle_vimotion.py): the filter driven exactly as F2FTracking drives it
+static ref::SE3 pose7_to_se3(const double* p) {
+  ref::SE3 T;
+  T.t = {p[0], p[1], p[2]};
+  T.q.x = p[3], T.q.y = p[4], T.q.z = p[5], T.q.w = p[6];
+  return T;
+}
+static void se3_to_pose7(const ref::SE3& T, double* p) {
+  double o[7] = {T.t.x, T.t.y, T.t.z, T.q.x, T.q.y, T.q.z, T.q.w};
+  memcpy(p, o, sizeof(o));
+}
+void* ref_vi_create(const double* T_i_c_pose7, double g, const double* para6) {
+  return new ref::VIMOTION(pose7_to_se3(T_i_c_pose7), g, para6[0], para6[1], para6[2], para6[3], para6[4], para6[5]);
+}
+void ref_vi_destroy(void* h) { delete (ref::VIMOTION*)h; }
+void ref_vi_feed(void* h, double t, const double* acc, const double* gyro, double* out10) {  // f2f_tracking.cpp:46-57
+  ref::VIMOTION* v = (ref::VIMOTION*)h;
+  ref::IMUSTATE s{{acc[0], acc[1], acc[2]}, {gyro[0], gyro[1], gyro[2]}, t};
+  ref::Quat q;
+  ref::Vec3 p, vel;
+  if (!v->imu_initialized)
+    v->viIMUinitialization(s, q, p, vel);
+  else
+    v->viIMUPropagation(s, q, p, vel);
+  double o[10] = {q.w, q.x, q.y, q.z, p.x, p.y, p.z, vel.x, vel.y, vel.z};
+  memcpy(out10, o, sizeof(o));
+}
+void ref_vi_vision_trigger(void* h, double* q_wxyz) {
+  ref::Quat q;
+  ((ref::VIMOTION*)h)->viVisiontrigger(q);
+  q_wxyz[0] = q.w, q_wxyz[1] = q.x, q_wxyz[2] = q.y, q_wxyz[3] = q.z;
+}
+int ref_vi_get_corr_frame_state(void* h, double time, double* pose7) {
+  ref::SE3 T = ref::se3_identity();
+  bool ok = ((ref::VIMOTION*)h)->viGetCorrFrameState(time, T);
+  se3_to_pose7(T, pose7);
+  return ok ? 1 : 0;
+}
+void ref_vi_rp_compensation(void* h, double time, double* pose7_inout) {
+  ref::SE3 T = pose7_to_se3(pose7_inout);
+  ((ref::VIMOTION*)h)->viVisionRPCompensation(time, T);
+  se3_to_pose7(T, pose7_inout);
+}
+void ref_vi_correction(void* h, double t_curr, const double* pose7_curr, double t_last, const double* pose7_last) {
+  ((ref::VIMOTION*)h)->viCorrectionFromVision(t_curr, pose7_to_se3(pose7_curr), t_last, pose7_to_se3(pose7_last), 0.0);
+}
+// rows of 11: t, q (w x y z), pos, vel; biases6: acc bias, gyro bias.  Returns the queue length.
+int ref_vi_states(void* h, int cap, double* rows11, double* biases6) {
+  ref::VIMOTION* v = (ref::VIMOTION*)h;
+  int n = (int)v->states.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    const ref::MOTION_STATE& s = v->states[i];
+    double o[11] = {s.imu_data.timestamp, s.q_w_i.w, s.q_w_i.x, s.q_w_i.y, s.q_w_i.z, s.pos.x, s.pos.y, s.pos.z, s.vel.x, s.vel.y, s.vel.z};
+    memcpy(rows11 + 11 * i, o, sizeof(o));
+  }
+  double b[6] = {v->acc_bias.x, v->acc_bias.y, v->acc_bias.z, v->gyro_bias.x, v->gyro_bias.y, v->gyro_bias.z};
+  memcpy(biases6, b, sizeof(b));
+  return n;
+}
 }
