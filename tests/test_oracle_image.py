@@ -200,3 +200,78 @@ def test_cvt_bgr_to_gray_matches_the_fixed_point_formula():
         assert np.array_equal(O.cvt_bgr_to_gray(img), want)
     grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)       # B = G = R -> unchanged
     assert np.array_equal(O.cvt_bgr_to_gray(grey)[0], np.arange(256))
+
+
+# ------------------------------------------------------------------------------------------------ FeatureDEM, restated again
+def np_harris_r(img, ptx, pty):
+    """FeatureDEM::calHarrisR (feature_dem.cpp:59-88) with its quirks: patch[5] is the (x+1, y+1) pixel, integer division
+    by 3, Y2 = IY*IX and XY = IX*IX."""
+    xx, yy = int(ptx), int(pty)
+    p = [int(img[yy - 1, xx - 1]), int(img[yy - 1, xx]), int(img[yy - 1, xx + 1]), int(img[yy, xx - 1]), int(img[yy, xx]),
+         int(img[yy + 1, xx + 1]), int(img[yy + 1, xx - 1]), int(img[yy + 1, xx]), int(img[yy + 1, xx + 1])]
+    tdiv = lambda a: int(a / 3)                      # C integer division truncates toward zero
+    IX = np.float32(tdiv(p[0] + p[3] + p[6] - (p[2] + p[5] + p[8])))
+    IY = np.float32(tdiv(p[0] + p[1] + p[2] - (p[6] + p[7] + p[8])))
+    X2, Y2, XY = IX * IX, IY * IX, IX * IX
+    return np.float32(np.float32(X2 * Y2) - np.float32(XY * XY)) - np.float32(np.float32(np.float32(0.05) * np.float32(X2 + Y2)) * np.float32(X2 + Y2))
+
+
+def np_fill_regions(img, pts, w, h, existed):
+    rw, rh = int(np.floor(w / 4.0)), int(np.floor(h / 4.0))
+    regions = [[] for _ in range(16)]
+    for (x, y) in pts:
+        x, y = np.float32(x), np.float32(y)
+        if x >= 3 and x < w - 3 and y >= 3 and y < h - 3:
+            r = int(np.float32(4 * np.floor(np.float32(y / np.float32(rh)))) + np.float32(x / np.float32(rw)))
+            regions[r].append(((x, y), np.float32(99999.0) if existed else np_harris_r(img, x, y)))
+    return regions
+
+
+def np_dem_detect(img, f_para):
+    h, w = img.shape
+    bd, maxn = int(np.floor(f_para[2] / 2.0)), int(f_para[0])
+    corners = O.gftt(img, 2 * int(f_para[3]), f_para[4], int(f_para[5]))
+    out = []
+    for reg in np_fill_regions(img, corners, w, h, False):
+        reg = sorted(reg, key=lambda e: -float(e[1]))          # stable: ties keep the GFTT rank order
+        kept = []
+        for (pt, _) in reg:
+            ok = all(not (abs(pt[0] - k[0]) <= bd or abs(pt[1] - k[1]) <= bd) for k in kept)
+            if ok:
+                kept.append(pt)
+                if len(kept) >= maxn:
+                    break
+        out += kept
+    return np.array(out, np.float32).reshape(-1, 2)
+
+
+def np_dem_redetect(img, f_para, existed):
+    h, w = img.shape
+    bd, maxn = int(np.floor(f_para[2] / 2.0)), int(f_para[0])
+    regions = np_fill_regions(img, [(np.float32(x), np.float32(y)) for x, y in existed], w, h, True)
+    regions = [[pt for pt, _ in reg] for reg in regions]
+    corners = O.gftt(img, int(f_para[3]), f_para[4], int(f_para[5]))
+    new = []
+    for i, reg in enumerate(np_fill_regions(img, corners, w, h, False)):
+        for (pt, _) in sorted(reg, key=lambda e: -float(e[1])):
+            ip = (int(np.rint(pt[0])), int(np.rint(pt[1])))     # cv::Point pt = Point2f: rounds half to even
+            near = any(abs(np.float32(ip[0]) - k[0]) <= bd or abs(np.float32(ip[1]) - k[1]) <= bd for k in regions[i])
+            if not near:
+                regions[i].append((np.float32(ip[0]), np.float32(ip[1])))
+                new.append(ip)
+                if len(regions[i]) >= maxn:
+                    break
+    return np.array(new, np.float32).reshape(-1, 2)
+
+
+@pytest.mark.parametrize("seed,fp", [(3, [15, 30, 5, 500, 0.001, 5]), (4, [30, 20, 5, 1000, 0.01, 10]), (5, [4, 30, 9, 300, 0.005, 7])])
+def test_feature_dem_matches_an_independent_restatement(seed, fp):
+    img = S.texture_u8(480, 640, seed)
+    got = O.dem_detect(img, fp)
+    want = np_dem_detect(img, fp)
+    assert len(want) > 30 and got.shape == want.shape and np.array_equal(got, want)
+    rng = np.random.default_rng(seed)
+    existed = got[rng.permutation(len(got))[: len(got) // 2]].astype(np.float64) + rng.uniform(-0.4, 0.4, (len(got) // 2, 2))
+    got2 = O.dem_redetect(img, fp, existed)
+    want2 = np_dem_redetect(img, fp, existed)
+    assert len(want2) > 5 and got2.shape == want2.shape and np.array_equal(got2, want2)
