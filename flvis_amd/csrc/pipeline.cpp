@@ -66,13 +66,24 @@ struct Pipeline {
   hipEvent_t ev_img = nullptr, ev_det = nullptr;
   hipEvent_t ev_fe[NBA] = {};
   bool feedback_used = false;  // flvis_correction_feed was called: k_apply_correction runs after every frame_begin
+  // flvis_image_feed_host: double-buffered device staging filled by async H2D copies on a copy stream, so that the upload of
+  // frame N+1 overlaps the kernels of frame N (allocated by the first call)
+  struct HostFeed {
+    hipStream_t strm = nullptr;
+    uint8_t* raw[2][2] = {};   // [slot][camera]: the images as handed over (tightly packed rows of w * bytes-per-pixel)
+    uint8_t* gray[2][2] = {};  // [slot][camera]: cvtColor output for 3/4-channel input
+    size_t raw_bytes[2] = {}, gray_bytes = 0;
+    hipEvent_t ev_done[2] = {}, ev_free[2] = {};
+    long long n = 0;
+    std::vector<double> times;
+  } hf;
 };
-constexpr int PROF_STAGES = 19;  // every stage has its own (begin, end) event pair on the stream it runs on
+constexpr int PROF_STAGES = 20;  // every stage has its own (begin, end) event pair on the stream it runs on
 static const char* kStageNames[PROF_STAGES] = {
     "imu_feed+frame_begin", "ingest(copy/equalize)", "pyr_down x6", "track_prepare", "lk_track(temporal)", "track_collect",
     "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_cand", "gftt:(merged)", "gftt:pick",
     "feature_dem+add_new", "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end",
-    "ba_worker(launch)"};
+    "ba_worker(launch)", "frame(chain)"};
 
 }  // namespace flvis
 
@@ -181,6 +192,14 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   if (pl->det_stream) {
     hipStreamSynchronize(pl->det_stream);
     hipStreamDestroy(pl->det_stream);
+  }
+  if (pl->hf.strm) {
+    hipStreamSynchronize(pl->hf.strm);
+    hipStreamDestroy(pl->hf.strm);
+    for (int k = 0; k < 2; k++) {
+      if (pl->hf.ev_done[k]) hipEventDestroy(pl->hf.ev_done[k]);
+      if (pl->hf.ev_free[k]) hipEventDestroy(pl->hf.ev_free[k]);
+    }
   }
   if (pl->ev_img) hipEventDestroy(pl->ev_img);
   if (pl->ev_det) hipEventDestroy(pl->ev_det);
@@ -497,6 +516,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i)], strm)
 #define PE(i, strm) \
   if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i) + 1], strm)
+  PB(19, st);  // the whole main-stream chain of this frame: per-frame GPU latency (p50/p99 in bench.py)
   PB(0, st);
   launch_imu_feed(st, p);
   launch_frame_begin(st, p, pl->d_time);
@@ -508,9 +528,10 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     PB(17, st);
     launch_frame_end(st, p, (int)pl->frames_fed);
     PE(17, st);
+    PE(19, st);
     if (prof) {
       for (int i = 1; i < PROF_STAGES; i++)
-        if (i != 17) {
+        if (i != 17 && i != 19) {
           PB(i, st);
           PE(i, st);
         }
@@ -619,6 +640,7 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PB(17, st);
   launch_frame_end(st, p, (int)pl->frames_fed);
   PE(17, st);
+  PE(19, st);
   if (with_local_map && (pl->frames_fed % pl->ba_every) == 0) {
     hipStream_t bs = pl->ba_stream[par];
     hipEventRecord(pl->ev_fe[par], st);
@@ -645,6 +667,97 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
     e = hipMemcpyAsync(h_out, p.out, sizeof(FrameOut) * S, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return ctx->hip_fail(e, "image_feed readback");
+  }
+  return FLVIS_OK;
+}
+
+// TrackingNodeletClass::image_input_callback (src/frontend/vo_tracking.cpp:396-430) hands F2FTracking::image_feed two HOST
+// cv::Mat (mono8, or 3/4 channels converted by cvtColor, f2f_tracking.cpp:74-111; depth rigs: img1 = 16UC1 depth): the same
+// hand-over with plain structs.  Uploads run on a copy stream into double-buffered device staging.
+int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis_image* h_img1, flvis_frame_out* h_out,
+                          int with_local_map, int hold_buffers) {
+  if (!ctx || !ctx->pipe || !h_img0 || !h_img1) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  const int S = pl->S, w = pl->cfg.image_width, h = pl->cfg.image_height;
+  const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;
+  const int ch0 = h_img0[0].channels, ch1 = h_img1[0].channels;
+  if ((ch0 != 1 && ch0 != 3 && ch0 != 4) || (ch1 != 1 && ch1 != 3 && ch1 != 4) || (depth_cam && ch1 != 1))
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "image_feed_host: channels must be 1, 3 or 4 (depth image: 1)");
+  const size_t bpp[2] = {(size_t)ch0, depth_cam ? (size_t)2 : (size_t)ch1};  // bytes per pixel as handed over
+  for (int s = 0; s < S; s++) {
+    const flvis_image* im[2] = {&h_img0[s], &h_img1[s]};
+    for (int c = 0; c < 2; c++)
+      if (!im[c]->data || im[c]->width != w || im[c]->height != h || im[c]->channels != (c ? ch1 : ch0) ||
+          (size_t)im[c]->pitch < (size_t)w * bpp[c])
+        return ctx->fail(FLVIS_ERR_INVALID_ARG, "image_feed_host: image size/channels/pitch do not match the configuration");
+  }
+  hipSetDevice(ctx->device);
+  Pipeline::HostFeed& hf = pl->hf;
+  if (!hf.strm) {
+    bool ok = hipStreamCreateWithFlags(&hf.strm, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++)
+      ok = hipEventCreateWithFlags(&hf.ev_done[k], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&hf.ev_free[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: cannot create the copy stream");
+    hf.times.assign(S, 0.0);
+  }
+  const size_t npix = (size_t)S * w * h;
+  for (int c = 0; c < 2; c++) {
+    const size_t need = npix * bpp[c] + 256;
+    if (hf.raw_bytes[c] < need) {
+      hipStreamSynchronize(hf.strm);
+      hipStreamSynchronize(ctx->stream);
+      for (int k = 0; k < 2; k++)
+        if (!(hf.raw[k][c] = dalloc<uint8_t>(pl, need, false))) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: device allocation failed");
+      hf.raw_bytes[c] = need;
+    }
+  }
+  if ((ch0 > 1 || (ch1 > 1 && !depth_cam)) && hf.gray_bytes < npix + 256) {
+    for (int k = 0; k < 2; k++)
+      for (int c = 0; c < 2; c++)
+        if (!(hf.gray[k][c] = dalloc<uint8_t>(pl, npix + 256, false))) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: device allocation failed");
+    hf.gray_bytes = npix + 256;
+  }
+  const int slot = (int)(hf.n & 1);
+  if (hf.n >= 1) hipEventSynchronize(hf.ev_done[slot ^ 1]);  // hold_buffers contract: the previous call's buffers are free now
+  if (hf.n >= 2) hipStreamWaitEvent(hf.strm, hf.ev_free[slot], 0);  // the frame that used this slot has been consumed
+  hipError_t e = hipSuccess;
+  for (int c = 0; c < 2 && e == hipSuccess; c++) {
+    const flvis_image* im = c ? h_img1 : h_img0;
+    const size_t row = (size_t)w * bpp[c], img_bytes = row * h;
+    bool contiguous = true;  // one block [S][h][w*bpp]: a single copy
+    for (int s = 0; s < S && contiguous; s++)
+      contiguous = (size_t)im[s].pitch == row && im[s].data == im[0].data + (size_t)s * img_bytes;
+    if (contiguous) {
+      e = hipMemcpyAsync(hf.raw[slot][c], im[0].data, img_bytes * S, hipMemcpyHostToDevice, hf.strm);
+    } else {
+      for (int s = 0; s < S && e == hipSuccess; s++)
+        e = hipMemcpy2DAsync(hf.raw[slot][c] + (size_t)s * img_bytes, row, im[s].data, (size_t)im[s].pitch, row, h,
+                             hipMemcpyHostToDevice, hf.strm);
+    }
+  }
+  if (e == hipSuccess) e = hipEventRecord(hf.ev_done[slot], hf.strm);
+  if (e != hipSuccess) return ctx->hip_fail(e, "image_feed_host upload");
+  hipStream_t st = ctx->stream;
+  hipStreamWaitEvent(st, hf.ev_done[slot], 0);
+  const uint8_t* d0 = hf.raw[slot][0];
+  const uint8_t* d1 = hf.raw[slot][1];
+  if (ch0 > 1) {
+    launch_bgr_to_gray(st, hf.raw[slot][0], ch0, hf.gray[slot][0], npix);
+    d0 = hf.gray[slot][0];
+  }
+  if (ch1 > 1 && !depth_cam) {
+    launch_bgr_to_gray(st, hf.raw[slot][1], ch1, hf.gray[slot][1], npix);
+    d1 = hf.gray[slot][1];
+  }
+  for (int s = 0; s < S; s++) hf.times[s] = h_img0[s].t;
+  const int rc = flvis_image_feed(ctx, d0, d1, hf.times.data(), h_out, with_local_map);
+  hipEventRecord(hf.ev_free[slot], st);
+  hf.n++;
+  if (rc != FLVIS_OK) return rc;
+  if (!hold_buffers) {  // the caller may reuse its buffers at once: wait for the uploads (not for the frame)
+    e = hipEventSynchronize(hf.ev_done[slot]);
+    if (e != hipSuccess) return ctx->hip_fail(e, "image_feed_host");
   }
   return FLVIS_OK;
 }
@@ -696,6 +809,20 @@ int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps) {
     }
   *n_steps = pl->prof_step;
   return FLVIS_OK;
+}
+
+int flvis_prof_read_steps(flvis_ctx* ctx, int stage, double* h_ms, int cap) {
+  if (!ctx || !ctx->pipe || !h_ms || stage < 0 || stage >= PROF_STAGES || cap < 0) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (!((pl->prof_mask >> stage) & 1ull)) return ctx->fail(FLVIS_ERR_INVALID_ARG, "prof_read_steps: stage was not enabled");
+  sync_all(ctx);
+  int n = 0;
+  for (int k = 0; k < pl->prof_step && n < cap; k++, n++) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage], pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage + 1]);
+    h_ms[n] = ms;
+  }
+  return n;
 }
 
 int flvis_get_landmarks(flvis_ctx* ctx, int stream, int cap, int64_t* h_id, double* h_2d, double* h_2du, double* h_3d,

@@ -188,6 +188,9 @@ int flvis_prof_enable_stages(flvis_ctx* ctx, int max_steps, uint64_t stage_mask)
 int flvis_prof_stage_count(void);
 const char* flvis_prof_stage_name(int i);
 int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps);
+/* Per-frame elapsed ms of one enabled stage (stage "frame(chain)" = the whole main-stream chain of a frame, i.e. the GPU
+ * latency of one batch step); returns the number of frames written (<= cap). */
+int flvis_prof_read_steps(flvis_ctx* ctx, int stage, double* h_ms, int cap);
 
 /* One stereo frame for every stream of the batch.  d_img0/d_img1: device [n_streams][h][w] mono8; h_times: host
  * [n_streams] seconds.  h_out (host, [n_streams], may be NULL): results; when NULL nothing is copied back and the call
@@ -196,6 +199,23 @@ int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps);
  * (F2FTracking::image_feed(time, img0, d_img, ...), src/frontend/vo_tracking.cpp:453, f2f_tracking.cpp:116-119). */
 int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
                      flvis_frame_out* h_out, int with_local_map);
+
+/* The same frame step with the images handed over as HOST buffers, the way TrackingNodeletClass::image_input_callback hands
+ * two cv::Mat to F2FTracking::image_feed (src/frontend/vo_tracking.cpp:396-430, f2f_tracking.cpp:59-119): one flvis_image
+ * per stream and camera.  channels 1 (mono8), 3 (BGR) or 4 (BGRA) -- colour input is converted like cv::cvtColor does at
+ * f2f_tracking.cpp:74-111; on depth rigs h_img1 is the 16UC1 depth image (channels 1, 2 bytes per pixel, pitch in bytes).
+ * The stamp of a stream's frame is h_img0[stream].t.  Rows may be padded (pitch >= width * bytes per pixel).  The uploads
+ * run asynchronously on a copy stream into double-buffered device staging, so the H2D transfer of a frame overlaps the
+ * kernels of the previous one; page-locked host memory (hipHostMalloc / hipHostRegister) is what makes them truly async.
+ * hold_buffers == 0: returns once the uploads are done (the caller may reuse its buffers immediately);
+ * hold_buffers != 0: returns at once, the buffers must stay valid until the next call on this context returns. */
+typedef struct flvis_image {
+  const uint8_t* data;
+  int width, height, pitch, channels;
+  double t;
+} flvis_image;
+int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis_image* h_img1, flvis_frame_out* h_out,
+                          int with_local_map, int hold_buffers);
 
 /* Landmarks of curr_frame of one stream (host arrays of capacity cap): ids, raw pixel, rectified pixel, world point,
  * flags (bit0 has_3d, bit1 is_tracking_inlier).  Returns the landmark count (or <0). */

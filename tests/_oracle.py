@@ -13,6 +13,9 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    if os.environ.get("FLVIS_ORACLE_LIB"):  # bench.py's timing build (oracle/_fast, -O3 -march=native); never set by the tests
+        _LIB = C.CDLL(os.environ["FLVIS_ORACLE_LIB"])
+        return _LIB
     so = os.path.join(ROOT, "oracle", "libflvis_ref.so")
     srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle"))
             if f.endswith((".cpp", ".h", ".hpp"))]
