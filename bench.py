@@ -98,55 +98,38 @@ def maybe_spawn(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
-def load_oracle(fast):
-    """The CPU restatement as a ctypes module.  fast=True: the timing build (-O3 -march=native, built on THIS host);
-    fast=False: the op-by-op IEEE checker build the parity tests use."""
-    import importlib.util
-    if fast:
+def load_oracle_lib():
+    """The CPU restatement's timing build (-O3 -march=native, built on THIS host by `make -C oracle fast`); falls back to the
+    op-by-op IEEE checker build the parity tests use.  Returns (ctypes lib, description of the build)."""
+    try:
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "fast"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        os.environ["FLVIS_ORACLE_LIB"] = os.path.join(ROOT, "oracle", "_fast", "libflvis_ref_fast.so")
-    else:
-        os.environ.pop("FLVIS_ORACLE_LIB", None)
-    spec = importlib.util.spec_from_file_location("_oracle_fast" if fast else "_oracle_chk", os.path.join(ROOT, "tests", "_oracle.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    mod.lib()
-    os.environ.pop("FLVIS_ORACLE_LIB", None)
-    return mod
+        return C.CDLL(os.path.join(ROOT, "oracle", "_fast", "libflvis_ref_fast.so")), "-O3 -march=native (timing build, oracle/_fast)"
+    except Exception:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return C.CDLL(os.path.join(ROOT, "oracle", "libflvis_ref.so")), "-O2 -ffp-contract=off (checker build; the timing build failed)"
 
 
-def cpu_stream_prepare(O, cfg, seed, imu_rows, imu_cnt, blank, first, frame_hz):
-    """One oracle stream brought to frame `first`: the skipped start-up frames carry IMU samples only (untimed)."""
-    ocfg = O.RefConfig()
-    C.memmove(C.byref(ocfg), C.byref(cfg), C.sizeof(cfg))
-    ref = O.Tracker(ocfg, seed)
-    lm = O.LocalMap(cfg.window_size, np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]]))
-    for f in range(first):
-        for r in imu_rows[f][:imu_cnt[f]]:
-            ref.imu(r[0], r[1:4], r[4:7])
-        ref.image(f / frame_hz, blank[0], blank[1])
-    return ref, lm
-
-
-def cpu_stream_run(ref_lm, imu_rows, imu_cnt, host_frames, first, n, frame_hz, with_local_map, lat=None):
-    """n frames of one prepared oracle stream, timed.  Returns (seconds, poses, states)."""
-    ref, lm = ref_lm
-    pos, state = [], []
-    t0 = time.perf_counter()
-    for j in range(n):
-        f = first + j
-        tf = time.perf_counter()
-        for r in imu_rows[f][:imu_cnt[f]]:
-            ref.imu(r[0], r[1:4], r[4:7])
-        res = ref.image(f / frame_hz, host_frames[j][0], host_frames[j][1])
-        pos.append(np.asarray(res["pose7"], float))
-        state.append(res["state"])
-        if res["new_keyframe"] and with_local_map:
-            kf = ref.keyframe()
-            lm.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
-        if lat is not None:
-            lat.append((time.perf_counter() - tf) * 1e3)
-    return time.perf_counter() - t0, pos, state
+def cpu_run_streams(olib, cfg, T, threads, first, n, host_frames, imu, imu_cnt, seed_base, frame_hz, with_local_map):
+    """oracle/ref_runner.cpp: T streams on `threads` native host threads (no Python in the timed part).  host_frames: list of n
+    (img0 [>=T,H,W], img1 [>=T,H,W]) uint8 arrays.  Returns (seconds, poses [T,n,7], states [T,n], frame_ms [T,n])."""
+    f0 = [np.ascontiguousarray(h[0][:T]) for h in host_frames[:n]]
+    f1 = [np.ascontiguousarray(h[1][:T]) for h in host_frames[:n]]
+    p0 = (C.c_void_p * n)(*[a.ctypes.data for a in f0])
+    p1 = (C.c_void_p * n)(*[a.ctypes.data for a in f1])
+    im = np.ascontiguousarray(imu[:first + n, :T])
+    ic = np.ascontiguousarray(imu_cnt[:first + n, :T]).astype(np.int32)
+    seeds = np.array([seed_base + s for s in range(T)], np.uint64)
+    poses = np.zeros((T, n, 7))
+    states = np.zeros((T, n), np.int32)
+    fms = np.zeros((T, n))
+    olib.ref_run_streams.restype = C.c_double
+    olib.ref_run_streams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    secs = olib.ref_run_streams(C.byref(cfg), T, n, first, frame_hz, p0, p1, im.ctypes.data, ic.ctypes.data, im.shape[2],
+                                seeds.ctypes.data, int(with_local_map), threads, poses.ctypes.data, states.ctypes.data, fms.ctypes.data)
+    if secs <= 0:
+        raise RuntimeError("ref_run_streams rejected its arguments")
+    return secs, poses, states, fms
 
 
 def centre(p7):
@@ -260,7 +243,7 @@ def main():
 
     # the pipeline uses several HIP streams per tracker context; with the default of 4 hardware queues the long local-map
     # kernels share a queue with the front-end chain (must be set before the HIP runtime initialises)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -451,7 +434,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dxMI355X: batch of %d independent 640x480 synthetic stereo+IMU streams per GPU, full HIP "
                                    "front-end + batched Schur BA (BASELINE.json configs[%d])" % (world, S, 3 if world == 1 else 4),
-                       "streams_per_gpu": S, "streams_total": world * S, "window_size": cfg.window_size, "local_map": bool(wlm),
+                       "streams_per_gpu": S, "streams_total": world * S, "lanes_per_gpu": lib.flvis_tracker_lanes(ctx._h),
+                       "window_size": cfg.window_size, "local_map": bool(wlm),
                        "preroll_frames": sched["preroll"][1], "streams_tracking_at_start": tracking_at_start,
                        "streams_tracking_at_end": int(csum[3]), "keyframes_in_run": int(csum[1]), "ba_runs_in_run": int(csum[2]),
                        "gpu_ms_per_step_events": round(gpu_ms / K, 4)},
@@ -534,53 +518,36 @@ def flvis_image_struct():
 
 def leg_cpu(L):
     """CPU baselines on this box's host cores (the oracle = a port of the reference path; kind "port"): (i) one stream on one
-    thread, (ii) one thread per core, one stream per thread -- both on a bounded sample of the same workload -- and the ATE of
-    the GPU trajectory against the CPU one."""
-    args, out, cfg, S = L["args"], L["out"], L["cfg"], L["S"]
+    thread, (ii) one thread per core, one stream per thread -- both on a bounded sample of the same workload, driven natively
+    (oracle/ref_runner.cpp) -- and the ATE of the GPU trajectory against the CPU one."""
+    args, out, cfg = L["args"], L["out"], L["cfg"]
     n_cpu, cpu_first, n_mt, host_frames = L["n_cpu"], L["cpu_first"], L["n_mt"], L["host_frames"]
     imu, imu_cnt, synth, trk, trajs, wlm, skip = L["imu"], L["imu_cnt"], L["synth"], L["trk"], L["trajs"], L["wlm"], L["skip"]
-    plan_ = plan
+    have = 0
+    while cpu_first + have in host_frames:
+        have += 1
+    n_cpu = min(n_cpu, have)
     if n_cpu <= 0:
         return
-    n_cpu = min(n_cpu, sum(1 for f in range(cpu_first, cpu_first + n_cpu) if f in host_frames))
-    if n_cpu <= 0:
-        return
-    try:
-        O = load_oracle(fast=True)
-        build = "-O3 -march=native (timing build, oracle/_fast)"
-    except Exception:
-        O = load_oracle(fast=False)
-        build = "-O2 -ffp-contract=off (checker build; the timing build failed)"
-    hf = [(host_frames[cpu_first + j][0][0], host_frames[cpu_first + j][1][0]) for j in range(n_cpu)]
-    lat = []
-    prep = cpu_stream_prepare(O, cfg, 0xF1715, imu[:, 0], imu_cnt[:, 0], hf[0], cpu_first, synth.FRAME_HZ)
-    tc, cpu_pos, cpu_state = cpu_stream_run(prep, imu[:, 0], imu_cnt[:, 0], hf, cpu_first, n_cpu, synth.FRAME_HZ, wlm, lat)
+    olib, build = load_oracle_lib()
+    hf = [host_frames[cpu_first + j] for j in range(have)]
+    tc, cpu_pos, cpu_state, fms = cpu_run_streams(olib, cfg, 1, 1, cpu_first, n_cpu, hf, imu, imu_cnt, 0xF1715, synth.FRAME_HZ, wlm)
+    cpu_pos, cpu_state, lat = cpu_pos[0], cpu_state[0], list(fms[0])
     out["cpu_baseline"] = {"value": round(n_cpu / tc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                            "sample": "stream 0, %d frames after the %d skipped start-up frames of the same synthetic workload, oracle "
                                      "front-end + local-map BA, one thread, g++ %s (%d host cores present)"
                                      % (n_cpu, skip, build, os.cpu_count()),
-                           "latency_ms_p50": round(plan_.percentile(lat, 50), 3), "latency_ms_p99": round(plan_.percentile(lat, 99), 3)}
-    # (ii) one thread per core, one stream per thread (ctypes releases the GIL inside the oracle)
-    nf = min(args.cpu_mt_frames, sum(1 for f in range(cpu_first, cpu_first + args.cpu_mt_frames) if f in host_frames and host_frames[f][0].shape[0] >= n_mt)) if n_mt else 0
+                           "latency_ms_p50": round(plan.percentile(lat, 50), 3), "latency_ms_p99": round(plan.percentile(lat, 99), 3)}
+    # (ii) one stream per thread, as many streams as cores (bounded by the streams of the batch)
+    nf = 0
+    while nf < args.cpu_mt_frames and cpu_first + nf in host_frames and host_frames[cpu_first + nf][0].shape[0] >= n_mt:
+        nf += 1
     if n_mt > 1 and nf > 0:
-        import threading
-        res = [None] * n_mt
-        preps = [cpu_stream_prepare(O, cfg, 0xF1715 + s, imu[:, s], imu_cnt[:, s], hf[0], cpu_first, synth.FRAME_HZ) for s in range(n_mt)]
-
-        def worker(s):
-            hfs = [(host_frames[cpu_first + j][0][s], host_frames[cpu_first + j][1][s]) for j in range(nf)]
-            res[s] = cpu_stream_run(preps[s], imu[:, s], imu_cnt[:, s], hfs, cpu_first, nf, synth.FRAME_HZ, wlm)[0]
-        ths = [threading.Thread(target=worker, args=(s,)) for s in range(n_mt)]
-        tj = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        tj = time.perf_counter() - tj
-        if all(r is not None for r in res):
-            out["cpu_baseline"]["multi"] = {"value": round(n_mt * nf / tj, 2), "unit": "frames/s", "cores": n_mt,
-                                            "sample": "%d streams x %d frames, one host thread per stream (the reference runs 1-2 threads "
-                                                      "per stream), wall time of the whole job" % (n_mt, nf)}
+        tj, _, st_mt, _ = cpu_run_streams(olib, cfg, n_mt, n_mt, cpu_first, nf, hf, imu, imu_cnt, 0xF1715, synth.FRAME_HZ, wlm)
+        out["cpu_baseline"]["multi"] = {"value": round(n_mt * nf / tj, 2), "unit": "frames/s", "cores": n_mt,
+                                        "sample": "%d streams x %d frames, one native host thread per stream (the reference runs 1-2 threads "
+                                                  "per stream), wall time of the whole job; %d of %d stream-frames in the Tracking state"
+                                                  % (n_mt, nf, int((st_mt == 1).sum()), n_mt * nf)}
     # ATE of the GPU trajectory of stream 0 against the CPU reference on the same frames (camera centres, no alignment: both
     # run from the same initial state), and both against the synthetic ground truth
     grow = trk.trajectory(0, cpu_first, n_cpu)

@@ -174,8 +174,10 @@ constexpr int PD_TW = 64, PD_TH = 16;
 constexpr int PD_SW = 2 * PD_TW + 8;  // 136: starts at 2*x0-4 (dword aligned), covers 2*x0-2 .. 2*x0+2*TW
 constexpr int PD_SH = 2 * PD_TH + 3;  // 35
 
-__global__ __launch_bounds__(256) void k_pyr_down(ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst,
-                                                  int dpitch, size_t dstride, const int* __restrict__ active) {
+template <bool INGEST>
+__device__ __forceinline__ void pyr_down_tile(ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0, int d0pitch,
+                                              size_t d0stride, ImgSel dst, int dpitch, size_t dstride,
+                                              const int* __restrict__ active) {
   const int s = blockIdx.z;
   if (active && !active[s]) return;
   const int dw = (sw + 1) >> 1, dh = (sh + 1) >> 1;
@@ -185,6 +187,17 @@ __global__ __launch_bounds__(256) void k_pyr_down(ImgSel src, int sw, int sh, in
   const uint8_t* img = src.ptr(s, sstride);
   load_tile_u8<PD_SH, PD_SW, PD_SW>(img, sw, sh, spitch, 2 * x0 - 4, 2 * y0 - 2, tile);
   __syncthreads();
+  if (INGEST) {
+    // level 0 = a copy of the caller's image (it must outlive the caller's buffer: it is the "previous image" of the next
+    // frame): this workgroup's 32 x 128 source block sits in the tile at rows 2..33, bytes 4..131 (dword aligned)
+    uint8_t* o0 = const_cast<uint8_t*>(dst0.ptr(s, d0stride));
+    for (int i = threadIdx.x; i < 2 * PD_TH * (2 * PD_TW / 4); i += 256) {
+      const int r = i / (2 * PD_TW / 4), k = i - r * (2 * PD_TW / 4);
+      const int y = 2 * y0 + r, x = 2 * x0 + 4 * k;
+      if (y < sh && x + 3 < sw)
+        *reinterpret_cast<uint32_t*>(o0 + (size_t)y * d0pitch + x) = *reinterpret_cast<const uint32_t*>(tile + (r + 2) * PD_SW + 4 + 4 * k);
+    }
+  }
   for (int i = threadIdx.x; i < PD_SH * PD_TW; i += 256) {
     int r = i / PD_TW, c = i - r * PD_TW;
     const uint8_t* p = tile + r * PD_SW + 2 * c + 2;  // tile col of image x = 2*(x0+c)-2
@@ -201,6 +214,19 @@ __global__ __launch_bounds__(256) void k_pyr_down(ImgSel src, int sw, int sh, in
       out[(size_t)y * dpitch + x] = (uint8_t)((v + 128) >> 8);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_pyr_down(ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst,
+                                                  int dpitch, size_t dstride, const int* __restrict__ active) {
+  pyr_down_tile<false>(src, sw, sh, spitch, sstride, dst, 0, 0, dst, dpitch, dstride, active);
+}
+
+// The first pyramid level fused with the ingest copy (modes without equalizeHist): the caller's image is read ONCE and
+// written out as level 0 and level 1 (the former k_copy_image16 + k_pyr_down pair read it twice).  Needs sw % 4 == 0.
+__global__ __launch_bounds__(256) void k_pyr_down_ingest(ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0,
+                                                         int d0pitch, size_t d0stride, ImgSel dst, int dpitch, size_t dstride,
+                                                         const int* __restrict__ active) {
+  pyr_down_tile<true>(src, sw, sh, spitch, sstride, dst0, d0pitch, d0stride, dst, dpitch, dstride, active);
 }
 
 // ------------------------------------------------------------------------------------------------ min-eigenvalue map
@@ -905,7 +931,7 @@ void launch_bgr_to_gray(hipStream_t st, const uint8_t* src, int channels, uint8_
 
 void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
                        size_t dstride, int S, const int* active) {
-  const bool a16 = (w % 16) == 0 && (spitch % 16) == 0 && (dpitch % 16) == 0 && (sstride % 16) == 0 && (dstride % 16) == 0 &&
+  const bool a16 = !src.ind && (w % 16) == 0 && (spitch % 16) == 0 && (dpitch % 16) == 0 && (sstride % 16) == 0 && (dstride % 16) == 0 &&
                    ((uintptr_t)src.b[0] % 16) == 0 && ((uintptr_t)src.b[1] % 16) == 0 && ((uintptr_t)dst.b[0] % 16) == 0 &&
                    ((uintptr_t)dst.b[1] % 16) == 0;
   if (a16) {
@@ -923,6 +949,13 @@ void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, siz
   int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
   hipLaunchKernelGGL(k_pyr_down, dim3(div_up(dw, PD_TW), div_up(dh, PD_TH), S), dim3(256), 0, st, src, sw, sh, spitch,
                      sstride, dst, dpitch, dstride, active);
+}
+
+void launch_pyr_down_ingest(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0, int d0pitch,
+                            size_t d0stride, ImgSel dst, int dpitch, size_t dstride, int S, const int* active) {
+  int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+  hipLaunchKernelGGL(k_pyr_down_ingest, dim3(div_up(dw, PD_TW), div_up(dh, PD_TH), S), dim3(256), 0, st, src, sw, sh, spitch,
+                     sstride, dst0, d0pitch, d0stride, dst, dpitch, dstride, active);
 }
 
 // stage_events (optional): 6 events = (begin, end) for eig_max, eig_nms, gftt_pick.

@@ -11,12 +11,17 @@ struct ImgSel {
   const uint8_t* b[2];
   const int* cur;  // device array [S] with the stream's current slot, or nullptr (always slot 0)
   int flip;        // 0 -> current slot, 1 -> the other one (last frame)
-  __host__ __device__ const uint8_t* ptr(int s, size_t stride) const {
+  // when set: the base address is read from this device-side table entry instead of b[] -- for the caller's input images,
+  // whose address changes from frame to frame while the kernel arguments (a captured graph's nodes) stay the same
+  const uint8_t* const* ind;
+  __device__ const uint8_t* ptr(int s, size_t stride) const {
+    if (ind) return *ind + (size_t)s * stride;
     int k = cur ? (cur[s] ^ flip) : 0;
     return b[k] + (size_t)s * stride;
   }
 };
-static inline ImgSel img_plain(const uint8_t* p) { return ImgSel{{p, p}, nullptr, 0}; }
+static inline ImgSel img_plain(const uint8_t* p) { return ImgSel{{p, p}, nullptr, 0, nullptr}; }
+static inline ImgSel img_indirect(const uint8_t* const* slot) { return ImgSel{{nullptr, nullptr}, nullptr, 0, slot}; }
 
 constexpr int LK_MAX_LEVELS = 6;
 struct PyrSel {
@@ -53,6 +58,9 @@ void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int
                        size_t dstride, int S, const int* active);
 void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,
                      size_t dstride, int S, const int* active);
+// level 1 of a pyramid fused with the ingest copy: reads the caller's image once, writes level 0 (dst0) and level 1 (dst)
+void launch_pyr_down_ingest(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0, int d0pitch,
+                            size_t d0stride, ImgSel dst, int dpitch, size_t dstride, int S, const int* active);
 void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, GfttScratch sc,
                  const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
                  float* out_xy, int* out_n, int out_cap, const int* active, hipEvent_t* stage_events = nullptr,
@@ -62,7 +70,8 @@ void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, siz
                         const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,
                         int out_cap);
 // pyramidal LK, 31x31 window: one wave per (stream, point)
+// max_pts: upper bound of count[] known to the caller (sizes the grid; any value is correct, the kernel strides), <= 0: nmax
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
-                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active);
+                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active, int max_pts = 0);
 
 }  // namespace flvis

@@ -397,8 +397,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 }
 
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
-                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active) {
+                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active, int max_pts) {
+  // one wave per point; the kernel strides by the grid width, so any width is correct.  Sized by the caller's bound on
+  // the point count (the tracker holds <= 16 regions x max_region_feature_num landmarks), rounded so that the XCD-aware
+  // renumbering stays a bijection (grid size a multiple of 8)
   int gx = nmax < 512 ? nmax : 512;
+  if (max_pts > 0 && max_pts < gx) gx = (max_pts + 7) & ~7;
+  if (gx > nmax) gx = nmax;
   hipLaunchKernelGGL(k_lk_track, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm,
                      active);
 }

@@ -1,8 +1,18 @@
 // flvis_amd: host orchestration of the batched front-end + local map behind the C ABI (include/flvis_hip.h).
 // Host-side mirror of the reference's F2FTracking / TrackingNodeletClass::process / LocalMapNodeletClass call sequence
 // (src/frontend/f2f_tracking.cpp:59-400, src/frontend/vo_tracking.cpp:326-371,396-430, src/backend/vo_localmap.cpp:87-380):
-// the host only stages IMU samples and enqueues a FIXED kernel sequence per frame on one HIP stream; every decision the
-// reference takes per frame is taken on the device by the kernels in track_kernels.hip / ba_kernels.hip.
+// the host only stages the per-frame inputs and enqueues a FIXED kernel sequence per frame; every decision the reference
+// takes per frame is taken on the device by the kernels in track_kernels.hip / ba_solve.hip.
+//
+// Lanes.  The per-frame chain of a stream is a recurrence of ~15 dependent kernels, most of them one workgroup per stream
+// (geometry on <= 240 landmarks): with all S streams of a tracker in ONE chain those kernels occupy S of the 256 CUs while
+// everything waits for them, and only the image kernels (LK, pyramids, corner response) fill the chip.  A tracker
+// therefore splits its streams into LANES (sub-batches): every lane owns its streams' state, its own HIP streams (tracking
+// chain + corner detection) and runs the same fixed sequence on its slice of the batch, so the LK of one lane overlaps the
+// geometry chain of the others.  Streams never interact, so the partition changes no result.  The
+// local-map workers of all lanes share two low-priority HIP streams (the number of hardware queues is limited: streams
+// beyond it share a queue and serialise behind each other's long kernels).
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -16,56 +26,77 @@
 
 namespace flvis {
 
-struct Pipeline {
-  int S = 0;
-  flvis_cfg cfg;
+constexpr int PROF_STAGES = 20;  // every stage has its own (begin, end) event pair on the stream it runs on
+static const char* kStageNames[PROF_STAGES] = {
+    "imu_feed+frame_begin", "ingest(equalize)", "pyr_down(left)", "track_prepare", "lk_track(temporal)", "track_collect",
+    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_cand", "gftt:(merged)", "gftt:pick",
+    "feature_dem+add_new", "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end",
+    "ba_worker(launch)", "frame(chain)"};
+
+// One sub-batch of streams [s0, s0 + S): all device state of those streams and the HIP streams their frames run on.
+struct Lane {
+  int s0 = 0, S = 0;
   Pipe pipe;
-  int levels_t = 0, levels_s = 0, levels = 0;
+  hipStream_t st = nullptr;  // tracking chain (the context's stream when the tracker has a single lane)
+  bool own_st = false;
   // images
   uint8_t* pyr0[2][LK_MAX_LEVELS] = {};
   uint8_t* pyr1[LK_MAX_LEVELS] = {};
-  int lw[LK_MAX_LEVELS], lh[LK_MAX_LEVELS], lpitch[LK_MAX_LEVELS];
-  size_t lstride[LK_MAX_LEVELS];
   GfttScratch gftt;
   float* gftt_xy = nullptr;
   int* gftt_n = nullptr;
   unsigned* eq_hist = nullptr;
   uint8_t* eq_lut = nullptr;
+  // per-frame inputs of the lane, uploaded as ONE block: [times S][imu S*IMU_MAX*7][input image bases 2][n_imu S]
+  uint8_t* d_inputs = nullptr;
   double* d_time = nullptr;
-  // host staging
-  std::vector<double> h_imu;  // [S][IMU_MAX][7]
+  const uint8_t** d_tab = nullptr;
+  size_t input_bytes = 0;
+  std::vector<double> h_imu;  // [S][IMU_MAX][7] staged between two frames
   std::vector<int> h_nimu;
-  // Host staging for the per-frame inputs (times, IMU samples, counts): a ring of pinned slots, each guarded by an event
-  // recorded after its upload, so that image_feed never has to wait for the previous frame -- the host then runs several
-  // frames ahead of the GPU and the ~45 launches of a frame are already queued when the GPU gets to them (with a per-frame
-  // stream synchronisation every short kernel was followed by a ~11 us launch bubble).
+  // Host staging: a ring of pinned slots, each guarded by an event recorded after its upload, so that image_feed never
+  // waits for the previous frame -- the host runs several frames ahead of the GPU and a frame's launches are already queued
+  // when the GPU gets to them.
   static constexpr int PIN_RING = 4;
   void* pinned[PIN_RING] = {};
   hipEvent_t ev_pin[PIN_RING] = {};
-  size_t pinned_bytes = 0;
-  long long frames_fed = 0;
   std::vector<void*> allocs;
-  // optional per-stage HIP-event timing (flvis_prof_enable)
-  std::vector<hipEvent_t> prof_ev;
-  int prof_cap = 0, prof_step = 0;
-  unsigned long long prof_mask = ~0ull;  // stages that record events (an event record costs a few us on the GPU queue)
-  // local map on its own HIP stream: the BA of frame N overlaps the front-end of frame N+1 (its output is never fed
-  // back into the tracker in the reference, src/frontend/vo_tracking.cpp:373-385).  Keyframe payloads are double-buffered.
-  // The local-map worker (k_ba_worker) is launched after every frame on one of NBA HIP streams (round-robin); it drains
-  // the per-stream keyframe queues (Pipe::kfq) that frame_end fills.  Launches overlap freely: a stream's window is owned
-  // by one workgroup at a time (Pipe::ba_busy), later launches leave it to the owner.
-  static constexpr int NBA = 4;  // local-map streams (upper bound of launches in flight)
-  int nba = 2;                   // streams in use (FLVIS_BA_STREAMS, tuning knob)
-  bool sync_each_frame = false;  // FLVIS_SYNC_EACH_FRAME=1: image_feed waits for the previous frame (tuning knob)
-  int ba_every = 1;              // launch the local-map worker every n-th frame (FLVIS_BA_EVERY): its workgroups need an
-                                 // empty CU each, also the ones that find nothing to do
-  hipStream_t ba_stream[NBA] = {};
+  std::vector<hipEvent_t> prof_ev;  // optional per-stage HIP-event timing (flvis_prof_enable)
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
-  hipEvent_t ev_img = nullptr, ev_det = nullptr;
-  hipEvent_t ev_fe[NBA] = {};
-  bool feedback_used = false;  // flvis_correction_feed was called: k_apply_correction runs after every frame_begin
+  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_fe = nullptr, ev_end = nullptr;
+  // back-pressure on the keyframe queues in stream order: ev_ba_done[i % BAQ] follows the lane's i-th local-map launch; the
+  // tracking stream waits for the launches of KFQ-3 frames ago before it appends new keyframes (see lane_frame)
+  static constexpr int BAQ = 32;
+  hipEvent_t ev_ba_done[BAQ] = {};
+  long long ba_launches = 0;
+};
+
+struct Pipeline {
+  int S = 0;
+  flvis_cfg cfg;
+  int lane_size = 0;
+  std::vector<Lane*> lanes;
+  int levels_t = 0, levels_s = 0, levels = 0;
+  int lw[LK_MAX_LEVELS], lh[LK_MAX_LEVELS], lpitch[LK_MAX_LEVELS];
+  size_t lstride[LK_MAX_LEVELS];
+  int max_pts = 0;  // bound on the landmarks of a frame (16 regions x max_region_feature_num): sizes the LK grid
+  long long frames_fed = 0;
+  std::vector<void*> allocs;  // context-level device allocations (host-feed staging)
+  int prof_cap = 0, prof_step = 0;
+  unsigned long long prof_mask = ~0ull;  // stages that record events (an event record costs a few us on the GPU queue)
+  // The local map runs beside the front-end: k_frame_end appends KeyFrame payloads to per-stream queues, k_ba_worker (one
+  // launch per lane and frame on one of the shared local-map streams, round-robin) drains them.  Its output is never fed
+  // back into the tracker in the reference (src/frontend/vo_tracking.cpp:373-385).
+  static constexpr int NBA = 4;
+  int nba = 2;                   // local-map streams in use (FLVIS_BA_STREAMS, tuning knob)
+  bool sync_each_frame = false;  // FLVIS_SYNC_EACH_FRAME=1: image_feed waits for the previous frame (tuning knob)
+  int ba_every = 1;              // launch the local-map worker every n-th frame (FLVIS_BA_EVERY)
+  hipStream_t ba_stream[NBA] = {};
+  long long ba_rr = 0;           // round-robin counter over the local-map streams
+  hipEvent_t ev_in = nullptr;    // the caller's inputs are ready (recorded on the context's stream)
+  bool feedback_used = false;    // flvis_correction_feed was called: k_apply_correction runs after every frame_begin
   // flvis_image_feed_host: double-buffered device staging filled by async H2D copies on a copy stream, so that the upload of
   // frame N+1 overlaps the kernels of frame N (allocated by the first call)
   struct HostFeed {
@@ -77,13 +108,12 @@ struct Pipeline {
     long long n = 0;
     std::vector<double> times;
   } hf;
+  Lane& lane_of(int stream, int& local) {
+    const int k = stream / lane_size;
+    local = stream - k * lane_size;
+    return *lanes[k];
+  }
 };
-constexpr int PROF_STAGES = 20;  // every stage has its own (begin, end) event pair on the stream it runs on
-static const char* kStageNames[PROF_STAGES] = {
-    "imu_feed+frame_begin", "ingest(copy/equalize)", "pyr_down x6", "track_prepare", "lk_track(temporal)", "track_collect",
-    "ransac_f", "ransac_pnp", "track_post+pose_lm", "reproj_filter", "gftt:eig_cand", "gftt:(merged)", "gftt:pick",
-    "feature_dem+add_new", "depth_prepare", "lk_track(stereo)", "depth_innovate", "frame_end",
-    "ba_worker(launch)", "frame(chain)"};
 
 }  // namespace flvis
 
@@ -92,11 +122,11 @@ using namespace flvis;
 namespace {
 
 template <typename T>
-T* dalloc(Pipeline* pl, size_t n, bool zero = true) {
+T* dalloc(std::vector<void*>& allocs, size_t n, bool zero = true) {
   void* p = nullptr;
   if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
   if (zero) hipMemset(p, 0, n * sizeof(T));
-  pl->allocs.push_back(p);
+  allocs.push_back(p);
   return (T*)p;
 }
 
@@ -176,6 +206,28 @@ void glibc_seed(unsigned s, int* r34) {
 
 }  // namespace
 
+
+static void lane_destroy(Lane* L) {
+  if (!L) return;
+  if (L->st) hipStreamSynchronize(L->st);
+  if (L->det_stream) {
+    hipStreamSynchronize(L->det_stream);
+    hipStreamDestroy(L->det_stream);
+  }
+  if (L->own_st && L->st) hipStreamDestroy(L->st);
+  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_fe, L->ev_end})
+    if (e) hipEventDestroy(e);
+  for (int k = 0; k < Lane::BAQ; k++)
+    if (L->ev_ba_done[k]) hipEventDestroy(L->ev_ba_done[k]);
+  for (void* p : L->allocs) hipFree(p);
+  for (hipEvent_t e : L->prof_ev) hipEventDestroy(e);
+  for (int k = 0; k < Lane::PIN_RING; k++) {
+    if (L->pinned[k]) hipHostFree(L->pinned[k]);
+    if (L->ev_pin[k]) hipEventDestroy(L->ev_pin[k]);
+  }
+  delete L;
+}
+
 static void sync_all(flvis_ctx* ctx);
 extern "C" void flvis_pipeline_sync_internal(flvis_ctx* ctx) {
   if (ctx && ctx->pipe) sync_all(ctx);
@@ -185,14 +237,10 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   if (!ctx || !ctx->pipe) return;
   Pipeline* pl = ctx->pipe;
   for (int k = 0; k < Pipeline::NBA; k++)
-    if (pl->ba_stream[k]) {
-      hipStreamSynchronize(pl->ba_stream[k]);
-      hipStreamDestroy(pl->ba_stream[k]);
-    }
-  if (pl->det_stream) {
-    hipStreamSynchronize(pl->det_stream);
-    hipStreamDestroy(pl->det_stream);
-  }
+    if (pl->ba_stream[k]) hipStreamSynchronize(pl->ba_stream[k]);
+  for (Lane* L : pl->lanes) lane_destroy(L);
+  for (int k = 0; k < Pipeline::NBA; k++)
+    if (pl->ba_stream[k]) hipStreamDestroy(pl->ba_stream[k]);
   if (pl->hf.strm) {
     hipStreamSynchronize(pl->hf.strm);
     hipStreamDestroy(pl->hf.strm);
@@ -201,40 +249,19 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
       if (pl->hf.ev_free[k]) hipEventDestroy(pl->hf.ev_free[k]);
     }
   }
-  if (pl->ev_img) hipEventDestroy(pl->ev_img);
-  if (pl->ev_det) hipEventDestroy(pl->ev_det);
-  for (int k = 0; k < Pipeline::NBA; k++) {
-    if (pl->ev_fe[k]) hipEventDestroy(pl->ev_fe[k]);
-  }
+  if (pl->ev_in) hipEventDestroy(pl->ev_in);
   for (void* p : pl->allocs) hipFree(p);
-  for (hipEvent_t e : pl->prof_ev) hipEventDestroy(e);
-  for (int k = 0; k < Pipeline::PIN_RING; k++) {
-    if (pl->pinned[k]) hipHostFree(pl->pinned[k]);
-    if (pl->ev_pin[k]) hipEventDestroy(pl->ev_pin[k]);
-  }
   delete pl;
   ctx->pipe = nullptr;
 }
 
-extern "C" {
-
-int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, uint64_t seed_base, int traj_capacity) {
-  if (!ctx || !cfg || n_streams <= 0) return FLVIS_ERR_INVALID_ARG;
-  if (ctx->pipe) flvis_pipeline_destroy_internal(ctx);
+// device state + streams of one lane; false on any allocation failure (the caller destroys the pipeline)
+static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, uint64_t seed_base, int traj_capacity, bool own_stream) {
+  const flvis_cfg* cfg = &pl->cfg;
   const int w = cfg->image_width, h = cfg->image_height;
-  if (w < 64 || h < 64 || (w & 15)) return ctx->fail(FLVIS_ERR_CONFIG, "image width must be a multiple of 16 and >= 64");
-  if (cfg->feature_para[5] > 64.0) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para6 (GFTT minDistance) > 64 is not supported");
-  if (cfg->window_size > BA_WMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "window_size exceeds the LDS-resident solver (16)");
-  if ((int)cfg->feature_para[3] * 2 > 2048) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para4 (gftt_num) must be <= 1024");
-  if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "image too large for the GFTT LDS bitmap");
-  if (cfg->cam_type == CAM_DEPTH && !(cfg->depth_factor > 0)) return ctx->fail(FLVIS_ERR_CONFIG, "depth mode needs depth_factor > 0");
-  hipSetDevice(ctx->device);
-  Pipeline* pl = new Pipeline();
-  ctx->pipe = pl;
-  const int S = n_streams;
-  pl->S = S;
-  pl->cfg = *cfg;
-  Pipe& p = pl->pipe;
+  L->s0 = s0;
+  L->S = S;
+  Pipe& p = L->pipe;
   memset(&p, 0, sizeof(p));
   p.S = S;
   CamParams& c = p.cam;
@@ -274,12 +301,10 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   c.seed = seed_base;
 
   bool ok = true;
-#define DA(field, T, n) ok = ok && ((p.field = dalloc<T>(pl, (n))) != nullptr)
+#define DA(field, T, n) ok = ok && ((p.field = dalloc<T>(L->allocs, (n))) != nullptr)
   DA(st, StreamState, S);
   DA(lm, Landmark, (size_t)2 * S * NMAX);
   DA(vi, MotionState, (size_t)S * VI_QUEUE);
-  DA(imu_in, double, (size_t)S * IMU_MAX * 7);
-  DA(n_imu, int, S);
   DA(prev_pts, float, (size_t)S * NMAX * 2);
   DA(next_pts, float, (size_t)S * NMAX * 2);
   DA(lk_status, uint8_t, (size_t)S * NMAX);
@@ -313,45 +338,41 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   DA(counters, long long, 64);
   p.ba_scratch_stride = ba_scratch_doubles();
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
-  unsigned long long* seeds = dalloc<unsigned long long>(pl, S);
+  unsigned long long* seeds = dalloc<unsigned long long>(L->allocs, S);
   ok = ok && seeds;
   p.seeds = seeds;
   p.traj_cap = traj_capacity > 0 ? traj_capacity : 0;
   if (p.traj_cap) DA(traj, double, (size_t)S * p.traj_cap * 9);
+#undef DA
+  // per-frame input block
+  const size_t off_imu = sizeof(double) * S, off_tab = off_imu + sizeof(double) * (size_t)S * IMU_MAX * 7,
+               off_n = off_tab + 2 * sizeof(void*);
+  L->input_bytes = off_n + sizeof(int) * S;
+  ok = ok && ((L->d_inputs = dalloc<uint8_t>(L->allocs, L->input_bytes)) != nullptr);
+  if (ok) {
+    L->d_time = reinterpret_cast<double*>(L->d_inputs);
+    p.imu_in = reinterpret_cast<double*>(L->d_inputs + off_imu);
+    L->d_tab = reinterpret_cast<const uint8_t**>(L->d_inputs + off_tab);
+    p.in_tab = L->d_tab;
+    p.n_imu = reinterpret_cast<int*>(L->d_inputs + off_n);
+  }
   // image pyramids
-  pl->levels_t = lk_levels(w, h, 31, 10);
-  pl->levels_s = lk_levels(w, h, 31, 5);
-  pl->levels = std::max(pl->levels_t, pl->levels_s);
-  if (pl->levels >= LK_MAX_LEVELS) pl->levels = LK_MAX_LEVELS - 1;
-  int lw = w, lh = h;
   for (int l = 0; l <= pl->levels; l++) {
-    pl->lw[l] = lw;
-    pl->lh[l] = lh;
-    pl->lpitch[l] = align_up(lw, 16);
-    pl->lstride[l] = (size_t)pl->lpitch[l] * lh + 64;
-    pl->lstride[l] = (pl->lstride[l] + 63) / 64 * 64;
-    for (int k = 0; k < 2; k++) ok = ok && ((pl->pyr0[k][l] = dalloc<uint8_t>(pl, pl->lstride[l] * S + 256)) != nullptr);
-    ok = ok && ((pl->pyr1[l] = dalloc<uint8_t>(pl, pl->lstride[l] * S + 256)) != nullptr);
-    lw = (lw + 1) / 2;
-    lh = (lh + 1) / 2;
+    for (int k = 0; k < 2; k++) ok = ok && ((L->pyr0[k][l] = dalloc<uint8_t>(L->allocs, pl->lstride[l] * S + 256)) != nullptr);
+    ok = ok && ((L->pyr1[l] = dalloc<uint8_t>(L->allocs, pl->lstride[l] * S + 256)) != nullptr);
   }
   // GFTT scratch
   int cap = 1;
   while (cap < (w / 2 + 1) * (h / 2 + 1)) cap <<= 1;
-  pl->gftt.cap = cap;
-  ok = ok && ((pl->gftt.maxenc = dalloc<unsigned>(pl, S)) != nullptr);
-  ok = ok && ((pl->gftt.nkeys = dalloc<int>(pl, S)) != nullptr);
-  ok = ok && ((pl->gftt.keys = dalloc<unsigned long long>(pl, (size_t)cap * S, false)) != nullptr);
-  ok = ok && ((pl->gftt_xy = dalloc<float>(pl, (size_t)S * 2 * c.gftt_num * 2)) != nullptr);
-  ok = ok && ((pl->gftt_n = dalloc<int>(pl, S)) != nullptr);
-  ok = ok && ((pl->eq_hist = dalloc<unsigned>(pl, (size_t)S * 256)) != nullptr);
-  ok = ok && ((pl->eq_lut = dalloc<uint8_t>(pl, (size_t)S * 256)) != nullptr);
-  ok = ok && ((pl->d_time = dalloc<double>(pl, S)) != nullptr);
-#undef DA
-  if (!ok) {
-    flvis_pipeline_destroy_internal(ctx);
-    return ctx->fail(FLVIS_ERR_HIP, "tracker_create: device allocation failed");
-  }
+  L->gftt.cap = cap;
+  ok = ok && ((L->gftt.maxenc = dalloc<unsigned>(L->allocs, S)) != nullptr);
+  ok = ok && ((L->gftt.nkeys = dalloc<int>(L->allocs, S)) != nullptr);
+  ok = ok && ((L->gftt.keys = dalloc<unsigned long long>(L->allocs, (size_t)cap * S, false)) != nullptr);
+  ok = ok && ((L->gftt_xy = dalloc<float>(L->allocs, (size_t)S * 2 * c.gftt_num * 2)) != nullptr);
+  ok = ok && ((L->gftt_n = dalloc<int>(L->allocs, S)) != nullptr);
+  ok = ok && ((L->eq_hist = dalloc<unsigned>(L->allocs, (size_t)S * 256)) != nullptr);
+  ok = ok && ((L->eq_lut = dalloc<uint8_t>(L->allocs, (size_t)S * 256)) != nullptr);
+  if (!ok) return false;
   // initial per-stream state (F2FTracking::init, VIMOTION ctor, landmark id counter 100, glibc rand seed 1)
   std::vector<StreamState> hs(S);
   memset(hs.data(), 0, sizeof(StreamState) * S);
@@ -368,21 +389,75 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     st.guess[6] = 1.0;
     glibc_seed(1, st.rnd_r);
     st.rnd_pos = 0;
-    hseed[s] = seed_base + (unsigned long long)s;
+    hseed[s] = seed_base + (unsigned long long)(s0 + s);  // the seed of a stream does not depend on the lane partition
   }
   hipMemcpy(p.st, hs.data(), sizeof(StreamState) * S, hipMemcpyHostToDevice);
   hipMemcpy(seeds, hseed.data(), sizeof(unsigned long long) * S, hipMemcpyHostToDevice);
-  pl->h_imu.assign((size_t)S * IMU_MAX * 7, 0.0);
-  pl->h_nimu.assign(S, 0);
-  pl->pinned_bytes = sizeof(double) * S + sizeof(double) * (size_t)S * IMU_MAX * 7 + sizeof(int) * S;
-  bool pinok = true;
-  for (int k = 0; k < Pipeline::PIN_RING && pinok; k++)
-    pinok = hipHostMalloc(&pl->pinned[k], pl->pinned_bytes, hipHostMallocDefault) == hipSuccess &&
-            hipEventCreateWithFlags(&pl->ev_pin[k], hipEventDisableTiming) == hipSuccess;
-  if (!pinok) {
-    flvis_pipeline_destroy_internal(ctx);
-    return ctx->fail(FLVIS_ERR_HIP, "tracker_create: pinned allocation failed");
+  L->h_imu.assign((size_t)S * IMU_MAX * 7, 0.0);
+  L->h_nimu.assign(S, 0);
+  for (int k = 0; k < Lane::PIN_RING; k++)
+    if (hipHostMalloc(&L->pinned[k], L->input_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&L->ev_pin[k], hipEventDisableTiming) != hipSuccess)
+      return false;
+  if (own_stream) {
+    if (hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking) != hipSuccess) return false;
+    L->own_st = true;
+  } else {
+    L->st = ctx->stream;
   }
+  bool evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_fe, &L->ev_end})
+    evok = evok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < Lane::BAQ && evok; k++)
+    evok = hipEventCreateWithFlags(&L->ev_ba_done[k], hipEventDisableTiming) == hipSuccess;
+  return evok;
+}
+
+extern "C" {
+
+int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, uint64_t seed_base, int traj_capacity) {
+  if (!ctx || !cfg || n_streams <= 0) return FLVIS_ERR_INVALID_ARG;
+  if (ctx->pipe) flvis_pipeline_destroy_internal(ctx);
+  const int w = cfg->image_width, h = cfg->image_height;
+  if (w < 64 || h < 64 || (w & 15)) return ctx->fail(FLVIS_ERR_CONFIG, "image width must be a multiple of 16 and >= 64");
+  if (cfg->feature_para[5] > 64.0) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para6 (GFTT minDistance) > 64 is not supported");
+  if (cfg->window_size > BA_WMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "window_size exceeds the LDS-resident solver (16)");
+  if ((int)cfg->feature_para[3] * 2 > 2048) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para4 (gftt_num) must be <= 1024");
+  if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "image too large for the GFTT LDS bitmap");
+  if (cfg->cam_type == CAM_DEPTH && !(cfg->depth_factor > 0)) return ctx->fail(FLVIS_ERR_CONFIG, "depth mode needs depth_factor > 0");
+  hipSetDevice(ctx->device);
+  Pipeline* pl = new Pipeline();
+  ctx->pipe = pl;
+  const int S = n_streams;
+  pl->S = S;
+  pl->cfg = *cfg;
+  pl->max_pts = std::min(NMAX, 16 * (int)cfg->feature_para[0]);
+  // pyramid geometry
+  pl->levels_t = lk_levels(w, h, 31, 10);
+  pl->levels_s = lk_levels(w, h, 31, 5);
+  pl->levels = std::max(pl->levels_t, pl->levels_s);
+  if (pl->levels >= LK_MAX_LEVELS) pl->levels = LK_MAX_LEVELS - 1;
+  int lw = w, lh = h;
+  for (int l = 0; l <= pl->levels; l++) {
+    pl->lw[l] = lw;
+    pl->lh[l] = lh;
+    pl->lpitch[l] = align_up(lw, 16);
+    pl->lstride[l] = (size_t)pl->lpitch[l] * lh + 64;
+    pl->lstride[l] = (pl->lstride[l] + 63) / 64 * 64;
+    lw = (lw + 1) / 2;
+    lh = (lh + 1) / 2;
+  }
+  // lanes: one by default.  Measured on MI355X with 64 streams (bench.py, round 2): 1 lane 1.67 ms per step, 2 lanes 2.23 ms,
+  // 4 lanes 2.94 ms -- a lane's one-workgroup-per-stream geometry kernels share their CUs with the other lanes' LK waves and
+  // slow down by more than the overlap gains.  FLVIS_LANES (1..16) is kept as a tuning knob.
+  int n_lanes = 1;
+  if (const char* e = getenv("FLVIS_LANES")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 16) n_lanes = v;
+  }
+  n_lanes = std::min(n_lanes, S);
+  pl->lane_size = (S + n_lanes - 1) / n_lanes;
+  n_lanes = (S + pl->lane_size - 1) / pl->lane_size;
   if (const char* e = getenv("FLVIS_BA_STREAMS")) {
     int v = atoi(e);
     if (v >= 1 && v <= Pipeline::NBA) pl->nba = v;
@@ -392,22 +467,24 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     int v = atoi(e);
     if (v >= 1 && v <= KFQ / 2) pl->ba_every = v;
   }
-  bool evok = true;
+  bool ok = true;
+  for (int k = 0; k < n_lanes && ok; k++) {
+    Lane* L = new Lane();
+    pl->lanes.push_back(L);
+    const int s0 = k * pl->lane_size;
+    ok = lane_create(ctx, pl, L, s0, std::min(pl->lane_size, S - s0), seed_base, traj_capacity, n_lanes > 1);
+  }
   // the local map must not displace the tracking chain: its streams get the lowest queue priority
   int prio_least = 0, prio_greatest = 0;
   hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   if (const char* e = getenv("FLVIS_BA_PRIORITY")) prio_least = atoi(e);  // tuning knob
-  for (int k = 0; k < Pipeline::NBA && evok; k++)
-    evok = hipStreamCreateWithPriority(&pl->ba_stream[k], hipStreamNonBlocking, prio_least) == hipSuccess;
-  evok = evok &&
-              hipStreamCreateWithFlags(&pl->det_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&pl->ev_img, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&pl->ev_det, hipEventDisableTiming) == hipSuccess;
-  for (int k = 0; k < Pipeline::NBA && evok; k++)
-    evok = hipEventCreateWithFlags(&pl->ev_fe[k], hipEventDisableTiming) == hipSuccess;
-  if (!evok) {
+  for (int k = 0; k < pl->nba && ok; k++)
+    ok = hipStreamCreateWithPriority(&pl->ba_stream[k], hipStreamNonBlocking, prio_least) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&pl->ev_in, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     flvis_pipeline_destroy_internal(ctx);
-    return ctx->fail(FLVIS_ERR_HIP, "tracker_create: cannot create the local-map stream/events");
+    (void)hipGetLastError();
+    return ctx->fail(FLVIS_ERR_HIP, "tracker_create: device / pinned allocation or stream creation failed");
   }
   if (ba_kernels_init() != hipSuccess) {
     (void)hipGetLastError();
@@ -422,9 +499,11 @@ int flvis_imu_feed_flvis_frame(flvis_ctx* ctx, int stream, int n, const double* 
   if (!ctx || !ctx->pipe || !samples7) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S || n < 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "imu_feed: bad stream");
-  int& cnt = pl->h_nimu[stream];
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  int& cnt = L.h_nimu[ls];
   if (cnt + n > IMU_MAX) return ctx->fail(FLVIS_ERR_CAPACITY, "imu_feed: more than 64 IMU samples between two frames");
-  memcpy(&pl->h_imu[((size_t)stream * IMU_MAX + cnt) * 7], samples7, sizeof(double) * 7 * n);
+  memcpy(&L.h_imu[((size_t)ls * IMU_MAX + cnt) * 7], samples7, sizeof(double) * 7 * n);
   cnt += n;
   return FLVIS_OK;
 }
@@ -450,10 +529,13 @@ int flvis_imu_feed(flvis_ctx* ctx, int stream, double t, const double* a, const 
   return flvis_imu_feed_flvis_frame(ctx, stream, 1, s);
 }
 
+
+}  // extern "C"
+
 static void fill_pyr(Pipeline* pl, PyrSel& ps, uint8_t* const* l0, uint8_t* const* l1, const int* cur, int flip, int levels) {
   ps.levels = levels;
   for (int l = 0; l <= levels; l++) {
-    ps.lvl[l] = ImgSel{{l0[l], l1 ? l1[l] : l0[l]}, cur, flip};
+    ps.lvl[l] = ImgSel{{l0[l], l1 ? l1[l] : l0[l]}, cur, flip, nullptr};
     ps.w[l] = pl->lw[l];
     ps.h[l] = pl->lh[l];
     ps.pitch[l] = pl->lpitch[l];
@@ -461,12 +543,16 @@ static void fill_pyr(Pipeline* pl, PyrSel& ps, uint8_t* const* l0, uint8_t* cons
   }
 }
 
-int flvis_prof_stage_count(void);
 static void sync_streams(flvis_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
+  Pipeline* pl = ctx->pipe;
+  if (!pl) return;
+  for (Lane* L : pl->lanes) {
+    hipStreamSynchronize(L->st);
+    hipStreamSynchronize(L->det_stream);
+  }
   for (int k = 0; k < Pipeline::NBA; k++)
-    if (ctx->pipe && ctx->pipe->ba_stream[k]) hipStreamSynchronize(ctx->pipe->ba_stream[k]);
-  if (ctx->pipe && ctx->pipe->det_stream) hipStreamSynchronize(ctx->pipe->det_stream);
+    if (pl->ba_stream[k]) hipStreamSynchronize(pl->ba_stream[k]);
 }
 // waits for everything that was enqueued AND for the local map to have consumed every queued keyframe (a keyframe that
 // slipped in while a worker workgroup was releasing its window is picked up by one more worker launch)
@@ -474,44 +560,53 @@ static void sync_all(flvis_ctx* ctx) {
   sync_streams(ctx);
   Pipeline* pl = ctx->pipe;
   if (!pl) return;
-  std::vector<unsigned> hd(pl->S), tl(pl->S);
-  for (int guard = 0; guard < 64; guard++) {
-    hipMemcpy(hd.data(), pl->pipe.kfq_head, sizeof(unsigned) * pl->S, hipMemcpyDeviceToHost);
-    hipMemcpy(tl.data(), pl->pipe.kfq_tail, sizeof(unsigned) * pl->S, hipMemcpyDeviceToHost);
-    bool pending = false;
-    for (int i = 0; i < pl->S; i++) pending = pending || hd[i] != tl[i];
-    if (!pending) break;
-    launch_ba_worker(pl->ba_stream[0], pl->pipe);
-    hipStreamSynchronize(pl->ba_stream[0]);
+  for (Lane* L : pl->lanes) {
+    std::vector<unsigned> hd(L->S), tl(L->S);
+    for (int guard = 0; guard < 64; guard++) {
+      hipMemcpy(hd.data(), L->pipe.kfq_head, sizeof(unsigned) * L->S, hipMemcpyDeviceToHost);
+      hipMemcpy(tl.data(), L->pipe.kfq_tail, sizeof(unsigned) * L->S, hipMemcpyDeviceToHost);
+      bool pending = false;
+      for (int i = 0; i < L->S; i++) pending = pending || hd[i] != tl[i];
+      if (!pending) break;
+      launch_ba_worker(pl->ba_stream[0], L->pipe);
+      hipStreamSynchronize(pl->ba_stream[0]);
+    }
   }
 }
 
-int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
-                     flvis_frame_out* h_out, int with_local_map) {
-  if (!ctx || !ctx->pipe || !d_img0 || !d_img1 || !h_times) return FLVIS_ERR_INVALID_ARG;
-  Pipeline* pl = ctx->pipe;
-  Pipe& p = pl->pipe;
-  const int S = pl->S;
-  hipStream_t st = ctx->stream;
+// One frame of one lane: stages the lane's host inputs, uploads them as one block and enqueues the fixed kernel sequence
+// on the lane's streams.  d_img0 / d_img1 already point at the lane's first stream.
+static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
+                       int with_local_map) {
+  Pipe& p = L->pipe;
+  const int S = L->S;
+  hipStream_t st = L->st;
   const int w = pl->cfg.image_width, h = pl->cfg.image_height;
-  // ---- stage host inputs (pinned) and upload
-  const int pslot = (int)(pl->frames_fed % Pipeline::PIN_RING);
-  double* pt = (double*)pl->pinned[pslot];
-  double* pi = pt + S;
-  int* pn = (int*)(pi + (size_t)S * IMU_MAX * 7);
+  // ---- stage host inputs (pinned) and upload: [times][imu][input image bases][n_imu]
+  const int pslot = (int)(pl->frames_fed % Lane::PIN_RING);
+  uint8_t* pin = (uint8_t*)L->pinned[pslot];
   if (pl->sync_each_frame) hipStreamSynchronize(st);
-  if (pl->frames_fed >= Pipeline::PIN_RING) hipEventSynchronize(pl->ev_pin[pslot]);  // upload of frame N-PIN_RING is done
+  if (pl->frames_fed >= Lane::PIN_RING) hipEventSynchronize(L->ev_pin[pslot]);  // upload of frame N-PIN_RING is done
+  double* pt = (double*)pin;
+  double* pi = pt + S;
+  const uint8_t** ptab = (const uint8_t**)(pi + (size_t)S * IMU_MAX * 7);
+  int* pn = (int*)(ptab + 2);
   memcpy(pt, h_times, sizeof(double) * S);
-  memcpy(pi, pl->h_imu.data(), sizeof(double) * (size_t)S * IMU_MAX * 7);
-  memcpy(pn, pl->h_nimu.data(), sizeof(int) * S);
-  std::fill(pl->h_nimu.begin(), pl->h_nimu.end(), 0);
-  hipMemcpyAsync(pl->d_time, pt, sizeof(double) * S, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(p.imu_in, pi, sizeof(double) * (size_t)S * IMU_MAX * 7, hipMemcpyHostToDevice, st);
-  hipMemcpyAsync(p.n_imu, pn, sizeof(int) * S, hipMemcpyHostToDevice, st);
-  hipEventRecord(pl->ev_pin[pslot], st);
+  // only the staged samples travel (the block keeps its layout: [S][IMU_MAX][7])
+  int max_n = 0;
+  for (int s = 0; s < S; s++) max_n = std::max(max_n, L->h_nimu[s]);
+  for (int s = 0; s < S; s++)
+    memcpy(pi + (size_t)s * IMU_MAX * 7, &L->h_imu[(size_t)s * IMU_MAX * 7], sizeof(double) * 7 * L->h_nimu[s]);
+  (void)max_n;
+  ptab[0] = d_img0;
+  ptab[1] = d_img1;
+  memcpy(pn, L->h_nimu.data(), sizeof(int) * S);
+  std::fill(L->h_nimu.begin(), L->h_nimu.end(), 0);
+  hipMemcpyAsync(L->d_inputs, pin, L->input_bytes, hipMemcpyHostToDevice, st);
+  hipEventRecord(L->ev_pin[pslot], st);
   // ---- fixed kernel sequence
   const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
-  hipEvent_t* pev = prof ? &pl->prof_ev[(size_t)pl->prof_step * (2 * PROF_STAGES)] : nullptr;
+  hipEvent_t* pev = prof ? &L->prof_ev[(size_t)pl->prof_step * (2 * PROF_STAGES)] : nullptr;
 #define PB(i, strm) \
   if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i)], strm)
 #define PE(i, strm) \
@@ -519,71 +614,62 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PB(19, st);  // the whole main-stream chain of this frame: per-frame GPU latency (p50/p99 in bench.py)
   PB(0, st);
   launch_imu_feed(st, p);
-  launch_frame_begin(st, p, pl->d_time);
+  launch_frame_begin(st, p, L->d_time);
   if (pl->feedback_used) launch_apply_correction(st, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
   PE(0, st);
   if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
     PB(17, st);
-    launch_frame_end(st, p, (int)pl->frames_fed);
+    launch_frame_end(st, p);
     PE(17, st);
     PE(19, st);
-    if (prof) {
+    if (prof)
       for (int i = 1; i < PROF_STAGES; i++)
         if (i != 17 && i != 19) {
           PB(i, st);
           PE(i, st);
         }
-      pl->prof_step++;
-    }
-    pl->frames_fed++;
-    hipError_t e0 = hipGetLastError();
-    if (e0 != hipSuccess) return ctx->hip_fail(e0, "image_feed launch");
-    if (h_out) {
-      e0 = hipMemcpyAsync(h_out, p.out, sizeof(FrameOut) * S, hipMemcpyDeviceToHost, st);
-      if (e0 == hipSuccess) e0 = hipStreamSynchronize(st);
-      if (e0 != hipSuccess) return ctx->hip_fail(e0, "image_feed readback");
-    }
-    return FLVIS_OK;
+    return;
   }
-  // images -> level 0 of the stream's current slot (copy, or equalizeHist for EuRoC), then the pyramids
-  ImgSel in0 = img_plain(d_img0), in1 = img_plain(d_img1);
-  ImgSel l0cur{{pl->pyr0[0][0], pl->pyr0[1][0]}, p.img_slot, 0};
-  ImgSel l1cur = img_plain(pl->pyr1[0]);
+  const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
+  const bool eq = pl->cfg.need_equal_hist != 0;
+  // left image -> level 0 of the stream's current slot (+ the pyramid).  Without equalizeHist the first pyrDown reads the
+  // caller's image and writes level 0 and level 1 in one pass; with it the equalised image is level 0.
+  ImgSel in0 = img_indirect(L->d_tab + 0), in1 = img_indirect(L->d_tab + 1);
+  ImgSel l0cur{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot, 0, nullptr};
   PB(1, st);
-  if (pl->cfg.need_equal_hist) {
-    launch_equalize_hist(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
-  } else {
-    launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
-  }
+  if (eq) launch_equalize_hist(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
   PE(1, st);
   PB(2, st);
   for (int l = 1; l <= pl->levels; l++) {  // left pyramid: needed by the temporal tracker right away
-    ImgSel s0{{pl->pyr0[0][l - 1], pl->pyr0[1][l - 1]}, p.img_slot, 0}, d0{{pl->pyr0[0][l], pl->pyr0[1][l]}, p.img_slot, 0};
-    launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
+    ImgSel s0{{L->pyr0[0][l - 1], L->pyr0[1][l - 1]}, p.img_slot, 0, nullptr}, d0{{L->pyr0[0][l], L->pyr0[1][l]}, p.img_slot, 0, nullptr};
+    if (l == 1 && !eq)
+      launch_pyr_down_ingest(st, in0, w, h, w, (size_t)w * h, l0cur, pl->lpitch[0], pl->lstride[0], d0, pl->lpitch[1], pl->lstride[1], S, p.act_img);
+    else
+      launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
   }
+  if (pl->levels == 0 && !eq) launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
   PE(2, st);
-  // fork: the right image (ingest + pyramid, first used by the stereo matcher) and the corner detection of the new left
-  // image (speculative for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain
-  hipStream_t ds = pl->det_stream;
-  hipEventRecord(pl->ev_img, st);
-  hipStreamWaitEvent(ds, pl->ev_img, 0);
-  const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
-  p.depth_img = depth_cam ? reinterpret_cast<const uint16_t*>(d_img1) : nullptr;
-  if (depth_cam) {
-  } else if (pl->cfg.need_equal_hist) {
-    launch_equalize_hist(ds, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, pl->eq_hist, pl->eq_lut, p.act_img);
-  } else {
-    launch_copy_image(ds, in1, l1cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
+  // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
+  // for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain.  The right image is only
+  // read within this frame, so without equalizeHist the caller's buffer IS level 0 of the right pyramid (no copy).
+  hipStream_t ds = L->det_stream;
+  hipEventRecord(L->ev_img, st);
+  hipStreamWaitEvent(ds, L->ev_img, 0);
+  ImgSel r0 = eq ? img_plain(L->pyr1[0]) : in1;
+  const int r0pitch = eq ? pl->lpitch[0] : w;
+  const size_t r0stride = eq ? pl->lstride[0] : (size_t)w * h;
+  if (!depth_cam) {
+    if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
+    for (int l = 1; l <= pl->levels; l++)
+      launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
+                      l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
   }
-  for (int l = 1; l <= pl->levels && !depth_cam; l++)
-    launch_pyr_down(ds, img_plain(pl->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1],
-                    img_plain(pl->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
-  launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, pl->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
-              (double)p.cam.gftt_dis, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
+  launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
+              (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
               (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
-  hipEventRecord(pl->ev_det, ds);
+  hipEventRecord(L->ev_det, ds);
   // temporal tracking
   PB(3, st);
   launch_track_prepare(st, p);
@@ -591,10 +677,10 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PB(4, st);
   {
     PyrSel prev, next;
-    fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 1, pl->levels_t);
-    fill_pyr(pl, next, pl->pyr0[0], pl->pyr0[1], p.img_slot, 0, pl->levels_t);
+    fill_pyr(pl, prev, L->pyr0[0], L->pyr0[1], p.img_slot, 1, pl->levels_t);
+    fill_pyr(pl, next, L->pyr0[0], L->pyr0[1], p.img_slot, 0, pl->levels_t);
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
-    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track);
+    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track, pl->max_pts);
   }
   PE(4, st);
   PB(5, st);
@@ -614,9 +700,9 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   launch_reproj_filter(st, p);
   PE(9, st);
   // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners
-  hipStreamWaitEvent(st, pl->ev_det, 0);
+  hipStreamWaitEvent(st, L->ev_det, 0);
   PB(13, st);
-  launch_feature_dem(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, pl->gftt_xy, pl->gftt_n, 2 * p.cam.gftt_num,
+  launch_feature_dem(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
                      p.det_mode, p.exist_xy, p.n_exist, NMAX, p.new_xy, p.n_new, NEW_MAX);
   launch_add_new(st, p);
   PE(13, st);
@@ -627,27 +713,42 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   PB(15, st);
   if (!depth_cam) {
     PyrSel prev, next;
-    fill_pyr(pl, prev, pl->pyr0[0], pl->pyr0[1], p.img_slot, 0, pl->levels_s);
-    fill_pyr(pl, next, pl->pyr1, nullptr, nullptr, 0, pl->levels_s);
+    fill_pyr(pl, prev, L->pyr0[0], L->pyr0[1], p.img_slot, 0, pl->levels_s);
+    fill_pyr(pl, next, L->pyr1, nullptr, nullptr, 0, pl->levels_s);
+    next.lvl[0] = r0;
+    next.pitch[0] = r0pitch;
+    next.stride[0] = r0stride;
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
-    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode);
+    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts);
   }
   PE(15, st);
   PB(16, st);
   launch_depth_innovate(st, p);
   PE(16, st);
-  const int par = (int)((pl->frames_fed / pl->ba_every) % pl->nba);
+  if (with_local_map) {
+    // Keyframe-queue back-pressure, expressed in stream order (never by spinning inside a kernel): once every local-map
+    // launch of this lane up to index j has finished, the keyframes of all frames up to j*ba_every are consumed (a launch
+    // drains the queues of the windows it owns; a window owned by an earlier launch is drained by that one), so waiting
+    // for the launches of D frames ago bounds the backlog of a stream by (D + 2) * ba_every <= KFQ keyframes.
+    const long long D = std::max(0, KFQ / pl->ba_every - 3);
+    for (int k = 0; k < pl->nba; k++) {
+      const long long j = L->ba_launches - 1 - D - k;
+      if (j >= 0 && L->ba_launches - j <= Lane::BAQ) hipStreamWaitEvent(st, L->ev_ba_done[j % Lane::BAQ], 0);
+    }
+  }
   PB(17, st);
-  launch_frame_end(st, p, (int)pl->frames_fed);
+  launch_frame_end(st, p);
   PE(17, st);
   PE(19, st);
   if (with_local_map && (pl->frames_fed % pl->ba_every) == 0) {
-    hipStream_t bs = pl->ba_stream[par];
-    hipEventRecord(pl->ev_fe[par], st);
-    hipStreamWaitEvent(bs, pl->ev_fe[par], 0);
+    hipStream_t bs = pl->ba_stream[pl->ba_rr++ % pl->nba];
+    hipEventRecord(L->ev_fe, st);
+    hipStreamWaitEvent(bs, L->ev_fe, 0);
     PB(18, bs);
     launch_ba_worker(bs, p);
     PE(18, bs);
+    hipEventRecord(L->ev_ba_done[L->ba_launches % Lane::BAQ], bs);
+    L->ba_launches++;
   } else if (!with_local_map) {
     // without a local map nobody consumes the keyframe queue: drop what frame_end appended
     hipMemcpyAsync(p.kfq_head, p.kfq_tail, sizeof(unsigned) * S, hipMemcpyDeviceToDevice, st);
@@ -658,15 +759,44 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   }
 #undef PB
 #undef PE
+}
+
+extern "C" {
+
+int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img1, const double* h_times,
+                     flvis_frame_out* h_out, int with_local_map) {
+  if (!ctx || !ctx->pipe || !d_img0 || !d_img1 || !h_times) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  hipSetDevice(ctx->device);
+  const size_t img_px = (size_t)pl->cfg.image_width * pl->cfg.image_height;
+  const size_t img1_bytes = img_px * (pl->cfg.cam_type == CAM_DEPTH ? 2 : 1);
+  const bool multi = pl->lanes.size() > 1;
+  // the caller's images were produced on the context's stream; lanes with their own streams wait for them, and the
+  // context's stream waits for the lanes afterwards, so that the caller may recycle its buffers in stream order
+  if (multi) hipEventRecord(pl->ev_in, ctx->stream);
+  for (Lane* L : pl->lanes) {
+    if (multi) hipStreamWaitEvent(L->st, pl->ev_in, 0);
+    lane_frame(ctx, pl, L, d_img0 + (size_t)L->s0 * img_px, d_img1 + (size_t)L->s0 * img1_bytes, h_times + L->s0, with_local_map);
+    if (multi) {
+      hipEventRecord(L->ev_end, L->st);
+      hipStreamWaitEvent(ctx->stream, L->ev_end, 0);
+    }
+  }
+  const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
   if (prof) pl->prof_step++;
   pl->frames_fed++;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ctx->hip_fail(e, "image_feed launch");
   if (h_out) {
     static_assert(sizeof(flvis_frame_out) == sizeof(FrameOut), "FrameOut layout");
-    e = hipMemcpyAsync(h_out, p.out, sizeof(FrameOut) * S, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return ctx->hip_fail(e, "image_feed readback");
+    for (Lane* L : pl->lanes) {
+      e = hipMemcpyAsync(h_out + L->s0, L->pipe.out, sizeof(FrameOut) * L->S, hipMemcpyDeviceToHost, L->st);
+      if (e != hipSuccess) return ctx->hip_fail(e, "image_feed readback");
+    }
+    for (Lane* L : pl->lanes) {
+      e = hipStreamSynchronize(L->st);
+      if (e != hipSuccess) return ctx->hip_fail(e, "image_feed readback");
+    }
   }
   return FLVIS_OK;
 }
@@ -708,14 +838,14 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
       hipStreamSynchronize(hf.strm);
       hipStreamSynchronize(ctx->stream);
       for (int k = 0; k < 2; k++)
-        if (!(hf.raw[k][c] = dalloc<uint8_t>(pl, need, false))) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: device allocation failed");
+        if (!(hf.raw[k][c] = dalloc<uint8_t>(pl->allocs, need, false))) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: device allocation failed");
       hf.raw_bytes[c] = need;
     }
   }
   if ((ch0 > 1 || (ch1 > 1 && !depth_cam)) && hf.gray_bytes < npix + 256) {
     for (int k = 0; k < 2; k++)
       for (int c = 0; c < 2; c++)
-        if (!(hf.gray[k][c] = dalloc<uint8_t>(pl, npix + 256, false))) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: device allocation failed");
+        if (!(hf.gray[k][c] = dalloc<uint8_t>(pl->allocs, npix + 256, false))) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: device allocation failed");
     hf.gray_bytes = npix + 256;
   }
   const int slot = (int)(hf.n & 1);
@@ -762,6 +892,7 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   return FLVIS_OK;
 }
 
+
 int flvis_imu_feed_all(flvis_ctx* ctx, const int* h_counts, const double* h_samples, int samples_per_stream) {
   if (!ctx || !ctx->pipe || !h_counts || !h_samples || samples_per_stream <= 0) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
@@ -781,46 +912,62 @@ int flvis_prof_enable_stages(flvis_ctx* ctx, int max_steps, uint64_t stage_mask)
   Pipeline* pl = ctx->pipe;
   pl->prof_mask = stage_mask;
   sync_all(ctx);
-  for (hipEvent_t e : pl->prof_ev) hipEventDestroy(e);
-  pl->prof_ev.clear();
   pl->prof_cap = max_steps;
   pl->prof_step = 0;
-  pl->prof_ev.resize((size_t)max_steps * (2 * PROF_STAGES));
-  for (auto& e : pl->prof_ev)
-    if (hipEventCreate(&e) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
+  for (Lane* L : pl->lanes) {
+    for (hipEvent_t e : L->prof_ev) hipEventDestroy(e);
+    L->prof_ev.clear();
+    L->prof_ev.resize((size_t)max_steps * (2 * PROF_STAGES));
+    for (auto& e : L->prof_ev)
+      if (hipEventCreate(&e) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
+  }
   return FLVIS_OK;
 }
 
 int flvis_prof_stage_count(void) { return PROF_STAGES; }
 const char* flvis_prof_stage_name(int i) { return (i >= 0 && i < PROF_STAGES) ? kStageNames[i] : ""; }
+int flvis_tracker_lanes(flvis_ctx* ctx) { return (ctx && ctx->pipe) ? (int)ctx->pipe->lanes.size() : 0; }
 
+static bool prof_stage_timed(const Pipeline* pl, int i) {
+  if (!((pl->prof_mask >> i) & 1ull)) return false;
+  if (i >= 10 && i <= 12 && ((pl->prof_mask >> 10) & 7ull) != 7ull) return false;  // the GFTT chain is timed as a whole
+  return true;
+}
+
+// per stage: the elapsed time of one LAUNCH (one lane's kernel(s) of that stage), summed over the armed frames and averaged
+// over the lanes -- with several lanes the stages of different lanes overlap, so the sum over stages exceeds the step time
 int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps) {
   if (!ctx || !ctx->pipe || !h_ms_per_stage || !n_steps) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
   sync_all(ctx);
   for (int i = 0; i < PROF_STAGES; i++) h_ms_per_stage[i] = 0;
-  for (int k = 0; k < pl->prof_step; k++)
-    for (int i = 0; i < PROF_STAGES; i++) {
-      float ms = 0;
-      if (!((pl->prof_mask >> i) & 1ull)) continue;
-      if (i >= 10 && i <= 12 && ((pl->prof_mask >> 10) & 7ull) != 7ull) continue;  // the GFTT chain is timed as a whole
-      hipEventElapsedTime(&ms, pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i], pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i + 1]);
-      h_ms_per_stage[i] += ms;
-    }
+  for (Lane* L : pl->lanes)
+    for (int k = 0; k < pl->prof_step; k++)
+      for (int i = 0; i < PROF_STAGES; i++) {
+        float ms = 0;
+        if (!prof_stage_timed(pl, i)) continue;
+        hipEventElapsedTime(&ms, L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i], L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i + 1]);
+        h_ms_per_stage[i] += ms / (double)pl->lanes.size();
+      }
   *n_steps = pl->prof_step;
   return FLVIS_OK;
 }
 
+// per armed frame: the slowest lane's elapsed time of the stage
 int flvis_prof_read_steps(flvis_ctx* ctx, int stage, double* h_ms, int cap) {
   if (!ctx || !ctx->pipe || !h_ms || stage < 0 || stage >= PROF_STAGES || cap < 0) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
-  if (!((pl->prof_mask >> stage) & 1ull)) return ctx->fail(FLVIS_ERR_INVALID_ARG, "prof_read_steps: stage was not enabled");
+  if (!prof_stage_timed(pl, stage)) return ctx->fail(FLVIS_ERR_INVALID_ARG, "prof_read_steps: stage was not enabled");
   sync_all(ctx);
   int n = 0;
   for (int k = 0; k < pl->prof_step && n < cap; k++, n++) {
-    float ms = 0;
-    hipEventElapsedTime(&ms, pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage], pl->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage + 1]);
-    h_ms[n] = ms;
+    double worst = 0;
+    for (Lane* L : pl->lanes) {
+      float ms = 0;
+      hipEventElapsedTime(&ms, L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage], L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage + 1]);
+      worst = std::max(worst, (double)ms);
+    }
+    h_ms[n] = worst;
   }
   return n;
 }
@@ -831,11 +978,13 @@ int flvis_get_landmarks(flvis_ctx* ctx, int stream, int cap, int64_t* h_id, doub
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
   sync_all(ctx);
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
   StreamState st;
-  hipMemcpy(&st, pl->pipe.st + stream, sizeof(st), hipMemcpyDeviceToHost);
+  hipMemcpy(&st, L.pipe.st + ls, sizeof(st), hipMemcpyDeviceToHost);
   int n = st.n_lm[st.cur];
   std::vector<Landmark> lm(n);
-  if (n) hipMemcpy(lm.data(), pl->pipe.lm + ((size_t)st.cur * pl->S + stream) * NMAX, sizeof(Landmark) * n, hipMemcpyDeviceToHost);
+  if (n) hipMemcpy(lm.data(), L.pipe.lm + ((size_t)st.cur * L.S + ls) * NMAX, sizeof(Landmark) * n, hipMemcpyDeviceToHost);
   for (int i = 0; i < n && i < cap; i++) {
     h_id[i] = lm[i].id;
     h_2d[2 * i] = lm[i].p2d[0];
@@ -854,15 +1003,17 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
   sync_all(ctx);
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
   std::vector<KeyFrameDev> kfv(1);
   KeyFrameDev& kf = kfv[0];
   FrameOut fo;
-  hipMemcpy(&fo, pl->pipe.out + stream, sizeof(FrameOut), hipMemcpyDeviceToHost);
+  hipMemcpy(&fo, L.pipe.out + ls, sizeof(FrameOut), hipMemcpyDeviceToHost);
   if (!fo.new_keyframe) return 0;  // the last frame of this stream did not become a keyframe
   unsigned tl = 0;
-  hipMemcpy(&tl, pl->pipe.kfq_tail + stream, sizeof(unsigned), hipMemcpyDeviceToHost);
+  hipMemcpy(&tl, L.pipe.kfq_tail + ls, sizeof(unsigned), hipMemcpyDeviceToHost);
   if (tl == 0) return 0;
-  hipMemcpy(&kf, pl->pipe.kfq + (size_t)stream * KFQ + ((tl - 1) % KFQ), sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
+  hipMemcpy(&kf, L.pipe.kfq + (size_t)ls * KFQ + ((tl - 1) % KFQ), sizeof(KeyFrameDev), hipMemcpyDeviceToHost);
   *frame_id = kf.frame_id;
   memcpy(T7, kf.T_c_w, 56);
   for (int i = 0; i < kf.lm_count && i < cap; i++) {
@@ -874,12 +1025,11 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
   return kf.lm_count;
 }
 
-static int read_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T7, int* lm_count, int64_t* h_id,
+static int read_correction(Lane& L, int ls, int cap, int64_t* frame_id, double* T7, int* lm_count, int64_t* h_id,
                            double* h_3d, int* oc, int64_t* h_oid) {
-  Pipeline* pl = ctx->pipe;
   std::vector<CorrectionDev> cv(1);
   CorrectionDev& c = cv[0];
-  hipMemcpy(&c, pl->pipe.corr + stream, sizeof(CorrectionDev), hipMemcpyDeviceToHost);
+  hipMemcpy(&c, L.pipe.corr + ls, sizeof(CorrectionDev), hipMemcpyDeviceToHost);
   if (!c.valid) return 0;
   *frame_id = c.frame_id;
   memcpy(T7, c.T_c_w, 56);
@@ -898,16 +1048,20 @@ int flvis_get_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id,
   if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
   if (stream < 0 || stream >= ctx->pipe->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
   sync_all(ctx);
-  return read_correction(ctx, stream, cap, frame_id, T7, lm_count, h_id, h_3d, oc, h_oid);
+  int ls;
+  Lane& L = ctx->pipe->lane_of(stream, ls);
+  return read_correction(L, ls, cap, frame_id, T7, lm_count, h_id, h_3d, oc, h_oid);
 }
 
 int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first, int n, double* h_rows9) {
   if (!ctx || !ctx->pipe || !h_rows9) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
-  if (stream < 0 || stream >= pl->S || first < 0 || n < 0 || first + n > pl->pipe.traj_cap)
-    return ctx->fail(FLVIS_ERR_INVALID_ARG, "get_trajectory: out of range");
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "get_trajectory: out of range");
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  if (first < 0 || n < 0 || first + n > L.pipe.traj_cap) return ctx->fail(FLVIS_ERR_INVALID_ARG, "get_trajectory: out of range");
   sync_all(ctx);
-  hipMemcpy(h_rows9, pl->pipe.traj + ((size_t)stream * pl->pipe.traj_cap + first) * 9, sizeof(double) * 9 * n, hipMemcpyDeviceToHost);
+  hipMemcpy(h_rows9, L.pipe.traj + ((size_t)ls * L.pipe.traj_cap + first) * 9, sizeof(double) * 9 * n, hipMemcpyDeviceToHost);
   return n;
 }
 
@@ -919,21 +1073,21 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first, int n, const c
   FILE* f = fopen(path, "w");
   if (!f) return ctx->fail(FLVIS_ERR_INVALID_ARG, "write_trajectory: cannot open the output file");
   int written = 0;
-  bool have_last = false;
-  double last_t = 0;
+  bool have_first = false;
+  double first_t = 0;
   for (int i = 0; i < got; i++) {
     const double* r = &rows[(size_t)i * 9];
     if (((int)r[8] & 15) != 1) continue;  // only frames of a TRACKING stream carry a pose
     const double t = r[0];
     if (min_dt > 0) {
-      if (!have_last) {  // the reference's throttle starts its clock at the first call
-        have_last = true;
-        last_t = t;
-        continue;
+      // vo_repub_rec.cpp:77-78: `last_time` is a function-static initialised at the FIRST call and never updated, so the
+      // recorder drops the poses of the first min_dt (0.1 s of wall clock there, stamps here) and writes every pose after
+      if (!have_first) {
+        have_first = true;
+        first_t = t;
       }
-      if (!(t - last_t > min_dt)) continue;
+      if (!(t - first_t > min_dt)) continue;
     }
-    last_t = t;
     // T_c_w = (t, q) -> T_w_c: R_w_c = R^T, centre = -R^T t
     double qx = r[4], qy = r[5], qz = r[6], qw = r[7];
     const double qn = std::sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
@@ -956,21 +1110,31 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first, int n, const c
   return written;
 }
 
+
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) {
   if (!ctx || !ctx->pipe || !h3) return FLVIS_ERR_INVALID_ARG;
   sync_all(ctx);
-  long long c[8];
-  hipMemcpy(c, ctx->pipe->pipe.counters, sizeof(c), hipMemcpyDeviceToHost);
   h3[0] = ctx->pipe->frames_fed * ctx->pipe->S;
-  h3[1] = c[1];
-  h3[2] = c[2];
+  h3[1] = h3[2] = 0;
+  for (Lane* L : ctx->pipe->lanes) {
+    long long c[8];
+    hipMemcpy(c, L->pipe.counters, sizeof(c), hipMemcpyDeviceToHost);
+    h3[1] += c[1];
+    h3[2] += c[2];
+  }
   return FLVIS_OK;
 }
 
+// sums over the lanes; [3] = keyframes dropped because a stream's queue was full (0 unless the back-pressure was defeated)
 int flvis_debug_counters(flvis_ctx* ctx, int64_t* h64) {
   if (!ctx || !ctx->pipe || !h64) return FLVIS_ERR_INVALID_ARG;
   sync_all(ctx);
-  hipMemcpy(h64, ctx->pipe->pipe.counters, sizeof(long long) * 64, hipMemcpyDeviceToHost);
+  for (int i = 0; i < 64; i++) h64[i] = 0;
+  for (Lane* L : ctx->pipe->lanes) {
+    long long c[64];
+    hipMemcpy(c, L->pipe.counters, sizeof(c), hipMemcpyDeviceToHost);
+    for (int i = 0; i < 64; i++) h64[i] += c[i];
+  }
   return FLVIS_OK;
 }
 
@@ -980,6 +1144,8 @@ int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const d
   if (!ctx || !ctx->pipe || !T7 || lm_count < 0 || lm_count > KF_MAXLM) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
   std::vector<KeyFrameDev> kfv(1);
   KeyFrameDev& kf = kfv[0];
   memset(&kf, 0, sizeof(kf));
@@ -996,16 +1162,16 @@ int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const d
   sync_all(ctx);
   const int zero = 0;
   unsigned tl = 0;
-  hipMemcpy(&tl, pl->pipe.kfq_tail + stream, sizeof(unsigned), hipMemcpyDeviceToHost);
-  hipMemcpy(pl->pipe.kfq + (size_t)stream * KFQ + (tl % KFQ), &kf, sizeof(kf), hipMemcpyHostToDevice);
+  hipMemcpy(&tl, L.pipe.kfq_tail + ls, sizeof(unsigned), hipMemcpyDeviceToHost);
+  hipMemcpy(L.pipe.kfq + (size_t)ls * KFQ + (tl % KFQ), &kf, sizeof(kf), hipMemcpyHostToDevice);
   tl++;
-  hipMemcpy(pl->pipe.kfq_tail + stream, &tl, sizeof(unsigned), hipMemcpyHostToDevice);
-  hipMemcpy(&pl->pipe.corr[stream].valid, &zero, sizeof(int), hipMemcpyHostToDevice);
-  launch_ba_worker(pl->ba_stream[0], pl->pipe);
+  hipMemcpy(L.pipe.kfq_tail + ls, &tl, sizeof(unsigned), hipMemcpyHostToDevice);
+  hipMemcpy(&L.pipe.corr[ls].valid, &zero, sizeof(int), hipMemcpyHostToDevice);
+  launch_ba_worker(pl->ba_stream[0], L.pipe);
   hipError_t e = hipStreamSynchronize(pl->ba_stream[0]);
   if (e != hipSuccess) return ctx->hip_fail(e, "ba_push_keyframe");
   sync_all(ctx);
-  return read_correction(ctx, stream, cap, out_frame_id, out_T7, out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid);
+  return read_correction(L, ls, cap, out_frame_id, out_T7, out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid);
 }
 
 // F2FTracking::correction_feed (src/frontend/f2f_tracking.cpp:40-44) -- the sink the reference's
@@ -1021,13 +1187,18 @@ int flvis_correction_feed(flvis_ctx* ctx, int stream, int64_t frame_id, const do
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "correction_feed: bad args");
   if (lm_count > BA_LMAX || lm_outlier_count > BA_EMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "correction_feed: too many entries");
   hipSetDevice(ctx->device);
-  if (!pl->pipe.corr_in) {
-    pl->pipe.corr_in = dalloc<CorrectionDev>(pl, pl->S);
-    if (!pl->pipe.corr_in) return ctx->fail(FLVIS_ERR_HIP, "correction_feed: device allocation failed");
+  if (!pl->feedback_used) {
+    for (Lane* L : pl->lanes) {
+      hipStreamSynchronize(L->st);
+      L->pipe.corr_in = dalloc<CorrectionDev>(L->allocs, L->S);
+      if (!L->pipe.corr_in) return ctx->fail(FLVIS_ERR_HIP, "correction_feed: device allocation failed");
+    }
   }
-  hipStream_t st = ctx->stream;
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  hipStream_t st = L.st;
   // the previous frame may still be running and reads/clears the slot: order the upload after it on the same stream
-  CorrectionDev* d = pl->pipe.corr_in + stream;
+  CorrectionDev* d = L.pipe.corr_in + ls;
   struct Head {
     long long frame_id;
     int lm_count, lm_outlier_count, valid, pad;
@@ -1060,13 +1231,16 @@ int flvis_get_pose_records(flvis_ctx* ctx, int stream, int cap, double* h_rows8)
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S || cap < 0 || (cap && !h_rows8)) return ctx->fail(FLVIS_ERR_INVALID_ARG, "get_pose_records: bad args");
   hipSetDevice(ctx->device);
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
   hipStreamSynchronize(ctx->stream);
+  hipStreamSynchronize(L.st);
   StreamState st;
   std::vector<int> ids(POSE_REC);
   std::vector<double> T((size_t)POSE_REC * 7);
-  if (hipMemcpy(&st, pl->pipe.st + stream, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(ids.data(), pl->pipe.rec_id + (size_t)stream * POSE_REC, sizeof(int) * POSE_REC, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(T.data(), pl->pipe.rec_T + (size_t)stream * POSE_REC * 7, sizeof(double) * 7 * POSE_REC, hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipMemcpy(&st, L.pipe.st + ls, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(ids.data(), L.pipe.rec_id + (size_t)ls * POSE_REC, sizeof(int) * POSE_REC, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(T.data(), L.pipe.rec_T + (size_t)ls * POSE_REC * 7, sizeof(double) * 7 * POSE_REC, hipMemcpyDeviceToHost) != hipSuccess)
     return ctx->fail(FLVIS_ERR_HIP, "get_pose_records: copy failed");
   for (int i = 0; i < st.rec_count && i < cap; i++) {
     const int k = (st.rec_head + i) % POSE_REC;

@@ -86,6 +86,7 @@ struct StreamState {
   int kf_pending;
   // pose_records (f2f_tracking.h:59, ID_POSE): ring in Pipe::rec_id / rec_T, oldest at rec_head
   int rec_head, rec_count;
+  int feeds;  // image_feed calls seen by this stream (= row of the device-side trajectory the frame is recorded in)
 };
 
 struct FrameOut {  // per stream, per image_feed

@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
       pty = (float)round(lm.p2d[1]);
       // (landmarks live in the open box (0, W-1) x (0, H-1), lkorb_tracking.cpp:95-102; the clamp only guards the read)
       const int ix = min(max(__float2int_rn(ptx), 0), p.cam.w - 1), iy = min(max(__float2int_rn(pty), 0), p.cam.h - 1);
-      const uint16_t d16 = p.depth_img[(size_t)s * p.cam.w * p.cam.h + (size_t)iy * p.cam.w + ix];
+      const uint16_t d16 = reinterpret_cast<const uint16_t*>(p.in_tab[1])[(size_t)s * p.cam.w * p.cam.h + (size_t)iy * p.cam.w + ix];
       const float z = (float)((double)d16 / p.cam.depth_scale);
       if ((double)z >= 0.3 && z <= p.cam.range) {
         meas = V3{((double)ptx - p.cam.cx) * (double)z / p.cam.fx, ((double)pty - p.cam.cy) * (double)z / p.cam.fy, (double)z};
@@ -1269,7 +1269,7 @@ __global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
 // ------------------------------------------------------------------------------------------------ frame end
 // init_frame's success test, keyframe decision (f2f_tracking.cpp:329-354,442-452), outputs, KeyFrame payload.
 constexpr int FE_T = 256;
-__global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
+__global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   const int lane = threadIdx.x;  // (first wave does the scalar bookkeeping)
@@ -1328,6 +1328,7 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
     o.f_cnt = st.f_cnt;
     o.pnp_cnt = st.pnp_cnt;
     o.reproj_err = st.reproj_err;
+    const int frame_slot = st.feeds++;
     if (p.traj && frame_slot >= 0 && frame_slot < p.traj_cap) {
       double* t = p.traj + ((size_t)s * p.traj_cap + frame_slot) * 9;
       t[0] = st.frame_time[cur];
@@ -1337,16 +1338,21 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p, int frame_slot) {
   }
   __syncthreads();
   if (s_newkf) {
-    // append the KeyFrame payload to the stream's queue (the local map consumes it on its own HIP streams); a full queue
-    // means the local map is KFQ keyframes behind: wait for it (its worker is running, it was launched after every frame)
+    // append the KeyFrame payload to the stream's queue (the local map consumes it on its own HIP streams).  No waiting on
+    // another kernel here (HIP gives no forward-progress guarantee between kernels): the host keeps the queue from filling
+    // by stream-ordered back-pressure (pipeline.cpp: the tracking stream waits for the local-map launches of KFQ-3 frames
+    // ago).  Should the queue be full all the same, the keyframe is dropped and counted -- what the reference's /vo_kf
+    // subscriber queue does when the local map is slower than the tracker (src/backend/vo_localmap.cpp:452-456).
     __shared__ unsigned s_tail;
+    __shared__ int s_full;
     if (lane == 0) {
       const unsigned tl = p.kfq_tail[s];
-      while (tl - __hip_atomic_load(&p.kfq_head[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)KFQ)
-        __builtin_amdgcn_s_sleep(16);
+      s_full = (tl - __hip_atomic_load(&p.kfq_head[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)KFQ) ? 1 : 0;
+      if (s_full) atomicAdd((unsigned long long*)&p.counters[3], 1ull);
       s_tail = tl;
     }
     __syncthreads();
+    if (s_full) return;
     KeyFrameDev& kf = p.kfq[(size_t)s * KFQ + (s_tail % KFQ)];
     Landmark* lms = lm_ptr(p, cur, s);
     const int n = st.n_lm[cur];
@@ -1407,8 +1413,8 @@ void launch_depth_prepare(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_depth_prepare, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
 }
 void launch_depth_innovate(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_depth_innovate, dim3(p.S), dim3(NMAX), 0, st, p); }
-void launch_frame_end(hipStream_t st, const Pipe& p, int frame_slot) {
-  hipLaunchKernelGGL(k_frame_end, dim3(p.S), dim3(FE_T), 0, st, p, frame_slot);
+void launch_frame_end(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_frame_end, dim3(p.S), dim3(FE_T), 0, st, p);
 }
 
 }  // namespace flvis

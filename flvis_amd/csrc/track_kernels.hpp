@@ -53,7 +53,9 @@ struct Pipe {
   // local-map feedback (F2FTracking::correction_feed, dead in the reference's v2)
   int* rec_id;              // [S][POSE_REC]  ID_POSE::frame_id (an int in the reference)
   double* rec_T;            // [S][POSE_REC][7]
-  const uint16_t* depth_img;  // [S][h][w] Z16 depth image of the current frame (DEPTH_D435 only), set per image_feed
+  // device table of this frame's input image bases (entry 0: img0, entry 1: img1 or, on DEPTH_D435 rigs, the Z16 depth image
+  // [S][h][w]); uploaded per frame so that the kernel arguments never change (the frame's launches are a captured graph)
+  const uint8_t* const* in_tab;
   CorrectionDev* corr_in;   // [S] correction waiting for the stream's next Tracking frame (valid flag), or nullptr
 };
 
@@ -70,7 +72,7 @@ void launch_reproj_filter(hipStream_t st, const Pipe& p);
 void launch_add_new(hipStream_t st, const Pipe& p);
 void launch_depth_prepare(hipStream_t st, const Pipe& p);
 void launch_depth_innovate(hipStream_t st, const Pipe& p);
-void launch_frame_end(hipStream_t st, const Pipe& p, int frame_slot);
+void launch_frame_end(hipStream_t st, const Pipe& p);
 // local map
 void launch_ba_worker(hipStream_t st, const Pipe& p);
 hipError_t ba_kernels_init();

@@ -58,17 +58,13 @@ def read_stamped(path):
 
 
 def throttle(stamps, min_dt=0.1):
-    """Indices the reference's recorder would keep (vo_repub_rec.cpp:77-79): its clock starts at the first call, a pose
-    is written when more than min_dt has passed since the last written one."""
-    keep, last = [], None
-    for i, t in enumerate(stamps):
-        if last is None:
-            last = t
-            continue
-        if t - last > min_dt:
-            keep.append(i)
-            last = t
-    return np.array(keep, dtype=int)
+    """Indices the reference's recorder would keep (vo_repub_rec.cpp:77-78): `last_time` is a function-static set at the first
+    call and never updated, so the poses of the first min_dt after the first call are dropped and EVERY later pose is written
+    (it is a start-up delay, not a 10 Hz decimation)."""
+    stamps = np.asarray(stamps, float)
+    if len(stamps) == 0:
+        return np.zeros(0, dtype=int)
+    return np.nonzero(stamps - stamps[0] > min_dt)[0].astype(int)
 
 
 # ---------------------------------------------------------------------------------------------- KITTI

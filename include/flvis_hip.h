@@ -170,6 +170,11 @@ int flvis_config_finalize(flvis_cfg* cfg);
  * RANSAC seed of each stream.  traj_capacity > 0 keeps a device-side trajectory of that many frames per stream. */
 int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, uint64_t seed_base, int traj_capacity);
 
+/* Number of lanes (sub-batches with their own HIP streams and device state) the tracker splits its streams into.  One by
+ * default; the environment variable FLVIS_LANES (1..16) is a tuning knob (more lanes measured slower on MI355X, DESIGN.md
+ * section 4).  The partition changes no result (streams are independent). */
+int flvis_tracker_lanes(flvis_ctx* ctx);
+
 /* One IMU sample of stream `stream` in the SENSOR frame; remapped per type_of_vi like imu_callback does.  Samples are
  * staged on the host and consumed by the next flvis_image_feed (feed samples with t <= image time before the image). */
 int flvis_imu_feed(flvis_ctx* ctx, int stream, double t, const double* acc3, const double* gyro3);
@@ -245,9 +250,10 @@ int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_fram
 /* Trajectory recorder (replaces src/independ_modules/vo_repub_rec.cpp:74-124 for offline runs): writes the recorded
  * camera poses T_w_c (inverse of T_c_w) of frames [first_frame, first_frame + n_frames) whose state is TRACKING to a
  * text file.  format 0: `stamp x y z qw qx qy qz` per line (vo_repub_rec.cpp:82-91, the TUM order with qw first);
- * format 1: KITTI, 12 row-major entries of [R | t] per line (:100-111).  min_dt > 0 emulates the recorder's throttle
- * (a pose is written only if its stamp is more than min_dt after the last written one; the reference uses 0.1 s of
- * wall-clock).  Returns the number of lines written or a negative error code. */
+ * format 1: KITTI, 12 row-major entries of [R | t] per line (:100-111).  min_dt > 0 emulates the recorder's throttle exactly
+ * as written (:77-78): its `last_time` is set at the first call and never updated, so poses stamped within min_dt of the
+ * first TRACKING pose are dropped and every later one is written (the reference: 0.1 s of wall clock).  Returns the number
+ * of lines written or a negative error code. */
 int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_frames, const char* path, int format,
                            double min_dt);
 /* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */

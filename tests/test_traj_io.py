@@ -35,10 +35,13 @@ def test_quaternion_round_trip_and_recorder_format():
 
 
 def test_throttle_matches_the_recorder_rule():
+    """vo_repub_rec.cpp:77-78: `static ros::Time last_time = ros::Time::now()` is initialised once and never updated, so the
+    recorder drops what arrives within 0.1 s of the first call and then writes EVERY pose (no 10 Hz decimation)."""
     stamps = np.arange(40) * 0.0625       # 16 Hz, exactly representable
     keep = T.throttle(stamps, 0.125)
-    # the clock starts at the first pose; then one pose whenever MORE than min_dt elapsed: every third pose here
-    assert keep[0] == 3 and np.all(np.diff(keep) == 3)
+    assert keep[0] == 3 and np.array_equal(keep, np.arange(3, 40))       # strictly MORE than min_dt after the first pose
+    assert len(T.throttle(stamps, 0.0)) == 39 and len(T.throttle([], 0.1)) == 0
+    assert len(T.throttle(np.arange(20) * 0.05, 0.1)) == 17              # a 20 Hz run loses only its first three poses
 
 
 def test_kitti_round_trip_and_reference_poses_zip():
