@@ -241,7 +241,7 @@ static int dem_common(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "feature_dem: bad args");
   int gftt_num = (int)f_para[3];
   int maxc = mode == 1 ? 2 * gftt_num : gftt_num;
-  if (maxc <= 0 || maxc > 2048) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_dem: gftt_num out of range (<=1024)");
+  if (maxc <= 0 || maxc > 4096) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_dem: gftt_num out of range (<=2048)");
   GfttScratch sc;
   int rc = gftt_scratch(ctx, w, h, n_img, sc);
   if (rc) return rc;

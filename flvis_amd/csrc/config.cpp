@@ -221,8 +221,38 @@ extern "C" int flvis_config_finalize(flvis_cfg* c) {
       for (int i = 0; i < 9; i++) c->R0[i] = c->R1[i] = (i % 4 == 0) ? 1.0 : 0.0;
       return c->depth_factor > 0 ? FLVIS_OK : FLVIS_ERR_CONFIG;
     }
+    case 4: {
+      // VI_TYPE_KITTI_STEREO (vo_tracking.cpp:146,265-306): STEREO_RECT without IMU.  The rig comes from the two projection
+      // matrices (flvis_config_load put their first three rows into P0 / P1): K0 = K1 = K0_rect = P0(0:3,0:3), no distortion,
+      // R0 = R1 = I, T_c0_c1 = [I | K^-1 * P1(:,3)] with K^-1 as Eigen's 3x3 inverse computes it (cofactors * (1 / det)),
+      // T_i_c0 is the dummy SE3(), init(..., 0, false): no skipped frames, no equalizeHist.
+      c->cam_type = 0;
+      c->imu_type = 3;  // NONE: imu_callback has no remap for it; flvis_imu_feed refuses samples for such a rig
+      c->skip_first_n_imgs = 0;
+      c->need_equal_hist = 0;
+      const double fx = c->P0[0], fy = c->P0[5], cx = c->P0[2], cy = c->P0[6];
+      if (!(fx > 0) || !(fy > 0)) return FLVIS_ERR_CONFIG;
+      const double K[4] = {fx, fy, cx, cy}, Z[4] = {0, 0, 0, 0};
+      memcpy(c->cam0_intrinsics, K, sizeof(K));
+      memcpy(c->cam1_intrinsics, K, sizeof(K));
+      memcpy(c->cam0_distortion, Z, sizeof(Z));
+      memcpy(c->cam1_distortion, Z, sizeof(Z));
+      for (int i = 0; i < 9; i++) c->R0[i] = c->R1[i] = (i % 4 == 0) ? 1.0 : 0.0;
+      // Eigen compute_inverse_size3 on K = [fx 0 cx; 0 fy cy; 0 0 1]: cofactor(i,j) * invdet, det = fx * cof00 (+ 0 + 0)
+      const double c00 = fy * 1.0 - cy * 0.0, det = fx * c00, invdet = 1.0 / det;
+      const double i00 = c00 * invdet, i01 = (cx * 0.0 - 0.0 * 1.0) * invdet, i02 = (0.0 * cy - cx * fy) * invdet;
+      const double i10 = (cy * 0.0 - 0.0 * 1.0) * invdet, i11 = (fx * 1.0 - cx * 0.0) * invdet, i12 = (0.0 * cx - fx * cy) * invdet;
+      const double i20 = (0.0 * 0.0 - 0.0 * fy) * invdet, i21 = (0.0 * 0.0 - fx * 0.0) * invdet, i22 = (fx * fy - 0.0 * 0.0) * invdet;
+      const double p0 = c->P1[3], p1 = c->P1[7], p2 = c->P1[11];  // P1(:,3); the 4x4's last row is zero in the yaml
+      const double tx = i00 * p0 + i01 * p1 + i02 * p2, ty = i10 * p0 + i11 * p1 + i12 * p2, tz = i20 * p0 + i21 * p1 + i22 * p2;
+      const double T01[16] = {1, 0, 0, tx, 0, 1, 0, ty, 0, 0, 1, tz, 0, 0, 0, 1};
+      const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      memcpy(c->T_cam0_cam1, T01, sizeof(T01));
+      memcpy(c->T_imu_cam0, eye, sizeof(eye));
+      return FLVIS_OK;
+    }
     default:
-      return FLVIS_ERR_CONFIG;  // KITTI (stereo without IMU) is not part of this path
+      return FLVIS_ERR_CONFIG;
   }
   double Tinv[16];
   mat44_inverse_rigid(c->T_cam0_cam1, Tinv);  // T_c1_c0
@@ -330,6 +360,11 @@ extern "C" int flvis_config_load(const char* path, flvis_cfg* c, char* err, int 
     return fail("yaml key missing or short: " + missing);
   }
   if (depth_mode) {
+  } else if (c->type_of_vi == 4) {  // KITTI: vo_tracking.cpp:267-270 reads the two 4x4 projection matrices
+    double a[16], b[16];
+    if (!need("cam0_projection_matrix", 16, a) || !need("cam1_projection_matrix", 16, b)) return fail("yaml key missing or short: " + missing);
+    memcpy(c->P0, a, sizeof(double) * 12);
+    memcpy(c->P1, b, sizeof(double) * 12);
   } else if (c->type_of_vi == 1) {
     double a[16], b[16], m[16], ai[16];
     if (!need("T_mavimu_cam0", 16, a) || !need("T_mavimu_cam1", 16, b) || !need("T_imu_mavimu", 16, m))

@@ -168,6 +168,27 @@ __global__ __launch_bounds__(256) void k_copy_image16(ImgSel src, ImgSel dst, in
   }
 }
 
+// ingest of images whose rows are not dword aligned (width not a multiple of 4, e.g. KITTI's 1241 x 376, tightly packed): one
+// destination dword per lane, its bytes read one by one; the padding bytes of the destination row are written as zero
+__global__ __launch_bounds__(256) void k_copy_image_any(ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch,
+                                                        size_t sstride, size_t dstride, const int* __restrict__ active) {
+  const int s = blockIdx.y;
+  if (active && !active[s]) return;
+  const uint8_t* in = src.ptr(s, sstride);
+  uint8_t* out = const_cast<uint8_t*>(dst.ptr(s, dstride));
+  const int dpr = dpitch >> 2;
+  const int total = dpr * h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int y = i / dpr, x = 4 * (i - y * dpr);
+    const uint8_t* r = in + (size_t)y * spitch + x;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (x + k < w) v |= (uint32_t)r[k] << (8 * k);
+    *reinterpret_cast<uint32_t*>(out + (size_t)y * dpitch + x) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ pyrDown
 // One workgroup -> PD_TH x PD_TW destination pixels.  Source tile (2*TH+3) x (2*TW+4(+pad)) staged in LDS.
 constexpr int PD_TW = 64, PD_TH = 16;
@@ -703,7 +724,7 @@ __global__ __launch_bounds__(SORT_T) void k_gftt_pick(unsigned long long* __rest
 // One wave per stream.  mode[s]==1: detect (init), mode[s]==2: redetect (existing landmark positions seed the regions).
 // Reproduces feature_dem.cpp including calHarrisR's quirks, integer cv::Point rounding in redetect, the cross-shaped
 // spacing test and the "push then check size" region cap.  std::sort ties are resolved stably (GFTT rank order).
-constexpr int DEM_MAXC = 2048;   // max GFTT corners per call (2*gftt_num)
+constexpr int DEM_MAXC = 4096;   // max GFTT corners per call (2*gftt_num; KITTI.yaml asks for 2 x 2000); candidate arrays in dynamic LDS
 constexpr int DEM_MAXR = 192;    // max entries kept per region (existing + new)
 
 __device__ __forceinline__ float dem_harris(const uint8_t* __restrict__ img, int pitch, float ptx, float pty) {
@@ -730,10 +751,15 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem(ImgSel src, int w, int h,
   const int md = mode ? mode[s] : 1;
   if (md == 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  __shared__ float cx[DEM_MAXC], cy[DEM_MAXC], cscore[DEM_MAXC];
-  __shared__ short creg[DEM_MAXC];
-  __shared__ short bucket[DEM_MAXC];      // candidate indices grouped by region, index order inside a region
-  __shared__ short sorted_idx[DEM_MAXC];  // ... sorted by score desc (stable)
+  // candidate arrays, sized by the corner capacity of the call (dynamic LDS: 18 bytes per corner)
+  extern __shared__ __attribute__((aligned(16))) unsigned char dem_smem[];
+  const int cmax = ((corner_cap < DEM_MAXC ? corner_cap : DEM_MAXC) + 1) & ~1;
+  float* cx = reinterpret_cast<float*>(dem_smem);
+  float* cy = cx + cmax;
+  float* cscore = cy + cmax;
+  short* creg = reinterpret_cast<short*>(cscore + cmax);
+  short* bucket = creg + cmax;      // candidate indices grouped by region, index order inside a region
+  short* sorted_idx = bucket + cmax;  // ... sorted by score desc (stable)
   __shared__ int rcount[16], roff[17];
   __shared__ float kx[16][DEM_MAXR], ky[16][DEM_MAXR];
   __shared__ int kcount[16], knew0[16], ooff[17];
@@ -944,6 +970,12 @@ void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int
                      (const uint8_t*)nullptr, active);
 }
 
+void launch_copy_image_any(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
+                           size_t dstride, int S, const int* active) {
+  hipLaunchKernelGGL(k_copy_image_any, dim3(div_up((dpitch / 4) * h, 256 * 4), S), dim3(256), 0, st, src, dst, w, h, spitch, dpitch,
+                     sstride, dstride, active);
+}
+
 void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,
                      size_t dstride, int S, const int* active) {
   int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
@@ -984,12 +1016,15 @@ void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, siz
                         const float* corners, const int* ncorners, int corner_cap, const int* mode,
                         const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,
                         int out_cap) {
-  hipLaunchKernelGGL(k_feature_dem, dim3(S), dim3(DEM_T), 0, st, src, w, h, pitch, sstride, prm, corners, ncorners,
+  const int cmax = ((corner_cap < DEM_MAXC ? corner_cap : DEM_MAXC) + 1) & ~1;
+  hipLaunchKernelGGL(k_feature_dem, dim3(S), dim3(DEM_T), (size_t)cmax * 18, st, src, w, h, pitch, sstride, prm, corners, ncorners,
                      corner_cap, mode, exist_xy, nexist, exist_cap, out_xy, out_n, out_cap);
 }
 
 hipError_t img_kernels_init() {
   // the selection bitmap may exceed the default 64 KB dynamic LDS window only for images > 512K pixels
+  hipError_t e = hipFuncSetAttribute((const void*)k_feature_dem, hipFuncAttributeMaxDynamicSharedMemorySize, DEM_MAXC * 18);
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_gftt_pick, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }
 

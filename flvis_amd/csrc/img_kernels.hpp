@@ -56,6 +56,9 @@ void launch_equalize_hist(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, 
 void launch_bgr_to_gray(hipStream_t st, const uint8_t* src, int channels, uint8_t* dst, size_t npixels);
 void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
                        size_t dstride, int S, const int* active);
+// any width / source pitch (rows need not be dword aligned); dpitch % 4 == 0
+void launch_copy_image_any(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
+                           size_t dstride, int S, const int* active);
 void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,
                      size_t dstride, int S, const int* active);
 // level 1 of a pyramid fused with the ingest copy: reads the caller's image once, writes level 0 (dst0) and level 1 (dst)

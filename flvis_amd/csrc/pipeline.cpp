@@ -419,10 +419,11 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   if (!ctx || !cfg || n_streams <= 0) return FLVIS_ERR_INVALID_ARG;
   if (ctx->pipe) flvis_pipeline_destroy_internal(ctx);
   const int w = cfg->image_width, h = cfg->image_height;
-  if (w < 64 || h < 64 || (w & 15)) return ctx->fail(FLVIS_ERR_CONFIG, "image width must be a multiple of 16 and >= 64");
+  if (w < 64 || h < 64) return ctx->fail(FLVIS_ERR_CONFIG, "image must be at least 64 x 64");
+  if (cfg->need_equal_hist && (w & 15)) return ctx->fail(FLVIS_ERR_CONFIG, "equalizeHist rigs need an image width that is a multiple of 16");
   if (cfg->feature_para[5] > 64.0) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para6 (GFTT minDistance) > 64 is not supported");
   if (cfg->window_size > BA_WMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "window_size exceeds the LDS-resident solver (16)");
-  if ((int)cfg->feature_para[3] * 2 > 2048) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para4 (gftt_num) must be <= 1024");
+  if ((int)cfg->feature_para[3] * 2 > 4096) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para4 (gftt_num) must be <= 2048");
   if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "image too large for the GFTT LDS bitmap");
   if (cfg->cam_type == CAM_DEPTH && !(cfg->depth_factor > 0)) return ctx->fail(FLVIS_ERR_CONFIG, "depth mode needs depth_factor > 0");
   hipSetDevice(ctx->device);
@@ -495,16 +496,40 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   return FLVIS_OK;
 }
 
+// The reference integrates every IMU message as it arrives, without a limit.  Here samples are staged per stream and consumed
+// by the next image_feed; when a stream's staging slot (IMU_MAX samples) is full -- an IMU that leads the camera, a dropped
+// image -- the staged samples of the lane are integrated at once (blocking upload + k_imu_feed: a rare path) and staging goes on.
+static int lane_flush_imu(flvis_ctx* ctx, Lane& L) {
+  hipError_t e = hipStreamSynchronize(L.st);
+  if (e == hipSuccess) e = hipMemcpy(L.pipe.imu_in, L.h_imu.data(), sizeof(double) * L.h_imu.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(L.pipe.n_imu, L.h_nimu.data(), sizeof(int) * L.S, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return ctx->hip_fail(e, "imu_feed (flush)");
+  launch_imu_feed(L.st, L.pipe);
+  e = hipStreamSynchronize(L.st);
+  if (e != hipSuccess) return ctx->hip_fail(e, "imu_feed (flush)");
+  std::fill(L.h_nimu.begin(), L.h_nimu.end(), 0);
+  return FLVIS_OK;
+}
+
 int flvis_imu_feed_flvis_frame(flvis_ctx* ctx, int stream, int n, const double* samples7) {
   if (!ctx || !ctx->pipe || !samples7) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S || n < 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "imu_feed: bad stream");
   int ls;
   Lane& L = pl->lane_of(stream, ls);
-  int& cnt = L.h_nimu[ls];
-  if (cnt + n > IMU_MAX) return ctx->fail(FLVIS_ERR_CAPACITY, "imu_feed: more than 64 IMU samples between two frames");
-  memcpy(&L.h_imu[((size_t)ls * IMU_MAX + cnt) * 7], samples7, sizeof(double) * 7 * n);
-  cnt += n;
+  while (n > 0) {
+    int& cnt = L.h_nimu[ls];
+    if (cnt == IMU_MAX) {
+      hipSetDevice(ctx->device);
+      const int rc = lane_flush_imu(ctx, L);
+      if (rc != FLVIS_OK) return rc;
+    }
+    const int m = std::min(n, IMU_MAX - L.h_nimu[ls]);
+    memcpy(&L.h_imu[((size_t)ls * IMU_MAX + L.h_nimu[ls]) * 7], samples7, sizeof(double) * 7 * m);
+    L.h_nimu[ls] += m;
+    samples7 += 7 * (size_t)m;
+    n -= m;
+  }
   return FLVIS_OK;
 }
 
@@ -512,6 +537,7 @@ int flvis_imu_feed(flvis_ctx* ctx, int stream, double t, const double* a, const 
   if (!ctx || !ctx->pipe || !a || !g) return FLVIS_ERR_INVALID_ARG;
   double s[7];
   s[0] = t;
+  if (ctx->pipe->cfg.imu_type == 3) return ctx->fail(FLVIS_ERR_CONFIG, "imu_feed: this rig has no IMU (type_of_vi 4: imu_type NONE)");
   switch (ctx->pipe->cfg.imu_type) {  // src/frontend/vo_tracking.cpp:331-357
     case 0:                            // D435I
       s[1] = -a[2]; s[2] = a[0]; s[3] = a[1];
@@ -634,22 +660,24 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   }
   const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
   const bool eq = pl->cfg.need_equal_hist != 0;
+  const bool aligned = (w & 15) == 0;  // otherwise (KITTI: 1241 x 376, tightly packed rows) both images are copied into pitch-aligned level 0
   // left image -> level 0 of the stream's current slot (+ the pyramid).  Without equalizeHist the first pyrDown reads the
   // caller's image and writes level 0 and level 1 in one pass; with it the equalised image is level 0.
   ImgSel in0 = img_indirect(L->d_tab + 0), in1 = img_indirect(L->d_tab + 1);
   ImgSel l0cur{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot, 0, nullptr};
   PB(1, st);
   if (eq) launch_equalize_hist(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
+  else if (!aligned) launch_copy_image_any(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
   PE(1, st);
   PB(2, st);
   for (int l = 1; l <= pl->levels; l++) {  // left pyramid: needed by the temporal tracker right away
     ImgSel s0{{L->pyr0[0][l - 1], L->pyr0[1][l - 1]}, p.img_slot, 0, nullptr}, d0{{L->pyr0[0][l], L->pyr0[1][l]}, p.img_slot, 0, nullptr};
-    if (l == 1 && !eq)
+    if (l == 1 && !eq && aligned)
       launch_pyr_down_ingest(st, in0, w, h, w, (size_t)w * h, l0cur, pl->lpitch[0], pl->lstride[0], d0, pl->lpitch[1], pl->lstride[1], S, p.act_img);
     else
       launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
   }
-  if (pl->levels == 0 && !eq) launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
+  if (pl->levels == 0 && !eq && aligned) launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
   PE(2, st);
   // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
   // for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain.  The right image is only
@@ -657,11 +685,13 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   hipStream_t ds = L->det_stream;
   hipEventRecord(L->ev_img, st);
   hipStreamWaitEvent(ds, L->ev_img, 0);
-  ImgSel r0 = eq ? img_plain(L->pyr1[0]) : in1;
-  const int r0pitch = eq ? pl->lpitch[0] : w;
-  const size_t r0stride = eq ? pl->lstride[0] : (size_t)w * h;
+  const bool r_in_place = !eq && aligned;
+  ImgSel r0 = r_in_place ? in1 : img_plain(L->pyr1[0]);
+  const int r0pitch = r_in_place ? w : pl->lpitch[0];
+  const size_t r0stride = r_in_place ? (size_t)w * h : pl->lstride[0];
   if (!depth_cam) {
     if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
+    else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
     for (int l = 1; l <= pl->levels; l++)
       launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
                       l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);

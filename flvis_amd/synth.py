@@ -153,6 +153,50 @@ window_size:       10
        _fmt44(_EUROC_T_B_C1))
 
 
+# KITTI-like rig (type_of_vi 4: rectified stereo given by two projection matrices, NO IMU; launch/KITTI/KITTI.yaml of the
+# reference): KITTI's image size, intrinsics and feature parameters.  The baseline is 0.12 m instead of KITTI's 0.537 m because
+# the synthetic room is 2-6 m deep (KITTI's street scenes are 5-50 m): disparities stay in KITTI's 15-45 px range.
+KITTI_W, KITTI_H = 1241, 376
+KITTI_FX, KITTI_CX, KITTI_CY = 718.856, 607.1928, 185.2157
+KITTI_LIKE_BASELINE = 0.12
+KITTI_LIKE_YAML = """type_of_vi: 4
+image_width: 1241
+image_height: 376
+cam0_intrinsics: [718.856, 718.856, 607.1928, 185.2157]
+cam0_distortion_coeffs: [0.0, 0.0, 0.0, 0.0]
+cam1_intrinsics: [718.856, 718.856, 607.1928, 185.2157]
+cam1_distortion_coeffs: [0.0, 0.0, 0.0, 0.0]
+cam0_projection_matrix:
+[718.856, 0.0,     607.1928, 0.0,
+ 0.0,     718.856, 185.2157, 0.0,
+ 0.0,     0.0,     1.0,      0.0,
+ 0.0,     0.0,     0.0,      0.0]
+cam1_projection_matrix:
+[718.856, 0.0,     607.1928, %.10g,
+ 0.0,     718.856, 185.2157, 0.0,
+ 0.0,     0.0,     1.0,      0.0,
+ 0.0,     0.0,     0.0,      0.0]
+is_lite_version: False
+vifusion_para1: 0.1
+vifusion_para2: 0.03
+vifusion_para3: 0.003
+vifusion_para4: 0.01
+vifusion_para5: 0.5
+vifusion_para6: 0.1
+feature_para1: 30
+feature_para2: 15
+feature_para3: 10
+feature_para4: 2000
+feature_para5: 0.0001
+feature_para6: 10
+dr_para1: 0.8
+dr_para2: 1000
+dr_para3: 0.0
+output_sparse_map: False
+window_size:       10
+""" % (-KITTI_FX * KITTI_LIKE_BASELINE)
+
+
 class Rig:
     """Stereo rig geometry for the renderer: intrinsics + radtan distortion per camera, camera0 -> body (R_i_c, t_i_c) and
     camera1 in camera0 coordinates (R_c0_c1, t_c0_c1)."""
@@ -170,6 +214,16 @@ def d435_rig():
     T01 = np.eye(4)
     T01[0, 3] = BASELINE
     return Rig(W, H, (FX, FY, CX, CY), (0.0, 0.0, 0.0, 0.0), (FX, FY, CX, CY), (0.0, 0.0, 0.0, 0.0), T_i_c, T01)
+
+
+def kitti_like_rig():
+    """cam1 sits KITTI_LIKE_BASELINE to the right of cam0 (P1 = K [I | -b]); the camera looks along the body's x axis."""
+    T_i_c = np.eye(4)
+    T_i_c[:3, :3] = R_I_C
+    T01 = np.eye(4)
+    T01[0, 3] = KITTI_LIKE_BASELINE
+    K = (KITTI_FX, KITTI_FX, KITTI_CX, KITTI_CY)
+    return Rig(KITTI_W, KITTI_H, K, (0.0, 0.0, 0.0, 0.0), K, (0.0, 0.0, 0.0, 0.0), T_i_c, T01)
 
 
 def euroc_rig():

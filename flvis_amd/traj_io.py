@@ -242,6 +242,53 @@ class EurocSequence:
             t_prev = t
 
 
+class KittiSequence:
+    """A KITTI odometry sequence folder as the reference's kitti_publisher reads it
+    (src/independ_modules/kitti_publisher.cpp:100-131): `image_0/%06d.png` + `image_1/%06d.png` (gray stereo pair with the
+    same index), published at a fixed rate (10 Hz there; `times.txt`, one stamp per line, is used when present), and an
+    optional ground-truth file of 12-column poses T_w_c (first camera frame = world)."""
+
+    def __init__(self, root, poses_file=None, rate_hz=10.0):
+        import os
+        self.root = root
+        d0, d1 = os.path.join(root, "image_0"), os.path.join(root, "image_1")
+        if not (os.path.isdir(d0) and os.path.isdir(d1)):
+            raise FileNotFoundError("not a KITTI odometry sequence (image_0/ and image_1/ expected): %s" % root)
+        n = 0
+        while os.path.exists(os.path.join(d0, "%06d.png" % n)) and os.path.exists(os.path.join(d1, "%06d.png" % n)):
+            n += 1
+        self.files = [(os.path.join(d0, "%06d.png" % k), os.path.join(d1, "%06d.png" % k)) for k in range(n)]
+        tp = os.path.join(root, "times.txt")
+        if os.path.exists(tp):
+            self.stamps = np.loadtxt(tp, ndmin=1)[:n]
+        else:
+            self.stamps = np.arange(n) / float(rate_hz)
+        self.groundtruth = None
+        if poses_file is None and os.path.exists(os.path.join(root, "poses.txt")):
+            poses_file = os.path.join(root, "poses.txt")
+        if poses_file is not None:
+            R, t = read_kitti(poses_file)
+            m = min(len(t), n)
+            self.groundtruth = (self.stamps[:m], t[:m], R[:m])   # camera poses T_w_c
+
+    def __len__(self):
+        return len(self.files)
+
+    def frames(self, first=0, count=None):
+        """yields (t_seconds, img0, img1, imu_rows) -- imu_rows is always empty: the KITTI rig of the reference has no IMU."""
+        last = len(self) if count is None else min(len(self), first + count)
+        for k in range(first, last):
+            yield float(self.stamps[k]), load_gray(self.files[k][0]), load_gray(self.files[k][1]), np.zeros((0, 7))
+
+
+def open_sequence(root):
+    """EuRoC ASL folder or KITTI odometry folder, by what is inside."""
+    import os
+    if os.path.isdir(os.path.join(root, "image_0")):
+        return KittiSequence(root)
+    return EurocSequence(root)
+
+
 def camera_to_body(positions_w_c, quats_wxyz_w_c, T_imu_cam44):
     """T_w_i = T_w_c * T_c_i for every pose (EuRoC ground truth is the body frame, the tracker reports the camera)."""
     T_c_i = np.linalg.inv(np.asarray(T_imu_cam44, float).reshape(4, 4))

@@ -141,7 +141,10 @@ int flvis_hip_orb_match(flvis_ctx* ctx, const uint8_t* d_a, const int* d_na, int
  */
 typedef struct flvis_cfg {
   int type_of_vi;                 /* 1 EuRoC (stereo unrectified + IMU), 3 D435i stereo, 5 D435 stereo + pixhawk,
-                                     0 D435i depth, 2 D435 depth + pixhawk (the second image is the Z16 depth image) */
+                                     0 D435i depth, 2 D435 depth + pixhawk (the second image is the Z16 depth image),
+                                     4 KITTI (rectified stereo, no IMU: the rig is given by cam{0,1}_projection_matrix, which
+                                     flvis_config_load stores in P0 / P1 and flvis_config_finalize turns into K, T_cam0_cam1;
+                                     src/frontend/vo_tracking.cpp:146,265-306) */
   int image_width, image_height;
   double cam0_intrinsics[4], cam0_distortion[4], cam1_intrinsics[4], cam1_distortion[4];
   double T_imu_cam0[16];          /* row-major 4x4 (EuRoC: T_imu_mavimu * T_mavimu_cam0) */

@@ -185,8 +185,44 @@ bool config_finalize(Config& c) {
       for (int i = 0; i < 9; i++) c.R0[i] = c.R1[i] = (i % 4 == 0) ? 1.0 : 0.0;
       return true;
     }
+    case 4: {  // vo_tracking.cpp:146,265-306: KITTI, STEREO_RECT, imu NONE, init(dc, SE3(), ..., 0, false)
+      c.cam_type = STEREO_RECT;
+      c.has_imu_type = 3;
+      c.skip_first_n_imgs = 0;
+      c.need_equal_hist = 0;
+      // K0 = K1 = K0_rect = P0.rowRange(0,3).colRange(0,3) (:284), D = 0 (:283), R = I (:289,:290)
+      const double fx = c.P0[0], fy = c.P0[5], cx = c.P0[2], cy = c.P0[6];
+      if (!(fx > 0) || !(fy > 0)) return false;
+      const double K[4] = {fx, fy, cx, cy};
+      for (int i = 0; i < 4; i++) {
+        c.cam0_intrinsics[i] = c.cam1_intrinsics[i] = K[i];
+        c.cam0_distortion[i] = c.cam1_distortion[i] = 0;
+      }
+      for (int i = 0; i < 9; i++) c.R0[i] = c.R1[i] = (i % 4 == 0) ? 1.0 : 0.0;
+      // mat_T_c0_c1 = K_inverse * P1_, rotation block set to identity (:272-276).  K.inverse() on a fixed 3x3 is Eigen's
+      // cofactor formula: inverse(i,j) = cofactor(j,i) * (1 / det), det = sum over column 0 of cofactor * entry
+      const double Km[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};
+      auto cof = [&](int i, int j) {  // cofactor_3x3<i,j>: m(i1,j1) * m(i2,j2) - m(i1,j2) * m(i2,j1), i1=(i+1)%3 ...
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return Km[i1][j1] * Km[i2][j2] - Km[i1][j2] * Km[i2][j1];
+      };
+      const double c0[3] = {cof(0, 0), cof(1, 0), cof(2, 0)};
+      const double det = (c0[0] * Km[0][0] + c0[1] * Km[1][0]) + c0[2] * Km[2][0];
+      const double invdet = 1.0 / det;
+      double inv[3][3];
+      for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++) inv[j][i] = cof(i, j) * invdet;
+      const double pc[3] = {c.P1[3], c.P1[7], c.P1[11]};
+      double t[3];
+      for (int r = 0; r < 3; r++) t[r] = (inv[r][0] * pc[0] + inv[r][1] * pc[1]) + inv[r][2] * pc[2];
+      const double T01[16] = {1, 0, 0, t[0], 0, 1, 0, t[1], 0, 0, 1, t[2], 0, 0, 0, 1};
+      const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      memcpy(c.T_cam0_cam1, T01, sizeof(T01));
+      memcpy(c.T_imu_cam0, eye, sizeof(eye));
+      return true;
+    }
     default:
-      return false;  // KITTI (no IMU) is not part of this path
+      return false;
   }
   SE3 T_c0_c1 = se3_from_mat44(c.T_cam0_cam1);
   SE3 T_c1_c0 = se3_inverse(T_c0_c1);
@@ -288,6 +324,11 @@ bool config_load_yaml(const char* path, Config& c, char* err, int errlen) {
     return false;
   }
   if (depth_mode) {
+  } else if (c.type_of_vi == 4) {  // KITTI: vo_tracking.cpp:267-270
+    double a[16], b[16];
+    if (!need("cam0_projection_matrix", 16, a) || !need("cam1_projection_matrix", 16, b)) return false;
+    memcpy(c.P0, a, sizeof(double) * 12);
+    memcpy(c.P1, b, sizeof(double) * 12);
   } else if (c.type_of_vi == 1) {  // EuRoC: vo_tracking.cpp:218-236
     double a[16], b[16], m[16];
     if (!need("T_mavimu_cam0", 16, a) || !need("T_mavimu_cam1", 16, b) || !need("T_imu_mavimu", 16, m)) return false;

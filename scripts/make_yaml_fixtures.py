@@ -2,7 +2,7 @@
 """Pins the config loaders on the reference's own yaml dependency: runs oracle/_ref/yaml_dump (yaml-cpp 0.6.2 compiled
 from /root/reference/3rdPartLib by oracle/Makefile, accessors as in src/utils/include/yamlRead.h) and commits what it
 reads as small fixtures under tests/golden/:
-  yaml_ref_<name>.txt    <- the reference's launch files of the supported sensor types (type_of_vi 0, 1, 2, 3, 5)
+  yaml_ref_<name>.txt    <- the reference's launch files of the supported sensor types (type_of_vi 0, 1, 2, 3, 4, 5)
   yaml_synth_<name>.txt  <- this repo's synthetic rig files (flvis_amd/synth.py)
 Run in the build container only (needs /root/reference)."""
 import os
@@ -20,8 +20,10 @@ REF_FILES = {
     "d435_stereo_px4": "/root/reference/launch/d435_pixhawk/sn943222072828_stereo_px4.yaml",
     "d435i_depth": "/root/reference/launch/d435i/sn943222072828_depth.yaml",
     "d435_depth_px4": "/root/reference/launch/d435_pixhawk/sn841512070537_depth_px4.yaml",
+    "kitti": "/root/reference/launch/KITTI/KITTI.yaml",
 }
-SYNTH = {"d435i_stereo": synth.D435I_STEREO_YAML, "euroc_like": synth.EUROC_LIKE_YAML, "d435i_depth": synth.D435I_DEPTH_YAML}
+SYNTH = {"d435i_stereo": synth.D435I_STEREO_YAML, "euroc_like": synth.EUROC_LIKE_YAML, "d435i_depth": synth.D435I_DEPTH_YAML,
+         "kitti_like": synth.KITTI_LIKE_YAML}
 
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
 dump = os.path.join(ROOT, "oracle", "_ref", "yaml_dump")

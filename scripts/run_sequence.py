@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs one EuRoC ASL sequence through the tracker and writes the trajectory the reference's recorder would write
+"""Runs one EuRoC ASL sequence (stereo + IMU) or KITTI odometry sequence (image_0/ image_1/, no IMU: type_of_vi 4) through the tracker and writes the trajectory the reference's recorder would write
 (`stamp x y z qw qx qy qz`, camera pose T_w_c); with ground truth present, prints the Umeyama-aligned ATE.
 
   run_sequence.py <sequence folder> <config yaml> <out.txt> [--backend hip|cpu] [--frames N] [--local-map]
@@ -27,13 +27,14 @@ def main():
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--local-map", action="store_true")
     args = ap.parse_args()
-    seq = traj_io.EurocSequence(args.sequence)
+    seq = traj_io.open_sequence(args.sequence)
+    kitti = isinstance(seq, traj_io.KittiSequence)
     stamps, pos, quat = [], [], []
     if args.backend == "cpu":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle as O
         cfg = O.load_config(args.config)
-        imu_type = {1: 1, 3: 0, 5: 2, 0: 0, 2: 2}[cfg.type_of_vi]
+        imu_type = {1: 1, 3: 0, 5: 2, 0: 0, 2: 2, 4: 3}[cfg.type_of_vi]
         trk = O.Tracker(cfg, 0xF1715)
         for t, i0, i1, imu in seq.frames(0, args.frames):
             for r in imu:
@@ -66,7 +67,10 @@ def main():
     out = {"backend": args.backend, "frames": len(seq) if args.frames is None else args.frames, "tracked": len(stamps)}
     if seq.groundtruth is not None and len(stamps) >= 3:
         gt_t, gt_p, _ = seq.groundtruth
-        body_p, _ = traj_io.camera_to_body(np.asarray(pos), np.asarray(quat), T_imu_cam)
+        if kitti:   # KITTI ground truth is the camera itself
+            body_p = np.asarray(pos)
+        else:
+            body_p, _ = traj_io.camera_to_body(np.asarray(pos), np.asarray(quat), T_imu_cam)
         ia, ib = traj_io.associate(np.asarray(stamps), gt_t, 0.02)
         if len(ia) >= 3:
             out["ate_rmse_m"] = traj_io.ate_rmse(body_p[ia], gt_p[ib])

@@ -95,3 +95,45 @@ def test_asl_folder_roundtrip_and_cpu_backend_run():
             want_p.append(-R.T @ p7[:3])
     assert len(want_t) == len(ts) and np.allclose(ts, want_t, atol=1e-6)
     assert np.allclose(pos, np.array(want_p), rtol=2e-5, atol=1e-6)
+
+
+def test_kitti_folder_reader_and_cpu_backend_run():
+    """The KITTI side of the dataset path: `image_0/%06d.png`, `image_1/%06d.png`, `times.txt` and a 12-column ground-truth file
+    (what src/independ_modules/kitti_publisher.cpp:100-131 reads) written from the synthetic KITTI-like rig, read back by
+    traj_io.KittiSequence and run through scripts/run_sequence.py (CPU backend, type_of_vi 4, no IMU)."""
+    from PIL import Image
+    from flvis_amd import synth, traj_io
+    yaml = os.path.join(tempfile.gettempdir(), "flvis_ds_kitti.yaml")
+    open(yaml, "w").write(synth.KITTI_LIKE_YAML)
+    rig = synth.kitti_like_rig()
+    tr = synth.Trajectory(5)
+    rnd = synth.Renderer("cpu", rig=rig)
+    root = tempfile.mkdtemp(prefix="flvis_kitti_")
+    os.makedirs(os.path.join(root, "image_0"))
+    os.makedirs(os.path.join(root, "image_1"))
+    n = 9
+    imgs, Rs, ts = [], [], []
+    R0, t0 = tr.T_c_w(0.0, rig)
+    for f in range(n):
+        t = f / 10.0
+        i0, i1 = rnd.stereo_frame([tr], t, f)
+        imgs.append((i0[0].numpy(), i1[0].numpy()))
+        Image.fromarray(imgs[-1][0]).save(os.path.join(root, "image_0", "%06d.png" % f))
+        Image.fromarray(imgs[-1][1]).save(os.path.join(root, "image_1", "%06d.png" % f))
+        Rc, tc = tr.T_c_w(t, rig)                       # world -> camera; KITTI poses are T_(first camera)_(camera)
+        Rs.append(R0 @ Rc.T)
+        ts.append(R0 @ (-Rc.T @ tc) + t0)
+    np.savetxt(os.path.join(root, "times.txt"), np.arange(n) / 10.0, fmt="%.6e")
+    traj_io.write_kitti(os.path.join(root, "poses.txt"), np.array(Rs), np.array(ts))
+    seq = traj_io.open_sequence(root)
+    assert isinstance(seq, traj_io.KittiSequence) and len(seq) == n and seq.groundtruth is not None
+    got = list(seq.frames())
+    assert all(len(g[3]) == 0 for g in got)                                                   # no IMU
+    assert all(np.array_equal(g[1], im[0]) and np.array_equal(g[2], im[1]) for g, im in zip(got, imgs))
+    assert np.allclose([g[0] for g in got], np.arange(n) / 10.0)
+    out = os.path.join(root, "traj_cpu.txt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), root, yaml, out, "--backend", "cpu"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    res = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert res["tracked"] == n and res["ate_rmse_m"] < 0.01, res

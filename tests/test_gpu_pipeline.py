@@ -46,7 +46,7 @@ def _cfgs_yaml(text, tag):
     return cfg, ocfg
 
 
-def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf, depth_range=None):
+def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf, depth_range=None, imu=True):
     import flvis_amd
     from flvis_amd import synth
     S = len(streams)
@@ -62,6 +62,8 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
     for f in range(nframes):
         t = f / synth.FRAME_HZ
         for i, s in enumerate(streams):
+            if not imu:
+                break                                  # rigs without an IMU (type_of_vi 4): no sample is ever fed
             smp = synth.imu_samples(trajs[i], s, t_prev, t)
             trk.imu_feed_flvis(i, smp)
             for r in smp:
@@ -159,6 +161,51 @@ def test_frontend_parity_depth_camera_mode(ctx):
     cfg, ocfg = _cfgs_yaml(synth.D435I_DEPTH_YAML, "d435i_depth")
     assert cfg.cam_type == 2 and cfg.depth_factor == 1000.0 and cfg.skip_first_n_imgs == 50
     _run_frontend_parity(ctx, cfg, ocfg, None, [3, 77], 50 + 36, 10, 3, depth_range=3.3)
+
+
+def test_frontend_parity_kitti_mode(ctx):
+    """type_of_vi 4 (vo_tracking.cpp:146,265-306): rectified stereo from two projection matrices, no IMU (fixed initial
+    attitude, P3P without a prior), no skipped frames, 1241 x 376 tightly packed images (rows not dword aligned: both images
+    are copied into pitch-aligned pyramids), GFTT with 2 x 2000 corners.  Same closed-loop comparison against the oracle."""
+    import flvis_amd
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.KITTI_LIKE_YAML, "kitti_like")
+    assert (cfg.type_of_vi, cfg.cam_type, cfg.imu_type, cfg.skip_first_n_imgs, cfg.image_width) == (4, 0, 3, 0, 1241)
+    _run_frontend_parity(ctx, cfg, ocfg, synth.kitti_like_rig(), [5, 77], 26, 8, 3, imu=False)
+    trk = flvis_amd.Tracker(ctx, cfg, 1)
+    with pytest.raises(flvis_amd.FlvisError):          # imu_callback has no remap for imu_type NONE
+        trk.imu_feed_sensor(0, 0.0, [0, 0, 9.81], [0, 0, 0])
+
+
+def test_imu_staging_overflow_is_integrated_not_refused(ctx):
+    """The reference integrates IMU messages as they arrive, without a limit (vo_tracking.cpp:326-371).  More than IMU_MAX = 64
+    samples between two images (an IMU that leads the camera, a dropped image) must be integrated in order, not refused:
+    150 samples before the first image and 90 between two later ones, compared with the oracle fed sample by sample."""
+    import flvis_amd
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
+    rig = synth.euroc_rig()
+    tr = synth.Trajectory(9)
+    rnd = synth.Renderer("cuda", rig=rig)
+    trk = flvis_amd.Tracker(ctx, cfg, 1, seed_base=0xF1715)
+    ref = O.Tracker(ocfg, 0xF1715)
+    # image times: 0.75 s (150 IMU samples before it), then every 50 ms, with one image "dropped" (0.45 s gap = 90 samples)
+    times = [0.75, 0.80, 0.85, 1.30, 1.35, 1.40, 1.45, 1.50]
+    t_prev = 0.0
+    for k, t in enumerate(times):
+        smp = synth.imu_samples(tr, 9, t_prev, t)
+        if k in (0, 3):
+            assert len(smp) > 64
+        trk.imu_feed_flvis(0, smp)
+        for r in smp:
+            ref.imu(r[0], r[1:4], r[4:7])
+        t_prev = t
+        i0, i1 = rnd.stereo_frame([tr], t, k)
+        got = trk.image_feed(i0, i1, [t], with_local_map=False)[0]
+        want = ref.image(t, i0[0].cpu().numpy(), i1[0].cpu().numpy())
+        assert got["state"] == want["state"] and got["n_landmarks"] == want["n_landmarks"], k
+        assert np.abs(got["pose7"] - want["pose7"]).max() < 1e-6, (k, got["pose7"] - want["pose7"])
+    assert want["state"] == 1
 
 
 def test_trajectory_recorder(ctx):

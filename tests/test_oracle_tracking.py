@@ -57,6 +57,37 @@ def test_oracle_tracks_synthetic_stream():
     assert ate < 0.05 * path + 0.01, (ate, path)                     # a few % of the distance travelled
 
 
+def test_oracle_tracks_kitti_like_stream_without_imu():
+    """KITTI mode (type_of_vi 4, vo_tracking.cpp:146,265-306): rectified stereo given by two projection matrices, NO IMU
+    (F2FTracking::has_imu stays false: the fixed initial attitude of f2f_tracking.cpp:157, P3P without a prior every frame),
+    no skipped frames, 1241 x 376 images (a width that is not a multiple of 4), 2000-corner GFTT."""
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_track_kitti.yaml")
+    open(p, "w").write(synth.KITTI_LIKE_YAML)
+    cfg = O.load_config(p)
+    assert (cfg.type_of_vi, cfg.cam_type, cfg.skip_first_n_imgs, cfg.need_equal_hist) == (4, 0, 0, 0)
+    assert (cfg.image_width, cfg.image_height, cfg.window_size) == (1241, 376, 10)
+    rig = synth.kitti_like_rig()
+    trk = O.Tracker(cfg, 7)
+    tr = synth.Trajectory(5)
+    rnd = synth.Renderer("cpu", rig=rig)
+    est, gt, kfs = [], [], 0
+    for f in range(12):
+        t = f / synth.FRAME_HZ
+        i0, i1 = rnd.stereo_frame([tr], t, f)
+        r = trk.image(t, i0[0].numpy(), i1[0].numpy())                # no imu() calls at all
+        assert r["state"] == 1, f                                     # init_frame on the very first frame, never lost
+        kfs += r["new_keyframe"]
+        R, tt = G.pose7_to_Rt(r["pose7"])
+        Rg, tg = tr.T_c_w(t, rig)
+        est.append(-R.T @ tt)
+        gt.append(-Rg.T @ tg)
+    # without an IMU the world frame is the fixed R_w_c of :157 at the first camera pose: compare after rigid alignment
+    assert kfs >= 3 and _umeyama_ate(np.array(est), np.array(gt)) < 0.01
+    lm = trk.landmarks()
+    assert 150 <= len(lm["ids"]) <= 480 and np.all(lm["flags"] & 1)
+
+
 def test_oracle_tracks_euroc_like_stream():
     """EuRoC mode (type_of_vi 1): unrectified stereo with radial-tangential distortion, 752x480, equalizeHist, no skipped
     frames, window 10 -- the oracle initialises once the IMU filter is ready and follows ground truth."""
