@@ -98,6 +98,12 @@ def maybe_spawn(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
+def load_checker_lib():
+    """the op-by-op IEEE build of the CPU restatement (what the parity tests compare the HIP path with, bit for bit)"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return C.CDLL(os.path.join(ROOT, "oracle", "libflvis_ref.so"))
+
+
 def load_oracle_lib():
     """The CPU restatement's timing build (-O3 -march=native, built on THIS host by `make -C oracle fast`); falls back to the
     op-by-op IEEE checker build the parity tests use.  Returns (ctypes lib, description of the build)."""
@@ -549,7 +555,10 @@ def leg_cpu(L):
                                                   "per stream), wall time of the whole job; %d of %d stream-frames in the Tracking state"
                                                   % (n_mt, nf, int((st_mt == 1).sum()), n_mt * nf)}
     # ATE of the GPU trajectory of stream 0 against the CPU reference on the same frames (camera centres, no alignment: both
-    # run from the same initial state), and both against the synthetic ground truth
+    # run from the same initial state), and both against the synthetic ground truth.  The CPU reference here is the IEEE
+    # op-by-op build (the timing build above contracts multiply-adds, which moves its trajectory by ~1 mm)
+    _, cpu_pos, cpu_state, _ = cpu_run_streams(load_checker_lib(), cfg, 1, 1, cpu_first, n_cpu, hf, imu, imu_cnt, 0xF1715, synth.FRAME_HZ, wlm)
+    cpu_pos, cpu_state = cpu_pos[0], cpu_state[0]
     grow = trk.trajectory(0, cpu_first, n_cpu)
     sel = [j for j in range(n_cpu) if cpu_state[j] == 1 and (int(grow[j, 8]) & 15) == 1]
     if len(sel) >= 3:
@@ -562,6 +571,7 @@ def leg_cpu(L):
         out["ate"] = {"gpu_vs_cpu_ref_m": float(np.sqrt(np.mean(np.sum((gc - cc) ** 2, 1)))),
                       "gpu_vs_ground_truth_m": ate_gpu, "cpu_ref_vs_ground_truth_m": ate_cpu,
                       "relative_difference": abs(ate_gpu - ate_cpu) / max(ate_cpu, 1e-12), "frames": len(sel),
+                      "poses_bit_identical": bool(np.array_equal(grow[sel, 1:8], cpu_pos[sel])),
                       "note": "stream 0, same frames on both sides: camera-centre RMSE HIP vs CPU restatement (no alignment) and "
                               "Umeyama-aligned ATE of each against the synthetic ground truth; EuRoC MH_05 itself is not available offline"}
 

@@ -1064,7 +1064,7 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
       if (!ok2) tempChi = 1.7976931348623157e308;
       rho = (currentChi - tempChi) / scale;
       if (rho > 0 && isfinite(tempChi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3.0);
+        double alpha = 1. - detm::det_powi((2 * rho - 1), 3);
         alpha = fmin(alpha, 2. / 3.);
         double scaleFactor = fmax(1. / 3., alpha);
         lambda *= scaleFactor;

@@ -3,6 +3,7 @@
 // 3rdPartLib/g2o/g2o/types/slam3d/se3quat.h, src/utils/include/kinetic_math.h).  Everything is plain IEEE + - * / sqrt in a
 // fixed order (the library is built with -ffp-contract=off), so scalar paths reproduce bit-for-bit across runs.
 #pragma once
+#include "det_math.hpp"  // sin / cos / atan / atan2 / log / small integer powers: one definition for the kernels and the oracle
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -189,7 +190,7 @@ FD V3 so3_log(Q4 q) {
   if (n < SMALL_EPS) {
     f = 2. / w - 2. * (n * n) / (w * squared_w);
   } else {
-    f = 2 * atan(n / w) / n;
+    f = 2 * detm::det_atan(n / w) / n;
   }
   return V3{f * q.x, f * q.y, f * q.z};
 }
@@ -228,7 +229,7 @@ FD SE3d g2o_exp(const double* upd) {
     R = m3_add(m3_add(I, Omega, 1.0), Omega2, 0.5);
     V = m3_add(m3_add(I, Omega, 0.5), Omega2, 1.0 / 6.0);
   } else {
-    double st = sin(theta), ct = cos(theta);
+    double st = detm::det_sin(theta), ct = detm::det_cos(theta);
     R = m3_add(m3_add(I, Omega, st / theta), Omega2, (1 - ct) / (theta * theta));
     V = m3_add(m3_add(I, Omega, (1 - ct) / (theta * theta)), Omega2, (theta - st) / (theta * theta * theta));
   }
@@ -240,7 +241,7 @@ FD SE3d g2o_exp(const double* upd) {
 // kinetic_math.h rpy helpers
 FD M3 rpy2R(V3 rpy) {
   double r = rpy.x, p = rpy.y, y = rpy.z;
-  double cy = cos(y), sy = sin(y), cp = cos(p), sp = sin(p), cr = cos(r), sr = sin(r);
+  double cy = detm::det_cos(y), sy = detm::det_sin(y), cp = detm::det_cos(p), sp = detm::det_sin(p), cr = detm::det_cos(r), sr = detm::det_sin(r);
   M3 R;
   R.m[0][0] = cy * cp;
   R.m[0][1] = cy * sp * sr - sy * cr;
@@ -254,8 +255,8 @@ FD M3 rpy2R(V3 rpy) {
   return R;
 }
 FD V3 R2rpy(const M3& R) {
-  return V3{atan2(R.m[2][1], R.m[2][2]), atan2(-R.m[2][0], sqrt(R.m[2][1] * R.m[2][1] + R.m[2][2] * R.m[2][2])),
-            atan2(R.m[1][0], R.m[0][0])};
+  return V3{detm::det_atan2(R.m[2][1], R.m[2][2]), detm::det_atan2(-R.m[2][0], sqrt(R.m[2][1] * R.m[2][1] + R.m[2][2] * R.m[2][2])),
+            detm::det_atan2(R.m[1][0], R.m[0][0])};
 }
 FD Q4 rpy2Q(V3 rpy) { return mat_to_q(rpy2R(rpy)); }
 FD V3 Q2rpy(Q4 q) { return R2rpy(q_to_mat(q)); }
@@ -299,10 +300,10 @@ FD int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIter
   ep = fmax(ep, 0.);
   ep = fmin(ep, 1.);
   double num = fmax(1. - p, 2.2250738585072014e-308);
-  double denom = 1. - pow(1. - ep, (double)modelPoints);
+  double denom = 1. - detm::det_powi(1. - ep, modelPoints);
   if (denom < 2.2250738585072014e-308) return 0;
-  num = log(num);
-  denom = log(denom);
+  num = detm::det_log(num);
+  denom = detm::det_log(denom);
   return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
 }
 

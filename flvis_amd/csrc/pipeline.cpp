@@ -140,19 +140,13 @@ int lk_levels(int w, int h, int win, int max_level) {
   return max_level;
 }
 
+// SE3 from a row-major 4x4 as Sophus builds it (SO3(Matrix3d): Eigen's matrix -> quaternion, no normalisation) and, with
+// `inverse`, Sophus' SE3::inverse() (se3.cpp:76-83): q^-1 = normalised conjugate, t^-1 = q^-1 * (-t) by the quaternion
+// rotation formula -- the same operations in the same order as the CPU restatement, so that T_c_i / T_c1_c0 are bit-identical
+// on both sides for a general extrinsic rotation (EuRoC), not only for an axis permutation (D435).
 void pose7_from_mat44(const double* m, double* out7, bool inverse) {
-  // rotation matrix -> quaternion (Eigen convention), host side
-  double R[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
+  const double R[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
   double t[3] = {m[3], m[7], m[11]};
-  if (inverse) {
-    double Rt[3][3];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) Rt[i][j] = R[j][i];
-    double ti[3];
-    for (int i = 0; i < 3; i++) ti[i] = -(Rt[i][0] * t[0] + Rt[i][1] * t[1] + Rt[i][2] * t[2]);
-    memcpy(R, Rt, sizeof(R));
-    memcpy(t, ti, sizeof(t));
-  }
   double q[4];  // w x y z
   double tr = R[0][0] + R[1][1] + R[2][2];
   if (tr > 0) {
@@ -178,9 +172,19 @@ void pose7_from_mat44(const double* m, double* out7, bool inverse) {
     q[2] = v[1];
     q[3] = v[2];
   }
-  if (inverse) {  // Sophus SO3::inverse() renormalises
-    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int i = 0; i < 4; i++) q[i] /= n;
+  if (inverse) {
+    const double cw = q[0], cx = -q[1], cy = -q[2], cz = -q[3];
+    const double n = std::sqrt(cw * cw + cx * cx + cy * cy + cz * cz);
+    q[0] = cw / n;
+    q[1] = cx / n;
+    q[2] = cy / n;
+    q[3] = cz / n;
+    // quat_rotate(q, -t): uv = cross(qv, v); uv += uv; v + w * uv + cross(qv, uv)
+    const double v[3] = {-1.0 * t[0], -1.0 * t[1], -1.0 * t[2]};
+    double uv[3] = {q[2] * v[2] - q[3] * v[1], q[3] * v[0] - q[1] * v[2], q[1] * v[1] - q[2] * v[0]};
+    for (int k = 0; k < 3; k++) uv[k] = uv[k] + uv[k];
+    const double c2[3] = {q[2] * uv[2] - q[3] * uv[1], q[3] * uv[0] - q[1] * uv[2], q[1] * uv[1] - q[2] * uv[0]};
+    for (int k = 0; k < 3; k++) t[k] = (v[k] + q[0] * uv[k]) + c2[k];
   }
   out7[0] = t[0];
   out7[1] = t[1];
@@ -1252,6 +1256,22 @@ int flvis_correction_feed(flvis_ctx* ctx, int stream, int64_t frame_id, const do
   if (e == hipSuccess) e = hipStreamSynchronize(st);  // the caller's buffers and `hd` may go away after return
   if (e != hipSuccess) return ctx->hip_fail(e, "correction_feed");
   pl->feedback_used = true;
+  return FLVIS_OK;
+}
+
+// stage poses of a stream's last Tracking frame (test aid): pose7 right after PnP-RANSAC, pose7 after the pose-only LM
+int flvis_debug_stage_poses(flvis_ctx* ctx, int stream, double* h_out21) {
+  if (!ctx || !ctx->pipe || !h_out21) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  sync_all(ctx);
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  StreamState st;
+  hipMemcpy(&st, L.pipe.st + ls, sizeof(st), hipMemcpyDeviceToHost);
+  memcpy(h_out21, st.dbg_T_pnp, 56);
+  memcpy(h_out21 + 7, st.dbg_T_lm, 56);
+  memcpy(h_out21 + 14, st.dbg_T_pre, 56);
   return FLVIS_OK;
 }
 

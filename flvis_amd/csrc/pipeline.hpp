@@ -86,6 +86,7 @@ struct StreamState {
   int kf_pending;
   // pose_records (f2f_tracking.h:59, ID_POSE): ring in Pipe::rec_id / rec_T, oldest at rec_head
   int rec_head, rec_count;
+  double dbg_T_pnp[7], dbg_T_lm[7], dbg_T_pre[7];  // pose right after PnP-RANSAC / after the pose LM of the last Tracking frame (tests)
   int feeds;  // image_feed calls seen by this stream (= row of the device-side trajectory the frame is recorded in)
 };
 

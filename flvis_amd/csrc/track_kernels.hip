@@ -704,34 +704,51 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
     }
     __syncthreads();
     inliers = ctl[1];
-    // Gauss-Newton refinement on the inliers (stand-in for OpenCV's final solvePnP)
+    // Gauss-Newton refinement on the inliers (stand-in for OpenCV's final solvePnP).  The 21 + 6 normal-equation sums are
+    // SEQUENTIAL sums over the inliers in index order (as the CPU restatement adds them): lane l computes the terms of
+    // correspondence 64 c + l into an LDS row, lanes 0..26 then each add one column of the chunk in order.
+    constexpr int GN_ROW = 29;
+    __shared__ double gterms[64 * GN_ROW];
     __shared__ double gn[32];
     SE3d Tb = g2o_from_mat(R, t);
     for (int it = 0; it < 10; it++) {
-      double acc[32];
+      double sum = 0;
+      for (int c0 = 0; c0 < np; c0 += 64) {
+        const int i = c0 + lane;
+        double* row = gterms + lane * GN_ROW;
+        if (i < np && smask[i]) {
+          double e[2], J[2][6];
+          proj_edge(Tb, V3{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]}, (double)s2d[2 * i],
+                    (double)s2d[2 * i + 1], fx, fy, cx, cy, e, J);
+          int q = 0;
 #pragma unroll
-      for (int k = 0; k < 32; k++) acc[k] = 0;
-      for (int i = lane; i < np; i += 64) {
-        if (!smask[i]) continue;
-        double e[2], J[2][6];
-        proj_edge(Tb, V3{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]}, (double)s2d[2 * i],
-                  (double)s2d[2 * i + 1], fx, fy, cx, cy, e, J);
-        int q = 0;
+          for (int r = 0; r < 6; r++) {
+            row[21 + r] = J[0][r] * e[0] + J[1][r] * e[1];
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-          acc[21 + r] -= J[0][r] * e[0] + J[1][r] * e[1];
+            for (int c = r; c < 6; c++) row[q++] = J[0][r] * J[0][c] + J[1][r] * J[1][c];
+          }
+        } else {
 #pragma unroll
-          for (int c = r; c < 6; c++) acc[q++] += J[0][r] * J[0][c] + J[1][r] * J[1][c];
+          for (int k = 0; k < 27; k++) row[k] = 0.0;
         }
-      }
-      {
-        int idx;
-        const double tot = wave_reduce_scatter32(acc, idx);
         __builtin_amdgcn_wave_barrier();
-        if (!(lane & 1)) gn[idx] = tot;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 27) {
+          const double* col = gterms + lane;
+          if (lane < 21) {
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) sum += col[k * GN_ROW];
+          } else {
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) sum -= col[k * GN_ROW];  // b[r] -= J^T e
+          }
+        }
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
       }
+      if (lane < 27) gn[lane] = sum;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       double H[36], b[6], dx[6];
       int q = 0;
 #pragma unroll
@@ -744,6 +761,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
           q++;
         }
       }
+      __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
       if (!solve_spd6(H, b, dx)) break;
       Tb = g2o_mul(g2o_exp(dx), Tb);
@@ -761,6 +779,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
     if (smask[i] == 0) to[sidx[i]].inlier = 0;  // CameraFrame::updateLMState
   if (lane == 0) {
     store_pose7(st.T_c_w[cur], T);
+    store_pose7(st.dbg_T_pnp, T);
     st.pnp_cnt = inliers;
     if (inliers < 10) st.ok = 0;
   }
@@ -788,89 +807,78 @@ __global__ void k_track_post(Pipe p) {
 
 // ------------------------------------------------------------------------------------------------ pose-only LM
 // OptimizeInFrame::optimize: g2o Levenberg on one free pose, Huber(1), optimize(2), drop chi2 > 3, optimize(2).
-// One workgroup of PL_T threads per stream, NMAX / PL_T edges per thread (point, measurement and alive flag in registers
-// -- 512 threads keep the 256-VGPR budget the 6x6 normal equations need); the
-// 21+6 normal-equation sums are reduced per wave with the scattered butterfly and folded over the waves through LDS in
-// wave order (reproducible); every thread then solves the same 6x6 system, so the pose needs no broadcast.
-constexpr int PL_T = 512;
-constexpr int PL_NW = PL_T / 64;
-constexpr int PL_EPT = NMAX / PL_T;
+//
+// ONE WAVE per stream, and every sum is a SEQUENTIAL sum in active-edge order (g2o walks its active edges sorted by edge id
+// = landmark id, sparse_optimizer.cpp:493-498, and adds each edge's J^T W J into the Hessian block one after the other): the
+// result is bit for bit what the CPU restatement computes, which is what keeps the closed-loop front-end in lockstep.
+//   * the edges (has_3d && inlier landmarks) are gathered and sorted by id once (rank by counting, ids are unique);
+//   * per pass, lane l computes the terms of edge 64 c + l of chunk c (the 21 + 6 normal-equation entries and the robust
+//     chi2) into an LDS row; lanes 0..27 then each own ONE of the 28 sums and add their column of the chunk in edge order.
+//     240 edges = 4 chunks = 4 x 64 dependent fp64 adds per sum -- about 2 us, far below what the former 512-thread
+//     version spent in workgroup barriers and tree reductions (0.11 ms per launch);
+//   * every lane then solves the same 6x6 system, so the pose needs no broadcast.
+constexpr int PL_T = 64;
+constexpr int PL_ROW = 29;   // 28 sums per edge, padded: lane l writes row l (stride 29 doubles: 2-way bank conflicts at most)
+constexpr int PL_NS = 28;    // 21 (upper H) + 6 (b) + 1 (robust chi2)
 struct PoseLMShared {
-  double part[PL_NW][32];
-  double tot[32];
-  double red[PL_NW];
-  int s_cnt[PL_NW];
+  double pw[3][NMAX];        // edges in id order
+  double zu[NMAX], zv[NMAX];
+  unsigned char alive[NMAX];
+  short src[NMAX];           // landmark index of the k-th gathered edge (frame order)
+  double terms[64 * PL_ROW]; // one chunk of per-edge terms; holds the ids (long long[NMAX]) while the edges are ranked
+  double tot[PL_NS];
 };
+static_assert(sizeof(double) * 64 * PL_ROW >= sizeof(long long) * NMAX, "the id scratch must fit the terms buffer");
 
-struct PoseEdge {
-  V3 pw;
-  double zu, zv;
-  bool alive;
-};
-
-__device__ inline double pose_block_sum(double v, PoseLMShared& sh) {
-  v = wave_sum_f64(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  double r = 0;
-#pragma unroll
-  for (int k = 0; k < PL_NW; k++) r += sh.red[k];
-  return r;
-}
-
-__device__ inline double pose_robust_chi2(const SE3d& T, const PoseEdge* ed, PoseLMShared& sh, double fx, double fy,
-                                          double cx, double cy) {
-  double chi = 0;
-#pragma unroll
-  for (int k = 0; k < PL_EPT; k++)
-    if (ed[k].alive) {
-      double e[2];
-      proj_edge(T, ed[k].pw, ed[k].zu, ed[k].zv, fx, fy, cx, cy, e, nullptr);
-      chi += huber_rho(e[0] * e[0] + e[1] * e[1]);
-    }
-  return pose_block_sum(chi, sh);
-}
-
-__device__ inline void pose_lm_optimize(SE3d& T, const PoseEdge* ed, PoseLMShared& sh, int iterations, double fx, double fy,
-                                        double cx, double cy) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double lambda = -1, ni = 2;
-  for (int iteration = 0; iteration < iterations; iteration++) {
-    double currentChi = pose_robust_chi2(T, ed, sh, fx, fy, cx, cy);
-    double acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) acc[k] = 0;
-#pragma unroll
-    for (int k = 0; k < PL_EPT; k++)
-      if (ed[k].alive) {
-        double e[2], J[2][6];
-        proj_edge(T, ed[k].pw, ed[k].zu, ed[k].zv, fx, fy, cx, cy, e, J);
-        double c2 = e[0] * e[0] + e[1] * e[1];
-        double w = huber_w(c2);
-        double o0 = -e[0] * w, o1 = -e[1] * w;
+// one pass over the edges at pose T: tot[0..20] upper triangle of H (row major), tot[21..26] b, tot[27] robust chi2
+// (want_H == false: only tot[27]).  Sequential sums in edge order (see above).
+__device__ inline void pose_pass(const SE3d& T, PoseLMShared& sh, int n, bool want_H, double fx, double fy, double cx, double cy) {
+  const int lane = threadIdx.x;
+  double sum = 0;
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int e = c0 + lane;
+    double* row = sh.terms + lane * PL_ROW;
+    const bool on = e < n && sh.alive[e];
+    if (on) {
+      double er[2], J[2][6];
+      proj_edge(T, V3{sh.pw[0][e], sh.pw[1][e], sh.pw[2][e]}, sh.zu[e], sh.zv[e], fx, fy, cx, cy, er, want_H ? J : nullptr);
+      const double c2 = er[0] * er[0] + er[1] * er[1];
+      row[27] = huber_rho(c2);
+      if (want_H) {
+        const double w = huber_w(c2);
+        const double o0 = -er[0] * w, o1 = -er[1] * w;
         int q = 0;
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-          acc[21 + r] += J[0][r] * o0 + J[1][r] * o1;
+          row[21 + r] = J[0][r] * o0 + J[1][r] * o1;
 #pragma unroll
-          for (int c = r; c < 6; c++) acc[q++] += (J[0][r] * w) * J[0][c] + (J[1][r] * w) * J[1][c];
+          for (int cc = r; cc < 6; cc++) row[q++] = (J[0][r] * w) * J[0][cc] + (J[1][r] * w) * J[1][cc];
         }
       }
-    {
-      int idx;
-      const double tot = wave_reduce_scatter32(acc, idx);
-      __syncthreads();  // (previous readers of part / tot are done)
-      if (!(lane & 1)) sh.part[wv][idx] = tot;
-      __syncthreads();
-      if (threadIdx.x < 32) {
-        double a = 0;
+    } else {
 #pragma unroll
-        for (int k = 0; k < PL_NW; k++) a += sh.part[k][threadIdx.x];
-        sh.tot[threadIdx.x] = a;
-      }
-      __syncthreads();
+      for (int k = 0; k < PL_NS; k++) row[k] = 0.0;  // adding +0.0 is exact: the same as skipping the edge
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < PL_NS && (want_H || lane == 27)) {
+      const double* col = sh.terms + lane;
+#pragma unroll 8
+      for (int k = 0; k < 64; k++) sum += col[k * PL_ROW];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (lane < PL_NS) sh.tot[lane] = sum;
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ inline void pose_lm_optimize(SE3d& T, PoseLMShared& sh, int n, int iterations, double fx, double fy, double cx, double cy) {
+  double lambda = -1, ni = 2;
+  for (int iteration = 0; iteration < iterations; iteration++) {
+    pose_pass(T, sh, n, true, fx, fy, cx, cy);
+    double currentChi = sh.tot[27];
     double H[36], b[6];
     int q = 0;
 #pragma unroll
@@ -905,7 +913,10 @@ __device__ inline void pose_lm_optimize(SE3d& T, const PoseEdge* ed, PoseLMShare
       }
       bool ok2 = solve_spd6(Hl, b, x);
       if (ok2) T = g2o_mul(g2o_exp(x), T);
-      double tempChi = pose_robust_chi2(T, ed, sh, fx, fy, cx, cy);
+      __builtin_amdgcn_wave_barrier();  // tot[] was read by every lane above
+      asm volatile("" ::: "memory");
+      pose_pass(T, sh, n, false, fx, fy, cx, cy);
+      double tempChi = sh.tot[27];
       if (!ok2) tempChi = 1.7976931348623157e308;
       rho = currentChi - tempChi;
       double scale = 0;
@@ -914,7 +925,7 @@ __device__ inline void pose_lm_optimize(SE3d& T, const PoseEdge* ed, PoseLMShare
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && isfinite(tempChi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3.0);
+        double alpha = 1. - detm::det_powi((2 * rho - 1), 3);
         alpha = fmin(alpha, 2. / 3.);
         double scaleFactor = fmax(1. / 3., alpha);
         lambda *= scaleFactor;
@@ -931,6 +942,8 @@ __device__ inline void pose_lm_optimize(SE3d& T, const PoseEdge* ed, PoseLMShare
       }
       qmax++;
     } while (rho < 0 && qmax < 10);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
     if (qmax == 10 || rho == 0 || lambda_bad) break;
   }
 }
@@ -939,57 +952,74 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK) return;
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x;
   const int cur = st.cur;
   Landmark* lms = lm_ptr(p, cur, s);
   const int nl = st.n_lm[cur];
   __shared__ PoseLMShared sh;
-  // the edges are the (has3d && inlier) landmarks; their order does not enter any result except through summation order,
-  // which is fixed by the thread index
-  PoseEdge ed[PL_EPT];
+  long long* ids = reinterpret_cast<long long*>(sh.terms);
+  // gather the edges (has3d && inlier) in frame order
   int n = 0;
-#pragma unroll
-  for (int k = 0; k < PL_EPT; k++) {
-    const int i = tid + k * PL_T;
-    ed[k].alive = false;
-    ed[k].pw = V3{0, 0, 1};
-    ed[k].zu = ed[k].zv = 0;
-    if (i < nl && lms[i].has3d && lms[i].inlier) {
-      ed[k].pw = V3{lms[i].p3w[0], lms[i].p3w[1], lms[i].p3w[2]};
-      ed[k].zu = lms[i].p2u[0];
-      ed[k].zv = lms[i].p2u[1];
-      ed[k].alive = true;
+  for (int base = 0; base < nl; base += 64) {
+    const int i = base + lane;
+    const bool sel = i < nl && lms[i].has3d && lms[i].inlier;
+    const unsigned long long bm = __ballot(sel);
+    if (sel) {
+      const int k = n + lane_prefix(bm);
+      ids[k] = lms[i].id;
+      sh.src[k] = (short)i;
     }
-    int tot;
-    block_rank<PL_NW>(ed[k].alive, sh.s_cnt, tot);
-    n += tot;
+    n += __popcll(bm);
   }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   bool ok = n >= 10;
   if (ok) {
+    // active-edge order = ascending edge id (ids are unique): rank by counting, then the edge data goes to its rank
+    for (int k = lane; k < n; k += 64) {
+      const long long id = ids[k];
+      int rank = 0;
+      for (int j = 0; j < n; j++) rank += ids[j] < id;
+      const Landmark& lm = lms[sh.src[k]];
+      sh.pw[0][rank] = lm.p3w[0];
+      sh.pw[1][rank] = lm.p3w[1];
+      sh.pw[2][rank] = lm.p3w[2];
+      sh.zu[rank] = lm.p2u[0];
+      sh.zv[rank] = lm.p2u[1];
+      sh.alive[rank] = 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const double fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
     SE3d T0 = load_pose7(st.T_c_w[cur]);
+    if (lane == 0) store_pose7(st.dbg_T_pre, T0);
     SE3d T = g2o_from_mat(q_to_mat(T0.q), T0.t);
-    pose_lm_optimize(T, ed, sh, 2, fx, fy, cx, cy);
+    pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
     int alive = 0;
-#pragma unroll
-    for (int k = 0; k < PL_EPT; k++) {
-      if (ed[k].alive) {
-        double e[2];
-        proj_edge(T, ed[k].pw, ed[k].zu, ed[k].zv, fx, fy, cx, cy, e, nullptr);
-        if (e[0] * e[0] + e[1] * e[1] > 3.0) ed[k].alive = false;
+    for (int base = 0; base < n; base += 64) {
+      const int e = base + lane;
+      bool keep = false;
+      if (e < n) {
+        double er[2];
+        proj_edge(T, V3{sh.pw[0][e], sh.pw[1][e], sh.pw[2][e]}, sh.zu[e], sh.zv[e], fx, fy, cx, cy, er, nullptr);
+        keep = !(er[0] * er[0] + er[1] * er[1] > 3.0);
+        if (!keep) sh.alive[e] = 0;
       }
-      int tot;
-      block_rank<PL_NW>(ed[k].alive, sh.s_cnt, tot);
-      alive += tot;
+      alive += __popcll(__ballot(keep));
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (alive < 10) {
       ok = false;
     } else {
-      pose_lm_optimize(T, ed, sh, 2, fx, fy, cx, cy);
-      if (tid == 0) store_pose7(st.T_c_w[cur], se3_from_mat(q_to_mat(T.q), T.t));
+      pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
+      if (lane == 0) {
+        store_pose7(st.T_c_w[cur], se3_from_mat(q_to_mat(T.q), T.t));
+        store_pose7(st.dbg_T_lm, load_pose7(st.T_c_w[cur]));
+      }
     }
   }
-  if (!ok && tid == 0) track_fail(st);
+  if (!ok && lane == 0) track_fail(st);
 }
 
 // ------------------------------------------------------------------------------------------------ reprojection filter

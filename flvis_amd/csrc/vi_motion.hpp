@@ -87,7 +87,7 @@ __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const 
     m.t = t;
     if (st.vi_first) {
       if ((norm(acc) - g) < 0.3) {
-        V3 rpy{atan2(-acc.y, -acc.z), atan2(acc.x, -acc.z), 0};
+        V3 rpy{detm::det_atan2(-acc.y, -acc.z), detm::det_atan2(acc.x, -acc.z), 0};
         ms_set_q(m, rpy2Q(rpy));
         ring.push_back(m);
         st.vi_first = 0;

@@ -261,6 +261,9 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_fr
                            double min_dt);
 /* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
+/* Test aid: poses (tx ty tz qx qy qz qw) of a stream's last Tracking frame right after PnP-RANSAC and after the pose-only LM
+ * (the two fp64 stages of LKORBTracking::tracking / OptimizeInFrame::optimize), h_out21 = 3 x 7 doubles (the third: the pose the LM starts from). */
+int flvis_debug_stage_poses(flvis_ctx* ctx, int stream, double* h_out21);
 /* Raw device counter block (64 x int64): [0..7] as above, [8..] per-phase cycle counters of the BA kernel, filled only by
  * builds with -DFLVIS_BA_PROF (tuning aid, not part of the reference interface). */
 int flvis_debug_counters(flvis_ctx* ctx, int64_t* h_counters64);

@@ -328,7 +328,7 @@ void BAGraph::optimize(int iterations) {
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        double alpha = 1. - detm::det_powi((2 * rho - 1), 3);
         alpha = std::min(alpha, 2. / 3.);
         double scaleFactor = std::max(1. / 3., alpha);
         lambda *= scaleFactor;

@@ -236,10 +236,10 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) 
   ep = std::max(ep, 0.);
   ep = std::min(ep, 1.);
   double num = std::max(1. - p, DBL_MIN);
-  double denom = 1. - std::pow(1. - ep, modelPoints);
+  double denom = 1. - detm::det_powi(1. - ep, modelPoints);
   if (denom < DBL_MIN) return 0;
-  num = std::log(num);
-  denom = std::log(denom);
+  num = detm::det_log(num);
+  denom = detm::det_log(denom);
   return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)lrint(num / denom);
 }
 
@@ -674,6 +674,11 @@ static void g2o_pose_optimize(SE3& T, const std::vector<PoseEdge>& E, int iterat
         for (int c = 0; c < 6; c++) H[6 * r + c] += (J[0][r] * w) * J[0][c] + (J[1][r] * w) * J[1][c];
       }
     }
+    // the linear solver reads ONE triangle: g2o's LinearSolverEigen factorises SimplicialLDLT<SparseMatrix, Eigen::Upper>
+    // (solvers/eigen/linear_solver_eigen.h:44).  With a robust weight w != 1 the two triangles of A^T (w Omega) A differ in
+    // the last bit ((J_r w) J_c vs (J_c w) J_r), so the upper triangle is mirrored before the solve.
+    for (int r = 0; r < 6; r++)
+      for (int c = r + 1; c < 6; c++) H[6 * c + r] = H[6 * r + c];
     if (iteration == 0) {
       double maxDiag = 0;
       for (int j = 0; j < 6; j++) maxDiag = std::max(std::fabs(H[7 * j]), maxDiag);
@@ -699,7 +704,7 @@ static void g2o_pose_optimize(SE3& T, const std::vector<PoseEdge>& E, int iterat
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        double alpha = 1. - detm::det_powi((2 * rho - 1), 3);
         alpha = std::min(alpha, 2. / 3.);
         double scaleFactor = std::max(1. / 3., alpha);
         lambda *= scaleFactor;

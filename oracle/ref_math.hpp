@@ -9,6 +9,10 @@
 //   kinetic_math.h                src/utils/include/kinetic_math.h:17-141
 // parity unpinned: the reference ships no golden vectors for any of this.
 #pragma once
+// sin / cos / atan / atan2 / log / small integer powers are the SHARED deterministic definitions of the HIP kernels
+// (flvis_amd/csrc/det_math.hpp, fdlibm algorithms, < 1 ulp from libm): one arithmetic on both sides makes the closed-loop
+// front-end comparable bit for bit.  Where the reference calls std::pow(x, 3) / pow(1 - ep, n) this oracle multiplies.
+#include "../flvis_amd/csrc/det_math.hpp"
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -186,7 +190,7 @@ inline Vec3 so3_log(Quat q) {
       else
         two_atan_nbyw_by_n = -M_PI / n;
     }
-    two_atan_nbyw_by_n = 2 * std::atan(n / w) / n;
+    two_atan_nbyw_by_n = 2 * detm::det_atan(n / w) / n;
   }
   return {two_atan_nbyw_by_n * q.x, two_atan_nbyw_by_n * q.y, two_atan_nbyw_by_n * q.z};
 }
@@ -226,9 +230,9 @@ inline SE3 g2o_exp(const double* upd) {
     R = mat3_add(mat3_add(I, Omega), Omega2, 0.5);
     V = mat3_add(mat3_add(I, Omega, 0.5), Omega2, 1.0 / 6.0);
   } else {
-    R = mat3_add(mat3_add(I, Omega, std::sin(theta) / theta), Omega2, (1 - std::cos(theta)) / (theta * theta));
-    V = mat3_add(mat3_add(I, Omega, (1 - std::cos(theta)) / (theta * theta)), Omega2,
-                 (theta - std::sin(theta)) / (theta * theta * theta));
+    const double st = detm::det_sin(theta), ct = detm::det_cos(theta);
+    R = mat3_add(mat3_add(I, Omega, st / theta), Omega2, (1 - ct) / (theta * theta));
+    V = mat3_add(mat3_add(I, Omega, (1 - ct) / (theta * theta)), Omega2, (theta - st) / (theta * theta * theta));
   }
   SE3 r{mat_to_quat(R), V * upsilon};
   g2o_normalize_rotation(r.q);
@@ -238,7 +242,7 @@ inline SE3 g2o_exp(const double* upd) {
 // kinetic_math.h:17-91 roll/pitch/yaw helpers (R = Rz*Ry*Rx)
 inline Mat3 rpy2R(Vec3 rpy) {
   double r = rpy.x, p = rpy.y, y = rpy.z;
-  double cy = std::cos(y), sy = std::sin(y), cp = std::cos(p), sp = std::sin(p), cr = std::cos(r), sr = std::sin(r);
+  double cy = detm::det_cos(y), sy = detm::det_sin(y), cp = detm::det_cos(p), sp = detm::det_sin(p), cr = detm::det_cos(r), sr = detm::det_sin(r);
   Mat3 R;
   R.m[0][0] = cy * cp;
   R.m[0][1] = cy * sp * sr - sy * cr;
@@ -253,9 +257,9 @@ inline Mat3 rpy2R(Vec3 rpy) {
 }
 inline Vec3 R2rpy(const Mat3& R) {
   Vec3 rpy;
-  rpy.x = std::atan2(R.m[2][1], R.m[2][2]);
-  rpy.y = std::atan2(-R.m[2][0], std::sqrt(R.m[2][1] * R.m[2][1] + R.m[2][2] * R.m[2][2]));
-  rpy.z = std::atan2(R.m[1][0], R.m[0][0]);
+  rpy.x = detm::det_atan2(R.m[2][1], R.m[2][2]);
+  rpy.y = detm::det_atan2(-R.m[2][0], std::sqrt(R.m[2][1] * R.m[2][1] + R.m[2][2] * R.m[2][2]));
+  rpy.z = detm::det_atan2(R.m[1][0], R.m[0][0]);
   return rpy;
 }
 inline Quat rpy2Q(Vec3 rpy) { return mat_to_quat(rpy2R(rpy)); }

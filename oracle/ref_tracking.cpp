@@ -423,7 +423,7 @@ void VIMOTION::viIMUinitialization(const IMUSTATE& imu, Quat& q_w_i, Vec3& pos, 
   Vec3 gyro = imu.gyro_raw - gyro_bias;
   if (is_first_data) {
     if ((norm(acc) - magnitude_g) < 0.3) {
-      Vec3 rpy{std::atan2(-acc.y, -acc.z), std::atan2(acc.x, -acc.z), 0};
+      Vec3 rpy{detm::det_atan2(-acc.y, -acc.z), detm::det_atan2(acc.x, -acc.z), 0};
       init_state.q_w_i = rpy2Q(rpy);
       states.push_back(init_state);
       if (states.size() >= STATES_QUEUE_SIZE) states.pop_front();
@@ -892,6 +892,7 @@ bool F2FTracking::lk_tracking(CameraFrame& from, CameraFrame& to, const SE3& gue
       indexLM++;
     }
   to.T_c_w = T;
+  dbg_T_pnp = T;
   dbg_pnp_inlier = pnp_inliers;
   return pnp_inliers >= 10;
 }
@@ -1005,8 +1006,10 @@ void F2FTracking::image_feed(double time, const uint8_t* img0_in, const uint8_t*
             p2.push_back(lm.lm_2d_undistort);
             ids.push_back(lm.lm_id);
           }
+        dbg_T_pre = curr_frame->T_c_w;
         bool ok = optimize_in_frame(curr_frame->T_c_w, p3.data(), p2.data(), ids.data(), (int)p3.size(), d_camera.cam0_fx,
                                     d_camera.cam0_fy, d_camera.cam0_cx, d_camera.cam0_cy);
+        dbg_T_lm = curr_frame->T_c_w;
         if (!ok) {
           continus_tracking_fail_cnt++;
           std::swap(last_frame, curr_frame);
@@ -1225,6 +1228,15 @@ void ref_tracker_correction_feed(void* h, int64_t frame_id, const double* pose7,
   f->correction_feed(c);
 }
 // pose_records dump: rows (frame_id, pose7), oldest first
+// stage poses of the last Tracking frame (tests): out21 = pose7 after solvePnPRansac, pose7 after OptimizeInFrame
+void ref_tracker_stage_poses(void* h, double* out21) {
+  ref::F2FTracking* f = (ref::F2FTracking*)h;
+  const ref::SE3* T[3] = {&f->dbg_T_pnp, &f->dbg_T_lm, &f->dbg_T_pre};
+  for (int k = 0; k < 3; k++) {
+    const double o[7] = {T[k]->t.x, T[k]->t.y, T[k]->t.z, T[k]->q.x, T[k]->q.y, T[k]->q.z, T[k]->q.w};
+    memcpy(out21 + 7 * k, o, sizeof(o));
+  }
+}
 int ref_tracker_pose_records(void* h, int cap, double* rows8) {
   ref::F2FTracking* f = (ref::F2FTracking*)h;
   int n = (int)f->pose_records.size();

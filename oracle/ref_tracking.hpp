@@ -141,6 +141,7 @@ class F2FTracking {  // src/frontend/f2f_tracking.cpp
   uint64_t ransac_seed;
   // per-frame diagnostics (tests): counts printed by lkorb_tracking.cpp:191
   int dbg_of_inlier, dbg_F_inlier, dbg_pnp_inlier;
+  SE3 dbg_T_pnp = se3_identity(), dbg_T_lm = se3_identity(), dbg_T_pre = se3_identity();  // pose right after solvePnPRansac / after OptimizeInFrame (tests)
 
  private:
   bool init_frame();

@@ -89,21 +89,16 @@ def _run_batch(cfg, S, nframes, sampled, ocfg=None, lanes=None):
 
 
 def _compare_stream(got, want, where):
-    """Frame-by-frame comparison of one stream: exact discrete decisions while in lockstep, statistical afterwards (see
-    test_gpu_pipeline.py for the two regimes).  Returns the number of tracked frames compared exactly."""
-    lock, n_lock = True, 0
+    """Frame-by-frame comparison of one stream: LOCKSTEP for the whole run -- every discrete decision and the pose itself are
+    identical on both sides (see tests/test_gpu_pipeline.py for what makes that possible).  Returns the tracked frames compared."""
+    n = 0
     for f, (g, w) in enumerate(zip(got, want)):
         tag = "%s frame %d" % (where, f)
         assert g["state"] == w["state"] and g["new_keyframe"] == w["new_keyframe"], tag
-        dpose = np.abs(g["pose7"] - w["pose7"]).max()
-        if lock and not (g["n_landmarks"] == w["n_landmarks"] and np.array_equal(g["dbg"], w["dbg"]) and dpose <= 1e-6):
-            lock = False
-        assert dpose < (1e-6 if lock else 1e-3), (tag, dpose)
-        if lock:
-            n_lock += w["state"] == 1
-        else:
-            assert abs(g["n_landmarks"] - w["n_landmarks"]) <= max(10, 0.1 * w["n_landmarks"]), tag
-    return n_lock, lock
+        assert g["n_landmarks"] == w["n_landmarks"] and np.array_equal(g["dbg"], w["dbg"]), tag
+        assert np.array_equal(g["pose7"], w["pose7"]), (tag, g["pose7"] - w["pose7"])
+        n += w["state"] == 1
+    return n
 
 
 def test_config3_batch_of_64_streams_with_local_map():
@@ -123,15 +118,14 @@ def test_config3_batch_of_64_streams_with_local_map():
     assert np.all(states[:, cfg.skip_first_n_imgs:] == 1), "a stream left the Tracking state"
     assert a["counters"][0] == S * nframes and a["counters"][1] >= 4 * S        # >= 4 keyframes per stream in 22 frames
     for i in sampled:
-        n_lock, locked = _compare_stream(a["got"][i], a["want"][i], "stream %d" % i)
-        assert n_lock >= 12
+        assert _compare_stream(a["got"][i], a["want"][i], "stream %d" % i) == 22
         gc, wc = a["corr"][i], a["ref_corr"][i]                                 # the last CorrectionInf of the stream
         assert (gc is None) == (wc is None)
-        if gc is not None:
+        if gc is not None:      # same keyframes in (bit-identical front-ends), same bookkeeping; the optimiser sums in another order
             assert gc["frame_id"] == wc["frame_id"]
-            if locked:
-                assert np.array_equal(gc["lm_id"], wc["lm_id"]) and np.array_equal(gc["outlier_id"], wc["outlier_id"])
-                assert np.allclose(gc["pose7"], wc["pose7"], atol=1e-4, rtol=0)
+            assert np.array_equal(gc["lm_id"], wc["lm_id"]) and np.array_equal(gc["outlier_id"], wc["outlier_id"])
+            assert np.allclose(gc["pose7"], wc["pose7"], atol=1e-6, rtol=0)
+            assert np.allclose(gc["lm_3d"], wc["lm_3d"], atol=1e-6, rtol=0)
     digest = hashlib.sha256(a["rows"].tobytes()).hexdigest()
     b = _run_batch(cfg, S, nframes, sampled)
     assert hashlib.sha256(b["rows"].tobytes()).hexdigest() == digest, "two identical runs differ"
@@ -167,7 +161,7 @@ def test_config2_single_stream_frontend_and_ba_together():
     cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
     assert cfg.window_size == 10
     rig = synth.euroc_rig()
-    nframes, sid = 52, 9
+    nframes, sid = 64, 9
     ctx = flvis_amd.Context(0)
     trk = flvis_amd.Tracker(ctx, cfg, 1, seed_base=0xF1715, traj_capacity=nframes)
     ref = O.Tracker(ocfg, 0xF1715)
@@ -175,7 +169,7 @@ def test_config2_single_stream_frontend_and_ba_together():
     tr = synth.Trajectory(sid)
     rnd = synth.Renderer("cuda", rig=rig)
     t_prev = -0.05
-    lock, n_corr, n_corr_exact, max_lm = True, 0, 0, 0
+    n_corr, max_lm = 0, 0
     want_c = None
     for f in range(nframes):
         t = f / synth.FRAME_HZ
@@ -189,10 +183,8 @@ def test_config2_single_stream_frontend_and_ba_together():
         w = ref.image(t, i0[0].cpu().numpy(), i1[0].cpu().numpy())
         where = "frame %d" % f
         assert g["state"] == w["state"] and g["new_keyframe"] == w["new_keyframe"], where
-        dpose = np.abs(g["pose7"] - w["pose7"]).max()
-        if lock and not (g["n_landmarks"] == w["n_landmarks"] and np.array_equal(g["dbg"], w["dbg"]) and dpose <= 1e-6):
-            lock = False
-        assert dpose < (1e-6 if lock else 3e-3), (where, dpose)   # out of lockstep: two valid roundings, a few mm apart
+        assert g["n_landmarks"] == w["n_landmarks"] and np.array_equal(g["dbg"], w["dbg"]), where
+        assert np.array_equal(g["pose7"], w["pose7"]), (where, g["pose7"] - w["pose7"])      # front-end: lockstep
         max_lm = max(max_lm, g["n_landmarks"])
         if not w["new_keyframe"]:
             continue
@@ -205,17 +197,13 @@ def test_config2_single_stream_frontend_and_ba_together():
         if want_c is None:
             continue
         n_corr += 1
+        # identical keyframes went in: the bookkeeping (ids, outliers) is exact, the optimiser (20 LM iterations, its sums are
+        # register-tile / wave reductions in another order than the restatement's loops) agrees to 1e-6 m
         assert got_c["frame_id"] == want_c["frame_id"], where
-        if lock:
-            n_corr_exact += 1
-            assert np.array_equal(got_c["lm_id"], want_c["lm_id"]), where
-            assert np.array_equal(got_c["outlier_id"], want_c["outlier_id"]), where
-            # the two windows were built from keyframes that agree to ~1e-9 (poses) / <= 2e-3 m (stereo depths): 20 LM iterations
-            assert np.allclose(got_c["pose7"], want_c["pose7"], atol=1e-4, rtol=0), (where, got_c["pose7"] - want_c["pose7"])
-            assert np.allclose(got_c["lm_3d"], want_c["lm_3d"], atol=5e-3, rtol=0), (where, np.abs(got_c["lm_3d"] - want_c["lm_3d"]).max())
-        else:
-            assert abs(len(got_c["lm_id"]) - len(want_c["lm_id"])) <= max(10, 0.1 * len(want_c["lm_id"])), where
-            assert np.allclose(got_c["pose7"], want_c["pose7"], atol=5e-3, rtol=0), where
+        assert np.array_equal(got_c["lm_id"], want_c["lm_id"]), where
+        assert np.array_equal(got_c["outlier_id"], want_c["outlier_id"]), where
+        assert np.allclose(got_c["pose7"], want_c["pose7"], atol=1e-6, rtol=0), (where, got_c["pose7"] - want_c["pose7"])
+        assert np.allclose(got_c["lm_3d"], want_c["lm_3d"], atol=1e-6, rtol=0), (where, np.abs(got_c["lm_3d"] - want_c["lm_3d"]).max())
     ctx.close()
-    assert n_corr >= 3 and n_corr_exact >= 1, (n_corr, n_corr_exact)
+    assert n_corr >= 3, n_corr
     assert 250 <= max_lm <= 480, max_lm
