@@ -115,6 +115,7 @@ struct BAShared {
   int NR, LD, off_linv, off_stage;  // reduced system geometry: Hs[NR][LD], Linv, chunk buffers (double offsets)
   int CI, CL, bufd, nchunk;         // chunk capacities (items, landmarks), doubles per buffer, chunk count
   int npairs, slices, rs;           // role partition of the Schur phase
+  int use_mfma, NRp, CLm, nchunk_m;  // MFMA variant of the Schur phase: padded system size, landmarks per dense chunk
   int wscan[BA_NW];
   int chunk_l0[BA_MAXCHUNK + 1];    // first landmark / first item of every chunk
   int chunk_i0[BA_MAXCHUNK + 1];
@@ -340,6 +341,13 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     sh.npairs = npairs;
     sh.slices = slices;
     sh.rs = rs;
+    // MFMA variant: the chunk is the DENSE (NR + 1 rows padded to 16) x (3 columns per landmark) slice of Z' = [Z; c^T]
+    const int NRp = (NR + 1 + 15) & ~15;
+    int CLm = ((2 * per_buf) / (3 * NRp)) & ~3;  // 3 * CLm columns, a multiple of the MFMA's K = 4
+    if (CLm > 252) CLm = 252;
+    sh.NRp = NRp;
+    sh.CLm = CLm;
+    sh.nchunk_m = CLm > 0 ? (L + CLm - 1) / CLm : 0;
   }
   __syncthreads();
   for (int l = t; l < Lc; l += BA_T) {
@@ -894,6 +902,147 @@ __device__ __noinline__ void ba_phase_schur(double lambda) {
   }
 }
 
+// The same reduced system through the matrix cores (north_star: "an MFMA dense solve only for the reduced camera block").
+// Z' = [Z; c^T] is formed DENSE, (NR + 1) rows padded to NRp (a multiple of 16) by 3 columns per landmark, in LDS chunks of CLm
+// landmarks, k-major (Zt[column][NRp]); unobserved (landmark, pose) blocks are written as zeros.  S' = Z' Z'^T is a SYRK:
+// every 16 x 16 tile of its lower triangle is accumulated by one wave with v_mfma_f64_16x16x4_f64 over all columns (A = rows
+// of tile ti, B = rows of tile tj, both read from the same Zt).  S' holds sum Z Z^T in its leading NR x NR block and sum Z c in
+// row NR.  More arithmetic than the sparse register-tile version (zeros are multiplied too), on units that are otherwise idle.
+typedef double ba_d4 __attribute__((ext_vector_type(4)));
+__device__ __noinline__ void ba_phase_schur_mfma(double lambda) {
+  BAShared& sh = ba_sh();
+  const BAScratch sc = sh.sc;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, Lc = sc.Lc, Ec = sc.Ec, P = sh.P, L = sh.L;
+  const int NR = sh.NR, NRp = sh.NRp, CLm = sh.CLm, LD = sh.LD;
+  double* Hs = ba_dyn();
+  double* Zt = Hs + sh.off_stage;
+  const int nt = NRp >> 4, ntiles = nt * (nt + 1) / 2;
+  // this wave's tiles (lower triangle, row-major enumeration): slot q handles tile index wv + q * BA_NW
+  constexpr int MAXQ = 3;  // 21 tiles (W = 16) over 8 waves
+  int ti[MAXQ], tj[MAXQ];
+  ba_d4 acc[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; q++) {
+    const int idx = wv + q * BA_NW;
+    ti[q] = -1;
+    tj[q] = 0;
+    if (idx < ntiles) {
+      int r = 0, rem = idx;
+      while (rem > r) {
+        rem -= r + 1;
+        r++;
+      }
+      ti[q] = r;
+      tj[q] = rem;
+    }
+    acc[q] = ba_d4{0, 0, 0, 0};
+  }
+  const int a_row = lane & 15, a_k = lane >> 4;
+  for (int c = 0; c < sh.nchunk_m; c++) {
+    const int l0 = c * CLm, nl = (L - l0 < CLm) ? L - l0 : CLm;
+    const int ncol = (3 * nl + 3) & ~3;
+    __syncthreads();  // the previous chunk's MFMAs are done with Zt
+    // stage: one (landmark, free pose) block per thread step -- Z = B G^-T or zeros; then the c row and the padding
+    for (int idx = t; idx < nl * P; idx += BA_T) {
+      const int ll = idx / P, h = idx - ll * P, l = l0 + ll;
+      const unsigned fm = sc.fmask[l];
+      double zz[18];
+      if ((fm >> h) & 1u) {
+        const int it = sc.ibase[l] + __popc(fm & ((1u << h) - 1u));
+        double rB[18], rH[6];
+#pragma unroll
+        for (int k = 0; k < 18; k++) rB[k] = sc.BdI[(size_t)k * Ec + it];
+#pragma unroll
+        for (int k = 0; k < 6; k++) rH[k] = sc.HllI[(size_t)k * Ec + it];
+        const Chol3 g = chol3(rH, lambda);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          zz[3 * r] = rB[3 * r] * g.i00;
+          zz[3 * r + 1] = (rB[3 * r + 1] - zz[3 * r] * g.g10) * g.i11;
+          zz[3 * r + 2] = (rB[3 * r + 2] - zz[3 * r] * g.g20 - zz[3 * r + 1] * g.g21) * g.i22;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 18; k++) zz[k] = 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        double* col = Zt + (size_t)(3 * ll + j) * NRp + 6 * h;
+#pragma unroll
+        for (int r = 0; r < 6; r++) col[r] = zz[3 * r + j];
+      }
+    }
+    for (int ll = t; ll < nl; ll += BA_T) {  // row NR: c = G^-1 bl; rows above it up to NRp: zero
+      const int l = l0 + ll;
+      double cv[3] = {0, 0, 0};
+      if (sc.fmask[l]) {
+        double rH2[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) rH2[k] = sc.Hll[(size_t)k * Lc + l];
+        const Chol3 g = chol3(rH2, lambda);
+        cv[0] = sc.bl[l] * g.i00;
+        cv[1] = (sc.bl[(size_t)Lc + l] - g.g10 * cv[0]) * g.i11;
+        cv[2] = (sc.bl[(size_t)2 * Lc + l] - g.g20 * cv[0] - g.g21 * cv[1]) * g.i22;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        double* col = Zt + (size_t)(3 * ll + j) * NRp;
+        col[NR] = cv[j];
+        for (int r = NR + 1; r < NRp; r++) col[r] = 0.0;
+      }
+    }
+    for (int i = t; i < (ncol - 3 * nl) * NRp; i += BA_T) Zt[(size_t)3 * nl * NRp + i] = 0.0;  // padding columns
+    __syncthreads();
+    BAPROF(2);
+    // SYRK on the matrix cores: operands of 8 k-steps are fetched from LDS before their 8 MFMAs are issued, two accumulators
+    // per tile (even / odd k-steps) keep consecutive MFMAs independent
+    const int ksteps = ncol >> 2;
+#pragma unroll
+    for (int q = 0; q < MAXQ; q++) {
+      if (ti[q] < 0) continue;
+      const double* pa = Zt + (size_t)a_k * NRp + 16 * ti[q] + a_row;
+      const double* pb = Zt + (size_t)a_k * NRp + 16 * tj[q] + a_row;
+      ba_d4 d0 = acc[q], d1 = ba_d4{0, 0, 0, 0};
+      int ks = 0;
+      for (; ks + 8 <= ksteps; ks += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          a[u] = pa[(size_t)4 * (ks + u) * NRp];
+          b[u] = pb[(size_t)4 * (ks + u) * NRp];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u + 1], b[u + 1], d1, 0, 0, 0);
+        }
+      }
+      for (; ks < ksteps; ks++) d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)4 * ks * NRp], pb[(size_t)4 * ks * NRp], d0, 0, 0, 0);
+      acc[q] = d0 + d1;
+    }
+    BAPROF(12);
+  }
+  // S (lower triangle + full diagonal blocks) and the rhs from the accumulated tiles.  C/D layout of v_mfma_f64_16x16x4_f64:
+  // register v of lane l holds D[(l >> 4) + 4 v][l & 15] (NOT the f32 forms' 4 (l >> 4) + v)
+#pragma unroll
+  for (int q = 0; q < MAXQ; q++) {
+    if (ti[q] < 0) continue;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int row = 16 * ti[q] + (lane >> 4) + 4 * v, col = 16 * tj[q] + (lane & 15);
+      const double a = acc[q][v];
+      if (row == NR && col < NR) sh.x[col] = sh.b[col] - a;  // bschur = bp - sum Z c
+      if (row < NR && col <= row) {
+        const bool same_block = (row / 6) == (col / 6);
+        double val = -a;
+        if (same_block) val += sh.Hpp[row / 6][6 * (col % 6) + (row % 6)] + (row == col ? lambda : 0.0);
+        Hs[row * LD + col] = val;
+        if (same_block && row != col) Hs[col * LD + row] = val;
+      }
+    }
+  }
+}
+
 // wave 0: factor + solve the reduced system, then form the trial poses x (+) pose (unchanged poses if the factorisation
 // failed) and their (R | t) tables
 __device__ __noinline__ void ba_phase_solve_poses() {
@@ -1045,7 +1194,10 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
     bool lambda_bad = false;
     do {
       BAPROF(0);
-      ba_phase_schur(lambda);
+      if (sh.use_mfma)
+        ba_phase_schur_mfma(lambda);
+      else
+        ba_phase_schur(lambda);
       __syncthreads();
       BAPROF(7);
       if (t < 64) ba_phase_solve_poses();
@@ -1109,6 +1261,7 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
   if (t == 0) {
     sh.sc = carve(p.ba_scratch + (size_t)s * p.ba_scratch_stride, L, E, W);
     sh.W = W;
+    sh.use_mfma = p.ba_mfma;
     sh.K[0] = p.cam.fx;
     sh.K[1] = p.cam.fy;
     sh.K[2] = p.cam.cx;

@@ -341,6 +341,8 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   p.corr_in = nullptr;  // allocated by the first flvis_correction_feed
   DA(counters, long long, 64);
   p.ba_scratch_stride = ba_scratch_doubles();
+  p.ba_mfma = 0;
+  if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;  // A/B knob, see DESIGN.md section 4
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
   unsigned long long* seeds = dalloc<unsigned long long>(L->allocs, S);
   ok = ok && seeds;

@@ -49,6 +49,7 @@ struct Pipe {
   CorrectionDev* corr;      // [S]
   double* ba_scratch;       // [S][ba_scratch_stride]
   size_t ba_scratch_stride;
+  int ba_mfma;              // Schur complement of the window solver on the matrix cores (v_mfma_f64_16x16x4_f64) or as register tiles
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
   // local-map feedback (F2FTracking::correction_feed, dead in the reference's v2)
   int* rec_id;              // [S][POSE_REC]  ID_POSE::frame_id (an int in the reference)
