@@ -1061,6 +1061,51 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
   return kf.lm_count;
 }
 
+int flvis_get_keyframe_msg(flvis_ctx* ctx, int stream, int cap, flvis_keyframe* kf, int64_t* h_id, double* h_2d, double* h_3d,
+                           uint8_t* h_img0, uint8_t* h_img1) {
+  if (!ctx || !ctx->pipe || !kf || cap < 0 || (cap && (!h_id || !h_2d || !h_3d))) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  int64_t fid = 0;
+  const int n = flvis_get_keyframe(ctx, stream, cap, &fid, kf->T_c_w, h_id, h_2d, h_3d);
+  if (n <= 0) return n;
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  const int w = pl->cfg.image_width, h = pl->cfg.image_height;
+  const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;
+  unsigned tl = 0;
+  double stamp = 0;
+  int slot = 0;
+  hipMemcpy(&tl, L.pipe.kfq_tail + ls, sizeof(unsigned), hipMemcpyDeviceToHost);
+  hipMemcpy(&stamp, &L.pipe.kfq[(size_t)ls * KFQ + ((tl - 1) % KFQ)].stamp, sizeof(double), hipMemcpyDeviceToHost);
+  hipMemcpy(&slot, L.pipe.img_slot + ls, sizeof(int), hipMemcpyDeviceToHost);
+  kf->frame_id = fid;
+  kf->command = 0;  // KFMSG_CMD_NONE (keyframe_msg.h:10)
+  kf->stamp = stamp;
+  kf->lm_count = n;
+  kf->lm_id = h_id;
+  kf->lm_2d = h_2d;
+  kf->lm_3d = h_3d;
+  kf->img0 = flvis_image{h_img0, w, h, w, 1, stamp};
+  kf->img1 = flvis_image{h_img1, w, h, depth_cam ? 2 * w : w, 1, stamp};
+  hipError_t e = hipSuccess;
+  if (h_img0)  // level 0 of the left pyramid, the slot of the stream's last processed frame (after equalizeHist where used)
+    e = hipMemcpy2D(h_img0, w, L.pyr0[slot & 1][0] + (size_t)ls * pl->lstride[0], pl->lpitch[0], w, h, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && h_img1) {
+    const bool eq = pl->cfg.need_equal_hist != 0, aligned = (w & 15) == 0;
+    const uint8_t* tab[2] = {nullptr, nullptr};
+    if (depth_cam || (!eq && aligned)) {  // read in place from the caller's buffer of that frame (still the table's entry)
+      e = hipMemcpy(tab, L.d_tab, sizeof(tab), hipMemcpyDeviceToHost);
+      const size_t bpp = depth_cam ? 2 : 1;
+      if (e == hipSuccess) e = hipMemcpy(h_img1, tab[1] + (size_t)ls * w * h * bpp, (size_t)w * h * bpp, hipMemcpyDeviceToHost);
+    } else {
+      e = hipMemcpy2D(h_img1, w, L.pyr1[0] + (size_t)ls * pl->lstride[0], pl->lpitch[0], w, h, hipMemcpyDeviceToHost);
+    }
+  }
+  if (e != hipSuccess) return ctx->hip_fail(e, "get_keyframe_msg");
+  return n;
+}
+
 static int read_correction(Lane& L, int ls, int cap, int64_t* frame_id, double* T7, int* lm_count, int64_t* h_id,
                            double* h_3d, int* oc, int64_t* h_oid) {
   std::vector<CorrectionDev> cv(1);

@@ -103,6 +103,7 @@ struct KeyFrameDev {
   long long frame_id;
   int lm_count, valid;
   double T_c_w[7];
+  double stamp;  // header.stamp of the message: the frame's image time
   long long lm_id[KF_MAXLM];
   double lm_2d[KF_MAXLM][2];
   double lm_3d[KF_MAXLM][3];

@@ -1407,6 +1407,7 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
     }
     if (lane == 0) {
       kf.frame_id = st.frame_id[cur];
+      kf.stamp = st.frame_time[cur];
       kf.lm_count = cnt < KF_MAXLM ? cnt : KF_MAXLM;
       for (int j = 0; j < 7; j++) kf.T_c_w[j] = st.T_c_w[cur][j];
       kf.valid = 1;

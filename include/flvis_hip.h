@@ -232,6 +232,27 @@ int flvis_get_landmarks(flvis_ctx* ctx, int stream, int cap, int64_t* h_id, doub
 /* Last KeyFrame payload of a stream: returns lm_count (or <0); arrays of capacity cap. */
 int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T_c_w7, int64_t* h_lm_id,
                        double* h_lm_2d, double* h_lm_3d);
+/* The same keyframe as the full flvis/KeyFrame message (msg/KeyFrame.msg:1-11 as KeyFrameMsg::pub fills it,
+ * src/utils/keyframe_msg.cpp:30-124): header.stamp, frame_id, command (KFMSG_CMD_NONE = 0; the reference's reset publisher is
+ * commented out, vo_tracking.cpp:431 -- the reset request is flvis_frame_out.reset_cmd), the two images the tracker worked on
+ * (img0: mono8 AFTER equalizeHist where the rig uses it; img1: mono8, or the 16UC1 depth image on depth rigs), lm_count with the
+ * id / undistorted-pixel / world-point arrays, T_c_w; lm_descriptor_data is empty in the reference (:71-81).  The caller provides
+ * the arrays (capacity cap) and, optionally, host buffers for the images (width * height bytes, 2 bytes per pixel for a depth
+ * img1; NULL = not wanted).  Call it right after the flvis_image_feed that reported new_keyframe: the images are the
+ * tracker's working copies of THAT frame.  Returns lm_count (0: the stream's last frame was no keyframe; < 0: error). */
+typedef struct flvis_keyframe {
+  int64_t frame_id;
+  int8_t command;
+  double stamp;
+  flvis_image img0, img1;       /* data = the host buffers passed in (or NULL), pitch = tightly packed */
+  int32_t lm_count;
+  const int64_t* lm_id;         /* the caller's arrays */
+  const double* lm_2d;          /* [lm_count][2] undistorted pixel */
+  const double* lm_3d;          /* [lm_count][3] world */
+  double T_c_w[7];              /* tx ty tz qx qy qz qw */
+} flvis_keyframe;
+int flvis_get_keyframe_msg(flvis_ctx* ctx, int stream, int cap, flvis_keyframe* kf, int64_t* h_lm_id, double* h_lm_2d,
+                           double* h_lm_3d, uint8_t* h_img0, uint8_t* h_img1);
 /* Last CorrectionInf of a stream: returns 1 if one exists (0 if not yet, <0 error). */
 int flvis_get_correction(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, double* T_c_w7, int* lm_count,
                          int64_t* h_lm_id, double* h_lm_3d, int* lm_outlier_count, int64_t* h_outlier_id);

@@ -102,3 +102,26 @@ def test_orb_default_pattern_matches_the_oracle_generator():
     import flvis_amd
     import _oracle as O
     assert np.array_equal(flvis_amd.orb_default_pattern(), O.orb_default_pattern())
+
+
+def test_ros_wrappers_are_compile_gated_and_call_only_declared_entry_points():
+    """ros/: the two nodelet wrappers (flvis/TrackingNodeletClass, flvis/LocalMapNodeletClass) cannot be built here (no ROS); what
+    can be checked: the package configures to nothing without catkin, the plugin description names the reference's classes, and
+    every flvis_* function the wrappers call is declared in include/flvis_hip.h."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hdr = open(os.path.join(ROOT, "include", "flvis_hip.h")).read()
+    declared = set(re.findall(r"\b(flvis_[a-z0-9_]+)\s*\(", hdr))
+    for f in ("tracking_nodelet.cpp", "localmap_nodelet.cpp"):
+        src = open(os.path.join(ROOT, "ros", "src", f)).read()
+        called = set(re.findall(r"\b(flvis_[a-z0-9_]+)\s*\(", src))
+        assert called and called <= declared, (f, called - declared)
+        assert "PLUGINLIB_EXPORT_CLASS" in src
+    xml = open(os.path.join(ROOT, "ros", "flvis_hip_nodelets.xml")).read()
+    assert 'name="flvis/TrackingNodeletClass"' in xml and 'name="flvis/LocalMapNodeletClass"' in xml
+    if shutil.which("cmake"):
+        d = tempfile.mkdtemp(prefix="flvis_ros_cfg_")
+        r = subprocess.run(["cmake", "-S", os.path.join(ROOT, "ros"), "-B", d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+        assert r.returncode == 0 and b"catkin not found" in r.stdout, r.stdout.decode()[-1500:]
