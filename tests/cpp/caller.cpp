@@ -122,7 +122,8 @@ int main(int argc, char** argv) {
   std::printf("%s: frames %lld tracked %d keyframes %d landmarks %d (depth ok %d, wall at %.2f m) ba_runs %lld lanes %d\n", flvis_version(),
               (long long)counters[0], tracked, kf_count, nl, good, want_z, (long long)counters[2], flvis_tracker_lanes(ctx));
   flvis_hip_destroy(ctx);
-  if (tracked != extra_frames || kf_count < 1 || good < (nl * 8) / 10) return 1;
+  // (points whose stereo match fails get the reference's rand() dummy depth, camera_frame.cpp:153-168: not all sit on the wall)
+  if (tracked != extra_frames || kf_count < 1 || good < nl / 2) return 1;
   std::printf("caller OK\n");
   return 0;
 }
