@@ -39,7 +39,8 @@ def load_library(rebuild_if_stale=True):
                 raise FlvisError("cannot build libflvis_hip.so: %s" % e)
     if not os.path.exists(_build.LIB):
         raise FlvisError("libflvis_hip.so is missing (run python -c 'import __graft_entry__ as g; g.build()')")
-    _LIB = C.CDLL(_build.LIB)
+    # FLVIS_LIB_PATH: load another build of the same library (A/B runs of a kernel variant inside one benchmark session)
+    _LIB = C.CDLL(os.environ.get("FLVIS_LIB_PATH") or _build.LIB)
     _LIB.flvis_version.restype = C.c_char_p
     _LIB.flvis_last_error.restype = C.c_char_p
     _LIB.flvis_last_error.argtypes = [C.c_void_p]

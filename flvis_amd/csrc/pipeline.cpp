@@ -429,6 +429,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   if (cfg->need_equal_hist && (w & 15)) return ctx->fail(FLVIS_ERR_CONFIG, "equalizeHist rigs need an image width that is a multiple of 16");
   if (cfg->feature_para[5] > 64.0) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para6 (GFTT minDistance) > 64 is not supported");
   if (cfg->window_size > BA_WMAX) return ctx->fail(FLVIS_ERR_CAPACITY, "window_size exceeds the LDS-resident solver (16)");
+  if (16 * (int)cfg->feature_para[0] > 512) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para1 (landmarks per region) must be <= 32: the pose LM holds 512 edges");
   if ((int)cfg->feature_para[3] * 2 > 4096) return ctx->fail(FLVIS_ERR_CAPACITY, "feature_para4 (gftt_num) must be <= 2048");
   if ((size_t)((w + 31) / 32) * h * 4 > 96 * 1024) return ctx->fail(FLVIS_ERR_CAPACITY, "image too large for the GFTT LDS bitmap");
   if (cfg->cam_type == CAM_DEPTH && !(cfg->depth_factor > 0)) return ctx->fail(FLVIS_ERR_CONFIG, "depth mode needs depth_factor > 0");
@@ -493,7 +494,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     (void)hipGetLastError();
     return ctx->fail(FLVIS_ERR_HIP, "tracker_create: device / pinned allocation or stream creation failed");
   }
-  if (ba_kernels_init() != hipSuccess) {
+  if (ba_kernels_init() != hipSuccess || track_kernels_init() != hipSuccess) {
     (void)hipGetLastError();
     flvis_pipeline_destroy_internal(ctx);
     return ctx->fail(FLVIS_ERR_HIP, "tracker_create: cannot reserve LDS for the BA kernel");

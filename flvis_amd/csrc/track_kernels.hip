@@ -31,6 +31,9 @@ namespace flvis {
 
 FD Landmark* lm_ptr(const Pipe& p, int slot, int s) { return p.lm + ((size_t)slot * p.S + s) * NMAX; }
 
+// dynamic LDS of the kernels that need more than the 64 KB static window (k_pose_lm, the refinement of k_ransac_pnp)
+extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+
 // glibc rand() (TYPE_3): next output from the stream's ring
 FD int glibc_rand_next(StreamState& st) {
   int pos = st.rnd_pos;
@@ -808,36 +811,37 @@ __global__ void k_track_post(Pipe p) {
 // ------------------------------------------------------------------------------------------------ pose-only LM
 // OptimizeInFrame::optimize: g2o Levenberg on one free pose, Huber(1), optimize(2), drop chi2 > 3, optimize(2).
 //
-// ONE WAVE per stream, and every sum is a SEQUENTIAL sum in active-edge order (g2o walks its active edges sorted by edge id
+// One workgroup per stream; every sum is a SEQUENTIAL sum in active-edge order (g2o walks its active edges sorted by edge id
 // = landmark id, sparse_optimizer.cpp:493-498, and adds each edge's J^T W J into the Hessian block one after the other): the
 // result is bit for bit what the CPU restatement computes, which is what keeps the closed-loop front-end in lockstep.
 //   * the edges (has_3d && inlier landmarks) are gathered and sorted by id once (rank by counting, ids are unique);
-//   * per pass, lane l computes the terms of edge 64 c + l of chunk c (the 21 + 6 normal-equation entries and the robust
-//     chi2) into an LDS row; lanes 0..27 then each own ONE of the 28 sums and add their column of the chunk in edge order.
-//     240 edges = 4 chunks = 4 x 64 dependent fp64 adds per sum -- about 2 us, far below what the former 512-thread
-//     version spent in workgroup barriers and tree reductions (0.11 ms per launch);
+//   * per pass, thread t computes the terms of edge t of the chunk (256 edges; the 21 + 6 normal-equation entries and the
+//     robust chi2) into an LDS row; threads 0..27 then each own ONE of the 28 sums and add their column in edge order:
+//     240 dependent fp64 adds per sum, ~1.5 us, while the other threads wait at the barrier;
 //   * every lane then solves the same 6x6 system, so the pose needs no broadcast.
-constexpr int PL_T = 64;
-constexpr int PL_ROW = 29;   // 28 sums per edge, padded: lane l writes row l (stride 29 doubles: 2-way bank conflicts at most)
+constexpr int PL_T = 256;    // 4 waves compute the per-edge terms; wave 0 owns the 28 sequential sums
+constexpr int PL_ROW = 29;   // 28 sums per edge, padded: thread t writes row t (stride 29 doubles: 2-way bank conflicts at most)
 constexpr int PL_NS = 28;    // 21 (upper H) + 6 (b) + 1 (robust chi2)
+constexpr int PL_EMAX = 512; // edges of one pose LM (16 regions x 30 landmarks is the largest configured frame: 480)
 struct PoseLMShared {
-  double pw[3][NMAX];        // edges in id order
-  double zu[NMAX], zv[NMAX];
-  unsigned char alive[NMAX];
-  short src[NMAX];           // landmark index of the k-th gathered edge (frame order)
-  double terms[64 * PL_ROW]; // one chunk of per-edge terms; holds the ids (long long[NMAX]) while the edges are ranked
+  double pw[3][PL_EMAX];     // edges in id order
+  double zu[PL_EMAX], zv[PL_EMAX];
+  unsigned char alive[PL_EMAX];
+  short src[PL_EMAX];        // landmark index of the k-th gathered edge (frame order)
+  double terms[PL_T * PL_ROW]; // one chunk of per-edge terms; holds the ids (long long[PL_EMAX]) while the edges are ranked
   double tot[PL_NS];
+  int n;
 };
-static_assert(sizeof(double) * 64 * PL_ROW >= sizeof(long long) * NMAX, "the id scratch must fit the terms buffer");
+static_assert(sizeof(double) * PL_T * PL_ROW >= sizeof(long long) * PL_EMAX, "the id scratch must fit the terms buffer");
 
 // one pass over the edges at pose T: tot[0..20] upper triangle of H (row major), tot[21..26] b, tot[27] robust chi2
-// (want_H == false: only tot[27]).  Sequential sums in edge order (see above).
+// (want_H == false: only tot[27]).  Sequential sums in edge order (see above).  All threads of the workgroup call it.
 __device__ inline void pose_pass(const SE3d& T, PoseLMShared& sh, int n, bool want_H, double fx, double fy, double cx, double cy) {
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   double sum = 0;
-  for (int c0 = 0; c0 < n; c0 += 64) {
-    const int e = c0 + lane;
-    double* row = sh.terms + lane * PL_ROW;
+  for (int c0 = 0; c0 < n; c0 += PL_T) {
+    const int e = c0 + tid;
+    double* row = sh.terms + tid * PL_ROW;
     const bool on = e < n && sh.alive[e];
     if (on) {
       double er[2], J[2][6];
@@ -855,23 +859,28 @@ __device__ inline void pose_pass(const SE3d& T, PoseLMShared& sh, int n, bool wa
           for (int cc = r; cc < 6; cc++) row[q++] = (J[0][r] * w) * J[0][cc] + (J[1][r] * w) * J[1][cc];
         }
       }
-    } else {
+    } else if (e < n) {
 #pragma unroll
       for (int k = 0; k < PL_NS; k++) row[k] = 0.0;  // adding +0.0 is exact: the same as skipping the edge
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane < PL_NS && (want_H || lane == 27)) {
-      const double* col = sh.terms + lane;
-#pragma unroll 8
-      for (int k = 0; k < 64; k++) sum += col[k * PL_ROW];
+    __syncthreads();
+    if (tid < PL_NS && (want_H || tid == 27)) {
+      const double* col = sh.terms + tid;
+      const int m = (n - c0 < PL_T) ? n - c0 : PL_T;
+      int k = 0;
+      for (; k + 8 <= m; k += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = col[(k + u) * PL_ROW];
+#pragma unroll
+        for (int u = 0; u < 8; u++) sum += v[u];
+      }
+      for (; k < m; k++) sum += col[k * PL_ROW];
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
+    __syncthreads();
   }
-  if (lane < PL_NS) sh.tot[lane] = sum;
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (tid < PL_NS) sh.tot[tid] = sum;
+  __syncthreads();
 }
 
 __device__ inline void pose_lm_optimize(SE3d& T, PoseLMShared& sh, int n, int iterations, double fx, double fy, double cx, double cy) {
@@ -913,8 +922,7 @@ __device__ inline void pose_lm_optimize(SE3d& T, PoseLMShared& sh, int n, int it
       }
       bool ok2 = solve_spd6(Hl, b, x);
       if (ok2) T = g2o_mul(g2o_exp(x), T);
-      __builtin_amdgcn_wave_barrier();  // tot[] was read by every lane above
-      asm volatile("" ::: "memory");
+      __syncthreads();  // tot[] was read by every thread above
       pose_pass(T, sh, n, false, fx, fy, cx, cy);
       double tempChi = sh.tot[27];
       if (!ok2) tempChi = 1.7976931348623157e308;
@@ -942,8 +950,7 @@ __device__ inline void pose_lm_optimize(SE3d& T, PoseLMShared& sh, int n, int it
       }
       qmax++;
     } while (rho < 0 && qmax < 10);
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
+    __syncthreads();
     if (qmax == 10 || rho == 0 || lambda_bad) break;
   }
 }
@@ -952,31 +959,36 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int cur = st.cur;
   Landmark* lms = lm_ptr(p, cur, s);
   const int nl = st.n_lm[cur];
-  __shared__ PoseLMShared sh;
+  PoseLMShared& sh = *reinterpret_cast<PoseLMShared*>(pl_smem);
   long long* ids = reinterpret_cast<long long*>(sh.terms);
-  // gather the edges (has3d && inlier) in frame order
-  int n = 0;
-  for (int base = 0; base < nl; base += 64) {
-    const int i = base + lane;
-    const bool sel = i < nl && lms[i].has3d && lms[i].inlier;
-    const unsigned long long bm = __ballot(sel);
-    if (sel) {
-      const int k = n + lane_prefix(bm);
-      ids[k] = lms[i].id;
-      sh.src[k] = (short)i;
+  // gather the edges (has3d && inlier) in frame order (wave 0)
+  if (tid < 64) {
+    int n = 0;
+    for (int base = 0; base < nl; base += 64) {
+      const int i = base + lane;
+      const bool sel = i < nl && lms[i].has3d && lms[i].inlier;
+      const unsigned long long bm = __ballot(sel);
+      if (sel) {
+        const int k = n + lane_prefix(bm);
+        if (k < PL_EMAX) {
+          ids[k] = lms[i].id;
+          sh.src[k] = (short)i;
+        }
+      }
+      n += __popcll(bm);
     }
-    n += __popcll(bm);
+    if (lane == 0) sh.n = n < PL_EMAX ? n : PL_EMAX;
   }
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int n = sh.n;
   bool ok = n >= 10;
   if (ok) {
     // active-edge order = ascending edge id (ids are unique): rank by counting, then the edge data goes to its rank
-    for (int k = lane; k < n; k += 64) {
+    for (int k = tid; k < n; k += PL_T) {
       const long long id = ids[k];
       int rank = 0;
       for (int j = 0; j < n; j++) rank += ids[j] < id;
@@ -988,16 +1000,16 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
       sh.zv[rank] = lm.p2u[1];
       sh.alive[rank] = 1;
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
     const double fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
     SE3d T0 = load_pose7(st.T_c_w[cur]);
-    if (lane == 0) store_pose7(st.dbg_T_pre, T0);
+    if (tid == 0) store_pose7(st.dbg_T_pre, T0);
     SE3d T = g2o_from_mat(q_to_mat(T0.q), T0.t);
     pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
+    __shared__ int s_alive[PL_T / 64];
     int alive = 0;
-    for (int base = 0; base < n; base += 64) {
-      const int e = base + lane;
+    for (int base = 0; base < n; base += PL_T) {
+      const int e = base + tid;
       bool keep = false;
       if (e < n) {
         double er[2];
@@ -1005,21 +1017,22 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
         keep = !(er[0] * er[0] + er[1] * er[1] > 3.0);
         if (!keep) sh.alive[e] = 0;
       }
-      alive += __popcll(__ballot(keep));
+      int tot;
+      block_rank<PL_T / 64>(keep, s_alive, tot);
+      alive += tot;
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
     if (alive < 10) {
       ok = false;
     } else {
       pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
-      if (lane == 0) {
+      if (tid == 0) {
         store_pose7(st.T_c_w[cur], se3_from_mat(q_to_mat(T.q), T.t));
         store_pose7(st.dbg_T_lm, load_pose7(st.T_c_w[cur]));
       }
     }
   }
-  if (!ok && lane == 0) track_fail(st);
+  if (!ok && tid == 0) track_fail(st);
 }
 
 // ------------------------------------------------------------------------------------------------ reprojection filter
@@ -1437,7 +1450,10 @@ void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ran
 void launch_track_post(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_track_post, dim3((p.S + 63) / 64), dim3(64), 0, st, p);
 }
-void launch_pose_lm(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_pose_lm, dim3(p.S), dim3(PL_T), 0, st, p); }
+void launch_pose_lm(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_pose_lm, dim3(p.S), dim3(PL_T), sizeof(PoseLMShared), st, p); }
+hipError_t track_kernels_init() {
+  return hipFuncSetAttribute((const void*)k_pose_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLMShared));
+}
 void launch_reproj_filter(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_reproj_filter, dim3(p.S), dim3(NMAX), 0, st, p); }
 void launch_add_new(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_add_new, dim3(p.S), dim3(64), 0, st, p); }
 void launch_depth_prepare(hipStream_t st, const Pipe& p) {

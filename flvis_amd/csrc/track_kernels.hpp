@@ -77,6 +77,7 @@ void launch_frame_end(hipStream_t st, const Pipe& p);
 // local map
 void launch_ba_worker(hipStream_t st, const Pipe& p);
 hipError_t ba_kernels_init();
+hipError_t track_kernels_init();
 size_t ba_scratch_doubles();
 
 }  // namespace flvis
