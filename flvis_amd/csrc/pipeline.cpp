@@ -65,7 +65,7 @@ struct Lane {
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
-  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_fe = nullptr, ev_end = nullptr;
+  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_end = nullptr;
   // back-pressure on the keyframe queues in stream order: ev_ba_done[i % BAQ] follows the lane's i-th local-map launch; the
   // tracking stream waits for the launches of KFQ-3 frames ago before it appends new keyframes (see lane_frame)
   static constexpr int BAQ = 32;
@@ -219,7 +219,7 @@ static void lane_destroy(Lane* L) {
     hipStreamDestroy(L->det_stream);
   }
   if (L->own_st && L->st) hipStreamDestroy(L->st);
-  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_fe, L->ev_end})
+  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_end})
     if (e) hipEventDestroy(e);
   for (int k = 0; k < Lane::BAQ; k++)
     if (L->ev_ba_done[k]) hipEventDestroy(L->ev_ba_done[k]);
@@ -412,7 +412,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
     L->st = ctx->stream;
   }
   bool evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
-  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_fe, &L->ev_end})
+  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_end})
     evok = evok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < Lane::BAQ && evok; k++)
     evok = hipEventCreateWithFlags(&L->ev_ba_done[k], hipEventDisableTiming) == hipSuccess;
@@ -696,6 +696,16 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   ImgSel r0 = r_in_place ? in1 : img_plain(L->pyr1[0]);
   const int r0pitch = r_in_place ? w : pl->lpitch[0];
   const size_t r0stride = r_in_place ? (size_t)w * h : pl->lstride[0];
+  // order on the detection stream: the corner response first (FeatureDEM waits for it at the join; it then overlaps the
+  // temporal LK instead of the one-workgroup-per-stream RANSAC kernels it would slow down), the right pyramid after it (only
+  // the stereo matcher needs it, much later).  FLVIS_DET_ORDER=0 restores the round-1 order (A/B knob).
+  static const bool gftt_first = !(getenv("FLVIS_DET_ORDER") && atoi(getenv("FLVIS_DET_ORDER")) == 0);
+  if (gftt_first) {
+    launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
+                (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
+                (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
+    hipEventRecord(L->ev_gftt, ds);
+  }
   if (!depth_cam) {
     if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
     else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
@@ -703,9 +713,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
                       l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
   }
-  launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
-              (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
-              (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
+  if (!gftt_first) {
+    launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
+                (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
+                (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
+  }
   hipEventRecord(L->ev_det, ds);
   // temporal tracking
   PB(3, st);
@@ -736,8 +748,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(9, st);
   launch_reproj_filter(st, p);
   PE(9, st);
-  // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners
-  hipStreamWaitEvent(st, L->ev_det, 0);
+  // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners; the right pyramid is joined before the stereo LK
+  hipStreamWaitEvent(st, gftt_first ? L->ev_gftt : L->ev_det, 0);
   PB(13, st);
   launch_feature_dem(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
                      p.det_mode, p.exist_xy, p.n_exist, NMAX, p.new_xy, p.n_new, NEW_MAX);
@@ -747,6 +759,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(14, st);
   launch_depth_prepare(st, p);
   PE(14, st);
+  if (gftt_first) hipStreamWaitEvent(st, L->ev_det, 0);
   PB(15, st);
   if (!depth_cam) {
     PyrSel prev, next;
