@@ -282,8 +282,11 @@ class KittiSequence:
 
 
 def open_sequence(root):
-    """EuRoC ASL folder or KITTI odometry folder, by what is inside."""
+    """EuRoC ASL folder, KITTI odometry folder or a rosbag (.bag) with the reference's topics, by what it is."""
     import os
+    if os.path.isfile(root) and root.endswith(".bag"):
+        from .rosbag_io import RosbagSequence
+        return RosbagSequence(root)
     if os.path.isdir(os.path.join(root, "image_0")):
         return KittiSequence(root)
     return EurocSequence(root)
