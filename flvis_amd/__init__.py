@@ -386,7 +386,21 @@ class Tracker:
         return dict(frame_id=fid.value, pose7=pose, lm_id=ids[:cnt.value].copy(), lm_3d=p3[:cnt.value].copy(),
                     outlier_id=oid[:oc.value].copy())
 
-    def ba_push_keyframe(self, stream, frame_id, pose7, lm_id, lm_2d, lm_3d, cap=8192):
+    def set_imu_factor(self, enable, sigma_gyro=0.002):
+        """flvis_set_imu_factor: gyro rotation-preintegration edges between consecutive keyframes in the window BA (off by default)."""
+        self.ctx._check(self.lib.flvis_set_imu_factor(self.ctx._h, int(bool(enable)), C.c_double(sigma_gyro)), "set_imu_factor")
+
+    def get_keyframe_imu(self, stream):
+        """flvis_get_keyframe_imu -> (valid, dq (w, x, y, z), dt) of the stream's last keyframe"""
+        np = self.np
+        dq = np.zeros(4)
+        dt = C.c_double(0)
+        r = self.lib.flvis_get_keyframe_imu(self.ctx._h, stream, _P(dq, C.c_double), C.byref(dt))
+        if r < 0:
+            self.ctx._check(r, "get_keyframe_imu")
+        return bool(r), dq, dt.value
+
+    def ba_push_keyframe(self, stream, frame_id, pose7, lm_id, lm_2d, lm_3d, cap=8192, imu_dq=None, imu_dt=0.0):
         np = self.np
         p7 = np.ascontiguousarray(pose7, np.float64)
         ids = np.ascontiguousarray(lm_id, np.int64)
@@ -399,10 +413,17 @@ class Tracker:
         o3 = np.zeros((cap, 3))
         oc = C.c_int(0)
         ooid = np.zeros(cap, np.int64)
-        r = self.lib.flvis_ba_push_keyframe(self.ctx._h, stream, C.c_int64(frame_id), _P(p7, C.c_double), len(ids),
-                                            _P(ids, C.c_int64), _P(l2, C.c_double), _P(l3, C.c_double), cap,
-                                            C.byref(fid), _P(pose, C.c_double), C.byref(cnt), _P(oid_, C.c_int64),
-                                            _P(o3, C.c_double), C.byref(oc), _P(ooid, C.c_int64))
+        if imu_dq is not None:
+            dq = np.ascontiguousarray(imu_dq, np.float64)
+            r = self.lib.flvis_ba_push_keyframe_imu(self.ctx._h, stream, C.c_int64(frame_id), _P(p7, C.c_double), _P(dq, C.c_double),
+                                                    C.c_double(imu_dt), len(ids), _P(ids, C.c_int64), _P(l2, C.c_double),
+                                                    _P(l3, C.c_double), cap, C.byref(fid), _P(pose, C.c_double), C.byref(cnt),
+                                                    _P(oid_, C.c_int64), _P(o3, C.c_double), C.byref(oc), _P(ooid, C.c_int64))
+        else:
+            r = self.lib.flvis_ba_push_keyframe(self.ctx._h, stream, C.c_int64(frame_id), _P(p7, C.c_double), len(ids),
+                                                _P(ids, C.c_int64), _P(l2, C.c_double), _P(l3, C.c_double), cap,
+                                                C.byref(fid), _P(pose, C.c_double), C.byref(cnt), _P(oid_, C.c_int64),
+                                                _P(o3, C.c_double), C.byref(oc), _P(ooid, C.c_int64))
         if r < 0:
             self.ctx._check(r, "ba_push_keyframe")
         if r == 0:

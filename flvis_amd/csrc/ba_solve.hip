@@ -116,6 +116,11 @@ struct BAShared {
   int CI, CL, bufd, nchunk;         // chunk capacities (items, landmarks), doubles per buffer, chunk count
   int npairs, slices, rs;           // role partition of the Schur phase
   int use_mfma, NRp, CLm, nchunk_m;  // MFMA variant of the Schur phase: padded system size, landmarks per dense chunk
+  // IMU rotation edges (optional factor): edge k links ring slots imu_a[k] -> imu_b[k]
+  int n_imu, imu_a[BA_WMAX], imu_b[BA_WMAX];
+  double imu_w[BA_WMAX], imu_dq[BA_WMAX][4], q_c_b[4];
+  double imu_aa[BA_WMAX][9], imu_bb[BA_WMAX][9], imu_ab[BA_WMAX][9], imu_ga[BA_WMAX][3], imu_gb[BA_WMAX][3];
+  double imu_chi[BA_WMAX], imu_chit[BA_WMAX];  // w |r|^2 at the accepted / the trial poses
   int wscan[BA_NW];
   int chunk_l0[BA_MAXCHUNK + 1];    // first landmark / first item of every chunk
   int chunk_i0[BA_MAXCHUNK + 1];
@@ -697,6 +702,105 @@ __device__ __noinline__ void ba_phase_finish_poses() {
   }
 }
 
+// ---- optional IMU rotation factor between consecutive keyframes (north_star: "reprojection + IMU-preintegration factors"; the
+// reference's window holds reprojection edges only).  With R_b = R_cw^T R_cb the body orientation of a keyframe and dq the gyro
+// preintegration between keyframes a and b:   r = Log(dq^T R_b(a)^T R_b(b)) = Log(dq^T R_cb^T R_cw(a) R_cw(b)^T R_cb),
+//   dr/domega_a = Jr^-1(r) R_cb^T (R_cw(a) R_cw(b)^T)^T,   dr/domega_b = -Jr^-1(r) R_cb^T     (g2o update T <- exp(dx) T),
+// information w I3 with w = 1 / (sigma_g^2 dt).  The edges touch the rotation rows / columns (0..2) of the 6x6 pose blocks and
+// add off-diagonal pose-pose blocks to the reduced system.
+FD V3 imu_edge_residual(const double* Ta7, const double* Tb7, Q4 qcb, Q4 dq) {
+  const Q4 qa = load_pose7(Ta7).q, qb = load_pose7(Tb7).q;
+  Q4 qr = q_normalized(q_mul(q_mul(q_mul(q_mul(q_conj(dq), q_conj(qcb)), qa), q_conj(qb)), qcb));
+  if (qr.w < 0) qr = Q4{-qr.w, -qr.x, -qr.y, -qr.z};
+  return so3_log(qr);
+}
+// lanes of wave 0, one per edge: linearise at the accepted poses
+__device__ __noinline__ void ba_phase_imu_linearize() {
+  BAShared& sh = ba_sh();
+  const int k = threadIdx.x;
+  if (k >= sh.n_imu) return;
+  const double* Ta = sh.pose[sh.imu_a[k]];
+  const double* Tb = sh.pose[sh.imu_b[k]];
+  const Q4 qcb{sh.q_c_b[0], sh.q_c_b[1], sh.q_c_b[2], sh.q_c_b[3]};
+  const Q4 dq{sh.imu_dq[k][0], sh.imu_dq[k][1], sh.imu_dq[k][2], sh.imu_dq[k][3]};
+  const V3 rv = imu_edge_residual(Ta, Tb, qcb, dq);
+  const double r[3] = {rv.x, rv.y, rv.z};
+  const double w = sh.imu_w[k];
+  const M3 Bt = transpose(q_to_mat(qcb));
+  const M3 M = q_to_mat(load_pose7(Ta).q) * transpose(q_to_mat(load_pose7(Tb).q));
+  const M3 Ji = so3_jr_inv(rv);
+  const M3 A = Ji * (Bt * transpose(M));
+  const M3 Bm = Ji * Bt;  // Jb = -Bm
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double aa = 0, bb = 0, ab = 0;
+#pragma unroll
+      for (int m = 0; m < 3; m++) {
+        aa += (A.m[m][i] * w) * A.m[m][j];
+        bb += (Bm.m[m][i] * w) * Bm.m[m][j];
+        ab -= (A.m[m][i] * w) * Bm.m[m][j];
+      }
+      sh.imu_aa[k][3 * i + j] = aa;
+      sh.imu_bb[k][3 * i + j] = bb;
+      sh.imu_ab[k][3 * i + j] = ab;
+    }
+    double ga = 0, gb = 0;
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      ga += (A.m[m][i] * w) * r[m];
+      gb -= (Bm.m[m][i] * w) * r[m];
+    }
+    sh.imu_ga[k][i] = ga;
+    sh.imu_gb[k][i] = gb;
+  }
+  sh.imu_chi[k] = w * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+}
+// one thread per free pose: gather the blocks of its (at most two) edges into Hpp / b, in edge order (call after a barrier)
+__device__ __noinline__ void ba_phase_imu_gather() {
+  BAShared& sh = ba_sh();
+  const int hi = threadIdx.x;
+  if (hi >= sh.P) return;
+  const int slot = sh.slot_of[hi];
+  for (int k = 0; k < sh.n_imu; k++) {
+    const bool isa = sh.imu_a[k] == slot, isb = sh.imu_b[k] == slot;
+    if (!isa && !isb) continue;
+    const double* blk = isa ? sh.imu_aa[k] : sh.imu_bb[k];
+    const double* g = isa ? sh.imu_ga[k] : sh.imu_gb[k];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int j = 0; j < 3; j++) sh.Hpp[hi][6 * i + j] += blk[3 * i + j];
+      sh.b[6 * hi + i] -= g[i];
+    }
+  }
+}
+// off-diagonal pose-pose blocks w Ja^T Jb into the lower triangle of the reduced system (after the Schur phase and a barrier)
+__device__ __noinline__ void ba_phase_imu_offdiag() {
+  BAShared& sh = ba_sh();
+  const int t = threadIdx.x;
+  if (t >= 9 * sh.n_imu) return;
+  const int k = t / 9, e = t - 9 * k, i = e / 3, j = e - 3 * i, LD = sh.LD;
+  const int ia = sh.hidx_of[sh.imu_a[k]], ib = sh.hidx_of[sh.imu_b[k]];
+  if (ia < 0 || ib < 0) return;
+  double* Hs = ba_dyn();
+  if (ia < ib)
+    Hs[(6 * ib + j) * LD + 6 * ia + i] += sh.imu_ab[k][e];
+  else
+    Hs[(6 * ia + i) * LD + 6 * ib + j] += sh.imu_ab[k][e];
+}
+// lanes of wave 0: chi2 of the edges at the trial poses
+FD void ba_phase_imu_trial() {
+  BAShared& sh = ba_sh();
+  const int k = threadIdx.x;
+  if (k >= sh.n_imu) return;
+  const Q4 qcb{sh.q_c_b[0], sh.q_c_b[1], sh.q_c_b[2], sh.q_c_b[3]};
+  const Q4 dq{sh.imu_dq[k][0], sh.imu_dq[k][1], sh.imu_dq[k][2], sh.imu_dq[k][3]};
+  const V3 r = imu_edge_residual(sh.poseT[sh.imu_a[k]], sh.poseT[sh.imu_b[k]], qcb, dq);
+  sh.imu_chit[k] = sh.imu_w[k] * ((r.x * r.x + r.y * r.y) + r.z * r.z);
+}
+
 // largest diagonal entry of the (unreduced) hessian -> initial lambda (computeLambdaInit); this thread's share
 __device__ __noinline__ double ba_phase_max_diag() {
   BAShared& sh = ba_sh();
@@ -1063,6 +1167,10 @@ __device__ __noinline__ void ba_phase_solve_poses() {
     }
     pose_to_rt(sh.poseT[lane], sh.RTt[lane]);
   }
+  if (sh.n_imu) {
+    wave_lds_fence();
+    ba_phase_imu_trial();
+  }
 }
 
 // landmark back-substitution and the robust chi2 of the trial state in one pass (thread per landmark): the observations
@@ -1183,7 +1291,13 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
     BAPROF(3);
     double currentChi = block_sum(chi, sh.red[0]);  // (its barriers also publish the per-wave partials / Hll / bl / B)
     ba_phase_finish_poses();
+    if (sh.n_imu && t < 64) ba_phase_imu_linearize();
     __syncthreads();
+    if (sh.n_imu) {
+      ba_phase_imu_gather();
+      for (int k = 0; k < sh.n_imu; k++) currentChi += sh.imu_chi[k];
+      __syncthreads();
+    }
     BAPROF(4);
     if (iteration == 0) {
       lambda = 1e-5 * block_max(ba_phase_max_diag(), sh.red[0]);
@@ -1199,6 +1313,10 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
       else
         ba_phase_schur(lambda);
       __syncthreads();
+      if (sh.n_imu) {
+        ba_phase_imu_offdiag();
+        __syncthreads();
+      }
       BAPROF(7);
       if (t < 64) ba_phase_solve_poses();
       __syncthreads();
@@ -1208,6 +1326,7 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
       ba_phase_update_chi2(lambda, ok2, parts);
       double scale = parts[0], tempChi = parts[1];
       block_sum2(scale, tempChi, sh.red);
+      for (int k = 0; k < sh.n_imu; k++) tempChi += sh.imu_chit[k];
       scale += 1e-3;
       BAPROF(9);
 #ifdef FLVIS_BA_PROF
@@ -1266,6 +1385,22 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
     sh.K[1] = p.cam.fy;
     sh.K[2] = p.cam.cx;
     sh.K[3] = p.cam.cy;
+    // IMU rotation edges of this window: slot j is linked to its chronological predecessor (the previous ring slot) unless j
+    // is the oldest pose
+    int ne = 0;
+    if (p.imu_factor) {
+      for (int j = 0; j < W; j++) {
+        const int i = (j + W - 1) % W;
+        if (j == w.oldest || !w.imu_has[j] || !(w.imu_dt[j] > 0) || !w.pose_present[i] || !w.pose_present[j]) continue;
+        sh.imu_a[ne] = i;
+        sh.imu_b[ne] = j;
+        for (int q = 0; q < 4; q++) sh.imu_dq[ne][q] = w.imu_dq[j][q];
+        sh.imu_w[ne] = 1.0 / (p.imu_sigma_g * p.imu_sigma_g * w.imu_dt[j]);
+        ne++;
+      }
+      sh.q_c_b[0] = p.cam.T_c_i[6], sh.q_c_b[1] = p.cam.T_c_i[3], sh.q_c_b[2] = p.cam.T_c_i[4], sh.q_c_b[3] = p.cam.T_c_i[5];
+    }
+    sh.n_imu = ne;
     sh.prof = nullptr;
 #ifdef FLVIS_BA_PROF
     sh.prof = p.counters ? p.counters + 8 : nullptr;

@@ -187,6 +187,9 @@ __device__ __noinline__ void ba_update_dev(const Pipe& p, int s, const KeyFrameD
       dst.lm_count = n;
       dst.valid = 1;
       for (int j = 0; j < 7; j++) dst.T_c_w[j] = src.T_c_w[j];
+      for (int j = 0; j < 4; j++) dst.imu_dq[j] = src.imu_dq[j];
+      dst.imu_dt = src.imu_dt;
+      dst.imu_valid = src.imu_valid;
       w.kfs_size++;
       if (p.counters) atomicAdd((unsigned long long*)&p.counters[1], 1ull);
     }
@@ -212,6 +215,10 @@ __device__ __noinline__ void ba_update_dev(const Pipe& p, int s, const KeyFrameD
       w.pose_present[tid] = 1;
       w.pose_fixed[tid] = (tid == w.oldest) ? 1 : 0;
       pose_to_g2o(w.bag_pose[tid], w.pose_est[tid]);
+      const KeyFrameDev& kf = ring[(w.kfs_head + tid) % W];  // slot tid holds the tid-th keyframe of the queue
+      for (int j = 0; j < 4; j++) w.imu_dq[tid][j] = kf.imu_dq[j];
+      w.imu_dt[tid] = kf.imu_dt;
+      w.imu_has[tid] = (tid > 0 && kf.imu_valid) ? 1 : 0;
     }
     for (int i = tid; i < w.n_lm; i += BU_T)
       for (int j = 0; j < 3; j++) w.lm_est[i][j] = w.lm_p3d[i][j];  // vertex estimate = running mean (quirk A23)
@@ -273,6 +280,9 @@ __device__ __noinline__ void ba_update_dev(const Pipe& p, int s, const KeyFrameD
       w.pose_fixed[w.newest] = 0;
       pose_to_g2o(kn.T_c_w, w.pose_est[w.newest]);
       w.pose_fixed[w.oldest] = 1;
+      for (int j = 0; j < 4; j++) w.imu_dq[w.newest][j] = kn.imu_dq[j];
+      w.imu_dt[w.newest] = kn.imu_dt;
+      w.imu_has[w.newest] = kn.imu_valid ? 1 : 0;
     }
     __syncthreads();
     bag_add_keyframe(w, sid, s_cnt, kn, true, w.newest);

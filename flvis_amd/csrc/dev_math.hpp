@@ -195,6 +195,22 @@ FD V3 so3_log(Q4 q) {
   return V3{f * q.x, f * q.y, f * q.z};
 }
 
+// rotation vector -> unit quaternion and the inverse right Jacobian of SO(3) (Forster et al., "On-Manifold Preintegration",
+// eq. 8): the gyro preintegration between keyframes and the IMU rotation factor of the window BA
+FD Q4 q_exp(V3 phi) {
+  const double th = norm(phi);
+  if (th < 1e-8) return q_normalized(Q4{1.0, 0.5 * phi.x, 0.5 * phi.y, 0.5 * phi.z});
+  const double s = detm::det_sin(0.5 * th) / th;
+  return Q4{detm::det_cos(0.5 * th), s * phi.x, s * phi.y, s * phi.z};
+}
+FD M3 so3_jr_inv(V3 phi) {
+  const double th = norm(phi);
+  const M3 S = skew(phi);
+  double c = 1.0 / 12.0;
+  if (th > 1e-5) c = 1.0 / (th * th) - (1.0 + detm::det_cos(th)) / (2.0 * th * detm::det_sin(th));
+  return m3_add(m3_add(m3_identity(), S, 0.5), S * S, c);
+}
+
 // g2o SE3Quat semantics
 FD void g2o_normalize_rotation(Q4& q) {
   if (q.w < 0) {

@@ -341,6 +341,8 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   p.corr_in = nullptr;  // allocated by the first flvis_correction_feed
   DA(counters, long long, 64);
   p.ba_scratch_stride = ba_scratch_doubles();
+  p.imu_factor = 0;
+  p.imu_sigma_g = 0;
   p.ba_mfma = 0;
   if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;  // A/B knob, see DESIGN.md section 4
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
@@ -390,6 +392,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
     st.skip_n = cfg->skip_first_n_imgs;
     st.lm_id_counter = 100;
     st.vi_first = 1;
+    st.kf_dq[0] = 1.0;
     for (int k = 0; k < 2; k++) st.T_c_w[k][6] = 1.0;
     st.T_kf[6] = 1.0;
     st.guess[6] = 1.0;
@@ -1233,9 +1236,63 @@ int flvis_debug_counters(flvis_ctx* ctx, int64_t* h64) {
   return FLVIS_OK;
 }
 
+// IMU rotation factor of the window BA (an addition: the reference's window holds reprojection edges only).  Off by default.
+int flvis_set_imu_factor(flvis_ctx* ctx, int enable, double sigma_gyro) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  if (enable && !(sigma_gyro > 0)) return ctx->fail(FLVIS_ERR_INVALID_ARG, "set_imu_factor: sigma_gyro must be positive");
+  sync_all(ctx);  // the flag travels in the kernel arguments of the next local-map launch
+  for (Lane* L : ctx->pipe->lanes) {
+    L->pipe.imu_factor = enable ? 1 : 0;
+    L->pipe.imu_sigma_g = sigma_gyro;
+  }
+  return FLVIS_OK;
+}
+
+int flvis_get_keyframe_imu(flvis_ctx* ctx, int stream, double* dq_wxyz, double* dt) {
+  if (!ctx || !ctx->pipe || !dq_wxyz || !dt) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  sync_all(ctx);
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  FrameOut fo;
+  hipMemcpy(&fo, L.pipe.out + ls, sizeof(FrameOut), hipMemcpyDeviceToHost);
+  unsigned tl = 0;
+  hipMemcpy(&tl, L.pipe.kfq_tail + ls, sizeof(unsigned), hipMemcpyDeviceToHost);
+  if (!fo.new_keyframe || tl == 0) return 0;
+  struct {
+    double dq[4], dt;
+    int valid, pad;
+  } h;
+  static_assert(offsetof(KeyFrameDev, imu_valid) == offsetof(KeyFrameDev, imu_dq) + 40, "KeyFrameDev imu block layout");
+  const char* src = reinterpret_cast<const char*>(L.pipe.kfq + (size_t)ls * KFQ + ((tl - 1) % KFQ)) + offsetof(KeyFrameDev, imu_dq);
+  hipMemcpy(&h, src, sizeof(h), hipMemcpyDeviceToHost);
+  memcpy(dq_wxyz, h.dq, 32);
+  *dt = h.dt;
+  return h.valid ? 1 : 0;
+}
+
+static int ba_push_impl(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, const double* imu_dq, double imu_dt,
+                        int lm_count, const int64_t* h_id, const double* h_2d, const double* h_3d, int cap, int64_t* out_frame_id,
+                        double* out_T7, int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid);
+
 int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, int lm_count, const int64_t* h_id,
                            const double* h_2d, const double* h_3d, int cap, int64_t* out_frame_id, double* out_T7,
                            int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid) {
+  return ba_push_impl(ctx, stream, frame_id, T7, nullptr, 0.0, lm_count, h_id, h_2d, h_3d, cap, out_frame_id, out_T7, out_lm_count,
+                      out_lm_id, out_lm_3d, out_oc, out_oid);
+}
+int flvis_ba_push_keyframe_imu(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, const double* imu_dq_wxyz,
+                               double imu_dt, int lm_count, const int64_t* h_id, const double* h_2d, const double* h_3d, int cap,
+                               int64_t* out_frame_id, double* out_T7, int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d,
+                               int* out_oc, int64_t* out_oid) {
+  return ba_push_impl(ctx, stream, frame_id, T7, imu_dq_wxyz, imu_dt, lm_count, h_id, h_2d, h_3d, cap, out_frame_id, out_T7,
+                      out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid);
+}
+
+static int ba_push_impl(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, const double* imu_dq, double imu_dt,
+                        int lm_count, const int64_t* h_id, const double* h_2d, const double* h_3d, int cap, int64_t* out_frame_id,
+                        double* out_T7, int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid) {
   if (!ctx || !ctx->pipe || !T7 || lm_count < 0 || lm_count > KF_MAXLM) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
@@ -1248,6 +1305,12 @@ int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const d
   kf.lm_count = lm_count;
   kf.valid = 1;
   memcpy(kf.T_c_w, T7, 56);
+  kf.imu_dq[0] = 1.0;
+  if (imu_dq && imu_dt > 0) {
+    memcpy(kf.imu_dq, imu_dq, 32);
+    kf.imu_dt = imu_dt;
+    kf.imu_valid = 1;
+  }
   for (int i = 0; i < lm_count; i++) {
     kf.lm_id[i] = h_id[i];
     kf.lm_2d[i][0] = h_2d[2 * i];

@@ -87,6 +87,7 @@ struct StreamState {
   // pose_records (f2f_tracking.h:59, ID_POSE): ring in Pipe::rec_id / rec_T, oldest at rec_head
   int rec_head, rec_count;
   double dbg_T_pnp[7], dbg_T_lm[7], dbg_T_pre[7];  // pose right after PnP-RANSAC / after the pose LM of the last Tracking frame (tests)
+  double kf_dq[4], kf_dt;  // gyro rotation preintegration since the last keyframe (w, x, y, z), see KeyFrameDev::imu_dq
   int feeds;  // image_feed calls seen by this stream (= row of the device-side trajectory the frame is recorded in)
 };
 
@@ -104,6 +105,10 @@ struct KeyFrameDev {
   int lm_count, valid;
   double T_c_w[7];
   double stamp;  // header.stamp of the message: the frame's image time
+  // (addition, not in KeyFrame.msg) gyro rotation preintegration since the previous keyframe of the chain: dq (w, x, y, z) =
+  // R_body(previous)^T R_body(this) as integrated from the bias-corrected gyro samples, over imu_dt seconds
+  double imu_dq[4], imu_dt;
+  int imu_valid, imu_pad;
   long long lm_id[KF_MAXLM];
   double lm_2d[KF_MAXLM][2];
   double lm_3d[KF_MAXLM][3];
@@ -140,6 +145,9 @@ struct WindowDev {
   int e_pose[BA_EMAX];
   int e_lidx[BA_EMAX];  // index of e_lm in the bag arrays (kept consistent across bag compaction)
   double e_uv[BA_EMAX][2];
+  // IMU rotation factor (optional): the preintegration that links ring slot j to its predecessor (j - 1 + W) % W
+  double imu_dq[BA_WMAX][4], imu_dt[BA_WMAX];
+  int imu_has[BA_WMAX];
   // keyframe queue (the `kfs` deque of vo_localmap.cpp:55): ring of the last `window` payloads, storage in Pipe::kfs_ring
   int kfs_head, kfs_size;
   int solve;        // set by the bookkeeping kernel when this keyframe triggers an optimisation

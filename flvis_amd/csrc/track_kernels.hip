@@ -1318,6 +1318,7 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
   const int lane = threadIdx.x;  // (first wave does the scalar bookkeeping)
   __shared__ int s_newkf;
   __shared__ int s_cnt[FE_T / 64];
+  const bool s_chain = st.phase == PH_TRACK;  // a keyframe of the Tracking branch continues the keyframe chain
   if (lane == 0) s_newkf = 0;
   __syncthreads();
   if (st.phase == PH_INIT) {
@@ -1423,6 +1424,14 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
       kf.stamp = st.frame_time[cur];
       kf.lm_count = cnt < KF_MAXLM ? cnt : KF_MAXLM;
       for (int j = 0; j < 7; j++) kf.T_c_w[j] = st.T_c_w[cur][j];
+      // the gyro preintegration since the previous keyframe travels with the payload and restarts; a keyframe made by
+      // init_frame() starts a new chain (nothing links it to the keyframes before the (re-)initialisation)
+      for (int j = 0; j < 4; j++) kf.imu_dq[j] = st.kf_dq[j];
+      kf.imu_dt = st.kf_dt;
+      kf.imu_valid = (s_chain && st.kf_dt > 0) ? 1 : 0;
+      kf.imu_pad = 0;
+      st.kf_dq[0] = 1.0, st.kf_dq[1] = st.kf_dq[2] = st.kf_dq[3] = 0.0;
+      st.kf_dt = 0;
       kf.valid = 1;
     }
     __atomic_thread_fence(__ATOMIC_RELEASE);

@@ -49,6 +49,8 @@ struct Pipe {
   CorrectionDev* corr;      // [S]
   double* ba_scratch;       // [S][ba_scratch_stride]
   size_t ba_scratch_stride;
+  int imu_factor;          // window BA: add the gyro rotation-preintegration edge between consecutive keyframes (off by default)
+  double imu_sigma_g;      // its gyro noise density [rad/s/sqrt(Hz)]: information = 1 / (sigma_g^2 dt)
   int ba_mfma;              // Schur complement of the window solver on the matrix cores (v_mfma_f64_16x16x4_f64) or as register tiles
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
   // local-map feedback (F2FTracking::correction_feed, dead in the reference's v2)

@@ -120,6 +120,11 @@ __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const 
     st3(s_new.acc, acc_raw);
     st3(s_new.gyro, gyro_raw);
     s_new.t = t;
+    {  // (addition) gyro rotation preintegration since the last keyframe, for the IMU factor of the window BA
+      Q4 dq = q_normalized(q_mul(Q4{st.kf_dq[0], st.kf_dq[1], st.kf_dq[2], st.kf_dq[3]}, q_exp(gyro * dt)));
+      st.kf_dq[0] = dq.w, st.kf_dq[1] = dq.x, st.kf_dq[2] = dq.y, st.kf_dq[3] = dq.z;
+      st.kf_dt += dt;
+    }
     ring.push_back(s_new);
   }
 }

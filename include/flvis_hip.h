@@ -296,6 +296,25 @@ int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const d
                            int64_t* out_frame_id, double* out_T_c_w7, int* out_lm_count, int64_t* out_lm_id,
                            double* out_lm_3d, int* out_outlier_count, int64_t* out_outlier_id);
 
+/* ---- IMU rotation factor of the window BA (an ADDITION -- the reference's local map, src/backend/vo_localmap.cpp,
+ * optimises reprojection edges only, so nothing here has a reference counterpart and everything is off by default).
+ *
+ * The tracker integrates the bias-corrected gyro samples between keyframes (the samples VIMOTION::viIMUPropagation consumes,
+ * src/processing/vi_motion.cpp:78-100) into dq = R_body(previous keyframe)^T R_body(this keyframe); the preintegration travels with
+ * the KeyFrame payload.  With the factor enabled, the window BA adds for every pair of consecutive keyframes the edge
+ *     r = Log(dq^T R_b(a)^T R_b(b)),   R_b = R_c_w^T R_c_i,   information I3 / (sigma_gyro^2 dt)
+ * next to the reprojection edges (pose-pose blocks in the reduced camera system).
+ *   flvis_set_imu_factor       enable != 0 switches the edges on for every stream; sigma_gyro = gyro noise density [rad/s/sqrt(Hz)]
+ *   flvis_get_keyframe_imu     the preintegration of the stream's last keyframe: dq (w, x, y, z), dt [s]; returns 1 when it links
+ *                              the keyframe to its predecessor, 0 otherwise (first keyframe after an initialisation, no IMU)
+ *   flvis_ba_push_keyframe_imu flvis_ba_push_keyframe with the preintegration of the pushed keyframe (imu_dt <= 0: none) */
+int flvis_set_imu_factor(flvis_ctx* ctx, int enable, double sigma_gyro);
+int flvis_get_keyframe_imu(flvis_ctx* ctx, int stream, double* dq_wxyz, double* dt);
+int flvis_ba_push_keyframe_imu(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T_c_w7, const double* imu_dq_wxyz,
+                               double imu_dt, int lm_count, const int64_t* h_lm_id, const double* h_lm_2d, const double* h_lm_3d,
+                               int cap, int64_t* out_frame_id, double* out_T_c_w7, int* out_lm_count, int64_t* out_lm_id,
+                               double* out_lm_3d, int* out_outlier_count, int64_t* out_outlier_id);
+
 #ifdef __cplusplus
 }
 #endif

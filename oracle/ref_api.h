@@ -81,6 +81,11 @@ struct KeyFrameStruct {
   std::vector<Vec2> lm_2d;
   std::vector<Vec3> lm_3d;
   SE3 T_c_w = se3_identity();
+  // optional (no field of msg/KeyFrame.msg): gyro preintegration since the previous keyframe -- the relative rotation of the
+  // IMU body frame R_b(prev)^T R_b(this) as a unit quaternion, the integrated time, and whether it is valid
+  Quat imu_dq = quat_identity();
+  double imu_dt = 0;
+  bool imu_valid = false;
 };
 struct CorrectionInfStruct {
   int64_t frame_id = 0;
@@ -132,6 +137,15 @@ struct BAGraph {
     int pose;
     Vec2 z;
   };
+  // optional IMU rotation factor between two pose slots (north_star's "IMU-preintegration factors"; the reference has no such
+  // edge, vo_localmap.cpp:191-206,263-280): residual Log(dq^T R_b(a)^T R_b(b)), information w * I
+  struct ImuEdge {
+    int a, b;
+    Quat dq;
+    double w;
+  };
+  std::vector<ImuEdge> imu_edges;
+  Quat q_c_b = quat_identity();  // rotation IMU body -> camera (T_c_i)
   double K[4];
   std::vector<PoseV> poses;
   std::map<int64_t, Vec3> lms;
@@ -141,6 +155,7 @@ struct BAGraph {
   void remove_lm(int64_t id);
 };
 
+void imu_edge_linearize(const SE3& Ta, const SE3& Tb, Quat q_c_b, Quat dq, double r[3], double Ja[3][3], double Jb[3][3]);
 class LocalMap {
  public:
   enum State { UN_INITIALIZED, SLIDING_WINDOW, OPTIMIZING, FAIL };
@@ -153,6 +168,14 @@ class LocalMap {
   int window_size;
   State state;
   int64_t edge_id;
+  // IMU factor (off by default): per pose slot the preintegrated rotation from the chronologically previous keyframe
+  bool imu_factor = false;
+  double imu_sigma_g = 0.002;  // gyro noise density [rad/s/sqrt(Hz)]: information 1 / (sigma^2 * dt)
+  std::vector<Quat> slot_dq;
+  std::vector<double> slot_dt;
+  std::vector<char> slot_has;
+  void set_imu_factor(bool on, double sigma_g, Quat q_c_b);
+  void rebuild_imu_edges();
 };
 
 }  // namespace ref

@@ -166,6 +166,30 @@ static bool chol_solve(std::vector<double>& A, int n, const double* b, double* x
   return true;
 }
 
+// IMU rotation factor between pose slots a and b (T_c_w estimates as g2o SE3Quat, update T <- exp(dx) T with dx = (omega, upsilon)):
+//   R_b = R_w_body = R_cw^T R_cb,   r = Log(dq^T R_b(a)^T R_b(b)) = Log(dq^T R_cb^T R_cw(a) R_cw(b)^T R_cb)
+//   d r / d omega_a = Jr^-1(r) R_cb^T (R_cw(a) R_cw(b)^T)^T,   d r / d omega_b = -Jr^-1(r) R_cb^T        (translations: zero)
+void imu_edge_linearize(const SE3& Ta, const SE3& Tb, Quat q_c_b, Quat dq, double r[3], double Ja[3][3], double Jb[3][3]) {
+  Quat qr = quat_mul(quat_mul(quat_mul(quat_mul(quat_conj(dq), quat_conj(q_c_b)), Ta.q), quat_conj(Tb.q)), q_c_b);
+  qr = quat_normalized(qr);
+  if (qr.w < 0) qr = {-qr.w, -qr.x, -qr.y, -qr.z};
+  const Vec3 rv = so3_log(qr);
+  r[0] = rv.x;
+  r[1] = rv.y;
+  r[2] = rv.z;
+  if (!Ja) return;
+  const Mat3 Bt = transpose(quat_to_mat(q_c_b));
+  const Mat3 M = quat_to_mat(Ta.q) * transpose(quat_to_mat(Tb.q));
+  const Mat3 Ji = so3_jr_inv(rv);
+  const Mat3 A = Ji * (Bt * transpose(M));
+  const Mat3 Bm = Ji * Bt;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      Ja[i][j] = A.m[i][j];
+      Jb[i][j] = -Bm.m[i][j];
+    }
+}
+
 // SparseOptimizer::initializeOptimization + optimize(iterations) on the current graph.
 void BAGraph::optimize(int iterations) {
   // active edges in id order; active vertices = those touched by an active edge (all edges are active: landmarks are never fixed)
@@ -195,12 +219,23 @@ void BAGraph::optimize(int iterations) {
   std::vector<double> Hpp((size_t)P * 36), Hll((size_t)L * 9), Hpl((size_t)E * 18), b(sizePoses + sizeLms),
       x(sizePoses + sizeLms);
 
+  // IMU rotation edges whose poses take part (a fixed pose contributes its estimate, not a block)
+  auto hidx = [&](int slot) {
+    auto it = pose_index.find(slot);
+    return (it == pose_index.end() || poses[slot].fixed) ? -1 : it->second;
+  };
+  std::vector<double> Hoff((size_t)imu_edges.size() * 9, 0.0);  // w Ja^T Jb of every IMU edge (block (a, b) of Hpp)
   auto robustChi2 = [&]() {
     double chi = 0;
     for (int k = 0; k < E; k++) {
       double er[2];
       edge_error(poses[act[k]->pose].est, lms[act[k]->lm], act[k]->z, K, er);
       chi += huber_rho(er[0] * er[0] + er[1] * er[1]);
+    }
+    for (const ImuEdge& e : imu_edges) {
+      double r[3];
+      imu_edge_linearize(poses[e.a].est, poses[e.b].est, q_c_b, e.dq, r, nullptr, nullptr);
+      chi += e.w * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
     }
     return chi;
   };
@@ -238,6 +273,33 @@ void BAGraph::optimize(int iterations) {
         }
       }
     }
+    for (size_t k = 0; k < imu_edges.size(); k++) {  // pose-pose edges: rotation rows / columns 0..2 of the 6x6 blocks
+      const ImuEdge& e = imu_edges[k];
+      double r[3], Ja[3][3], Jb[3][3];
+      imu_edge_linearize(poses[e.a].est, poses[e.b].est, q_c_b, e.dq, r, Ja, Jb);
+      const int ia = hidx(e.a), ib = hidx(e.b);
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+          double aa = 0, bb = 0, ab = 0;
+          for (int m = 0; m < 3; m++) {
+            aa += (Ja[m][i] * e.w) * Ja[m][j];
+            bb += (Jb[m][i] * e.w) * Jb[m][j];
+            ab += (Ja[m][i] * e.w) * Jb[m][j];
+          }
+          if (ia >= 0) Hpp[(size_t)ia * 36 + 6 * i + j] += aa;
+          if (ib >= 0) Hpp[(size_t)ib * 36 + 6 * i + j] += bb;
+          Hoff[k * 9 + 3 * i + j] = ab;
+        }
+      for (int i = 0; i < 3; i++) {
+        double ga = 0, gb = 0;
+        for (int m = 0; m < 3; m++) {
+          ga += (Ja[m][i] * e.w) * r[m];
+          gb += (Jb[m][i] * e.w) * r[m];
+        }
+        if (ia >= 0) b[6 * ia + i] -= ga;
+        if (ib >= 0) b[6 * ib + i] -= gb;
+      }
+    }
     if (iteration == 0) {
       double maxDiag = 0;
       for (int i = 0; i < P; i++)
@@ -262,6 +324,15 @@ void BAGraph::optimize(int iterations) {
         for (int r = 0; r < 6; r++)
           for (int c = 0; c < 6; c++)
             Hs[(size_t)(6 * i + r) * sizePoses + 6 * i + c] = Hpp[(size_t)i * 36 + 6 * r + c] + (r == c ? lambda : 0.0);
+      for (size_t k = 0; k < imu_edges.size(); k++) {
+        const int ia = hidx(imu_edges[k].a), ib = hidx(imu_edges[k].b);
+        if (ia < 0 || ib < 0) continue;
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) {
+            Hs[(size_t)(6 * ia + i) * sizePoses + 6 * ib + j] += Hoff[k * 9 + 3 * i + j];
+            Hs[(size_t)(6 * ib + j) * sizePoses + 6 * ia + i] += Hoff[k * 9 + 3 * i + j];
+          }
+      }
       std::vector<Mat3> Dinv(L);
       std::vector<std::vector<int>> lm_edges(L);
       for (int k = 0; k < E; k++)
@@ -368,6 +439,27 @@ LocalMap::LocalMap(int window, double fx, double fy, double cx, double cy) : bag
   graph.poses.assign(window, BAGraph::PoseV{se3_identity(), false, false});
   state = UN_INITIALIZED;
   edge_id = 0;
+  slot_dq.assign(window, quat_identity());
+  slot_dt.assign(window, 0.0);
+  slot_has.assign(window, 0);
+}
+
+void LocalMap::set_imu_factor(bool on, double sigma_g, Quat q_c_b) {
+  imu_factor = on;
+  imu_sigma_g = sigma_g;
+  graph.q_c_b = q_c_b;
+}
+// the IMU edges of the current window: pose slot j is linked to its chronological predecessor (the previous ring slot) unless j
+// is the oldest pose of the window
+void LocalMap::rebuild_imu_edges() {
+  graph.imu_edges.clear();
+  if (!imu_factor) return;
+  const int W = window_size;
+  for (int j = 0; j < W; j++) {
+    const int i = (j + W - 1) % W;
+    if (j == bag.oldest || !slot_has[j] || !(slot_dt[j] > 0) || !graph.poses[i].present || !graph.poses[j].present) continue;
+    graph.imu_edges.push_back({i, j, slot_dq[j], 1.0 / (imu_sigma_g * imu_sigma_g * slot_dt[j])});
+  }
 }
 
 void LocalMap::reset() {  // KFMSG_CMD_RESET_LM, vo_localmap.cpp:89-98
@@ -389,6 +481,11 @@ bool LocalMap::frame_callback(const KeyFrameStruct& kf, CorrectionInfStruct& out
       for (int f = 0; f < window_size; f++) {
         bag.addPose(kfs[f].frame_id, kfs[f].T_c_w);
         for (int i = 0; i < kfs[f].lm_count; i++) bag.addLMObservation(kfs[f].lm_id[i], kfs[f].lm_3d[i]);
+      }
+      for (int f = 0; f < window_size; f++) {  // slot f holds keyframe f during initialisation
+        slot_dq[f] = kfs[f].imu_dq;
+        slot_dt[f] = kfs[f].imu_dt;
+        slot_has[f] = (f > 0 && kfs[f].imu_valid) ? 1 : 0;
       }
       int oldest = bag.oldest;
       for (int i = 0; i < window_size; i++) {
@@ -418,6 +515,9 @@ bool LocalMap::frame_callback(const KeyFrameStruct& kf, CorrectionInfStruct& out
       nv.present = true;
       nv.fixed = false;
       nv.est = to_g2o(kfs.back().T_c_w);
+      slot_dq[bag.newest] = kfs.back().imu_dq;
+      slot_dt[bag.newest] = kfs.back().imu_dt;
+      slot_has[bag.newest] = kfs.back().imu_valid ? 1 : 0;
       graph.poses[bag.oldest].fixed = true;
       for (int i = 0; i < kfs.back().lm_count; i++)
         if (bag.addLMObservationSlidingWindow(kfs.back().lm_id[i], kfs.back().lm_3d[i]))
@@ -439,6 +539,7 @@ bool LocalMap::frame_callback(const KeyFrameStruct& kf, CorrectionInfStruct& out
   bool produced = false;
   if (state == OPTIMIZING) {
     out = CorrectionInfStruct();
+    rebuild_imu_edges();
     graph.optimize(12);
     std::vector<int64_t> ids;
     for (auto& kv : graph.edges) ids.push_back(kv.first);
@@ -478,6 +579,38 @@ bool LocalMap::frame_callback(const KeyFrameStruct& kf, CorrectionInfStruct& out
 extern "C" {
 void* ref_localmap_create(int window, const double* K4) { return new ref::LocalMap(window, K4[0], K4[1], K4[2], K4[3]); }
 void ref_localmap_destroy(void* h) { delete (ref::LocalMap*)h; }
+// optional IMU rotation factor (off by default): q_c_b = rotation IMU body -> camera as (w, x, y, z)
+void ref_localmap_set_imu_factor(void* h, int on, double sigma_g, const double* q_c_b_wxyz) {
+  ((ref::LocalMap*)h)->set_imu_factor(on != 0, sigma_g, ref::Quat{q_c_b_wxyz[0], q_c_b_wxyz[1], q_c_b_wxyz[2], q_c_b_wxyz[3]});
+}
+static ref::Quat g_next_imu_dq = ref::quat_identity();
+static double g_next_imu_dt = 0;
+static bool g_next_imu_valid = false;
+// the gyro preintegration that comes with the NEXT ref_localmap_push: dq (w, x, y, z) = R_b(previous keyframe)^T R_b(this), dt
+void ref_localmap_next_imu(const double* dq_wxyz, double dt) {
+  g_next_imu_dq = ref::Quat{dq_wxyz[0], dq_wxyz[1], dq_wxyz[2], dq_wxyz[3]};
+  g_next_imu_dt = dt;
+  g_next_imu_valid = true;
+}
+// residual and Jacobians of one IMU rotation edge (tests: central differences)
+void ref_imu_edge_linearize(const double* Ta7, const double* Tb7, const double* q_c_b_wxyz, const double* dq_wxyz, double* r3, double* Ja9,
+                            double* Jb9) {
+  auto se3 = [](const double* p) { return ref::SE3{{p[6], p[3], p[4], p[5]}, {p[0], p[1], p[2]}}; };
+  double Ja[3][3], Jb[3][3];
+  ref::imu_edge_linearize(se3(Ta7), se3(Tb7), ref::Quat{q_c_b_wxyz[0], q_c_b_wxyz[1], q_c_b_wxyz[2], q_c_b_wxyz[3]},
+                          ref::Quat{dq_wxyz[0], dq_wxyz[1], dq_wxyz[2], dq_wxyz[3]}, r3, Ja, Jb);
+  for (int i = 0; i < 9; i++) {
+    Ja9[i] = Ja[i / 3][i % 3];
+    Jb9[i] = Jb[i / 3][i % 3];
+  }
+}
+// T <- exp(dx) T with g2o's SE3Quat update (tests)
+void ref_g2o_oplus(const double* T7, const double* dx6, double* out7) {
+  ref::SE3 T{{T7[6], T7[3], T7[4], T7[5]}, {T7[0], T7[1], T7[2]}};
+  T = ref::g2o_mul(ref::g2o_exp(dx6), T);
+  const double o[7] = {T.t.x, T.t.y, T.t.z, T.q.x, T.q.y, T.q.z, T.q.w};
+  memcpy(out7, o, sizeof(o));
+}
 // pose7 = tx ty tz qx qy qz qw.  Outputs: returns 1 if a CorrectionInf was produced.
 int ref_localmap_push(void* h, int64_t frame_id, const double* pose7, int n, const int64_t* lm_id, const double* lm_2d,
                       const double* lm_3d, int64_t* out_frame_id, double* out_pose7, int* out_lm_count,
@@ -485,6 +618,12 @@ int ref_localmap_push(void* h, int64_t frame_id, const double* pose7, int n, con
                       int64_t* out_outlier_id, int outlier_cap) {
   ref::LocalMap* lm = (ref::LocalMap*)h;
   ref::KeyFrameStruct kf;
+  if (g_next_imu_valid) {  // set by ref_localmap_next_imu for this keyframe
+    kf.imu_dq = g_next_imu_dq;
+    kf.imu_dt = g_next_imu_dt;
+    kf.imu_valid = true;
+    g_next_imu_valid = false;
+  }
   kf.frame_id = frame_id;
   kf.lm_count = n;
   kf.T_c_w = ref::SE3{{pose7[6], pose7[3], pose7[4], pose7[5]}, {pose7[0], pose7[1], pose7[2]}};

@@ -195,6 +195,22 @@ inline Vec3 so3_log(Quat q) {
   return {two_atan_nbyw_by_n * q.x, two_atan_nbyw_by_n * q.y, two_atan_nbyw_by_n * q.z};
 }
 
+// rotation vector -> unit quaternion (the increment of a gyro preintegration step) and the inverse right Jacobian of SO(3)
+// (Forster et al., "On-Manifold Preintegration", eq. 8): used by the optional IMU rotation factor of the window BA
+inline Quat quat_exp(Vec3 phi) {
+  const double th = norm(phi);
+  if (th < 1e-8) return quat_normalized({1.0, 0.5 * phi.x, 0.5 * phi.y, 0.5 * phi.z});
+  const double s = detm::det_sin(0.5 * th) / th;
+  return {detm::det_cos(0.5 * th), s * phi.x, s * phi.y, s * phi.z};
+}
+inline Mat3 so3_jr_inv(Vec3 phi) {
+  const double th = norm(phi);
+  const Mat3 S = skew(phi);
+  double c = 1.0 / 12.0;
+  if (th > 1e-5) c = 1.0 / (th * th) - (1.0 + detm::det_cos(th)) / (2.0 * th * detm::det_sin(th));
+  return mat3_add(mat3_add(mat3_identity(), S, 0.5), S * S, c);
+}
+
 // g2o::SE3Quat (rotation first in the tangent): se3quat.h
 inline void g2o_normalize_rotation(Quat& q) {
   if (q.w < 0) {

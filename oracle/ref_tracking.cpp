@@ -471,6 +471,8 @@ void VIMOTION::viIMUPropagation(const IMUSTATE& imu, Quat& q_w_i, Vec3& pos, Vec
   s_new.pos = s_prev.pos + s_prev.vel * dt;
   s_new.vel = s_prev.vel + ((R_prev * acc) - gravity) * dt;
   s_new.imu_data = imu;
+  kf_dq = quat_normalized(quat_mul(kf_dq, quat_exp(gyro * dt)));
+  kf_dt += dt;
   states.push_back(s_new);
   if (states.size() >= STATES_QUEUE_SIZE) states.pop_front();
   q_w_i = s_new.q_w_i;
@@ -923,6 +925,7 @@ void F2FTracking::image_feed(double time, const uint8_t* img0_in, const uint8_t*
     if (d_camera.cam_type != DEPTH_D435)
       equalize_hist(curr_frame->img1.data(), curr_frame->img1.data(), cfg.image_width, cfg.image_height);
   }
+  const int state_in = vo_tracking_state;
   switch (vo_tracking_state) {
     case UnInit: {
       Mat3 R_w_c = {{{0, 0, 1}, {-1, 0, 0}, {0, -1, 0}}};
@@ -1109,6 +1112,16 @@ void F2FTracking::image_feed(double time, const uint8_t* img0_in, const uint8_t*
       break;
     }
   }
+  if (new_keyframe) {  // (addition) hand the gyro preintegration since the previous keyframe to the KeyFrame payload, restart it
+    const bool chained = state_in == Tracking && vimotion != nullptr;  // a keyframe of init_frame() starts a new chain
+    kf_imu_dq = vimotion ? vimotion->kf_dq : quat_identity();
+    kf_imu_dt = vimotion ? vimotion->kf_dt : 0.0;
+    kf_imu_valid = chained && kf_imu_dt > 0;
+    if (vimotion) {
+      vimotion->kf_dq = quat_identity();
+      vimotion->kf_dt = 0;
+    }
+  }
 }
 
 void F2FTracking::correction_feed(const CorrectionInfStruct& corr) {  // f2f_tracking.cpp:40-44
@@ -1127,6 +1140,9 @@ void F2FTracking::getKeyFrameInf(KeyFrameStruct& kf) const {
       kf.lm_id.push_back(lm.lm_id);
     }
   kf.lm_count = (int)kf.lm_id.size();
+  kf.imu_dq = kf_imu_dq;
+  kf.imu_dt = kf_imu_dt;
+  kf.imu_valid = kf_imu_valid;
 }
 
 }  // namespace ref
@@ -1209,6 +1225,13 @@ int ref_tracker_keyframe(void* h, int cap, int64_t* frame_id, double* pose7, int
     p3w[3 * i + 2] = kf.lm_3d[i].z;
   }
   return kf.lm_count;
+}
+// (addition) the gyro preintegration attached to the last keyframe: dq (w, x, y, z) = body rotation since the previous keyframe
+int ref_tracker_keyframe_imu(void* h, double* dq_wxyz, double* dt) {
+  ref::F2FTracking* f = (ref::F2FTracking*)h;
+  dq_wxyz[0] = f->kf_imu_dq.w, dq_wxyz[1] = f->kf_imu_dq.x, dq_wxyz[2] = f->kf_imu_dq.y, dq_wxyz[3] = f->kf_imu_dq.z;
+  *dt = f->kf_imu_dt;
+  return f->kf_imu_valid ? 1 : 0;
 }
 // F2FTracking::correction_feed (f2f_tracking.cpp:40-44) with the CorrectionInf fields flattened
 void ref_tracker_correction_feed(void* h, int64_t frame_id, const double* pose7, int lm_count, const int64_t* lm_id,

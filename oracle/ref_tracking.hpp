@@ -101,6 +101,9 @@ class VIMOTION {  // src/processing/vi_motion.cpp
   std::deque<MOTION_STATE> states;
   MOTION_STATE init_state;
   bool imu_initialized, is_first_data;
+  // gyro rotation preintegration since the last keyframe (not in the reference: input of the optional IMU factor of the window BA)
+  Quat kf_dq = quat_identity();
+  double kf_dt = 0;
 };
 
 enum TRACKINGSTATE { UnInit, Tracking, TrackingFail };
@@ -112,6 +115,9 @@ class F2FTracking {  // src/frontend/f2f_tracking.cpp
   void imu_feed(double time, Vec3 acc, Vec3 gyro, Quat& q_w_i, Vec3& pos_w_i, Vec3& vel_w_i);
   void image_feed(double time, const uint8_t* img0, const uint8_t* img1, bool& new_keyframe, bool& reset_cmd);
   void getKeyFrameInf(KeyFrameStruct& kf) const;  // CameraFrame::getKeyFrameInf + pose (what KeyFrameMsg::pub sends)
+  Quat kf_imu_dq = quat_identity();  // preintegrated body rotation between the previous keyframe and the last published one
+  double kf_imu_dt = 0;
+  bool kf_imu_valid = false;
   // local-map feedback (f2f_tracking.cpp:40-44): dead in v2 (vo_tracking.cpp:373-385 unpacks the message and drops it);
   // restated for the SURVEY 8f-2 row, applied at the next Tracking frame (f2f_tracking.cpp:189-219)
   void correction_feed(const CorrectionInfStruct& corr);

@@ -217,6 +217,15 @@ class LocalMap:
         return dict(frame_id=ofid.value, pose7=opose, lm_id=oid[:ocnt.value].copy(), lm_3d=o3d[:ocnt.value].copy(),
                     outlier_id=ooid[:oocnt.value].copy())
 
+    def set_imu_factor(self, on, sigma_g, q_c_b_wxyz):
+        q = np.ascontiguousarray(q_c_b_wxyz, np.float64)
+        lib().ref_localmap_set_imu_factor(self.h, int(bool(on)), C.c_double(sigma_g), _p(q, C.c_double))
+
+    def next_imu(self, dq_wxyz, dt):
+        """the gyro preintegration that comes with the NEXT pushed keyframe"""
+        q = np.ascontiguousarray(dq_wxyz, np.float64)
+        lib().ref_localmap_next_imu(_p(q, C.c_double), C.c_double(dt))
+
     def poses(self):
         p = np.zeros((self.window, 7))
         f = np.zeros(self.window, np.int32)
@@ -317,6 +326,13 @@ class Tracker:
         n = lib().ref_tracker_keyframe(self.h, cap, C.byref(fid), _p(pose, C.c_double), _p(ids, C.c_int64),
                                        _p(p2u, C.c_double), _p(p3w, C.c_double))
         return dict(frame_id=fid.value, pose7=pose, lm_id=ids[:n].copy(), lm_2d=p2u[:n].copy(), lm_3d=p3w[:n].copy())
+
+    def keyframe_imu(self):
+        """(valid, dq (w, x, y, z), dt): the gyro preintegration attached to the last keyframe (an addition, see ref_tracking.hpp)"""
+        dq = np.zeros(4)
+        dt = C.c_double(0)
+        v = lib().ref_tracker_keyframe_imu(self.h, _p(dq, C.c_double), C.byref(dt))
+        return bool(v), dq, dt.value
 
     def correction_feed(self, frame_id, pose7, lm_id, lm_3d, outlier_id):
         """F2FTracking::correction_feed (dead in v2; SURVEY 8f-2)."""

@@ -152,6 +152,16 @@ def test_config3_batch_of_64_streams_local_map_optimises():
 
 
 def test_config2_single_stream_frontend_and_ba_together():
+    _config2_frontend_and_ba(imu_factor=False)
+
+
+def test_config2_with_imu_rotation_factor():
+    """The same loop with the IMU rotation factor enabled on both sides (flvis_set_imu_factor): the gyro
+    preintegration the front-end attaches to every keyframe reaches the window BA through the keyframe queue."""
+    _config2_frontend_and_ba(imu_factor=True)
+
+
+def _config2_frontend_and_ba(imu_factor):
     """BASELINE configs[2] on the EuRoC-like rig (window 10, <= 480 landmarks per frame): ONE stream through the HIP front-end
     with the HIP local map consuming its keyframe queue, beside the oracle front-end feeding the oracle's LocalMap.  After
     every keyframe the CorrectionInf of both sides is compared: same keyframe, same landmark id list, same outliers while the
@@ -166,6 +176,14 @@ def test_config2_single_stream_frontend_and_ba_together():
     trk = flvis_amd.Tracker(ctx, cfg, 1, seed_base=0xF1715, traj_capacity=nframes)
     ref = O.Tracker(ocfg, 0xF1715)
     lmap = O.LocalMap(cfg.window_size, np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]]))
+    n_links = 0
+    if imu_factor:
+        import _geom as G
+        sigma_g = 0.004
+        R_c_i = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)[:3, :3].T
+        q = G.pose7(R_c_i, np.zeros(3))
+        lmap.set_imu_factor(True, sigma_g, np.array([q[6], q[3], q[4], q[5]]))
+        trk.set_imu_factor(True, sigma_g)
     tr = synth.Trajectory(sid)
     rnd = synth.Renderer("cuda", rig=rig)
     t_prev = -0.05
@@ -189,6 +207,10 @@ def test_config2_single_stream_frontend_and_ba_together():
         if not w["new_keyframe"]:
             continue
         kf = ref.keyframe()
+        valid, dq, dt = ref.keyframe_imu()
+        if imu_factor and valid:
+            lmap.next_imu(dq, dt)
+            n_links += 1
         c = lmap.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
         if c is not None:
             want_c = c
@@ -207,3 +229,4 @@ def test_config2_single_stream_frontend_and_ba_together():
     ctx.close()
     assert n_corr >= 3, n_corr
     assert 250 <= max_lm <= 480, max_lm
+    assert n_links >= 10 if imu_factor else n_links == 0

@@ -56,7 +56,7 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
     trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=seed_base, traj_capacity=nframes)
     refs = [O.Tracker(ocfg, seed_base + i) for i in range(S)]
     t_prev = -0.05
-    n_kf = 0
+    n_kf = n_imu_links = 0
     lock_frames = [0] * S      # tracked frames (all compared exactly)
     for f in range(nframes):
         t = f / synth.FRAME_HZ
@@ -96,7 +96,12 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
                 assert gk["frame_id"] == wk["frame_id"] and np.array_equal(gk["lm_id"], wk["lm_id"]), where
                 assert np.array_equal(gk["lm_2d"], wk["lm_2d"]) and np.array_equal(gk["lm_3d"], wk["lm_3d"]), where
                 assert np.array_equal(gk["pose7"], wk["pose7"]), where
+                gv, gdq, gdt = trk.get_keyframe_imu(i)             # gyro preintegration since the previous keyframe
+                wv, wdq, wdt = refs[i].keyframe_imu()
+                assert gv == wv and gdt == wdt and np.array_equal(gdq, wdq), (where, gdq - wdq, gdt - wdt)
+                n_imu_links += int(wv)
     assert n_kf >= min_kf
+    assert (n_imu_links >= (min_kf - S) // 2) if imu else (n_imu_links == 0)
     assert min(lock_frames) >= min_lock, lock_frames
     rows = trk.trajectory(0, 0, nframes)
     assert np.allclose(rows[:, 0], np.arange(nframes) / synth.FRAME_HZ)
@@ -342,6 +347,62 @@ def test_local_map_feedback_closed_loop(ctx):
     est = np.array([-(traj_io.quat_to_rot(rows[i, 7], rows[i, 4], rows[i, 5], rows[i, 6])).T @ rows[i, 1:4] for i in tracked])
     gt = np.array([-(tr.T_c_w(rows[i, 0], rig)[0]).T @ tr.T_c_w(rows[i, 0], rig)[1] for i in tracked])
     assert traj_io.ate_rmse(est, gt) < 0.05
+
+
+def _quat_wxyz(R):
+    import _geom as G
+    p7 = G.pose7(R, np.zeros(3))
+    return np.array([p7[6], p7[3], p7[4], p7[5]])
+
+
+def test_local_map_parity_with_imu_factor(ctx):
+    """The window BA with the optional IMU rotation edges (flvis_set_imu_factor / flvis_ba_push_keyframe_imu) against the
+    oracle's BAGraph with the same edges: every keyframe comes with the true relative body rotation + 1 mrad noise."""
+    import flvis_amd
+    import _geom as G
+    cfg, _ = _cfgs()
+    K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
+    T_i_c = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)
+    Rcb = T_i_c[:3, :3].T                                        # camera <- body
+    sigma_g = 0.004
+    # the keyframes of the first sequence without the factor (a context holds one tracker at a time: this one goes first)
+    plain = flvis_amd.Tracker(ctx, cfg, 1, seed_base=1)
+    seq0 = B.make_sequence(21, n_kf=14, n_lm=260, outlier_frac=0.03)
+    base_out = [plain.ba_push_keyframe(0, kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"]) for kf in seq0["kfs"]]
+    del plain
+    trk = flvis_amd.Tracker(ctx, cfg, 2, seed_base=1)
+    for stream, seed in ((0, 21), (1, 22)):
+        seq = B.make_sequence(seed, n_kf=14, n_lm=260, outlier_frac=0.03)
+        rng = np.random.default_rng(seed)
+        ref = O.LocalMap(cfg.window_size, K4)
+        ref.set_imu_factor(True, sigma_g, _quat_wxyz(Rcb))
+        trk.set_imu_factor(True, sigma_g)
+        produced, moved = 0, 0.0
+        for k, kf in enumerate(seq["kfs"]):
+            dq, dt = None, 0.0
+            if k > 0:
+                Ra, Rb = seq["gt"][k - 1][0], seq["gt"][k][0]
+                dR = (Ra.T @ Rcb).T @ (Rb.T @ Rcb) @ G.rodrigues(rng.normal(0, 1e-3, 3))
+                dq, dt = _quat_wxyz(dR), 0.1 + 0.02 * (k % 3)
+                ref.next_imu(dq, dt)
+            want = ref.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
+            got = trk.ba_push_keyframe(stream, kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"], imu_dq=dq, imu_dt=dt)
+            base = base_out[k] if stream == 0 else None
+            assert (want is None) == (got is None), k
+            if want is None:
+                continue
+            produced += 1
+            assert got["frame_id"] == want["frame_id"]
+            assert np.array_equal(got["lm_id"], want["lm_id"]), k
+            assert np.array_equal(got["outlier_id"], want["outlier_id"]), k
+            # fp64 LM chain with a different summation order: 1e-6 on pose and landmarks, as for the reprojection-only window
+            assert np.allclose(got["pose7"], want["pose7"], atol=1e-6, rtol=0), (k, got["pose7"] - want["pose7"])
+            assert np.allclose(got["lm_3d"], want["lm_3d"], atol=1e-6, rtol=0), (k, np.abs(got["lm_3d"] - want["lm_3d"]).max())
+            if base is not None:
+                moved = max(moved, np.abs(got["pose7"] - base["pose7"]).max())
+        assert produced == len(seq["kfs"]) - cfg.window_size + 1
+        if stream == 0:
+            assert moved > 1e-4          # the edges do change the solution (the parity above is not vacuous)
 
 
 def test_local_map_parity(ctx):
