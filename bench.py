@@ -54,6 +54,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=64, help="independent streams per GPU (weak scaling)")
+    ap.add_argument("--input-hold", type=int, default=4, help="multi-lane trackers (FLVIS_LANES > 1): frames an input buffer stays "
+                    "untouched after it was handed over (flvis_set_input_hold); every frame of the run has its own buffer here")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--total-streams", type=int, default=512, help="fixed total for --scaling strong")
     ap.add_argument("--cpu-frames", type=int, default=80, help="frames of the bounded single-thread CPU-baseline sample (0 = skip)")
@@ -274,10 +276,16 @@ def main():
     skip = cfg.skip_first_n_imgs
     epi = 0 if args.no_epilogue else plan.EPILOGUE
     nmax = plan.max_frames(K, Wm, skip, epilogue=epi)
-    ctx = flvis_amd.Context(local_rank)
+    # multi-lane trackers run on their own streams: a private context stream keeps torch's (null) stream out of the frame loop;
+    # the rendered inputs are synchronised explicitly below
+    own_stream = int(os.environ.get("FLVIS_LANES", "1") or 1) > 1
+    ctx = flvis_amd.Context(local_rank, own_stream=own_stream)
     trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715 + rank * S, traj_capacity=nmax)
     lib = ctx._lib
     wlm = 0 if args.no_local_map else 1
+    if lib.flvis_tracker_lanes(ctx._h) > 1 and args.input_hold > 0:
+        # every frame of the run is resident in its own buffer: the lanes need not wait for each other at frame boundaries
+        ctx._check(lib.flvis_set_input_hold(ctx._h, args.input_hold), "set_input_hold")
 
     # ---- synthetic inputs
     stream_ids = fdist.shard_streams(rank, world, S)
@@ -304,6 +312,8 @@ def main():
 
     def render(f):
         fr = rnd.stereo_frame(trajs, f / synth.FRAME_HZ, f)
+        if own_stream:
+            torch.cuda.synchronize()
         if rank == 0 and cpu_first <= f < cpu_first + n_keep:
             ns = max(1, n_mt) if f < cpu_first + (args.cpu_mt_frames if n_mt else 0) else 1
             host_frames[f] = (fr[0][:ns].cpu().numpy(), fr[1][:ns].cpu().numpy())
@@ -389,11 +399,20 @@ def main():
     barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def host_times():
+        h = (C.c_double * 3)()
+        lib.flvis_debug_host_times(ctx._h, h)
+        return list(h)
+
+    host0 = host_times()
     t0 = time.perf_counter()
     e0.record()
     for g in range(*sched["timed"]):
         feed(g, frames[g])
     e1.record()
+    t_issue = time.perf_counter() - t0   # host loop over the K steps (the calls return before the GPU has run them, but block on the
+    host1 = host_times()                 # pinned upload ring once the host is 4 frames ahead); host1 - host0: time inside image_feed
     ctx._check(lib.flvis_hip_synchronize(ctx._h), "synchronize")  # everything enqueued AND every queued keyframe consumed by the local map
     torch.cuda.synchronize()
     barrier()
@@ -444,7 +463,10 @@ def main():
                        "window_size": cfg.window_size, "local_map": bool(wlm),
                        "preroll_frames": sched["preroll"][1], "streams_tracking_at_start": tracking_at_start,
                        "streams_tracking_at_end": int(csum[3]), "keyframes_in_run": int(csum[1]), "ba_runs_in_run": int(csum[2]),
-                       "gpu_ms_per_step_events": round(gpu_ms / K, 4)},
+                       "gpu_ms_per_step_events": round(gpu_ms / K, 4),
+                       "host_loop_ms_per_step": round(t_issue / K * 1e3, 4),
+                       "host_enqueue_ms_per_step": round((host1[0] - host1[1] - host0[0] + host0[1]) / K, 4),
+                       "input_hold_frames": args.input_hold if lib.flvis_tracker_lanes(ctx._h) > 1 else 0},
             "latency_ms": {"gpu_frame_chain_p50": round(plan.percentile(chain_ms, 50), 4),
                            "gpu_frame_chain_p99": round(plan.percentile(chain_ms, 99), 4),
                            "note": "HIP events around the whole main-stream chain of one batch step (all %d streams of the GPU "
@@ -453,6 +475,10 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": dom_bytes, "launches_per_step": 2},
         }
+        try:
+            out["roofline"]["hbm_copy_measured"] = measure_copy_bandwidth(dev)
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("leg_errors", []).append("copy bandwidth: %s" % e)
         if stages is not None:
             out["stages_ms_per_step"] = {k: round(v, 4) for k, v in stages.items()}
             out["stages_note"] = "per-stage times from %d untimed frames after the timed region (all stages bracketed by events)" % epi
@@ -468,6 +494,25 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def measure_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
+    """What this GPU's HBM actually sustains on a plain device-to-device copy (read + write counted), next to the 8 TB/s peak the
+    roofline fraction is priced against."""
+    import torch
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.fill_(3)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"GB/s": round(2 * nbytes / (ms * 1e-3) / 1e9, 1), "bytes_copied": nbytes, "note": "torch device-to-device copy of 1 GiB, read + write bytes"}
 
 
 def leg_h2d(L):

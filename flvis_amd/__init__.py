@@ -386,6 +386,10 @@ class Tracker:
         return dict(frame_id=fid.value, pose7=pose, lm_id=ids[:cnt.value].copy(), lm_3d=p3[:cnt.value].copy(),
                     outlier_id=oid[:oc.value].copy())
 
+    def set_input_hold(self, n_frames):
+        """flvis_set_input_hold: multi-lane trackers -- the caller leaves a call's input images untouched during the next n calls."""
+        self.ctx._check(self.lib.flvis_set_input_hold(self.ctx._h, int(n_frames)), "set_input_hold")
+
     def set_imu_factor(self, enable, sigma_gyro=0.002):
         """flvis_set_imu_factor: gyro rotation-preintegration edges between consecutive keyframes in the window BA (off by default)."""
         self.ctx._check(self.lib.flvis_set_imu_factor(self.ctx._h, int(bool(enable)), C.c_double(sigma_gyro)), "set_imu_factor")

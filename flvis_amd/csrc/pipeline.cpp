@@ -13,6 +13,7 @@
 // local-map workers of all lanes share two low-priority HIP streams (the number of hardware queues is limited: streams
 // beyond it share a queue and serialise behind each other's long kernels).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -65,7 +66,14 @@ struct Lane {
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
-  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_end = nullptr;
+  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr;
+  int idx = 0;  // position in Pipeline::lanes
+  // multi-lane trackers: ev_end[n % HOLD_RING] follows the lane's n-th frame (the context's stream waits for the frame whose
+  // input buffers the caller may reuse next, see flvis_set_input_hold); ev_stagger follows the temporal LK of the lane's first
+  // processed frame (the next lane starts its first frame there, so that the lanes run out of phase)
+  static constexpr int HOLD_RING = 8;
+  hipEvent_t ev_end[HOLD_RING] = {};
+  hipEvent_t ev_stagger = nullptr;
   // back-pressure on the keyframe queues in stream order: ev_ba_done[i % BAQ] follows the lane's i-th local-map launch; the
   // tracking stream waits for the launches of KFQ-3 frames ago before it appends new keyframes (see lane_frame)
   static constexpr int BAQ = 32;
@@ -89,8 +97,12 @@ struct Pipeline {
   // The local map runs beside the front-end: k_frame_end appends KeyFrame payloads to per-stream queues, k_ba_worker (one
   // launch per lane and frame on one of the shared local-map streams, round-robin) drains them.  Its output is never fed
   // back into the tracker in the reference (src/frontend/vo_tracking.cpp:373-385).
-  static constexpr int NBA = 4;
-  int nba = 2;                   // local-map streams in use (FLVIS_BA_STREAMS, tuning knob)
+  static constexpr int NBA = 8;
+  int nba = 2;                   // local-map streams in use: 2 per lane (FLVIS_BA_STREAMS per lane, tuning knob)
+  int nba_lane = 2;              // ... of which every lane uses its own nba_lane
+  int input_hold = 0;            // flvis_set_input_hold: frames the caller keeps its input buffers untouched after handing them over
+  bool stagger = true;           // FLVIS_LANE_STAGGER=0: lanes start their first frame together
+  double host_ms_total = 0, host_ms_wait = 0;  // host time inside flvis_image_feed / of it blocked on the pinned ring
   bool sync_each_frame = false;  // FLVIS_SYNC_EACH_FRAME=1: image_feed waits for the previous frame (tuning knob)
   int ba_every = 1;              // launch the local-map worker every n-th frame (FLVIS_BA_EVERY)
   hipStream_t ba_stream[NBA] = {};
@@ -219,7 +231,8 @@ static void lane_destroy(Lane* L) {
     hipStreamDestroy(L->det_stream);
   }
   if (L->own_st && L->st) hipStreamDestroy(L->st);
-  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_end})
+  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
+                       L->ev_end[4], L->ev_end[5], L->ev_end[6], L->ev_end[7]})
     if (e) hipEventDestroy(e);
   for (int k = 0; k < Lane::BAQ; k++)
     if (L->ev_ba_done[k]) hipEventDestroy(L->ev_ba_done[k]);
@@ -415,7 +428,9 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
     L->st = ctx->stream;
   }
   bool evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
-  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_end})
+  static_assert(Lane::HOLD_RING == 8, "event list below");
+  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
+                        &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
     evok = evok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < Lane::BAQ && evok; k++)
     evok = hipEventCreateWithFlags(&L->ev_ba_done[k], hipEventDisableTiming) == hipSuccess;
@@ -471,8 +486,11 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   n_lanes = (S + pl->lane_size - 1) / pl->lane_size;
   if (const char* e = getenv("FLVIS_BA_STREAMS")) {
     int v = atoi(e);
-    if (v >= 1 && v <= Pipeline::NBA) pl->nba = v;
+    if (v >= 1 && v <= 4) pl->nba_lane = v;
   }
+  pl->nba_lane = std::max(1, std::min(pl->nba_lane, Pipeline::NBA / n_lanes));
+  pl->nba = std::min(Pipeline::NBA, pl->nba_lane * n_lanes);  // (more than NBA / nba_lane lanes share local-map streams)
+  if (const char* e = getenv("FLVIS_LANE_STAGGER")) pl->stagger = atoi(e) != 0;
   if (const char* e = getenv("FLVIS_SYNC_EACH_FRAME")) pl->sync_each_frame = atoi(e) != 0;
   if (const char* e = getenv("FLVIS_BA_EVERY")) {
     int v = atoi(e);
@@ -481,6 +499,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   bool ok = true;
   for (int k = 0; k < n_lanes && ok; k++) {
     Lane* L = new Lane();
+    L->idx = k;
     pl->lanes.push_back(L);
     const int s0 = k * pl->lane_size;
     ok = lane_create(ctx, pl, L, s0, std::min(pl->lane_size, S - s0), seed_base, traj_capacity, n_lanes > 1);
@@ -622,7 +641,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   const int pslot = (int)(pl->frames_fed % Lane::PIN_RING);
   uint8_t* pin = (uint8_t*)L->pinned[pslot];
   if (pl->sync_each_frame) hipStreamSynchronize(st);
-  if (pl->frames_fed >= Lane::PIN_RING) hipEventSynchronize(L->ev_pin[pslot]);  // upload of frame N-PIN_RING is done
+  if (pl->frames_fed >= Lane::PIN_RING) {  // upload of frame N-PIN_RING is done
+    const auto tw = std::chrono::steady_clock::now();
+    hipEventSynchronize(L->ev_pin[pslot]);
+    pl->host_ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+  }
   double* pt = (double*)pin;
   double* pi = pt + S;
   const uint8_t** ptab = (const uint8_t**)(pi + (size_t)S * IMU_MAX * 7);
@@ -668,6 +691,10 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
         }
     return;
   }
+  // lanes out of phase: a lane's first processed frame starts when the previous lane has finished the temporal LK of its own, so
+  // that from then on the image kernels of one lane overlap the one-workgroup-per-stream geometry chain of another
+  const bool first_processed = pl->frames_fed == (long long)pl->cfg.skip_first_n_imgs;
+  if (first_processed && pl->stagger && L->idx > 0) hipStreamWaitEvent(st, pl->lanes[L->idx - 1]->ev_stagger, 0);
   const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
   const bool eq = pl->cfg.need_equal_hist != 0;
   const bool aligned = (w & 15) == 0;  // otherwise (KITTI: 1241 x 376, tightly packed rows) both images are copied into pitch-aligned level 0
@@ -675,6 +702,10 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // caller's image and writes level 0 and level 1 in one pass; with it the equalised image is level 0.
   ImgSel in0 = img_indirect(L->d_tab + 0), in1 = img_indirect(L->d_tab + 1);
   ImgSel l0cur{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot, 0, nullptr};
+  // (the guesses of the temporal tracker only need the state frame_begin left: launched before the chain hands over to the image stream)
+  PB(3, st);
+  launch_track_prepare(st, p);
+  PE(3, st);
   PB(1, st);
   if (eq) launch_equalize_hist(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
   else if (!aligned) launch_copy_image_any(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
@@ -723,9 +754,6 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   }
   hipEventRecord(L->ev_det, ds);
   // temporal tracking
-  PB(3, st);
-  launch_track_prepare(st, p);
-  PE(3, st);
   PB(4, st);
   {
     PyrSel prev, next;
@@ -738,6 +766,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(5, st);
   launch_track_collect(st, p);
   PE(5, st);
+  if (first_processed && pl->lanes.size() > 1) hipEventRecord(L->ev_stagger, st);
   PB(6, st);
   launch_ransac_f(st, p);
   PE(6, st);
@@ -784,7 +813,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     // drains the queues of the windows it owns; a window owned by an earlier launch is drained by that one), so waiting
     // for the launches of D frames ago bounds the backlog of a stream by (D + 2) * ba_every <= KFQ keyframes.
     const long long D = std::max(0, KFQ / pl->ba_every - 3);
-    for (int k = 0; k < pl->nba; k++) {
+    for (int k = 0; k < pl->nba_lane; k++) {
       const long long j = L->ba_launches - 1 - D - k;
       if (j >= 0 && L->ba_launches - j <= Lane::BAQ) hipStreamWaitEvent(st, L->ev_ba_done[j % Lane::BAQ], 0);
     }
@@ -794,7 +823,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(17, st);
   PE(19, st);
   if (with_local_map && (pl->frames_fed % pl->ba_every) == 0) {
-    hipStream_t bs = pl->ba_stream[pl->ba_rr++ % pl->nba];
+    hipStream_t bs = pl->ba_stream[(L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba];
     hipEventRecord(L->ev_fe, st);
     hipStreamWaitEvent(bs, L->ev_fe, 0);
     PB(18, bs);
@@ -824,17 +853,22 @@ int flvis_image_feed(flvis_ctx* ctx, const uint8_t* d_img0, const uint8_t* d_img
   const size_t img_px = (size_t)pl->cfg.image_width * pl->cfg.image_height;
   const size_t img1_bytes = img_px * (pl->cfg.cam_type == CAM_DEPTH ? 2 : 1);
   const bool multi = pl->lanes.size() > 1;
+  const auto t_host0 = std::chrono::steady_clock::now();
   // the caller's images were produced on the context's stream; lanes with their own streams wait for them, and the
-  // context's stream waits for the lanes afterwards, so that the caller may recycle its buffers in stream order
+  // context's stream waits for the lanes afterwards, so that the caller may recycle its buffers in stream order -- the buffers
+  // of THIS frame by default, those handed over input_hold frames ago when the caller cycles through more buffers
+  // (flvis_set_input_hold): only then can the lanes drift apart by more than a frame
   if (multi) hipEventRecord(pl->ev_in, ctx->stream);
   for (Lane* L : pl->lanes) {
     if (multi) hipStreamWaitEvent(L->st, pl->ev_in, 0);
     lane_frame(ctx, pl, L, d_img0 + (size_t)L->s0 * img_px, d_img1 + (size_t)L->s0 * img1_bytes, h_times + L->s0, with_local_map);
     if (multi) {
-      hipEventRecord(L->ev_end, L->st);
-      hipStreamWaitEvent(ctx->stream, L->ev_end, 0);
+      hipEventRecord(L->ev_end[pl->frames_fed % Lane::HOLD_RING], L->st);
+      const long long rel = pl->frames_fed - pl->input_hold;
+      if (rel >= 0) hipStreamWaitEvent(ctx->stream, L->ev_end[rel % Lane::HOLD_RING], 0);
     }
   }
+  pl->host_ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
   const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
   if (prof) pl->prof_step++;
   pl->frames_fed++;
@@ -1233,6 +1267,24 @@ int flvis_debug_counters(flvis_ctx* ctx, int64_t* h64) {
     hipMemcpy(c, L->pipe.counters, sizeof(c), hipMemcpyDeviceToHost);
     for (int i = 0; i < 64; i++) h64[i] += c[i];
   }
+  return FLVIS_OK;
+}
+
+// Multi-lane trackers: how many later flvis_image_feed calls the caller leaves the input buffers of a call untouched (it cycles
+// through n + 1 buffers).  0 (default): the context's stream waits for every lane to finish the frame before it goes on.
+int flvis_set_input_hold(flvis_ctx* ctx, int n_frames) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  if (n_frames < 0 || n_frames >= Lane::HOLD_RING) return ctx->fail(FLVIS_ERR_INVALID_ARG, "set_input_hold: 0 .. 7 frames");
+  ctx->pipe->input_hold = n_frames;
+  return FLVIS_OK;
+}
+// Tuning aid: host milliseconds spent inside flvis_image_feed since the tracker was created, [0] in total, [1] of it blocked on
+// the pinned upload ring (the host running PIN_RING frames ahead of the GPU), [2] calls.
+int flvis_debug_host_times(flvis_ctx* ctx, double* h_out3) {
+  if (!ctx || !ctx->pipe || !h_out3) return FLVIS_ERR_INVALID_ARG;
+  h_out3[0] = ctx->pipe->host_ms_total;
+  h_out3[1] = ctx->pipe->host_ms_wait;
+  h_out3[2] = (double)ctx->pipe->frames_fed;
   return FLVIS_OK;
 }
 

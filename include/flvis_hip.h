@@ -177,6 +177,14 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
  * default; the environment variable FLVIS_LANES (1..16) is a tuning knob (more lanes measured slower on MI355X, DESIGN.md
  * section 4).  The partition changes no result (streams are independent). */
 int flvis_tracker_lanes(flvis_ctx* ctx);
+/* Trackers with more than one lane (FLVIS_LANES): by default the context's stream waits for every lane at the end of a call, so
+ * that the caller may overwrite the input images in stream order right away -- which also keeps the lanes in step.  A caller that
+ * cycles through n + 1 input buffers (leaves a call's images untouched during the next n calls) says so here (0 <= n <= 7); the
+ * lanes may then run up to n frames apart and the image kernels of one lane overlap the geometry chain of another. */
+int flvis_set_input_hold(flvis_ctx* ctx, int n_frames);
+/* Tuning aid: host milliseconds inside flvis_image_feed since flvis_tracker_create: [0] total, [1] of it blocked on the pinned
+ * upload ring, [2] calls. */
+int flvis_debug_host_times(flvis_ctx* ctx, double* h_out3);
 
 /* One IMU sample of stream `stream` in the SENSOR frame; remapped per type_of_vi like imu_callback does.  Samples are
  * staged on the host and consumed by the next flvis_image_feed (feed samples with t <= image time before the image). */

@@ -29,7 +29,7 @@ def _cfgs_yaml(text, tag):
     return cfg, ocfg
 
 
-def _run_batch(cfg, S, nframes, sampled, ocfg=None, lanes=None):
+def _run_batch(cfg, S, nframes, sampled, ocfg=None, lanes=None, input_hold=0):
     """Feeds `nframes` frames of S synthetic streams with the local map on.  Returns per-frame outputs of the sampled streams,
     all trajectories, the counters and (when ocfg is given) the oracle's per-frame results for the sampled streams."""
     import flvis_amd
@@ -42,6 +42,9 @@ def _run_batch(cfg, S, nframes, sampled, ocfg=None, lanes=None):
         trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715, traj_capacity=nframes)
     finally:
         os.environ.pop("FLVIS_LANES", None)
+    held = []            # with input_hold = n the caller leaves a frame's input buffers alone during the next n calls
+    if input_hold:
+        trk.set_input_hold(input_hold)
     skip = cfg.skip_first_n_imgs
     trajs = [synth.Trajectory(s) for s in range(S)]
     rnd = synth.Renderer("cuda")
@@ -66,6 +69,10 @@ def _run_batch(cfg, S, nframes, sampled, ocfg=None, lanes=None):
                 standin = (i0, i1)
         else:
             i0, i1 = standin
+        if input_hold:   # free-running lanes: no per-frame read-back (it would wait for every lane), only the recorded trajectory
+            held = (held + [(i0, i1)])[-(input_hold + 1):]
+            trk.image_feed(i0, i1, [t] * S, want_out=False, with_local_map=True)
+            continue
         outs = trk.image_feed(i0, i1, [t] * S, with_local_map=True)
         for i in sampled:
             got[i].append(outs[i])
@@ -132,6 +139,8 @@ def test_config3_batch_of_64_streams_with_local_map():
     assert b["counters"] == a["counters"]
     c = _run_batch(cfg, S, nframes, sampled, lanes=2)
     assert c["lanes"] == 2 and np.array_equal(c["rows"], a["rows"]), "a stream's trajectory depends on the lane partition"
+    d = _run_batch(cfg, S, nframes, [], lanes=4, input_hold=3)   # lanes out of step by up to 3 frames (flvis_set_input_hold)
+    assert d["lanes"] == 4 and d["dropped"] == 0 and np.array_equal(d["rows"], a["rows"]), "free-running lanes change a trajectory"
 
 
 def test_config3_batch_of_64_streams_local_map_optimises():
