@@ -244,6 +244,56 @@ class Context:
         return pairs, npairs
 
 
+    def bow_set_vocabulary(self, child_ptr, child_idx, desc, weight, word_id):
+        """flvis_hip_bow_set_vocabulary: the DBoW3 tree as flat arrays (see include/flvis_hip.h)."""
+        import numpy as np
+        cp = np.ascontiguousarray(child_ptr, np.int32)
+        ci = np.ascontiguousarray(child_idx, np.int32)
+        ds = np.ascontiguousarray(desc, np.uint8)
+        wt = np.ascontiguousarray(weight, np.float64)
+        wi = np.ascontiguousarray(word_id, np.int32)
+        n = len(cp) - 1
+        assert ds.shape == (n, 32) and len(wt) == n and len(wi) == n
+        self._check(self._lib.flvis_hip_bow_set_vocabulary(self._h, n, _P(cp, C.c_int), _P(ci, C.c_int), _P(ds, C.c_uint8),
+                                                           _P(wt, C.c_double), _P(wi, C.c_int)), "bow_set_vocabulary")
+
+    def bow_transform(self, desc, count, vcap=2048):
+        """desc uint8 [n,dcap,32], count int32 [n] (device) -> (ids int32 [n,vcap], vals float64 [n,vcap], nnz int32 [n])."""
+        import torch
+        desc = desc.contiguous()
+        n, dcap, _ = desc.shape
+        ids = torch.full((n, vcap), -1, dtype=torch.int32, device=desc.device)
+        vals = torch.zeros((n, vcap), dtype=torch.float64, device=desc.device)
+        nnz = torch.zeros((n,), dtype=torch.int32, device=desc.device)
+        self._check(self._lib.flvis_hip_bow_transform(self._h, _ptr(desc), _ptr(count), dcap, n, vcap, _ptr(ids), _ptr(vals),
+                                                      _ptr(nnz)), "bow_transform")
+        return ids, vals, nnz
+
+    def bow_score(self, q_ids, q_vals, q_nnz, db_ids, db_vals, db_nnz):
+        """one similarity-matrix row: query (1-D device tensors + nnz [1]) against db [m,vcap] -> scores float64 [m]."""
+        import torch
+        m, vcap = db_ids.shape
+        scores = torch.full((m,), -1.0, dtype=torch.float64, device=db_ids.device)
+        self._check(self._lib.flvis_hip_bow_score(self._h, _ptr(q_ids), _ptr(q_vals), _ptr(q_nnz), _ptr(db_ids), _ptr(db_vals),
+                                                  _ptr(db_nnz), vcap, m, _ptr(scores)), "bow_score")
+        return scores
+
+
+def loop_candidate(row, present, lcKFDist, lcKFMaxDist, lcNKFClosest, minScore):
+    """flvis_loop_candidate (host control logic of isLoopCandidate): returns the earlier keyframe's index or None."""
+    import numpy as np
+    lib = load_library()
+    row = np.ascontiguousarray(row, np.float64)
+    pres = np.ascontiguousarray(present, np.uint8)
+    out = C.c_int64(-1)
+    lib.flvis_loop_candidate.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_double,
+                                         C.POINTER(C.c_int64)]
+    r = lib.flvis_loop_candidate(len(row), _P(row, C.c_double), _P(pres, C.c_uint8), lcKFDist, lcKFMaxDist, lcNKFClosest,
+                                 C.c_double(minScore), C.byref(out))
+    if r < 0:
+        raise FlvisError("flvis_loop_candidate failed: %d" % r)
+    return int(out.value) if r == 1 else None
+
 
 class OrbParams(C.Structure):
     """flvis_orb_params of include/flvis_hip.h."""

@@ -124,6 +124,27 @@ int flvis_hip_hamming_knn2(flvis_ctx* ctx, const uint8_t* d_query, const int* d_
 int flvis_hip_orb_match(flvis_ctx* ctx, const uint8_t* d_a, const int* d_na, int acap, const uint8_t* d_b, const int* d_nb,
                         int bcap, int n_pairs, double ratio_max, int* d_pairs, int* d_npairs);
 
+/* ---- place recognition of the loop closing: DBoW3 bag of words + L1 score + candidate selection ---------------
+ * The vocabulary is handed over as flat arrays (the reference loads a DBoW3 file that is not shipped with it,
+ * vo_loopclosing.cpp:1097): node 0 is the root, the children of node n are h_child_idx[h_child_ptr[n] .. h_child_ptr[n+1]) in
+ * DBoW3's order (3rdPartLib/DBow3/src/Vocabulary.h m_nodes[n].children), a node without children is a word with id h_word_id[n]
+ * and weight h_weight[n] (idf); h_desc: 32 bytes per node.  Weighting TF_IDF, scoring L1_NORM (DBoW3's defaults). */
+int flvis_hip_bow_set_vocabulary(flvis_ctx* ctx, int n_nodes, const int* h_child_ptr, const int* h_child_idx, const uint8_t* h_desc,
+                                 const double* h_weight, const int* h_word_id);
+/* voc.transform(kf.lm_descriptor, kf_bv) (vo_loopclosing.cpp:249-253; Vocabulary.cpp:628-688) for n_img keyframes:
+ * d_desc [n_img][dcap][32] + d_count [n_img] as flvis_hip_orb_detect_and_compute leaves them (dcap <= 2048);
+ * out: d_ids / d_vals [n_img][vcap] ascending word ids and L1-normalised values, d_nnz [n_img]. */
+int flvis_hip_bow_transform(flvis_ctx* ctx, const uint8_t* d_desc, const int* d_count, int dcap, int n_img, int vcap, int* d_ids,
+                            double* d_vals, int* d_nnz);
+/* one row of the similarity matrix (vo_loopclosing.cpp:417-437): voc.score(query, db[j]) for j < n_db (ScoringObject.cpp:23-68);
+ * the query is one vector on the device (d_q_nnz[0] entries), the database [n_db][vcap]; d_db_nnz[j] < 0 marks an absent keyframe
+ * (kf_lc_tmp[j] == nullptr: score 0). */
+int flvis_hip_bow_score(flvis_ctx* ctx, const int* d_q_ids, const double* d_q_vals, const int* d_q_nnz, const int* d_db_ids,
+                        const double* d_db_vals, const int* d_db_nnz, int vcap, int n_db, double* d_scores);
+/* isLoopCandidate (vo_loopclosing.cpp:520-590) on the newest keyframe's row h_row[i] = sim_matrix[i][g_size-1] (host control
+ * logic, as in the reference's pgoProcess thread).  Returns 1 and *kf_prev_idx when there is a candidate, 0 when not. */
+int flvis_loop_candidate(int g_size, const double* h_row, const uint8_t* h_present, int lcKFDist, int lcKFMaxDist, int lcNKFClosest,
+                         double minScore, int64_t* kf_prev_idx);
 
 /* ---- pipeline-level entry points: F2FTracking + LocalMap for a batch of independent streams ------------------------
  *
