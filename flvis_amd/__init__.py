@@ -278,6 +278,33 @@ class Context:
                                                   _ptr(db_nnz), vcap, m, _ptr(scores)), "bow_score")
         return scores
 
+    def pgo_loop_closure(self, T_c_w_list, present_list, loops_list, loop_poses_list, iterations=100, use_initial_guess=True):
+        """flvis_hip_pgo_loop_closure for a batch of pose graphs (lists of per-graph numpy arrays: T_c_w [n,7], present [n], loops
+        [m,2], loop poses [m,7]).  Returns (list of optimised T_c_w arrays, drift [g,7], stats [g,5], ran [g])."""
+        import numpy as np
+        import torch
+        g = len(T_c_w_list)
+        n_kf = np.array([len(t) for t in T_c_w_list], np.int32)
+        n_loops = np.array([len(l) for l in loops_list], np.int32)
+        T = torch.from_numpy(np.ascontiguousarray(np.concatenate(T_c_w_list), np.float64).reshape(-1, 7)).cuda()
+        pres = np.ascontiguousarray(np.concatenate(present_list), np.uint8)
+        loops = np.ascontiguousarray(np.concatenate([np.asarray(l, np.int32).reshape(-1, 2) for l in loops_list] + [np.zeros((1, 2), np.int32)]), np.int32)
+        lp = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(p, np.float64).reshape(-1, 7) for p in loop_poses_list] +
+                                                                  [np.zeros((1, 7))]))).cuda()
+        drift = torch.zeros((g, 7), dtype=torch.float64, device="cuda")
+        stats = torch.zeros((g, 5), dtype=torch.float64, device="cuda")
+        ran = np.zeros(g, np.int32)
+        self._check(self._lib.flvis_hip_pgo_loop_closure(self._h, g, _P(n_kf, C.c_int), _ptr(T), _P(pres, C.c_uint8), _P(n_loops, C.c_int),
+                                                         _P(loops, C.c_int), _ptr(lp), int(iterations), int(bool(use_initial_guess)),
+                                                         _ptr(drift), _ptr(stats), _P(ran, C.c_int)), "pgo_loop_closure")
+        self._check(self._lib.flvis_hip_synchronize(self._h), "synchronize")
+        out = T.cpu().numpy()
+        res, o = [], 0
+        for k in n_kf:
+            res.append(out[o:o + k].copy())
+            o += k
+        return res, drift.cpu().numpy(), stats.cpu().numpy(), ran
+
 
 def loop_candidate(row, present, lcKFDist, lcKFMaxDist, lcNKFClosest, minScore):
     """flvis_loop_candidate (host control logic of isLoopCandidate): returns the earlier keyframe's index or None."""

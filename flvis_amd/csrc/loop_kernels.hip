@@ -7,7 +7,7 @@
 // (Vocabulary.cpp:836-874), a word's value is its idf weight added once per occurrence (BowVector.cpp:34-46), the vector is
 // L1-normalised with the norm summed in ascending word order (BowVector.cpp:62-84), and the L1 score is summed over the common
 // words in ascending order (ScoringObject.cpp:23-68).  The fp64 sums are kept SEQUENTIAL in exactly that order, so ids, values
-// and scores are bit-identical to the CPU restatement (oracle/ref_bow.cpp): the candidate selection thresholds the scores.
+// and scores are bit-identical to the CPU restatement the tests check against: the candidate selection thresholds the scores.
 //
 // All byte / integer work plus short fp64 sums, keyframe rate (not on the per-frame path): one thread per descriptor for the
 // descent (the tree, <= 1 MB for a 10^6-word vocabulary's upper levels, stays in L2), one 1024-thread workgroup per keyframe for
@@ -24,6 +24,7 @@
 #include "../../include/flvis_hip.h"
 #include "ctx.hpp"
 #include "dev_common.hpp"
+#include "dev_math.hpp"
 
 namespace flvis {
 
@@ -219,6 +220,372 @@ __global__ __launch_bounds__(256) void k_bow_score(const int* __restrict__ q_ids
   if (lane == 0) scores[j] = -score / 2.0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ pose-graph optimisation
+// loopClosureOnCovGraphG2ONew (vo_loopclosing.cpp:742-944): vertices kf_prev..kf_curr (g2o VertexSE3, estimate T_w_c), EdgeSE3 to
+// the next five keyframes with the current relative poses as measurements plus one edge per recorded loop, Cauchy kernel,
+// Levenberg (lambda 1e-10, up to 100 iterations, up to 10 trials each), Cholesky on the pose blocks.  g2o semantics as cited in
+// the test-side CPU restatement (error / update in the translation + compact-quaternion chart of types/slam3d/isometry3d_mappings.cpp).
+//
+// One workgroup per graph (a batch = the graphs of independent sequences).  The host only does the integer bookkeeping (which
+// keyframes become vertices, which are fixed, the edge list, the block profile); measurements, initial guess, linearisation,
+// factorisation and write-back run here.  The normal matrix is block-banded (5 neighbours) with one wide block row per loop edge
+// between two free vertices: stored and factored as a block PROFILE (every block row from its first non-zero column to the
+// diagonal; fill stays inside), row by row by one wave -- lane (r, c) owns one entry of the current 6x6 block.
+constexpr int PGO_T = 256;
+
+struct PgoGraph {
+  int n, E, P, n_kf, iterations, use_guess;
+  const int *vkf, *fixed, *hidx, *ea, *eb, *eloop, *adj_ptr, *adj_e, *first;
+  const long long* boff;  // block offset of block row i's first block; boff[P] = number of blocks
+  int* queue;             // [n] BFS scratch
+  int* dist;              // [n]
+  double *est, *bak, *Z, *H, *L, *b, *x;
+  double* T_c_w;            // [n_kf][7] in / out
+  const double* loop_pose;  // [n_loops][7]
+  double* drift;            // [7]
+  double* stats;            // [5]
+};
+
+FD SE3d iso_mul(const SE3d& a, const SE3d& b) { return SE3d{q_mul(a.q, b.q), a.t + q_rotate(a.q, b.t)}; }
+FD SE3d iso_inv(const SE3d& a) {
+  const Q4 qi = q_conj(a.q);
+  return SE3d{qi, q_rotate(qi, -1.0 * a.t)};
+}
+FD SE3d pgo_from_mqt(const double* v) {
+  const double w = 1 - (v[3] * v[3] + v[4] * v[4] + v[5] * v[5]);
+  const Q4 q = w < 0 ? q_identity() : Q4{sqrt(w), v[3], v[4], v[5]};
+  return SE3d{q, V3{v[0], v[1], v[2]}};
+}
+FD void pgo_error(const SE3d& Xi, const SE3d& Xj, const SE3d& Z, double* e) {
+  const SE3d Ee = iso_mul(iso_mul(iso_inv(Z), iso_inv(Xi)), Xj);
+  Q4 q = q_normalized(Ee.q);
+  if (q.w < 0) q = Q4{-q.w, -q.x, -q.y, -q.z};
+  e[0] = Ee.t.x, e[1] = Ee.t.y, e[2] = Ee.t.z, e[3] = q.x, e[4] = q.y, e[5] = q.z;
+}
+// Jacobians of the error w.r.t. the updates of Xi (Ji) and Xj (Jj): rows = error, columns = (translation, compact quaternion)
+FD void pgo_linearize(const SE3d& Xi, const SE3d& Xj, const SE3d& Z, double Ji[6][6], double Jj[6][6]) {
+  const SE3d A = iso_inv(Z), B = iso_mul(iso_inv(Xi), Xj), Ee = iso_mul(A, B);
+  const M3 Ra = q_to_mat(A.q), Re = q_to_mat(Ee.q);
+  const M3 RaS = Ra * skew(B.t);
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c < 6; c++) Ji[r][c] = Jj[r][c] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Ji[r][c] = -Ra.m[r][c];
+      Jj[r][c] = Re.m[r][c];
+      Ji[r][3 + c] = 2.0 * RaS.m[r][c];
+    }
+  const Q4 qe = q_normalized(Ee.q);
+  const double sgn = qe.w < 0 ? -1.0 : 1.0;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const Q4 u{0, c == 0 ? 1.0 : 0.0, c == 1 ? 1.0 : 0.0, c == 2 ? 1.0 : 0.0};
+    const Q4 di = q_mul(q_mul(A.q, u), B.q), dj = q_mul(Ee.q, u);
+    Ji[3][3 + c] = -sgn * di.x, Ji[4][3 + c] = -sgn * di.y, Ji[5][3 + c] = -sgn * di.z;
+    Jj[3][3 + c] = sgn * dj.x, Jj[4][3 + c] = sgn * dj.y, Jj[5][3 + c] = sgn * dj.z;
+  }
+}
+
+// sum over the workgroup in a fixed order (per-wave butterfly, waves in order): the same value in every thread
+__device__ inline double pgo_block_sum(double v, double* s_red) {
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = 0;
+#pragma unroll
+  for (int i = 0; i < PGO_T / 64; i++) r += s_red[i];
+  __syncthreads();
+  return r;
+}
+
+__device__ inline double pgo_chi2(const PgoGraph& g, double* s_red) {
+  double chi = 0;
+  for (int k = threadIdx.x; k < g.E; k += PGO_T) {
+    double e[6];
+    pgo_error(load_pose7(g.est + 7 * g.ea[k]), load_pose7(g.est + 7 * g.eb[k]), load_pose7(g.Z + 7 * k), e);
+    double e2 = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) e2 += e[q] * e[q];
+    chi += detm::det_log(e2 + 1.0);
+  }
+  return pgo_block_sum(chi, s_red);
+}
+
+// H (block profile, lower triangle) and b: one thread per free vertex gathers its incident edges in adjacency order
+__device__ inline void pgo_build(const PgoGraph& g) {
+  for (int v = threadIdx.x; v < g.n; v += PGO_T) {
+    const int hi = g.hidx[v];
+    if (hi < 0) continue;
+    const int f = g.first[hi];
+    double* Hrow = g.H + g.boff[hi] * 36;
+    for (int q = 0; q < (hi - f + 1) * 36; q++) Hrow[q] = 0.0;
+    double bb[6] = {0, 0, 0, 0, 0, 0};
+    double* Hd = Hrow + (size_t)(hi - f) * 36;
+    for (int a = g.adj_ptr[v]; a < g.adj_ptr[v + 1]; a++) {
+      const int k = g.adj_e[a];
+      const int va = g.ea[k], vb = g.eb[k];
+      const SE3d Xi = load_pose7(g.est + 7 * va), Xj = load_pose7(g.est + 7 * vb), Z = load_pose7(g.Z + 7 * k);
+      double e[6], Ji[6][6], Jj[6][6];
+      pgo_error(Xi, Xj, Z, e);
+      pgo_linearize(Xi, Xj, Z, Ji, Jj);
+      double e2 = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) e2 += e[q] * e[q];
+      const double w = 1.0 / (e2 + 1.0);  // Cauchy rho'
+      const bool is_a = va == v;
+      const double(*Jm)[6] = is_a ? Ji : Jj;   // this vertex's Jacobian
+      const double(*Jo)[6] = is_a ? Jj : Ji;   // the other end's
+      for (int r = 0; r < 6; r++) {
+        double gsum = 0;
+        for (int q = 0; q < 6; q++) gsum += Jm[q][r] * (-e[q] * w);
+        bb[r] += gsum;
+        for (int c = 0; c <= r; c++) {
+          double h = 0;
+          for (int q = 0; q < 6; q++) h += (Jm[q][r] * w) * Jm[q][c];
+          Hd[6 * r + c] += h;
+        }
+      }
+      const int ho = g.hidx[is_a ? vb : va];
+      if (ho >= 0 && ho < hi) {  // block (hi, ho) of the lower triangle: Jm^T w Jo
+        double* Ho = Hrow + (size_t)(ho - f) * 36;
+        for (int r = 0; r < 6; r++)
+          for (int c = 0; c < 6; c++) {
+            double h = 0;
+            for (int q = 0; q < 6; q++) h += (Jm[q][r] * w) * Jo[q][c];
+            Ho[6 * r + c] += h;
+          }
+      }
+    }
+    for (int r = 0; r < 6; r++) g.b[6 * hi + r] = bb[r];
+  }
+}
+
+// wave 0: block-profile Cholesky of H + lambda I into L, then x = (L L^T)^-1 b.  Returns false on a non-positive pivot.
+__device__ inline bool pgo_factor_solve(const PgoGraph& g, double lambda) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane / 6, c = lane - 6 * r;  // lanes 0..35 own entry (r, c) of the current block
+  const bool act = lane < 36;
+  bool ok = true;
+  for (int i = 0; i < g.P && ok; i++) {
+    const int f = g.first[i];
+    const double* Hrow = g.H + g.boff[i] * 36;
+    double* Lrow = g.L + g.boff[i] * 36;
+    for (int j = f; j <= i; j++) {
+      const int fj = g.first[j];
+      const double* Lj = g.L + g.boff[j] * 36;  // block row j: blocks fj..j
+      double s = act ? Hrow[(size_t)(j - f) * 36 + 6 * r + c] : 0.0;
+      if (j == i && act && r == c) s += lambda;
+      if (act) {
+        for (int k = max(f, fj); k < j; k++) {
+          const double* A = Lrow + (size_t)(k - f) * 36 + 6 * r;   // L(i,k)[r][:]
+          const double* Bk = Lj + (size_t)(k - fj) * 36 + 6 * c;   // L(j,k)[c][:]
+#pragma unroll
+          for (int m = 0; m < 6; m++) s -= A[m] * Bk[m];
+        }
+      }
+      if (j < i) {  // X Ljj^T = S, column by column
+        const double* D = Lj + (size_t)(j - fj) * 36;  // Ljj (lower)
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) {
+          const double dcc = D[7 * cc];
+          if (act && c == cc) s = s / dcc;
+          const double xr = __shfl(s, r * 6 + cc, 64);  // X[r][cc]
+          if (act && c > cc) s -= xr * D[6 * c + cc];
+        }
+        if (act) Lrow[(size_t)(j - f) * 36 + 6 * r + c] = s;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+      } else {  // 6x6 Cholesky of the diagonal block (lower triangle, zeros above)
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) {
+          const double d = __shfl(s, cc * 6 + cc, 64);
+          if (!(d > 0) || !isfinite(d)) ok = false;
+          const double l = sqrt(ok ? d : 1.0);
+          if (act && c == cc) s = (r >= cc) ? s / l : 0.0;
+          if (act && c == cc && r == cc) s = l;
+          const double lr = __shfl(s, r * 6 + cc, 64), lc = __shfl(s, c * 6 + cc, 64);  // L[r][cc], L[c][cc]
+          if (act && c > cc && r >= c) s -= lr * lc;
+        }
+        if (act) Lrow[(size_t)(i - f) * 36 + 6 * r + c] = (c <= r) ? s : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+      }
+    }
+  }
+  if (!ok) return false;
+  // forward: y_i = Lii^-1 (b_i - sum_k L(i,k) y_k), kept in x
+  for (int i = 0; i < g.P; i++) {
+    const int f = g.first[i];
+    const double* Lrow = g.L + g.boff[i] * 36;
+    double s = 0;
+    if (lane < 6) {
+      s = g.b[6 * i + lane];
+      for (int k = f; k < i; k++) {
+        const double* A = Lrow + (size_t)(k - f) * 36 + 6 * lane;
+#pragma unroll
+        for (int m = 0; m < 6; m++) s -= A[m] * g.x[6 * k + m];
+      }
+    }
+    const double* D = Lrow + (size_t)(i - f) * 36;
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) {
+      if (lane == cc) s = s / D[7 * cc];
+      const double yc = __shfl(s, cc, 64);
+      if (lane > cc && lane < 6) s -= D[6 * lane + cc] * yc;
+    }
+    if (lane < 6) g.x[6 * i + lane] = s;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+  }
+  // backward: x_i = Lii^-T y_i, then y_k -= L(i,k)^T x_i for the blocks of row i
+  for (int i = g.P - 1; i >= 0; i--) {
+    const int f = g.first[i];
+    const double* Lrow = g.L + g.boff[i] * 36;
+    const double* D = Lrow + (size_t)(i - f) * 36;
+    double s = lane < 6 ? g.x[6 * i + lane] : 0.0;
+#pragma unroll
+    for (int cc = 5; cc >= 0; cc--) {
+      if (lane == cc) s = s / D[7 * cc];
+      const double xc = __shfl(s, cc, 64);
+      if (lane < cc) s -= D[6 * cc + lane] * xc;
+    }
+    if (lane < 6) g.x[6 * i + lane] = s;
+    double xi[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) xi[m] = __shfl(s, m, 64);
+    // lanes = (block within a group of 10, column): y_k[c] -= sum_r L(i,k)[r][c] x_i[r]
+    for (int k0 = f; k0 < i; k0 += 10) {
+      const int k = k0 + lane / 6, cc = lane % 6;
+      if (lane < 60 && k < i) {
+        const double* A = Lrow + (size_t)(k - f) * 36;
+        double acc = g.x[6 * k + cc];
+#pragma unroll
+        for (int m = 0; m < 6; m++) acc -= A[6 * m + cc] * xi[m];
+        g.x[6 * k + cc] = acc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(PGO_T) void k_pgo(const PgoGraph* graphs) {
+  const PgoGraph g = graphs[blockIdx.x];
+  __shared__ double s_red[PGO_T / 64];
+  __shared__ int s_ok;
+  const int t = threadIdx.x;
+  // vertices: T_w_c of the keyframe; measurements: the current relative pose / the verified loop pose
+  for (int v = t; v < g.n; v += PGO_T) store_pose7(g.est + 7 * v, iso_inv(load_pose7(g.T_c_w + 7 * g.vkf[v])));
+  for (int k = t; k < g.E; k += PGO_T) {
+    SE3d Z;
+    if (g.eloop[k] < 0) {
+      const SE3d Ti = load_pose7(g.T_c_w + 7 * g.vkf[g.ea[k]]), Tj = load_pose7(g.T_c_w + 7 * g.vkf[g.eb[k]]);
+      Z = iso_inv(iso_mul(Tj, iso_inv(Ti)));  // sij = (T_c_w(j) T_c_w(i)^-1)^-1
+    } else {
+      Z = iso_inv(load_pose7(g.loop_pose + 7 * g.eloop[k]));
+    }
+    store_pose7(g.Z + 7 * k, Z);
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (g.use_guess && t == 0) {
+    // computeInitialGuess: breadth first from the fixed vertices, neighbours in ascending index (the adjacency lists are sorted)
+    int qh = 0, qt = 0;
+    for (int v = 0; v < g.n; v++) {
+      g.dist[v] = g.fixed[v] ? 0 : -1;
+      if (g.fixed[v]) g.queue[qt++] = v;
+    }
+    while (qh < qt) {
+      const int u = g.queue[qh++];
+      const SE3d Xu = load_pose7(g.est + 7 * u);
+      for (int a = g.adj_ptr[u]; a < g.adj_ptr[u + 1]; a++) {
+        const int k = g.adj_e[a];
+        const int z = g.ea[k] == u ? g.eb[k] : g.ea[k];
+        if (g.dist[z] >= 0) continue;
+        g.dist[z] = g.dist[u] + 1;
+        const SE3d Zk = load_pose7(g.Z + 7 * k);
+        store_pose7(g.est + 7 * z, g.ea[k] == u ? iso_mul(Xu, Zk) : iso_mul(Xu, iso_inv(Zk)));
+        g.queue[qt++] = z;
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  double currentChi = pgo_chi2(g, s_red);
+  const double chi_initial = currentChi;
+  int done = 0;
+  if (g.P > 0 && g.E > 0) {
+    double lambda = 1e-10, ni = 2;
+    for (int iteration = 0; iteration < g.iterations; iteration++) {
+      currentChi = pgo_chi2(g, s_red);
+      pgo_build(g);
+      __threadfence_block();
+      __syncthreads();
+      double rho = 0;
+      int qmax = 0;
+      bool lambda_bad = false;
+      do {
+        for (int q = t; q < 7 * g.n; q += PGO_T) g.bak[q] = g.est[q];
+        if (t < 64) {
+          const bool okf = pgo_factor_solve(g, lambda);
+          if (t == 0) s_ok = okf ? 1 : 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int ok2 = s_ok;
+        double scale = 0;
+        if (ok2) {
+          for (int v = t; v < g.n; v += PGO_T)
+            if (g.hidx[v] >= 0) store_pose7(g.est + 7 * v, iso_mul(load_pose7(g.est + 7 * v), pgo_from_mqt(g.x + 6 * g.hidx[v])));
+          for (int j = t; j < 6 * g.P; j += PGO_T) scale += g.x[j] * (lambda * g.x[j] + g.b[j]);
+        }
+        __threadfence_block();
+        __syncthreads();
+        scale = pgo_block_sum(scale, s_red) + 1e-3;
+        double tempChi = pgo_chi2(g, s_red);
+        if (!ok2) tempChi = 1.7976931348623157e308;
+        rho = (currentChi - tempChi) / scale;
+        if (rho > 0 && isfinite(tempChi)) {
+          double alpha = 1. - detm::det_powi(2 * rho - 1, 3);
+          alpha = fmin(alpha, 2. / 3.);
+          lambda *= fmax(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          for (int q = t; q < 7 * g.n; q += PGO_T) g.est[q] = g.bak[q];
+          __threadfence_block();
+          __syncthreads();
+          if (!isfinite(lambda)) {
+            lambda_bad = true;
+            break;
+          }
+        }
+        qmax++;
+      } while (rho < 0 && qmax < 10);
+      done = iteration + 1;
+      if (qmax == 10 || rho == 0 || lambda_bad) break;
+    }
+  }
+  const double chi_final = pgo_chi2(g, s_red);
+  // write-back: T_c_w = (T_w_c)^-1; drift of the last optimised keyframe Tw1_w2 = (Tw2c * Tcw1)^-1
+  if (t == 0 && g.n > 0) {
+    const int v = g.n - 1;
+    store_pose7(g.drift, iso_inv(iso_mul(load_pose7(g.est + 7 * v), load_pose7(g.T_c_w + 7 * g.vkf[v]))));
+    g.stats[0] = done, g.stats[1] = chi_initial, g.stats[2] = chi_final, g.stats[3] = g.n, g.stats[4] = g.E;
+  }
+  __syncthreads();
+  for (int v = t; v < g.n; v += PGO_T) store_pose7(g.T_c_w + 7 * g.vkf[v], iso_inv(load_pose7(g.est + 7 * v)));
+}
+
 }  // namespace flvis
 
 using namespace flvis;
@@ -300,6 +667,177 @@ int flvis_hip_bow_score(flvis_ctx* ctx, const int* d_q_ids, const double* d_q_va
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_score: bad args");
   k_bow_score<<<(n_db + 3) / 4, 256, 0, ctx->stream>>>(d_q_ids, d_q_vals, d_q_nnz, d_db_ids, d_db_vals, d_db_nnz, vcap, n_db, d_scores);
   CHECK_LAUNCH(ctx, "bow_score");
+  return FLVIS_OK;
+}
+
+// loopClosureOnCovGraphG2ONew for n_graphs independent sequences in one launch.  Host side: the integer bookkeeping of
+// vo_loopclosing.cpp:747-875 (vertex range, fixed flags, edge list) plus the adjacency lists and the block profile of the normal
+// matrix; everything numeric runs in k_pgo.
+int flvis_hip_pgo_loop_closure(flvis_ctx* ctx, int n_graphs, const int* h_n_kf, double* d_T_c_w7, const uint8_t* h_present,
+                               const int* h_n_loops, const int* h_loop_ids, const double* d_loop_pose7, int iterations,
+                               int use_initial_guess, double* d_drift7, double* d_stats5, int* h_ran) {
+  CHECK_CTX(ctx);
+  if (n_graphs <= 0 || !h_n_kf || !d_T_c_w7 || !h_present || !h_n_loops || !h_loop_ids || !d_loop_pose7 || !d_drift7 || !d_stats5 ||
+      !h_ran || iterations < 0)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "pgo_loop_closure: bad args");
+  struct HostGraph {
+    int n = 0, E = 0, P = 0, n_kf = 0;
+    size_t int_off = 0, dbl_off = 0;  // offsets into the packed int / double scratch
+    long long nblk = 0;
+    size_t kf_base = 0, loop_base = 0;
+    int slot = 0;
+  };
+  std::vector<HostGraph> hg;
+  std::vector<int> ints;          // per graph: vkf n | fixed n | hidx n | ea E | eb E | eloop E | adj_ptr n+1 | adj_e 2E | first P | queue n | dist n
+  std::vector<long long> boffs;   // per graph: P + 1
+  std::vector<size_t> boff_off;
+  size_t kf_base = 0, loop_base = 0, dbl_total = 0;
+  for (int gi = 0; gi < n_graphs; gi++) {
+    const int n_kf = h_n_kf[gi], n_loops = h_n_loops[gi];
+    const uint8_t* present = h_present + kf_base;
+    const int* loops = h_loop_ids + 2 * loop_base;
+    h_ran[gi] = 0;
+    HostGraph G;
+    G.n_kf = n_kf;
+    G.kf_base = kf_base;
+    G.loop_base = loop_base;
+    G.slot = gi;
+    kf_base += (size_t)std::max(n_kf, 0);
+    loop_base += (size_t)std::max(n_loops, 0);
+    if (n_kf <= 0 || n_loops <= 0) continue;
+    long long kf_prev = 2LL * n_kf, kf_curr = 0;  // vo_loopclosing.cpp:747-756
+    bool valid = true;
+    for (int k = 0; k < n_loops; k++) {
+      const int a = loops[2 * k], b = loops[2 * k + 1];
+      if (a < 0 || b < 0 || a >= n_kf || b >= n_kf || !present[a] || !present[b]) valid = false;
+      kf_prev = std::min<long long>(kf_prev, a);
+      kf_curr = std::max<long long>(kf_curr, b);
+    }
+    if (!valid || kf_prev > kf_curr) continue;  // (the reference would dereference a missing vertex)
+    std::vector<int> vid((size_t)n_kf, -1), vkf, fixed;
+    for (long long i = kf_prev; i <= kf_curr; i++) {
+      if (!present[i]) continue;
+      bool later_end = false;  // :786-800: the first loop that names i decides
+      for (int k = 0; k < n_loops; k++) {
+        if (loops[2 * k] == i) break;
+        if (loops[2 * k + 1] == i) {
+          later_end = true;
+          break;
+        }
+      }
+      vid[i] = (int)vkf.size();
+      vkf.push_back((int)i);
+      fixed.push_back((!later_end && (i == 0 || i == kf_prev)) ? 1 : 0);
+    }
+    std::vector<int> ea, eb, eloop;
+    for (long long i = kf_prev; i <= kf_curr; i++)
+      for (long long j = i + 1; j <= std::min(kf_curr, i + 5); j++)
+        if (present[i] && present[j]) {
+          ea.push_back(vid[i]);
+          eb.push_back(vid[j]);
+          eloop.push_back(-1);
+        }
+    for (int k = 0; k < n_loops; k++) {
+      ea.push_back(vid[loops[2 * k]]);
+      eb.push_back(vid[loops[2 * k + 1]]);
+      eloop.push_back(k);
+    }
+    const int n = (int)vkf.size(), E = (int)ea.size();
+    std::vector<int> hidx((size_t)n, -1);
+    int P = 0;
+    for (int v = 0; v < n; v++)
+      if (!fixed[v]) hidx[v] = P++;
+    std::vector<std::vector<std::pair<int, int>>> adj((size_t)n);  // (neighbour, edge)
+    for (int k = 0; k < E; k++) {
+      adj[ea[k]].push_back({eb[k], k});
+      adj[eb[k]].push_back({ea[k], k});
+    }
+    std::vector<int> first((size_t)P);
+    for (int i = 0; i < P; i++) first[i] = i;
+    for (int k = 0; k < E; k++) {
+      const int ia = hidx[ea[k]], ib = hidx[eb[k]];
+      if (ia >= 0 && ib >= 0) first[std::max(ia, ib)] = std::min(first[std::max(ia, ib)], std::min(ia, ib));
+    }
+    G.n = n, G.E = E, G.P = P;
+    G.int_off = ints.size();
+    ints.insert(ints.end(), vkf.begin(), vkf.end());
+    ints.insert(ints.end(), fixed.begin(), fixed.end());
+    ints.insert(ints.end(), hidx.begin(), hidx.end());
+    ints.insert(ints.end(), ea.begin(), ea.end());
+    ints.insert(ints.end(), eb.begin(), eb.end());
+    ints.insert(ints.end(), eloop.begin(), eloop.end());
+    int run = 0;
+    for (int v = 0; v < n; v++) {
+      ints.push_back(run);
+      run += (int)adj[v].size();
+    }
+    ints.push_back(run);
+    for (int v = 0; v < n; v++) {
+      std::sort(adj[v].begin(), adj[v].end());
+      for (auto& pr : adj[v]) ints.push_back(pr.second);
+    }
+    ints.insert(ints.end(), first.begin(), first.end());
+    ints.insert(ints.end(), (size_t)2 * n, 0);  // queue, dist
+    boff_off.push_back(boffs.size());
+    long long nb = 0;
+    for (int i = 0; i < P; i++) {
+      boffs.push_back(nb);
+      nb += i - first[i] + 1;
+    }
+    boffs.push_back(nb);
+    G.nblk = nb;
+    G.dbl_off = dbl_total;
+    dbl_total += (size_t)14 * n + (size_t)7 * E + (size_t)72 * nb + (size_t)12 * P + 16;
+    h_ran[gi] = 1;
+    hg.push_back(G);
+  }
+  if (hg.empty()) return FLVIS_OK;
+  hipSetDevice(ctx->device);
+  int* d_ints = (int*)ctx->scratch("pgo_ints", sizeof(int) * ints.size());
+  long long* d_boff = (long long*)ctx->scratch("pgo_boff", sizeof(long long) * boffs.size());
+  double* d_dbl = (double*)ctx->scratch("pgo_dbl", sizeof(double) * dbl_total);
+  PgoGraph* d_graphs = (PgoGraph*)ctx->scratch("pgo_graphs", sizeof(PgoGraph) * hg.size());
+  if (!d_ints || !d_boff || !d_dbl || !d_graphs) return ctx->fail(FLVIS_ERR_HIP, "pgo_loop_closure: device allocation failed");
+  std::vector<PgoGraph> descs(hg.size());
+  for (size_t q = 0; q < hg.size(); q++) {
+    const HostGraph& G = hg[q];
+    PgoGraph& d = descs[q];
+    const int n = G.n, E = G.E, P = G.P;
+    int* ip = d_ints + G.int_off;
+    d.n = n, d.E = E, d.P = P, d.n_kf = G.n_kf, d.iterations = iterations, d.use_guess = use_initial_guess;
+    d.vkf = ip, ip += n;
+    d.fixed = ip, ip += n;
+    d.hidx = ip, ip += n;
+    d.ea = ip, ip += E;
+    d.eb = ip, ip += E;
+    d.eloop = ip, ip += E;
+    d.adj_ptr = ip, ip += n + 1;
+    d.adj_e = ip, ip += 2 * E;
+    d.first = ip, ip += P;
+    d.queue = ip, ip += n;
+    d.dist = ip;
+    d.boff = d_boff + boff_off[q];
+    double* dp = d_dbl + G.dbl_off;
+    d.est = dp, dp += (size_t)7 * n;
+    d.bak = dp, dp += (size_t)7 * n;
+    d.Z = dp, dp += (size_t)7 * E;
+    d.H = dp, dp += (size_t)36 * G.nblk;
+    d.L = dp, dp += (size_t)36 * G.nblk;
+    d.b = dp, dp += (size_t)6 * P;
+    d.x = dp;
+    d.T_c_w = d_T_c_w7 + 7 * G.kf_base;
+    d.loop_pose = d_loop_pose7 + 7 * G.loop_base;
+    d.drift = d_drift7 + 7 * (size_t)G.slot;
+    d.stats = d_stats5 + 5 * (size_t)G.slot;
+  }
+  hipStream_t st = ctx->stream;
+  hipError_t e = hipStreamSynchronize(st);  // (pageable host vectors: plain synchronous copies)
+  if (e == hipSuccess) e = hipMemcpy(d_ints, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_boff, boffs.data(), sizeof(long long) * boffs.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_graphs, descs.data(), sizeof(PgoGraph) * descs.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return ctx->hip_fail(e, "pgo_loop_closure upload");
+  k_pgo<<<(int)hg.size(), PGO_T, 0, st>>>(d_graphs);
+  CHECK_LAUNCH(ctx, "pgo_loop_closure");
   return FLVIS_OK;
 }
 

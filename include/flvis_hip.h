@@ -145,6 +145,17 @@ int flvis_hip_bow_score(flvis_ctx* ctx, const int* d_q_ids, const double* d_q_va
  * logic, as in the reference's pgoProcess thread).  Returns 1 and *kf_prev_idx when there is a candidate, 0 when not. */
 int flvis_loop_candidate(int g_size, const double* h_row, const uint8_t* h_present, int lcKFDist, int lcKFMaxDist, int lcNKFClosest,
                          double minScore, int64_t* kf_prev_idx);
+/* loopClosureOnCovGraphG2ONew (vo_loopclosing.cpp:742-944) for n_graphs independent sequences in one launch (one workgroup per
+ * pose graph): graph g has h_n_kf[g] keyframes with T_c_w (device, 7 doubles each: tx ty tz qx qy qz qw, graphs concatenated, in/out)
+ * and presence flags (host, concatenated; 0 = kf_map_lc[i] == nullptr), h_n_loops[g] recorded loops (host ids: earlier, later
+ * keyframe; device poses: the verified T_later_earlier the reference keeps in loop_poses).  Vertices kf_prev..kf_curr, EdgeSE3 to
+ * the next five keyframes + one per loop, information I, Cauchy kernel, Levenberg with lambda 1e-10, `iterations` (100 in the
+ * reference); use_initial_guess = optimizer.computeInitialGuess() (:883).  Out: the optimised keyframes' T_c_w in place,
+ * d_drift7 [n_graphs][7] = Tw1_w2 of the last optimised keyframe (:899-910), d_stats5 [n_graphs][5] = iterations run, robust chi2
+ * before / after, vertices, edges; h_ran[g] = 1 when graph g was optimised (0: no loop / a loop names an absent keyframe). */
+int flvis_hip_pgo_loop_closure(flvis_ctx* ctx, int n_graphs, const int* h_n_kf, double* d_T_c_w7, const uint8_t* h_present,
+                               const int* h_n_loops, const int* h_loop_ids, const double* d_loop_pose7, int iterations,
+                               int use_initial_guess, double* d_drift7, double* d_stats5, int* h_ran);
 
 /* ---- pipeline-level entry points: F2FTracking + LocalMap for a batch of independent streams ------------------------
  *

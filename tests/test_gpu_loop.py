@@ -89,3 +89,42 @@ def test_orb_to_bow_chain(ctx):
     for i in range(6):
         wi, wv = rv.transform(train[i])
         assert nnz[i] == len(wi) and np.array_equal(ids[i, :nnz[i]], wi) and np.array_equal(vals[i, :nnz[i]], wv), i
+
+
+def test_pose_graph_optimisation_parity(ctx):
+    """loopClosureOnCovGraphG2ONew on the GPU (one workgroup per pose graph, a batch of graphs in one launch) against the CPU
+    oracle: the same graph, the same Levenberg decisions; fp64 with other summation orders (block-profile Cholesky by one wave vs
+    the scalar profile Cholesky of the restatement): optimised poses within 1e-8."""
+    import _pgo_synth as PS
+    from test_oracle_pgo import pgo as ref_pgo
+    cases = [PS.make_loop(3), PS.make_loop(5, n_kf=90, extra_loops=2), PS.make_loop(7, n_kf=40), PS.make_loop(9, n_kf=130, extra_loops=1)]
+    present = [np.ones(len(c["est"]), np.uint8) for c in cases]
+    present[1][[20, 21, 47]] = 0
+    # a graph without loops, and one whose loop names an absent keyframe: both are left alone
+    cases.append(dict(est=cases[0]["est"].copy(), loops=np.zeros((0, 2), np.int32), loop_poses=np.zeros((0, 7))))
+    present.append(np.ones(len(cases[0]["est"]), np.uint8))
+    cases.append(dict(est=cases[2]["est"].copy(), loops=cases[2]["loops"], loop_poses=cases[2]["loop_poses"]))
+    bad = np.ones(len(cases[2]["est"]), np.uint8)
+    bad[cases[2]["loops"][0][1]] = 0
+    present.append(bad)
+    worst = 0.0
+    for guess in (True, False):
+        got, drift, stats, ran = ctx.pgo_loop_closure([c["est"] for c in cases], present, [c["loops"] for c in cases],
+                                                      [c["loop_poses"] for c in cases], use_initial_guess=guess)
+        assert list(ran) == [1, 1, 1, 1, 0, 0]
+        for k, c in enumerate(cases):
+            r, want, wdrift, wstats = ref_pgo(c["est"], present[k], c["loops"], c["loop_poses"], initial_guess=guess)
+            assert r == ran[k]
+            if not r:
+                assert np.array_equal(got[k], c["est"])
+                continue
+            assert stats[k][3] == wstats[3] and stats[k][4] == wstats[4]
+            # (at convergence the chi2 decrease is rounding noise, so the iteration at which Levenberg stops -- rho == 0 or ten failed
+            # trials -- is not comparable; the optimum is)
+            assert stats[k][0] >= 3 and wstats[0] >= 3, (k, stats[k], wstats)
+            assert abs(stats[k][1] - wstats[1]) < 1e-9 * max(1.0, wstats[1]) and abs(stats[k][2] - wstats[2]) < 1e-9
+            assert np.abs(got[k] - want).max() < 1e-8, (k, guess, np.abs(got[k] - want).max())
+            assert np.abs(drift[k] - wdrift).max() < 1e-8
+            assert wstats[2] < 0.2 * wstats[1]
+            worst = max(worst, np.abs(got[k] - want).max())
+    print("worst pose difference vs the oracle: %.3g" % worst)
