@@ -672,8 +672,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i) + 1], strm)
   PB(19, st);  // the whole main-stream chain of this frame: per-frame GPU latency (p50/p99 in bench.py)
   PB(0, st);
-  launch_imu_feed(st, p);
-  launch_frame_begin(st, p, L->d_time);
+  launch_frame_head(st, p, L->d_time);  // the staged IMU samples, then frame_begin
   if (pl->feedback_used) launch_apply_correction(st, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
   PE(0, st);
   if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {

@@ -56,18 +56,48 @@ FD void track_fail(StreamState& st) {  // f2f_tracking.cpp:235-247 / 257-269
 }
 
 // ------------------------------------------------------------------------------------------------ IMU
-__global__ void k_imu_feed(Pipe p) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= p.S) return;
+// the staged samples of stream s, in order.  Once the filter is initialised the samples are integrated on REGISTER-resident state
+// (the previous state, the ring cursor, the keyframe preintegration are loaded once and written back once; only the new ring
+// entries are stored) -- per sample the same arithmetic as vi_imu_feed, without a store -> load round trip through HBM per sample
+__device__ inline void imu_feed_dev(const Pipe& p, int s) {
   StreamState& st = p.st[s];
   ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
   int n = p.n_imu[s];
   if (n > IMU_MAX) n = IMU_MAX;
   const double* in = p.imu_in + (size_t)s * IMU_MAX * 7;
-  for (int i = 0; i < n; i++)
+  int i = 0;
+  for (; i < n && !st.vi_initialized; i++)  // start-up: attitude initialisation, sample by sample
     vi_imu_feed(p.cam, st, ring, in[7 * i], V3{in[7 * i + 1], in[7 * i + 2], in[7 * i + 3]},
                 V3{in[7 * i + 4], in[7 * i + 5], in[7 * i + 6]});
+  if (i < n) {
+    const V3 acc_bias = ld3(st.acc_bias), gyro_bias = ld3(st.gyro_bias);
+    int head = st.vi_head, count = st.vi_count;
+    MotionState prev = ring.back();
+    Q4 kdq{st.kf_dq[0], st.kf_dq[1], st.kf_dq[2], st.kf_dq[3]};
+    double kdt = st.kf_dt;
+    for (; i < n; i++) {
+      MotionState cur;
+      vi_propagate(p.cam, prev, in[7 * i], V3{in[7 * i + 1], in[7 * i + 2], in[7 * i + 3]},
+                   V3{in[7 * i + 4], in[7 * i + 5], in[7 * i + 6]}, acc_bias, gyro_bias, cur, kdq, kdt);
+      ring.base[(head + count) % VI_QUEUE] = cur;  // ViRing::push_back on the local cursor
+      count++;
+      if (count >= VI_QUEUE) {
+        head = (head + 1) % VI_QUEUE;
+        count--;
+      }
+      prev = cur;
+    }
+    st.vi_head = head;
+    st.vi_count = count;
+    st.kf_dq[0] = kdq.w, st.kf_dq[1] = kdq.x, st.kf_dq[2] = kdq.y, st.kf_dq[3] = kdq.z;
+    st.kf_dt = kdt;
+  }
   p.n_imu[s] = 0;
+}
+__global__ void k_imu_feed(Pipe p) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.S) return;
+  imu_feed_dev(p, s);
 }
 
 // pose_records.push_back(...) (+ pop_front once 1000 entries are reached on a tracking frame, f2f_tracking.cpp:334-337)
@@ -159,12 +189,22 @@ __global__ __launch_bounds__(AC_T) void k_apply_correction(Pipe p) {
 }
 
 // ------------------------------------------------------------------------------------------------ frame begin
+__device__ inline void frame_begin_dev(const Pipe& p, int s, double time);
 __global__ void k_frame_begin(Pipe p, const double* __restrict__ frame_time) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= p.S) return;
+  frame_begin_dev(p, s, frame_time[s]);
+}
+// the head of a frame in one launch: the staged IMU samples (F2FTracking::imu_feed), then the frame set-up
+__global__ void k_frame_head(Pipe p, const double* __restrict__ frame_time) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.S) return;
+  imu_feed_dev(p, s);
+  frame_begin_dev(p, s, frame_time[s]);
+}
+__device__ inline void frame_begin_dev(const Pipe& p, int s, double time) {
   StreamState& st = p.st[s];
   ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
-  const double time = frame_time[s];
   st.frameCount++;
   st.cur ^= 1;
   const int c = st.cur;
@@ -1446,6 +1486,9 @@ void launch_imu_feed(hipStream_t st, const Pipe& p) {
 }
 void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time) {
   hipLaunchKernelGGL(k_frame_begin, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time);
+}
+void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time) {
+  hipLaunchKernelGGL(k_frame_head, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time);
 }
 void launch_apply_correction(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_apply_correction, dim3(p.S), dim3(AC_T), 0, st, p);

@@ -64,6 +64,7 @@ struct Pipe {
 
 void launch_imu_feed(hipStream_t st, const Pipe& p);
 void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time);
+void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time);  // imu_feed + frame_begin in one launch
 void launch_apply_correction(hipStream_t st, const Pipe& p);
 void launch_track_prepare(hipStream_t st, const Pipe& p);
 void launch_track_collect(hipStream_t st, const Pipe& p);

@@ -72,6 +72,29 @@ FD void madgwick_feedback(Q4 q_prev, V3 acc, double acc_norm, double gain, Q4& q
   qdot.z -= gain * s3;
 }
 
+// VIMOTION::viIMUPropagation (vi_motion.cpp:78-100) on values: the state after one sample from the state before it, plus the gyro
+// rotation preintegration since the last keyframe (an addition, see KeyFrameDev::imu_dq)
+__device__ inline void vi_propagate(const CamParams& cam, const MotionState& s_prev, double t, V3 acc_raw, V3 gyro_raw, V3 acc_bias,
+                                    V3 gyro_bias, MotionState& s_new, Q4& kf_dq, double& kf_dt) {
+  const double g = 9.81;
+  const V3 acc = acc_raw - acc_bias, gyro = gyro_raw - gyro_bias;
+  const double dt = t - s_prev.t;
+  const Q4 q_prev = ms_q(s_prev);
+  const M3 R_prev = q_to_mat(q_prev);
+  const Q4 omega{0, gyro.x, gyro.y, gyro.z};
+  Q4 qdot = scalar_multi_q(0.5f, q1_multi_q2(q_prev, omega));
+  const double acc_norm = norm(acc);
+  if ((acc_norm - g) < 0.3) madgwick_feedback(q_prev, acc, acc_norm, cam.vi_para[0], qdot);
+  ms_set_q(s_new, q_normalized(q_plus_q(q_prev, scalar_multi_q((float)dt, qdot))));
+  st3(s_new.pos, ld3(s_prev.pos) + ld3(s_prev.vel) * dt);
+  st3(s_new.vel, ld3(s_prev.vel) + ((R_prev * acc) - V3{0, 0, -g}) * dt);
+  st3(s_new.acc, acc_raw);
+  st3(s_new.gyro, gyro_raw);
+  s_new.t = t;
+  kf_dq = q_normalized(q_mul(kf_dq, q_exp(gyro * dt)));
+  kf_dt += dt;
+}
+
 // F2FTracking::imu_feed for one sample (f2f_tracking.cpp:46-57)
 __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const ViRing& ring, double t, V3 acc_raw,
                                    V3 gyro_raw) {
@@ -106,25 +129,12 @@ __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const 
       if (ring.size() > 30) st.vi_initialized = 1;
     }
   } else {
-    MotionState s_prev = ring.back(), s_new;
-    double dt = t - s_prev.t;
-    Q4 q_prev = ms_q(s_prev);
-    M3 R_prev = q_to_mat(q_prev);
-    Q4 omega{0, gyro.x, gyro.y, gyro.z};
-    Q4 qdot = scalar_multi_q(0.5f, q1_multi_q2(q_prev, omega));
-    double acc_norm = norm(acc);
-    if ((acc_norm - g) < 0.3) madgwick_feedback(q_prev, acc, acc_norm, cam.vi_para[0], qdot);
-    ms_set_q(s_new, q_normalized(q_plus_q(q_prev, scalar_multi_q((float)dt, qdot))));
-    st3(s_new.pos, ld3(s_prev.pos) + ld3(s_prev.vel) * dt);
-    st3(s_new.vel, ld3(s_prev.vel) + ((R_prev * acc) - V3{0, 0, -g}) * dt);
-    st3(s_new.acc, acc_raw);
-    st3(s_new.gyro, gyro_raw);
-    s_new.t = t;
-    {  // (addition) gyro rotation preintegration since the last keyframe, for the IMU factor of the window BA
-      Q4 dq = q_normalized(q_mul(Q4{st.kf_dq[0], st.kf_dq[1], st.kf_dq[2], st.kf_dq[3]}, q_exp(gyro * dt)));
-      st.kf_dq[0] = dq.w, st.kf_dq[1] = dq.x, st.kf_dq[2] = dq.y, st.kf_dq[3] = dq.z;
-      st.kf_dt += dt;
-    }
+    MotionState s_new;
+    Q4 kdq{st.kf_dq[0], st.kf_dq[1], st.kf_dq[2], st.kf_dq[3]};
+    double kdt = st.kf_dt;
+    vi_propagate(cam, ring.back(), t, acc_raw, gyro_raw, ld3(st.acc_bias), ld3(st.gyro_bias), s_new, kdq, kdt);
+    st.kf_dq[0] = kdq.w, st.kf_dq[1] = kdq.x, st.kf_dq[2] = kdq.y, st.kf_dq[3] = kdq.z;
+    st.kf_dt = kdt;
     ring.push_back(s_new);
   }
 }
