@@ -249,9 +249,6 @@ def main():
     if args.stub:
         return run_stub(args, rank, world)
 
-    # the pipeline uses several HIP streams per tracker context; with the default of 4 hardware queues the long local-map
-    # kernels share a queue with the front-end chain (must be set before the HIP runtime initialises)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
