@@ -278,6 +278,24 @@ class Context:
                                                   _ptr(db_nnz), vcap, m, _ptr(scores)), "bow_score")
         return scores
 
+    def pnp_ransac(self, p3d, p2d, count, K4, seeds, iterations=100, reproj_px=2.0, confidence=0.99):
+        """flvis_hip_pnp_ransac: p3d float32 [n,cap,3], p2d float32 [n,cap,2], count int32 [n] (device) -> (pose7 [n,7], mask [n,cap],
+        n_inliers [n])."""
+        import numpy as np
+        import torch
+        p3d, p2d = p3d.contiguous(), p2d.contiguous()
+        n, cap, _ = p3d.shape
+        K = np.ascontiguousarray(K4, np.float64)
+        sd = np.ascontiguousarray(seeds, np.uint64)
+        assert len(sd) == n and len(K) == 4
+        pose = torch.zeros((n, 7), dtype=torch.float64, device=p3d.device)
+        mask = torch.zeros((n, cap), dtype=torch.uint8, device=p3d.device)
+        ninl = torch.zeros((n,), dtype=torch.int32, device=p3d.device)
+        self._check(self._lib.flvis_hip_pnp_ransac(self._h, _ptr(p3d), _ptr(p2d), _ptr(count), cap, n, _P(K, C.c_double), int(iterations),
+                                                   C.c_double(reproj_px), C.c_double(confidence), _P(sd, C.c_uint64), _ptr(pose),
+                                                   _ptr(mask), _ptr(ninl)), "pnp_ransac")
+        return pose, mask, ninl
+
     def pgo_loop_closure(self, T_c_w_list, present_list, loops_list, loop_poses_list, iterations=100, use_initial_guess=True):
         """flvis_hip_pgo_loop_closure for a batch of pose graphs (lists of per-graph numpy arrays: T_c_w [n,7], present [n], loops
         [m,2], loop poses [m,7]).  Returns (list of optimised T_c_w arrays, drift [g,7], stats [g,5], ran [g])."""

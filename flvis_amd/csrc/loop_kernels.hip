@@ -25,6 +25,7 @@
 #include "ctx.hpp"
 #include "dev_common.hpp"
 #include "dev_math.hpp"
+#include "track_kernels.hpp"
 
 namespace flvis {
 
@@ -667,6 +668,29 @@ int flvis_hip_bow_score(flvis_ctx* ctx, const int* d_q_ids, const double* d_q_va
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_score: bad args");
   k_bow_score<<<(n_db + 3) / 4, 256, 0, ctx->stream>>>(d_q_ids, d_q_vals, d_q_nnz, d_db_ids, d_db_vals, d_db_nnz, vcap, n_db, d_scores);
   CHECK_LAUNCH(ctx, "bow_score");
+  return FLVIS_OK;
+}
+
+// isLoopClosureKF's geometric check (vo_loopclosing.cpp:660-686) for n_sets candidate pairs: solvePnPRansac on the matched
+// (3-D point of the earlier keyframe, pixel in the current keyframe) correspondences -- the tracker's solver (track_kernels.hip),
+// P3P hypotheses, on caller arrays.
+int flvis_hip_pnp_ransac(flvis_ctx* ctx, const float* d_p3d, const float* d_p2d, const int* d_count, int cap, int n_sets, const double* h_K4,
+                         int iterations, double reproj_px, double confidence, const uint64_t* h_seeds, double* d_pose7,
+                         uint8_t* d_inlier_mask, int* d_n_inliers) {
+  CHECK_CTX(ctx);
+  if (!d_p3d || !d_p2d || !d_count || !h_K4 || !h_seeds || !d_pose7 || !d_inlier_mask || !d_n_inliers || cap <= 0 || n_sets <= 0 ||
+      iterations <= 0 || !(reproj_px > 0) || !(confidence > 0 && confidence < 1))
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "pnp_ransac: bad args");
+  if (cap > pnp_ransac_max_points()) return ctx->fail(FLVIS_ERR_CAPACITY, "pnp_ransac: at most 1024 correspondences per set");
+  hipSetDevice(ctx->device);
+  unsigned long long* seeds = (unsigned long long*)ctx->scratch("pnp_seeds", sizeof(unsigned long long) * (size_t)n_sets);
+  if (!seeds) return ctx->fail(FLVIS_ERR_HIP, "pnp_ransac: scratch allocation failed");
+  hipError_t e = hipMemcpyAsync(seeds, h_seeds, sizeof(unsigned long long) * (size_t)n_sets, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (h_seeds is pageable caller memory)
+  if (e != hipSuccess) return ctx->hip_fail(e, "pnp_ransac seeds");
+  launch_pnp_ransac_sets(ctx->stream, d_p3d, d_p2d, d_count, cap, n_sets, h_K4, 0, nullptr, seeds, iterations, reproj_px, confidence,
+                         d_pose7, d_inlier_mask, d_n_inliers);
+  CHECK_LAUNCH(ctx, "pnp_ransac");
   return FLVIS_OK;
 }
 

@@ -556,65 +556,57 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
 // ------------------------------------------------------------------------------------------------ PnP RANSAC
 // cv::solvePnPRansac(p3d, p2d, K_rect, 0, r, t, false, 100, 3.0, 0.99, inliers, ITERATIVE|P3P) control flow; hypotheses
 // by Grunert P3P (first 3 sample points, the rest disambiguate), Gauss-Newton refinement on the inliers.
+// cv::solvePnPRansac(p3d, p2d, K_rect, 0, r, t, false, iterations, reprojErr, confidence, inliers, ITERATIVE|P3P) control flow;
+// hypotheses by Grunert P3P (first 3 sample points, the rest disambiguate), Gauss-Newton refinement on the inliers.  The core works on
+// correspondences staged in LDS by the caller (the tracker's kernel gathers a frame's landmarks; the standalone kernel of the loop
+// closing's geometric check loads caller arrays) and is entered by the WHOLE workgroup; only wave 0 returns with the result.
 constexpr int RP_T = 512;
-__global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
-  const int s = blockIdx.x;
-  StreamState& st = p.st[s];
-  if (st.phase != PH_TRACK || !st.ok) return;
+constexpr int PNP_GN_ROW = 29;
+struct PnpShared {
+  float* s2d;            // [n][2]
+  float* s3d;            // [n][3]
+  unsigned char* smask;  // [n] out: inlier mask of the winning model
+  int* hcnt;             // [64]
+  double (*hpose)[12];   // [64]
+  int* ctl;              // [4]
+  double* bpose;         // [12]
+  double* gterms;        // [64 * PNP_GN_ROW]
+  double* gn;            // [32]
+};
+template <bool PROF>
+__device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np, const bool iterative, const SE3d guess, const double fx,
+                                                const double fy, const double cx, const double cy, const unsigned long long seed,
+                                                const int max_iters, const float t2, const double conf, long long* prof,
+                                                long long& tlast_, SE3d& T, int& inliers) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#ifdef FLVIS_RANSAC_PROF
-  long long tlast_ = (long long)wall_clock64();
-  if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[32 + 7], 1ull);
-#endif
-  const int cur = st.cur;
-  Landmark* to = lm_ptr(p, cur, s);
-  const int nl = st.n_lm[cur];
-  __shared__ float s2d[NMAX * 2], s3d[NMAX * 3];
-  __shared__ short sidx[NMAX];
-  __shared__ unsigned char smask[NMAX];
-  __shared__ int hcnt[64];
-  __shared__ double hpose[64][12];
-  __shared__ int ctl[4];
-  __shared__ double bpose[12];
-  __shared__ int snp;
-  // gather (has3d && inlier) in order (wave 0)
-  if (wv == 0) {
-    int np0 = 0;
-    for (int base = 0; base < nl; base += 64) {
-      int i = base + lane;
-      bool sel = i < nl && to[i].has3d && to[i].inlier;
-      unsigned long long b = __ballot(sel);
-      if (sel) {
-        int k = np0 + lane_prefix(b);
-        s2d[2 * k] = (float)to[i].p2u[0];
-        s2d[2 * k + 1] = (float)to[i].p2u[1];
-        s3d[3 * k] = (float)to[i].p3w[0];
-        s3d[3 * k + 1] = (float)to[i].p3w[1];
-        s3d[3 * k + 2] = (float)to[i].p3w[2];
-        sidx[k] = (short)i;
-      }
-      np0 += __popcll(b);
-    }
-    if (lane == 0) {
-      snp = np0;
-      ctl[0] = 100;
-      ctl[1] = 0;
-      ctl[2] = -1;
-    }
+  float* const s2d = sh.s2d;
+  float* const s3d = sh.s3d;
+  unsigned char* const smask = sh.smask;
+  int* const hcnt = sh.hcnt;
+  double(*const hpose)[12] = sh.hpose;
+  int* const ctl = sh.ctl;
+  double* const bpose = sh.bpose;
+  double* const gterms = sh.gterms;
+  double* const gn = sh.gn;
+#define PNP_PROF(i)                                                                             \
+  do {                                                                                          \
+    if (PROF && threadIdx.x == 0 && prof) {                                                     \
+      long long now_ = (long long)wall_clock64();                                               \
+      atomicAdd((unsigned long long*)&prof[i], (unsigned long long)(now_ - tlast_));            \
+      tlast_ = now_;                                                                            \
+    }                                                                                           \
+  } while (0)
+  if (tid == 0) {
+    ctl[0] = max_iters;
+    ctl[1] = 0;
+    ctl[2] = -1;
   }
   __syncthreads();
-  const int np = snp;
-  const bool iterative = st.use_guess != 0;
   const int modelPoints = iterative ? 5 : 4;
-  const double fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
-  const unsigned long long seed = mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[cur] + 1));
-  const float t2 = 9.0f;
-  RPROF(32, 0);
+  PNP_PROF(0);
   if (np >= modelPoints) {
     for (int base = 0; base < ctl[0]; base += 64) {
-#ifdef FLVIS_RANSAC_PROF
-      if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[32 + 6], 1ull);
-#endif
+      if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[6], 1ull);
       if (wv == 0) {  // hypotheses of this batch: P3P on the first 3 sample points, the rest disambiguate
         const int iter = base + lane;
         int cnt = -1;  // -1: no model / beyond niters, -2: subset impossible, -3: model in hpose[lane], to be scored
@@ -677,7 +669,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
         hcnt[lane] = cnt;
       }
       __syncthreads();
-      RPROF(32, 1);
+      PNP_PROF(1);
       for (int hy = wv; hy < 64; hy += RP_T / 64) {  // score the models: lanes stride the correspondences
         if (hcnt[hy] != -3) continue;
         M3 R;
@@ -702,7 +694,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
         if (lane == 0) hcnt[hy] = good;
       }
       __syncthreads();
-      RPROF(32, 2);
+      PNP_PROF(2);
       if (tid == 0) {
         int niters = ctl[0], maxGood = ctl[1];
         for (int k = 0; k < 64; k++) {
@@ -717,7 +709,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
             maxGood = good;
             ctl[2] = base + k;
             for (int j = 0; j < 12; j++) bpose[j] = hpose[k][j];
-            niters = ransac_update_num_iters(0.99, (double)(np - good) / np, modelPoints, niters);
+            niters = ransac_update_num_iters(conf, (double)(np - good) / np, modelPoints, niters);
           }
         }
         ctl[0] = niters;
@@ -726,11 +718,11 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
       __syncthreads();
     }
   }
-  RPROF(32, 3);
+  PNP_PROF(3);
   if (wv != 0) return;  // mask + final refinement: one wave
-  SE3d T = iterative ? load_pose7(st.guess) : se3_identity();
+  T = iterative ? guess : se3_identity();
   if (iterative) T = se3_from_mat(q_to_mat(T.q), T.t);
-  int inliers = 0;
+  inliers = 0;
   if (ctl[2] >= 0) {
     M3 R;
 #pragma unroll
@@ -750,9 +742,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
     // Gauss-Newton refinement on the inliers (stand-in for OpenCV's final solvePnP).  The 21 + 6 normal-equation sums are
     // SEQUENTIAL sums over the inliers in index order (as the CPU restatement adds them): lane l computes the terms of
     // correspondence 64 c + l into an LDS row, lanes 0..26 then each add one column of the chunk in order.
-    constexpr int GN_ROW = 29;
-    __shared__ double gterms[64 * GN_ROW];
-    __shared__ double gn[32];
+    constexpr int GN_ROW = PNP_GN_ROW;
     SE3d Tb = g2o_from_mat(R, t);
     for (int it = 0; it < 10; it++) {
       double sum = 0;
@@ -817,6 +807,64 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   } else {
     for (int i = lane; i < np; i += 64) smask[i] = 0;
   }
+#undef PNP_PROF
+}
+
+__global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
+  const int s = blockIdx.x;
+  StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK || !st.ok) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  long long tlast_ = 0;
+#ifdef FLVIS_RANSAC_PROF
+  constexpr bool kProf = true;
+  tlast_ = (long long)wall_clock64();
+  if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[32 + 7], 1ull);
+#else
+  constexpr bool kProf = false;
+#endif
+  const int cur = st.cur;
+  Landmark* to = lm_ptr(p, cur, s);
+  const int nl = st.n_lm[cur];
+  __shared__ float s2d[NMAX * 2], s3d[NMAX * 3];
+  __shared__ short sidx[NMAX];
+  __shared__ unsigned char smask[NMAX];
+  __shared__ int hcnt[64];
+  __shared__ double hpose[64][12];
+  __shared__ int ctl[4];
+  __shared__ double bpose[12];
+  __shared__ double gterms[64 * PNP_GN_ROW];
+  __shared__ double gn[32];
+  __shared__ int snp;
+  // gather (has3d && inlier) in order (wave 0)
+  if (wv == 0) {
+    int np0 = 0;
+    for (int base = 0; base < nl; base += 64) {
+      int i = base + lane;
+      bool sel = i < nl && to[i].has3d && to[i].inlier;
+      unsigned long long b = __ballot(sel);
+      if (sel) {
+        int k = np0 + lane_prefix(b);
+        s2d[2 * k] = (float)to[i].p2u[0];
+        s2d[2 * k + 1] = (float)to[i].p2u[1];
+        s3d[3 * k] = (float)to[i].p3w[0];
+        s3d[3 * k + 1] = (float)to[i].p3w[1];
+        s3d[3 * k + 2] = (float)to[i].p3w[2];
+        sidx[k] = (short)i;
+      }
+      np0 += __popcll(b);
+    }
+    if (lane == 0) snp = np0;
+  }
+  __syncthreads();
+  const int np = snp;
+  SE3d T;
+  int inliers = 0;
+  // solvePnPRansac(..., 100, 3.0, 0.99, ...) of LKORBTracking::tracking (lkorb_tracking.cpp:170-177)
+  pnp_ransac_core<kProf>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, bpose, gterms, gn}, np, st.use_guess != 0, load_pose7(st.guess),
+                         p.cam.fx, p.cam.fy, p.cam.cx, p.cam.cy, mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[cur] + 1)),
+                         100, 9.0f, 0.99, p.counters ? p.counters + 32 : nullptr, tlast_, T, inliers);
+  if (wv != 0) return;
   __syncthreads();
   for (int i = lane; i < np; i += 64)
     if (smask[i] == 0) to[sidx[i]].inlier = 0;  // CameraFrame::updateLMState
@@ -827,6 +875,50 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
     if (inliers < 10) st.ok = 0;
   }
   RPROF(32, 4);
+}
+
+// The same solver on caller-supplied correspondences: the geometric check of the loop closing, isLoopClosureKF
+// (vo_loopclosing.cpp:660-686: solvePnPRansac(p3d, p2d, K, Mat(), r, t, false, 100, 2.0, 0.99, inliers, SOLVEPNP_P3P)); one
+// workgroup per correspondence set.
+constexpr int PNP_MAXN = 1024;
+__global__ __launch_bounds__(RP_T) void k_pnp_ransac_sets(const float* __restrict__ p3d, const float* __restrict__ p2d,
+                                                          const int* __restrict__ count, int cap, double fx, double fy, double cx, double cy,
+                                                          int iterative, const double* __restrict__ guess7,
+                                                          const unsigned long long* __restrict__ seeds, int max_iters, float t2, double conf,
+                                                          double* __restrict__ pose7, unsigned char* __restrict__ mask,
+                                                          int* __restrict__ n_inliers) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ float s2d[PNP_MAXN * 2], s3d[PNP_MAXN * 3];
+  __shared__ unsigned char smask[PNP_MAXN];
+  __shared__ int hcnt[64];
+  __shared__ double hpose[64][12];
+  __shared__ int ctl[4];
+  __shared__ double bpose[12];
+  __shared__ double gterms[64 * PNP_GN_ROW];
+  __shared__ double gn[32];
+  int np = count[b];
+  np = np < 0 ? 0 : (np > cap ? cap : np);
+  for (int i = tid; i < np; i += RP_T) {
+    s2d[2 * i] = p2d[((size_t)b * cap + i) * 2];
+    s2d[2 * i + 1] = p2d[((size_t)b * cap + i) * 2 + 1];
+    s3d[3 * i] = p3d[((size_t)b * cap + i) * 3];
+    s3d[3 * i + 1] = p3d[((size_t)b * cap + i) * 3 + 1];
+    s3d[3 * i + 2] = p3d[((size_t)b * cap + i) * 3 + 2];
+  }
+  __syncthreads();
+  SE3d T;
+  int inliers = 0;
+  long long tl = 0;
+  pnp_ransac_core<false>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, bpose, gterms, gn}, np, iterative != 0,
+                         iterative ? load_pose7(guess7 + 7 * b) : se3_identity(), fx, fy, cx, cy, seeds[b], max_iters, t2, conf, nullptr, tl, T,
+                         inliers);
+  if (wv != 0) return;
+  __syncthreads();
+  for (int i = lane; i < cap; i += 64) mask[(size_t)b * cap + i] = i < np ? smask[i] : 0;
+  if (lane == 0) {
+    store_pose7(pose7 + 7 * b, T);  // (identity / the guess when no model was found, n_inliers 0)
+    n_inliers[b] = inliers;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ after tracking
@@ -1499,6 +1591,13 @@ void launch_track_prepare(hipStream_t st, const Pipe& p) {
 void launch_track_collect(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_track_collect, dim3(p.S), dim3(64), 0, st, p); }
 void launch_ransac_f(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_f, dim3(p.S), dim3(RF_T), 0, st, p); }
 void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_pnp, dim3(p.S), dim3(RP_T), 0, st, p); }
+int pnp_ransac_max_points() { return PNP_MAXN; }
+void launch_pnp_ransac_sets(hipStream_t st, const float* p3d, const float* p2d, const int* count, int cap, int n_sets, const double* K4,
+                            int iterative, const double* guess7, const unsigned long long* seeds, int max_iters, double reproj_px,
+                            double conf, double* pose7, unsigned char* mask, int* n_inliers) {
+  hipLaunchKernelGGL(k_pnp_ransac_sets, dim3(n_sets), dim3(RP_T), 0, st, p3d, p2d, count, cap, K4[0], K4[1], K4[2], K4[3], iterative,
+                     guess7, seeds, max_iters, (float)(reproj_px * reproj_px), conf, pose7, mask, n_inliers);
+}
 void launch_track_post(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_track_post, dim3((p.S + 63) / 64), dim3(64), 0, st, p);
 }

@@ -145,6 +145,16 @@ int flvis_hip_bow_score(flvis_ctx* ctx, const int* d_q_ids, const double* d_q_va
  * logic, as in the reference's pgoProcess thread).  Returns 1 and *kf_prev_idx when there is a candidate, 0 when not. */
 int flvis_loop_candidate(int g_size, const double* h_row, const uint8_t* h_present, int lcKFDist, int lcKFMaxDist, int lcNKFClosest,
                          double minScore, int64_t* kf_prev_idx);
+/* the geometric check of isLoopClosureKF (vo_loopclosing.cpp:660-686): cv::solvePnPRansac(p3d, p2d, K, Mat(), r, t, false,
+ * iterations = 100, reprojectionError = 2.0, confidence = 0.99, inliers, SOLVEPNP_P3P) for n_sets independent correspondence sets
+ * (one workgroup each): d_p3d [n_sets][cap][3] / d_p2d [n_sets][cap][2] float (what the reference casts to), d_count [n_sets]
+ * (cap <= 1024), h_K4 = fx fy cx cy, h_seeds: one 64-bit seed of the sample generator per set.  Out: d_pose7 [n_sets][7]
+ * (tx ty tz qx qy qz qw of T_c_w; identity when no model was found), d_inlier_mask [n_sets][cap], d_n_inliers [n_sets] (the caller
+ * applies the acceptance rule of :677-686).  The tracker's solver on caller arrays: Grunert P3P hypotheses on a counter RNG + ten
+ * Gauss-Newton steps on the inliers (inlier sets are statistically, not bitwise, OpenCV's). */
+int flvis_hip_pnp_ransac(flvis_ctx* ctx, const float* d_p3d, const float* d_p2d, const int* d_count, int cap, int n_sets, const double* h_K4,
+                         int iterations, double reproj_px, double confidence, const uint64_t* h_seeds, double* d_pose7,
+                         uint8_t* d_inlier_mask, int* d_n_inliers);
 /* loopClosureOnCovGraphG2ONew (vo_loopclosing.cpp:742-944) for n_graphs independent sequences in one launch (one workgroup per
  * pose graph): graph g has h_n_kf[g] keyframes with T_c_w (device, 7 doubles each: tx ty tz qx qy qz qw, graphs concatenated, in/out)
  * and presence flags (host, concatenated; 0 = kf_map_lc[i] == nullptr), h_n_loops[g] recorded loops (host ids: earlier, later

@@ -128,3 +128,100 @@ def test_pose_graph_optimisation_parity(ctx):
             assert wstats[2] < 0.2 * wstats[1]
             worst = max(worst, np.abs(got[k] - want).max())
     print("worst pose difference vs the oracle: %.3g" % worst)
+
+
+def test_pnp_ransac_sets_parity(ctx):
+    """flvis_hip_pnp_ransac (the geometric check of isLoopClosureKF: solvePnPRansac P3P, 100 iterations, 2.0 px, 0.99) against the
+    CPU oracle's solver on the same correspondences and seeds: the same winning hypothesis, the same inlier mask, the same refined pose
+    bit for bit (it is the tracker's solver, whose sums run in the oracle's order)."""
+    import torch
+    import _geom as G
+    rng = np.random.default_rng(8)
+    K4 = np.array([384.0, 385.0, 320.0, 240.0])
+    cap, sets = 700, []
+    for n, outl in ((650, 0.3), (120, 0.1), (40, 0.5), (3, 0.0), (0, 0.0), (700, 0.6)):
+        R = G.rodrigues(rng.normal(0, 0.3, 3))
+        t = rng.normal(0, 0.5, 3)
+        P = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(2, 8, n)], 1)
+        X = P @ R.T + t
+        uv = np.stack([K4[0] * X[:, 0] / X[:, 2] + K4[2], K4[1] * X[:, 1] / X[:, 2] + K4[3]], 1) + rng.normal(0, 0.4, (n, 2))
+        bad = rng.random(n) < outl
+        uv[bad] = np.stack([rng.uniform(0, 640, bad.sum()), rng.uniform(0, 480, bad.sum())], 1)
+        sets.append((P.astype(np.float32), uv.astype(np.float32), R, t, bad))
+    p3 = np.zeros((len(sets), cap, 3), np.float32)
+    p2 = np.zeros((len(sets), cap, 2), np.float32)
+    cnt = np.zeros(len(sets), np.int32)
+    for k, (P, uv, _, _, _) in enumerate(sets):
+        p3[k, :len(P)], p2[k, :len(P)], cnt[k] = P, uv, len(P)
+    seeds = np.array([0x1234 + 77 * k for k in range(len(sets))], np.uint64)
+    pose, mask, ninl = ctx.pnp_ransac(torch.from_numpy(p3).cuda(), torch.from_numpy(p2).cuda(), torch.from_numpy(cnt).cuda(), K4, seeds)
+    pose, mask, ninl = pose.cpu().numpy(), mask.cpu().numpy(), ninl.cpu().numpy()
+    for k, (P, uv, R, t, bad) in enumerate(sets):
+        n_want, pose_want, mask_want = O.solve_pnp_ransac(P, uv, K4, iterative=False, iterations=100, reproj=2.0, conf=0.99, seed=int(seeds[k]))
+        assert ninl[k] == n_want, (k, ninl[k], n_want)
+        assert np.array_equal(mask[k, :len(P)], mask_want) and not mask[k, len(P):].any(), k
+        assert np.array_equal(pose[k], pose_want), (k, pose[k] - pose_want)
+        if len(P) >= 40:
+            Rg, tg = G.pose7_to_Rt(pose[k])
+            assert np.degrees(np.arccos(np.clip((np.trace(Rg @ R.T) - 1) / 2, -1, 1))) < 0.3 and np.linalg.norm(tg - t) < 0.02, k
+            assert (mask[k, :len(P)][~bad] == 1).mean() > 0.8 and (mask[k, :len(P)][bad] == 1).mean() < 0.05   # (the mask is the winning P3P hypothesis', before the refinement)
+    assert ninl[3] == 0 and ninl[4] == 0                      # fewer than four correspondences: no model
+
+
+def test_loop_verification_chain_on_device(ctx):
+    """isLoopClosureKF (vo_loopclosing.cpp:593-700) with the device kernels: ORB of both keyframes, knn x2 + mutual/ratio test,
+    solvePnPRansac on the matches that have a 3-D point, the acceptance rule -- beside the same chain assembled from the oracle
+    (tests/test_oracle_loop_verification.py).  The 3-D points of the earlier keyframe come from the oracle here (stereo LK + DLT of the
+    ORB keypoints, :283-306: arithmetic the tracker's kernels cover, not exposed per keypoint)."""
+    import os
+    import tempfile
+    import torch
+    import _geom as G
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_loop_gpu.yaml")
+    open(p, "w").write(synth.D435I_STEREO_YAML)
+    cfg = O.load_config(p)
+    K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
+    P0, P1 = np.array(list(cfg.P0)), np.array(list(cfg.P1))
+    tr = synth.Trajectory(5)
+    rnd = synth.Renderer("cuda")
+    ta, tb = 1.0, 1.6
+    a0, a1 = [x[0] for x in rnd.stereo_frame([tr], ta, 20)]
+    b0, _ = [x[0] for x in rnd.stereo_frame([tr], tb, 32)]
+    kps, desc, cnt, ovf = ctx.orb_detect_and_compute(torch.stack([a0, b0]), cap=1024)
+    hk, hd, hc = kps.cpu().numpy(), desc.cpu().numpy(), cnt.cpu().numpy()
+    ka, da = O.orb_detect_and_compute(a0.cpu().numpy())
+    kb, db = O.orb_detect_and_compute(b0.cpu().numpy())
+    assert hc[0] == len(ka) and hc[1] == len(kb) and np.array_equal(hd[0, :hc[0]], da) and np.array_equal(hd[1, :hc[1]], db)
+    pairs, npairs = ctx.orb_match(desc[0:1], cnt[0:1], desc[1:2], cnt[1:2], 0.8)
+    pairs = pairs.cpu().numpy()[0, :int(npairs[0])]
+    assert np.array_equal(pairs, np.array(O.orb_match(da, db, 0.8)))
+    # 3-D of keyframe 0's ORB points (oracle: 5-level stereo LK from the same pixel + DLT, valid range of trignaulationPtFromStereo)
+    pts = ka[:, :2].copy()
+    nxt, st = O.lk(a0.cpu().numpy(), a1.cpu().numpy(), pts, pts, max_level=5)
+    p3d = np.zeros((len(ka), 3))
+    has3d = np.zeros(len(ka), bool)
+    for i in range(len(ka)):
+        if st[i] == 1:
+            pc = O.triangulate_dlt(pts[i].astype(np.float64), nxt[i].astype(np.float64), P0, P1)
+            if 0 < pc[2] < 20:
+                p3d[i], has3d[i] = pc, True
+    sel = np.array([pr for pr in pairs if has3d[pr[0]]])
+    assert len(sel) >= 60
+    cap = 1024
+    d3 = np.zeros((1, cap, 3), np.float32)
+    d2 = np.zeros((1, cap, 2), np.float32)
+    d3[0, :len(sel)] = p3d[sel[:, 0]]
+    d2[0, :len(sel)] = hk[1, sel[:, 1], :2]
+    pose, mask, ninl = ctx.pnp_ransac(torch.from_numpy(d3).cuda(), torch.from_numpy(d2).cuda(),
+                                      torch.tensor([len(sel)], dtype=torch.int32, device="cuda"), K4, [11])
+    n_want, pose_want, mask_want = O.solve_pnp_ransac(p3d[sel[:, 0]], kb[sel[:, 1], :2], K4, iterative=False, iterations=100, reproj=2.0,
+                                                      conf=0.99, seed=11)
+    n_inl = int(ninl[0])
+    assert n_inl == n_want and np.array_equal(pose.cpu().numpy()[0], pose_want) and np.array_equal(mask.cpu().numpy()[0, :len(sel)], mask_want)
+    assert n_inl >= 20 and n_inl / len(sel) >= 0.5                      # acceptance rule (:677-686, ratioRansac 0.5, minPts 20)
+    Ra, tta = tr.T_c_w(ta)
+    Rb, ttb = tr.T_c_w(tb)
+    R_gt = Rb @ Ra.T
+    R, t = G.pose7_to_Rt(pose.cpu().numpy()[0])
+    assert np.degrees(np.arccos(np.clip((np.trace(R @ R_gt.T) - 1) / 2, -1, 1))) < 0.5 and np.linalg.norm(t - (ttb - R_gt @ tta)) < 0.03
