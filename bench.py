@@ -372,6 +372,8 @@ def main():
     lk_idx = [i for i, n in enumerate(names) if n.startswith("lk_track")]
     chain_idx = names.index("frame(chain)")
     timed_mask = sum(1 << i for i in lk_idx) | (1 << chain_idx)
+    if os.environ.get("FLVIS_BENCH_FRAMES"):   # diagnosis: every stage carries events in the timed region (slows it a little)
+        timed_mask = (1 << nst) - 1
 
     def read_stages():
         ms = (C.c_double * nst)()
@@ -405,8 +407,11 @@ def main():
     host0 = host_times()
     t0 = time.perf_counter()
     e0.record()
+    host_call_ms = []
     for g in range(*sched["timed"]):
+        tc = time.perf_counter()
         feed(g, frames[g])
+        host_call_ms.append((time.perf_counter() - tc) * 1e3)
     e1.record()
     t_issue = time.perf_counter() - t0   # host loop over the K steps (the calls return before the GPU has run them, but block on the
     host1 = host_times()                 # pinned upload ring once the host is 4 frames ahead); host1 - host0: time inside image_feed
@@ -467,7 +472,17 @@ def main():
             "latency_ms": {"gpu_frame_chain_p50": round(plan.percentile(chain_ms, 50), 4),
                            "gpu_frame_chain_p99": round(plan.percentile(chain_ms, 99), 4),
                            "note": "HIP events around the whole main-stream chain of one batch step (all %d streams of the GPU "
-                                   "advance together), timed region" % S} if chain_ms else None,
+                                   "advance together), timed region" % S,
+                           # where the wall time of the timed region goes: the frames' own chains, the idle time between them on
+                           # the tracking stream, and the time after the last frame in which the local map finishes its keyframes
+                           "timed_region_ms": {"wall": round(elapsed * 1e3, 3), "tracking_stream_span": round(gpu_ms, 3),
+                                               "sum_of_frame_chains": round(sum(chain_ms), 3),
+                                               "local_map_tail_after_last_frame": round(elapsed * 1e3 - gpu_ms, 3)},
+                           "frame_chain_ms": [round(v, 3) for v in chain_ms] if os.environ.get("FLVIS_BENCH_FRAMES") else None,
+                           "host_call_ms": [round(v, 3) for v in host_call_ms] if os.environ.get("FLVIS_BENCH_FRAMES") else None,
+                           "host_in_image_feed_ms": {"total": round(host1[0] - host0[0], 3), "waiting_for_a_staging_slot": round(host1[1] - host0[1], 3)},
+                           "frame_stage_ms": {names[i]: [round(v, 3) for v in read_steps(i, K)] for i in range(nst)}
+                           if os.environ.get("FLVIS_BENCH_FRAMES") else None} if chain_ms else None,
             "roofline": {"bound": "hbm", "kernel": "k_lk_track", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": dom_bytes, "launches_per_step": 2},

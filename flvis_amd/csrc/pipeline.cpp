@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/flvis_hip.h"
@@ -60,7 +61,13 @@ struct Lane {
   // when the GPU gets to them.
   static constexpr int PIN_RING = 4;
   void* pinned[PIN_RING] = {};
-  hipEvent_t ev_pin[PIN_RING] = {};
+  // the slot of frame n may be refilled once frame n's upload is done: k_frame_head (the first kernel after the upload) stores the
+  // frame number into this host-mapped word and the host polls it.  (hipEventSynchronize on an event recorded after the upload
+  // returned only when EVERYTHING enqueued so far had finished -- measured: the host then slept through four queued frames and the
+  // GPU ran dry once per burst, a 0.9 ms hole in every fifth frame.)
+  volatile long long* h_progress = nullptr;  // host view
+  long long* d_progress = nullptr;           // device view of the same word
+  long long frames_uploaded = 0;             // frames this lane has enqueued
   std::vector<void*> allocs;
   std::vector<hipEvent_t> prof_ev;  // optional per-stage HIP-event timing (flvis_prof_enable)
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
@@ -100,6 +107,7 @@ struct Pipeline {
   static constexpr int NBA = 8;
   int nba = 2;                   // local-map streams in use: 2 per lane (FLVIS_BA_STREAMS per lane, tuning knob)
   int nba_lane = 2;              // ... of which every lane uses its own nba_lane
+  int host_lead = 2;             // frames the host may run ahead of the GPU (FLVIS_HOST_LEAD, 1 .. PIN_RING)
   int input_hold = 0;            // flvis_set_input_hold: frames the caller keeps its input buffers untouched after handing them over
   bool stagger = true;           // FLVIS_LANE_STAGGER=0: lanes start their first frame together
   double host_ms_total = 0, host_ms_wait = 0;  // host time inside flvis_image_feed / of it blocked on the pinned ring
@@ -238,10 +246,9 @@ static void lane_destroy(Lane* L) {
     if (L->ev_ba_done[k]) hipEventDestroy(L->ev_ba_done[k]);
   for (void* p : L->allocs) hipFree(p);
   for (hipEvent_t e : L->prof_ev) hipEventDestroy(e);
-  for (int k = 0; k < Lane::PIN_RING; k++) {
+  for (int k = 0; k < Lane::PIN_RING; k++)
     if (L->pinned[k]) hipHostFree(L->pinned[k]);
-    if (L->ev_pin[k]) hipEventDestroy(L->ev_pin[k]);
-  }
+  if (L->h_progress) hipHostFree((void*)L->h_progress);
   delete L;
 }
 
@@ -418,9 +425,15 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   L->h_imu.assign((size_t)S * IMU_MAX * 7, 0.0);
   L->h_nimu.assign(S, 0);
   for (int k = 0; k < Lane::PIN_RING; k++)
-    if (hipHostMalloc(&L->pinned[k], L->input_bytes, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&L->ev_pin[k], hipEventDisableTiming) != hipSuccess)
-      return false;
+    if (hipHostMalloc(&L->pinned[k], L->input_bytes, hipHostMallocDefault) != hipSuccess) return false;
+  {
+    void* hp = nullptr;
+    void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) return false;
+    L->h_progress = (volatile long long*)hp;
+    L->d_progress = (long long*)dp;
+    *L->h_progress = 0;
+  }
   if (own_stream) {
     if (hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking) != hipSuccess) return false;
     L->own_st = true;
@@ -491,6 +504,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   pl->nba_lane = std::max(1, std::min(pl->nba_lane, Pipeline::NBA / n_lanes));
   pl->nba = std::min(Pipeline::NBA, pl->nba_lane * n_lanes);  // (more than NBA / nba_lane lanes share local-map streams)
   if (const char* e = getenv("FLVIS_LANE_STAGGER")) pl->stagger = atoi(e) != 0;
+  if (const char* e = getenv("FLVIS_HOST_LEAD")) pl->host_lead = std::max(1, std::min(atoi(e), (int)Lane::PIN_RING));
   if (const char* e = getenv("FLVIS_SYNC_EACH_FRAME")) pl->sync_each_frame = atoi(e) != 0;
   if (const char* e = getenv("FLVIS_BA_EVERY")) {
     int v = atoi(e);
@@ -638,12 +652,21 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   hipStream_t st = L->st;
   const int w = pl->cfg.image_width, h = pl->cfg.image_height;
   // ---- stage host inputs (pinned) and upload: [times][imu][input image bases][n_imu]
-  const int pslot = (int)(pl->frames_fed % Lane::PIN_RING);
+  const long long frame_no = ++L->frames_uploaded;  // 1-based count of the frames this lane has been fed
+  const int pslot = (int)((frame_no - 1) % Lane::PIN_RING);
   uint8_t* pin = (uint8_t*)L->pinned[pslot];
   if (pl->sync_each_frame) hipStreamSynchronize(st);
-  if (pl->frames_fed >= Lane::PIN_RING) {  // upload of frame N-PIN_RING is done
+  // run at most host_lead frames ahead of the GPU (<= PIN_RING: the staging slot of frame N - PIN_RING must be free).  Not further:
+  // beyond ~5 queued frames (~300 commands) the HIP runtime itself blocks the enqueuing thread for 7-9 ms at a time and the GPU
+  // then runs dry while the queue is refilled (measured)
+  const long long lead = pl->host_lead;
+  if (frame_no > lead && *L->h_progress < frame_no - lead) {
     const auto tw = std::chrono::steady_clock::now();
-    hipEventSynchronize(L->ev_pin[pslot]);
+    int polls = 0;
+    while (*L->h_progress < frame_no - lead) {
+      if ((++polls & 255) == 0 && hipStreamQuery(st) == hipSuccess && *L->h_progress < frame_no - lead) break;  // (idle stream: a failed launch)
+      std::this_thread::sleep_for(std::chrono::microseconds(30));
+    }
     pl->host_ms_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
   }
   double* pt = (double*)pin;
@@ -662,7 +685,6 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   memcpy(pn, L->h_nimu.data(), sizeof(int) * S);
   std::fill(L->h_nimu.begin(), L->h_nimu.end(), 0);
   hipMemcpyAsync(L->d_inputs, pin, L->input_bytes, hipMemcpyHostToDevice, st);
-  hipEventRecord(L->ev_pin[pslot], st);
   // ---- fixed kernel sequence
   const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
   hipEvent_t* pev = prof ? &L->prof_ev[(size_t)pl->prof_step * (2 * PROF_STAGES)] : nullptr;
@@ -672,7 +694,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i) + 1], strm)
   PB(19, st);  // the whole main-stream chain of this frame: per-frame GPU latency (p50/p99 in bench.py)
   PB(0, st);
-  launch_frame_head(st, p, L->d_time);  // the staged IMU samples, then frame_begin
+  launch_frame_head(st, p, L->d_time, L->d_progress, frame_no);  // the staged IMU samples, then frame_begin
   if (pl->feedback_used) launch_apply_correction(st, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
   PE(0, st);
   if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {

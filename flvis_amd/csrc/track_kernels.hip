@@ -196,8 +196,11 @@ __global__ void k_frame_begin(Pipe p, const double* __restrict__ frame_time) {
   frame_begin_dev(p, s, frame_time[s]);
 }
 // the head of a frame in one launch: the staged IMU samples (F2FTracking::imu_feed), then the frame set-up
-__global__ void k_frame_head(Pipe p, const double* __restrict__ frame_time) {
+__global__ void k_frame_head(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress, long long frame_no) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
+  // tell the host that this frame's inputs have been uploaded (this kernel follows the upload in stream order): the pinned
+  // staging slot of the frame may be refilled (a store to host-mapped memory; the host polls it, see lane_frame)
+  if (s == 0 && host_progress) __hip_atomic_store(host_progress, frame_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (s >= p.S) return;
   imu_feed_dev(p, s);
   frame_begin_dev(p, s, frame_time[s]);
@@ -1579,8 +1582,8 @@ void launch_imu_feed(hipStream_t st, const Pipe& p) {
 void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time) {
   hipLaunchKernelGGL(k_frame_begin, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time);
 }
-void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time) {
-  hipLaunchKernelGGL(k_frame_head, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time);
+void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time, long long* host_progress, long long frame_no) {
+  hipLaunchKernelGGL(k_frame_head, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time, host_progress, frame_no);
 }
 void launch_apply_correction(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_apply_correction, dim3(p.S), dim3(AC_T), 0, st, p);
