@@ -1582,6 +1582,14 @@ void launch_imu_feed(hipStream_t st, const Pipe& p) {
 void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time) {
   hipLaunchKernelGGL(k_frame_begin, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time);
 }
+// stream-ordered store of a counter into host-mapped memory (the host polls it where it must know that earlier work of the stream
+// has finished: hipEventSynchronize returned only when everything enqueued so far, on any stream, was done -- DESIGN.md section 4)
+__global__ void k_store_progress(long long* __restrict__ host_word, long long v) {
+  __hip_atomic_store(host_word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_store_progress(hipStream_t st, long long* host_word, long long v) {
+  hipLaunchKernelGGL(k_store_progress, dim3(1), dim3(1), 0, st, host_word, v);
+}
 void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time, long long* host_progress, long long frame_no) {
   hipLaunchKernelGGL(k_frame_head, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time, host_progress, frame_no);
 }

@@ -69,6 +69,7 @@ int pnp_ransac_max_points();
 void launch_pnp_ransac_sets(hipStream_t st, const float* p3d, const float* p2d, const int* count, int cap, int n_sets, const double* K4,
                             int iterative, const double* guess7, const unsigned long long* seeds, int max_iters, double reproj_px,
                             double conf, double* pose7, unsigned char* mask, int* n_inliers);
+void launch_store_progress(hipStream_t st, long long* host_word, long long v);  // stream-ordered store into host-mapped memory
 void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time, long long* host_progress, long long frame_no);  // imu_feed + frame_begin in one launch
 void launch_apply_correction(hipStream_t st, const Pipe& p);
 void launch_track_prepare(hipStream_t st, const Pipe& p);
