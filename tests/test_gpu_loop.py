@@ -225,3 +225,28 @@ def test_loop_verification_chain_on_device(ctx):
     R_gt = Rb @ Ra.T
     R, t = G.pose7_to_Rt(pose.cpu().numpy()[0])
     assert np.degrees(np.arccos(np.clip((np.trace(R @ R_gt.T) - 1) / 2, -1, 1))) < 0.5 and np.linalg.norm(t - (ttb - R_gt @ tta)) < 0.03
+
+
+def test_loop_entry_points_reject_bad_input(ctx):
+    """capacities and argument checks of the loop-closing entry points fail loudly (error code + message), nothing is launched"""
+    import ctypes as C
+    import torch
+    import flvis_amd
+    lib, h = ctx._lib, ctx._h
+    cp = np.array([0, 2, 2, 2], np.int32)
+    ci = np.array([1, 2], np.int32)
+    ds = np.zeros((3, 32), np.uint8)
+    wt = np.array([0.0, 1.0, 1.0])
+    wi = np.array([-1, 0, 1], np.int32)
+    ctx.bow_set_vocabulary(cp, ci, ds, wt, wi)                                   # a valid two-word tree
+    with pytest.raises(flvis_amd.FlvisError):
+        ctx.bow_set_vocabulary(np.array([1, 2, 2, 2], np.int32), ci, ds, wt, wi)  # node 0 is not the root
+    with pytest.raises(flvis_amd.FlvisError):
+        ctx.bow_set_vocabulary(cp, np.array([1, 7], np.int32), ds, wt, wi)       # child index out of range
+    big = torch.zeros((1, 4096, 32), dtype=torch.uint8, device="cuda")
+    with pytest.raises(flvis_amd.FlvisError):
+        ctx.bow_transform(big, torch.zeros(1, dtype=torch.int32, device="cuda"))   # more than 2048 descriptors per keyframe
+    p3 = torch.zeros((1, 2048, 3), dtype=torch.float32, device="cuda")
+    p2 = torch.zeros((1, 2048, 2), dtype=torch.float32, device="cuda")
+    with pytest.raises(flvis_amd.FlvisError):
+        ctx.pnp_ransac(p3, p2, torch.zeros(1, dtype=torch.int32, device="cuda"), [1.0, 1.0, 0.0, 0.0], [1])   # > 1024 correspondences
