@@ -649,6 +649,8 @@ int flvis_hip_bow_transform(flvis_ctx* ctx, const uint8_t* d_desc, const int* d_
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_transform: bad args");
   if (dcap > BOW_MAXF) return ctx->fail(FLVIS_ERR_CAPACITY, "bow_transform: at most 2048 descriptors per keyframe");
   if (ctx->voc_nodes < 2) return ctx->fail(FLVIS_ERR_CONFIG, "bow_transform: no vocabulary (flvis_hip_bow_set_vocabulary)");
+  if (vcap < std::min(dcap, ctx->voc_words))
+    return ctx->fail(FLVIS_ERR_CAPACITY, "bow_transform: vcap must hold min(dcap, number of words) entries (a vector is never truncated)");
   VocDev v{(const int*)ctx->scratch("voc_child_ptr", 0), (const int*)ctx->scratch("voc_child_idx", 0),
            (const uint8_t*)ctx->scratch("voc_desc", 0), (const int*)ctx->scratch("voc_word_id", 0),
            (const double*)ctx->scratch("voc_weight", 0), (const double*)ctx->scratch("voc_word_weight", 0), ctx->voc_nodes, ctx->voc_words};

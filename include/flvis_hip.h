@@ -133,7 +133,8 @@ int flvis_hip_bow_set_vocabulary(flvis_ctx* ctx, int n_nodes, const int* h_child
                                  const double* h_weight, const int* h_word_id);
 /* voc.transform(kf.lm_descriptor, kf_bv) (vo_loopclosing.cpp:249-253; Vocabulary.cpp:628-688) for n_img keyframes:
  * d_desc [n_img][dcap][32] + d_count [n_img] as flvis_hip_orb_detect_and_compute leaves them (dcap <= 2048);
- * out: d_ids / d_vals [n_img][vcap] ascending word ids and L1-normalised values, d_nnz [n_img]. */
+ * out: d_ids / d_vals [n_img][vcap] ascending word ids and L1-normalised values, d_nnz [n_img]; vcap >= min(dcap, words of the
+ * vocabulary), so that no vector is ever truncated. */
 int flvis_hip_bow_transform(flvis_ctx* ctx, const uint8_t* d_desc, const int* d_count, int dcap, int n_img, int vcap, int* d_ids,
                             double* d_vals, int* d_nnz);
 /* one row of the similarity matrix (vo_loopclosing.cpp:417-437): voc.score(query, db[j]) for j < n_db (ScoringObject.cpp:23-68);
