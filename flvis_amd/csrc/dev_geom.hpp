@@ -138,8 +138,14 @@ __device__ inline V3 triangulate_two_view(double u1, double v1, double u2, doubl
 #ifndef SP_STAMP
 #define SP_STAMP(i) do { } while (0)
 #endif
+// state of a 7-point solve between the cubic's coefficients and its roots
+struct SevenPointMid {
+  double f2[9], Bm[9];
+  double s1, s2, c1[2], c2[2];
+};
+// first half: normalisation, null space, coefficients c[0..3] of det(f2 + x (f1 - f2)).  false: degenerate sample, no model
 template <int WS>
-__device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], double (*F)[9], double* wk) {
+__device__ inline bool seven_point_a(const double (*x1)[2], const double (*x2)[2], double* wk, SevenPointMid& mid, double* c) {
 #define SP_A(i, j) wk[(9 * (i) + (j)) * WS]
   double c1[2] = {0, 0}, c2[2] = {0, 0};
 #pragma unroll
@@ -160,7 +166,7 @@ __device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], 
     d1 += sqrt((x1[i][0] - c1[0]) * (x1[i][0] - c1[0]) + (x1[i][1] - c1[1]) * (x1[i][1] - c1[1]));
     d2 += sqrt((x2[i][0] - c2[0]) * (x2[i][0] - c2[0]) + (x2[i][1] - c2[1]) * (x2[i][1] - c2[1]));
   }
-  if (d1 < 1e-12 || d2 < 1e-12) return 0;
+  if (d1 < 1e-12 || d2 < 1e-12) return false;
   const double s1 = sqrt(2.0) * 7 / d1, s2 = sqrt(2.0) * 7 / d2;
 #pragma unroll
   for (int i = 0; i < 7; i++) {
@@ -196,7 +202,7 @@ __device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], 
           bc = j;
         }
     }
-    if (bv < 1e-12) return 0;
+    if (bv < 1e-12) return false;
     if (br != r) {
       double ra[9], rb[9];
 #pragma unroll
@@ -267,15 +273,26 @@ __device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], 
 #pragma unroll
   for (int j = 0; j < 9; j++) Bm[j] = f1[j] - f2[j];
   const double *a0 = f2, *a1 = f2 + 3, *a2 = f2 + 6, *b0 = Bm, *b1 = Bm + 3, *b2 = Bm + 6;
-  double c[4];
   c[0] = det3(a0, a1, a2);
   c[1] = det3(b0, a1, a2) + det3(a0, b1, a2) + det3(a0, a1, b2);
   c[2] = det3(b0, b1, a2) + det3(b0, a1, b2) + det3(a0, b1, b2);
   c[3] = det3(b0, b1, b2);
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    mid.f2[j] = f2[j];
+    mid.Bm[j] = Bm[j];
+  }
+  mid.s1 = s1, mid.s2 = s2;
+  mid.c1[0] = c1[0], mid.c1[1] = c1[1], mid.c2[0] = c2[0], mid.c2[1] = c2[1];
   SP_STAMP(2);
-  double roots[4];
-  int nr = poly_real_roots(c, 3, roots);
-  SP_STAMP(3);
+  return true;
+}
+// second half: one fundamental matrix per real root of the cubic (de-normalised, unit Frobenius norm)
+__device__ inline int seven_point_b(const SevenPointMid& mid, const double* roots, int nr, double (*F)[9]) {
+  const double* f2 = mid.f2;
+  const double* Bm = mid.Bm;
+  const double s1 = mid.s1, s2 = mid.s2;
+  const double c1[2] = {mid.c1[0], mid.c1[1]}, c2[2] = {mid.c2[0], mid.c2[1]};
   int nm = 0;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -321,6 +338,17 @@ __device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], 
   return nm;
 }
 
+template <int WS>
+__device__ inline int seven_point(const double (*x1)[2], const double (*x2)[2], double (*F)[9], double* wk) {
+  SevenPointMid mid;
+  double c[4];
+  if (!seven_point_a<WS>(x1, x2, wk, mid, c)) return 0;
+  double roots[4];
+  const int nr = poly_real_roots(c, 3, roots);
+  SP_STAMP(3);
+  return seven_point_b(mid, roots, nr, F);
+}
+
 // OpenCV FMEstimatorCallback::computeError (max of the two squared point-line distances, float)
 FD float f_error(const double* F, double x1, double y1, double x2, double y2) {
   double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
@@ -337,13 +365,16 @@ FD float f_error(const double* F, double x1, double y1, double x2, double y2) {
 // Grunert P3P: up to 4 (R, t) with X_cam = R P + t
 // Calls fn(R, t) for every solution (X_cam = R P + t), in root order; returns their number.  Everything is statically
 // indexed (no solution arrays): indexed local arrays would live in scratch memory.
-template <class Fn>
-__device__ inline int p3p_grunert_each(const V3* P, const V3* f, Fn&& fn) {
+// state of a P3P solve between the quartic's coefficients and its roots
+struct P3PMid {
+  double b2, ca, cb, cg, A;
+};
+// first half: the quartic q[0..4] in v = s3 / s1.  false: degenerate triangle
+__device__ inline bool p3p_grunert_a(const V3* P, const V3* f, P3PMid& mid, double* q) {
   double a2 = dot(P[1] - P[2], P[1] - P[2]), b2 = dot(P[0] - P[2], P[0] - P[2]), c2 = dot(P[0] - P[1], P[0] - P[1]);
-  if (b2 < 1e-20 || a2 < 1e-20 || c2 < 1e-20) return 0;
+  if (b2 < 1e-20 || a2 < 1e-20 || c2 < 1e-20) return false;
   double ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
   double A = (a2 - c2) / b2, C = c2 / b2;
-  double q[5];
   q[4] = A * A - 2 * A - 4 * C * ca * ca + 1;
   q[3] = -4 * A * A * cb + 4 * A * ca * cg + 4 * A * cb + 8 * C * ca * ca * cb + 8 * C * ca * cg - 4 * ca * cg;
   q[2] = 4 * A * A * cb * cb + 2 * A * A - 8 * A * ca * cb * cg - 4 * A * cg * cg - 4 * C * ca * ca - 16 * C * ca * cb * cg -
@@ -351,8 +382,13 @@ __device__ inline int p3p_grunert_each(const V3* P, const V3* f, Fn&& fn) {
   q[1] = -4 * A * A * cb + 4 * A * ca * cg + 8 * A * cb * cg * cg - 4 * A * cb + 8 * C * ca * cg + 8 * C * cb * cg * cg -
          4 * ca * cg;
   q[0] = A * A - 4 * A * cg * cg + 2 * A - 4 * C * cg * cg + 1;
-  double roots[4];
-  int nr = poly_real_roots(q, 4, roots);
+  mid.b2 = b2, mid.ca = ca, mid.cb = cb, mid.cg = cg, mid.A = A;
+  return true;
+}
+// second half: a pose per admissible root, in root order
+template <class Fn>
+__device__ inline int p3p_grunert_b(const V3* P, const V3* f, const P3PMid& mid, const double* roots, int nr, Fn&& fn) {
+  const double b2 = mid.b2, ca = mid.ca, cb = mid.cb, cg = mid.cg, A = mid.A;
   int ns = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -388,6 +424,16 @@ __device__ inline int p3p_grunert_each(const V3* P, const V3* f, Fn&& fn) {
     ns++;
   }
   return ns;
+}
+
+template <class Fn>
+__device__ inline int p3p_grunert_each(const V3* P, const V3* f, Fn&& fn) {
+  P3PMid mid;
+  double q[5];
+  if (!p3p_grunert_a(P, f, mid, q)) return 0;
+  double roots[4];
+  const int nr = poly_real_roots(q, 4, roots);
+  return p3p_grunert_b(P, f, mid, roots, nr, fn);
 }
 
 // g2o EdgeSE3ProjectXYZ error + pose Jacobian (tangent = omega, upsilon)

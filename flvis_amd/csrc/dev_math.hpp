@@ -357,43 +357,126 @@ FD double poly_eval5(double a0, double a1, double a2, double a3, double a4, doub
 // one bracketing level: roots of `a` (degree deg >= 3) given the real roots `crit` of its derivative.
 // The coefficients and the knots live in registers (selects instead of indexed local arrays: indexed arrays end up in
 // scratch memory, and the ~60-step bisections of every root then run at memory latency).
-__device__ inline int poly_roots_bracket(const double* a, int deg, const double* crit, int nc, double* roots) {
-  const double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = deg >= 4 ? a[4] : 0.0;
-  const double alead = deg >= 4 ? a4 : a3;
+// The level comes in three pieces -- knots, the bisection of ONE interval, the emission of the roots -- so that the (up to four)
+// bisections of a polynomial can also run on different waves (the RANSAC kernels: one hypothesis per lane, one interval per wave);
+// every interval performs exactly the sequential arithmetic of the CPU restatement wherever it runs.
+struct PolyBracket {
+  double a0, a1, a2, a3, a4;  // coefficients (a4 = 0 for a cubic)
+  double k0, k1, k2, k3, k4;  // knots: -B, the critical points inside (-B, B) in order, +B
+  int nk;                     // number of knots (nk - 1 intervals)
+};
+FD double poly_bracket_lo(const PolyBracket& t, int i) { return i == 0 ? t.k0 : (i == 1 ? t.k1 : (i == 2 ? t.k2 : t.k3)); }
+FD double poly_bracket_hi(const PolyBracket& t, int i) { return i == 0 ? t.k1 : (i == 1 ? t.k2 : (i == 2 ? t.k3 : t.k4)); }
+__device__ inline PolyBracket poly_bracket_knots(const double* a, int deg, const double* crit, int nc) {
+  PolyBracket t;
+  t.a0 = a[0], t.a1 = a[1], t.a2 = a[2], t.a3 = a[3], t.a4 = deg >= 4 ? a[4] : 0.0;
+  const double alead = deg >= 4 ? t.a4 : t.a3;
   double B = 0;
-  B = fmax(B, fabs(a0 / alead));
-  B = fmax(B, fabs(a1 / alead));
-  B = fmax(B, fabs(a2 / alead));
-  if (deg >= 4) B = fmax(B, fabs(a3 / alead));
+  B = fmax(B, fabs(t.a0 / alead));
+  B = fmax(B, fabs(t.a1 / alead));
+  B = fmax(B, fabs(t.a2 / alead));
+  if (deg >= 4) B = fmax(B, fabs(t.a3 / alead));
   B += 1.0;
-  // knots: -B, the critical points inside (-B, B) in order, +B  (at most 5 values)
-  double k0 = -B, k1 = B, k2 = B, k3 = B, k4 = B;
+  t.k0 = -B, t.k1 = B, t.k2 = B, t.k3 = B, t.k4 = B;
   int nk = 1;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     if (i < nc) {
       const double c = crit[i];
       if (c > -B && c < B) {
-        if (nk == 1) k1 = c;
-        else if (nk == 2) k2 = c;
-        else k3 = c;
+        if (nk == 1) t.k1 = c;
+        else if (nk == 2) t.k2 = c;
+        else t.k3 = c;
         nk++;
       }
     }
   }
-  if (nk == 1) k1 = B;
-  else if (nk == 2) k2 = B;
-  else if (nk == 3) k3 = B;
-  else k4 = B;
+  if (nk == 1) t.k1 = B;
+  else if (nk == 2) t.k2 = B;
+  else if (nk == 3) t.k3 = B;
+  else t.k4 = B;
   nk++;
-  // the (up to 4) sign-change intervals are bisected TOGETHER: the chains are independent, so interleaving them hides the
-  // fp64 dependency latency of one chain behind the others; every chain performs exactly the sequential arithmetic
+  t.nk = nk;
+  return t;
+}
+// interval i of the level: is there a sign change, and if so the bisected root 0.5 (lo + hi)
+__device__ inline void poly_bracket_bisect(const PolyBracket& t, int i, bool& bis, double& root) {
+  double lo = poly_bracket_lo(t, i), hi = poly_bracket_hi(t, i);
+  const bool on = i + 1 < t.nk;
+  double flo = on ? poly_eval5(t.a0, t.a1, t.a2, t.a3, t.a4, lo) : 1.0;
+  const double fhi = on ? poly_eval5(t.a0, t.a1, t.a2, t.a3, t.a4, hi) : 1.0;
+  bis = on && flo != 0 && fhi != 0 && ((flo < 0) != (fhi < 0));
+  if (bis) {
+    for (int it = 0; it < 200; it++) {
+      const double mid = 0.5 * (lo + hi);
+      if (mid == lo || mid == hi) break;
+      const double fm = poly_eval5(t.a0, t.a1, t.a2, t.a3, t.a4, mid);
+      if (fm == 0) {
+        lo = hi = mid;
+        break;
+      } else if ((fm < 0) == (flo < 0)) {
+        lo = mid;
+        flo = fm;
+      } else {
+        hi = mid;
+      }
+    }
+  }
+  root = 0.5 * (lo + hi);
+}
+// the roots of the level in ascending order from the intervals' results (a knot that is an exact root is reported once)
+__device__ inline int poly_bracket_emit(const PolyBracket& t, const bool* bis, const double* mid, double* roots) {
+  const double a0 = t.a0, a1 = t.a1, a2 = t.a2, a3 = t.a3, a4 = t.a4;
+  const int nk = t.nk;
+  int nr = 0;
+  double rprev = 0;  // roots[nr - 1]
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i + 1 < nk) {
+      const double klo = poly_bracket_lo(t, i), khi = poly_bracket_hi(t, i);
+      bool emit = false;
+      double rv = 0;
+      if (bis[i]) {
+        emit = true;
+        rv = mid[i];
+      } else {
+        const double f0 = poly_eval5(a0, a1, a2, a3, a4, klo), f1 = poly_eval5(a0, a1, a2, a3, a4, khi);
+        if (f0 == 0) {
+          if (nr == 0 || rprev != klo) {
+            emit = true;
+            rv = klo;
+          }
+        } else if (f1 == 0) {
+          if (i + 2 == nk) {
+            emit = true;
+            rv = khi;
+          }
+        }
+      }
+      if (emit) {
+        if (nr == 0) roots[0] = rv;
+        else if (nr == 1) roots[1] = rv;
+        else if (nr == 2) roots[2] = rv;
+        else roots[3] = rv;
+        rprev = rv;
+        nr++;
+      }
+    }
+  }
+  return nr;
+}
+// the whole level inside one lane: the (up to 4) sign-change intervals are bisected TOGETHER -- the chains are independent, so
+// interleaving them hides the fp64 dependency latency of one chain behind the others
+__device__ inline int poly_roots_bracket(const double* a, int deg, const double* crit, int nc, double* roots) {
+  const PolyBracket t = poly_bracket_knots(a, deg, crit, nc);
+  const double a0 = t.a0, a1 = t.a1, a2 = t.a2, a3 = t.a3, a4 = t.a4;
+  const int nk = t.nk;
   double lo[4], hi[4], flo[4], fhi[4];
   bool bis[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    lo[i] = i == 0 ? k0 : (i == 1 ? k1 : (i == 2 ? k2 : k3));
-    hi[i] = i == 0 ? k1 : (i == 1 ? k2 : (i == 2 ? k3 : k4));
+    lo[i] = poly_bracket_lo(t, i);
+    hi[i] = poly_bracket_hi(t, i);
     const bool on = i + 1 < nk;
     flo[i] = on ? poly_eval5(a0, a1, a2, a3, a4, lo[i]) : 1.0;
     fhi[i] = on ? poly_eval5(a0, a1, a2, a3, a4, hi[i]) : 1.0;
@@ -424,43 +507,10 @@ __device__ inline int poly_roots_bracket(const double* a, int deg, const double*
       }
     }
   }
-  int nr = 0;
-  double rprev = 0;  // roots[nr - 1]
+  double mid[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    if (i + 1 < nk) {
-      const double klo = i == 0 ? k0 : (i == 1 ? k1 : (i == 2 ? k2 : k3));
-      const double khi = i == 0 ? k1 : (i == 1 ? k2 : (i == 2 ? k3 : k4));
-      bool emit = false;
-      double rv = 0;
-      if (bis[i]) {
-        emit = true;
-        rv = 0.5 * (lo[i] + hi[i]);
-      } else {
-        const double f0 = poly_eval5(a0, a1, a2, a3, a4, klo), f1 = poly_eval5(a0, a1, a2, a3, a4, khi);
-        if (f0 == 0) {
-          if (nr == 0 || rprev != klo) {
-            emit = true;
-            rv = klo;
-          }
-        } else if (f1 == 0) {
-          if (i + 2 == nk) {
-            emit = true;
-            rv = khi;
-          }
-        }
-      }
-      if (emit) {
-        if (nr == 0) roots[0] = rv;
-        else if (nr == 1) roots[1] = rv;
-        else if (nr == 2) roots[2] = rv;
-        else roots[3] = rv;
-        rprev = rv;
-        nr++;
-      }
-    }
-  }
-  return nr;
+  for (int i = 0; i < 4; i++) mid[i] = 0.5 * (lo[i] + hi[i]);
+  return poly_bracket_emit(t, bis, mid, roots);
 }
 // generic entry (no recursion on device: explicit cascade 4 -> 3 -> 2)
 __device__ inline int poly_real_roots(const double* a_in, int deg, double* roots) {
@@ -515,6 +565,108 @@ __device__ inline int poly_real_roots(const double* a_in, int deg, double* roots
   }
   return poly_roots_bracket(a, deg, c1, nc1, roots);
 }
+
+// poly_real_roots(a_in, 3, roots) up to its bracketing level, for callers that bisect the level's intervals elsewhere (another
+// wave): returns 1 when the level `t` has to be bisected and emitted, 0 when roots / nr are final (degenerate leading coefficients)
+__device__ inline int poly_cubic_prepare(const double* a_in, PolyBracket& t, double* roots, int& nr) {
+  double a[5];
+  double amax = 0;
+  int deg = 3;
+  for (int i = 0; i <= deg; i++) {
+    a[i] = a_in[i];
+    amax = fmax(amax, fabs(a[i]));
+  }
+  a[4] = 0;
+  nr = 0;
+  if (amax == 0) return 0;
+  while (deg > 0 && fabs(a[deg]) <= 1e-14 * amax) deg--;
+  if (deg == 0) return 0;
+  if (deg == 1) {
+    roots[0] = -a[0] / a[1];
+    nr = 1;
+    return 0;
+  }
+  if (deg == 2) {
+    nr = poly_roots_quadratic(a, roots);
+    return 0;
+  }
+  double d1[4];
+  for (int i = 1; i <= 3; i++) d1[i - 1] = a[i] * i;
+  double c1[4];
+  int nc1;
+  double m1 = 0;
+  for (int i = 0; i <= 2; i++) m1 = fmax(m1, fabs(d1[i]));
+  int e1 = 2;
+  while (e1 > 0 && fabs(d1[e1]) <= 1e-14 * m1) e1--;
+  if (m1 == 0 || e1 == 0) {
+    nc1 = 0;
+  } else if (e1 == 1) {
+    c1[0] = -d1[0] / d1[1];
+    nc1 = 1;
+  } else {
+    nc1 = poly_roots_quadratic(d1, c1);
+  }
+  t = poly_bracket_knots(a, 3, c1, nc1);
+  return 1;
+}
+
+// poly_real_roots(a_in, 4, roots) in stages, for callers that bisect the bracketing levels' intervals elsewhere.
+//   stage 1: returns 0: roots / nr are final (degenerate leading coefficients);
+//            returns 1: the derivative is a true cubic -- bisect and emit its level t1 (<= 3 intervals), then call stage 2 with its roots;
+//            returns 2: the derivative's roots c1 / nc1 came in closed form -- call stage 2 with them.
+//   stage 2: the quartic's own level (<= 4 intervals) from the derivative's roots.
+// `a` receives the trimmed coefficients (needed again by stage 2).
+__device__ inline int poly_quartic_stage1(const double* a_in, double* a, PolyBracket& t1, double* c1, int& nc1, double* roots, int& nr) {
+  double amax = 0;
+  int deg = 4;
+  for (int i = 0; i <= deg; i++) {
+    a[i] = a_in[i];
+    amax = fmax(amax, fabs(a[i]));
+  }
+  nr = 0;
+  nc1 = 0;
+  if (amax == 0) return 0;
+  while (deg > 0 && fabs(a[deg]) <= 1e-14 * amax) deg--;
+  if (deg < 4) {  // (not a quartic after trimming: the generic solver, inside this lane)
+    nr = poly_real_roots(a_in, 4, roots);
+    return 0;
+  }
+  double d1[4], d2[3];
+  for (int i = 1; i <= 4; i++) d1[i - 1] = a[i] * i;
+  double m1 = 0;
+  for (int i = 0; i <= 3; i++) m1 = fmax(m1, fabs(d1[i]));
+  int e1 = 3;
+  while (e1 > 0 && fabs(d1[e1]) <= 1e-14 * m1) e1--;
+  if (m1 == 0 || e1 == 0) {
+    nc1 = 0;
+    return 2;
+  }
+  if (e1 == 1) {
+    c1[0] = -d1[0] / d1[1];
+    nc1 = 1;
+    return 2;
+  }
+  if (e1 == 2) {
+    nc1 = poly_roots_quadratic(d1, c1);
+    return 2;
+  }
+  for (int i = 1; i <= 3; i++) d2[i - 1] = d1[i] * i;
+  double c2[2];
+  int nc2;
+  const double m2 = fmax(fmax(fabs(d2[0]), fabs(d2[1])), fabs(d2[2]));
+  int e2 = 2;
+  while (e2 > 0 && fabs(d2[e2]) <= 1e-14 * m2) e2--;
+  if (m2 == 0 || e2 == 0)
+    nc2 = 0;
+  else if (e2 == 1) {
+    c2[0] = -d2[0] / d2[1];
+    nc2 = 1;
+  } else
+    nc2 = poly_roots_quadratic(d2, c2);
+  t1 = poly_bracket_knots(d1, 3, c2, nc2);
+  return 1;
+}
+__device__ inline PolyBracket poly_quartic_stage2(const double* a, const double* c1, int nc1) { return poly_bracket_knots(a, 4, c1, nc1); }
 
 FD double det3(const double* r0, const double* r1, const double* r2) {
   return r0[0] * (r1[1] * r2[2] - r1[2] * r2[1]) - r0[1] * (r1[0] * r2[2] - r1[2] * r2[0]) +

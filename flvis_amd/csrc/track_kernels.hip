@@ -447,9 +447,17 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
 #ifdef FLVIS_RANSAC_PROF
       if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[24 + 6], 1ull);
 #endif
-      if (wv == 0) {  // hypotheses of this batch
+      // hypotheses of this batch, one per lane of wave 0.  The bisections of the cubic's (up to three) sign-change intervals are
+      // handed to waves 0..2, one interval each (a lane's whole bracketing level inside wave 0 was a third of the generation time:
+      // a single wave is VALU-issue bound); the level travels through the per-lane workspace, which is free after the elimination
+      SevenPointMid sp_mid;
+      PolyBracket sp_t;
+      double sp_roots[4];
+      int sp_nr = 0, sp_mode = -1;  // -1: no polynomial, 0: roots final, 1: level to be bisected
+      int nm = -1;                  // -1: beyond niters, -2: subset impossible (the reference loop stops)
+      double* const xw = spw + lane;  // element e of this lane at xw[e * 64]
+      if (wv == 0) {
         const int iter = base + lane;
-        int nm = -1;  // -1: beyond niters, -2: subset impossible (the reference loop stops)
         if (iter < ctl[0]) {
 #ifdef FLVIS_RANSAC_PROF
           if (tid == 0) {
@@ -466,14 +474,45 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
               x2[k][0] = sm2[2 * idx[k]];
               x2[k][1] = sm2[2 * idx[k] + 1];
             }
-            double F[3][9];
-            nm = seven_point<64>(x1, x2, F, spw + lane);
-            SP_STAMP(4);
-            for (int m = 0; m < nm; m++)
-              for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
+            double cc[4];
+            nm = 0;
+            if (seven_point_a<64>(x1, x2, xw, sp_mid, cc)) sp_mode = poly_cubic_prepare(cc, sp_t, sp_roots, sp_nr);
           } else {
             nm = -2;
           }
+        }
+        if (sp_mode == 1) {
+          xw[0 * 64] = sp_t.a0, xw[1 * 64] = sp_t.a1, xw[2 * 64] = sp_t.a2, xw[3 * 64] = sp_t.a3, xw[4 * 64] = sp_t.a4;
+          xw[5 * 64] = sp_t.k0, xw[6 * 64] = sp_t.k1, xw[7 * 64] = sp_t.k2, xw[8 * 64] = sp_t.k3, xw[9 * 64] = sp_t.k4;
+        }
+        xw[10 * 64] = sp_mode == 1 ? (double)sp_t.nk : 0.0;  // 0: nothing to bisect for this lane
+      }
+      __syncthreads();
+      if (wv < 3 && xw[10 * 64] != 0.0) {
+        PolyBracket t;
+        t.a0 = xw[0 * 64], t.a1 = xw[1 * 64], t.a2 = xw[2 * 64], t.a3 = xw[3 * 64], t.a4 = xw[4 * 64];
+        t.k0 = xw[5 * 64], t.k1 = xw[6 * 64], t.k2 = xw[7 * 64], t.k3 = xw[8 * 64], t.k4 = xw[9 * 64];
+        t.nk = (int)xw[10 * 64];
+        bool bis;
+        double root;
+        poly_bracket_bisect(t, wv, bis, root);
+        xw[(11 + wv) * 64] = root;
+        xw[(15 + wv) * 64] = bis ? 1.0 : 0.0;
+      }
+      __syncthreads();
+      if (wv == 0) {
+        if (sp_mode == 1) {
+          const bool bis[4] = {xw[15 * 64] != 0.0, xw[16 * 64] != 0.0, xw[17 * 64] != 0.0, false};
+          const double mid[4] = {xw[11 * 64], xw[12 * 64], xw[13 * 64], 0.0};
+          sp_nr = poly_bracket_emit(sp_t, bis, mid, sp_roots);
+        }
+        SP_STAMP(3);
+        if (sp_mode >= 0) {
+          double F[3][9];
+          nm = seven_point_b(sp_mid, sp_roots, sp_nr, F);
+          SP_STAMP(4);
+          for (int m = 0; m < nm; m++)
+            for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
         }
         hnm[lane] = nm;
       }
@@ -610,63 +649,129 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
   if (np >= modelPoints) {
     for (int base = 0; base < ctl[0]; base += 64) {
       if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[6], 1ull);
-      if (wv == 0) {  // hypotheses of this batch: P3P on the first 3 sample points, the rest disambiguate
+      // hypotheses of this batch, one per lane of wave 0: P3P on the first 3 sample points, the rest disambiguate.  The bisections of
+      // the quartic's two bracketing levels (its derivative's <= 3 sign-change intervals, then its own <= 4) are handed to waves
+      // 0..3, one interval each: inside one lane they were most of the generation time (a single wave is VALU-issue bound).  The
+      // level travels through hpose[lane] (written only at the end of the generation), the results through gterms (used later).
+      int cnt = -1;  // -1: no model / beyond niters, -2: subset impossible, -3: model in hpose[lane], to be scored
+      int idx[5];
+      bool have = false;
+      P3PMid pm;
+      PolyBracket lvl;
+      double qa[5], c1[4], roots[4];
+      int nc1 = 0, nr = 0, qmode = -1;  // poly_quartic_stage1's result; -1: no polynomial for this lane
+      double* const task = hpose[lane];
+      double* const res = gterms + lane * PNP_GN_ROW;
+      auto put_task = [&](bool on) {
+        if (on) {
+          task[0] = lvl.a0, task[1] = lvl.a1, task[2] = lvl.a2, task[3] = lvl.a3, task[4] = lvl.a4;
+          task[5] = lvl.k0, task[6] = lvl.k1, task[7] = lvl.k2, task[8] = lvl.k3, task[9] = lvl.k4;
+        }
+        task[10] = on ? (double)lvl.nk : 0.0;
+      };
+      auto run_task = [&](int n_intervals) {  // waves 0 .. n_intervals-1: interval wv of lane's level
+        if (wv < n_intervals && task[10] != 0.0) {
+          PolyBracket t;
+          t.a0 = task[0], t.a1 = task[1], t.a2 = task[2], t.a3 = task[3], t.a4 = task[4];
+          t.k0 = task[5], t.k1 = task[6], t.k2 = task[7], t.k3 = task[8], t.k4 = task[9];
+          t.nk = (int)task[10];
+          bool bis;
+          double root;
+          poly_bracket_bisect(t, wv, bis, root);
+          res[wv] = root;
+          res[4 + wv] = bis ? 1.0 : 0.0;
+        }
+      };
+      if (wv == 0) {
         const int iter = base + lane;
-        int cnt = -1;  // -1: no model / beyond niters, -2: subset impossible, -3: model in hpose[lane], to be scored
         if (iter < ctl[0]) {
-          int idx[5];
           if (ransac_subset(seed, (unsigned)iter, np, modelPoints, idx)) {
+            have = true;
             V3 P[3], f[3];
             for (int k = 0; k < 3; k++) {
               P[k] = V3{(double)s3d[3 * idx[k]], (double)s3d[3 * idx[k] + 1], (double)s3d[3 * idx[k] + 2]};
               V3 d{((double)s2d[2 * idx[k]] - cx) / fx, ((double)s2d[2 * idx[k] + 1] - cy) / fy, 1.0};
               f[k] = (1.0 / norm(d)) * d;
             }
-            // the first solution with the smallest reprojection error on the remaining sample points wins
-            int bk = -1;
-            double be = 1.7976931348623157e308;
-            M3 R;
-            V3 t;
-            V3 Pm[2];
-            double zm[2][2];
-#pragma unroll
-            for (int m = 3; m < 5; m++) {
-              const int im = m < modelPoints ? idx[m] : idx[3];
-              Pm[m - 3] = V3{(double)s3d[3 * im], (double)s3d[3 * im + 1], (double)s3d[3 * im + 2]};
-              zm[m - 3][0] = (double)s2d[2 * im];
-              zm[m - 3][1] = (double)s2d[2 * im + 1];
-            }
-            int kk = 0;
-            p3p_grunert_each(P, f, [&](const M3& Rk, const V3& tk) {
-              double e = 0;
-#pragma unroll
-              for (int m = 3; m < 5; m++) {
-                if (m >= modelPoints) break;
-                V3 X = Rk * Pm[m - 3] + tk;
-                double z = X.z ? 1. / X.z : 1;
-                double du = fx * X.x * z + cx - zm[m - 3][0], dv = fy * X.y * z + cy - zm[m - 3][1];
-                e += du * du + dv * dv;
-              }
-              if (e < be) {
-                be = e;
-                bk = kk;
-                R = Rk;
-                t = tk;
-              }
-              kk++;
-            });
-            if (bk >= 0) {
-#pragma unroll
-              for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) hpose[lane][3 * r + c] = R.m[r][c];
-              hpose[lane][9] = t.x;
-              hpose[lane][10] = t.y;
-              hpose[lane][11] = t.z;
-              cnt = -3;
-            }
+            double q[5];
+            qmode = p3p_grunert_a(P, f, pm, q) ? poly_quartic_stage1(q, qa, lvl, c1, nc1, roots, nr) : 0;
           } else {
             cnt = -2;
+          }
+        }
+        put_task(qmode == 1);
+      }
+      __syncthreads();
+      run_task(3);
+      __syncthreads();
+      if (wv == 0) {
+        if (qmode == 1) {
+          const bool bis[4] = {res[4] != 0.0, res[5] != 0.0, res[6] != 0.0, false};
+          const double mid[4] = {res[0], res[1], res[2], 0.0};
+          nc1 = poly_bracket_emit(lvl, bis, mid, c1);
+          qmode = 2;
+        }
+        if (qmode == 2) lvl = poly_quartic_stage2(qa, c1, nc1);
+        put_task(qmode == 2);
+      }
+      __syncthreads();
+      run_task(4);
+      __syncthreads();
+      if (wv == 0) {
+        if (qmode == 2) {
+          const bool bis[4] = {res[4] != 0.0, res[5] != 0.0, res[6] != 0.0, res[7] != 0.0};
+          const double mid[4] = {res[0], res[1], res[2], res[3]};
+          nr = poly_bracket_emit(lvl, bis, mid, roots);
+        }
+        if (have && qmode >= 0) {
+          V3 P[3], f[3];
+          for (int k = 0; k < 3; k++) {
+            P[k] = V3{(double)s3d[3 * idx[k]], (double)s3d[3 * idx[k] + 1], (double)s3d[3 * idx[k] + 2]};
+            V3 d{((double)s2d[2 * idx[k]] - cx) / fx, ((double)s2d[2 * idx[k] + 1] - cy) / fy, 1.0};
+            f[k] = (1.0 / norm(d)) * d;
+          }
+          // the first solution with the smallest reprojection error on the remaining sample points wins
+          int bk = -1;
+          double be = 1.7976931348623157e308;
+          M3 R;
+          V3 t;
+          V3 Pm[2];
+          double zm[2][2];
+#pragma unroll
+          for (int m = 3; m < 5; m++) {
+            const int im = m < modelPoints ? idx[m] : idx[3];
+            Pm[m - 3] = V3{(double)s3d[3 * im], (double)s3d[3 * im + 1], (double)s3d[3 * im + 2]};
+            zm[m - 3][0] = (double)s2d[2 * im];
+            zm[m - 3][1] = (double)s2d[2 * im + 1];
+          }
+          int kk = 0;
+          p3p_grunert_b(P, f, pm, roots, nr, [&](const M3& Rk, const V3& tk) {
+            double e = 0;
+#pragma unroll
+            for (int m = 3; m < 5; m++) {
+              if (m >= modelPoints) break;
+              V3 X = Rk * Pm[m - 3] + tk;
+              double z = X.z ? 1. / X.z : 1;
+              double du = fx * X.x * z + cx - zm[m - 3][0], dv = fy * X.y * z + cy - zm[m - 3][1];
+              e += du * du + dv * dv;
+            }
+            if (e < be) {
+              be = e;
+              bk = kk;
+              R = Rk;
+              t = tk;
+            }
+            kk++;
+          });
+          if (bk >= 0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+              for (int c = 0; c < 3; c++) hpose[lane][3 * r + c] = R.m[r][c];
+            hpose[lane][9] = t.x;
+            hpose[lane][10] = t.y;
+            hpose[lane][11] = t.z;
+            cnt = -3;
           }
         }
         hcnt[lane] = cnt;
