@@ -518,58 +518,65 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
       }
       __syncthreads();
       RPROF(24, 1);
-      for (int mi = wv; mi < 64 * 3; mi += RF_T / 64) {  // score the models
-        const int hyp = mi / 3, m = mi - 3 * hyp;
-        if (m >= hnm[hyp]) continue;
-        double F[9];
+      // score + replay in sub-batches of 16 hypotheses: the adaptive stop usually ends the search within the first few hypotheses
+      // (niters drops to ~8 once a model with 90 % inliers is seen), so the later models of the batch are never looked at
+      constexpr int SB = 16;
+      for (int sb = 0; sb < 64; sb += SB) {
+        if (base + sb >= ctl[0]) break;  // (uniform: ctl[0] was written before the last barrier)
+        for (int mi = 3 * sb + wv; mi < 3 * (sb + SB); mi += RF_T / 64) {  // score the models
+          const int hyp = mi / 3, m = mi - 3 * hyp;
+          if (m >= hnm[hyp]) continue;
+          double F[9];
 #pragma unroll
-        for (int j = 0; j < 9; j++) F[j] = Fm[mi][j];
-        int good = 0;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-          const int i = i0 + lane;
-          const bool in = i < n && f_error(F, sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1]) <= thr2;
-          good += __popcll(__ballot(in));
-        }
-        if (lane == 0) mcnt[mi] = good;
-      }
-      __syncthreads();
-      RPROF(24, 2);
-      if (tid < 64) {  // best model of each hypothesis: first maximum in model order
-        const int nm = hnm[tid];
-        int cnt = nm == -2 ? -2 : (nm < 0 ? -1 : 0), model = 0;
-        for (int m = 0; m < nm; m++) {
-          const int good = mcnt[tid * 3 + m];
-          if (good > cnt) {
-            cnt = good;
-            model = m;
+          for (int j = 0; j < 9; j++) F[j] = Fm[mi][j];
+          int good = 0;
+          for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool in = i < n && f_error(F, sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1]) <= thr2;
+            good += __popcll(__ballot(in));
           }
+          if (lane == 0) mcnt[mi] = good;
         }
-        hcnt[tid] = cnt;
-        hmodel[tid] = model;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int niters = ctl[0], maxGood = ctl[1];
-        for (int k = 0; k < 64; k++) {
-          if (base + k >= niters) break;
-          if (hcnt[k] == -2) {
-            niters = 0;
-            break;
+        __syncthreads();
+        RPROF(24, 2);
+        if (tid < SB) {  // best model of each hypothesis: first maximum in model order
+          const int h = sb + tid;
+          const int nm = hnm[h];
+          int cnt = nm == -2 ? -2 : (nm < 0 ? -1 : 0), model = 0;
+          for (int m = 0; m < nm; m++) {
+            const int good = mcnt[h * 3 + m];
+            if (good > cnt) {
+              cnt = good;
+              model = m;
+            }
           }
-          int good = hcnt[k];
-          int lim = maxGood > 6 ? maxGood : 6;
-          if (good > lim) {
-            maxGood = good;
-            ctl[2] = base + k;
-            ctl[3] = hmodel[k];
-            for (int j = 0; j < 9; j++) bestF[j] = Fm[k * 3 + hmodel[k]][j];
-            niters = ransac_update_num_iters(0.99, (double)(n - good) / n, 7, niters);
-          }
+          hcnt[h] = cnt;
+          hmodel[h] = model;
         }
-        ctl[0] = niters;
-        ctl[1] = maxGood;
+        __syncthreads();
+        if (tid == 0) {
+          int niters = ctl[0], maxGood = ctl[1];
+          for (int k = sb; k < sb + SB; k++) {
+            if (base + k >= niters) break;
+            if (hcnt[k] == -2) {
+              niters = 0;
+              break;
+            }
+            int good = hcnt[k];
+            int lim = maxGood > 6 ? maxGood : 6;
+            if (good > lim) {
+              maxGood = good;
+              ctl[2] = base + k;
+              ctl[3] = hmodel[k];
+              for (int j = 0; j < 9; j++) bestF[j] = Fm[k * 3 + hmodel[k]][j];
+              niters = ransac_update_num_iters(0.99, (double)(n - good) / n, 7, niters);
+            }
+          }
+          ctl[0] = niters;
+          ctl[1] = maxGood;
+        }
+        __syncthreads();
       }
-      __syncthreads();
       RPROF(24, 3);
     }
     // apply the winning model's mask with the reference's mirrored index
@@ -778,52 +785,57 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
       }
       __syncthreads();
       PNP_PROF(1);
-      for (int hy = wv; hy < 64; hy += RP_T / 64) {  // score the models: lanes stride the correspondences
-        if (hcnt[hy] != -3) continue;
-        M3 R;
+      // score + replay in sub-batches of 16 hypotheses (the adaptive stop usually ends the search within the first few)
+      constexpr int SB = 16;
+      for (int sb = 0; sb < 64; sb += SB) {
+        if (base + sb >= ctl[0]) break;  // (uniform: ctl[0] was written before the last barrier)
+        for (int hy = sb + wv; hy < sb + SB; hy += RP_T / 64) {  // score the models: lanes stride the correspondences
+          if (hcnt[hy] != -3) continue;
+          M3 R;
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+          for (int r = 0; r < 3; r++)
 #pragma unroll
-          for (int c = 0; c < 3; c++) R.m[r][c] = hpose[hy][3 * r + c];
-        const V3 t{hpose[hy][9], hpose[hy][10], hpose[hy][11]};
-        int good = 0;
-        for (int i0 = 0; i0 < np; i0 += 64) {
-          const int i = i0 + lane;
-          bool in = false;
-          if (i < np) {
-            V3 Pi{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]};
-            V3 X = R * Pi + t;
-            double z = X.z ? 1. / X.z : 1;
-            float du = (float)(fx * X.x * z + cx) - s2d[2 * i], dv = (float)(fy * X.y * z + cy) - s2d[2 * i + 1];
-            in = du * du + dv * dv <= t2;
+            for (int c = 0; c < 3; c++) R.m[r][c] = hpose[hy][3 * r + c];
+          const V3 t{hpose[hy][9], hpose[hy][10], hpose[hy][11]};
+          int good = 0;
+          for (int i0 = 0; i0 < np; i0 += 64) {
+            const int i = i0 + lane;
+            bool in = false;
+            if (i < np) {
+              V3 Pi{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]};
+              V3 X = R * Pi + t;
+              double z = X.z ? 1. / X.z : 1;
+              float du = (float)(fx * X.x * z + cx) - s2d[2 * i], dv = (float)(fy * X.y * z + cy) - s2d[2 * i + 1];
+              in = du * du + dv * dv <= t2;
+            }
+            good += __popcll(__ballot(in));
           }
-          good += __popcll(__ballot(in));
+          if (lane == 0) hcnt[hy] = good;
         }
-        if (lane == 0) hcnt[hy] = good;
-      }
-      __syncthreads();
-      PNP_PROF(2);
-      if (tid == 0) {
-        int niters = ctl[0], maxGood = ctl[1];
-        for (int k = 0; k < 64; k++) {
-          if (base + k >= niters) break;
-          if (hcnt[k] == -2) {
-            niters = 0;
-            break;
+        __syncthreads();
+        PNP_PROF(2);
+        if (tid == 0) {
+          int niters = ctl[0], maxGood = ctl[1];
+          for (int k = sb; k < sb + SB; k++) {
+            if (base + k >= niters) break;
+            if (hcnt[k] == -2) {
+              niters = 0;
+              break;
+            }
+            int good = hcnt[k];
+            int lim = maxGood > modelPoints - 1 ? maxGood : modelPoints - 1;
+            if (good > lim) {
+              maxGood = good;
+              ctl[2] = base + k;
+              for (int j = 0; j < 12; j++) bpose[j] = hpose[k][j];
+              niters = ransac_update_num_iters(conf, (double)(np - good) / np, modelPoints, niters);
+            }
           }
-          int good = hcnt[k];
-          int lim = maxGood > modelPoints - 1 ? maxGood : modelPoints - 1;
-          if (good > lim) {
-            maxGood = good;
-            ctl[2] = base + k;
-            for (int j = 0; j < 12; j++) bpose[j] = hpose[k][j];
-            niters = ransac_update_num_iters(conf, (double)(np - good) / np, modelPoints, niters);
-          }
+          ctl[0] = niters;
+          ctl[1] = maxGood;
         }
-        ctl[0] = niters;
-        ctl[1] = maxGood;
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
   PNP_PROF(3);
