@@ -20,7 +20,9 @@ RCCL all-gather of the final poses + all-reduce of counters after the timed regi
 --pmc: runs itself twice under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE: separate passes) and writes
 profiles/<tag>_lk_pmc.json, the source of roofline.traffic (ignored when the kernel source changed since).
 
-Prints ONE JSON line (rank 0).
+Prints ONE JSON line (rank 0).  `latency_ms.timed_region_ms` says where the wall time of the timed region went (frame chains, idle
+time between frames, the local map's tail after the last frame).  FLVIS_BENCH_FRAMES=1 (diagnosis) adds per-frame chain / stage /
+host-call times to the line and puts events around every stage in the timed region.
 """
 import argparse
 import ctypes as C
