@@ -432,7 +432,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   {
     void* hp = nullptr;
     void* dp = nullptr;
-    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) return false;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) return false;
     L->h_progress = (volatile long long*)hp;
     L->d_progress = (long long*)dp;
     *L->h_progress = 0;
@@ -942,7 +942,7 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
     if (!ok) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: cannot create the copy stream");
     void* hp = nullptr;
     void* dp = nullptr;
-    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess)
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess)
       return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: cannot map the progress word");
     hf.h_up = (volatile long long*)hp;
     hf.d_up = (long long*)dp;
