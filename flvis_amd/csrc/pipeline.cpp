@@ -108,6 +108,7 @@ struct Pipeline {
   int nba = 2;                   // local-map streams in use: 2 per lane (FLVIS_BA_STREAMS per lane, tuning knob)
   int nba_lane = 2;              // ... of which every lane uses its own nba_lane
   int host_lead = 2;             // frames the host may run ahead of the GPU (FLVIS_HOST_LEAD, 1 .. PIN_RING)
+  int host_lead_cap = 4;         // (flvis_image_feed_host lowers it to 1 for its call: its copies and events add to the queued commands)
   int input_hold = 0;            // flvis_set_input_hold: frames the caller keeps its input buffers untouched after handing them over
   bool stagger = true;           // FLVIS_LANE_STAGGER=0: lanes start their first frame together
   double host_ms_total = 0, host_ms_wait = 0;  // host time inside flvis_image_feed / of it blocked on the pinned ring
@@ -662,7 +663,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // run at most host_lead frames ahead of the GPU (<= PIN_RING: the staging slot of frame N - PIN_RING must be free).  Not further:
   // beyond ~5 queued frames (~300 commands) the HIP runtime itself blocks the enqueuing thread for 7-9 ms at a time and the GPU
   // then runs dry while the queue is refilled (measured)
-  const long long lead = pl->host_lead;
+  const long long lead = std::min(pl->host_lead, pl->host_lead_cap);
   if (frame_no > lead && *L->h_progress < frame_no - lead) {
     const auto tw = std::chrono::steady_clock::now();
     int polls = 0;
@@ -1010,7 +1011,11 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
     d1 = hf.gray[slot][1];
   }
   for (int s = 0; s < S; s++) hf.times[s] = h_img0[s].t;
+  // one frame of lead in this mode: with two, the uploads' copies and events push the queued commands over what the HIP runtime
+  // accepts without blocking the caller for milliseconds (measured: 16k vs 28k frames/s when that happened mid-run)
+  pl->host_lead_cap = 1;
   const int rc = flvis_image_feed(ctx, d0, d1, hf.times.data(), h_out, with_local_map);
+  pl->host_lead_cap = 4;
   hipEventRecord(hf.ev_free[slot], st);
   hf.n++;
   if (rc != FLVIS_OK) return rc;
