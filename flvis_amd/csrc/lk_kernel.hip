@@ -79,14 +79,17 @@ __device__ __forceinline__ int descale_i(int x, int n) { return (x + (1 << (n - 
   ((((K)&3) == 3) ? __builtin_amdgcn_perm((D)[((K) >> 2) + 1], (D)[(K) >> 2], 0x0c040c03u)                         \
                   : __builtin_amdgcn_perm(0u, (D)[(K) >> 2], 0x0c000c00u | (uint32_t)((K)&3) | ((uint32_t)(((K)&3) + 1) << 16)))
 
-// sum of v over the wave as a wave-uniform value: 4 DPP steps give every lane its row-of-16 total, 4 readlanes add the rows
+// sum of v over the wave as a wave-uniform value: 4 DPP steps give every lane its row-of-16 total, two row broadcasts
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) carry the row totals upwards, lane 63 holds the wave total --
+// one readlane instead of four readlanes + three scalar adds (integer sums: any order is exact)
 __device__ __forceinline__ int lk_wave_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
   v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
-  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-         __builtin_amdgcn_readlane(v, 48);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15, rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31, rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 // exact 64-bit total of a per-lane int32: 16-bit halves cannot overflow 32 bits over 64 lanes
 __device__ __forceinline__ long long lk_wave_sum_wide(int v) {
