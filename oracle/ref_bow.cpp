@@ -13,6 +13,8 @@
 // The vocabulary FILE the reference loads (vo_loopclosing.cpp:1097) is not shipped with it; the tree is handed over as flat
 // arrays (children of node n: child_idx[child_ptr[n] .. child_ptr[n+1]), node descriptors, word id and weight of the leaves).
 // Weighting TF_IDF and scoring L1_NORM (DBoW3's defaults and what the ORB vocabularies are built with) are the only ones restated.
+// parity unpinned: DBoW3 needs OpenCV to build and its tests (3rdPartLib/DBow3/tests) read vocabulary / image files that are not in
+// the reference; the restatement is checked against an independent plain-Python restatement of the same lines (tests/_voc.py).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
