@@ -257,6 +257,10 @@ class Context:
         self._check(self._lib.flvis_hip_bow_set_vocabulary(self._h, n, _P(cp, C.c_int), _P(ci, C.c_int), _P(ds, C.c_uint8),
                                                            _P(wt, C.c_double), _P(wi, C.c_int)), "bow_set_vocabulary")
 
+    def bow_load_vocabulary(self, path):
+        """flvis_hip_bow_load_vocabulary: `Vocabulary voc(path)` of vo_loopclosing.cpp:1097 (.dbow3 / .txt / .yml / .yml.gz)."""
+        self._check(self._lib.flvis_hip_bow_load_vocabulary(self._h, C.c_char_p(os.fsencode(path))), "bow_load_vocabulary")
+
     def bow_transform(self, desc, count, vcap=2048):
         """desc uint8 [n,dcap,32], count int32 [n] (device) -> (ids int32 [n,vcap], vals float64 [n,vcap], nnz int32 [n])."""
         import torch
@@ -338,6 +342,37 @@ def loop_candidate(row, present, lcKFDist, lcKFMaxDist, lcNKFClosest, minScore):
     if r < 0:
         raise FlvisError("flvis_loop_candidate failed: %d" % r)
     return int(out.value) if r == 1 else None
+
+
+def read_vocabulary_file(path):
+    """flvis_voc_file_* (host only): a DBoW3 vocabulary file as the flat arrays `Context.bow_set_vocabulary` takes.
+
+    Returns a dict: child_ptr, child_idx, desc [n,32], weight, word_id (-1 on inner nodes), k, L, scoring, weighting, n_words,
+    layout ("binary" | "binary-quicklz" | "text" | "yaml")."""
+    import numpy as np
+    lib = load_library()
+    h = C.c_void_p(0)
+    err = C.create_string_buffer(512)
+    lib.flvis_voc_file_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+    rc = lib.flvis_voc_file_open(os.fsencode(path), C.byref(h), err, 512)
+    if rc != FLVIS_OK:
+        raise FlvisError("flvis_voc_file_open(%s): %s" % (path, err.value.decode(errors="replace") or rc))
+    try:
+        info = (C.c_int * 8)()
+        lib.flvis_voc_file_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.flvis_voc_file_info(h, info)
+        n, n_words, k, L, scoring, weighting, n_edges, layout = list(info)
+        ptrs = [C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_double)(), C.POINTER(C.c_int)()]
+        lib.flvis_voc_file_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        lib.flvis_voc_file_arrays(h, *[C.byref(q) for q in ptrs])
+        take = lambda q, cnt, dt: np.ctypeslib.as_array(q, shape=(cnt,)).astype(dt, copy=True) if cnt else np.zeros(0, dt)
+        return {"child_ptr": take(ptrs[0], n + 1, np.int32), "child_idx": take(ptrs[1], n_edges, np.int32),
+                "desc": take(ptrs[2], n * 32, np.uint8).reshape(n, 32), "weight": take(ptrs[3], n, np.float64),
+                "word_id": take(ptrs[4], n, np.int32), "k": k, "L": L, "scoring": scoring, "weighting": weighting,
+                "n_words": n_words, "layout": ["binary", "binary-quicklz", "text", "yaml"][layout]}
+    finally:
+        lib.flvis_voc_file_close.argtypes = [C.c_void_p]
+        lib.flvis_voc_file_close(h)
 
 
 class OrbParams(C.Structure):

@@ -131,6 +131,20 @@ int flvis_hip_orb_match(flvis_ctx* ctx, const uint8_t* d_a, const int* d_na, int
  * and weight h_weight[n] (idf); h_desc: 32 bytes per node.  Weighting TF_IDF, scoring L1_NORM (DBoW3's defaults). */
 int flvis_hip_bow_set_vocabulary(flvis_ctx* ctx, int n_nodes, const int* h_child_ptr, const int* h_child_idx, const uint8_t* h_desc,
                                  const double* h_weight, const int* h_word_id);
+/* `Vocabulary vocTmp(vocFile)` (vo_loopclosing.cpp:1095-1099; Vocabulary::load, 3rdPartLib/DBow3/src/Vocabulary.cpp:1082-1096):
+ * reads a DBoW3 vocabulary file -- binary .dbow3 (plain or QuickLZ-compressed, Vocabulary.cpp:1335-1407), ORB-SLAM2 style .txt
+ * (:1259-1332) or OpenCV FileStorage yaml / yaml.gz (:1411-1462) -- and makes it the context's vocabulary.  ORB vocabularies
+ * (32-byte CV_8U descriptors) with weighting TF_IDF or TF and scoring L1_NORM; anything else fails with FLVIS_ERR_CONFIG. */
+int flvis_hip_bow_load_vocabulary(flvis_ctx* ctx, const char* path);
+/* the file reader on its own (host only, no device needed): the flat arrays flvis_hip_bow_set_vocabulary takes, owned by the
+ * handle until flvis_voc_file_close.  info8 = {n_nodes, n_words, k, L, scoringType, weightingType, n_edges, layout}, layout
+ * 0 binary, 1 binary QuickLZ, 2 text, 3 yaml.  word_id is -1 on inner nodes. */
+typedef struct flvis_voc_file flvis_voc_file;
+int flvis_voc_file_open(const char* path, flvis_voc_file** out, char* err, int errlen);
+int flvis_voc_file_info(const flvis_voc_file* voc, int* info8);
+int flvis_voc_file_arrays(const flvis_voc_file* voc, const int** child_ptr, const int** child_idx, const uint8_t** desc,
+                          const double** weight, const int** word_id);
+void flvis_voc_file_close(flvis_voc_file* voc);
 /* voc.transform(kf.lm_descriptor, kf_bv) (vo_loopclosing.cpp:249-253; Vocabulary.cpp:628-688) for n_img keyframes:
  * d_desc [n_img][dcap][32] + d_count [n_img] as flvis_hip_orb_detect_and_compute leaves them (dcap <= 2048);
  * out: d_ids / d_vals [n_img][vcap] ascending word ids and L1-normalised values, d_nnz [n_img]; vcap >= min(dcap, words of the

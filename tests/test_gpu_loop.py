@@ -50,6 +50,37 @@ def test_bow_transform_parity_bit_exact(ctx):
     assert nnz[20] == 0 and nnz[21] <= 1 and nnz[:20].min() > 5
 
 
+def test_bow_vocabulary_from_a_dbow3_file(ctx, tmp_path):
+    """`Vocabulary voc(path)` (vo_loopclosing.cpp:1097): the golden file the reference's QuickLZ compressed, loaded by the library,
+    gives the vectors the oracle computes on the tree that was written; the other layouts of the same tree give the same."""
+    import os
+    import flvis_amd
+    import _vocfile as VF
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(gold, "voc_k6.npz"))
+    voc = (z["child_ptr"], z["child_idx"], z["desc"], z["weight"], z["word_id"])
+    rv = RefVoc(voc)
+    kfs = V.make_keyframes(2024, n_img=12, n_proto=50, per_img=(150, 250))
+    desc, cnt = _batch(kfs, 256)
+    paths = [os.path.join(gold, "voc_k6_quicklz.dbow3"), str(tmp_path / "v.yml.gz"), str(tmp_path / "v.dbow3")]
+    VF.write_yaml(paths[1], voc, 6, 3, gz=True)
+    VF.write_binary(paths[2], voc, 6, 3)
+    for path in paths:
+        ctx.bow_set_vocabulary(*V.build_vocabulary(kfs[:4], k=3, depth=2))     # something else resident first
+        ctx.bow_load_vocabulary(path)
+        ids, vals, nnz = [t.cpu().numpy() for t in ctx.bow_transform(desc, cnt, vcap=256)]
+        for i, k in enumerate(kfs):
+            wi, wv = rv.transform(k[:256])
+            assert nnz[i] == len(wi) and np.array_equal(ids[i, :nnz[i]], wi) and np.array_equal(vals[i, :nnz[i]], wv), (path, i)
+    with pytest.raises(flvis_amd.FlvisError) as e:
+        ctx.bow_load_vocabulary(str(tmp_path / "absent.dbow3"))
+    assert "cannot open" in str(e.value)
+    VF.write_binary(paths[2], voc, 6, 3, scoring=3)
+    with pytest.raises(flvis_amd.FlvisError) as e:
+        ctx.bow_load_vocabulary(paths[2])
+    assert "scoring type 3" in str(e.value)
+
+
 def test_bow_score_row_parity_bit_exact(ctx):
     import torch
     kfs = V.make_keyframes(4, n_img=40, per_img=(250, 400))
