@@ -282,6 +282,31 @@ class Context:
                                                   _ptr(db_nnz), vcap, m, _ptr(scores)), "bow_score")
         return scores
 
+    def lc_keyframe_landmarks(self, img0, img1, cam_type, kps, desc, count, P0=None, P1=None, K4=None, in_place=False):
+        """flvis_hip_lc_keyframe_landmarks (vo_loopclosing.cpp:255-372): kps float32 [n,cap,6], desc uint8 [n,cap,32], count int32 [n] as
+        orb_detect_and_compute returns them; img0 uint8 [n,h,w]; img1 uint8 (stereo, cam_type 0) or int16/uint16 Z16 (depth, cam_type 2).
+        Returns (lm_2d float32 [n,cap,2], lm_3d float64 [n,cap,3], lm_desc uint8 [n,cap,32], lm_count int32 [n])."""
+        import numpy as np
+        import torch
+        kps, desc = kps.contiguous(), desc.contiguous()
+        n, cap, _ = kps.shape
+        ref = img0 if img0 is not None else img1
+        h, w = ref.shape[-2:]
+        img0 = img0.contiguous() if img0 is not None else None
+        img1 = img1.contiguous() if img1 is not None else None
+        dbl = lambda a, m: None if a is None else np.ascontiguousarray(a, np.float64).reshape(m)
+        p0, p1, k4 = dbl(P0, 12), dbl(P1, 12), dbl(K4, 4)
+        hp = lambda a: _P(a, C.c_double) if a is not None else None
+        lm2 = torch.zeros((n, cap, 2), dtype=torch.float32, device=kps.device)
+        lm3 = torch.zeros((n, cap, 3), dtype=torch.float64, device=kps.device)
+        lmd = desc if in_place else torch.zeros_like(desc)
+        cnt = torch.zeros((n,), dtype=torch.int32, device=kps.device)
+        self._check(self._lib.flvis_hip_lc_keyframe_landmarks(
+            self._h, _ptr(img0) if img0 is not None else C.c_void_p(0), _ptr(img1) if img1 is not None else C.c_void_p(0), w, h, n,
+            int(cam_type), hp(p0), hp(p1), hp(k4), _ptr(kps), _ptr(desc), _ptr(count), cap, _ptr(lm2), _ptr(lm3), _ptr(lmd), _ptr(cnt)),
+            "lc_keyframe_landmarks")
+        return lm2, lm3, lmd, cnt
+
     def pnp_ransac(self, p3d, p2d, count, K4, seeds, iterations=100, reproj_px=2.0, confidence=0.99):
         """flvis_hip_pnp_ransac: p3d float32 [n,cap,3], p2d float32 [n,cap,2], count int32 [n] (device) -> (pose7 [n,7], mask [n,cap],
         n_inliers [n])."""

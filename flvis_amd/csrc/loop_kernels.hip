@@ -24,6 +24,7 @@
 #include "../../include/flvis_hip.h"
 #include "ctx.hpp"
 #include "dev_common.hpp"
+#include "dev_geom.hpp"
 #include "dev_math.hpp"
 #include "track_kernels.hpp"
 
@@ -587,6 +588,82 @@ __global__ __launch_bounds__(PGO_T) void k_pgo(const PgoGraph* graphs) {
   for (int v = t; v < g.n; v += PGO_T) store_pose7(g.T_c_w + 7 * g.vkf[v], iso_inv(load_pose7(g.est + 7 * v)));
 }
 
+
+// ---- 3-D positions of a keyframe's ORB keypoints (vo_loopclosing.cpp:255-372) ---------------------------------------------------
+struct LcCam {
+  double P0[12], P1[12];  // STEREO_RECT: the rectified projection matrices (dc.P0_, dc.P1_)
+  double fx, fy, cx, cy;  // DEPTH_D435
+  int cam_type, w, h;
+};
+constexpr int LC_T = 1024;
+constexpr int LC_MAXF = 2048;
+
+// keypoint rows (x, y, size, angle, response, octave) -> the two point lists of calcOpticalFlowPyrLK (lm_img1 = lm_img0, :270)
+__global__ __launch_bounds__(256) void k_lc_points(const float* __restrict__ kps, const int* __restrict__ count, int cap, float* __restrict__ p0,
+                                                   float* __restrict__ p1) {
+  const int img = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cap) return;
+  const size_t o = (size_t)img * cap + i;
+  float x = 0.f, y = 0.f;
+  if (i < count[img]) x = kps[o * 6], y = kps[o * 6 + 1];
+  p0[o * 2] = p1[o * 2] = x;
+  p0[o * 2 + 1] = p1[o * 2 + 1] = y;
+}
+
+// one workgroup per keyframe, two keypoints per thread: the mask of :280-349, then the ordered removal of :362-371
+__global__ __launch_bounds__(LC_T) void k_lc_landmarks(LcCam cam, const float* __restrict__ kps, const uint8_t* desc, const int* __restrict__ count,
+                                                       int cap, const float* __restrict__ next_pts, const uint8_t* __restrict__ status,
+                                                       const uint16_t* __restrict__ depth, float* lm_2d, double* lm_3d, uint8_t* lm_desc,
+                                                       int* __restrict__ lm_count) {
+  __shared__ int s_scan[LC_T / 64];
+  const int img = blockIdx.x, t = threadIdx.x;
+  const int n = min(count[img], cap);
+  bool keep[2] = {false, false};
+  float xy[2][2];
+  V3 p3[2];
+  uint4 d[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const int i = 2 * t + e;
+    if (i >= n) continue;
+    const size_t o = (size_t)img * cap + i;
+    const float x = kps[o * 6], y = kps[o * 6 + 1];
+    xy[e][0] = x, xy[e][1] = y;
+    const uint4* q = reinterpret_cast<const uint4*>(desc + o * 32);
+    d[e][0] = q[0], d[e][1] = q[1];
+    if (cam.cam_type == 0) {
+      if (status[o] == 1) {
+        const V3 pc = triangulate_dlt((double)x, (double)y, (double)next_pts[o * 2], (double)next_pts[o * 2 + 1], cam.P0, cam.P1);
+        if (!(pc.z < 0 || pc.z > (double)100.0f)) {  // trignaulationPtFromStereo, range = 100.0 (triangulation.h:24)
+          keep[e] = true;
+          p3[e] = pc;
+        }
+      }
+    } else if (cam.cam_type == 2) {
+      // img1.at<ushort>(Point2f): nearest-even rounding of the position; `ushort / 1000` is an integer division (:331)
+      const int ix = min(max(__float2int_rn(x), 0), cam.w - 1), iy = min(max(__float2int_rn(y), 0), cam.h - 1);
+      const double dm = (double)(depth[(size_t)img * cam.w * cam.h + (size_t)iy * cam.w + ix] / 1000);
+      if (dm >= 0.3 && dm <= 10) {
+        keep[e] = true;
+        p3[e] = V3{((double)x - cam.cx) / cam.fx * dm, ((double)y - cam.cy) / cam.fy * dm, dm};
+      }
+    }
+  }
+  int tot;
+  int k = block_exclusive_scan<LC_T / 64>((int)keep[0] + (int)keep[1], s_scan, tot);  // (its barriers also order the in-place case)
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    if (!keep[e]) continue;
+    const size_t o = (size_t)img * cap + k;
+    lm_2d[o * 2] = xy[e][0], lm_2d[o * 2 + 1] = xy[e][1];
+    lm_3d[o * 3] = p3[e].x, lm_3d[o * 3 + 1] = p3[e].y, lm_3d[o * 3 + 2] = p3[e].z;
+    uint4* q = reinterpret_cast<uint4*>(lm_desc + o * 32);
+    q[0] = d[e][0], q[1] = d[e][1];
+    k++;
+  }
+  if (t == 0) lm_count[img] = tot;
+}
+
 }  // namespace flvis
 
 using namespace flvis;
@@ -639,6 +716,53 @@ int flvis_hip_bow_set_vocabulary(flvis_ctx* ctx, int n_nodes, const int* h_child
   if (e != hipSuccess) return ctx->hip_fail(e, "bow_set_vocabulary");
   ctx->voc_nodes = n_nodes;
   ctx->voc_words = n_words;
+  return FLVIS_OK;
+}
+
+// STEP 1.5 / 1.6 of the loop-closing keyframe (vo_loopclosing.cpp:255-372) for n_img keyframes: which ORB keypoints get a 3-D
+// position (stereo LK into img1 + DLT triangulation, or the depth image), and the keypoint / descriptor lists without the others.
+int flvis_hip_lc_keyframe_landmarks(flvis_ctx* ctx, const uint8_t* d_img0, const void* d_img1, int w, int h, int n_img, int cam_type,
+                                    const double* h_P0, const double* h_P1, const double* h_K4, const float* d_kps, const uint8_t* d_desc,
+                                    const int* d_count, int cap, float* d_lm_2d, double* d_lm_3d, uint8_t* d_lm_desc, int* d_lm_count) {
+  CHECK_CTX(ctx);
+  if (!d_kps || !d_desc || !d_count || !d_lm_2d || !d_lm_3d || !d_lm_desc || !d_lm_count || n_img <= 0 || cap <= 0 || w <= 0 || h <= 0)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "lc_keyframe_landmarks: bad args");
+  if (cap > LC_MAXF) return ctx->fail(FLVIS_ERR_CAPACITY, "lc_keyframe_landmarks: at most 2048 keypoints per keyframe");
+  if (cam_type < 0 || cam_type > 2) return ctx->fail(FLVIS_ERR_INVALID_ARG, "lc_keyframe_landmarks: cam_type must be 0 (stereo rectified), 1 (stereo unrectified) or 2 (depth)");
+  // (d_lm_desc == d_desc is fine: every workgroup reads its keyframe's rows before the scan's barrier and writes after)
+  LcCam cam{};
+  cam.cam_type = cam_type, cam.w = w, cam.h = h;
+  hipStream_t st = ctx->stream;
+  if (cam_type == 1) {  // the reference's STEREO_UNRECT case is empty (:316-322): no keypoint gets a position
+    hipError_t e = hipMemsetAsync(d_lm_count, 0, sizeof(int) * (size_t)n_img, st);
+    if (e != hipSuccess) return ctx->hip_fail(e, "lc_keyframe_landmarks");
+    return FLVIS_OK;
+  }
+  if (!d_img1) return ctx->fail(FLVIS_ERR_INVALID_ARG, "lc_keyframe_landmarks: no second image");
+  const float* next = nullptr;
+  const uint8_t* status = nullptr;
+  if (cam_type == 0) {
+    if (!d_img0 || !h_P0 || !h_P1) return ctx->fail(FLVIS_ERR_INVALID_ARG, "lc_keyframe_landmarks: stereo needs img0, P0 and P1");
+    memcpy(cam.P0, h_P0, sizeof(cam.P0));
+    memcpy(cam.P1, h_P1, sizeof(cam.P1));
+    hipSetDevice(ctx->device);
+    const size_t np = (size_t)n_img * cap;
+    float* p0 = (float*)ctx->scratch("lc_pts0", sizeof(float) * 2 * np);
+    float* p1 = (float*)ctx->scratch("lc_pts1", sizeof(float) * 2 * np);
+    uint8_t* stt = (uint8_t*)ctx->scratch("lc_status", np);
+    if (!p0 || !p1 || !stt) return ctx->fail(FLVIS_ERR_HIP, "lc_keyframe_landmarks: scratch allocation failed");
+    k_lc_points<<<dim3((cap + 255) / 256, n_img), 256, 0, st>>>(d_kps, d_count, cap, p0, p1);
+    // calcOpticalFlowPyrLK(img0, img1, lm_img0, lm_img1, ., ., Size(31,31), 5, (COUNT+EPS, 30, 0.001), OPTFLOW_USE_INITIAL_FLOW)  (:274-278)
+    const int rc = flvis_hip_lk_track(ctx, d_img0, (const uint8_t*)d_img1, w, h, n_img, p0, p1, stt, d_count, cap, 5, 30, 0.001, 1);
+    if (rc != FLVIS_OK) return rc;
+    next = p1, status = stt;
+  } else {
+    if (!h_K4) return ctx->fail(FLVIS_ERR_INVALID_ARG, "lc_keyframe_landmarks: the depth camera needs fx, fy, cx, cy");
+    cam.fx = h_K4[0], cam.fy = h_K4[1], cam.cx = h_K4[2], cam.cy = h_K4[3];
+  }
+  k_lc_landmarks<<<n_img, LC_T, 0, st>>>(cam, d_kps, d_desc, d_count, cap, next, status, (const uint16_t*)d_img1, d_lm_2d, d_lm_3d, d_lm_desc,
+                                         d_lm_count);
+  CHECK_LAUNCH(ctx, "lc_keyframe_landmarks");
   return FLVIS_OK;
 }
 

@@ -151,6 +151,18 @@ void flvis_voc_file_close(flvis_voc_file* voc);
  * vocabulary), so that no vector is ever truncated. */
 int flvis_hip_bow_transform(flvis_ctx* ctx, const uint8_t* d_desc, const int* d_count, int dcap, int n_img, int vcap, int* d_ids,
                             double* d_vals, int* d_nnz);
+/* STEP 1.5 / 1.6 of the loop-closing keyframe (vo_loopclosing.cpp:255-372) for n_img keyframes: the 3-D position of every ORB
+ * keypoint and the lists without the keypoints that have none.  cam_type as flvis_cfg.cam_type: 0 STEREO_RECT -- d_img0 / d_img1
+ * [n_img][h][w] mono8, calcOpticalFlowPyrLK(Size(31,31), 5, 30 / 0.001, USE_INITIAL_FLOW) from the keypoints into img1 (:274-278),
+ * then Triangulation::trignaulationPtFromStereo with the rectified 3x4 projections h_P0 / h_P1 (row-major; range 100);
+ * 2 DEPTH_D435 -- d_img1 [n_img][h][w] Z16, d = Z16 / 1000 as the INTEGER division the reference writes (:331), kept when
+ * 0.3 <= d <= 10, back-projected with h_K4 = fx, fy, cx, cy (d_img0 unused); 1 STEREO_UNRECT -- the reference's case is empty,
+ * every count is 0.  d_kps [n_img][cap][6] / d_desc [n_img][cap][32] / d_count as flvis_hip_orb_detect_and_compute leaves them
+ * (cap <= 2048).  Out, order kept: d_lm_2d [n_img][cap][2] float, d_lm_3d [n_img][cap][3] double (camera frame), d_lm_desc
+ * [n_img][cap][32] (may alias d_desc), d_lm_count [n_img]. */
+int flvis_hip_lc_keyframe_landmarks(flvis_ctx* ctx, const uint8_t* d_img0, const void* d_img1, int w, int h, int n_img, int cam_type,
+                                    const double* h_P0, const double* h_P1, const double* h_K4, const float* d_kps, const uint8_t* d_desc,
+                                    const int* d_count, int cap, float* d_lm_2d, double* d_lm_3d, uint8_t* d_lm_desc, int* d_lm_count);
 /* one row of the similarity matrix (vo_loopclosing.cpp:417-437): voc.score(query, db[j]) for j < n_db (ScoringObject.cpp:23-68);
  * the query is one vector on the device (d_q_nnz[0] entries), the database [n_db][vcap]; d_db_nnz[j] < 0 marks an absent keyframe
  * (kf_lc_tmp[j] == nullptr: score 0). */

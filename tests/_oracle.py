@@ -483,3 +483,25 @@ def orb_match(a, b, ratio_max):
     f.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_double, C.POINTER(C.c_int)]
     n = f(_p(a, C.c_uint8), len(a), _p(b, C.c_uint8), len(b), float(ratio_max), _p(pairs, C.c_int))
     return pairs[:n].copy()
+
+
+def lc_keyframe_landmarks(img0, img1, cam_type, kps, desc, P0=None, P1=None, K4=None):
+    """ref_lc_keyframe_landmarks (vo_loopclosing.cpp:255-372): -> (lm_2d [k,2] float32, lm_3d [k,3], lm_desc [k,32])"""
+    kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 6)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n = len(kps)
+    i1 = None if img1 is None else np.ascontiguousarray(img1, np.uint16 if cam_type == 2 else np.uint8)
+    i0 = None if img0 is None else np.ascontiguousarray(img0, np.uint8)
+    h, w = (i0 if i0 is not None else i1).shape
+    dd = lambda a, m: None if a is None else np.ascontiguousarray(a, np.float64).reshape(m)
+    p0, p1, k4 = dd(P0, 12), dd(P1, 12), dd(K4, 4)
+    lm2 = np.zeros((max(n, 1), 2), np.float32)
+    lm3 = np.zeros((max(n, 1), 3), np.float64)
+    lmd = np.zeros((max(n, 1), 32), np.uint8)
+    f = lib().ref_lc_keyframe_landmarks
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                  C.c_void_p, C.c_void_p, C.c_void_p]
+    ptr = lambda a: None if a is None else a.ctypes.data
+    k = f(ptr(i0), ptr(i1), w, h, int(cam_type), ptr(p0), ptr(p1), ptr(k4), ptr(kps), ptr(desc), n, ptr(lm2), ptr(lm3), ptr(lmd))
+    return lm2[:k].copy(), lm3[:k].copy(), lmd[:k].copy()

@@ -258,6 +258,55 @@ def test_loop_verification_chain_on_device(ctx):
     assert np.degrees(np.arccos(np.clip((np.trace(R @ R_gt.T) - 1) / 2, -1, 1))) < 0.5 and np.linalg.norm(t - (ttb - R_gt @ tta)) < 0.03
 
 
+def test_lc_keyframe_landmarks_parity(ctx):
+    """STEP 1.5 / 1.6 of the loop-closing keyframe (vo_loopclosing.cpp:255-372): ORB keypoints -> stereo LK + DLT (or the depth image)
+    -> the lists without the keypoints that got no position.  Kept set, order, 2-D and descriptors exact; 3-D as the tracker's DLT."""
+    import os
+    import tempfile
+    import torch
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_lckf_gpu.yaml")
+    open(p, "w").write(synth.D435I_STEREO_YAML)
+    cfg = O.load_config(p)
+    P0, P1 = np.array(list(cfg.P0)), np.array(list(cfg.P1))
+    K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
+    trs = [synth.Trajectory(5), synth.Trajectory(9)]
+    rnd = synth.Renderer("cuda")
+    i0, i1 = rnd.stereo_frame(trs, 1.0, 20)
+    kps, desc, cnt, _ = ctx.orb_detect_and_compute(i0, cap=1024)
+    hk, hd, hc = kps.cpu().numpy(), desc.cpu().numpy(), cnt.cpu().numpy()
+    # (a) rectified stereo, two keyframes per call
+    lm2, lm3, lmd, lmc = [t.cpu().numpy() for t in ctx.lc_keyframe_landmarks(i0, i1, 0, kps, desc, cnt, P0=P0, P1=P1)]
+    for s in range(2):
+        w2, w3, wd = O.lc_keyframe_landmarks(i0[s].cpu().numpy(), i1[s].cpu().numpy(), 0, hk[s, :hc[s]], hd[s, :hc[s]], P0, P1)
+        assert lmc[s] == len(w2) and 100 < len(w2) <= hc[s], (s, lmc[s], len(w2), hc[s])
+        assert np.array_equal(lm2[s, :lmc[s]], w2) and np.array_equal(lmd[s, :lmc[s]], wd)
+        assert np.abs(lm3[s, :lmc[s]] - w3).max() <= 1e-9 * max(1.0, np.abs(w3).max()), np.abs(lm3[s, :lmc[s]] - w3).max()
+    # (b) the depth camera: Z16 image, whole metres as the reference's integer division leaves them
+    j0, d16 = rnd.depth_frame(trs, 1.0, 20)
+    hz = d16.cpu().numpy().view(np.uint16)
+    m2, m3, md, mc = [t.cpu().numpy() for t in ctx.lc_keyframe_landmarks(None, d16, 2, kps, desc, cnt, K4=K4)]
+    for s in range(2):
+        w2, w3, wd = O.lc_keyframe_landmarks(None, hz[s], 2, hk[s, :hc[s]], hd[s, :hc[s]], K4=K4)
+        assert mc[s] == len(w2) and len(w2) > 50
+        assert np.array_equal(m2[s, :mc[s]], w2) and np.array_equal(md[s, :mc[s]], wd) and np.array_equal(m3[s, :mc[s]], w3)
+        assert set(np.unique(w3[:, 2])) <= set(float(v) for v in range(1, 11))
+    # (c) unrectified stereo: the reference's case is empty
+    assert ctx.lc_keyframe_landmarks(i0, i1, 1, kps, desc, cnt)[3].cpu().numpy().tolist() == [0, 0]
+    # (d) descriptors compacted in place
+    d2 = desc.clone()
+    q2, q3, qd, qc = ctx.lc_keyframe_landmarks(i0, i1, 0, kps, d2, cnt, P0=P0, P1=P1, in_place=True)
+    assert qd.data_ptr() == d2.data_ptr() and np.array_equal(qc.cpu().numpy(), lmc)
+    for s in range(2):
+        assert np.array_equal(d2[s, :lmc[s]].cpu().numpy(), lmd[s, :lmc[s]])
+    # (e) the kept lists feed solvePnPRansac directly (float positions, as cv::Point3f in isLoopClosureKF :643-650)
+    pose, mask, ninl = ctx.pnp_ransac(torch.from_numpy(lm3.astype(np.float32)).cuda(), torch.from_numpy(lm2).cuda(),
+                                      torch.from_numpy(lmc).cuda(), K4, [3, 4])
+    assert int(ninl.min()) > 0.8 * int(lmc.min())                        # a keyframe against itself: identity pose
+    hp = pose.cpu().numpy()
+    assert np.abs(hp[:, :3]).max() < 0.02 and np.abs(np.abs(hp[:, 6]) - 1).max() < 1e-3, hp
+
+
 def test_loop_entry_points_reject_bad_input(ctx):
     """capacities and argument checks of the loop-closing entry points fail loudly (error code + message), nothing is launched"""
     import ctypes as C
@@ -281,3 +330,17 @@ def test_loop_entry_points_reject_bad_input(ctx):
     p2 = torch.zeros((1, 2048, 2), dtype=torch.float32, device="cuda")
     with pytest.raises(flvis_amd.FlvisError):
         ctx.pnp_ransac(p3, p2, torch.zeros(1, dtype=torch.int32, device="cuda"), [1.0, 1.0, 0.0, 0.0], [1])   # > 1024 correspondences
+    kp = torch.zeros((1, 64, 6), dtype=torch.float32, device="cuda")
+    dd = torch.zeros((1, 64, 32), dtype=torch.uint8, device="cuda")
+    c1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    im = torch.zeros((1, 64, 64), dtype=torch.uint8, device="cuda")
+    with pytest.raises(flvis_amd.FlvisError) as e:
+        ctx.lc_keyframe_landmarks(im, im, 0, kp, dd, c1)                          # stereo without projection matrices
+    assert "P0 and P1" in str(e.value)
+    with pytest.raises(flvis_amd.FlvisError):
+        ctx.lc_keyframe_landmarks(im, im, 3, kp, dd, c1)                          # no such camera type
+    with pytest.raises(flvis_amd.FlvisError):
+        ctx.lc_keyframe_landmarks(None, im, 2, kp, dd, c1)                        # depth camera without intrinsics
+    with pytest.raises(flvis_amd.FlvisError):
+        ctx.lc_keyframe_landmarks(im, im, 1, torch.zeros((1, 4096, 6), dtype=torch.float32, device="cuda"),
+                                  torch.zeros((1, 4096, 32), dtype=torch.uint8, device="cuda"), c1)   # > 2048 keypoints
