@@ -200,10 +200,9 @@ def test_pnp_ransac_sets_parity(ctx):
 
 
 def test_loop_verification_chain_on_device(ctx):
-    """isLoopClosureKF (vo_loopclosing.cpp:593-700) with the device kernels: ORB of both keyframes, knn x2 + mutual/ratio test,
-    solvePnPRansac on the matches that have a 3-D point, the acceptance rule -- beside the same chain assembled from the oracle
-    (tests/test_oracle_loop_verification.py).  The 3-D points of the earlier keyframe come from the oracle here (stereo LK + DLT of the
-    ORB keypoints, :283-306: arithmetic the tracker's kernels cover, not exposed per keypoint)."""
+    """isLoopClosureKF (vo_loopclosing.cpp:593-700) with the device kernels, no host step in between: ORB of both keyframes, their 3-D
+    positions and compacted lists (flvis_hip_lc_keyframe_landmarks), knn x2 + mutual/ratio test on the compacted descriptors,
+    solvePnPRansac on (3-D of the earlier keyframe, pixel in the current one), the acceptance rule -- each stage beside the oracle's."""
     import os
     import tempfile
     import torch
@@ -218,39 +217,38 @@ def test_loop_verification_chain_on_device(ctx):
     rnd = synth.Renderer("cuda")
     ta, tb = 1.0, 1.6
     a0, a1 = [x[0] for x in rnd.stereo_frame([tr], ta, 20)]
-    b0, _ = [x[0] for x in rnd.stereo_frame([tr], tb, 32)]
-    kps, desc, cnt, ovf = ctx.orb_detect_and_compute(torch.stack([a0, b0]), cap=1024)
+    b0, b1 = [x[0] for x in rnd.stereo_frame([tr], tb, 32)]
+    i0, i1 = torch.stack([a0, b0]), torch.stack([a1, b1])
+    kps, desc, cnt, ovf = ctx.orb_detect_and_compute(i0, cap=1024)
     hk, hd, hc = kps.cpu().numpy(), desc.cpu().numpy(), cnt.cpu().numpy()
     ka, da = O.orb_detect_and_compute(a0.cpu().numpy())
     kb, db = O.orb_detect_and_compute(b0.cpu().numpy())
     assert hc[0] == len(ka) and hc[1] == len(kb) and np.array_equal(hd[0, :hc[0]], da) and np.array_equal(hd[1, :hc[1]], db)
-    pairs, npairs = ctx.orb_match(desc[0:1], cnt[0:1], desc[1:2], cnt[1:2], 0.8)
-    pairs = pairs.cpu().numpy()[0, :int(npairs[0])]
-    assert np.array_equal(pairs, np.array(O.orb_match(da, db, 0.8)))
-    # 3-D of keyframe 0's ORB points (oracle: 5-level stereo LK from the same pixel + DLT, valid range of trignaulationPtFromStereo)
-    pts = ka[:, :2].copy()
-    nxt, st = O.lk(a0.cpu().numpy(), a1.cpu().numpy(), pts, pts, max_level=5)
-    p3d = np.zeros((len(ka), 3))
-    has3d = np.zeros(len(ka), bool)
-    for i in range(len(ka)):
-        if st[i] == 1:
-            pc = O.triangulate_dlt(pts[i].astype(np.float64), nxt[i].astype(np.float64), P0, P1)
-            if 0 < pc[2] < 20:
-                p3d[i], has3d[i] = pc, True
-    sel = np.array([pr for pr in pairs if has3d[pr[0]]])
-    assert len(sel) >= 60
+    # KeyFrameLC of both: lm_2d / lm_3d / lm_descriptor without the keypoints that have no 3-D position
+    lm2, lm3, lmd, lmc = ctx.lc_keyframe_landmarks(i0, i1, 0, kps, desc, cnt, P0=P0, P1=P1)
+    h2, h3, hdd, hcc = lm2.cpu().numpy(), lm3.cpu().numpy(), lmd.cpu().numpy(), lmc.cpu().numpy()
+    wa = O.lc_keyframe_landmarks(a0.cpu().numpy(), a1.cpu().numpy(), 0, ka, da, P0, P1)
+    wb = O.lc_keyframe_landmarks(b0.cpu().numpy(), b1.cpu().numpy(), 0, kb, db, P0, P1)
+    for s, wk in enumerate((wa, wb)):
+        assert hcc[s] == len(wk[0]) and np.array_equal(h2[s, :hcc[s]], wk[0]) and np.array_equal(hdd[s, :hcc[s]], wk[2])
+        assert np.abs(h3[s, :hcc[s]] - wk[1]).max() <= 1e-9 * np.abs(wk[1]).max()
+    pairs, npairs = ctx.orb_match(lmd[0:1], lmc[0:1], lmd[1:2], lmc[1:2], 0.8)
+    m = int(npairs[0])
+    hp = pairs.cpu().numpy()[0, :m]
+    assert np.array_equal(hp, np.array(O.orb_match(wa[2], wb[2], 0.8))) and m >= 60
+    # gather on the device: cv::Point3f(kf0->lm_3d[queryIdx]), cv::Point2f(kf1->lm_2d[trainIdx])   (:643-652)
     cap = 1024
-    d3 = np.zeros((1, cap, 3), np.float32)
-    d2 = np.zeros((1, cap, 2), np.float32)
-    d3[0, :len(sel)] = p3d[sel[:, 0]]
-    d2[0, :len(sel)] = hk[1, sel[:, 1], :2]
-    pose, mask, ninl = ctx.pnp_ransac(torch.from_numpy(d3).cuda(), torch.from_numpy(d2).cuda(),
-                                      torch.tensor([len(sel)], dtype=torch.int32, device="cuda"), K4, [11])
-    n_want, pose_want, mask_want = O.solve_pnp_ransac(p3d[sel[:, 0]], kb[sel[:, 1], :2], K4, iterative=False, iterations=100, reproj=2.0,
+    qi, ti = pairs[0, :m, 0].long(), pairs[0, :m, 1].long()
+    d3 = torch.zeros((1, cap, 3), dtype=torch.float32, device="cuda")
+    d2 = torch.zeros((1, cap, 2), dtype=torch.float32, device="cuda")
+    d3[0, :m] = lm3[0, qi].float()
+    d2[0, :m] = lm2[1, ti]
+    pose, mask, ninl = ctx.pnp_ransac(d3, d2, torch.tensor([m], dtype=torch.int32, device="cuda"), K4, [11])
+    n_want, pose_want, mask_want = O.solve_pnp_ransac(h3[0, hp[:, 0]], h2[1, hp[:, 1]], K4, iterative=False, iterations=100, reproj=2.0,
                                                       conf=0.99, seed=11)
     n_inl = int(ninl[0])
-    assert n_inl == n_want and np.array_equal(pose.cpu().numpy()[0], pose_want) and np.array_equal(mask.cpu().numpy()[0, :len(sel)], mask_want)
-    assert n_inl >= 20 and n_inl / len(sel) >= 0.5                      # acceptance rule (:677-686, ratioRansac 0.5, minPts 20)
+    assert n_inl == n_want and np.array_equal(pose.cpu().numpy()[0], pose_want) and np.array_equal(mask.cpu().numpy()[0, :m], mask_want)
+    assert n_inl >= 20 and n_inl / m >= 0.5                            # acceptance rule (:677-686, ratioRansac 0.5, minPts 20)
     Ra, tta = tr.T_c_w(ta)
     Rb, ttb = tr.T_c_w(tb)
     R_gt = Rb @ Ra.T
