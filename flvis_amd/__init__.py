@@ -452,6 +452,103 @@ def _P(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+class LcParams(C.Structure):
+    """flvis_lc_params of include/flvis_hip.h (LC_PARAS, vo_loopclosing.cpp:86-97)."""
+    _fields_ = [("lcKFStart", C.c_int), ("lcKFDist", C.c_int), ("lcKFMaxDist", C.c_int), ("lcKFLast", C.c_int), ("lcNKFClosest", C.c_int),
+                ("minPts", C.c_int), ("ratioMax", C.c_double), ("ratioRansac", C.c_double), ("minScore", C.c_double)]
+
+
+class LcEvent(C.Structure):
+    """flvis_lc_event of include/flvis_hip.h."""
+    _fields_ = [("kf_prev", C.c_int64), ("kf_curr", C.c_int64), ("candidate", C.c_int), ("n_matches", C.c_int), ("n_inliers", C.c_int),
+                ("loop_accepted", C.c_int), ("optimised", C.c_int), ("pgo_iterations", C.c_int), ("loop_pose7", C.c_double * 7),
+                ("chi2_before", C.c_double), ("chi2_after", C.c_double)]
+
+
+def load_lc_params(yaml_path):
+    """flvis_lc_params_load: the loop-closing block of the reference's yaml files.  Host-only."""
+    prm = LcParams()
+    err = C.create_string_buffer(256)
+    rc = load_library().flvis_lc_params_load(os.fsencode(yaml_path), C.byref(prm), err, 256)
+    if rc != FLVIS_OK:
+        raise FlvisError("flvis_lc_params_load(%s) failed (%d): %s" % (yaml_path, rc, err.value.decode()))
+    return prm
+
+
+class LoopCloser:
+    """flvis_loop_closer: LoopClosingNodeletClass (vo_loopclosing.cpp) for n_streams sequences; the keyframe database stays on the GPU."""
+
+    def __init__(self, ctx, cfg, prm, n_streams=1, max_keyframes=2000, orb_pattern=None):
+        import numpy as np
+        self._ctx, self._lib, self.n_streams = ctx, ctx._lib, n_streams
+        if isinstance(prm, dict):
+            prm = LcParams(**prm)
+        pat = None
+        if orb_pattern is not None:
+            pat = np.ascontiguousarray(orb_pattern, np.int8)
+            assert pat.size == 1024
+        h = C.c_void_p(0)
+        ctx._check(self._lib.flvis_loop_closer_create(ctx._h, C.byref(cfg), C.byref(prm), int(n_streams), int(max_keyframes),
+                                                      C.c_void_p(pat.ctypes.data if pat is not None else 0), C.byref(h)), "loop_closer_create")
+        self._h = h
+        self._lib.flvis_loop_closer_destroy.argtypes = [C.c_void_p]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.flvis_loop_closer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_keyframes(self, streams, img0, img1, T_c_w_odom):
+        """streams: the sequence of each keyframe (distinct); img0 uint8 [n,h,w], img1 uint8 / Z16 [n,h,w] (device); T_c_w_odom [n,7].
+        Returns the keyframes' indices in their sequences."""
+        import numpy as np
+        st = np.ascontiguousarray(streams, np.int32)
+        n = len(st)
+        T = np.ascontiguousarray(T_c_w_odom, np.float64).reshape(n, 7)
+        img0 = img0.contiguous()
+        img1 = img1.contiguous() if img1 is not None else None
+        assert img0.shape[0] == n
+        ids = np.zeros(n, np.int64)
+        self._ctx._check(self._lib.flvis_loop_closer_add_keyframes(self._h, n, _P(st, C.c_int), _ptr(img0), _ptr(img1), _P(T, C.c_double),
+                                                                   _P(ids, C.c_int64)), "loop_closer_add_keyframes")
+        return ids
+
+    def process(self):
+        """-> list of n_streams dicts (flvis_lc_event)"""
+        ev = (LcEvent * self.n_streams)()
+        self._ctx._check(self._lib.flvis_loop_closer_process(self._h, ev), "loop_closer_process")
+        return [dict(kf_prev=int(e.kf_prev), kf_curr=int(e.kf_curr), candidate=bool(e.candidate), n_matches=e.n_matches,
+                     n_inliers=e.n_inliers, accepted=bool(e.loop_accepted), optimised=bool(e.optimised), pgo_iterations=e.pgo_iterations,
+                     pose=[float(x) for x in e.loop_pose7], chi2_before=e.chi2_before, chi2_after=e.chi2_after) for e in ev]
+
+    def poses(self, stream=0, cap=1 << 16):
+        import numpy as np
+        n = C.c_int(0)
+        buf = np.zeros((cap, 7))
+        self._ctx._check(self._lib.flvis_loop_closer_poses(self._h, int(stream), _P(buf, C.c_double), cap, C.byref(n)), "loop_closer_poses")
+        return buf[:n.value].copy()
+
+    def drift(self, stream=0):
+        import numpy as np
+        T = np.zeros(7)
+        self._ctx._check(self._lib.flvis_loop_closer_drift(self._h, int(stream), _P(T, C.c_double)), "loop_closer_drift")
+        return T
+
+    def similarity_row(self, stream=0, cap=1 << 16):
+        import numpy as np
+        n = C.c_int(0)
+        buf = np.zeros(cap)
+        self._ctx._check(self._lib.flvis_loop_closer_similarity_row(self._h, int(stream), _P(buf, C.c_double), cap, C.byref(n)),
+                         "loop_closer_similarity_row")
+        return buf[:n.value].copy()
+
+
 class Tracker:
     """Batched F2FTracking + LocalMap for n_streams independent streams on one GPU (flvis_tracker_create)."""
 

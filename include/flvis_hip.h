@@ -392,6 +392,50 @@ int flvis_ba_push_keyframe_imu(flvis_ctx* ctx, int stream, int64_t frame_id, con
                                int cap, int64_t* out_frame_id, double* out_T_c_w7, int* out_lm_count, int64_t* out_lm_id,
                                double* out_lm_3d, int* out_outlier_count, int64_t* out_outlier_id);
 
+/* ---- the loop-closing nodelet's control flow for a batch of independent sequences --------------------------------
+ * LoopClosingNodeletClass (src/backend/vo_loopclosing.cpp:118-1119) without ROS: the keyframe database stays on the device.
+ *   flvis_lc_params_load             <- onInit's LC_PARAS block                  :955-963
+ *   flvis_loop_closer_create         <- onInit (camera from the same yaml, vocabulary already in the context: :1095-1101)
+ *   flvis_loop_closer_add_keyframes  <- frame_callback + kfmsgProcess            :178-391
+ *   flvis_loop_closer_process        <- one pass of pgoProcess per new keyframe  :393-518 (+ :520-944)
+ * The reference's pgoProcess thread polls the newest keyframe (a keyframe may be examined twice or never); here every keyframe is
+ * examined exactly once, in order. */
+typedef struct flvis_lc_params {
+  int lcKFStart, lcKFDist, lcKFMaxDist, lcKFLast, lcNKFClosest, minPts; /* lcKFStart / lcKFLast are read but unused by the reference too */
+  double ratioMax, ratioRansac, minScore;
+} flvis_lc_params;
+typedef struct flvis_lc_event {
+  int64_t kf_prev, kf_curr;  /* kf_curr = -1: the sequence had no new keyframe; kf_prev = -1: no candidate */
+  int candidate;             /* isLoopCandidate */
+  int n_matches, n_inliers;  /* mutual + ratio matches (p3d.size()), inliers of solvePnPRansac */
+  int loop_accepted;         /* isLoopClosureKF: the loop went into loop_ids / loop_poses */
+  int optimised;             /* loopClosureOnCovGraphG2ONew ran (:492-497) */
+  int pgo_iterations;
+  double loop_pose7[7];      /* se_ji (tx ty tz qx qy qz qw): the later keyframe's camera from the earlier one's */
+  double chi2_before, chi2_after;
+} flvis_lc_event;
+typedef struct flvis_loop_closer flvis_loop_closer;
+int flvis_lc_params_load(const char* yaml_path, flvis_lc_params* prm, char* err, int errlen);
+/* cfg: flvis_config_load of the same yaml (image size, cam_type, rectified P0 / P1); the vocabulary must be resident
+ * (flvis_hip_bow_load_vocabulary).  max_keyframes slots per sequence are allocated up front (76 KB each).  h_orb_pattern: see
+ * flvis_hip_orb_detect_and_compute (NULL = the built-in pattern). */
+int flvis_loop_closer_create(flvis_ctx* ctx, const flvis_cfg* cfg, const flvis_lc_params* prm, int n_streams, int max_keyframes,
+                             const int8_t* h_orb_pattern, flvis_loop_closer** out);
+void flvis_loop_closer_destroy(flvis_loop_closer* lc);
+/* one keyframe for each of the n sequences h_stream[i] (distinct): d_img0 [n][h][w] mono8, d_img1 [n][h][w] mono8 (stereo) or Z16
+ * (depth camera), h_T_c_w_odom7 [n][7] the tracker's pose of the keyframe (KeyFrame.msg T_c_w).  h_kf_id (optional): the keyframe's
+ * index in its sequence. */
+int flvis_loop_closer_add_keyframes(flvis_loop_closer* lc, int n, const int* h_stream, const uint8_t* d_img0, const void* d_img1,
+                                    const double* h_T_c_w_odom7, int64_t* h_kf_id);
+/* examines the newest keyframe of every sequence that got one since the last call; h_events [n_streams] */
+int flvis_loop_closer_process(flvis_loop_closer* lc, flvis_lc_event* h_events);
+/* kf_map_lc[i]->T_c_w of one sequence (host, [cap][7]); *n_out = keyframes in the sequence */
+int flvis_loop_closer_poses(flvis_loop_closer* lc, int stream, double* h_T_c_w7, int cap, int* n_out);
+/* T_odom_map (:138, the tf map -> odom the nodelet broadcasts is its inverse) */
+int flvis_loop_closer_drift(flvis_loop_closer* lc, int stream, double* h_T_odom_map7);
+/* the newest row of the sequence's similarity matrix as the last flvis_loop_closer_process computed it */
+int flvis_loop_closer_similarity_row(flvis_loop_closer* lc, int stream, double* h_row, int cap, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,104 @@
+"""GPU: flvis_loop_closer (the loop-closing nodelet's control flow around the device kernels, keyframe database resident in HBM)
+against the same control flow assembled from the CPU oracle's functions (tests/_loop_chain.py), for two sequences at once that both
+return to where they started.  The per-keyframe features the oracle chain works on are the device's (each kernel has its own
+parity test in test_gpu_orb.py / test_gpu_loop.py); compared here is everything downstream: similarity rows, candidates, matches,
+PnP poses and inliers, accepted loops, when the pose graph is optimised, the optimised poses and the map -> odom correction."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import _geom as G
+import _loop_chain as LC
+import _pgo_synth as PS
+import _voc as V
+
+pytestmark = pytest.mark.gpu
+
+
+def test_loop_closer_two_sequences_against_the_oracle_chain():
+    import torch
+    import flvis_amd
+    from flvis_amd import synth
+    ctx = flvis_amd.Context(0)
+    p = os.path.join(tempfile.gettempdir(), "flvis_loopcloser_gpu.yaml")
+    open(p, "w").write(synth.D435I_STEREO_YAML)
+    cfg = flvis_amd.load_config(p)
+    P0, P1 = np.array(list(cfg.P0)), np.array(list(cfg.P1))
+    K4 = np.array([P0[0], P0[5], P0[2], P0[6]])
+    trs = [LC.LoopTrajectory(phase=0.0), LC.LoopTrajectory(phase=0.9)]
+    rnd = synth.Renderer("cuda")
+    n_kf, per = 62, 50
+    times = LC.keyframe_times(n_kf, per)
+    frames = [rnd.stereo_frame(trs, t, i) for i, t in enumerate(times)]
+    gt = [[G.pose7(*tr.T_c_w(t, rnd.rig)) for t in times] for tr in trs]
+    odom = [LC.drifted_odometry(gt[s], 10 + s, sigma_t=0.008, sigma_r=0.002) for s in range(2)]
+    # vocabulary from the device's descriptors of every sixth keyframe of sequence 0
+    train = []
+    for i in range(0, n_kf, 6):
+        k, d, c, _ = ctx.orb_detect_and_compute(frames[i][0][0:1], cap=1024)
+        train.append(d[0, :int(c[0])].cpu().numpy())
+    voc = V.build_vocabulary(train, k=8, depth=3)
+    ctx.bow_set_vocabulary(*voc)
+    with pytest.raises(flvis_amd.FlvisError):                                   # capacity is checked, nothing is overwritten
+        flvis_amd.LoopCloser(ctx, cfg, LC.LC_PARAMS, n_streams=2, max_keyframes=0)
+    lc = flvis_amd.LoopCloser(ctx, cfg, LC.LC_PARAMS, n_streams=2, max_keyframes=64)
+    ref = [LC.RefLoopCloser(K4, stream=s) for s in range(2)]
+    n_added = [0, 0]
+    log = [[], []]
+    for i in range(n_kf):
+        i0, i1 = frames[i]
+        # sequence 1 misses every ninth call (keyframes of different sequences do not arrive in step)
+        streams = [0] if i % 9 == 4 else [0, 1]
+        sel = torch.tensor(streams, device="cuda")
+        a0, a1 = i0[sel].contiguous(), i1[sel].contiguous()
+        T = np.array([odom[s][n_added[s]] if s == 0 else odom[s][i] for s in streams])
+        ids = lc.add_keyframes(streams, a0, a1, T)
+        assert ids.tolist() == [n_added[s] for s in streams]
+        # the same keyframes through the separate entry points, for the oracle chain
+        kps, desc, cnt, _ = ctx.orb_detect_and_compute(a0, cap=1024)
+        bi, bv, bn = [t.cpu().numpy() for t in ctx.bow_transform(desc, cnt, vcap=1024)]
+        lm2, lm3, lmd, lmc = [t.cpu().numpy() for t in ctx.lc_keyframe_landmarks(a0, a1, 0, kps, desc, cnt, P0=P0, P1=P1)]
+        for j, s in enumerate(streams):
+            ref[s].add(dict(bow=(bi[j, :bn[j]].copy(), bv[j, :bn[j]].copy()), lm2=lm2[j, :lmc[j]].copy(), lm3=lm3[j, :lmc[j]].copy(),
+                            lmd=lmd[j, :lmc[j]].copy()), T[j])
+            n_added[s] += 1
+        ev = lc.process()
+        for s in range(2):
+            if s not in streams:
+                assert ev[s]["kf_curr"] == -1 and not ev[s]["candidate"]
+                continue
+            want = ref[s].process()
+            got = ev[s]
+            row = lc.similarity_row(s)
+            assert np.array_equal(row, ref[s].rows[-1]), (i, s, np.abs(row - ref[s].rows[-1]).max())
+            for key in ("kf_curr", "kf_prev", "candidate", "n_matches", "n_inliers", "accepted", "optimised"):
+                assert got[key] == want[key], (i, s, key, got, want)
+            if want["pose"] is not None:
+                assert np.array_equal(np.array(got["pose"]), want["pose"]), (i, s)
+            log[s].append(got)
+        for s in streams:
+            Tg, Tw = lc.poses(s), np.array(ref[s].T_c_w)
+            assert Tg.shape == Tw.shape and np.abs(Tg - Tw).max() < 1e-7, (i, s, np.abs(Tg - Tw).max())
+            assert np.abs(lc.drift(s) - ref[s].T_odom_map).max() < 1e-7
+    for s in range(2):
+        n = n_added[s]
+        closing = [e for e in log[s] if e["accepted"] and e["kf_curr"] - e["kf_prev"] >= 40]
+        assert len(closing) >= 2 and any(e["optimised"] for e in log[s]), (s, [(e["kf_prev"], e["kf_curr"]) for e in log[s] if e["accepted"]])
+        od = np.array(odom[s][:n] if s == 0 else [odom[s][i] for i in range(n_kf) if i % 9 != 4])
+        g = np.array(gt[s][:n] if s == 0 else [gt[s][i] for i in range(n_kf) if i % 9 != 4])
+        gap0, gap1 = PS.loop_gap(od, g, 2, n - 1), PS.loop_gap(lc.poses(s), g, 2, n - 1)
+        assert gap1[0] < 0.5 * gap0[0], (s, gap0, gap1)
+    # a full sequence refuses the next keyframe instead of overwriting
+    small = flvis_amd.LoopCloser(ctx, cfg, LC.LC_PARAMS, n_streams=1, max_keyframes=2)
+    for k in range(2):
+        small.add_keyframes([0], frames[k][0][0:1], frames[k][1][0:1], [odom[0][k]])
+    with pytest.raises(flvis_amd.FlvisError) as e:
+        small.add_keyframes([0], frames[2][0][0:1], frames[2][1][0:1], [odom[0][2]])
+    assert "capacity" in str(e.value)
+    with pytest.raises(flvis_amd.FlvisError):
+        lc.add_keyframes([0, 0], frames[0][0], frames[0][1], [odom[0][0], odom[0][0]])   # two keyframes for one sequence in one call
+    small.close()
+    lc.close()
+    ctx.close()
