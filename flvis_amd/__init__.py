@@ -452,6 +452,12 @@ def _P(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+class FlvisImage(C.Structure):
+    """flvis_image of include/flvis_hip.h: one host image (pitch in bytes)."""
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("width", C.c_int), ("height", C.c_int), ("pitch", C.c_int), ("channels", C.c_int),
+                ("t", C.c_double)]
+
+
 class LcParams(C.Structure):
     """flvis_lc_params of include/flvis_hip.h (LC_PARAS, vo_loopclosing.cpp:86-97)."""
     _fields_ = [("lcKFStart", C.c_int), ("lcKFDist", C.c_int), ("lcKFMaxDist", C.c_int), ("lcKFLast", C.c_int), ("lcNKFClosest", C.c_int),
@@ -517,6 +523,26 @@ class LoopCloser:
         ids = np.zeros(n, np.int64)
         self._ctx._check(self._lib.flvis_loop_closer_add_keyframes(self._h, n, _P(st, C.c_int), _ptr(img0), _ptr(img1), _P(T, C.c_double),
                                                                    _P(ids, C.c_int64)), "loop_closer_add_keyframes")
+        return ids
+
+    def add_keyframes_host(self, streams, img0, img1, T_c_w_odom):
+        """flvis_loop_closer_add_keyframes_host: numpy images [n,h,w(+padding)]; img0 uint8, img1 uint8 or uint16 (depth rig).  A
+        2-D-strided view (rows padded) is passed with its pitch."""
+        import numpy as np
+        st = np.ascontiguousarray(streams, np.int32)
+        n = len(st)
+        T = np.ascontiguousarray(T_c_w_odom, np.float64).reshape(n, 7)
+        ids = np.zeros(n, np.int64)
+        a = (FlvisImage * n)()
+        b = (FlvisImage * n)()
+        keep = []
+        for i in range(n):
+            for arr, dst in ((img0[i], a), (img1[i], b)):
+                assert arr.ndim == 2 and arr.strides[1] == arr.itemsize
+                keep.append(arr)
+                dst[i] = FlvisImage(C.cast(C.c_void_p(arr.ctypes.data), C.POINTER(C.c_uint8)), arr.shape[1], arr.shape[0], arr.strides[0], 1, 0.0)
+        self._ctx._check(self._lib.flvis_loop_closer_add_keyframes_host(self._h, n, _P(st, C.c_int), a, b, _P(T, C.c_double), _P(ids, C.c_int64)),
+                         "loop_closer_add_keyframes_host")
         return ids
 
     def process(self):

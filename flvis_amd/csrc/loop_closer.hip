@@ -305,6 +305,33 @@ int flvis_loop_closer_add_keyframes(flvis_loop_closer* lc, int n, const int* h_s
   return FLVIS_OK;
 }
 
+// KeyFrameMsg::unpack (:206) hands the nodelet HOST images; this is the same call on host buffers: mono8 img0, mono8 or 16UC1 img1
+int flvis_loop_closer_add_keyframes_host(flvis_loop_closer* lc, int n, const int* h_stream, const flvis_image* h_img0, const flvis_image* h_img1,
+                                         const double* h_T_c_w_odom7, int64_t* h_kf_id) {
+  if (!lc) return FLVIS_ERR_INVALID_ARG;
+  flvis_ctx* ctx = lc->ctx;
+  if (n <= 0 || n > lc->S || !h_img0 || !h_img1) return ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_add_keyframes_host: bad args");
+  const int bpp1 = lc->cfg.cam_type == 2 ? 2 : 1;
+  const size_t px = (size_t)lc->w * lc->h;
+  hipSetDevice(ctx->device);
+  uint8_t* d0 = (uint8_t*)ctx->scratch("lc_host_img0", px * (size_t)lc->S);
+  uint8_t* d1 = (uint8_t*)ctx->scratch("lc_host_img1", px * 2 * (size_t)lc->S);
+  if (!d0 || !d1) return ctx->fail(FLVIS_ERR_HIP, "loop_closer_add_keyframes_host: staging allocation failed");
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < n && e == hipSuccess; i++) {
+    const flvis_image &a = h_img0[i], &b = h_img1[i];
+    if (!a.data || !b.data || a.width != lc->w || a.height != lc->h || b.width != lc->w || b.height != lc->h || a.channels != 1 || b.channels != 1 ||
+        a.pitch < lc->w || b.pitch < lc->w * bpp1)
+      return ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_add_keyframes_host: images must be mono8 (img1: 16UC1 on a depth rig) of the configured size");
+    e = hipMemcpy2DAsync(d0 + px * i, (size_t)lc->w, a.data, (size_t)a.pitch, (size_t)lc->w, (size_t)lc->h, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(d1 + px * bpp1 * i, (size_t)lc->w * bpp1, b.data, (size_t)b.pitch, (size_t)lc->w * bpp1, (size_t)lc->h,
+                           hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_add_keyframes_host");
+  return flvis_loop_closer_add_keyframes(lc, n, h_stream, d0, d1, h_T_c_w_odom7, h_kf_id);  // (it synchronises before it returns)
+}
+
 int flvis_loop_closer_process(flvis_loop_closer* lc, flvis_lc_event* h_events) {
   if (!lc) return FLVIS_ERR_INVALID_ARG;
   flvis_ctx* ctx = lc->ctx;

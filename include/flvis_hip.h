@@ -427,6 +427,9 @@ void flvis_loop_closer_destroy(flvis_loop_closer* lc);
  * index in its sequence. */
 int flvis_loop_closer_add_keyframes(flvis_loop_closer* lc, int n, const int* h_stream, const uint8_t* d_img0, const void* d_img1,
                                     const double* h_T_c_w_odom7, int64_t* h_kf_id);
+/* the same on HOST images (what KeyFrameMsg::unpack hands the nodelet, :206): h_img0[i] mono8, h_img1[i] mono8 or 16UC1, pitch in bytes */
+int flvis_loop_closer_add_keyframes_host(flvis_loop_closer* lc, int n, const int* h_stream, const flvis_image* h_img0,
+                                         const flvis_image* h_img1, const double* h_T_c_w_odom7, int64_t* h_kf_id);
 /* examines the newest keyframe of every sequence that got one since the last call; h_events [n_streams] */
 int flvis_loop_closer_process(flvis_loop_closer* lc, flvis_lc_event* h_events);
 /* kf_map_lc[i]->T_c_w of one sequence (host, [cap][7]); *n_out = keyframes in the sequence */

@@ -90,6 +90,16 @@ def test_loop_closer_two_sequences_against_the_oracle_chain():
         g = np.array(gt[s][:n] if s == 0 else [gt[s][i] for i in range(n_kf) if i % 9 != 4])
         gap0, gap1 = PS.loop_gap(od, g, 2, n - 1), PS.loop_gap(lc.poses(s), g, 2, n - 1)
         assert gap1[0] < 0.5 * gap0[0], (s, gap0, gap1)
+    # the same keyframes handed over as HOST images with padded rows (what the nodelet unpacks from KeyFrame.msg): same similarity row
+    hostlc = flvis_amd.LoopCloser(ctx, cfg, LC.LC_PARAMS, n_streams=1, max_keyframes=4)
+    for k in range(3):
+        pad = [np.zeros((480, 704), np.uint8) for _ in range(2)]
+        pad[0][:, :640], pad[1][:, :640] = frames[k][0][0].cpu().numpy(), frames[k][1][0].cpu().numpy()
+        assert hostlc.add_keyframes_host([0], [pad[0][:, :640]], [pad[1][:, :640]], [odom[0][k]]).tolist() == [k]
+        hostlc.process()
+    assert np.array_equal(hostlc.similarity_row(0), ref[0].rows[2])
+    assert np.abs(hostlc.poses(0) - np.array(odom[0][:3])).max() < 1e-12        # T_odom_map is still the identity
+    hostlc.close()
     # a full sequence refuses the next keyframe instead of overwriting
     small = flvis_amd.LoopCloser(ctx, cfg, LC.LC_PARAMS, n_streams=1, max_keyframes=2)
     for k in range(2):
