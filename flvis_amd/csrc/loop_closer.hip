@@ -149,7 +149,7 @@ struct flvis_loop_closer {
   uint8_t *desc = nullptr, *da = nullptr, *db = nullptr, *mask = nullptr;
   int *cnt = nullptr, *ovf = nullptr, *ids = nullptr, *nnz = nullptr, *lmc = nullptr, *slot_a = nullptr, *slot_b = nullptr, *na = nullptr,
       *nb = nullptr, *pairs = nullptr, *npairs = nullptr, *ninl = nullptr;
-  double *vals = nullptr, *lm3 = nullptr, *rows = nullptr, *pose = nullptr, *loop_pose = nullptr, *drift = nullptr, *stats = nullptr;
+  double *vals = nullptr, *lm3 = nullptr, *rows = nullptr, *pose = nullptr, *loop_pose = nullptr, *drift = nullptr, *stats = nullptr, *pgo_T = nullptr;
   std::vector<void*> owned;
   std::vector<Seq> seq;
   std::vector<double> h_rows;
@@ -235,7 +235,7 @@ int flvis_loop_closer_create(flvis_ctx* ctx, const flvis_cfg* cfg, const flvis_l
             lc->alloc(lc->db, S * LCC_CAP * 32) && lc->alloc(lc->na, S) && lc->alloc(lc->nb, S) && lc->alloc(lc->pairs, S * LCC_CAP * 2) &&
             lc->alloc(lc->npairs, S) && lc->alloc(lc->p3d, S * LCC_CAP * 3) && lc->alloc(lc->p2d, S * LCC_CAP * 2) &&
             lc->alloc(lc->mask, S * LCC_CAP) && lc->alloc(lc->ninl, S) && lc->alloc(lc->pose, S * 7) && lc->alloc(lc->rows, slots) &&
-            lc->alloc(lc->loop_pose, (size_t)max_keyframes * 7) && lc->alloc(lc->drift, 7) && lc->alloc(lc->stats, 5);
+            lc->alloc(lc->loop_pose, slots * 7) && lc->alloc(lc->drift, S * 7) && lc->alloc(lc->stats, S * 5) && lc->alloc(lc->pgo_T, slots * 7);
   if (!ok) {
     for (void* p : lc->owned) hipFree(p);
     delete lc;
@@ -400,6 +400,7 @@ int flvis_loop_closer_process(flvis_loop_closer* lc, flvis_lc_event* h_events) {
   if (e == hipSuccess) e = hipMemcpyAsync(h_pose.data(), lc->pose, sizeof(double) * 7 * (size_t)nc, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_process");
+  std::vector<int> pgo;  // sequences whose pose graph is due (:492-497)
   for (int i = 0; i < nc; i++) {
     const int s = cand[i];
     Seq& q = lc->seq[s];
@@ -420,34 +421,60 @@ int flvis_loop_closer_process(flvis_loop_closer* lc, flvis_lc_event* h_events) {
     q.loop_ids.push_back(q.n - 1);
     q.loop_poses.insert(q.loop_poses.end(), T, T + 7);
     const int thre = (int)(((double)q.n / 100) * 2);  // :490
-    const long long since = (long long)(q.n - 1) - q.last_pgo;
-    if (since > thre) {
-      const int n_loops = (int)(q.loop_ids.size() / 2);
-      if (n_loops > lc->maxkf) return ctx->fail(FLVIS_ERR_CAPACITY, "loop_closer_process: more loops than keyframe slots");
-      e = hipMemcpyAsync(lc->loop_pose, q.loop_poses.data(), sizeof(double) * 7 * (size_t)n_loops, hipMemcpyHostToDevice, st);
-      if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_process");
-      const std::vector<uint8_t> present((size_t)q.n, 1);
-      int ran = 0;
-      rc = flvis_hip_pgo_loop_closure(ctx, 1, &q.n, lc->db_T + (size_t)s * lc->maxkf * 7, present.data(), &n_loops, q.loop_ids.data(), lc->loop_pose,
-                                      100, 1, lc->drift, lc->stats, &ran);
-      if (rc != FLVIS_OK) return rc;
-      if (ran) {
-        double d[7], stats[5], m2[7];
-        e = hipMemcpyAsync(d, lc->drift, sizeof(d), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(stats, lc->stats, sizeof(stats), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_process");
-        pose_mul(q.T_odom_map, d, m2);  // T_odom_map = T_odom_map * Tw1_w2 (:908)
-        memcpy(q.T_odom_map, m2, sizeof(m2));
-        ev.optimised = 1;
-        ev.pgo_iterations = (int)stats[0];
-        ev.chi2_before = stats[1];
-        ev.chi2_after = stats[2];
-        // (:922-925 re-derives the keyframes BEHIND the last optimised one from their odometry pose; the newest keyframe is the
-        //  last optimised one here, so there is none)
-      }
+    if ((long long)(q.n - 1) - q.last_pgo > thre) {
+      pgo.push_back(s);
       q.last_pgo = q.n - 1;
     }
+  }
+  // loopClosureOnCovGraphG2ONew (:742-944) for every sequence that asked for it, ONE launch (one workgroup per pose graph): the
+  // sequences' pose arrays are gathered into one contiguous batch, optimised, and copied back
+  const int ng = (int)pgo.size();
+  if (ng == 0) return FLVIS_OK;
+  std::vector<int> n_kf((size_t)ng), n_loops((size_t)ng), ids, ran((size_t)ng, 0);
+  std::vector<uint8_t> present;
+  std::vector<double> lp;
+  size_t off = 0;
+  e = hipSuccess;
+  for (int g = 0; g < ng; g++) {
+    const Seq& q = lc->seq[pgo[g]];
+    n_kf[g] = q.n;
+    n_loops[g] = (int)(q.loop_ids.size() / 2);
+    ids.insert(ids.end(), q.loop_ids.begin(), q.loop_ids.end());
+    lp.insert(lp.end(), q.loop_poses.begin(), q.loop_poses.end());
+    present.insert(present.end(), (size_t)q.n, 1);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(lc->pgo_T + off * 7, lc->db_T + (size_t)pgo[g] * lc->maxkf * 7, sizeof(double) * 7 * (size_t)q.n, hipMemcpyDeviceToDevice, st);
+    off += (size_t)q.n;
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(lc->loop_pose, lp.data(), sizeof(double) * lp.size(), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_process");
+  rc = flvis_hip_pgo_loop_closure(ctx, ng, n_kf.data(), lc->pgo_T, present.data(), n_loops.data(), ids.data(), lc->loop_pose, 100, 1, lc->drift,
+                                  lc->stats, ran.data());
+  if (rc != FLVIS_OK) return rc;
+  std::vector<double> drift((size_t)ng * 7), stats((size_t)ng * 5);
+  off = 0;
+  for (int g = 0; g < ng && e == hipSuccess; g++) {
+    if (ran[g])
+      e = hipMemcpyAsync(lc->db_T + (size_t)pgo[g] * lc->maxkf * 7, lc->pgo_T + off * 7, sizeof(double) * 7 * (size_t)n_kf[g], hipMemcpyDeviceToDevice, st);
+    off += (size_t)n_kf[g];
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(drift.data(), lc->drift, sizeof(double) * drift.size(), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(stats.data(), lc->stats, sizeof(double) * stats.size(), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_process");
+  for (int g = 0; g < ng; g++) {
+    if (!ran[g]) continue;
+    Seq& q = lc->seq[pgo[g]];
+    flvis_lc_event& ev = h_events[pgo[g]];
+    double m2[7];
+    pose_mul(q.T_odom_map, &drift[7 * (size_t)g], m2);  // T_odom_map = T_odom_map * Tw1_w2 (:908)
+    memcpy(q.T_odom_map, m2, sizeof(m2));
+    ev.optimised = 1;
+    ev.pgo_iterations = (int)stats[5 * (size_t)g];
+    ev.chi2_before = stats[5 * (size_t)g + 1];
+    ev.chi2_after = stats[5 * (size_t)g + 2];
+    // (:922-925 re-derives the keyframes BEHIND the last optimised one from their odometry pose; the newest keyframe is the last
+    //  optimised one here, so there is none)
   }
   return FLVIS_OK;
 }
