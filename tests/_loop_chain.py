@@ -42,6 +42,15 @@ class LoopTrajectory:
         a = self._a(t)
         return synth._rot_zyx(0.9 * math.sin(a), 0.12 * math.sin(2 * a + 0.3), 0.08 * math.cos(a))
 
+    def acc(self, t):
+        a, w = self._a(t), 2 * math.pi / self.T
+        return np.array([-0.9 * w * w * math.cos(a), -1.1 * w * w * math.sin(a), -0.25 * 4 * w * w * math.sin(2 * a)])
+
+    def omega_body(self, t, h=1e-4):
+        """body rate from the central difference of R_w_i (the angles are slow sinusoids: error ~1e-9 rad/s)"""
+        W = self.R_w_i(t).T @ (self.R_w_i(t + h) - self.R_w_i(t - h)) / (2 * h)
+        return np.array([W[2, 1] - W[1, 2], W[0, 2] - W[2, 0], W[1, 0] - W[0, 1]]) / 2
+
     def T_c_w(self, t, rig):
         R_w_c = self.R_w_i(t) @ rig.R_i_c
         c = self.pos(t) + self.R_w_i(t) @ rig.t_i_c

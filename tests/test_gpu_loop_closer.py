@@ -112,3 +112,20 @@ def test_loop_closer_two_sequences_against_the_oracle_chain():
     small.close()
     lc.close()
     ctx.close()
+
+
+def test_tracker_keyframes_through_the_loop_closer():
+    """the three nodelets' work chained in one process (scripts/run_loop_demo.py): the tracker on a rendered stereo + IMU sequence,
+    its keyframes into the loop closer; loops are found and verified and the corrected keyframe path is no worse than the tracker's"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "run_loop_demo.py"), "32", "60"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=240)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    r = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert r["tracking_frames"] >= r["frames"] - 60 and r["keyframes"] >= 60, r
+    assert r["loops_accepted"] >= 3 and r["pose_graph_runs"] >= 1, r
+    assert all(l[3] >= 20 and l[3] >= 0.5 * l[2] for l in r["loops"]), r            # the acceptance rule held for what was accepted
+    assert r["ate_keyframes_m_loop_closed"] <= 1.1 * r["ate_keyframes_m_tracker"] + 0.005, r
