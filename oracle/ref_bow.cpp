@@ -13,8 +13,12 @@
 // The vocabulary FILE the reference loads (vo_loopclosing.cpp:1097) is not shipped with it; the tree is handed over as flat
 // arrays (children of node n: child_idx[child_ptr[n] .. child_ptr[n+1]), node descriptors, word id and weight of the leaves).
 // Weighting TF_IDF and scoring L1_NORM (DBoW3's defaults and what the ORB vocabularies are built with) are the only ones restated.
-// parity unpinned: DBoW3 needs OpenCV to build and its tests (3rdPartLib/DBow3/tests) read vocabulary / image files that are not in
-// the reference; the restatement is checked against an independent plain-Python restatement of the same lines (tests/_voc.py).
+// Pinning: the VALUE half of the transform (addWeight once per feature with a positive weight, normalize(L1)) is pinned on the
+// reference's own BowVector.cpp, which builds from the standard library alone (oracle/bowvector_ref.cpp ->
+// tests/golden/bowvector_ref.npz, bit-exact).  parity unpinned for the rest: the tree descent, the Hamming distance and the L1 score
+// live in sources that need OpenCV (Vocabulary.cpp, DescManip.cpp, ScoringObject.cpp via Vocabulary.h) and DBoW3's tests
+// (3rdPartLib/DBow3/tests) read vocabulary / image files that are not in the reference; those are checked against an independent
+// plain-Python restatement of the same lines (tests/_voc.py).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>

@@ -111,3 +111,26 @@ def py_score(a_ids, a_vals, b_ids, b_vals):
         if i in b:
             s += abs(v - b[i]) - abs(v) - abs(b[i])
     return -s / 2.0
+
+
+def flat_vocabulary(word_weight, seed=5):
+    """a one-level tree: every word a child of the root with its own random descriptor, so that a SEQUENCE OF WORDS can be fed through
+    transform() as the sequence of those descriptors (Hamming distance 0 to its own leaf).  Returns (voc arrays, leaf descriptors)."""
+    n = len(word_weight)
+    rng = np.random.default_rng(seed)
+    leaf = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    assert len(np.unique(leaf, axis=0)) == n
+    child_ptr = np.zeros(n + 2, np.int32)
+    child_ptr[1:] = n
+    child_idx = np.arange(1, n + 1, dtype=np.int32)
+    desc = np.concatenate([np.zeros((1, 32), np.uint8), leaf])
+    weight = np.concatenate([[0.0], np.asarray(word_weight, np.float64)])
+    word_id = np.concatenate([[-1], np.arange(n)]).astype(np.int32)
+    return (child_ptr, child_idx, desc, weight, word_id), leaf
+
+
+def bowvector_golden():
+    """tests/golden/bowvector_ref.npz (written by the reference's own BowVector class): [(words, ids, vals)], word weights"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bowvector_ref.npz"))
+    return [(z["words_%d" % c], z["ids_%d" % c], z["vals_%d" % c]) for c in range(int(z["n_cases"]))], z["word_weight"]

@@ -81,6 +81,17 @@ def test_bow_vocabulary_from_a_dbow3_file(ctx, tmp_path):
     assert "scoring type 3" in str(e.value)
 
 
+def test_bow_values_match_the_reference_bowvector_class(ctx):
+    """pinned on reference code: golden vectors built by DBoW3's own BowVector class (tests/golden/bowvector_ref.npz)"""
+    cases, word_weight = V.bowvector_golden()
+    voc, leaf = V.flat_vocabulary(word_weight)
+    ctx.bow_set_vocabulary(*voc)
+    desc, cnt = _batch([leaf[w] for w, _, _ in cases], 2048)
+    ids, vals, nnz = [t.cpu().numpy() for t in ctx.bow_transform(desc, cnt, vcap=512)]
+    for i, (words, wi, wv) in enumerate(cases):
+        assert nnz[i] == len(wi) and np.array_equal(ids[i, :nnz[i]], wi) and np.array_equal(vals[i, :nnz[i]], wv), (i, len(words))
+
+
 def test_bow_score_row_parity_bit_exact(ctx):
     import torch
     kfs = V.make_keyframes(4, n_img=40, per_img=(250, 400))

@@ -2,6 +2,7 @@
 restatements of the same reference lines, and the product's host-side candidate selection (flvis_loop_candidate: control logic, no
 GPU involved) against the oracle's."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -137,3 +138,24 @@ def test_loop_candidate_logic_oracle_and_product_host_code():
     pres = np.ones(60, np.uint8)
     assert ref_candidate(row, pres, 18, 50, 2, 0.05) == 11 == flvis_amd.loop_candidate(row, pres, 18, 50, 2, 0.05)
     assert ref_candidate(row[:39], pres[:39], 18, 50, 2, 0.05) is None          # fewer than 40 keyframes
+
+
+def test_values_match_the_reference_bowvector_class():
+    """pinned on reference code: the golden vectors were built by DBoW3's own BowVector (addWeight per feature, normalize(L1)),
+    compiled from the reference where it lies (oracle/bowvector_ref.cpp, tests/golden/make_bowvector_fixture.py)"""
+    cases, word_weight = V.bowvector_golden()
+    voc, leaf = V.flat_vocabulary(word_weight)
+    rv = RefVoc(voc)
+    for words, ids, vals in cases:
+        gi, gv = rv.transform(leaf[words])
+        assert np.array_equal(gi, ids) and np.array_equal(gv, vals), (len(words), len(ids))
+    lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "libdbow3_bowvector.so")
+    if os.path.exists(lib):      # in the build container: the committed vectors are what the reference's class says today
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mk", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                                         "make_bowvector_fixture.py"))
+        mk = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mk)
+        for words, ids, vals in cases:
+            ri, rvv = mk.reference_bowvector(words, word_weight[words])
+            assert np.array_equal(ri, ids) and np.array_equal(rvv, vals)
