@@ -133,7 +133,7 @@ struct flvis_loop_closer {
   flvis_lc_params prm;
   flvis_orb_params orb{1000, 1.2f, 8, 20};  // :242
   std::vector<int8_t> pattern;
-  int S = 0, maxkf = 0, w = 0, h = 0;
+  int S = 0, maxkf = 0, w = 0, h = 0, device = 0;
   double K4[4];
   // keyframe database, [S * maxkf] slots
   int* db_ids = nullptr;
@@ -220,7 +220,7 @@ int flvis_loop_closer_create(flvis_ctx* ctx, const flvis_cfg* cfg, const flvis_l
     return ctx->fail(FLVIS_ERR_CAPACITY, "loop_closer_create: n_streams * max_keyframes is too large");
   hipSetDevice(ctx->device);
   flvis_loop_closer* lc = new flvis_loop_closer();
-  lc->ctx = ctx, lc->cfg = *cfg, lc->prm = *prm, lc->S = n_streams, lc->maxkf = max_keyframes;
+  lc->ctx = ctx, lc->device = ctx->device, lc->cfg = *cfg, lc->prm = *prm, lc->S = n_streams, lc->maxkf = max_keyframes;
   lc->w = cfg->image_width, lc->h = cfg->image_height;
   lc->K4[0] = cfg->P0[0], lc->K4[1] = cfg->P0[5], lc->K4[2] = cfg->P0[2], lc->K4[3] = cfg->P0[6];  // dc.K0_rect (:670)
   if (h_orb_pattern) lc->pattern.assign(h_orb_pattern, h_orb_pattern + 1024);
@@ -249,8 +249,8 @@ int flvis_loop_closer_create(flvis_ctx* ctx, const flvis_cfg* cfg, const flvis_l
 
 void flvis_loop_closer_destroy(flvis_loop_closer* lc) {
   if (!lc) return;
-  hipSetDevice(lc->ctx->device);
-  hipStreamSynchronize(lc->ctx->stream);
+  hipSetDevice(lc->device);  // (the context may already be gone: nothing of it is touched here)
+  hipDeviceSynchronize();
   for (void* p : lc->owned) hipFree(p);
   delete lc;
 }

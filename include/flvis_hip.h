@@ -421,6 +421,7 @@ int flvis_lc_params_load(const char* yaml_path, flvis_lc_params* prm, char* err,
  * flvis_hip_orb_detect_and_compute (NULL = the built-in pattern). */
 int flvis_loop_closer_create(flvis_ctx* ctx, const flvis_cfg* cfg, const flvis_lc_params* prm, int n_streams, int max_keyframes,
                              const int8_t* h_orb_pattern, flvis_loop_closer** out);
+/* (destroy it before the context it was created on: every other call runs on that context's stream) */
 void flvis_loop_closer_destroy(flvis_loop_closer* lc);
 /* one keyframe for each of the n sequences h_stream[i] (distinct): d_img0 [n][h][w] mono8, d_img1 [n][h][w] mono8 (stereo) or Z16
  * (depth camera), h_T_c_w_odom7 [n][7] the tracker's pose of the keyframe (KeyFrame.msg T_c_w).  h_kf_id (optional): the keyframe's

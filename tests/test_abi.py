@@ -105,7 +105,7 @@ def test_orb_default_pattern_matches_the_oracle_generator():
 
 
 def test_ros_wrappers_are_compile_gated_and_call_only_declared_entry_points():
-    """ros/: the two nodelet wrappers (flvis/TrackingNodeletClass, flvis/LocalMapNodeletClass) cannot be built here (no ROS); what
+    """ros/: the three nodelet wrappers (flvis/TrackingNodeletClass, flvis/LocalMapNodeletClass, flvis/LoopClosingNodeletClass) cannot be built here (no ROS); what
     can be checked: the package configures to nothing without catkin, the plugin description names the reference's classes, and
     every flvis_* function the wrappers call is declared in include/flvis_hip.h."""
     import re
@@ -114,14 +114,33 @@ def test_ros_wrappers_are_compile_gated_and_call_only_declared_entry_points():
     import tempfile
     hdr = open(os.path.join(ROOT, "include", "flvis_hip.h")).read()
     declared = set(re.findall(r"\b(flvis_[a-z0-9_]+)\s*\(", hdr))
-    for f in ("tracking_nodelet.cpp", "localmap_nodelet.cpp"):
+    for f in ("tracking_nodelet.cpp", "localmap_nodelet.cpp", "loopclosing_nodelet.cpp"):
         src = open(os.path.join(ROOT, "ros", "src", f)).read()
         called = set(re.findall(r"\b(flvis_[a-z0-9_]+)\s*\(", src))
         assert called and called <= declared, (f, called - declared)
         assert "PLUGINLIB_EXPORT_CLASS" in src
     xml = open(os.path.join(ROOT, "ros", "flvis_hip_nodelets.xml")).read()
     assert 'name="flvis/TrackingNodeletClass"' in xml and 'name="flvis/LocalMapNodeletClass"' in xml
+    assert 'name="flvis/LoopClosingNodeletClass"' in xml                       # flvis.xml:17 of the reference
     if shutil.which("cmake"):
         d = tempfile.mkdtemp(prefix="flvis_ros_cfg_")
         r = subprocess.run(["cmake", "-S", os.path.join(ROOT, "ros"), "-B", d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
         assert r.returncode == 0 and b"catkin not found" in r.stdout, r.stdout.decode()[-1500:]
+
+
+def test_header_is_plain_c_and_cxx():
+    """the boundary is a C ABI: include/flvis_hip.h compiles as C99 and as C++11 on its own (no torch, no HIP types in a signature)"""
+    import shutil
+    import subprocess
+    import tempfile
+    hdr = os.path.join(ROOT, "include", "flvis_hip.h")
+    d = tempfile.mkdtemp(prefix="flvis_hdr_")
+    for cc, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "cpp")):
+        if not shutil.which(cc):
+            pytest.skip("no " + cc)
+        src = os.path.join(d, "t." + ext)
+        open(src, "w").write('#include "flvis_hip.h"\nint main(void) { flvis_lc_params p; flvis_lc_event e; flvis_image i; (void)p; (void)e; (void)i; '
+                             'return sizeof(flvis_cfg) > 0 ? 0 : 1; }\n')
+        r = subprocess.run([cc, std, "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.dirname(hdr), src], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
