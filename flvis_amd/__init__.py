@@ -282,6 +282,18 @@ class Context:
                                                   _ptr(db_nnz), vcap, m, _ptr(scores)), "bow_score")
         return scores
 
+    def bow_score_jobs(self, jobs, ids, vals, nnz):
+        """flvis_hip_bow_score_jobs: jobs [(query vector, first database vector, n database vectors)] over one store ids / vals
+        [n_vectors, vcap], nnz [n_vectors] (device) -> scores float64 [n_vectors] (entries outside the jobs' ranges stay -1)."""
+        import numpy as np
+        import torch
+        j = np.ascontiguousarray(jobs, np.int32).reshape(-1, 3)
+        nv, vcap = ids.shape
+        scores = torch.full((nv,), -1.0, dtype=torch.float64, device=ids.device)
+        self._check(self._lib.flvis_hip_bow_score_jobs(self._h, len(j), _P(j, C.c_int), _ptr(ids), _ptr(vals), _ptr(nnz), vcap, _ptr(scores)),
+                    "bow_score_jobs")
+        return scores
+
     def lc_keyframe_landmarks(self, img0, img1, cam_type, kps, desc, count, P0=None, P1=None, K4=None, in_place=False):
         """flvis_hip_lc_keyframe_landmarks (vo_loopclosing.cpp:255-372): kps float32 [n,cap,6], desc uint8 [n,cap,32], count int32 [n] as
         orb_detect_and_compute returns them; img0 uint8 [n,h,w]; img1 uint8 (stereo, cam_type 0) or int16/uint16 Z16 (depth, cam_type 2).

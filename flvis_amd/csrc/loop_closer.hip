@@ -346,17 +346,24 @@ int flvis_loop_closer_process(flvis_loop_closer* lc, flvis_lc_event* h_events) {
     ev.kf_curr = lc->seq[s].fresh ? lc->seq[s].n - 1 : -1;
     ev.loop_pose7[6] = 1.0;
   }
-  // STEP 3 (:417-437): the newest keyframe of every sequence that got one against all keyframes of that sequence
-  hipError_t e = hipSuccess;
+  // STEP 3 (:417-437): the newest keyframe of every sequence that got one against all keyframes of that sequence -- one launch for all
+  // sequences, one strided copy of the rows
+  std::vector<int> jobs;
+  int max_n = 0;
   for (int s = 0; s < lc->S; s++) {
     const Seq& q = lc->seq[s];
     if (!q.fresh) continue;
-    const size_t base = (size_t)s * lc->maxkf, cur = base + q.n - 1;
-    const int rc = flvis_hip_bow_score(ctx, lc->db_ids + cur * LCC_VCAP, lc->db_vals + cur * LCC_VCAP, lc->db_nnz + cur, lc->db_ids + base * LCC_VCAP,
-                                       lc->db_vals + base * LCC_VCAP, lc->db_nnz + base, LCC_VCAP, q.n, lc->rows + base);
-    if (rc != FLVIS_OK) return rc;
-    if (e == hipSuccess) e = hipMemcpyAsync(&lc->h_rows[base], lc->rows + base, sizeof(double) * (size_t)q.n, hipMemcpyDeviceToHost, st);
+    const int base = s * lc->maxkf;
+    jobs.push_back(base + q.n - 1);
+    jobs.push_back(base);
+    jobs.push_back(q.n);
+    max_n = std::max(max_n, q.n);
   }
+  if (jobs.empty()) return FLVIS_OK;
+  int rc0 = flvis_hip_bow_score_jobs(ctx, (int)(jobs.size() / 3), jobs.data(), lc->db_ids, lc->db_vals, lc->db_nnz, LCC_VCAP, lc->rows);
+  if (rc0 != FLVIS_OK) return rc0;
+  hipError_t e = hipMemcpy2DAsync(lc->h_rows.data(), sizeof(double) * (size_t)lc->maxkf, lc->rows, sizeof(double) * (size_t)lc->maxkf,
+                                  sizeof(double) * (size_t)max_n, (size_t)lc->S, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_process");
   // :453 + isLoopCandidate (:520-590) on the host

@@ -171,21 +171,10 @@ __global__ __launch_bounds__(BOW_T) void k_bow_vector(VocDev v, const int* __res
     for (int i = t; i < n_out; i += BOW_T) ov[i] /= norm;
 }
 
-// one wave per database vector: L1Scoring::score(query, db[j]); db_nnz[j] < 0 marks an absent keyframe (score 0)
-__global__ __launch_bounds__(256) void k_bow_score(const int* __restrict__ q_ids, const double* __restrict__ q_vals, const int* __restrict__ q_nnz,
-                                                   const int* __restrict__ db_ids, const double* __restrict__ db_vals,
-                                                   const int* __restrict__ db_nnz, int vcap, int n_db, double* __restrict__ scores) {
-  __shared__ double s_term[4][64];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + wv;
-  if (j >= n_db) return;
-  const int nd = db_nnz[j], nq = q_nnz[0];
-  if (nd < 0) {
-    if (lane == 0) scores[j] = 0.0;
-    return;
-  }
-  const int* di = db_ids + (size_t)j * vcap;
-  const double* dv = db_vals + (size_t)j * vcap;
+// L1Scoring::score(query, db vector) by one wave: lanes binary-search the query's words in the database vector, the terms of a chunk of
+// 64 query words go to LDS and lane 0 adds them in ascending word order (DBoW3's order)
+__device__ inline double bow_score_wave(const int* __restrict__ q_ids, const double* __restrict__ q_vals, int nq, const int* __restrict__ di,
+                                        const double* __restrict__ dv, int nd, double* s_term, int lane) {
   double score = 0;
   for (int base = 0; base < nq; base += 64) {
     const int i = base + lane;
@@ -207,19 +196,49 @@ __global__ __launch_bounds__(256) void k_bow_score(const int* __restrict__ q_ids
     }
     const unsigned long long m = __ballot(hit);
     if (m == 0ull) continue;
-    s_term[wv][lane] = term;
+    s_term[lane] = term;
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
       unsigned long long mm = m;
       while (mm) {  // common words in ascending order
         const int b = __ffsll((long long)mm) - 1;
-        score += s_term[wv][b];
+        score += s_term[b];
         mm &= mm - 1;
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0) scores[j] = -score / 2.0;
+  return -score / 2.0;
+}
+
+// one wave per database vector; db_nnz[j] < 0 marks an absent keyframe (score 0)
+__global__ __launch_bounds__(256) void k_bow_score(const int* __restrict__ q_ids, const double* __restrict__ q_vals, const int* __restrict__ q_nnz,
+                                                   const int* __restrict__ db_ids, const double* __restrict__ db_vals,
+                                                   const int* __restrict__ db_nnz, int vcap, int n_db, double* __restrict__ scores) {
+  __shared__ double s_term[4][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wv;
+  if (j >= n_db) return;
+  const int nd = db_nnz[j], nq = q_nnz[0];
+  double sc = 0.0;
+  if (nd >= 0) sc = bow_score_wave(q_ids, q_vals, nq, db_ids + (size_t)j * vcap, db_vals + (size_t)j * vcap, nd, s_term[wv], lane);
+  if (lane == 0) scores[j] = sc;
+}
+
+// the same for several (query, database range) jobs of one vector store in one launch: job = (query vector, first database vector,
+// number of database vectors), all indices into the store; scores[first + j]
+__global__ __launch_bounds__(256) void k_bow_score_jobs(const int* __restrict__ jobs, const int* __restrict__ ids, const double* __restrict__ vals,
+                                                        const int* __restrict__ nnz, int vcap, double* __restrict__ scores) {
+  __shared__ double s_term[4][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = jobs[3 * blockIdx.y], first = jobs[3 * blockIdx.y + 1], n_db = jobs[3 * blockIdx.y + 2];
+  const int j = blockIdx.x * 4 + wv;
+  if (j >= n_db) return;
+  const size_t v = (size_t)first + j;
+  const int nd = nnz[v], nq = nnz[q];
+  double sc = 0.0;
+  if (nd >= 0 && nq >= 0) sc = bow_score_wave(ids + (size_t)q * vcap, vals + (size_t)q * vcap, nq, ids + v * vcap, vals + v * vcap, nd, s_term[wv], lane);
+  if (lane == 0) scores[v] = sc;
 }
 
 
@@ -794,6 +813,27 @@ int flvis_hip_bow_score(flvis_ctx* ctx, const int* d_q_ids, const double* d_q_va
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_score: bad args");
   k_bow_score<<<(n_db + 3) / 4, 256, 0, ctx->stream>>>(d_q_ids, d_q_vals, d_q_nnz, d_db_ids, d_db_vals, d_db_nnz, vcap, n_db, d_scores);
   CHECK_LAUNCH(ctx, "bow_score");
+  return FLVIS_OK;
+}
+
+int flvis_hip_bow_score_jobs(flvis_ctx* ctx, int n_jobs, const int* h_jobs3, const int* d_ids, const double* d_vals, const int* d_nnz, int vcap,
+                             double* d_scores) {
+  CHECK_CTX(ctx);
+  if (n_jobs <= 0 || !h_jobs3 || !d_ids || !d_vals || !d_nnz || !d_scores || vcap <= 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_score_jobs: bad args");
+  int max_n = 0;
+  for (int i = 0; i < n_jobs; i++) {
+    if (h_jobs3[3 * i] < 0 || h_jobs3[3 * i + 1] < 0 || h_jobs3[3 * i + 2] < 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_score_jobs: negative index");
+    max_n = std::max(max_n, h_jobs3[3 * i + 2]);
+  }
+  if (max_n == 0) return FLVIS_OK;
+  hipSetDevice(ctx->device);
+  int* jobs = (int*)ctx->scratch("bow_jobs", sizeof(int) * 3 * (size_t)n_jobs);
+  if (!jobs) return ctx->fail(FLVIS_ERR_HIP, "bow_score_jobs: scratch allocation failed");
+  hipError_t e = hipMemcpyAsync(jobs, h_jobs3, sizeof(int) * 3 * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // h_jobs3 is the caller's: done with it before returning
+  if (e != hipSuccess) return ctx->hip_fail(e, "bow_score_jobs");
+  k_bow_score_jobs<<<dim3((max_n + 3) / 4, n_jobs), 256, 0, ctx->stream>>>(jobs, d_ids, d_vals, d_nnz, vcap, d_scores);
+  CHECK_LAUNCH(ctx, "bow_score_jobs");
   return FLVIS_OK;
 }
 

@@ -168,6 +168,11 @@ int flvis_hip_lc_keyframe_landmarks(flvis_ctx* ctx, const uint8_t* d_img0, const
  * (kf_lc_tmp[j] == nullptr: score 0). */
 int flvis_hip_bow_score(flvis_ctx* ctx, const int* d_q_ids, const double* d_q_vals, const int* d_q_nnz, const int* d_db_ids,
                         const double* d_db_vals, const int* d_db_nnz, int vcap, int n_db, double* d_scores);
+/* several rows in one launch over ONE store of vectors (d_ids / d_vals [n_vectors][vcap], d_nnz [n_vectors]): job i = h_jobs3[3i..3i+2]
+ * = (query vector, first database vector, number of database vectors); d_scores[first + j] = score(query, first + j).  The loop
+ * closer's rows of all sequences that got a keyframe. */
+int flvis_hip_bow_score_jobs(flvis_ctx* ctx, int n_jobs, const int* h_jobs3, const int* d_ids, const double* d_vals, const int* d_nnz, int vcap,
+                             double* d_scores);
 /* isLoopCandidate (vo_loopclosing.cpp:520-590) on the newest keyframe's row h_row[i] = sim_matrix[i][g_size-1] (host control
  * logic, as in the reference's pgoProcess thread).  Returns 1 and *kf_prev_idx when there is a candidate, 0 when not. */
 int flvis_loop_candidate(int g_size, const double* h_row, const uint8_t* h_present, int lcKFDist, int lcKFMaxDist, int lcNKFClosest,

@@ -110,6 +110,12 @@ def test_bow_score_row_parity_bit_exact(ctx):
         want = 0.0 if j in absent else ref_score(vecs[q], vecs[j])
         assert scores[j] == want, (j, scores[j], want)
     assert abs(scores[q] - 1.0) < 1e-12 and scores[q - 1] > scores[q - 15]
+    # several rows of one store in one launch (the loop closer's rows of all sequences; disjoint output ranges): the same numbers
+    jobs = [(39, 0, 20), (20, 25, 10), (7, 38, 1), (3, 36, 0)]
+    got = ctx.bow_score_jobs(jobs, ids, vals, nnz).cpu().numpy()
+    for qv, first, n in jobs:
+        assert np.array_equal(got[first:first + n], [ref_score(vecs[qv], vecs[j]) for j in range(first, first + n)]), (qv, first, n)
+    assert np.all(got[20:25] == -1) and np.all(got[35:38] == -1) and got[39] == -1
 
 
 def test_orb_to_bow_chain(ctx):
