@@ -572,6 +572,18 @@ class LoopCloser:
         self._ctx._check(self._lib.flvis_loop_closer_poses(self._h, int(stream), _P(buf, C.c_double), cap, C.byref(n)), "loop_closer_poses")
         return buf[:n.value].copy()
 
+    def keyframe(self, stream, kf, cap=1024):
+        """flvis_loop_closer_keyframe -> dict(lm2 [k,2] f32, lm3 [k,3] f64, lmd [k,32] u8, bow=(ids, vals))"""
+        import numpy as np
+        lm2, lm3, lmd = np.zeros((cap, 2), np.float32), np.zeros((cap, 3)), np.zeros((cap, 32), np.uint8)
+        bi, bv = np.zeros(cap, np.int32), np.zeros(cap)
+        nl, nv = C.c_int(0), C.c_int(0)
+        self._ctx._check(self._lib.flvis_loop_closer_keyframe(self._h, int(stream), int(kf), cap, _P(lm2, C.c_float), _P(lm3, C.c_double),
+                                                              _P(lmd, C.c_uint8), C.byref(nl), _P(bi, C.c_int), _P(bv, C.c_double), C.byref(nv)),
+                         "loop_closer_keyframe")
+        k, v = min(nl.value, cap), min(nv.value, cap)
+        return dict(lm2=lm2[:k].copy(), lm3=lm3[:k].copy(), lmd=lmd[:k].copy(), bow=(bi[:v].copy(), bv[:v].copy()))
+
     def drift(self, stream=0):
         import numpy as np
         T = np.zeros(7)

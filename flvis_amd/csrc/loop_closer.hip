@@ -500,6 +500,34 @@ int flvis_loop_closer_poses(flvis_loop_closer* lc, int stream, double* h_T_c_w7,
   return FLVIS_OK;
 }
 
+// one keyframe of the database back on the host (KeyFrameLC: lm_2d / lm_3d / lm_descriptor / kf_bv, :100-112); any output may be NULL
+int flvis_loop_closer_keyframe(flvis_loop_closer* lc, int stream, int kf, int cap, float* h_lm_2d, double* h_lm_3d, uint8_t* h_lm_desc,
+                               int* lm_count, int* h_bow_ids, double* h_bow_vals, int* bow_count) {
+  if (!lc) return FLVIS_ERR_INVALID_ARG;
+  flvis_ctx* ctx = lc->ctx;
+  if (stream < 0 || stream >= lc->S || kf < 0 || kf >= lc->seq[stream].n || cap < 0)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_keyframe: no such keyframe");
+  hipSetDevice(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t slot = (size_t)stream * lc->maxkf + kf;
+  int cnt[2] = {0, 0};
+  hipError_t e = hipMemcpyAsync(&cnt[0], lc->db_lmc + slot, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(&cnt[1], lc->db_nnz + slot, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_keyframe");
+  const size_t nl = (size_t)std::min(cnt[0], cap), nv = (size_t)std::min(cnt[1], cap);
+  if (h_lm_2d && nl) e = hipMemcpyAsync(h_lm_2d, lc->db_lm2 + slot * LCC_CAP * 2, sizeof(float) * 2 * nl, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && h_lm_3d && nl) e = hipMemcpyAsync(h_lm_3d, lc->db_lm3 + slot * LCC_CAP * 3, sizeof(double) * 3 * nl, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && h_lm_desc && nl) e = hipMemcpyAsync(h_lm_desc, lc->db_lmd + slot * LCC_CAP * 32, 32 * nl, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && h_bow_ids && nv) e = hipMemcpyAsync(h_bow_ids, lc->db_ids + slot * LCC_VCAP, sizeof(int) * nv, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && h_bow_vals && nv) e = hipMemcpyAsync(h_bow_vals, lc->db_vals + slot * LCC_VCAP, sizeof(double) * nv, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_keyframe");
+  if (lm_count) *lm_count = cnt[0];
+  if (bow_count) *bow_count = cnt[1];
+  return FLVIS_OK;
+}
+
 int flvis_loop_closer_drift(flvis_loop_closer* lc, int stream, double* h_T_odom_map7) {
   if (!lc) return FLVIS_ERR_INVALID_ARG;
   if (stream < 0 || stream >= lc->S || !h_T_odom_map7) return lc->ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_drift: bad args");

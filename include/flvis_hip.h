@@ -440,6 +440,10 @@ int flvis_loop_closer_add_keyframes_host(flvis_loop_closer* lc, int n, const int
 int flvis_loop_closer_process(flvis_loop_closer* lc, flvis_lc_event* h_events);
 /* kf_map_lc[i]->T_c_w of one sequence (host, [cap][7]); *n_out = keyframes in the sequence */
 int flvis_loop_closer_poses(flvis_loop_closer* lc, int stream, double* h_T_c_w7, int cap, int* n_out);
+/* one keyframe of the device-resident database on the host (KeyFrameLC, :100-112): the kept ORB landmarks (pixel, camera-frame position,
+ * descriptor; arrays of capacity cap) and the bag-of-words vector; any output pointer may be NULL; the counts are the full counts */
+int flvis_loop_closer_keyframe(flvis_loop_closer* lc, int stream, int kf, int cap, float* h_lm_2d, double* h_lm_3d, uint8_t* h_lm_desc,
+                               int* lm_count, int* h_bow_ids, double* h_bow_vals, int* bow_count);
 /* T_odom_map (:138, the tf map -> odom the nodelet broadcasts is its inverse) */
 int flvis_loop_closer_drift(flvis_loop_closer* lc, int stream, double* h_T_odom_map7);
 /* the newest row of the sequence's similarity matrix as the last flvis_loop_closer_process computed it */

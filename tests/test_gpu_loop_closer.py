@@ -64,6 +64,11 @@ def test_loop_closer_two_sequences_against_the_oracle_chain():
             ref[s].add(dict(bow=(bi[j, :bn[j]].copy(), bv[j, :bn[j]].copy()), lm2=lm2[j, :lmc[j]].copy(), lm3=lm3[j, :lmc[j]].copy(),
                             lmd=lmd[j, :lmc[j]].copy()), T[j])
             n_added[s] += 1
+            if i % 20 == 3:     # what the database holds for this keyframe is what the separate entry points computed
+                kf = lc.keyframe(s, n_added[s] - 1)
+                f = ref[s].kfs[-1]
+                assert np.array_equal(kf["lm2"], f["lm2"]) and np.array_equal(kf["lm3"], f["lm3"]) and np.array_equal(kf["lmd"], f["lmd"])
+                assert np.array_equal(kf["bow"][0], f["bow"][0]) and np.array_equal(kf["bow"][1], f["bow"][1])
         ev = lc.process()
         for s in range(2):
             if s not in streams:
@@ -110,6 +115,43 @@ def test_loop_closer_two_sequences_against_the_oracle_chain():
     with pytest.raises(flvis_amd.FlvisError):
         lc.add_keyframes([0, 0], frames[0][0], frames[0][1], [odom[0][0], odom[0][0]])   # two keyframes for one sequence in one call
     small.close()
+    lc.close()
+    ctx.close()
+
+
+def test_loop_closer_on_a_depth_camera_rig():
+    """DEPTH_D435 (vo_loopclosing.cpp:325-349): the keyframes' landmarks come from the Z16 image (whole metres, as the reference's integer
+    division leaves them); the database holds what flvis_hip_lc_keyframe_landmarks computes for cam_type 2"""
+    import flvis_amd
+    from flvis_amd import synth
+    ctx = flvis_amd.Context(0)
+    p = os.path.join(tempfile.gettempdir(), "flvis_loopcloser_depth_gpu.yaml")
+    open(p, "w").write(synth.D435I_DEPTH_YAML)
+    cfg = flvis_amd.load_config(p)
+    assert cfg.cam_type == 2
+    K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
+    trs = [LC.LoopTrajectory(phase=0.0), LC.LoopTrajectory(phase=2.0)]
+    rnd = synth.Renderer("cuda")
+    frames = [rnd.depth_frame(trs, t, i) for i, t in enumerate(LC.keyframe_times(4, 50))]
+    k, d, c, _ = ctx.orb_detect_and_compute(frames[0][0], cap=1024)
+    ctx.bow_set_vocabulary(*V.build_vocabulary([d[0, :int(c[0])].cpu().numpy(), d[1, :int(c[1])].cpu().numpy()], k=6, depth=2))
+    lc = flvis_amd.LoopCloser(ctx, cfg, LC.LC_PARAMS, n_streams=2, max_keyframes=8)
+    ident = np.array([[0, 0, 0, 0, 0, 0, 1.0]] * 2)
+    for i0, d16 in frames:
+        lc.add_keyframes([0, 1], i0, d16, ident)
+        ev = lc.process()
+        assert [e["kf_curr"] for e in ev] == [lc.poses(0).shape[0] - 1] * 2 and not any(e["candidate"] for e in ev)
+    kps, desc, cnt, _ = ctx.orb_detect_and_compute(frames[3][0], cap=1024)
+    lm2, lm3, lmd, lmc = [t.cpu().numpy() for t in ctx.lc_keyframe_landmarks(None, frames[3][1], 2, kps, desc, cnt, K4=K4)]
+    for s in range(2):
+        kf = lc.keyframe(s, 3)
+        assert len(kf["lm2"]) == lmc[s] > 50
+        assert np.array_equal(kf["lm2"], lm2[s, :lmc[s]]) and np.array_equal(kf["lm3"], lm3[s, :lmc[s]]) and np.array_equal(kf["lmd"], lmd[s, :lmc[s]])
+        assert set(np.unique(kf["lm3"][:, 2])) <= set(float(v) for v in range(1, 11))
+        row = lc.similarity_row(s)
+        assert len(row) == 4 and abs(row[3] - 1.0) < 1e-12 and np.all(row[:3] < 1.0)
+    with pytest.raises(flvis_amd.FlvisError):
+        lc.keyframe(0, 4)
     lc.close()
     ctx.close()
 
