@@ -13,6 +13,7 @@ import _geom as G
 import _loop_chain as LC
 import _pgo_synth as PS
 import _voc as V
+from test_oracle_bow import ref_score
 
 pytestmark = pytest.mark.gpu
 
@@ -133,8 +134,11 @@ def test_loop_closer_on_a_depth_camera_rig():
     trs = [LC.LoopTrajectory(phase=0.0), LC.LoopTrajectory(phase=2.0)]
     rnd = synth.Renderer("cuda")
     frames = [rnd.depth_frame(trs, t, i) for i, t in enumerate(LC.keyframe_times(4, 50))]
-    k, d, c, _ = ctx.orb_detect_and_compute(frames[0][0], cap=1024)
-    ctx.bow_set_vocabulary(*V.build_vocabulary([d[0, :int(c[0])].cpu().numpy(), d[1, :int(c[1])].cpu().numpy()], k=6, depth=2))
+    train = []
+    for i0, _ in frames:                                     # eight training images (a word seen in ALL of them has idf 0 and is stopped)
+        k, d, c, _ = ctx.orb_detect_and_compute(i0, cap=1024)
+        train += [d[s, :int(c[s])].cpu().numpy() for s in range(2)]
+    ctx.bow_set_vocabulary(*V.build_vocabulary(train, k=6, depth=3))
     lc = flvis_amd.LoopCloser(ctx, cfg, LC.LC_PARAMS, n_streams=2, max_keyframes=8)
     ident = np.array([[0, 0, 0, 0, 0, 0, 1.0]] * 2)
     for i0, d16 in frames:
@@ -149,7 +153,9 @@ def test_loop_closer_on_a_depth_camera_rig():
         assert np.array_equal(kf["lm2"], lm2[s, :lmc[s]]) and np.array_equal(kf["lm3"], lm3[s, :lmc[s]]) and np.array_equal(kf["lmd"], lmd[s, :lmc[s]])
         assert set(np.unique(kf["lm3"][:, 2])) <= set(float(v) for v in range(1, 11))
         row = lc.similarity_row(s)
-        assert len(row) == 4 and abs(row[3] - 1.0) < 1e-12 and np.all(row[:3] < 1.0)
+        bows = [lc.keyframe(s, j)["bow"] for j in range(4)]
+        assert len(bows[3][0]) > 20
+        assert np.array_equal(row, [ref_score(bows[3], bows[j]) for j in range(4)]) and abs(row[3] - 1.0) < 1e-12
     with pytest.raises(flvis_amd.FlvisError):
         lc.keyframe(0, 4)
     lc.close()
