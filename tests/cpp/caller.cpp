@@ -6,7 +6,7 @@
 // Feeds a static synthetic stereo pair (a noise texture, the right image shifted by a constant disparity = a fronto-parallel
 // wall) and IMU samples of a rig at rest through flvis_imu_feed / flvis_image_feed_host for a D435i-stereo configuration and
 // checks what the reference's process() loop would consume: the tracking state, the KeyFrame message of the first frame, the
-// landmark depths.  Exit codes: 0 ok, 3 no GPU (flvis_hip_create refused: the library has no CPU fallback), 1 failure.
+// landmark depths; then the loop-closing nodelet's calls (vocabulary file, keyframes in, events / similarity row / poses out).  Exit codes: 0 ok, 3 no GPU (flvis_hip_create refused: the library has no CPU fallback), 1 failure.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -121,8 +121,76 @@ int main(int argc, char** argv) {
   CHECK(flvis_get_counters(ctx, counters));
   std::printf("%s: frames %lld tracked %d keyframes %d landmarks %d (depth ok %d, wall at %.2f m) ba_runs %lld lanes %d\n", flvis_version(),
               (long long)counters[0], tracked, kf_count, nl, good, want_z, (long long)counters[2], flvis_tracker_lanes(ctx));
+  // ---- the loop-closing nodelet's calls (vo_loopclosing.cpp onInit / kfmsgProcess / pgoProcess) from the same caller -----------------
+  // a vocabulary FILE as `Vocabulary voc(path)` reads it: DBoW3's plain binary layout, 64 words directly under the root
+  const char* voc_path = "/tmp/flvis_cpp_caller_voc.dbow3";
+  {
+    std::FILE* f = std::fopen(voc_path, "wb");
+    if (!f) return 1;
+    const uint64_t magic = 88877711233ull;
+    const uint8_t compressed = 0;
+    const uint32_t n_nodes = 65, n_words = 64;
+    const int32_t head[4] = {64, 1, 0, 0};  // k, L, scoring L1_NORM, weighting TF_IDF
+    std::fwrite(&magic, 8, 1, f);
+    std::fwrite(&compressed, 1, 1, f);
+    std::fwrite(&n_nodes, 4, 1, f);
+    std::fwrite(head, 4, 4, f);
+    for (uint32_t i = 1; i < n_nodes; i++) {
+      const uint32_t parent = 0;
+      const double weight = 1.0 + 0.01 * i;
+      const int32_t mat[3] = {32, 1, 0};  // cols, rows, CV_8U
+      uint8_t d[32];
+      for (int b = 0; b < 32; b++) {
+        lcg = lcg * 1664525u + 1013904223u;
+        d[b] = (uint8_t)(lcg >> 24);
+      }
+      std::fwrite(&i, 4, 1, f);
+      std::fwrite(&parent, 4, 1, f);
+      std::fwrite(&weight, 8, 1, f);
+      std::fwrite(mat, 4, 3, f);
+      std::fwrite(d, 1, 32, f);
+    }
+    std::fwrite(&n_words, 4, 1, f);
+    for (uint32_t wid = 0; wid < n_words; wid++) {
+      const uint32_t nid = wid + 1;
+      std::fwrite(&wid, 4, 1, f);
+      std::fwrite(&nid, 4, 1, f);
+    }
+    std::fclose(f);
+  }
+  CHECK(flvis_hip_bow_load_vocabulary(ctx, voc_path));
+  if (flvis_hip_bow_load_vocabulary(ctx, "/tmp/flvis_no_such_vocabulary.dbow3") != FLVIS_ERR_CONFIG) {
+    std::fprintf(stderr, "a missing vocabulary file must be refused\n");
+    return 1;
+  }
+  const flvis_lc_params lcp = {25, 18, 50, 20, 2, 20, 0.5, 0.5, 0.12};  // launch/KITTI/KITTI.yaml:110-127
+  flvis_loop_closer* lc = nullptr;
+  CHECK(flvis_loop_closer_create(ctx, &cfg, &lcp, 1, 8, nullptr, &lc));
+  const int stream0 = 0;
+  flvis_lc_event ev;
+  std::vector<double> row(8), poses(7 * 8);
+  int n_row = 0, n_pose = 0, lm_kept = 0, bow_n = 0;
+  for (int k = 0; k < 3; k++) {
+    const flvis_image a = {img0.data(), w, h, w, 1, 0.0}, b = {img1.data(), w, h, w, 1, 0.0};
+    const double T[7] = {0.1 * k, 0, 0, 0, 0, 0, 1};
+    int64_t kf_id = -1;
+    CHECK(flvis_loop_closer_add_keyframes_host(lc, 1, &stream0, &a, &b, T, &kf_id));
+    CHECK(flvis_loop_closer_process(lc, &ev));
+    if (kf_id != k || ev.kf_curr != k || ev.candidate || ev.loop_accepted) {  // fewer than 50 keyframes: nothing to close yet
+      std::fprintf(stderr, "loop closer: keyframe %d came back as %lld / event kf_curr %lld\n", k, (long long)kf_id, (long long)ev.kf_curr);
+      return 1;
+    }
+  }
+  CHECK(flvis_loop_closer_similarity_row(lc, 0, row.data(), 8, &n_row));
+  CHECK(flvis_loop_closer_poses(lc, 0, poses.data(), 8, &n_pose));
+  CHECK(flvis_loop_closer_keyframe(lc, 0, 2, 0, nullptr, nullptr, nullptr, &lm_kept, nullptr, nullptr, &bow_n));
+  bool lc_ok = n_row == 3 && n_pose == 3 && lm_kept > 30 && bow_n > 5 && std::fabs(poses[14] - 0.2) < 1e-15 && poses[20] == 1.0;
+  for (int j = 0; j < 3 && lc_ok; j++) lc_ok = std::fabs(row[j] - 1.0) < 1e-12;  // three times the same image: every score is 1
+  std::printf("loop closer: %d keyframes, %d landmarks kept, %d words, scores %.15g %.15g %.15g\n", n_pose, lm_kept, bow_n, row[0], row[1], row[2]);
+  flvis_loop_closer_destroy(lc);
   flvis_hip_destroy(ctx);
   // (points whose stereo match fails get the reference's rand() dummy depth, camera_frame.cpp:153-168: not all sit on the wall)
+  if (!lc_ok) return 1;
   if (tracked != extra_frames || kf_count < 1 || good < nl / 2) return 1;
   std::printf("caller OK\n");
   return 0;
