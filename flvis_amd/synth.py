@@ -194,6 +194,15 @@ dr_para2: 1000
 dr_para3: 0.0
 output_sparse_map: False
 window_size:       10
+lcKFStart: 25
+lcKFDist: 18
+lcKFMaxDist: 50
+lcKFLast: 20
+lcNKFClosest: 2
+ratioMax: 0.5
+ratioRansac: 0.5
+minPts: 20
+minScore: 0.12
 """ % (-KITTI_FX * KITTI_LIKE_BASELINE)
 
 

@@ -137,6 +137,32 @@ def test_kitti_folder_reader_and_cpu_backend_run():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert res["tracked"] == n and res["ate_rmse_m"] < 0.01, res
+    # the same run with the loop closing switched on: the tracker's keyframes go through ORB / bag of words / landmarks into the
+    # keyframe map, with the vocabulary read from a (QuickLZ-compressed) DBoW3 file and the lcKF* block of the yaml.  Nine frames
+    # cannot close a loop (the nodelet waits for 50 keyframes): what is checked is that the keyframe path is the tracker's own.
+    import _voc as V
+    import _vocfile as VF
+    k, d = O.orb_detect_and_compute(imgs[0][0])
+    voc = V.build_vocabulary([d[i::3] for i in range(3)], k=5, depth=2)
+    voc_path = os.path.join(root, "voc.dbow3")
+    VF.write_binary(voc_path, voc, 5, 2, compress=VF.qlz1_compress)
+    out2, lc_out = os.path.join(root, "traj_cpu_lc.txt"), os.path.join(root, "keyframes_lc.txt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), root, yaml, out2, "--backend", "cpu", "--loop-closing",
+                        "--voc", voc_path, "--lc-out", lc_out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    res2 = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert open(out2).read() == open(out).read()                               # the tracker's output does not change
+    lcr = res2["loop_closing"]
+    assert lcr["keyframes"] >= 1 and lcr["candidates"] == 0 and lcr["loops_accepted"] == 0 and lcr["pose_graph_runs"] == 0, res2
+    ks, kp, kq = traj_io.read_stamped(lc_out)
+    ts_all, ps_all, qs_all = traj_io.read_stamped(out)
+    assert len(ks) == lcr["keyframes"]
+    for t_kf, p_kf in zip(ks, kp):                                             # every keyframe pose is the tracker's pose of that frame
+        j = int(np.argmin(np.abs(np.asarray(ts_all) - t_kf)))
+        assert abs(ts_all[j] - t_kf) < 1e-9 and np.abs(np.asarray(ps_all[j]) - np.asarray(p_kf)).max() < 1e-6
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), root, yaml, out2, "--backend", "cpu", "--loop-closing"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode != 0 and b"--voc" in r.stderr                          # no vocabulary named
 
 
 def test_rosbag_reader_roundtrip_and_cpu_backend_run():
