@@ -149,6 +149,18 @@ static int build_pyramid(flvis_ctx* ctx, const char* name, const uint8_t* d_img,
   pyr.h[0] = h;
   pyr.pitch[0] = w;
   pyr.stride[0] = (size_t)w * h;
+  if (w & 3) {
+    // rows that are not dword aligned (KITTI's 1241 x 376, tightly packed): level 0 is copied into a pitch-aligned buffer first, as
+    // the tracker's ingest does
+    const int pitch0 = align_up(w, 16);
+    const size_t stride0 = (size_t)pitch0 * h;
+    uint8_t* l0 = (uint8_t*)ctx->scratch(std::string(name) + "_l0", stride0 * n_img + 256);
+    if (!l0) return ctx->fail(FLVIS_ERR_HIP, "pyramid scratch allocation failed");
+    launch_copy_image_any(ctx->stream, img_plain(d_img), img_plain(l0), w, h, w, pitch0, (size_t)w * h, stride0, n_img, nullptr);
+    pyr.lvl[0] = img_plain(l0);
+    pyr.pitch[0] = pitch0;
+    pyr.stride[0] = stride0;
+  }
   size_t total = 0;
   size_t off[LK_MAX_LEVELS] = {0};
   int lw = w, lh = h;
@@ -177,8 +189,8 @@ int flvis_hip_lk_track(flvis_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_n
                        const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, const int* d_count, int nmax,
                        int max_level, int max_iter, double eps, int use_initial_flow) {
   CHECK_CTX(ctx);
-  if (!d_prev || !d_next || !d_prev_pts || !d_next_pts || !d_status || !d_count || w < 32 || h < 32 || (w & 3) ||
-      n_img <= 0 || nmax <= 0 || max_level < 0)
+  if (!d_prev || !d_next || !d_prev_pts || !d_next_pts || !d_status || !d_count || w < 32 || h < 32 || n_img <= 0 || nmax <= 0 ||
+      max_level < 0)
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "lk_track: bad args");
   int L = lk_levels(w, h, 31, max_level);
   if (L >= LK_MAX_LEVELS) L = LK_MAX_LEVELS - 1;

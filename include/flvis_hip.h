@@ -67,7 +67,8 @@ int flvis_hip_pyr_down(flvis_ctx* ctx, const uint8_t* d_src, int w, int h, int s
 
 /* cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(31,31), max_level,
  *                          TermCriteria(COUNT+EPS, max_iter, eps), use_initial_flow ? OPTFLOW_USE_INITIAL_FLOW : 0)
- * for n_img image pairs at once.  d_prev/d_next: [n_img][h][w] u8.  Points: d_prev_pts/d_next_pts [n_img][nmax][2]
+ * for n_img image pairs at once.  d_prev/d_next: [n_img][h][w] u8, tightly packed, any w >= 32 (rows that are not dword aligned, e.g.
+ * KITTI's 1241, are first copied into a pitch-aligned level 0).  Points: d_prev_pts/d_next_pts [n_img][nmax][2]
  * float (x,y); d_next_pts is in/out; d_status [n_img][nmax] u8; d_count [n_img] int = valid points per image.
  * Pyramids are built internally (as OpenCV does for raw Mats). */
 int flvis_hip_lk_track(flvis_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_next, int w, int h, int n_img,

@@ -97,10 +97,8 @@ def test_asl_folder_roundtrip_and_cpu_backend_run():
     assert np.allclose(pos, np.array(want_p), rtol=2e-5, atol=1e-6)
 
 
-def test_kitti_folder_reader_and_cpu_backend_run():
-    """The KITTI side of the dataset path: `image_0/%06d.png`, `image_1/%06d.png`, `times.txt` and a 12-column ground-truth file
-    (what src/independ_modules/kitti_publisher.cpp:100-131 reads) written from the synthetic KITTI-like rig, read back by
-    traj_io.KittiSequence and run through scripts/run_sequence.py (CPU backend, type_of_vi 4, no IMU)."""
+def make_kitti_folder(n=9):
+    """a KITTI odometry folder written from the synthetic KITTI-like rig: (root, yaml path, [(img0, img1)])"""
     from PIL import Image
     from flvis_amd import synth, traj_io
     yaml = os.path.join(tempfile.gettempdir(), "flvis_ds_kitti.yaml")
@@ -111,7 +109,6 @@ def test_kitti_folder_reader_and_cpu_backend_run():
     root = tempfile.mkdtemp(prefix="flvis_kitti_")
     os.makedirs(os.path.join(root, "image_0"))
     os.makedirs(os.path.join(root, "image_1"))
-    n = 9
     imgs, Rs, ts = [], [], []
     R0, t0 = tr.T_c_w(0.0, rig)
     for f in range(n):
@@ -125,6 +122,27 @@ def test_kitti_folder_reader_and_cpu_backend_run():
         ts.append(R0 @ (-Rc.T @ tc) + t0)
     np.savetxt(os.path.join(root, "times.txt"), np.arange(n) / 10.0, fmt="%.6e")
     traj_io.write_kitti(os.path.join(root, "poses.txt"), np.array(Rs), np.array(ts))
+    return root, yaml, imgs
+
+
+def make_vocabulary_file(root, img):
+    """a small QuickLZ-compressed DBoW3 vocabulary file trained on one image's ORB descriptors"""
+    import _voc as V
+    import _vocfile as VF
+    k, d = O.orb_detect_and_compute(img)
+    voc = V.build_vocabulary([d[i::3] for i in range(3)], k=5, depth=2)
+    path = os.path.join(root, "voc.dbow3")
+    VF.write_binary(path, voc, 5, 2, compress=VF.qlz1_compress)
+    return path
+
+
+def test_kitti_folder_reader_and_cpu_backend_run():
+    """The KITTI side of the dataset path: `image_0/%06d.png`, `image_1/%06d.png`, `times.txt` and a 12-column ground-truth file
+    (what src/independ_modules/kitti_publisher.cpp:100-131 reads) written from the synthetic KITTI-like rig, read back by
+    traj_io.KittiSequence and run through scripts/run_sequence.py (CPU backend, type_of_vi 4, no IMU)."""
+    from flvis_amd import traj_io
+    n = 9
+    root, yaml, imgs = make_kitti_folder(n)
     seq = traj_io.open_sequence(root)
     assert isinstance(seq, traj_io.KittiSequence) and len(seq) == n and seq.groundtruth is not None
     got = list(seq.frames())
@@ -140,12 +158,7 @@ def test_kitti_folder_reader_and_cpu_backend_run():
     # the same run with the loop closing switched on: the tracker's keyframes go through ORB / bag of words / landmarks into the
     # keyframe map, with the vocabulary read from a (QuickLZ-compressed) DBoW3 file and the lcKF* block of the yaml.  Nine frames
     # cannot close a loop (the nodelet waits for 50 keyframes): what is checked is that the keyframe path is the tracker's own.
-    import _voc as V
-    import _vocfile as VF
-    k, d = O.orb_detect_and_compute(imgs[0][0])
-    voc = V.build_vocabulary([d[i::3] for i in range(3)], k=5, depth=2)
-    voc_path = os.path.join(root, "voc.dbow3")
-    VF.write_binary(voc_path, voc, 5, 2, compress=VF.qlz1_compress)
+    voc_path = make_vocabulary_file(root, imgs[0][0])
     out2, lc_out = os.path.join(root, "traj_cpu_lc.txt"), os.path.join(root, "keyframes_lc.txt")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), root, yaml, out2, "--backend", "cpu", "--loop-closing",
                         "--voc", voc_path, "--lc-out", lc_out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)

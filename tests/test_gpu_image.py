@@ -134,7 +134,8 @@ def _lk_case(h, w, n, seed, shifts, npts, max_level=10):
 
 @pytest.mark.parametrize("h,w,n,seed,max_level,use_initial", [
     (480, 640, 2, 100, 10, True), (480, 640, 2, 110, 5, True), (240, 320, 3, 120, 10, False),
-    (480, 752, 1, 130, 10, True), (120, 160, 2, 140, 1, True)])
+    (480, 752, 1, 130, 10, True), (120, 160, 2, 140, 1, True),
+    (376, 1241, 1, 150, 5, True), (203, 322, 2, 160, 10, True)])      # rows that are not dword aligned (KITTI's 1241 x 376)
 def test_lk_parity_bit_exact(ctx, h, w, n, seed, max_level, use_initial):
     shifts = [(3.3, -2.1), (-7.6, 5.2), (0.3, 0.2)]
     prev, nxt, pp, init, cnt = _lk_case(h, w, n, seed, shifts, 120)
