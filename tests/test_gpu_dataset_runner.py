@@ -32,4 +32,4 @@ def test_run_sequence_hip_backend_matches_the_cpu_backend_with_loop_closing():
     for which in (0, 1):                                   # the tracker's trajectory, the loop closing's keyframe path
         (ta, pa, qa), (tb, pb, qb) = files["hip"][which], files["cpu"][which]
         assert np.allclose(ta, tb, atol=1e-9) and np.abs(np.asarray(pa) - np.asarray(pb)).max() < 1e-6
-        assert np.abs(np.abs(np.sum(np.asarray(qa) * np.asarray(qb), axis=1)) - 1).max() < 1e-9
+        assert np.abs(np.abs(np.sum(np.asarray(qa) * np.asarray(qb), axis=1)) - 1).max() < 5e-6     # (the files carry six decimals)
