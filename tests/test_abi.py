@@ -122,6 +122,14 @@ def test_ros_wrappers_are_compile_gated_and_call_only_declared_entry_points():
     xml = open(os.path.join(ROOT, "ros", "flvis_hip_nodelets.xml")).read()
     assert 'name="flvis/TrackingNodeletClass"' in xml and 'name="flvis/LocalMapNodeletClass"' in xml
     assert 'name="flvis/LoopClosingNodeletClass"' in xml                       # flvis.xml:17 of the reference
+    import xml.etree.ElementTree as ET
+    for lf, classes in (("flvis_hip_kitti.launch", ("TrackingNodeletClass", "LocalMapNodeletClass", "LoopClosingNodeletClass")),
+                        ("flvis_hip_euroc.launch", ("TrackingNodeletClass", "LocalMapNodeletClass"))):
+        tree = ET.parse(os.path.join(ROOT, "ros", "launch", lf))                # well-formed
+        loads = [n.get("args") for n in tree.getroot().iter("node") if n.get("pkg") == "nodelet" and "load" in (n.get("args") or "")]
+        assert sorted(a.split()[1] for a in loads) == sorted("flvis/" + c for c in classes), (lf, loads)
+        params = [n.get("name") for n in tree.getroot().iter("param")]
+        assert "/yamlconfigfile" in params
     if shutil.which("cmake"):
         d = tempfile.mkdtemp(prefix="flvis_ros_cfg_")
         r = subprocess.run(["cmake", "-S", os.path.join(ROOT, "ros"), "-B", d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
