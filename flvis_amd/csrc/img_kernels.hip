@@ -13,7 +13,10 @@
 // Streaming passes over u8 images (O(1) flop/byte): tiles are staged in LDS with dword global loads, one workgroup per
 // (tile, stream).  Measured, they are issue/latency bound rather than HBM bound (DESIGN.md sections 4, 8, 10).
 // Built with -ffp-contract=off: float arithmetic is op-for-op the oracle's (tests compare bit-exactly).
+#include <cstdlib>
+
 #include "dev_common.hpp"
+#include "eig_strip.hpp"
 #include "img_kernels.hpp"
 
 namespace flvis {
@@ -385,6 +388,71 @@ __global__ __launch_bounds__(256) void k_eig_cand(ImgSel src, int w, int h, int 
 #pragma unroll
       for (int k = -1; k <= 1; k++)
         if (e[j * T::OW + k] > v) ismax = false;
+    if (ismax) {
+      int slot = atomicAdd(&lcount, 1);
+      unsigned long long key = ((unsigned long long)ev << 32) | (unsigned)(y * w + x);
+      lkeys[slot] = ~key;
+    }
+  }
+  m = wave_max_u32(m);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const int n = lcount;
+  if (threadIdx.x == 0) {
+    unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    atomicMax(&maxenc[s], a > b ? a : b);
+    if (n > 0) lbase = atomicAdd(&nkeys[s], n);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    int slot = lbase + i;
+    if (slot < cap) keys[(size_t)s * cap + slot] = lkeys[i];
+  }
+}
+
+// The same pass with the strip-mined phases of eig_strip.hpp (four Sobel pairs / four responses per thread from one register
+// window; bit-identical values -- tests/test_eig_strip.py runs those very functions on the host over whole images).  Opt-in
+// (FLVIS_EIG_STRIP=1) until it has been measured on the GPU against k_eig_cand; everything after the response map is k_eig_cand's.
+__global__ __launch_bounds__(256) void k_eig_cand_strip(ImgSel src, int w, int h, int pitch, size_t sstride, unsigned* __restrict__ maxenc,
+                                                        unsigned long long* __restrict__ keys, int* __restrict__ nkeys, int cap,
+                                                        const int* __restrict__ active) {
+  namespace ES = eigstrip;
+  static_assert(ES::TW == EG_TW && ES::TH == EG_TH && ES::IW == EigTile<1>::IW && ES::IH == EigTile<1>::IH && ES::CW == EigTile<1>::CW &&
+                    ES::OW == EigTile<1>::OW,
+                "eig_strip.hpp describes the tile of k_eig_cand");
+  const int s = blockIdx.z;
+  if (active && !active[s]) return;
+  __shared__ __attribute__((aligned(16))) uint8_t tile[ES::IH * ES::IW];
+  __shared__ __attribute__((aligned(16))) float sfx[ES::CH * ES::CW], sfy[ES::CH * ES::CW], eig[ES::OH * ES::OW];
+  __shared__ unsigned wmax[4];
+  const int x0 = blockIdx.x * EG_TW, y0 = blockIdx.y * EG_TH;
+  load_tile_u8<ES::IH, ES::IW, ES::IW>(src.ptr(s, sstride), w, h, pitch, x0 - ES::XOFF, y0 - ES::HALO - 2, tile);
+  __syncthreads();
+  for (int item = threadIdx.x; item < ES::A_ITEMS; item += 256) ES::sobel_strip(item, w, h, x0, y0, tile, sfx, sfy);
+  __syncthreads();
+  for (int item = threadIdx.x; item < ES::B_ITEMS; item += 256) ES::box_strip(item, sfx, sfy, eig);
+  __syncthreads();
+  __shared__ unsigned long long lkeys[EG_TH * EG_TW];
+  __shared__ int lcount, lbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+  unsigned m = 0;
+  for (int i = threadIdx.x; i < EG_TH * EG_TW; i += 256) {
+    int r = i / EG_TW, c = i - r * EG_TW;
+    int x = x0 + c, y = y0 + r;
+    if (x >= w || y >= h) continue;
+    const float* e = eig + (r + 1) * ES::OW + (c + 1);
+    const float v = e[0];
+    const unsigned ev = f32_ordered(v);
+    m = ev > m ? ev : m;
+    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
+    if (!(v > 0.f)) continue;
+    bool ismax = true;
+#pragma unroll
+    for (int j = -1; j <= 1; j++)
+#pragma unroll
+      for (int k = -1; k <= 1; k++)
+        if (e[j * ES::OW + k] > v) ismax = false;
     if (ismax) {
       int slot = atomicAdd(&lcount, 1);
       unsigned long long key = ((unsigned long long)ev << 32) | (unsigned)(y * w + x);
@@ -1029,8 +1097,15 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
   }
   dim3 grid(div_up(w, EG_TW), div_up(h, EG_TH), S);
   if (ev) hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_eig_cand, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, sc.keys, sc.nkeys, sc.cap,
-                     active);
+  static const bool strip = [] {
+    const char* e = getenv("FLVIS_EIG_STRIP");  // opt-in variant of the corner-response pass (see k_eig_cand_strip)
+    return e && atoi(e) != 0;
+  }();
+  if (strip)
+    hipLaunchKernelGGL(k_eig_cand_strip, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, sc.keys, sc.nkeys, sc.cap, active);
+  else
+    hipLaunchKernelGGL(k_eig_cand, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, sc.keys, sc.nkeys, sc.cap,
+                       active);
   if (ev) hipEventRecord(ev[1], st), hipEventRecord(ev[2], st), hipEventRecord(ev[3], st), hipEventRecord(ev[4], st);
   const size_t lds = sizeof(unsigned long long) * SORT_LDS + sizeof(int) * (PICK_BINS + 8) +
                      (size_t)((w + 31) / 32) * h * sizeof(unsigned);

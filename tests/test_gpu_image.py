@@ -158,3 +158,19 @@ def test_lk_empty_and_ragged(ctx):
     assert np.array_equal(out[1], init[1])          # untouched
     want, wst = O.lk(prev[2], nxt[2], pp[2, :cnt[2]], init[2, :cnt[2]])
     assert np.array_equal(out[2, :cnt[2]], want)
+
+
+def test_gftt_parity_with_the_strip_mined_response_kernel():
+    """FLVIS_EIG_STRIP=1 selects k_eig_cand_strip (four Sobel pairs / responses per thread, flvis_amd/csrc/eig_strip.hpp) for the
+    corner-response pass; the switch is read once per process, so the goodFeaturesToTrack / FeatureDEM parity tests of this file
+    are re-run in a child process with it set: the same corners, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("FLVIS_EIG_STRIP_CHILD"):
+        pytest.skip("this is the child run")
+    env = dict(os.environ, FLVIS_EIG_STRIP="1", FLVIS_EIG_STRIP_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "gftt_parity or gftt_flat or feature_dem"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and " passed" in out and "failed" not in out, out[-3000:]
