@@ -1,6 +1,7 @@
 // flvis_amd: strip-mined phases of the corner-response tile (cornerMinEigenVal of cv::goodFeaturesToTrack, blockSize 3, Sobel 3):
 // the same arithmetic as eig_tile<1> of img_kernels.hip, pixel for pixel and operation for operation, with every thread producing
 // FOUR horizontally adjacent values from one register-resident window instead of one value from nine (eighteen) LDS reads:
+//   * 3x3 local maxima: a 3 x 6 window of responses -> the candidate keys of 4 output pixels (phase C).
 //   * Sobel: a 3 x 6 byte window -> 4 (fx, fy) pairs.  The integer sums are exact, so they are shared as column sums
 //     (dx = col[k+2] - col[k], col = top + 2 mid + bottom) and row differences (dy = d[k] + 2 d[k+1] + d[k+2], d = bottom - top).
 //   * covariance box sums + smaller eigenvalue: a 3 x 6 window of fx / fy -> the 18 products fx*fx, fx*fy, fy*fy once, then the
@@ -138,6 +139,50 @@ FLVIS_EIG_HD void box_strip(int item, const float* sfx, const float* sfy, float*
     const int r = item - OH * B_FULL, c0 = 4 * B_FULL;  // the last two responses of row r
     box_window<2>(sfx + r * CW + c0, sfy + r * CW + c0, eig + r * OW + c0);
   }
+}
+
+// order-preserving float -> uint32 (larger float => larger uint), as dev_common.hpp's f32_ordered
+FLVIS_EIG_HD uint32_t ordered_bits(float f) {
+  uint32_t b;
+  memcpy(&b, &f, 4);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+constexpr int C_ITEMS = TH * (TW / 4);  // 256: one strip of four output pixels per thread
+
+// phase C, item in [0, C_ITEMS): the four output pixels (y0 + r, x0 + 4 q .. + 3).  Returns the number of 3x3 local maxima among them
+// (a pixel strictly inside the image whose response is positive and not exceeded by any neighbour -- see k_eig_cand) with their
+// sort keys ~((ordered(response) << 32) | pixel offset) in keys[0 .. n), and in max_ordered the largest ordered(response) of the
+// strip's pixels that lie in the image (0 when none does): exactly what the one-pixel loop of k_eig_cand contributes for them.
+FLVIS_EIG_HD int nms_strip(int item, int w, int h, int x0, int y0, const float* eig, unsigned long long* keys, uint32_t& max_ordered) {
+  const int r = item / (TW / 4), c0 = 4 * (item - r * (TW / 4));
+  const int y = y0 + r;
+  max_ordered = 0;
+  if (y >= h || x0 + c0 >= w) return 0;
+  float win[3][6];  // responses of rows r .. r + 2, columns c0 .. c0 + 5 of the response region (output pixel (r, c) sits at (r + 1, c + 1))
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) win[j][k] = eig[(r + j) * OW + c0 + k];
+  int n = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int x = x0 + c0 + q;
+    if (x >= w) continue;
+    const float v = win[1][q + 1];
+    const uint32_t ev = ordered_bits(v);
+    max_ordered = ev > max_ordered ? ev : max_ordered;
+    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
+    if (!(v > 0.f)) continue;
+    bool ismax = true;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        if (win[j][q + k] > v) ismax = false;
+    if (ismax) keys[n++] = ~(((unsigned long long)ev << 32) | (unsigned)(y * w + x));
+  }
+  return n;
 }
 
 }  // namespace eigstrip

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_eig_cand(ImgSel src, int w, int h, int 
 
 // The same pass with the strip-mined phases of eig_strip.hpp (four Sobel pairs / four responses per thread from one register
 // window; bit-identical values -- tests/test_eig_strip.py runs those very functions on the host over whole images).  Opt-in
-// (FLVIS_EIG_STRIP=1) until it has been measured on the GPU against k_eig_cand; everything after the response map is k_eig_cand's.
+// (FLVIS_EIG_STRIP=1) until it has been measured on the GPU against k_eig_cand.
 __global__ __launch_bounds__(256) void k_eig_cand_strip(ImgSel src, int w, int h, int pitch, size_t sstride, unsigned* __restrict__ maxenc,
                                                         unsigned long long* __restrict__ keys, int* __restrict__ nkeys, int cap,
                                                         const int* __restrict__ active) {
@@ -432,32 +432,21 @@ __global__ __launch_bounds__(256) void k_eig_cand_strip(ImgSel src, int w, int h
   __syncthreads();
   for (int item = threadIdx.x; item < ES::B_ITEMS; item += 256) ES::box_strip(item, sfx, sfy, eig);
   __syncthreads();
+  // 3x3 maxima: one strip of four output pixels per thread; the keys of the workgroup are gathered in LDS (one LDS atomic per
+  // thread that found any) and appended to the stream's list with ONE global atomic, as in k_eig_cand
   __shared__ unsigned long long lkeys[EG_TH * EG_TW];
   __shared__ int lcount, lbase;
   if (threadIdx.x == 0) lcount = 0;
   __syncthreads();
-  unsigned m = 0;
-  for (int i = threadIdx.x; i < EG_TH * EG_TW; i += 256) {
-    int r = i / EG_TW, c = i - r * EG_TW;
-    int x = x0 + c, y = y0 + r;
-    if (x >= w || y >= h) continue;
-    const float* e = eig + (r + 1) * ES::OW + (c + 1);
-    const float v = e[0];
-    const unsigned ev = f32_ordered(v);
-    m = ev > m ? ev : m;
-    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
-    if (!(v > 0.f)) continue;
-    bool ismax = true;
+  static_assert(ES::C_ITEMS == 256, "one strip per thread");
+  unsigned long long k4[4];
+  uint32_t m = 0;
+  const int nk = ES::nms_strip(threadIdx.x, w, h, x0, y0, eig, k4, m);
+  if (nk > 0) {
+    const int slot = atomicAdd(&lcount, nk);
 #pragma unroll
-    for (int j = -1; j <= 1; j++)
-#pragma unroll
-      for (int k = -1; k <= 1; k++)
-        if (e[j * ES::OW + k] > v) ismax = false;
-    if (ismax) {
-      int slot = atomicAdd(&lcount, 1);
-      unsigned long long key = ((unsigned long long)ev << 32) | (unsigned)(y * w + x);
-      lkeys[slot] = ~key;
-    }
+    for (int i = 0; i < 4; i++)
+      if (i < nk) lkeys[slot + i] = k4[i];
   }
   m = wave_max_u32(m);
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
