@@ -14,6 +14,16 @@
  *   flvis_hip_gftt               <- cv::goodFeaturesToTrack     src/processing/feature_dem.cpp:160,221
  *   flvis_hip_feature_dem_detect / _redetect <- FeatureDEM::detect / ::redetect   src/processing/feature_dem.cpp:124-266
  *                                              (include/feature_dem.h:40-50)
+ *   flvis_hip_orb_detect_and_compute / _hamming_knn2 / _orb_match  <- cv::ORB, cv::BFMatcher   src/backend/vo_loopclosing.cpp:242-243,601-639
+ *   flvis_hip_bow_load_vocabulary / _set_vocabulary / _transform / _score / _score_jobs, flvis_loop_candidate
+ *                                <- DBoW3::Vocabulary(file), ::transform, ::score; isLoopCandidate   vo_loopclosing.cpp:1097,249-253,417-437,520-590
+ *   flvis_hip_lc_keyframe_landmarks  <- stereo LK + triangulation / depth lookup of the ORB keypoints   vo_loopclosing.cpp:255-372
+ *   flvis_hip_pnp_ransac         <- cv::solvePnPRansac of isLoopClosureKF                             vo_loopclosing.cpp:660-686
+ *   flvis_hip_pgo_loop_closure   <- loopClosureOnCovGraphG2ONew (g2o EdgeSE3 pose graph)              vo_loopclosing.cpp:742-944
+ * Pipeline-level entry points (the nodelets' work for a batch of streams / sequences):
+ *   flvis_config_load, flvis_tracker_create, flvis_imu_feed, flvis_image_feed(_host), flvis_get_*   <- TrackingNodeletClass / F2FTracking
+ *   flvis_ba_push_keyframe, flvis_get_correction, flvis_correction_feed                               <- LocalMapNodeletClass
+ *   flvis_lc_params_load, flvis_loop_closer_*                                                          <- LoopClosingNodeletClass
  */
 #ifndef FLVIS_HIP_H
 #define FLVIS_HIP_H
