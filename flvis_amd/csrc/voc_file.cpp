@@ -247,6 +247,9 @@ void parse_binary(const std::vector<uint8_t>& file, flvis_voc_file& v) {
   b.L = c.get<int32_t>();
   b.scoring = c.get<int32_t>();
   b.weighting = c.get<int32_t>();
+  // a record is 60 bytes (id, parent, weight, cv::Mat header, 32 descriptor bytes): a node count the stream cannot hold is refused
+  // before anything of that size is allocated
+  if ((uint64_t)(nnodes - 1) * 60 > (uint64_t)(c.end - c.p)) bad("vocabulary: the node count exceeds what the file holds");
   b.recs.resize(nnodes - 1);
   for (auto& r : b.recs) {
     r.id = c.get<uint32_t>();

@@ -158,7 +158,9 @@ def test_refusals(voc, tmp_path):
     VF.write_binary(p, voc, 5, 3)
     raw = open(p, "rb").read()
     open(p, "wb").write(raw[:len(raw) // 2])
-    refused(p, "unexpected end")
+    refused(p, "node count exceeds")                               # half the node records are missing
+    open(p, "wb").write(raw[:-5])
+    refused(p, "unexpected end")                                   # the word table is cut short
     bad = bytearray(raw)
     struct.pack_into("<I", bad, 13 + 16, 10 ** 6)                  # first node id far out of range
     open(p, "wb").write(bytes(bad))
@@ -167,6 +169,10 @@ def test_refusals(voc, tmp_path):
     struct.pack_into("<I", bad, 13 + 16 + 4, struct.unpack_from("<I", raw, 13 + 16)[0])   # a node that is its own parent
     open(p, "wb").write(bytes(bad))
     refused(p, "out of range")
+    bad = bytearray(raw)
+    struct.pack_into("<I", bad, 9, 0xFFFFFFF0)                     # a node count no file of this size can hold: refused, not allocated
+    open(p, "wb").write(bytes(bad))
+    refused(p, "node count exceeds")
     open(p, "wb").write(b"neither binary nor yaml\n")
     refused(p, "neither a DBoW3 binary")
     t = str(tmp_path / "v.txt")
