@@ -79,6 +79,8 @@ struct Qlz1 {
       out.insert(out.end(), src + hs, end);
       return csize;
     }
+    // (a 3-byte token yields at most 255 bytes: a size no block of this length can decode to is refused before it is allocated)
+    if (dsize > 90 * csize + 64) bad("compressed vocabulary: implausible decompressed size");
     out.resize(base + dsize);
     uint8_t* dst0 = out.data() + base;
     for (int i = 0; i < 4096; i++) table[i] = -1;

@@ -203,6 +203,18 @@ def test_corrupt_compressed_streams_are_refused_not_crashed(voc, tmp_path):
     assert "refused" in outcomes
 
 
+def test_implausible_block_size_is_refused_before_allocating(voc, tmp_path):
+    p = str(tmp_path / "v.dbow3")
+    VF.write_binary(p, voc, 5, 3, compress=VF.qlz1_compress)
+    raw = bytearray(open(p, "rb").read())
+    assert raw[17] & 2                                             # first block: long header (flags, u32 compressed, u32 decompressed)
+    struct.pack_into("<I", raw, 17 + 5, 0xFFFFFF00)
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(flvis_amd.FlvisError) as e:
+        flvis_amd.read_vocabulary_file(p)
+    assert "implausible" in str(e.value)
+
+
 def test_symbols_exported():
     lib = flvis_amd.load_library()
     for name in ("flvis_voc_file_open", "flvis_voc_file_info", "flvis_voc_file_arrays", "flvis_voc_file_close",
