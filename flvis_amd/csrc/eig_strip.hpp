@@ -150,39 +150,40 @@ FLVIS_EIG_HD uint32_t ordered_bits(float f) {
 
 constexpr int C_ITEMS = TH * (TW / 4);  // 256: one strip of four output pixels per thread
 
-// phase C, item in [0, C_ITEMS): the four output pixels (y0 + r, x0 + 4 q .. + 3).  Returns the number of 3x3 local maxima among them
-// (a pixel strictly inside the image whose response is positive and not exceeded by any neighbour -- see k_eig_cand) with their
-// sort keys ~((ordered(response) << 32) | pixel offset) in keys[0 .. n), and in max_ordered the largest ordered(response) of the
-// strip's pixels that lie in the image (0 when none does): exactly what the one-pixel loop of k_eig_cand contributes for them.
-FLVIS_EIG_HD int nms_strip(int item, int w, int h, int x0, int y0, const float* eig, unsigned long long* keys, uint32_t& max_ordered) {
+// phase C, item in [0, C_ITEMS): the four output pixels (y0 + r, x0 + 4 q .. + 3).  Returns a 4-bit mask of the 3x3 local maxima among
+// them (a pixel strictly inside the image whose response is positive and not exceeded by any neighbour -- see k_eig_cand) with the
+// sort key ~((ordered(response) << 32) | pixel offset) of pixel q in keys[q] (defined where the mask bit is set), and in max_ordered
+// the largest ordered(response) of the strip's pixels that lie in the image (0 when none does): exactly what the one-pixel loop of
+// k_eig_cand contributes for them.  Written without branches over the pixels: "no neighbour is greater" is !(max of the eight > v)
+// (fmaxf ignores a NaN operand just as the comparison `neighbour > v` does).
+FLVIS_EIG_HD unsigned nms_strip(int item, int w, int h, int x0, int y0, const float* eig, unsigned long long* keys, uint32_t& max_ordered) {
   const int r = item / (TW / 4), c0 = 4 * (item - r * (TW / 4));
   const int y = y0 + r;
   max_ordered = 0;
-  if (y >= h || x0 + c0 >= w) return 0;
+  if (y >= h || x0 + c0 >= w) return 0u;
   float win[3][6];  // responses of rows r .. r + 2, columns c0 .. c0 + 5 of the response region (output pixel (r, c) sits at (r + 1, c + 1))
 #pragma unroll
   for (int j = 0; j < 3; j++)
 #pragma unroll
     for (int k = 0; k < 6; k++) win[j][k] = eig[(r + j) * OW + c0 + k];
-  int n = 0;
+  float colmax[6];  // max of the top and bottom row per column: shared by the pixels whose windows contain the column
+#pragma unroll
+  for (int k = 0; k < 6; k++) colmax[k] = fmaxf(win[0][k], win[2][k]);
+  const bool row_inside = y >= 1 && y < h - 1;
+  unsigned mask = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int x = x0 + c0 + q;
-    if (x >= w) continue;
     const float v = win[1][q + 1];
     const uint32_t ev = ordered_bits(v);
-    max_ordered = ev > max_ordered ? ev : max_ordered;
-    if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) continue;
-    if (!(v > 0.f)) continue;
-    bool ismax = true;
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-#pragma unroll
-      for (int k = 0; k < 3; k++)
-        if (win[j][q + k] > v) ismax = false;
-    if (ismax) keys[n++] = ~(((unsigned long long)ev << 32) | (unsigned)(y * w + x));
+    const bool in_image = x < w;
+    max_ordered = (in_image && ev > max_ordered) ? ev : max_ordered;
+    const float nb = fmaxf(fmaxf(fmaxf(colmax[q], colmax[q + 1]), colmax[q + 2]), fmaxf(win[1][q], win[1][q + 2]));
+    const bool is_max = in_image && row_inside && x >= 1 && x < w - 1 && v > 0.f && !(nb > v);
+    keys[q] = ~(((unsigned long long)ev << 32) | (unsigned)(y * w + x));
+    mask |= is_max ? (1u << q) : 0u;
   }
-  return n;
+  return mask;
 }
 
 }  // namespace eigstrip

@@ -441,12 +441,12 @@ __global__ __launch_bounds__(256) void k_eig_cand_strip(ImgSel src, int w, int h
   static_assert(ES::C_ITEMS == 256, "one strip per thread");
   unsigned long long k4[4];
   uint32_t m = 0;
-  const int nk = ES::nms_strip(threadIdx.x, w, h, x0, y0, eig, k4, m);
-  if (nk > 0) {
-    const int slot = atomicAdd(&lcount, nk);
+  const unsigned found = ES::nms_strip(threadIdx.x, w, h, x0, y0, eig, k4, m);
+  if (found) {
+    const int slot = atomicAdd(&lcount, __popc(found));
 #pragma unroll
     for (int i = 0; i < 4; i++)
-      if (i < nk) lkeys[slot + i] = k4[i];
+      if (found >> i & 1u) lkeys[slot + __popc(found & ((1u << i) - 1u))] = k4[i];
   }
   m = wave_max_u32(m);
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;

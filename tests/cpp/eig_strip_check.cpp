@@ -49,8 +49,9 @@ int main(int argc, char** argv) {
         for (int item = 0; item < C_ITEMS; item++) {
           unsigned long long k4[4];
           uint32_t m = 0;
-          const int n = nms_strip(item, w, h, x0, y0, eig.data(), k4, m);
-          for (int i = 0; i < n; i++) got.push_back(k4[i]);
+          const unsigned mask = nms_strip(item, w, h, x0, y0, eig.data(), k4, m);
+          for (int i = 0; i < 4; i++)
+            if (mask >> i & 1u) got.push_back(k4[i]);
           gmax = m > gmax ? m : gmax;
         }
         for (int i = 0; i < TH * TW; i++) {
