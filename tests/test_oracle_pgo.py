@@ -109,3 +109,75 @@ def test_several_loops_absent_keyframes_and_degenerate_inputs():
     # deterministic
     r, T_again, _, _ = pgo(p["est"], present, p["loops"], p["loop_poses"])
     assert np.array_equal(T, T_again)
+
+
+def test_optimum_matches_an_independent_scipy_minimisation_of_the_same_robust_cost():
+    """The same problem stated from scratch with rotation matrices (scipy Rotation) -- vertices T_w_c of keyframes kf_prev..kf_curr,
+    EdgeSE3 error (translation, vector part of the w >= 0 quaternion) of X_i^-1 X_j against the measurement, Cauchy on each edge's
+    squared error (delta 1, information I), first vertex fixed -- and minimised by scipy.optimize.least_squares on residuals whose
+    squared norm per edge is log(1 + |e|^2).  The oracle's Levenberg (g2o's schedule) must land on the same optimum."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+
+    p = PS.make_loop(11, n_kf=24, drift=(0.03, 0.006))
+    n = len(p["est"])
+    a, b = [int(x) for x in p["loops"][0]]
+    r, T, drift, stats = pgo(p["est"], np.ones(n, np.uint8), p["loops"], p["loop_poses"])
+    assert r == 1
+
+    def to_Rt(p7):                                      # pose7 (t, q xyzw) -> (R, t)
+        return Rotation.from_quat(p7[3:7]).as_matrix(), np.asarray(p7[:3], float)
+
+    def inv(Rt):
+        return Rt[0].T, -Rt[0].T @ Rt[1]
+
+    def mul(A, B):
+        return A[0] @ B[0], A[0] @ B[1] + A[1]
+
+    ids = list(range(a, b + 1))                          # vertices; the first one (kf_prev) is fixed
+    X0 = [inv(to_Rt(p["est"][i])) for i in ids]          # estimates T_w_c = T_c_w^-1
+    edges = []
+    for i in ids:
+        for j in range(i + 1, min(b, i + 5) + 1):
+            Tji = mul(to_Rt(p["est"][j]), inv(to_Rt(p["est"][i])))
+            edges.append((i - a, j - a, inv(Tji)))       # measurement X_i^-1 X_j = (T_c_w,j T_w_c,i)^-1
+    edges.append((0, b - a, inv(to_Rt(p["loop_poses"][0]))))
+
+    def unpack(x):
+        X = [X0[0]]
+        for k in range(1, len(ids)):
+            d = x[6 * (k - 1):6 * k]
+            X.append(mul(X0[k], (Rotation.from_rotvec(d[3:]).as_matrix(), d[:3])))
+        return X
+
+    def edge_errors(X):
+        out = []
+        for i, j, Z in edges:
+            E = mul(mul(inv(Z), inv(X[i])), X[j])
+            q = Rotation.from_matrix(E[0]).as_quat()
+            if q[3] < 0:
+                q = -q
+            out.append(np.concatenate([E[1], q[:3]]))
+        return np.array(out)
+
+    def residuals(x):
+        e = edge_errors(unpack(x))
+        s2 = (e * e).sum(1)
+        scale = np.where(s2 > 1e-24, np.sqrt(np.log1p(s2) / np.maximum(s2, 1e-300)), 1.0)
+        return (e * scale[:, None]).ravel()
+
+    def cost_of(T_c_w):
+        X = [inv(to_Rt(T_c_w[i])) for i in ids]
+        e = edge_errors(X)
+        return float(np.log1p((e * e).sum(1)).sum())
+
+    sol = least_squares(residuals, np.zeros(6 * (len(ids) - 1)), method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=200)
+    cost_scipy = 2 * sol.cost
+    cost_oracle = cost_of(T)
+    assert abs(cost_oracle - stats[2]) < 1e-9 * max(1.0, stats[2])         # the oracle reports the cost this test defines
+    assert cost_of(p["est"]) > 5 * cost_scipy                               # the drifted input is far from the optimum
+    assert abs(cost_oracle - cost_scipy) < 1e-6 * cost_scipy + 1e-10, (cost_oracle, cost_scipy)
+    Xs = unpack(sol.x)
+    for k, i in enumerate(ids):
+        Ro, to = inv(to_Rt(T[i]))
+        assert np.linalg.norm(to - Xs[k][1]) < 1e-4 and np.linalg.norm(Ro - Xs[k][0]) < 1e-4, (i, np.linalg.norm(to - Xs[k][1]))
