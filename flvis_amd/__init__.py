@@ -626,6 +626,34 @@ class Tracker:
         g = (C.c_double * 3)(*[float(x) for x in gyro])
         self.ctx._check(self.lib.flvis_imu_feed(self.ctx._h, stream, C.c_double(t), a, g), "imu_feed")
 
+    def imu_feed_out(self, stream, t, acc, gyro):
+        """F2FTracking::imu_feed with its outputs: integrates the sensor-frame sample now; returns (q_w_i wxyz, pos_w_i, vel_w_i)."""
+        np = self.np
+        a = (C.c_double * 3)(*[float(x) for x in acc])
+        g = (C.c_double * 3)(*[float(x) for x in gyro])
+        q, p, v = np.zeros(4), np.zeros(3), np.zeros(3)
+        self.ctx._check(self.lib.flvis_imu_feed_out(self.ctx._h, stream, C.c_double(t), a, g, _P(q, C.c_double), _P(p, C.c_double),
+                                                    _P(v, C.c_double)), "imu_feed_out")
+        return q, p, v
+
+    def imu_states(self, stream, cap=512):
+        """Rows (t, q_w_i wxyz, pos_w_i, vel_w_i) of the IMU samples integrated since the previous call; also the rows lost."""
+        np = self.np
+        rows = np.zeros((cap, 11), np.float64)
+        n, dropped = C.c_int(0), C.c_int(0)
+        self.ctx._check(self.lib.flvis_get_imu_states(self.ctx._h, stream, cap, _P(rows, C.c_double), C.byref(n), C.byref(dropped)),
+                        "get_imu_states")
+        return rows[:n.value].copy(), dropped.value
+
+    def write_imu_trajectory(self, rows11, path, min_dt=0.0, append=False):
+        """The recorder on /imu_pose: rows of imu_states() as `stamp x y z qw qx qy qz` lines; returns the lines written."""
+        np = self.np
+        r = np.ascontiguousarray(rows11, np.float64).reshape(-1, 11)
+        n = self.lib.flvis_write_imu_trajectory(_P(r, C.c_double), len(r), path.encode(), C.c_double(min_dt), int(append))
+        if n < 0:
+            raise FlvisError("write_imu_trajectory failed (%d)" % n)
+        return n
+
     def image_feed(self, img0, img1, times, want_out=True, with_local_map=True):
         """img0/img1: uint8 cuda tensors [S,H,W]; times: sequence of S floats."""
         np = self.np

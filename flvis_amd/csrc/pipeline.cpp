@@ -56,6 +56,7 @@ struct Lane {
   size_t input_bytes = 0;
   std::vector<double> h_imu;  // [S][IMU_MAX][7] staged between two frames
   std::vector<int> h_nimu;
+  std::vector<long long> imu_read;  // [S] rows of the stream's IMU-state ring the caller has fetched (flvis_get_imu_states)
   // Host staging: a ring of pinned slots, each guarded by an event recorded after its upload, so that image_feed never
   // waits for the previous frame -- the host runs several frames ahead of the GPU and a frame's launches are already queued
   // when the GPU gets to them.
@@ -333,6 +334,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   DA(st, StreamState, S);
   DA(lm, Landmark, (size_t)2 * S * NMAX);
   DA(vi, MotionState, (size_t)S * VI_QUEUE);
+  DA(imu_out, double, (size_t)S * IMU_OUT_CAP * 11);
   DA(prev_pts, float, (size_t)S * NMAX * 2);
   DA(next_pts, float, (size_t)S * NMAX * 2);
   DA(lk_status, uint8_t, (size_t)S * NMAX);
@@ -428,6 +430,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   hipMemcpy(seeds, hseed.data(), sizeof(unsigned long long) * S, hipMemcpyHostToDevice);
   L->h_imu.assign((size_t)S * IMU_MAX * 7, 0.0);
   L->h_nimu.assign(S, 0);
+  L->imu_read.assign(S, 0);
   for (int k = 0; k < Lane::PIN_RING; k++)
     if (hipHostMalloc(&L->pinned[k], L->input_bytes, hipHostMallocDefault) != hipSuccess) return false;
   {
@@ -600,6 +603,79 @@ int flvis_imu_feed(flvis_ctx* ctx, int stream, double t, const double* a, const 
       break;
   }
   return flvis_imu_feed_flvis_frame(ctx, stream, 1, s);
+}
+
+// F2FTracking::imu_feed's outputs (f2f_tracking.cpp:46-57), fetched in batches: the rows written since the previous call.
+int flvis_get_imu_states(flvis_ctx* ctx, int stream, int cap, double* h_rows11, int* n_out, int* n_dropped) {
+  if (!ctx || !ctx->pipe || !n_out || cap < 0 || (cap > 0 && !h_rows11)) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "get_imu_states: bad stream");
+  hipSetDevice(ctx->device);
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  // samples staged since the last image feed are integrated now (same arithmetic, same order as at the next frame head)
+  bool staged = false;
+  for (int s = 0; s < L.S; s++) staged = staged || L.h_nimu[s] > 0;
+  if (staged) {
+    const int rc = lane_flush_imu(ctx, L);
+    if (rc != FLVIS_OK) return rc;
+  } else {
+    hipError_t e = hipStreamSynchronize(L.st);
+    if (e != hipSuccess) return ctx->hip_fail(e, "get_imu_states");
+  }
+  long long seen = 0;
+  hipError_t e = hipMemcpy(&seen, reinterpret_cast<const char*>(L.pipe.st + ls) + offsetof(StreamState, imu_seen), sizeof(seen),
+                           hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return ctx->hip_fail(e, "get_imu_states");
+  long long first = L.imu_read[ls];
+  int dropped = 0;
+  if (seen - first > IMU_OUT_CAP) {  // the ring wrapped since the last fetch: the oldest rows are gone
+    dropped = (int)std::min<long long>(seen - first - IMU_OUT_CAP, 0x7fffffff);
+    first = seen - IMU_OUT_CAP;
+  }
+  const long long avail = seen - first;
+  const int n = (int)std::min<long long>(avail, cap);
+  const double* ring = L.pipe.imu_out + (size_t)ls * IMU_OUT_CAP * 11;
+  for (int done = 0; done < n && e == hipSuccess;) {  // at most two pieces (ring wrap)
+    const int r0 = (int)((first + done) % IMU_OUT_CAP);
+    const int m = std::min(n - done, IMU_OUT_CAP - r0);
+    e = hipMemcpy(h_rows11 + (size_t)done * 11, ring + (size_t)r0 * 11, sizeof(double) * 11 * m, hipMemcpyDeviceToHost);
+    done += m;
+  }
+  if (e != hipSuccess) return ctx->hip_fail(e, "get_imu_states");
+  L.imu_read[ls] = first + n;  // rows beyond cap stay for the next call
+  *n_out = n;
+  if (n_dropped) *n_dropped = dropped;
+  return FLVIS_OK;
+}
+
+// The call-for-call form of F2FTracking::imu_feed(time, acc, gyro, q_w_i&, pos_w_i&, vel_w_i&): the sample is integrated NOW
+// (upload + k_imu_feed + read-back, ~0.1 ms) and its state returned, as imu_callback needs it for /imu_pose, /imu_odom and
+// /imu_path (vo_tracking.cpp:362-369).
+int flvis_imu_feed_out(flvis_ctx* ctx, int stream, double t, const double* acc3, const double* gyro3, double* q_w_i_wxyz,
+                       double* pos_w_i, double* vel_w_i) {
+  if (!q_w_i_wxyz || !pos_w_i || !vel_w_i) return FLVIS_ERR_INVALID_ARG;
+  int rc = flvis_imu_feed(ctx, stream, t, acc3, gyro3);
+  if (rc != FLVIS_OK) return rc;
+  Pipeline* pl = ctx->pipe;
+  hipSetDevice(ctx->device);
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  rc = lane_flush_imu(ctx, L);
+  if (rc != FLVIS_OK) return rc;
+  long long seen = 0;
+  hipError_t e = hipMemcpy(&seen, reinterpret_cast<const char*>(L.pipe.st + ls) + offsetof(StreamState, imu_seen), sizeof(seen),
+                           hipMemcpyDeviceToHost);
+  double row[11];
+  if (e == hipSuccess && seen > 0)
+    e = hipMemcpy(row, L.pipe.imu_out + ((size_t)ls * IMU_OUT_CAP + (size_t)((seen - 1) % IMU_OUT_CAP)) * 11, sizeof(row),
+                  hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return ctx->hip_fail(e, "imu_feed_out");
+  if (seen <= 0) return ctx->fail(FLVIS_ERR_HIP, "imu_feed_out: the sample was not integrated");
+  memcpy(q_w_i_wxyz, row + 1, 32);
+  memcpy(pos_w_i, row + 5, 24);
+  memcpy(vel_w_i, row + 8, 24);
+  return FLVIS_OK;
 }
 
 
@@ -1286,6 +1362,24 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first, int n, const c
   return written;
 }
 
+
+// The recorder on /imu_pose (launch/flvis_euroc_mav.launch:83-103: vo_repub_rec with sub_type PoseStamped, sub_topic /imu_pose,
+// output est.txt): pubPose(q_w_i, pos_w_i, stamp) of every IMU sample, `stamp x y z qw qx qy qz` (vo_repub_rec.cpp:74-91), with
+// the throttle as written there (see flvis_write_trajectory).  Rows as flvis_get_imu_states returns them.
+int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, double min_dt, int append) {
+  if (!path || n < 0 || (n > 0 && !h_rows11)) return FLVIS_ERR_INVALID_ARG;
+  FILE* f = fopen(path, append ? "a" : "w");
+  if (!f) return FLVIS_ERR_INVALID_ARG;
+  int written = 0;
+  for (int i = 0; i < n; i++) {
+    const double* r = h_rows11 + (size_t)i * 11;
+    if (min_dt > 0 && !(r[0] - h_rows11[0] > min_dt)) continue;
+    fprintf(f, "%.9f %.6g %.6g %.6g %.6g %.6g %.6g %.6g\n", r[0], r[5], r[6], r[7], r[1], r[2], r[3], r[4]);
+    written++;
+  }
+  fclose(f);
+  return written;
+}
 
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) {
   if (!ctx || !ctx->pipe || !h3) return FLVIS_ERR_INVALID_ARG;

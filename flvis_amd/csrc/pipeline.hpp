@@ -15,6 +15,7 @@ namespace flvis {
 
 constexpr int NMAX = 1024;        // landmark capacity per stream and frame slot
 constexpr int IMU_MAX = 64;       // IMU samples accepted per stream between two frames
+constexpr int IMU_OUT_CAP = 512;  // rows of the per-stream ring behind F2FTracking::imu_feed's outputs (flvis_get_imu_states)
 constexpr int VI_QUEUE = 400;     // STATES_QUEUE_SIZE (src/processing/include/vi_motion.h:10)
 constexpr int KF_MAXLM = 1024;    // landmarks per keyframe payload
 constexpr int KFQ = 16;            // per-stream keyframe queue between the tracker and the local map
@@ -89,6 +90,7 @@ struct StreamState {
   double dbg_T_pnp[7], dbg_T_lm[7], dbg_T_pre[7];  // pose right after PnP-RANSAC / after the pose LM of the last Tracking frame (tests)
   double kf_dq[4], kf_dt;  // gyro rotation preintegration since the last keyframe (w, x, y, z), see KeyFrameDev::imu_dq
   int feeds;  // image_feed calls seen by this stream (= row of the device-side trajectory the frame is recorded in)
+  long long imu_seen;  // IMU samples integrated so far (= rows ever written to the stream's IMU-state output ring)
 };
 
 struct FrameOut {  // per stream, per image_feed

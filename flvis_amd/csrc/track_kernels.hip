@@ -65,20 +65,24 @@ __device__ inline void imu_feed_dev(const Pipe& p, int s) {
   int n = p.n_imu[s];
   if (n > IMU_MAX) n = IMU_MAX;
   const double* in = p.imu_in + (size_t)s * IMU_MAX * 7;
+  // F2FTracking::imu_feed's per-sample outputs go to the stream's output ring (row = sample number % IMU_OUT_CAP)
+  double* const out = p.imu_out + (size_t)s * IMU_OUT_CAP * IMU_ROW;
+  long long seen = st.imu_seen;
   int i = 0;
-  for (; i < n && !st.vi_initialized; i++)  // start-up: attitude initialisation, sample by sample
+  for (; i < n && !st.vi_initialized; i++, seen++)  // start-up: attitude initialisation, sample by sample
     vi_imu_feed(p.cam, st, ring, in[7 * i], V3{in[7 * i + 1], in[7 * i + 2], in[7 * i + 3]},
-                V3{in[7 * i + 4], in[7 * i + 5], in[7 * i + 6]});
+                V3{in[7 * i + 4], in[7 * i + 5], in[7 * i + 6]}, out + (size_t)(seen % IMU_OUT_CAP) * IMU_ROW);
   if (i < n) {
     const V3 acc_bias = ld3(st.acc_bias), gyro_bias = ld3(st.gyro_bias);
     int head = st.vi_head, count = st.vi_count;
     MotionState prev = ring.back();
     Q4 kdq{st.kf_dq[0], st.kf_dq[1], st.kf_dq[2], st.kf_dq[3]};
     double kdt = st.kf_dt;
-    for (; i < n; i++) {
+    for (; i < n; i++, seen++) {
       MotionState cur;
       vi_propagate(p.cam, prev, in[7 * i], V3{in[7 * i + 1], in[7 * i + 2], in[7 * i + 3]},
                    V3{in[7 * i + 4], in[7 * i + 5], in[7 * i + 6]}, acc_bias, gyro_bias, cur, kdq, kdt);
+      imu_row_store(out + (size_t)(seen % IMU_OUT_CAP) * IMU_ROW, cur.t, ms_q(cur), ld3(cur.pos), ld3(cur.vel));
       ring.base[(head + count) % VI_QUEUE] = cur;  // ViRing::push_back on the local cursor
       count++;
       if (count >= VI_QUEUE) {
@@ -92,6 +96,7 @@ __device__ inline void imu_feed_dev(const Pipe& p, int s) {
     st.kf_dq[0] = kdq.w, st.kf_dq[1] = kdq.x, st.kf_dq[2] = kdq.y, st.kf_dq[3] = kdq.z;
     st.kf_dt = kdt;
   }
+  st.imu_seen = seen;
   p.n_imu[s] = 0;
 }
 __global__ void k_imu_feed(Pipe p) {

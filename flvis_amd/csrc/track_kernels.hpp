@@ -15,6 +15,7 @@ struct Pipe {
   const unsigned long long* seeds;  // [S] RANSAC seeds
   double* imu_in;           // [S][IMU_MAX][7]  (t, acc, gyro) in the FLVIS IMU frame
   int* n_imu;               // [S]
+  double* imu_out;          // [S][IMU_OUT_CAP][11]  F2FTracking::imu_feed's outputs per sample: (t, q_w_i wxyz, pos_w_i, vel_w_i)
   float* prev_pts;          // [S][NMAX][2]
   float* next_pts;          // [S][NMAX][2]
   uint8_t* lk_status;       // [S][NMAX]

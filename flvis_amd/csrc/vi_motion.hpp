@@ -95,13 +95,26 @@ __device__ inline void vi_propagate(const CamParams& cam, const MotionState& s_p
   kf_dt += dt;
 }
 
-// F2FTracking::imu_feed for one sample (f2f_tracking.cpp:46-57)
+// what F2FTracking::imu_feed hands back per sample (q_w_i, pos_w_i, vel_w_i; f2f_tracking.cpp:46-57): a row of the stream's
+// IMU-state output ring, (t, qw qx qy qz, px py pz, vx vy vz)
+constexpr int IMU_ROW = 11;
+FD void imu_row_store(double* row, double t, Q4 q, V3 p, V3 v) {
+  row[0] = t;
+  row[1] = q.w, row[2] = q.x, row[3] = q.y, row[4] = q.z;
+  row[5] = p.x, row[6] = p.y, row[7] = p.z;
+  row[8] = v.x, row[9] = v.y, row[10] = v.z;
+}
+
+// F2FTracking::imu_feed for one sample (f2f_tracking.cpp:46-57); `row` receives the outputs of the call: during the attitude
+// initialisation viIMUinitialization returns the identity / zeros (vi_motion.cpp:39-40) except for the sample that sets the first
+// attitude (:60), afterwards viIMUPropagation returns the new state (:206-208)
 __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const ViRing& ring, double t, V3 acc_raw,
-                                   V3 gyro_raw) {
+                                   V3 gyro_raw, double* row) {
   const double g = 9.81;
   V3 acc = acc_raw - ld3(st.acc_bias), gyro = gyro_raw - ld3(st.gyro_bias);
   if (!st.vi_initialized) {
     st.has_imu = 1;
+    Q4 q_out{1, 0, 0, 0};
     MotionState m;
     st3(m.pos, V3{0, 0, 0});
     st3(m.vel, V3{0, 0, 0});
@@ -114,6 +127,7 @@ __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const 
         ms_set_q(m, rpy2Q(rpy));
         ring.push_back(m);
         st.vi_first = 0;
+        q_out = ms_q(m);
       }
     } else {
       const MotionState& b = ring.back();
@@ -128,6 +142,7 @@ __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const 
       ring.push_back(m);
       if (ring.size() > 30) st.vi_initialized = 1;
     }
+    imu_row_store(row, t, q_out, V3{0, 0, 0}, V3{0, 0, 0});
   } else {
     MotionState s_new;
     Q4 kdq{st.kf_dq[0], st.kf_dq[1], st.kf_dq[2], st.kf_dq[3]};
@@ -136,6 +151,7 @@ __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const 
     st.kf_dq[0] = kdq.w, st.kf_dq[1] = kdq.x, st.kf_dq[2] = kdq.y, st.kf_dq[3] = kdq.z;
     st.kf_dt = kdt;
     ring.push_back(s_new);
+    imu_row_store(row, t, ms_q(s_new), ld3(s_new.pos), ld3(s_new.vel));
   }
 }
 

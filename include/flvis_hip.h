@@ -216,7 +216,8 @@ int flvis_hip_pgo_loop_closure(flvis_ctx* ctx, int n_graphs, const int* h_n_kf, 
  *   flvis_config_load        <- TrackingNodeletClass::onInit yaml handling      src/frontend/vo_tracking.cpp:103-306
  *                                (accepts the reference's yaml files unchanged; src/utils/include/yamlRead.h)
  *   flvis_tracker_create     <- F2FTracking::init                               src/frontend/f2f_tracking.cpp:5-38
- *   flvis_imu_feed           <- TrackingNodeletClass::imu_callback + F2FTracking::imu_feed
+ *   flvis_imu_feed(_out)     <- TrackingNodeletClass::imu_callback + F2FTracking::imu_feed (_out: with its q_w_i / pos_w_i / vel_w_i)
+ *   flvis_get_imu_states     <- the same outputs, batched
  *                                                                               src/frontend/vo_tracking.cpp:326-371, f2f_tracking.cpp:46-57
  *   flvis_image_feed         <- F2FTracking::image_feed (+ KeyFrameMsg::pub + LocalMapNodeletClass::frame_callback when
  *                                with_local_map != 0)                           f2f_tracking.cpp:59-400, vo_tracking.cpp:396-430
@@ -279,6 +280,22 @@ int flvis_imu_feed_flvis_frame(flvis_ctx* ctx, int stream, int n, const double* 
 
 /* All streams at once: h_counts [n_streams], h_samples [n_streams][samples_per_stream][7] (FLVIS IMU frame). */
 int flvis_imu_feed_all(flvis_ctx* ctx, const int* h_counts, const double* h_samples, int samples_per_stream);
+
+/* The outputs of F2FTracking::imu_feed(time, acc, gyro, q_w_i&, pos_w_i&, vel_w_i&) (src/frontend/f2f_tracking.cpp:46-57): the
+ * propagated IMU state after every sample -- what imu_callback publishes as /imu_pose, /imu_odom and /imu_path
+ * (src/frontend/vo_tracking.cpp:362-369) and what the EuRoC launch file records as the estimated trajectory
+ * (launch/flvis_euroc_mav.launch:88,103).  During the attitude initialisation the reference returns the identity attitude and
+ * zero position / velocity (vi_motion.cpp:39-40; the sample that sets the first attitude returns it, :60); so do these.
+ *   flvis_imu_feed_out     the call-for-call form: the sample is integrated now (one small upload + kernel + read-back) and its
+ *                          state is returned: q_w_i (w, x, y, z), pos_w_i, vel_w_i.  For a nodelet that publishes at IMU rate.
+ *   flvis_get_imu_states   the batched form for the deferred path (flvis_imu_feed stages, the next flvis_image_feed integrates):
+ *                          the rows written since the previous call for that stream, oldest first, at most cap; a row is
+ *                          (t, qw, qx, qy, qz, px, py, pz, vx, vy, vz).  Samples still staged are integrated first.  The device keeps
+ *                          the last 512 rows per stream; *n_dropped (may be NULL) = older rows lost since the previous call.
+ * Both forms run the same device code in the same order as the next frame head would, so the values are identical. */
+int flvis_imu_feed_out(flvis_ctx* ctx, int stream, double t, const double* acc3, const double* gyro3, double* q_w_i_wxyz,
+                       double* pos_w_i3, double* vel_w_i3);
+int flvis_get_imu_states(flvis_ctx* ctx, int stream, int cap, double* h_rows11, int* n_out, int* n_dropped);
 
 /* Optional per-stage timing of flvis_image_feed with HIP events on the context's stream (for bench.py's roofline).
  * flvis_prof_enable(max_steps) arms it for the next max_steps frames; flvis_prof_read sums the elapsed ms per stage. */
@@ -373,6 +390,11 @@ int flvis_get_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_fram
  * of lines written or a negative error code. */
 int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_frames, const char* path, int format,
                            double min_dt);
+/* The recorder on /imu_pose (launch/flvis_euroc_mav.launch:83-103: vo_repub_rec, sub_type PoseStamped, sub_topic /imu_pose -> est.txt,
+ * the trajectory the reference scores on EuRoC): writes rows of flvis_get_imu_states as `stamp x y z qw qx qy qz` (position pos_w_i,
+ * attitude q_w_i; vo_repub_rec.cpp:74-91).  min_dt > 0: the throttle as written (rows within min_dt of the first row are dropped).
+ * append != 0 appends to the file.  Returns the number of lines written or a negative error code. */
+int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, double min_dt, int append);
 /* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
 /* Test aid: poses (tx ty tz qx qy qz qw) of a stream's last Tracking frame right after PnP-RANSAC and after the pose-only LM

@@ -3,12 +3,17 @@
 //   in : /vo/input_image_0, /vo/input_image_1 (sensor_msgs/Image, ExactTime, queue 2; mono8 or bgr8 / bgra8), /imu (sensor_msgs/Imu)
 //        /vo_localmap_feedback (flvis/CorrectionInf: ignored unless ~use_localmap_feedback is set -- the reference unpacks it and
 //        drops it, vo_tracking.cpp:373-385)
-//   out: /vo_kf (flvis/KeyFrame, as KeyFrameMsg::pub fills it), /vo_camera_pose (geometry_msgs/PoseStamped, T_w_c)
+//   out: /vo_kf (flvis/KeyFrame, as KeyFrameMsg::pub fills it), /vo_camera_pose (geometry_msgs/PoseStamped, T_w_c),
+//        /imu_pose (geometry_msgs/PoseStamped), /imu_odom (nav_msgs/Odometry), /imu_path (nav_msgs/Path): F2FTracking::imu_feed's
+//        q_w_i / pos_w_i / vel_w_i per IMU sample, as imu_callback publishes them (vo_tracking.cpp:362-369); /imu_pose is the topic
+//        the reference's EuRoC launch file records as its estimated trajectory (launch/flvis_euroc_mav.launch:83-103)
 //   param: /yamlconfigfile (the reference's yaml files unchanged)
 // Compile-gated by ros/CMakeLists.txt (needs catkin + the reference's `flvis` message package); never compiled in this repository's
 // build image, which has no ROS.
 #include <geometry_msgs/PoseStamped.h>
 #include <message_filters/subscriber.h>
+#include <nav_msgs/Odometry.h>
+#include <nav_msgs/Path.h>
 #include <message_filters/sync_policies/exact_time.h>
 #include <message_filters/synchronizer.h>
 #include <nodelet/nodelet.h>
@@ -53,6 +58,10 @@ class TrackingNodelet : public nodelet::Nodelet {
     }
     kf_pub_ = nh.advertise<flvis::KeyFrame>("/vo_kf", 1);
     pose_pub_ = nh.advertise<geometry_msgs::PoseStamped>("/vo_camera_pose", 10);
+    imu_pose_pub_ = nh.advertise<geometry_msgs::PoseStamped>("/imu_pose", 10);
+    imu_odom_pub_ = nh.advertise<nav_msgs::Odometry>("/imu_odom", 10);
+    imu_path_pub_ = nh.advertise<nav_msgs::Path>("/imu_path", 10);
+    imu_path_.header.frame_id = "map";
     img0_sub_.subscribe(nh, "/vo/input_image_0", 3);
     img1_sub_.subscribe(nh, "/vo/input_image_1", 3);
     sync_.reset(new message_filters::Synchronizer<SyncPolicy>(SyncPolicy(2), img0_sub_, img1_sub_));
@@ -69,8 +78,37 @@ class TrackingNodelet : public nodelet::Nodelet {
     if (cfg_.imu_type == 3) return;  // KITTI rig: no IMU
     const double a[3] = {m->linear_acceleration.x, m->linear_acceleration.y, m->linear_acceleration.z};
     const double g[3] = {m->angular_velocity.x, m->angular_velocity.y, m->angular_velocity.z};
-    std::lock_guard<std::mutex> lk(mu_);
-    if (flvis_imu_feed(ctx_, 0, m->header.stamp.toSec(), a, g) != FLVIS_OK) NODELET_WARN_THROTTLE(1.0, "imu_feed: %s", flvis_last_error(ctx_));
+    double q[4], p[3], v[3];  // q_w_i (w, x, y, z), pos_w_i, vel_w_i: the outputs of F2FTracking::imu_feed (f2f_tracking.cpp:46-57)
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (flvis_imu_feed_out(ctx_, 0, m->header.stamp.toSec(), a, g, q, p, v) != FLVIS_OK) {
+        NODELET_WARN_THROTTLE(1.0, "imu_feed: %s", flvis_last_error(ctx_));
+        return;
+      }
+    }
+    // pose_imu_pub->pubPose, odom_imu_pub->pubOdom, imu_path_pub->pubPathT_w_c (vo_tracking.cpp:367-369)
+    geometry_msgs::PoseStamped ps;
+    ps.header.stamp = m->header.stamp;
+    ps.header.frame_id = "map";
+    ps.pose.position.x = p[0];
+    ps.pose.position.y = p[1];
+    ps.pose.position.z = p[2];
+    ps.pose.orientation.w = q[0];
+    ps.pose.orientation.x = q[1];
+    ps.pose.orientation.y = q[2];
+    ps.pose.orientation.z = q[3];
+    imu_pose_pub_.publish(ps);
+    nav_msgs::Odometry od;
+    od.header = ps.header;
+    od.pose.pose = ps.pose;
+    od.twist.twist.linear.x = v[0];
+    od.twist.twist.linear.y = v[1];
+    od.twist.twist.linear.z = v[2];
+    imu_odom_pub_.publish(od);
+    imu_path_.header.stamp = m->header.stamp;
+    imu_path_.poses.push_back(ps);
+    if (imu_path_.poses.size() >= 400) imu_path_.poses.erase(imu_path_.poses.begin());  // RVIZPath(nh, "/imu_path", "map", 1, 400), rviz_path.cpp:43-46
+    imu_path_pub_.publish(imu_path_);
   }
 
   void correctionCallback(const flvis::CorrectionInfConstPtr& c) {
@@ -171,7 +209,8 @@ class TrackingNodelet : public nodelet::Nodelet {
   flvis_cfg cfg_;
   bool use_feedback_ = false;
   std::mutex mu_;  // flvis_imu_feed may arrive concurrently with flvis_image_feed_host (MT nodelet handle)
-  ros::Publisher kf_pub_, pose_pub_;
+  ros::Publisher kf_pub_, pose_pub_, imu_pose_pub_, imu_odom_pub_, imu_path_pub_;
+  nav_msgs::Path imu_path_;
   ros::Subscriber imu_sub_, corr_sub_;
   message_filters::Subscriber<sensor_msgs::Image> img0_sub_, img1_sub_;
   std::shared_ptr<message_filters::Synchronizer<SyncPolicy>> sync_;

@@ -2,8 +2,12 @@
 """Runs one EuRoC ASL sequence (stereo + IMU) or KITTI odometry sequence (image_0/ image_1/, no IMU: type_of_vi 4) through the tracker and writes the trajectory the reference's recorder would write
 (`stamp x y z qw qx qy qz`, camera pose T_w_c); with ground truth present, prints the Umeyama-aligned ATE.
 
-  run_sequence.py <sequence folder> <config yaml> <out.txt> [--backend hip|cpu] [--frames N] [--local-map]
+  run_sequence.py <sequence folder> <config yaml> <out.txt> [--backend hip|cpu] [--frames N] [--local-map] [--imu-out <est.txt>]
                   [--loop-closing --voc <DBoW3 vocabulary file> [--lc-out <keyframes.txt>]]
+
+--imu-out : rigs with an IMU: additionally the IMU-rate trajectory of F2FTracking::imu_feed's outputs (pos_w_i, q_w_i per sample) -- the
+/imu_pose topic, which is what the reference's EuRoC launch file records as est.txt (launch/flvis_euroc_mav.launch:83-103) and scores;
+with ground truth present its ATE is printed as ate_rmse_m_imu_pose (the body frame itself: no camera-to-body step).
 
 --backend hip : the product (flvis_amd, needs an MI355X)          -- BASELINE.json configs[1..2] on real data
 --backend cpu : the CPU restatement under oracle/ (test infrastructure) -- configs[0], "the reference CPU path"
@@ -35,12 +39,14 @@ def main():
     ap.add_argument("--loop-closing", action="store_true")
     ap.add_argument("--voc", default=None)
     ap.add_argument("--lc-out", default=None)
+    ap.add_argument("--imu-out", default=None)
     args = ap.parse_args()
     if args.loop_closing and not args.voc:
         ap.error("--loop-closing needs --voc <vocabulary file>")
     seq = traj_io.open_sequence(args.sequence)
     kitti = isinstance(seq, traj_io.KittiSequence)
     stamps, pos, quat = [], [], []
+    imu_rows = []            # (t, q_w_i wxyz, pos_w_i, vel_w_i) per IMU sample
     if args.backend == "cpu":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle as O
@@ -61,7 +67,7 @@ def main():
         for t, i0, i1, imu in seq.frames(0, args.frames):
             for r in imu:
                 a, g = traj_io.sensor_to_flvis_imu(imu_type, r[4:7], r[1:4])
-                trk.imu(r[0], a, g)
+                imu_rows.append(np.concatenate([[r[0]], trk.imu(r[0], a, g)]))
             res = trk.image(t, i0, i1)
             if closer is not None and res["new_keyframe"]:
                 k, d = O.orb_detect_and_compute(i0)
@@ -76,6 +82,9 @@ def main():
                 pos.append(-R.T @ p7[:3])
                 quat.append(traj_io.rot_to_quat(R.T))
         traj_io.write_stamped(args.out, stamps, pos, quat)
+        imu_rows = np.array(imu_rows).reshape(-1, 11)
+        if args.imu_out and len(imu_rows):
+            traj_io.write_stamped(args.imu_out, imu_rows[:, 0], imu_rows[:, 5:8], imu_rows[:, 1:5])
         T_imu_cam = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)
         kf_T_c_w = np.array(closer.T_c_w).reshape(-1, 7) if closer is not None else None
     else:
@@ -94,11 +103,16 @@ def main():
                 trk.imu_feed_sensor(0, r[0], r[4:7], r[1:4])                   # the library applies the axis remap
             d0, d1 = torch.from_numpy(i0[None]).cuda(), torch.from_numpy(i1[None]).cuda()
             res = trk.image_feed(d0, d1, [t], want_out=closer is not None, with_local_map=args.local_map)
+            if args.imu_out and len(imu):
+                imu_rows.append(trk.imu_states(0)[0])
             if closer is not None and res[0]["new_keyframe"]:
                 closer.add_keyframes([0], d0, d1, [res[0]["pose7"]])
                 lc_events.append(closer.process()[0])
                 kf_stamps.append(t)
         trk.write_trajectory(0, 0, n, args.out, 0)
+        imu_rows = np.concatenate(imu_rows) if imu_rows else np.zeros((0, 11))
+        if args.imu_out and len(imu_rows):
+            trk.write_imu_trajectory(imu_rows, args.imu_out)
         kf_T_c_w = closer.poses(0) if closer is not None else None
         T_imu_cam = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)
         stamps, pos, quat = traj_io.read_stamped(args.out)
@@ -124,6 +138,11 @@ def main():
         if len(ia) >= 3:
             out["ate_rmse_m"] = traj_io.ate_rmse(body_p[ia], gt_p[ib])
             out["associated"] = int(len(ia))
+        if args.imu_out and len(imu_rows) >= 3:       # /imu_pose: the trajectory the reference records and scores on EuRoC
+            ja, jb = traj_io.associate(imu_rows[:, 0], gt_t, 0.02)
+            if len(ja) >= 3:
+                out["ate_rmse_m_imu_pose"] = traj_io.ate_rmse(imu_rows[ja, 5:8], gt_p[jb])
+                out["associated_imu_pose"] = int(len(ja))
         if args.loop_closing and len(kf_stamps) >= 3:
             kp = np.asarray(kf_pos) if kitti else traj_io.camera_to_body(np.asarray(kf_pos), np.asarray(kf_quat), T_imu_cam)[0]
             ka, kb = traj_io.associate(np.asarray(kf_stamps), gt_t, 0.02)

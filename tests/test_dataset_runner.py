@@ -38,15 +38,15 @@ def _write_asl(root, frames, imu_sensor, gt_rows):
             f.write("%d,%.9f,%.9f,%.9f,1,0,0,0\n" % (r[0], r[1], r[2], r[3]))
 
 
-def test_asl_folder_roundtrip_and_cpu_backend_run():
-    from flvis_amd import synth, traj_io
+def make_asl_folder(nframes=17):
+    """an EuRoC ASL folder written from the synthetic EuRoC-like rig: (root, yaml, frames, imu_sensor, direct_in, t0_ns)"""
+    from flvis_amd import synth
     yaml = os.path.join(tempfile.gettempdir(), "flvis_ds_euroc.yaml")
     open(yaml, "w").write(synth.EUROC_LIKE_YAML)
     rig = synth.euroc_rig()
     tr = synth.Trajectory(9)
     rnd = synth.Renderer("cpu", rig=rig)
     t0_ns = 1403636579000000000
-    nframes = 17
     frames, imu_sensor, gt_rows, direct_in = [], [], [], []
     t_prev = -0.05
     for f in range(nframes):
@@ -63,6 +63,13 @@ def test_asl_folder_roundtrip_and_cpu_backend_run():
         gt_rows.append([ns] + list(tr.pos(t)))
     root = tempfile.mkdtemp(prefix="flvis_asl_")
     _write_asl(root, frames, imu_sensor, gt_rows)
+    return root, yaml, frames, imu_sensor, direct_in, t0_ns
+
+
+def test_asl_folder_roundtrip_and_cpu_backend_run():
+    from flvis_amd import synth, traj_io
+    nframes = 17
+    root, yaml, frames, imu_sensor, direct_in, t0_ns = make_asl_folder(nframes)
     # the reader
     seq = traj_io.EurocSequence(root)
     assert len(seq) == nframes and seq.groundtruth is not None and len(seq.imu) == len(imu_sensor)
@@ -74,11 +81,16 @@ def test_asl_folder_roundtrip_and_cpu_backend_run():
     assert list(a) == [-3.0, 2.0, -1.0] and list(g) == [6.0, -5.0, 4.0]
     # the runner with the CPU backend
     out = os.path.join(root, "traj_cpu.txt")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), root, yaml, out, "--backend", "cpu"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    imu_out = os.path.join(root, "imu_cpu.txt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), root, yaml, out, "--backend", "cpu",
+                        "--imu-out", imu_out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     res = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert res["tracked"] >= 6 and res["ate_rmse_m"] < 0.05, res
+    # the IMU-rate trajectory (/imu_pose, the reference's est.txt on EuRoC): one line per IMU sample, scored against the ground truth
+    it, ip, iq = traj_io.read_stamped(imu_out)
+    assert len(it) == len(imu_sensor) and np.isfinite(res["ate_rmse_m_imu_pose"]) and res["associated_imu_pose"] >= 10, res
+    assert np.allclose(np.linalg.norm(np.asarray(iq), axis=1), 1.0, atol=1e-5)
     ts, pos, quat = traj_io.read_stamped(out)
     # the same frames fed to the oracle directly give the same poses (to the 6 significant digits the recorder writes)
     cfg = O.load_config(yaml)

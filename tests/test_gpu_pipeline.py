@@ -56,8 +56,9 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
     trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=seed_base, traj_capacity=nframes)
     refs = [O.Tracker(ocfg, seed_base + i) for i in range(S)]
     t_prev = -0.05
-    n_kf = n_imu_links = 0
+    n_kf = n_imu_links = n_imu_rows = 0
     lock_frames = [0] * S      # tracked frames (all compared exactly)
+    imu_want = [[] for _ in range(S)]   # F2FTracking::imu_feed's outputs per sample (q_w_i, pos_w_i, vel_w_i) on the oracle side
     for f in range(nframes):
         t = f / synth.FRAME_HZ
         for i, s in enumerate(streams):
@@ -66,7 +67,7 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
             smp = synth.imu_samples(trajs[i], s, t_prev, t)
             trk.imu_feed_flvis(i, smp)
             for r in smp:
-                refs[i].imu(r[0], r[1:4], r[4:7])
+                imu_want[i].append(np.concatenate([[r[0]], refs[i].imu(r[0], r[1:4], r[4:7])]))
         t_prev = t
         if depth_range is None:
             i0, i1 = rnd.stereo_frame(trajs, t, f)
@@ -76,6 +77,14 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
             h0, h1 = i0.cpu().numpy(), i1.cpu().numpy().view(np.uint16)
         outs = trk.image_feed(i0, i1, [t] * S, with_local_map=False)
         for i in range(S):
+            # the IMU-rate trajectory (/imu_pose, what the reference records on EuRoC): every sample's q / p / v bit-identical;
+            # fetched every third frame so that a fetch spans several image feeds (and the vision corrections between them)
+            if imu and (f % 3 == 2 or f == nframes - 1):
+                rows, dropped = trk.imu_states(i)
+                assert dropped == 0 and len(rows) == len(imu_want[i]), ("frame %d stream %d" % (f, i), len(rows), len(imu_want[i]))
+                assert np.array_equal(rows, np.array(imu_want[i]).reshape(-1, 11)), "IMU states, frame %d stream %d" % (f, i)
+                n_imu_rows += len(rows)
+                imu_want[i] = []
             want = refs[i].image(t, h0[i], h1[i])
             got = outs[i]
             where = "frame %d stream %d" % (f, i)
@@ -101,6 +110,7 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
                 assert gv == wv and gdt == wdt and np.array_equal(gdq, wdq), (where, gdq - wdq, gdt - wdt)
                 n_imu_links += int(wv)
     assert n_kf >= min_kf
+    assert (n_imu_rows >= 9 * S * (nframes - 1)) if imu else (n_imu_rows == 0)
     assert (n_imu_links >= (min_kf - S) // 2) if imu else (n_imu_links == 0)
     assert min(lock_frames) >= min_lock, lock_frames
     rows = trk.trajectory(0, 0, nframes)
@@ -172,13 +182,14 @@ def test_imu_staging_overflow_is_integrated_not_refused(ctx):
     # image times: 0.75 s (150 IMU samples before it), then every 50 ms, with one image "dropped" (0.45 s gap = 90 samples)
     times = [0.75, 0.80, 0.85, 1.30, 1.35, 1.40, 1.45, 1.50]
     t_prev = 0.0
+    imu_want = []
     for k, t in enumerate(times):
         smp = synth.imu_samples(tr, 9, t_prev, t)
         if k in (0, 3):
             assert len(smp) > 64
         trk.imu_feed_flvis(0, smp)
         for r in smp:
-            ref.imu(r[0], r[1:4], r[4:7])
+            imu_want.append(np.concatenate([[r[0]], ref.imu(r[0], r[1:4], r[4:7])]))
         t_prev = t
         i0, i1 = rnd.stereo_frame([tr], t, k)
         got = trk.image_feed(i0, i1, [t], with_local_map=False)[0]
@@ -186,6 +197,49 @@ def test_imu_staging_overflow_is_integrated_not_refused(ctx):
         assert got["state"] == want["state"] and got["n_landmarks"] == want["n_landmarks"], k
         assert np.abs(got["pose7"] - want["pose7"]).max() < 1e-6, (k, got["pose7"] - want["pose7"])
     assert want["state"] == 1
+    rows, dropped = trk.imu_states(0)                    # all 300 samples, through the flushes, in order
+    assert dropped == 0 and np.array_equal(rows, np.array(imu_want))
+
+
+def test_imu_feed_out_call_for_call(ctx):
+    """flvis_imu_feed_out = F2FTracking::imu_feed(time, acc, gyro, q_w_i&, pos_w_i&, vel_w_i&) (f2f_tracking.cpp:46-57) sample by
+    sample in the SENSOR frame (EuRoC remap of imu_callback, vo_tracking.cpp:341-349): identity / zeros during the attitude
+    initialisation, the propagated state afterwards, re-anchored by the vision corrections of the images in between --
+    bit-identical to the oracle's outputs, and the batched getter returns the same rows afterwards; a ring that wrapped
+    reports the rows it lost."""
+    import flvis_amd
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
+    assert cfg.imu_type == 1
+    tr = synth.Trajectory(9)
+    rnd = synth.Renderer("cuda", rig=synth.euroc_rig())
+    trk = flvis_amd.Tracker(ctx, cfg, 1, seed_base=0xF1715)
+    ref = O.Tracker(ocfg, 0xF1715)
+    t_prev, want_rows, n_moving = 0.0, [], 0
+    for k in range(14):
+        t = 0.30 + k / synth.FRAME_HZ
+        for r in synth.imu_samples(tr, 9, t_prev, t):
+            acc_s = [-r[3], r[2], -r[1]]               # inverse of acc = (-z, y, -x)
+            gyro_s = [r[6], -r[5], r[4]]               # inverse of gyro = (z, -y, x)
+            q, p, v = trk.imu_feed_out(0, r[0], acc_s, gyro_s)
+            w = ref.imu(r[0], r[1:4], r[4:7])
+            assert np.array_equal(np.concatenate([q, p, v]), w), (k, r[0])
+            want_rows.append(np.concatenate([[r[0]], w]))
+            n_moving += int(np.any(w[4:] != 0))
+        t_prev = t
+        i0, i1 = rnd.stereo_frame([tr], t, k)
+        got = trk.image_feed(i0, i1, [t], with_local_map=False)[0]
+        want = ref.image(t, i0[0].cpu().numpy(), i1[0].cpu().numpy())
+        assert got["state"] == want["state"] and np.array_equal(got["pose7"], want["pose7"]), k
+    assert want["state"] == 1 and n_moving > 50        # propagation (not only the initialisation) was compared
+    rows, dropped = trk.imu_states(0, cap=100)           # the batched form hands out the same rows, cap at a time
+    assert dropped == 0 and np.array_equal(rows, np.array(want_rows)[:100])
+    rows2, _ = trk.imu_states(0)
+    assert np.array_equal(rows2, np.array(want_rows)[100:])
+    smp = synth.imu_samples(tr, 9, t_prev, t_prev + 3.0)  # 600 samples without a fetch: the 512-row ring wraps
+    trk.imu_feed_flvis(0, smp)
+    rows3, dropped = trk.imu_states(0)
+    assert dropped == len(smp) - 512 and len(rows3) == 512 and np.array_equal(rows3[:, 0], smp[-512:, 0])
 
 
 def test_trajectory_recorder(ctx):
