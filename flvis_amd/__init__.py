@@ -145,6 +145,25 @@ class Context:
                                              C.c_double(min_distance), _ptr(out), _ptr(cnt)), "gftt")
         return out, cnt
 
+    def debug_corner_response(self, img, variant, rows=0, key_cap=1 << 17):
+        """test aid: (max ordered bits [n], sorted candidate keys per image) of the corner-response pass with the chosen kernel"""
+        import numpy as np
+        img = img.contiguous()
+        n, h, w = img.shape
+        mx = np.zeros(n, np.uint32)
+        nk = np.zeros(n, np.int32)
+        keys = np.zeros((n, key_cap), np.uint64)
+        self._check(self._lib.flvis_hip_debug_corner_response(self._h, _ptr(img), w, h, n, int(variant), int(rows), _P(mx, C.c_uint32),
+                                                              _P(nk, C.c_int), _P(keys, C.c_uint64), key_cap), "corner_response")
+        return mx, [np.sort(keys[i, :nk[i]]) for i in range(n)]
+
+    def debug_sqrt_check(self, first_bits, n):
+        """test aid: arguments in [first_bits, first_bits + n) (float bit patterns) on which the corner-response kernel's square
+        root differs from the correctly rounded sqrtf"""
+        bad = C.c_uint64(0)
+        self._check(self._lib.flvis_hip_debug_sqrt_check(self._h, C.c_uint32(first_bits), C.c_uint32(n), C.byref(bad)), "sqrt_check")
+        return bad.value
+
     def feature_dem_detect(self, img, f_para, out_cap=1024):
         import torch
         img = img.contiguous()

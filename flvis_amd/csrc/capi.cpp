@@ -287,5 +287,46 @@ int flvis_hip_feature_dem_redetect(flvis_ctx* ctx, const uint8_t* d_img, int w, 
                     out_cap);
 }
 
-}  // extern "C"
+// Test aid: the corner-response pass of goodFeaturesToTrack alone, with the chosen kernel variant (0 LDS tiles, 1 strip-mined tiles, 2 wave
+// walk with `rows` rows per chunk): per image the ordered bits of the maximum response, the number of 3x3 local maxima and their sort keys
+// (unsorted; key = ~((ordered(response) << 32) | pixel offset)) in h_keys [n_img][key_cap].
+int flvis_hip_debug_corner_response(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img, int variant, int rows, uint32_t* h_max_bits,
+                                    int* h_nkeys, uint64_t* h_keys, int key_cap) {
+  CHECK_CTX(ctx);
+  if (!d_img || !h_max_bits || !h_nkeys || !h_keys || w < 8 || h < 8 || (w & 3) || n_img <= 0 || variant < 0 || variant > 2 || key_cap <= 0)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "corner_response: bad args");
+  GfttScratch sc;
+  int rc = gftt_scratch(ctx, w, h, n_img, sc);
+  if (rc) return rc;
+  hipMemsetAsync(sc.maxenc, 0, sizeof(unsigned) * n_img, ctx->stream);
+  hipMemsetAsync(sc.nkeys, 0, sizeof(int) * n_img, ctx->stream);
+  launch_corner_response(ctx->stream, variant, rows, img_plain(d_img), w, h, w, (size_t)w * h, n_img, sc.maxenc, sc.keys, sc.nkeys, sc.cap, nullptr);
+  hipError_t e = hipMemcpyAsync(h_max_bits, sc.maxenc, sizeof(unsigned) * n_img, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h_nkeys, sc.nkeys, sizeof(int) * n_img, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < n_img && e == hipSuccess; i++) {
+    const int n = std::min(std::min(h_nkeys[i], sc.cap), key_cap);
+    e = hipMemcpy(h_keys + (size_t)i * key_cap, sc.keys + (size_t)i * sc.cap, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
+  }
+  if (e != hipSuccess) return ctx->hip_fail(e, "corner_response");
+  return FLVIS_OK;
+}
 
+// Test aid for the corner-response kernel's square root (eig_walk.hip: ew_sqrt_pos against the compiler's correctly rounded sqrtf)
+// on every float with bit pattern in [first_bits, first_bits + n): the number of arguments on which they differ.
+int flvis_hip_debug_sqrt_check(flvis_ctx* ctx, uint32_t first_bits, uint32_t n, uint64_t* h_mismatches) {
+  CHECK_CTX(ctx);
+  if (!h_mismatches) return ctx->fail(FLVIS_ERR_INVALID_ARG, "sqrt_check: bad args");
+  unsigned long long* d = (unsigned long long*)ctx->scratch("sqrt_check", sizeof(unsigned long long));
+  if (!d) return ctx->fail(FLVIS_ERR_HIP, "sqrt_check: scratch allocation failed");
+  hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream);
+  launch_sqrt_check(ctx->stream, first_bits, n, d);
+  unsigned long long h = 0;
+  hipError_t e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ctx->hip_fail(e, "sqrt_check");
+  *h_mismatches = h;
+  return FLVIS_OK;
+}
+
+}  // extern "C"

@@ -43,24 +43,43 @@ M3h transp(const M3h& a) {
   return r;
 }
 M3h ident() { return M3h{{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}}; }
+// cvRodrigues2 (OpenCV 3.x) as cvStereoRectify calls it, operation for operation: matrix -> vector by
+// r = (R32 - R23, R13 - R31, R21 - R12), s = sqrt(r.r / 4), theta = acos((trace - 1) / 2), r *= theta / (2 s) (without OpenCV's SVD
+// re-orthonormalisation: the rig rotations are orthonormal to rounding); vector -> matrix by R = c I + (1 - c) r r^T + s [r]x
 V3h rotvec_from_mat(const M3h& R) {
-  double tr = R.m[0][0] + R.m[1][1] + R.m[2][2];
-  double c = (tr - 1) * 0.5;
-  c = c > 1 ? 1 : (c < -1 ? -1 : c);
-  double theta = std::acos(c);
-  V3h r{{R.m[2][1] - R.m[1][2], R.m[0][2] - R.m[2][0], R.m[1][0] - R.m[0][1]}};
-  double s = std::sqrt(r.v[0] * r.v[0] + r.v[1] * r.v[1] + r.v[2] * r.v[2]);  // 2 sin(theta)
-  if (s < 1e-12) return V3h{{0.5 * r.v[0], 0.5 * r.v[1], 0.5 * r.v[2]}};
-  double k = theta / s;
-  return V3h{{k * r.v[0], k * r.v[1], k * r.v[2]}};
+  double rx = R.m[2][1] - R.m[1][2], ry = R.m[0][2] - R.m[2][0], rz = R.m[1][0] - R.m[0][1];
+  const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = (R.m[0][0] + R.m[1][1] + R.m[2][2] - 1) * 0.5;
+  c = c > 1. ? 1. : (c < -1. ? -1. : c);
+  const double theta = std::acos(c);
+  if (s < 1e-5) {
+    if (c > 0) return V3h{{0, 0, 0}};
+    double t;
+    t = (R.m[0][0] + 1) * 0.5;
+    rx = std::sqrt(std::max(t, 0.));
+    t = (R.m[1][1] + 1) * 0.5;
+    ry = std::sqrt(std::max(t, 0.)) * (R.m[0][1] < 0 ? -1. : 1.);
+    t = (R.m[2][2] + 1) * 0.5;
+    rz = std::sqrt(std::max(t, 0.)) * (R.m[0][2] < 0 ? -1. : 1.);
+    if (std::fabs(rx) < std::fabs(ry) && std::fabs(rx) < std::fabs(rz) && (R.m[1][2] > 0) != (ry * rz > 0)) rz = -rz;
+    const double k = theta / std::sqrt(rx * rx + ry * ry + rz * rz);
+    return V3h{{rx * k, ry * k, rz * k}};
+  }
+  double vth = 1 / (2 * s);
+  vth *= theta;
+  return V3h{{rx * vth, ry * vth, rz * vth}};
 }
 M3h mat_from_rotvec(const V3h& r) {
-  double th = std::sqrt(r.v[0] * r.v[0] + r.v[1] * r.v[1] + r.v[2] * r.v[2]);
-  if (th < 1e-15) return ident();
-  double x = r.v[0] / th, y = r.v[1] / th, z = r.v[2] / th, c = std::cos(th), s = std::sin(th), C = 1 - c;
-  return M3h{{{c + x * x * C, x * y * C - z * s, x * z * C + y * s},
-              {y * x * C + z * s, c + y * y * C, y * z * C - x * s},
-              {z * x * C - y * s, z * y * C + x * s, c + z * z * C}}};
+  const double theta = std::sqrt(r.v[0] * r.v[0] + r.v[1] * r.v[1] + r.v[2] * r.v[2]);
+  if (theta < DBL_EPSILON) return ident();
+  const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, itheta = 1. / theta;
+  const double x = r.v[0] * itheta, y = r.v[1] * itheta, z = r.v[2] * itheta;
+  const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+  const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  M3h R;
+  for (int k = 0; k < 9; k++) R.m[k / 3][k % 3] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+  return R;
 }
 
 // cv::undistortPoints(pt, K, D, R, P) for one point (5 iterations)
@@ -167,21 +186,87 @@ void stereo_rectify(const double* K1, const double* D1, const double* K2, const 
   P2[4 * idx + 3] = s0 * P2[4 * idx + 3];
 }
 
-void mat44_inverse_rigid(const double* m, double* o) {
-  // [R t; 0 1]^-1 = [R^T  -R^T t]
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) o[4 * i + j] = m[4 * j + i];
-  for (int i = 0; i < 3; i++) o[4 * i + 3] = -(o[4 * i] * m[3] + o[4 * i + 1] * m[7] + o[4 * i + 2] * m[11]);
-  o[12] = o[13] = o[14] = 0;
-  o[15] = 1;
+// Rig transforms the way the reference composes them: Sophus SE3 objects (vo_tracking.cpp:183-236), i.e. a quaternion taken from
+// the yaml's rotation matrix (Eigen's matrix -> quaternion, not renormalised), products and inverses on quaternions with a
+// renormalisation after each (se3.cpp:59-83), translations rotated by Eigen's quaternion formula, and rotation_matrix() by
+// Eigen's toRotationMatrix.  A 4x4 matrix product agrees with that only to ~1e-13 for a general rotation (EuRoC), and a rig that
+// differs in the thirteenth digit ends in other RANSAC inlier sets after a few hundred frames.
+struct RigT {
+  double w, x, y, z;  // rotation
+  double t[3];
+};
+RigT rig_from_mat44(const double* m) {
+  const double R[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
+  RigT r;
+  double tr = R[0][0] + R[1][1] + R[2][2];
+  if (tr > 0) {
+    double s = std::sqrt(tr + 1.0);
+    r.w = 0.5 * s;
+    s = 0.5 / s;
+    r.x = (R[2][1] - R[1][2]) * s;
+    r.y = (R[0][2] - R[2][0]) * s;
+    r.z = (R[1][0] - R[0][1]) * s;
+  } else {
+    int i = 0;
+    if (R[1][1] > R[0][0]) i = 1;
+    if (R[2][2] > R[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+    double v[3];
+    v[i] = 0.5 * s;
+    s = 0.5 / s;
+    r.w = (R[k][j] - R[j][k]) * s;
+    v[j] = (R[j][i] + R[i][j]) * s;
+    v[k] = (R[k][i] + R[i][k]) * s;
+    r.x = v[0], r.y = v[1], r.z = v[2];
+  }
+  r.t[0] = m[3], r.t[1] = m[7], r.t[2] = m[11];
+  return r;
 }
-void mat44_mul(const double* a, const double* b, double* o) {
-  for (int i = 0; i < 4; i++)
-    for (int j = 0; j < 4; j++) {
-      double s = 0;
-      for (int k = 0; k < 4; k++) s += a[4 * i + k] * b[4 * k + j];
-      o[4 * i + j] = s;
-    }
+void rig_normalise(RigT& r) {
+  const double n = std::sqrt(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z);
+  r.w = r.w / n, r.x = r.x / n, r.y = r.y / n, r.z = r.z / n;
+}
+void rig_rotate(const RigT& q, const double* v, double* o) {  // Eigen QuaternionBase::_transformVector
+  double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
+  for (int k = 0; k < 3; k++) uv[k] = uv[k] + uv[k];
+  const double c2[3] = {q.y * uv[2] - q.z * uv[1], q.z * uv[0] - q.x * uv[2], q.x * uv[1] - q.y * uv[0]};
+  for (int k = 0; k < 3; k++) o[k] = (v[k] + q.w * uv[k]) + c2[k];
+}
+RigT rig_mul(const RigT& a, const RigT& b) {
+  RigT r;
+  double rt[3];
+  rig_rotate(a, b.t, rt);
+  for (int k = 0; k < 3; k++) r.t[k] = a.t[k] + rt[k];
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  rig_normalise(r);
+  return r;
+}
+RigT rig_inverse(const RigT& a) {
+  RigT r;
+  r.w = a.w, r.x = -a.x, r.y = -a.y, r.z = -a.z;
+  rig_normalise(r);
+  const double nt[3] = {-1.0 * a.t[0], -1.0 * a.t[1], -1.0 * a.t[2]};
+  rig_rotate(r, nt, r.t);
+  return r;
+}
+void rig_rotation_matrix(const RigT& q, double R[3][3]) {  // Eigen QuaternionBase::toRotationMatrix
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0][0] = 1 - (tyy + tzz), R[0][1] = txy - twz, R[0][2] = txz + twy;
+  R[1][0] = txy + twz, R[1][1] = 1 - (txx + tzz), R[1][2] = tyz - twx;
+  R[2][0] = txz - twy, R[2][1] = tyz + twx, R[2][2] = 1 - (txx + tyy);
+}
+void rig_to_mat44(const RigT& a, double* o) {
+  double R[3][3];
+  rig_rotation_matrix(a, R);
+  const double m[16] = {R[0][0], R[0][1], R[0][2], a.t[0], R[1][0], R[1][1], R[1][2], a.t[1], R[2][0], R[2][1], R[2][2], a.t[2], 0, 0, 0, 1};
+  memcpy(o, m, sizeof(m));
 }
 
 }  // namespace
@@ -254,10 +339,12 @@ extern "C" int flvis_config_finalize(flvis_cfg* c) {
     default:
       return FLVIS_ERR_CONFIG;
   }
-  double Tinv[16];
-  mat44_inverse_rigid(c->T_cam0_cam1, Tinv);  // T_c1_c0
-  M3h R{{{Tinv[0], Tinv[1], Tinv[2]}, {Tinv[4], Tinv[5], Tinv[6]}, {Tinv[8], Tinv[9], Tinv[10]}}};
-  V3h T{{Tinv[3], Tinv[7], Tinv[11]}};
+  // SE3 T_c1_c0 = T_c0_c1.inverse(); its rotation_matrix() and translation() go into cv::stereoRectify (vo_tracking.cpp:190-200,237-247)
+  const RigT T10 = rig_inverse(rig_from_mat44(c->T_cam0_cam1));
+  double R10[3][3];
+  rig_rotation_matrix(T10, R10);
+  M3h R{{{R10[0][0], R10[0][1], R10[0][2]}, {R10[1][0], R10[1][1], R10[1][2]}, {R10[2][0], R10[2][1], R10[2][2]}}};
+  V3h T{{T10.t[0], T10.t[1], T10.t[2]}};
   M3h R0, R1;
   stereo_rectify(c->cam0_intrinsics, c->cam0_distortion, c->cam1_intrinsics, c->cam1_distortion, c->image_width,
                  c->image_height, R, T, R0, R1, c->P0, c->P1);
@@ -366,12 +453,13 @@ extern "C" int flvis_config_load(const char* path, flvis_cfg* c, char* err, int 
     memcpy(c->P0, a, sizeof(double) * 12);
     memcpy(c->P1, b, sizeof(double) * 12);
   } else if (c->type_of_vi == 1) {
-    double a[16], b[16], m[16], ai[16];
+    double a[16], b[16], m[16];
     if (!need("T_mavimu_cam0", 16, a) || !need("T_mavimu_cam1", 16, b) || !need("T_imu_mavimu", 16, m))
       return fail("yaml key missing or short: " + missing);
-    mat44_inverse_rigid(a, ai);
-    mat44_mul(ai, b, c->T_cam0_cam1);  // T_c0_c1 = T_mavimu_cam0^-1 * T_mavimu_cam1
-    mat44_mul(m, a, c->T_imu_cam0);    // T_i_c0  = T_imu_mavimu * T_mavimu_cam0
+    // vo_tracking.cpp:229-236: T_c0_c1 = T_mavi_c0.inverse() * T_mavi_c1, T_i_c0 = T_i_mavi * T_mavi_c0, as Sophus SE3 objects
+    const RigT Ta = rig_from_mat44(a), Tb = rig_from_mat44(b), Tm = rig_from_mat44(m);
+    rig_to_mat44(rig_mul(rig_inverse(Ta), Tb), c->T_cam0_cam1);
+    rig_to_mat44(rig_mul(Tm, Ta), c->T_imu_cam0);
   } else {
     if (!need("T_imu_cam0", 16, c->T_imu_cam0) || !need("T_cam0_cam1", 16, c->T_cam0_cam1))
       return fail("yaml key missing or short: " + missing);

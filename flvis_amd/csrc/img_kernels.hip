@@ -1077,6 +1077,19 @@ void launch_pyr_down_ingest(hipStream_t st, ImgSel src, int sw, int sh, int spit
 // stage_events (optional): 6 events = (begin, end) for eig_max, eig_nms, gftt_pick.
 // reset_counters: zero maxenc / nkeys first; a caller that allocated them zeroed and always runs the full chain can pass
 // false -- k_gftt_pick hands them back zeroed.
+// the corner-response pass on its own: per-stream maximum (maxenc, zeroed by the caller) and the candidate keys (keys / nkeys, zeroed)
+// variant 0: k_eig_cand (LDS tiles), 1: k_eig_cand_strip, 2: k_eig_walk with `rows` rows per chunk
+void launch_corner_response(hipStream_t st, int variant, int rows, ImgSel src, int w, int h, int pitch, size_t sstride, int S, unsigned* maxenc,
+                            unsigned long long* keys, int* nkeys, int cap, const int* active) {
+  dim3 grid(div_up(w, EG_TW), div_up(h, EG_TH), S);
+  if (variant == 2)
+    launch_eig_walk(st, src, w, h, pitch, sstride, S, maxenc, keys, nkeys, cap, active, rows);
+  else if (variant == 1)
+    hipLaunchKernelGGL(k_eig_cand_strip, grid, dim3(256), 0, st, src, w, h, pitch, sstride, maxenc, keys, nkeys, cap, active);
+  else
+    hipLaunchKernelGGL(k_eig_cand, grid, dim3(256), 0, st, src, w, h, pitch, sstride, maxenc, keys, nkeys, cap, active);
+}
+
 void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, GfttScratch sc,
                  const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
                  float* out_xy, int* out_n, int out_cap, const int* active, hipEvent_t* ev, bool reset_counters) {
@@ -1084,17 +1097,17 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
     hipMemsetAsync(sc.maxenc, 0, sizeof(unsigned) * S, st);
     hipMemsetAsync(sc.nkeys, 0, sizeof(int) * S, st);
   }
-  dim3 grid(div_up(w, EG_TW), div_up(h, EG_TH), S);
   if (ev) hipEventRecord(ev[0], st);
-  static const bool strip = [] {
-    const char* e = getenv("FLVIS_EIG_STRIP");  // opt-in variant of the corner-response pass (see k_eig_cand_strip)
-    return e && atoi(e) != 0;
+  // which kernel computes the corner response: FLVIS_EIG_WALK=<rows per chunk> the wave walk (eig_walk.hip), FLVIS_EIG_STRIP=1 the
+  // strip-mined tile kernel, otherwise the tile kernel
+  static const int variant_rows = [] {
+    const char* e = getenv("FLVIS_EIG_WALK");
+    if (e) return atoi(e) > 0 ? atoi(e) : -1;
+    e = getenv("FLVIS_EIG_STRIP");
+    return (e && atoi(e) != 0) ? -2 : -1;
   }();
-  if (strip)
-    hipLaunchKernelGGL(k_eig_cand_strip, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, sc.keys, sc.nkeys, sc.cap, active);
-  else
-    hipLaunchKernelGGL(k_eig_cand, grid, dim3(256), 0, st, src, w, h, pitch, sstride, sc.maxenc, sc.keys, sc.nkeys, sc.cap,
-                       active);
+  launch_corner_response(st, variant_rows > 0 ? 2 : (variant_rows == -2 ? 1 : 0), variant_rows, src, w, h, pitch, sstride, S, sc.maxenc, sc.keys,
+                         sc.nkeys, sc.cap, active);
   if (ev) hipEventRecord(ev[1], st), hipEventRecord(ev[2], st), hipEventRecord(ev[3], st), hipEventRecord(ev[4], st);
   const size_t lds = sizeof(unsigned long long) * SORT_LDS + sizeof(int) * (PICK_BINS + 8) +
                      (size_t)((w + 31) / 32) * h * sizeof(unsigned);

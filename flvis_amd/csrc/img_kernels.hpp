@@ -68,6 +68,12 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
                  const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
                  float* out_xy, int* out_n, int out_cap, const int* active, hipEvent_t* stage_events = nullptr,
                  bool reset_counters = true);
+// the corner-response pass of launch_gftt as a wave walk (eig_walk.hip): fills maxenc / keys / nkeys like k_eig_cand
+void launch_eig_walk(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, unsigned* maxenc, unsigned long long* keys,
+                     int* nkeys, int cap, const int* active, int rows_per_chunk);
+void launch_corner_response(hipStream_t st, int variant, int rows, ImgSel src, int w, int h, int pitch, size_t sstride, int S, unsigned* maxenc,
+                            unsigned long long* keys, int* nkeys, int cap, const int* active);
+void launch_sqrt_check(hipStream_t st, unsigned first_bits, unsigned n, unsigned long long* mismatches);  // test aid, eig_walk.hip
 void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
                         const float* corners, const int* ncorners, int corner_cap, const int* mode,
                         const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,

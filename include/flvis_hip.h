@@ -400,6 +400,14 @@ int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
 /* Test aid: poses (tx ty tz qx qy qz qw) of a stream's last Tracking frame right after PnP-RANSAC and after the pose-only LM
  * (the two fp64 stages of LKORBTracking::tracking / OptimizeInFrame::optimize), h_out21 = 3 x 7 doubles (the third: the pose the LM starts from). */
 int flvis_debug_stage_poses(flvis_ctx* ctx, int stream, double* h_out21);
+/* Test aid: the corner-response pass of flvis_hip_gftt alone (cornerMinEigenVal + the 3x3 local maxima), with the kernel variant chosen
+ * (0: LDS tiles, 1: strip-mined tiles, 2: wave walk with `rows` rows per chunk): per image the ordered bits of the maximum response, the
+ * number of local maxima and their sort keys ~((ordered(response) << 32) | pixel offset), unsorted, in h_keys [n_img][key_cap]. */
+int flvis_hip_debug_corner_response(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_img, int variant, int rows,
+                                    uint32_t* h_max_bits, int* h_nkeys, uint64_t* h_keys, int key_cap);
+/* Test aid: the corner-response kernel's square root against the correctly rounded sqrtf on every float whose bit pattern lies in
+ * [first_bits, first_bits + n); *h_mismatches = arguments on which the two differ (0 over the kernel's domain, see eig_walk.hip). */
+int flvis_hip_debug_sqrt_check(flvis_ctx* ctx, uint32_t first_bits, uint32_t n, uint64_t* h_mismatches);
 /* Raw device counter block (64 x int64): [0..7] as above, [8..] per-phase cycle counters of the BA kernel, filled only by
  * builds with -DFLVIS_BA_PROF (tuning aid, not part of the reference interface). */
 int flvis_debug_counters(flvis_ctx* ctx, int64_t* h_counters64);

@@ -55,12 +55,51 @@ static SE3 se3_from_mat44(const double* m) {
   return se3_from_mat(R, {m[3], m[7], m[11]});
 }
 
+// cvRodrigues2 (OpenCV 3.x calibration.cpp) as cvStereoRectify calls it, with the formulas in OpenCV's order.  Matrix -> vector:
+// r = (R32 - R23, R13 - R31, R21 - R12), s = sqrt(r.r / 4), c = (trace - 1) / 2, theta = acos(c), r *= theta / (2 s)  (OpenCV first
+// re-orthonormalises R by an SVD; the rig rotations are orthonormal to rounding).  Vector -> matrix: R = c I + (1 - c) r r^T + s [r]x.
+static Vec3 cv_rodrigues_from_mat(const Mat3& R) {
+  double rx = R.m[2][1] - R.m[1][2], ry = R.m[0][2] - R.m[2][0], rz = R.m[1][0] - R.m[0][1];
+  const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = (R.m[0][0] + R.m[1][1] + R.m[2][2] - 1) * 0.5;
+  c = c > 1. ? 1. : (c < -1. ? -1. : c);
+  const double theta = std::acos(c);
+  if (s < 1e-5) {
+    if (c > 0) return {0, 0, 0};
+    double t;
+    t = (R.m[0][0] + 1) * 0.5;
+    rx = std::sqrt(std::max(t, 0.));
+    t = (R.m[1][1] + 1) * 0.5;
+    ry = std::sqrt(std::max(t, 0.)) * (R.m[0][1] < 0 ? -1. : 1.);
+    t = (R.m[2][2] + 1) * 0.5;
+    rz = std::sqrt(std::max(t, 0.)) * (R.m[0][2] < 0 ? -1. : 1.);
+    if (std::fabs(rx) < std::fabs(ry) && std::fabs(rx) < std::fabs(rz) && (R.m[1][2] > 0) != (ry * rz > 0)) rz = -rz;
+    const double k = theta / std::sqrt(rx * rx + ry * ry + rz * rz);
+    return {rx * k, ry * k, rz * k};
+  }
+  double vth = 1 / (2 * s);
+  vth *= theta;
+  return {rx * vth, ry * vth, rz * vth};
+}
+static Mat3 cv_rodrigues_to_mat(Vec3 r) {
+  const double theta = std::sqrt(r.x * r.x + r.y * r.y + r.z * r.z);
+  if (theta < DBL_EPSILON) return mat3_identity();
+  const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, itheta = 1. / theta;
+  const double x = r.x * itheta, y = r.y * itheta, z = r.z * itheta;
+  const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+  const double r_x[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  Mat3 R;
+  for (int k = 0; k < 9; k++) R.m[k / 3][k % 3] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+  return R;
+}
+
 // cvStereoRectify (OpenCV 3.x), flags = CALIB_ZERO_DISPARITY, alpha = 0, newImageSize = imageSize
 static void stereo_rectify(const double K1[4], const double D1[4], const double K2[4], const double D2[4], int nx, int ny,
                            const Mat3& R, Vec3 T, Mat3& R1, Mat3& R2, double P1[12], double P2[12]) {
-  Vec3 om = rodrigues_from_mat(R);
+  Vec3 om = cv_rodrigues_from_mat(R);
   om = -0.5 * om;
-  Mat3 r_r = rodrigues_to_mat(om);
+  Mat3 r_r = cv_rodrigues_to_mat(om);
   Vec3 t = r_r * T;
   int idx = std::fabs(t[0]) > std::fabs(t[1]) ? 0 : 1;
   double c = t[idx], nt = norm(t);
@@ -69,7 +108,7 @@ static void stereo_rectify(const double K1[4], const double D1[4], const double 
   Vec3 ww = cross(t, uu);
   double nw = norm(ww);
   if (nw > 0.0) ww = (std::acos(std::fabs(c) / nt) / nw) * ww;
-  Mat3 wR = rodrigues_to_mat(ww);
+  Mat3 wR = cv_rodrigues_to_mat(ww);
   R1 = wR * transpose(r_r);
   R2 = wR * r_r;
   t = R2 * T;

@@ -56,10 +56,12 @@ def test_product_does_not_reference_oracle():
 
 def test_config_loader_matches_oracle_on_both_rigs():
     """Host logic of the boundary: the product's yaml loader + stereoRectify (csrc/config.cpp, no GPU involved) and the
-    oracle's are independent implementations; they must produce the same flvis_cfg for the rectified D435i rig and the
-    unrectified EuRoC-like rig: integers exactly, doubles to 1e-9 (4x4 products / inverses and the Rodrigues steps of stereoRectify are associated
-    differently).  The one field with a different meaning on the two sides (IMU axis-remap selector vs. an unused flag)
-    is skipped."""
+    oracle's are independent implementations; they must produce the same flvis_cfg -- every integer and every double BIT FOR BIT --
+    for the synthetic rigs and for the reference's own launch files: both compose the rig transforms as Sophus SE3 objects the way
+    vo_tracking.cpp:183-236 does and run cvStereoRectify / cvRodrigues2 in OpenCV's operation order.  (Round 2 allowed 1e-9: a 4x4
+    matrix product instead of the quaternion composition moved the EuRoC extrinsics by 1e-13, which a run with the two loaders --
+    scripts/run_sequence.py hip vs cpu -- turned into 3e-4 m of trajectory after 17 frames through differing RANSAC inlier sets.)
+    The one field with a different meaning on the two sides (IMU axis-remap selector vs. an unused flag) is skipped."""
     import tempfile
     import sys
     import numpy as np
@@ -67,9 +69,18 @@ def test_config_loader_matches_oracle_on_both_rigs():
     import _oracle as O
     import flvis_amd
     from flvis_amd import synth
-    for tag, text in (("d435", synth.D435I_STEREO_YAML), ("euroc", synth.EUROC_LIKE_YAML)):
+    files = []
+    for tag, text in (("d435", synth.D435I_STEREO_YAML), ("euroc", synth.EUROC_LIKE_YAML), ("kitti", synth.KITTI_LIKE_YAML),
+                      ("depth", synth.D435I_DEPTH_YAML)):
         p = os.path.join(tempfile.gettempdir(), "flvis_cfgpar_%s.yaml" % tag)
         open(p, "w").write(text)
+        files.append((tag, p))
+    for rel in ("launch/EuRoC_MAV/euroc.yaml", "launch/d435i/sn943222072828_stereo.yaml", "launch/d435i/sn943222072828_depth.yaml",
+                "launch/d435_pixhawk/sn943222072828_stereo_px4.yaml", "launch/KITTI/KITTI.yaml"):
+        p = os.path.join("/root/reference", rel)          # (absent on the GPU box: this is a CPU test)
+        if os.path.exists(p):
+            files.append((rel, p))
+    for tag, p in files:
         a, b = flvis_amd.load_config(p), O.load_config(p)
         assert C.sizeof(a) == C.sizeof(b)
         fb = {getattr(type(b), n).offset: n for n, _ in b._fields_}
@@ -78,12 +89,9 @@ def test_config_loader_matches_oracle_on_both_rigs():
                 continue
             va, vb = getattr(a, name), getattr(b, fb[getattr(type(a), name).offset])
             if hasattr(va, "__len__"):
-                assert np.allclose(np.array(list(va), float), np.array(list(vb), float), atol=1e-9, rtol=0), (tag, name)
-            elif isinstance(va, float):
-                assert abs(va - vb) <= 1e-9, (tag, name)
+                assert list(va) == list(vb), (tag, name, [x - y for x, y in zip(va, vb)])
             else:
                 assert va == vb, (tag, name, va, vb)
-        assert a.image_width in (640, 752) and a.window_size in (8, 10)
 
 
 def test_config_loader_rejects_bad_files():

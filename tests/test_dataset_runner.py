@@ -38,7 +38,7 @@ def _write_asl(root, frames, imu_sensor, gt_rows):
             f.write("%d,%.9f,%.9f,%.9f,1,0,0,0\n" % (r[0], r[1], r[2], r[3]))
 
 
-def make_asl_folder(nframes=17):
+def make_asl_folder(nframes=17, t0_ns=1403636579000000000):
     """an EuRoC ASL folder written from the synthetic EuRoC-like rig: (root, yaml, frames, imu_sensor, direct_in, t0_ns)"""
     from flvis_amd import synth
     yaml = os.path.join(tempfile.gettempdir(), "flvis_ds_euroc.yaml")
@@ -46,7 +46,6 @@ def make_asl_folder(nframes=17):
     rig = synth.euroc_rig()
     tr = synth.Trajectory(9)
     rnd = synth.Renderer("cpu", rig=rig)
-    t0_ns = 1403636579000000000
     frames, imu_sensor, gt_rows, direct_in = [], [], [], []
     t_prev = -0.05
     for f in range(nframes):

@@ -160,6 +160,69 @@ def test_lk_empty_and_ragged(ctx):
     assert np.array_equal(out[2, :cnt[2]], want)
 
 
+def _want_corner_response(img):
+    """max ordered bits and the sorted candidate keys of cv::goodFeaturesToTrack's response pass, from the oracle's min-eigenvalue map"""
+    e = O.min_eigen_map(img)
+    h, w = e.shape
+    b = e.view(np.uint32).astype(np.uint64)
+    ordered = np.where(b >> np.uint64(31), b ^ np.uint64(0xFFFFFFFF), b ^ np.uint64(0x80000000))
+    pad = np.full((h + 2, w + 2), -np.inf, np.float32)
+    pad[1:-1, 1:-1] = e
+    nb = np.full((h, w), -np.inf, np.float32)
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            if (dy, dx) != (1, 1):
+                nb = np.maximum(nb, pad[dy:dy + h, dx:dx + w])
+    ismax = (e > 0) & ~(nb > e)
+    ismax[0, :] = ismax[-1, :] = False
+    ismax[:, 0] = ismax[:, -1] = False
+    ys, xs = np.nonzero(ismax)
+    keys = ~((ordered[ys, xs] << np.uint64(32)) | (ys * w + xs).astype(np.uint64))
+    return int(ordered.max()), np.sort(keys)
+
+
+@pytest.mark.parametrize("variant,rows", [(0, 0), (1, 0), (2, 60), (2, 37), (2, 8), (2, 500)])
+@pytest.mark.parametrize("h,w", [(480, 640), (480, 752), (376, 1244), (96, 128), (61, 64), (9, 8), (100, 60)])
+def test_corner_response_parity(ctx, h, w, variant, rows):
+    """The response pass of goodFeaturesToTrack on its own, every kernel variant (LDS tiles, strip-mined tiles, the wave walk with
+    several chunk heights incl. one chunk pair per image and chunks shorter than the pipeline lag): the maximum and the COMPLETE
+    set of 3x3 local maxima (value bits and pixel offset of every candidate) are those of the oracle's min-eigenvalue map -- at
+    image sizes whose strips / chunks / tiles end inside, at and beyond the borders."""
+    n = 3
+    imgs = np.stack([S.texture_u8(h, w, 70 + i) for i in range(n)])
+    imgs[1, : h // 2] = 77                     # flat half: zero responses, no candidates there
+    imgs[2] = np.where(np.add.outer(np.arange(h), np.arange(w)) % 2 == 0, 255, 0).astype(np.uint8)  # checkerboard: plateaus of equal maxima
+    mx, keys = ctx.debug_corner_response(_cuda(imgs), variant, rows, key_cap=max(1024, h * w))
+    for i in range(n):
+        wmax, wkeys = _want_corner_response(imgs[i])
+        assert int(mx[i]) == wmax, (i, hex(int(mx[i])), hex(wmax))
+        assert len(keys[i]) == len(wkeys) and np.array_equal(keys[i], wkeys), (i, len(keys[i]), len(wkeys))
+
+
+def test_corner_response_sqrt_is_correctly_rounded(ctx):
+    """ew_sqrt_pos (eig_walk.hip) drops the rescaling and the special-value fix-up of the correctly rounded sqrtf; over EVERY float of
+    its domain -- 0 and [2^-96, 4) -- it returns the same bits (8.2e8 arguments, compared on the device)."""
+    assert ctx.debug_sqrt_check(0, 1) == 0
+    lo, hi = (127 - 96) << 23, 0x40800000
+    assert ctx.debug_sqrt_check(lo, hi - lo) == 0
+    assert ctx.debug_sqrt_check(0x00800000, 1 << 20) > 0     # (outside the domain the two do differ: the check is not vacuous)
+
+
+def test_gftt_parity_with_the_wave_walk_response_kernel():
+    """FLVIS_EIG_WALK=<rows per chunk> selects the wave-walk corner-response kernel inside flvis_hip_gftt / FeatureDEM; the switch is
+    read once per process, so the parity tests of this file are re-run in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("FLVIS_EIG_STRIP_CHILD"):
+        pytest.skip("this is the child run")
+    env = dict(os.environ, FLVIS_EIG_WALK="60", FLVIS_EIG_STRIP_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "gftt_parity or gftt_flat or feature_dem"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and " passed" in out and "failed" not in out, out[-3000:]
+
+
 def test_gftt_parity_with_the_strip_mined_response_kernel():
     """FLVIS_EIG_STRIP=1 selects k_eig_cand_strip (four Sobel pairs / responses per thread, flvis_amd/csrc/eig_strip.hpp) for the
     corner-response pass; the switch is read once per process, so the goodFeaturesToTrack / FeatureDEM parity tests of this file

@@ -46,7 +46,7 @@ def _cfgs_yaml(text, tag):
     return cfg, ocfg
 
 
-def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf, depth_range=None, imu=True):
+def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf, depth_range=None, imu=True, t_offset=0.0):
     import flvis_amd
     from flvis_amd import synth
     S = len(streams)
@@ -65,6 +65,7 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
             if not imu:
                 break                                  # rigs without an IMU (type_of_vi 4): no sample is ever fed
             smp = synth.imu_samples(trajs[i], s, t_prev, t)
+            smp[:, 0] += t_offset                      # stamps as a dataset carries them (EuRoC: seconds since 1970)
             trk.imu_feed_flvis(i, smp)
             for r in smp:
                 imu_want[i].append(np.concatenate([[r[0]], refs[i].imu(r[0], r[1:4], r[4:7])]))
@@ -75,7 +76,7 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
         else:  # depth-camera mode: the second image is the Z16 depth image aligned to cam0
             i0, i1 = rnd.depth_frame(trajs, t, f, max_range=depth_range)
             h0, h1 = i0.cpu().numpy(), i1.cpu().numpy().view(np.uint16)
-        outs = trk.image_feed(i0, i1, [t] * S, with_local_map=False)
+        outs = trk.image_feed(i0, i1, [t + t_offset] * S, with_local_map=False)
         for i in range(S):
             # the IMU-rate trajectory (/imu_pose, what the reference records on EuRoC): every sample's q / p / v bit-identical;
             # fetched every third frame so that a fetch spans several image feeds (and the vision corrections between them)
@@ -85,7 +86,7 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
                 assert np.array_equal(rows, np.array(imu_want[i]).reshape(-1, 11)), "IMU states, frame %d stream %d" % (f, i)
                 n_imu_rows += len(rows)
                 imu_want[i] = []
-            want = refs[i].image(t, h0[i], h1[i])
+            want = refs[i].image(t + t_offset, h0[i], h1[i])
             got = outs[i]
             where = "frame %d stream %d" % (f, i)
             # LOCKSTEP for the whole run: every discrete decision and every fp64 value of the frame is IDENTICAL on both sides
@@ -114,7 +115,7 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
     assert (n_imu_links >= (min_kf - S) // 2) if imu else (n_imu_links == 0)
     assert min(lock_frames) >= min_lock, lock_frames
     rows = trk.trajectory(0, 0, nframes)
-    assert np.allclose(rows[:, 0], np.arange(nframes) / synth.FRAME_HZ)
+    assert np.allclose(rows[:, 0], np.arange(nframes) / synth.FRAME_HZ + t_offset, rtol=0, atol=1e-6)
 
 
 
@@ -140,6 +141,14 @@ def test_frontend_parity_euroc_mode(ctx):
     cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
     assert cfg.cam_type == 1 and cfg.need_equal_hist == 1 and cfg.image_width == 752
     _run_frontend_parity(ctx, cfg, ocfg, synth.euroc_rig(), [9], 60, 50, 2)
+
+
+def test_frontend_parity_euroc_mode_epoch_stamps(ctx):
+    """The EuRoC-mode comparison with the stamps a dataset carries (seconds since 1970, ~1.4e9: a double resolves 2.4e-7 s there):
+    every difference of two stamps (IMU dt, the vision correction's dt, the state lookup) must round the same way on both sides."""
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
+    _run_frontend_parity(ctx, cfg, ocfg, synth.euroc_rig(), [9], 40, 30, 2, t_offset=1403636579.0)
 
 
 def test_frontend_parity_depth_camera_mode(ctx):
