@@ -350,13 +350,14 @@ def main():
         while f < p_end:
             feed(f, standin if f < skip else (standin if f == skip else render(f)), want_out=(f == p_end - 1))
             f += 1
-        ok_local = n_tracking() == S
+        ok_local = plan.steady_state(n_tracking(), S, trk.local_map_counts()[1] if wlm else [], bool(wlm))
         ok_all = fdist.exchange_results(torch.zeros((1, 7), dtype=torch.float64, device=dev), [0 if ok_local else 1], dev)[1][0] == 0
         if ok_all:
             break
         if extra >= plan.EXTRA_SETTLE_MAX:
-            raise SystemExit("bench.py: after %d frames only %d of %d streams are in the Tracking state -- refusing to time a "
-                             "non-steady-state region" % (f, n_tracking(), S))
+            raise SystemExit("bench.py: after %d frames %d of %d streams are in the Tracking state and %d have optimised their window -- "
+                             "refusing to time a non-steady-state region"
+                             % (f, n_tracking(), S, int((trk.local_map_counts()[1] >= 1).sum()) if wlm else 0))
         extra += 1
         sched = plan.frame_schedule(K, Wm, skip, epilogue=epi, extra_settle=extra)
     tracking_at_start = n_tracking()
@@ -394,6 +395,7 @@ def main():
         feed(g, frames[g])
     ctx._check(lib.flvis_hip_synchronize(ctx._h), "synchronize")
     torch.cuda.synchronize()
+    kf_at_start, ba_at_start = (int(x.sum()) for x in trk.local_map_counts())   # queues drained: counts at the start of the clock
 
     # ---- timed region: only k_lk_track (the dominant kernel, 2 launches per step) and the whole-frame chain carry HIP events
     ctx._check(lib.flvis_prof_enable_stages(ctx._h, K, C.c_uint64(timed_mask)), "prof_enable")
@@ -423,6 +425,9 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_ms = e0.elapsed_time(e1)
     elapsed = fdist.max_over_ranks(elapsed, dev)
+    kf_in_region, ba_in_region = (int(x.sum()) for x in trk.local_map_counts())  # (the queues were drained inside the clock)
+    kf_in_region -= kf_at_start
+    ba_in_region -= ba_at_start
     lk_stages = read_stages()
     chain_ms = read_steps(chain_idx, K)
     # ---- untimed epilogue: all stages
@@ -439,8 +444,12 @@ def main():
     cnt = trk.counters()
     rows = np.stack([trk.trajectory(i, last, 1)[0] for i in range(S)])
     tracking = int((rows[:, 8].astype(int) & 15 == 1).sum())
-    all_poses, csum = fdist.exchange_results(torch.from_numpy(rows[:, 1:8].copy()).to(dev), [cnt[0], cnt[1], cnt[2], tracking], dev)
+    all_poses, csum = fdist.exchange_results(torch.from_numpy(rows[:, 1:8].copy()).to(dev),
+                                             [cnt[0], cnt[1], cnt[2], tracking, kf_in_region, ba_in_region], dev)
     assert all_poses.shape[0] == world * S
+    if not plan.region_is_ba_steady(csum[4], csum[5], bool(wlm)):
+        raise SystemExit("bench.py: %d keyframes but %d local-map optimisations inside the timed region -- not the steady state of the "
+                         "path (one optimisation per keyframe)" % (csum[4], csum[5]))
     if csum[3] == 0:
         raise SystemExit("bench.py: no stream is tracking at the end of the run -- the measured region is not the hot path")
 
@@ -467,6 +476,7 @@ def main():
                        "window_size": cfg.window_size, "local_map": bool(wlm),
                        "preroll_frames": sched["preroll"][1], "streams_tracking_at_start": tracking_at_start,
                        "streams_tracking_at_end": int(csum[3]), "keyframes_in_run": int(csum[1]), "ba_runs_in_run": int(csum[2]),
+                       "keyframes_in_timed_region": int(csum[4]), "ba_runs_in_timed_region": int(csum[5]),
                        "gpu_ms_per_step_events": round(gpu_ms / K, 4),
                        "host_loop_ms_per_step": round(t_issue / K * 1e3, 4),
                        "host_enqueue_ms_per_step": round((host1[0] - host1[1] - host0[0] + host0[1]) / K, 4),

@@ -664,6 +664,13 @@ class Tracker:
                         "get_imu_states")
         return rows[:n.value].copy(), dropped.value
 
+    def local_map_counts(self):
+        """(keyframes emitted, local-map optimisations run) per stream"""
+        np = self.np
+        kf, ba = np.zeros(self.S, np.int64), np.zeros(self.S, np.int64)
+        self.ctx._check(self.lib.flvis_get_local_map_counts(self.ctx._h, _P(kf, C.c_int64), _P(ba, C.c_int64)), "get_local_map_counts")
+        return kf, ba
+
     def write_imu_trajectory(self, rows11, path, min_dt=0.0, append=False):
         """The recorder on /imu_pose: rows of imu_states() as `stamp x y z qw qx qy qz` lines; returns the lines written."""
         np = self.np

@@ -5,10 +5,16 @@ The reference drops the first `skip_first_n_imgs` frames of a stream before any 
 attitude initialisation and one `init_frame` before a stream is in the Tracking state.  A timed region that starts before
 that measures skip-path frames (no vision work).  The schedule therefore always runs an UNTIMED pre-roll of
 skip + SETTLE frames (+ up to EXTRA_SETTLE_MAX more while some stream is not yet tracking) before the caller's --warmup.
+
+The local map does not optimise until a stream's window holds `window_size` keyframes (vo_localmap.cpp:211-214): the first 40 frames
+emit a keyframe every fifth frame (f2f_tracking.cpp:339-354), so the first optimisation of a stream comes ~35-40 tracked frames
+after its init_frame.  A timed region before that contains no optimiser work (round 2 timed exactly that with the driver's
+--warmup 5).  With the local map on, the pre-roll therefore also continues until EVERY stream has run at least one optimisation
+(`steady_state`), after which every keyframe triggers one: the region is BA-steady-state for any --warmup / --steps.
 """
 
 SETTLE = 12            # tracked frames fed after the skipped ones before the state of every stream is checked
-EXTRA_SETTLE_MAX = 30  # additional pre-roll frames while a stream is still not in the Tracking state
+EXTRA_SETTLE_MAX = 90  # additional pre-roll frames while a stream is still not tracking / has not yet run its first optimisation
 EPILOGUE = 20          # untimed frames after the timed region: every stage bracketed by HIP events (costs ~10 %)
 
 
@@ -31,6 +37,23 @@ def frame_schedule(steps, warmup, skip, settle=SETTLE, epilogue=EPILOGUE, extra_
     t1 = t0 + steps
     return {"skip": skip, "preroll": (0, p), "warmup": (w0, t0), "timed": (t0, t1), "epilogue": (t1, t1 + epilogue),
             "n_frames": t1 + epilogue}
+
+
+def steady_state(n_tracking, n_streams, ba_runs_per_stream, local_map):
+    """The pre-roll may end: every stream tracks and (with the local map on) every stream's window has optimised at least once."""
+    if n_tracking != n_streams:
+        return False
+    if not local_map:
+        return True
+    runs = list(ba_runs_per_stream)
+    return len(runs) == n_streams and min(runs) >= 1
+
+
+def region_is_ba_steady(keyframes_in_region, ba_runs_in_region, local_map):
+    """One optimisation per keyframe inside the clock (vo_localmap.cpp:292-366); both counts are taken with the queues drained."""
+    if not local_map:
+        return True
+    return keyframes_in_region > 0 and abs(ba_runs_in_region - keyframes_in_region) <= max(1, keyframes_in_region // 50)
 
 
 def max_frames(steps, warmup, skip, settle=SETTLE, epilogue=EPILOGUE):

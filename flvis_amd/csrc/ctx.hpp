@@ -24,7 +24,7 @@ struct flvis_ctx {
   };
   std::map<std::string, Buf> bufs;  // named scratch buffers, grown on demand (never inside a steady-state loop)
   flvis::Pipeline* pipe = nullptr;
-  int voc_nodes = 0, voc_words = 0;  // the DBoW3 vocabulary resident in the `voc_*` scratch buffers (flvis_hip_bow_set_vocabulary)
+  int voc_nodes = 0, voc_words = 0, voc_depth = 0;  // the DBoW3 vocabulary resident in the `voc_*` scratch buffers (flvis_hip_bow_set_vocabulary)
   std::string orb_pattern;  // the BRIEF pattern currently resident in the `orb_pattern` scratch buffer (1024 bytes) or empty
 
   // returns a device buffer of at least `bytes` bytes (contents undefined after growth)

@@ -1098,11 +1098,13 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
     hipMemsetAsync(sc.nkeys, 0, sizeof(int) * S, st);
   }
   if (ev) hipEventRecord(ev[0], st);
-  // which kernel computes the corner response: FLVIS_EIG_WALK=<rows per chunk> the wave walk (eig_walk.hip), FLVIS_EIG_STRIP=1 the
-  // strip-mined tile kernel, otherwise the tile kernel
+  // which kernel computes the corner response: the wave walk (eig_walk.hip) with 120 rows per chunk unless FLVIS_EIG_WALK=<rows> says
+  // otherwise; FLVIS_EIG_WALK=0 selects the LDS-tile kernel k_eig_cand, FLVIS_EIG_WALK=0 FLVIS_EIG_STRIP=1 its strip-mined form (both
+  // kept for the A/B of profiles/r03_eig_walk_ab.md and as independent implementations in the parity tests)
   static const int variant_rows = [] {
     const char* e = getenv("FLVIS_EIG_WALK");
-    if (e) return atoi(e) > 0 ? atoi(e) : -1;
+    if (!e) return 120;
+    if (atoi(e) > 0) return atoi(e);
     e = getenv("FLVIS_EIG_STRIP");
     return (e && atoi(e) != 0) ? -2 : -1;
   }();

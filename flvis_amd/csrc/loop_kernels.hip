@@ -41,6 +41,7 @@ struct VocDev {
   const double* weight;     // per node (leaves: idf)
   const double* word_weight;  // per word id
   int n_nodes, n_words;
+  int depth;  // levels below the root (bounds the descent of k_bow_words)
 };
 
 // exclusive prefix sum of one int per thread over the workgroup (NW waves); total = the sum
@@ -84,9 +85,15 @@ __global__ __launch_bounds__(256) void k_bow_words(VocDev v, const uint8_t* __re
     const uint4* f = reinterpret_cast<const uint4*>(desc + ((size_t)img * dcap + r) * 32);
     const uint4 f0 = f[0], f1 = f[1];
     int node = 0;
-    while (true) {
+    // (flvis_hip_bow_set_vocabulary only accepts trees, so the descent ends after at most `depth` levels; the bound keeps a
+    // corrupted table from hanging the GPU: it then yields no word)
+    bool leaf = false;
+    for (int level = 0; level <= v.depth; level++) {
       const int c0 = v.child_ptr[node], c1 = v.child_ptr[node + 1];
-      if (c0 == c1) break;  // leaf
+      if (c0 == c1) {
+        leaf = true;
+        break;
+      }
       int best_d = INT_MAX, best = node;
       for (int c = c0; c < c1; c++) {
         const int id = v.child_idx[c];
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void k_bow_words(VocDev v, const uint8_t* __re
       }
       node = best;
     }
-    if (v.weight[node] > 0) out = v.word_id[node];
+    if (leaf && v.weight[node] > 0) out = v.word_id[node];
   }
   words[(size_t)img * dcap + r] = out;
 }
@@ -712,8 +719,29 @@ int flvis_hip_bow_set_vocabulary(flvis_ctx* ctx, int n_nodes, const int* h_child
     }
   }
   const int n_edges = h_child_ptr[n_nodes];
+  if (n_edges != n_nodes - 1) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_set_vocabulary: a tree of n nodes has n - 1 child links");
   for (int c = 0; c < n_edges; c++)
     if (h_child_idx[c] <= 0 || h_child_idx[c] >= n_nodes) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_set_vocabulary: bad child index");
+  // the links must form a tree below node 0: every non-root node listed exactly once and reached from the root (k_bow_words walks
+  // down until it meets a leaf: a node that is its own descendant would never let it)
+  int depth = 0;
+  {
+    std::vector<char> listed((size_t)n_nodes, 0);
+    for (int c = 0; c < n_edges; c++) {
+      if (listed[h_child_idx[c]]) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_set_vocabulary: a node is the child of two nodes");
+      listed[h_child_idx[c]] = 1;
+    }
+    std::vector<std::pair<int, int>> stack{{0, 0}};
+    size_t reached = 0;
+    while (!stack.empty()) {
+      const std::pair<int, int> nd = stack.back();
+      stack.pop_back();
+      reached++;
+      depth = std::max(depth, nd.second);
+      for (int c = h_child_ptr[nd.first]; c < h_child_ptr[nd.first + 1]; c++) stack.push_back({h_child_idx[c], nd.second + 1});
+    }
+    if (reached != (size_t)n_nodes) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bow_set_vocabulary: nodes that are not reachable from the root");
+  }
   std::vector<double> ww((size_t)n_words, 0.0);
   for (int n = 0; n < n_nodes; n++)
     if (h_child_ptr[n + 1] == h_child_ptr[n]) ww[h_word_id[n]] = h_weight[n];
@@ -735,6 +763,7 @@ int flvis_hip_bow_set_vocabulary(flvis_ctx* ctx, int n_nodes, const int* h_child
   if (e != hipSuccess) return ctx->hip_fail(e, "bow_set_vocabulary");
   ctx->voc_nodes = n_nodes;
   ctx->voc_words = n_words;
+  ctx->voc_depth = depth;
   return FLVIS_OK;
 }
 
@@ -796,7 +825,7 @@ int flvis_hip_bow_transform(flvis_ctx* ctx, const uint8_t* d_desc, const int* d_
     return ctx->fail(FLVIS_ERR_CAPACITY, "bow_transform: vcap must hold min(dcap, number of words) entries (a vector is never truncated)");
   VocDev v{(const int*)ctx->scratch("voc_child_ptr", 0), (const int*)ctx->scratch("voc_child_idx", 0),
            (const uint8_t*)ctx->scratch("voc_desc", 0), (const int*)ctx->scratch("voc_word_id", 0),
-           (const double*)ctx->scratch("voc_weight", 0), (const double*)ctx->scratch("voc_word_weight", 0), ctx->voc_nodes, ctx->voc_words};
+           (const double*)ctx->scratch("voc_weight", 0), (const double*)ctx->scratch("voc_word_weight", 0), ctx->voc_nodes, ctx->voc_words, ctx->voc_depth};
   int* words = (int*)ctx->scratch("bow_words", sizeof(int) * (size_t)dcap * n_img);
   if (!words) return ctx->fail(FLVIS_ERR_HIP, "bow_transform: scratch allocation failed");
   hipStream_t st = ctx->stream;

@@ -1395,6 +1395,28 @@ int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) {
   return FLVIS_OK;
 }
 
+// per stream: keyframes the tracker has emitted (KeyFrame messages of /vo_kf) and optimisations its local map has run
+int flvis_get_local_map_counts(flvis_ctx* ctx, int64_t* h_keyframes, int64_t* h_ba_runs) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  sync_all(ctx);
+  for (Lane* L : ctx->pipe->lanes) {
+    if (h_keyframes) {
+      std::vector<unsigned> tl(L->S);
+      hipError_t e = hipMemcpy(tl.data(), L->pipe.kfq_tail, sizeof(unsigned) * L->S, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return ctx->hip_fail(e, "get_local_map_counts");
+      for (int i = 0; i < L->S; i++) h_keyframes[L->s0 + i] = tl[i];
+    }
+    if (h_ba_runs) {
+      std::vector<long long> r(L->S);
+      hipError_t e = hipMemcpy2D(r.data(), sizeof(long long), reinterpret_cast<const char*>(L->pipe.win) + offsetof(WindowDev, ba_runs),
+                                 sizeof(WindowDev), sizeof(long long), L->S, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return ctx->hip_fail(e, "get_local_map_counts");
+      for (int i = 0; i < L->S; i++) h_ba_runs[L->s0 + i] = r[i];
+    }
+  }
+  return FLVIS_OK;
+}
+
 // sums over the lanes; [3] = keyframes dropped because a stream's queue was full (0 unless the back-pressure was defeated)
 int flvis_debug_counters(flvis_ctx* ctx, int64_t* h64) {
   if (!ctx || !ctx->pipe || !h64) return FLVIS_ERR_INVALID_ARG;

@@ -397,6 +397,9 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_fr
 int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, double min_dt, int append);
 /* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
+/* Per stream (arrays of n_streams, either may be NULL): keyframes the tracker has emitted and optimisations the stream's local map has
+ * run (one per keyframe once the window holds window_size keyframes, vo_localmap.cpp:211-214,292-366).  Drains the queues first. */
+int flvis_get_local_map_counts(flvis_ctx* ctx, int64_t* h_keyframes, int64_t* h_ba_runs);
 /* Test aid: poses (tx ty tz qx qy qz qw) of a stream's last Tracking frame right after PnP-RANSAC and after the pose-only LM
  * (the two fp64 stages of LKORBTracking::tracking / OptimizeInFrame::optimize), h_out21 = 3 x 7 doubles (the third: the pose the LM starts from). */
 int flvis_debug_stage_poses(flvis_ctx* ctx, int stream, double* h_out21);

@@ -40,6 +40,21 @@ def test_extra_settle_shifts_everything():
     assert b["preroll"] == (0, a["preroll"][1] + 3)
 
 
+def test_preroll_ends_only_in_the_ba_steady_state():
+    """The local map optimises only once a stream's window is full (vo_localmap.cpp:211-214): the pre-roll goes on until every stream
+    tracks AND has run an optimisation, and a value is printed only if the timed region saw one optimisation per keyframe."""
+    assert not plan.steady_state(63, 64, [1] * 64, True)                 # a stream not tracking yet
+    assert not plan.steady_state(64, 64, [1] * 63 + [0], True)           # a window still filling
+    assert not plan.steady_state(64, 64, [], True)
+    assert plan.steady_state(64, 64, [1] * 63 + [3], True)
+    assert plan.steady_state(64, 64, [], False)                          # front-end only runs: tracking is enough
+    assert plan.region_is_ba_steady(412, 412, True) and plan.region_is_ba_steady(412, 410, True)
+    assert not plan.region_is_ba_steady(883, 435, True)                  # round 2's driver line: half the keyframes never optimised
+    assert not plan.region_is_ba_steady(0, 0, True)
+    assert plan.region_is_ba_steady(0, 0, False)
+    assert plan.EXTRA_SETTLE_MAX >= 60                                   # room for the ~40 tracked frames a window needs to fill
+
+
 def test_cpu_sample_is_never_empty_for_the_driver_arguments():
     s = plan.frame_schedule(20, 5, 50)
     first, n = plan.cpu_sample(80, s)

@@ -208,15 +208,17 @@ def test_corner_response_sqrt_is_correctly_rounded(ctx):
     assert ctx.debug_sqrt_check(0x00800000, 1 << 20) > 0     # (outside the domain the two do differ: the check is not vacuous)
 
 
-def test_gftt_parity_with_the_wave_walk_response_kernel():
-    """FLVIS_EIG_WALK=<rows per chunk> selects the wave-walk corner-response kernel inside flvis_hip_gftt / FeatureDEM; the switch is
-    read once per process, so the parity tests of this file are re-run in a child process with it set."""
+@pytest.mark.parametrize("walk", ["60", "0"])
+def test_gftt_parity_with_the_other_response_kernels(walk):
+    """The corner-response pass inside flvis_hip_gftt / FeatureDEM is the wave walk with 120 rows per chunk; FLVIS_EIG_WALK=<rows>
+    changes the chunk height, FLVIS_EIG_WALK=0 selects the LDS-tile kernel.  The switch is read once per process, so the parity tests
+    of this file are re-run in a child process with it set: the same corners, bit for bit."""
     import os
     import subprocess
     import sys
     if os.environ.get("FLVIS_EIG_STRIP_CHILD"):
         pytest.skip("this is the child run")
-    env = dict(os.environ, FLVIS_EIG_WALK="60", FLVIS_EIG_STRIP_CHILD="1")
+    env = dict(os.environ, FLVIS_EIG_WALK=walk, FLVIS_EIG_STRIP_CHILD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "gftt_parity or gftt_flat or feature_dem"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
     out = r.stdout.decode()
@@ -232,7 +234,7 @@ def test_gftt_parity_with_the_strip_mined_response_kernel():
     import sys
     if os.environ.get("FLVIS_EIG_STRIP_CHILD"):
         pytest.skip("this is the child run")
-    env = dict(os.environ, FLVIS_EIG_STRIP="1", FLVIS_EIG_STRIP_CHILD="1")
+    env = dict(os.environ, FLVIS_EIG_WALK="0", FLVIS_EIG_STRIP="1", FLVIS_EIG_STRIP_CHILD="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "gftt_parity or gftt_flat or feature_dem"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
     out = r.stdout.decode()
