@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 from flvis_amd import bench_plan as plan  # noqa: E402  (pure python, no GPU)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
-ROUND_TAG = "r02"
+ROUND_TAG = "r03"
 
 # algorithmic HBM bytes per launch of the image-scan kernels for ONE stream, 640x480:
 PYR_BYTES = 307200 + 76800 + 19200 + 4800          # one pyramid (levels 0..3)
@@ -186,40 +186,93 @@ def run_stub(args, rank, world):
 
 
 # --------------------------------------------------------------------------------------------------------------- PMC
+def csrc_hash():
+    """hash of every kernel source: the per-kernel counters in profiles/ belong to exactly this code"""
+    import glob
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "flvis_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def short_kernel_name(full):
+    n = full.split("(")[0]
+    n = n.split("::")[-1]
+    return n.split("<")[0].strip()
+
+
 def run_pmc(args):
-    """Two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass on gfx950) of a short run of this script;
-    per-launch averages of k_lk_track over the launches of the timed region (the last 2 x steps launches before the epilogue
-    is disabled) -> profiles/<tag>_lk_pmc.json."""
+    """Four rocprofv3 passes of a short run of this script: a plain kernel trace (durations), then FETCH_SIZE, WRITE_SIZE (they do not
+    fit one pass on gfx950) and SQ_INSTS_VALU, each in its own --pmc pass.  Per kernel the averages over the launches of the second half
+    of the run (the timed region; the first half is pre-roll and warm-up) -> profiles/<tag>_kernel_pmc.json, and k_lk_track's traffic
+    additionally as profiles/<tag>_lk_pmc.json (the file `roofline.traffic` is read from)."""
     import csv
     import glob
-    out = {"kernel": "k_lk_track", "lk_source_sha": lk_source_hash(), "steps": args.steps, "streams": args.streams}
-    vals = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    base = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+            "--streams", str(args.streams), "--cpu-frames", "0", "--cpu-mt-frames", "0", "--no-epilogue", "--no-h2d"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    kern = {}
+
+    def second_half(rows):
+        return rows[len(rows) // 2:] if len(rows) >= 2 else rows
+
+    d = tempfile.mkdtemp(prefix="flvis_trace_", dir="/tmp")
+    r = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base, cwd="/tmp", env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if r.returncode != 0 or not files:
+        raise SystemExit("rocprofv3 --kernel-trace failed (rc %d):\n%s" % (r.returncode, r.stdout.decode(errors="replace")[-2000:]))
+    per = {}
+    for x in csv.DictReader(open(files[0])):
+        if "flvis::" in x["Kernel_Name"]:
+            per.setdefault(short_kernel_name(x["Kernel_Name"]), []).append(float(x["End_Timestamp"]) - float(x["Start_Timestamp"]))
+    for k, v in per.items():
+        t = second_half(v)
+        kern[k] = {"launches_total": len(v), "launches_averaged": len(t), "avg_ns": sum(t) / len(t)}
+    for ctr, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb"), ("SQ_INSTS_VALU", "valu_insts")):
         d = tempfile.mkdtemp(prefix="flvis_pmc_%s_" % ctr, dir="/tmp")
-        cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-               sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--streams", str(args.streams), "--cpu-frames", "0", "--cpu-mt-frames", "0", "--no-epilogue", "--no-h2d"]
-        env = dict(os.environ, TMPDIR="/tmp")
-        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        r = subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base,
+                           cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
             raise SystemExit("rocprofv3 --pmc %s failed (rc %d):\n%s" % (ctr, r.returncode, r.stdout.decode(errors="replace")[-2000:]))
-        rows = [float(x["Counter_Value"]) for x in csv.DictReader(open(files[0]))
-                if "k_lk_track" in x["Kernel_Name"] and x["Counter_Name"] == ctr]
-        timed = rows[-2 * args.steps:]  # two launches per step; the timed steps are the last ones fed
-        vals[ctr] = (sum(timed) / len(timed), len(timed))
-    f, w = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
-    out.update({"fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
-                "launches": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]],
-                "traffic_bytes_per_launch": (f + w) * 1024.0,
-                "note": "rocprofv3 FETCH_SIZE / WRITE_SIZE (KB), separate --pmc passes of `bench.py --steps %d --warmup %d`, averaged "
-                        "over the k_lk_track launches of the timed region; uncorrected: the gfx950 factor 2 documented for 16 B/lane "
-                        "streaming reads is not calibrated for this kernel's dword accesses (MI355X_MICROARCH.md, HBM section)"
-                        % (args.steps, args.warmup)})
+        per = {}
+        for x in csv.DictReader(open(files[0])):
+            if "flvis::" in x["Kernel_Name"] and x["Counter_Name"] == ctr:
+                per.setdefault(short_kernel_name(x["Kernel_Name"]), []).append(float(x["Counter_Value"]))
+        for k, v in per.items():
+            t = second_half(v)
+            kern.setdefault(k, {})[key] = sum(t) / len(t)
+    out = {"source_sha": csrc_hash(), "steps": args.steps, "warmup": args.warmup, "streams": args.streams, "kernels": kern,
+           "note": "rocprofv3, four passes of `bench.py --steps %d --warmup %d --no-epilogue --no-h2d`: kernel trace (avg_ns), --pmc "
+                   "FETCH_SIZE, --pmc WRITE_SIZE (KB; uncorrected: the gfx950 factor 2 of MI355X_MICROARCH.md's HBM section is calibrated "
+                   "for 16 B/lane streaming reads only), --pmc SQ_INSTS_VALU (wave instructions); per kernel the average over the second "
+                   "half of its launches (the timed region)" % (args.steps, args.warmup)}
+    lk = kern.get("k_lk_track", {})
+    lkout = {"kernel": "k_lk_track", "lk_source_sha": lk_source_hash(), "steps": args.steps, "streams": args.streams,
+             "fetch_size_kb_per_launch": lk.get("fetch_kb"), "write_size_kb_per_launch": lk.get("write_kb"),
+             "traffic_bytes_per_launch": (lk.get("fetch_kb", 0) + lk.get("write_kb", 0)) * 1024.0 if lk else None,
+             "note": "from %s_kernel_pmc.json" % ROUND_TAG}
     for dst in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
         os.makedirs(dst, exist_ok=True)
-        json.dump(out, open(os.path.join(dst, "%s_lk_pmc.json" % ROUND_TAG), "w"), indent=1)
+        json.dump(out, open(os.path.join(dst, "%s_kernel_pmc.json" % ROUND_TAG), "w"), indent=1)
+        json.dump(lkout, open(os.path.join(dst, "%s_lk_pmc.json" % ROUND_TAG), "w"), indent=1)
     print(json.dumps(out))
+
+
+def read_kernel_pmc(S):
+    """per-kernel counters from the newest committed PMC file -- only if it was measured on THIS source tree and batch size"""
+    import glob
+    want = csrc_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_pmc.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except Exception:
+            continue
+        if pmc.get("source_sha") == want and pmc.get("streams") == S:
+            return pmc, os.path.basename(path)
+    return None, None
 
 
 def read_traffic(S):
@@ -432,12 +485,26 @@ def main():
     chain_ms = read_steps(chain_idx, K)
     # ---- untimed epilogue: all stages
     stages = None
+    lk_iters = None
     if epi:
         ctx._check(lib.flvis_prof_enable_stages(ctx._h, epi, C.c_uint64((1 << 64) - 1)), "prof_enable")
+        ctx._check(lib.flvis_debug_lk_stats(ctx._h, 1), "lk_stats")   # (epilogue only: one atomic per point and level)
         for g in range(*sched["epilogue"]):
             feed(g, frames[g])
         torch.cuda.synchronize()
+        ctx._check(lib.flvis_debug_lk_stats(ctx._h, 0), "lk_stats")
         stages = read_stages()
+        dbg = (C.c_int64 * 64)()
+        ctx._check(lib.flvis_debug_counters(ctx._h, dbg), "debug_counters")
+        lk_iters = {}
+        for tag, base in (("temporal", 36), ("stereo", 48)):
+            per = {}
+            for lv in range(6):
+                if dbg[base + 2 * lv + 1]:
+                    per["level%d" % lv] = {"points_per_launch": round(dbg[base + 2 * lv + 1] / epi, 1),
+                                           "mean_iterations": round(dbg[base + 2 * lv] / dbg[base + 2 * lv + 1], 2)}
+            tot_it = sum(dbg[base + 2 * lv] for lv in range(6))
+            lk_iters[tag] = {"per_level": per, "window_evaluations_per_launch": round(tot_it / epi, 1)}
     last = sched["n_frames"] - 1
 
     # ---- results: tracker health, final poses; the path's only exchange: all-gather poses, all-reduce counters
@@ -506,6 +573,32 @@ def main():
         if stages is not None:
             out["stages_ms_per_step"] = {k: round(v, 4) for k, v in stages.items()}
             out["stages_note"] = "per-stage times from %d untimed frames after the timed region (all stages bracketed by events)" % epi
+            # ---- per-kernel roofline table: every kernel priced against the resource that bounds it
+            try:
+                from flvis_amd import roofline as rf
+                dbg = (C.c_int64 * 64)()
+                ctx._check(lib.flvis_debug_counters(ctx._h, dbg), "debug_counters")
+                ba = {"runs": int(dbg[2]), "trials": int(dbg[4]), "trials_items": int(dbg[5]), "trials_landmarks": int(dbg[6]),
+                      "trials_poses": int(dbg[7]), "ms_per_optimisation": (dbg[60] * 1e-5 / dbg[2]) if dbg[2] else None,
+                      "worker_ms_per_launch": stages.get("ba_worker(launch)")}
+                kpmc, kpmc_src = read_kernel_pmc(S)
+                copy_gbs = out["roofline"].get("hbm_copy_measured", {}).get("GB/s")
+                out["roofline"]["kernels"] = rf.kernel_table(stages, S, 640, 480, copy_gbs, kpmc, ba if wlm else None, elapsed / K * 1e3)
+                if lk_iters:
+                    out["roofline"]["lk_iterations"] = lk_iters
+                    for r in out["roofline"]["kernels"]:   # instruction budget of LK: wave instructions per iteration (31 x 31 window)
+                        for tag in ("temporal", "stereo"):
+                            if r["kernel"] == "k_lk_track (%s)" % tag and r.get("valu_insts_per_launch") and lk_iters[tag]["window_evaluations_per_launch"]:
+                                per_it = r["valu_insts_per_launch"] / lk_iters[tag]["window_evaluations_per_launch"]
+                                r["valu_insts_per_iteration"] = round(per_it, 1)
+                                r["valu_insts_per_window_pixel"] = round(per_it * 64 / 961.0, 2)
+                out["roofline"]["kernels_note"] = (
+                    "avg_launch_ms: HIP events of this run (epilogue frames); counters / rocprof_avg_launch_ms: %s; valu_issue_frac against "
+                    "%.1f G wave-instructions/s (1024 SIMDs x 2.4 GHz / 4); k_ba_worker: SURVEY 8d's flop formula on the kernel's own trial / "
+                    "observation / landmark counters, time = the kernel's wall clock per optimisation"
+                    % (kpmc_src or "no PMC file matches this source tree (run `bench.py --pmc`)", rf.VALU_ISSUE_PEAK_GINST))
+            except Exception as e:  # noqa: BLE001
+                out.setdefault("leg_errors", []).append("kernel table: %s: %s" % (type(e).__name__, e))
         # ---- legs that must never suppress the GPU line: host-image variant, CPU baselines, ATE
         for leg in (leg_h2d, leg_cpu):
             try:

@@ -112,6 +112,8 @@ struct BAShared {
   int hidx_of[BA_WMAX];
   int slot_cnt[BA_WMAX];
   int P, L, E, flag, cnt, W, nitems;
+  int n_trials;  // LM trials (reduced-system solves) of this optimisation: flop accounting of bench.py
+  long long t_begin;  // wall_clock64 (100 MHz) at the start of the optimisation
   int NR, LD, off_linv, off_stage;  // reduced system geometry: Hs[NR][LD], Linv, chunk buffers (double offsets)
   int CI, CL, bufd, nchunk;         // chunk capacities (items, landmarks), doubles per buffer, chunk count
   int npairs, slices, rs;           // role partition of the Schur phase
@@ -1363,6 +1365,7 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
         }
       }
       qmax++;
+      if (t == 0) sh.n_trials++;
     } while (rho < 0 && qmax < 10);
     if (qmax == 10 || rho == 0 || lambda_bad) break;
   }
@@ -1401,6 +1404,8 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
       sh.q_c_b[0] = p.cam.T_c_i[6], sh.q_c_b[1] = p.cam.T_c_i[3], sh.q_c_b[2] = p.cam.T_c_i[4], sh.q_c_b[3] = p.cam.T_c_i[5];
     }
     sh.n_imu = ne;
+    sh.n_trials = 0;
+    sh.t_begin = (long long)wall_clock64();
     sh.prof = nullptr;
 #ifdef FLVIS_BA_PROF
     sh.prof = p.counters ? p.counters + 8 : nullptr;
@@ -1536,7 +1541,17 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
       p.st[s].lm_state = 1;
       w.solve = 0;
       w.ba_runs++;
-      if (p.counters) atomicAdd((unsigned long long*)&p.counters[2], 1ull);
+      if (p.counters) {
+        atomicAdd((unsigned long long*)&p.counters[2], 1ull);
+        // flop accounting (per trial E (120 + 300) + sum_l k_l^2 / 2 * 324 + (6 P)^3 / 3): trials, trials x observations by
+        // free poses, trials x landmarks, trials x free poses
+        const unsigned long long nt = (unsigned long long)sh.n_trials;
+        atomicAdd((unsigned long long*)&p.counters[4], nt);
+        atomicAdd((unsigned long long*)&p.counters[5], nt * (unsigned long long)sh.nitems);
+        atomicAdd((unsigned long long*)&p.counters[6], nt * (unsigned long long)sh.L);
+        atomicAdd((unsigned long long*)&p.counters[7], nt * (unsigned long long)sh.P);
+        atomicAdd((unsigned long long*)&p.counters[60], (unsigned long long)((long long)wall_clock64() - sh.t_begin));  // 10 ns ticks
+      }
     }
   }
   BAPROF(11);

@@ -36,6 +36,8 @@ struct LKParams {
   double eps2;      // epsilon^2
   float min_eig;    // minEigThreshold (1e-4)
   int use_initial;  // OPTFLOW_USE_INITIAL_FLOW
+  // optional statistics (nullptr: none): stats[2 l] += Gauss-Newton iterations run at level l, stats[2 l + 1] += points that iterated there
+  unsigned long long* stats = nullptr;
 };
 
 struct DemParams {

@@ -315,7 +315,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const uint8_t* Jimg = next.lvl[level].ptr(s, next.stride[level]);
       bool region_ok = false;
       int RX0 = 0, RY0 = 0;
+      int iters_run = 0;
       for (int j = 0; j < prm.max_iter; j++) {
+        iters_run = j + 1;
         const int inx = (int)floorf(npx), iny = (int)floorf(npy);
         if (inx < -LK_WIN || inx >= JW || iny < -LK_WIN || iny >= JH) {
           if (level == 0) st = 0;
@@ -384,6 +386,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         pdx = ddx;
         pdy = ddy;
+      }
+      if (prm.stats && lane == 0) {
+        atomicAdd(&prm.stats[2 * level], (unsigned long long)iters_run);
+        atomicAdd(&prm.stats[2 * level + 1], 1ull);
       }
       if (st && level == 0) {  // error stage of calcOpticalFlowPyrLK: final window must still start inside
         const float fx = nx - halfWin, fy = ny - halfWin;

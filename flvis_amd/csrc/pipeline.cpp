@@ -115,6 +115,7 @@ struct Pipeline {
   double host_ms_total = 0, host_ms_wait = 0;  // host time inside flvis_image_feed / of it blocked on the pinned ring
   bool sync_each_frame = false;  // FLVIS_SYNC_EACH_FRAME=1: image_feed waits for the previous frame (tuning knob)
   int ba_every = 1;              // launch the local-map worker every n-th frame (FLVIS_BA_EVERY)
+  bool lk_stats = false;         // flvis_debug_lk_stats: the LK launches count their iterations per level into counters[36 .. 59]
   hipStream_t ba_stream[NBA] = {};
   long long ba_rr = 0;           // round-robin counter over the local-map streams
   hipEvent_t ev_in = nullptr;    // the caller's inputs are ready (recorded on the context's stream)
@@ -861,6 +862,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     fill_pyr(pl, prev, L->pyr0[0], L->pyr0[1], p.img_slot, 1, pl->levels_t);
     fill_pyr(pl, next, L->pyr0[0], L->pyr0[1], p.img_slot, 0, pl->levels_t);
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
+    if (pl->lk_stats) prm.stats = reinterpret_cast<unsigned long long*>(p.counters) + 36;  // temporal: counters[36 .. 47]
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track, pl->max_pts);
   }
   PE(4, st);
@@ -902,6 +904,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     next.pitch[0] = r0pitch;
     next.stride[0] = r0stride;
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
+    if (pl->lk_stats) prm.stats = reinterpret_cast<unsigned long long*>(p.counters) + 48;  // stereo: counters[48 .. 59]
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts);
   }
   PE(15, st);
@@ -1414,6 +1417,14 @@ int flvis_get_local_map_counts(flvis_ctx* ctx, int64_t* h_keyframes, int64_t* h_
       for (int i = 0; i < L->S; i++) h_ba_runs[L->s0 + i] = r[i];
     }
   }
+  return FLVIS_OK;
+}
+
+// measurement aid: from now on the tracker's two LK launches per frame count Gauss-Newton iterations and points per pyramid level
+// (flvis_debug_counters [36 + 2 l], [37 + 2 l]: temporal LK, level l; [48 + 2 l], [49 + 2 l]: stereo LK); costs one atomic per point and level
+int flvis_debug_lk_stats(flvis_ctx* ctx, int enable) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  ctx->pipe->lk_stats = enable != 0;
   return FLVIS_OK;
 }
 

@@ -403,6 +403,10 @@ int flvis_get_local_map_counts(flvis_ctx* ctx, int64_t* h_keyframes, int64_t* h_
 /* Test aid: poses (tx ty tz qx qy qz qw) of a stream's last Tracking frame right after PnP-RANSAC and after the pose-only LM
  * (the two fp64 stages of LKORBTracking::tracking / OptimizeInFrame::optimize), h_out21 = 3 x 7 doubles (the third: the pose the LM starts from). */
 int flvis_debug_stage_poses(flvis_ctx* ctx, int stream, double* h_out21);
+/* Measurement aid (bench.py's LK instruction budget): enable != 0 makes the tracker's two LK launches per frame count their Gauss-Newton
+ * iterations and the points that iterated, per pyramid level, into flvis_debug_counters: [36 + 2 l], [37 + 2 l] temporal LK at level l,
+ * [48 + 2 l], [49 + 2 l] stereo LK. */
+int flvis_debug_lk_stats(flvis_ctx* ctx, int enable);
 /* Test aid: the corner-response pass of flvis_hip_gftt alone (cornerMinEigenVal + the 3x3 local maxima), with the kernel variant chosen
  * (0: LDS tiles, 1: strip-mined tiles, 2: wave walk with `rows` rows per chunk): per image the ordered bits of the maximum response, the
  * number of local maxima and their sort keys ~((ordered(response) << 32) | pixel offset), unsorted, in h_keys [n_img][key_cap]. */

@@ -338,6 +338,17 @@ def test_loop_entry_points_reject_bad_input(ctx):
         ctx.bow_set_vocabulary(np.array([1, 2, 2, 2], np.int32), ci, ds, wt, wi)  # node 0 is not the root
     with pytest.raises(flvis_amd.FlvisError):
         ctx.bow_set_vocabulary(cp, np.array([1, 7], np.int32), ds, wt, wi)       # child index out of range
+    # links that do not form a tree (k_bow_words walks down until it meets a leaf: such a table used to hang the GPU)
+    ds5, wt5, wi5 = np.zeros((5, 32), np.uint8), np.array([0.0, 0.0, 1.0, 1.0, 1.0]), np.array([-1, -1, 0, 1, 2], np.int32)
+    ctx.bow_set_vocabulary(np.array([0, 2, 4, 4, 4, 4], np.int32), np.array([1, 2, 3, 4], np.int32), ds5, wt5, wi5)   # valid: 0 -> {1, 2}, 1 -> {3, 4}
+    with pytest.raises(flvis_amd.FlvisError):      # node 1 lists itself as its child (and node 4 hangs nowhere)
+        ctx.bow_set_vocabulary(np.array([0, 2, 4, 4, 4, 4], np.int32), np.array([1, 2, 1, 3], np.int32), ds5, wt5, wi5)
+    with pytest.raises(flvis_amd.FlvisError):      # node 3 is the child of two nodes
+        ctx.bow_set_vocabulary(np.array([0, 2, 4, 4, 4, 4], np.int32), np.array([1, 3, 3, 4], np.int32), ds5, wt5, wi5)
+    with pytest.raises(flvis_amd.FlvisError):      # nodes 3 and 4 form a cycle that the root does not reach
+        ctx.bow_set_vocabulary(np.array([0, 2, 2, 2, 3, 4], np.int32), np.array([1, 2, 4, 3], np.int32), ds5,
+                               np.array([0.0, 1.0, 1.0, 0.0, 0.0]), np.array([-1, 0, 1, -1, -1], np.int32))
+    ctx.bow_set_vocabulary(cp, ci, ds, wt, wi)
     big = torch.zeros((1, 4096, 32), dtype=torch.uint8, device="cuda")
     with pytest.raises(flvis_amd.FlvisError):
         ctx.bow_transform(big, torch.zeros(1, dtype=torch.int32, device="cuda"))   # more than 2048 descriptors per keyframe
