@@ -289,25 +289,55 @@ FD void store_pose7(double* p, const SE3d& T) {
   p[6] = T.q.w;
 }
 
-// counter-based RNG shared by both RANSACs (definition: DESIGN.md "RANSAC"; OpenCV's RNG stream cannot be matched)
-FD uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
+// cv::RNG (core/operations.hpp): multiply-with-carry, output = low word of the new state.  Every RANSAC / LMedS run of OpenCV draws
+// from its own `RNG rng((uint64)-1)` (calib3d/src/ptsetreg.cpp): the samples of a call depend on the point count alone.
+struct CvRng {
+  uint64_t state;
+};
+FD CvRng cv_rng_init() { return CvRng{0xffffffffffffffffull}; }
+FD uint32_t cv_rng_next(CvRng& r) {
+  r.state = (uint64_t)(uint32_t)r.state * 4164903690u + (uint32_t)(r.state >> 32);
+  return (uint32_t)r.state;
 }
-FD uint32_t rng_draw(uint64_t seed, uint32_t hyp, uint32_t k) {
-  return (uint32_t)(mix64(seed ^ ((uint64_t)hyp * 0xD1B54A32D192ED03ull) ^ ((uint64_t)k * 0x8CB92BA72F3D8DD7ull)) >> 32);
+// x % c for a divisor fixed per call: the quotient estimate mulhi(x, floor((2^32 - 1) / c)) is at most 2 too small
+struct ModC {
+  uint32_t c, inv;
+};
+FD ModC mod_c_make(uint32_t c) { return ModC{c, 0xffffffffu / c}; }
+FD uint32_t mod_c(uint32_t x, ModC m) {
+  const uint32_t q = (uint32_t)(((uint64_t)x * m.inv) >> 32);
+  uint32_t r = x - q * m.c;
+  if (r >= m.c) r -= m.c;
+  if (r >= m.c) r -= m.c;
+  return r;
 }
-FD bool ransac_subset(uint64_t seed, uint32_t hyp, int count, int m, int* idx) {
-  int got = 0;
-  for (uint32_t k = 0; k < 256 && got < m; k++) {
-    int c = (int)(rng_draw(seed, hyp, k) % (uint32_t)count);
-    bool dup = false;
-    for (int j = 0; j < got; j++) dup |= (idx[j] == c);
-    if (!dup) idx[got++] = c;
+// RANSACPointSetRegistrator::getSubset (ptsetreg.cpp, checkPartialSubsets false): per slot rng.uniform(0, count), redrawn while it
+// repeats an earlier slot; the complete subset is redrawn (one more attempt) while `check` refuses it.  Control flow and draws are
+// wave-uniform: a whole wave may run it redundantly and let `check` spread its work over the lanes.
+template <int MAXM, class Check>
+FD bool cv_get_subset(CvRng& rng, ModC mc, int m, int maxAttempts, int* idx, Check check) {
+#pragma unroll
+  for (int j = 0; j < MAXM; j++) idx[j] = -1;
+  int iters = 0, i = 0;
+  for (; iters < maxAttempts; iters++) {
+    for (i = 0; i < m;) {
+      int idx_i;
+      for (;;) {
+        idx_i = (int)mod_c(cv_rng_next(rng), mc);
+        bool dup = false;
+#pragma unroll
+        for (int j = 0; j < MAXM; j++) dup = dup || (j < i && idx[j] == idx_i);
+        if (!dup) break;
+      }
+#pragma unroll
+      for (int j = 0; j < MAXM; j++)
+        if (j == i) idx[j] = idx_i;  // (static indices: the subset stays in registers)
+      i++;
+    }
+    if (!check(idx)) continue;
+    break;
   }
-  return got == m;
+  return iters < maxAttempts;
 }
 // cv::RANSACUpdateNumIters
 FD int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {

@@ -394,11 +394,14 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
 }
 
 // ------------------------------------------------------------------------------------------------ F-matrix RANSAC
-// cv::findFundamentalMat(FM_RANSAC, 5.0, 0.99) control flow with the counter RNG.  One workgroup of RF_T threads per
-// stream, 64 hypotheses per batch: wave 0 solves the 7-point systems (one per lane, up to 3 models each -> LDS), then ALL
-// waves score the <= 192 models (a wave takes a model, its lanes stride the correspondences, ballot-popcount counts the
-// inliers) and the adaptive stop is replayed sequentially over the batch.  Only the mask is used
-// (lkorb_tracking.cpp:133-158).
+// cv::findFundamentalMat(FM_RANSAC, 5.0, 0.99) (lkorb_tracking.cpp:134-135; fundam.cpp + ptsetreg.cpp): from 15 points on the
+// RANSAC registrator, with 8 .. 14 points the LMedS registrator, both drawing their 7-point subsets from cv::RNG((uint64)-1) in
+// getSubset's order (repeated index redrawn per slot, a subset with a collinear last point redrawn as a whole).  One workgroup of RF_T
+// threads per stream.  The subsets of a batch (16 hypotheses first -- the adaptive stop usually ends the search there -- then 64) are
+// drawn SERIALLY, as the generator demands, by wave 0 running the draw loop wave-uniformly (the collinearity test of a subset is
+// spread over 30 lanes); wave 0 then solves the 7-point systems (one per lane, up to 3 models each -> LDS), ALL waves score the
+// models (a wave takes a model, its lanes stride the correspondences, ballot-popcount counts the inliers) and the adaptive stop is
+// replayed sequentially over the batch.  Only the mask is used (lkorb_tracking.cpp:133-158).
 #ifdef FLVIS_RANSAC_PROF
 #define RPROF(base, i)                                                                                   \
   do {                                                                                                   \
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
   __shared__ double spw[63 * 64];  // 7-point workspaces of the 64 hypothesis lanes (element-major: conflict-free)
   __shared__ int hnm[64], mcnt[64 * 3];
   __shared__ int hcnt[64], hmodel[64];
+  __shared__ int s_sub[64][8];  // the batch's subsets (7 indices each)
   __shared__ double bestF[9];
   __shared__ int ctl[4];  // niters, maxGood, best_iter, best_model
   const float* gm1 = p.m1 + (size_t)s * NMAX * 2;
@@ -443,12 +447,166 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
     ctl[3] = 0;
   }
   __syncthreads();
-  const unsigned long long seed = mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[st.cur]));
   const float thr2 = 25.0f;
   Landmark* to = lm_ptr(p, st.cur, s);
   RPROF(24, 0);
-  if (n > 7) {
-    for (int base = 0; base < ctl[0]; base += 64) {
+  CvRng rng = cv_rng_init();  // RNG rng((uint64)-1) of RANSACPointSetRegistrator::run / LMeDSPointSetRegistrator::run
+  const ModC mc = mod_c_make((uint32_t)(n > 0 ? n : 1));
+  // FMEstimatorCallback::checkSubset = !haveCollinearPoints(m1) && !haveCollinearPoints(m2) (fundam.cpp): the LAST point of the subset
+  // against the 15 pairs of earlier ones, on the Point2f coordinates; lanes 0 .. 29 take one (pair, image) each
+  int* s_chk = s_sub[0];
+  auto fm_check = [&](const int* idx) -> bool {
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) s_chk[j] = idx[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bool bad = false;
+    if (lane < 30) {
+      const int pr = lane < 15 ? lane : lane - 15;
+      int j = 1, k = pr;
+      while (k >= j) {
+        k -= j;
+        j++;
+      }
+      const float* m = lane < 15 ? sm1 : sm2;
+      const int ii = s_chk[6], ij = s_chk[j], ik = s_chk[k];
+      const double dx1 = m[2 * ij] - m[2 * ii], dy1 = m[2 * ij + 1] - m[2 * ii + 1];
+      const double dx2 = m[2 * ik] - m[2 * ii], dy2 = m[2 * ik + 1] - m[2 * ii + 1];
+      bad = fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+    }
+    return __ballot(bad) == 0ull;
+  };
+  // draws the subsets of hypotheses [base, base + B) that lie below the current iteration limit into s_sub (wave 0, uniform);
+  // a failed draw (10000 refused subsets) marks the hypothesis and ends the batch -- the reference loop stops there
+  auto draw_batch = [&](int base, int B, int limit, int max_attempts) {
+    s_sub[lane][7] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < B && base + k < limit; k++) {
+      int idx[7];
+      s_chk = s_sub[k];
+      const bool ok = cv_get_subset<7>(rng, mc, 7, max_attempts, idx, fm_check);
+      if (lane == 0) s_sub[k][7] = ok ? 1 : 0;
+      if (!ok) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  if (n > 7 && n < 15) {
+    // ---- LMeDSPointSetRegistrator::run: max(RANSACUpdateNumIters(0.99, 0.45, 7, 1000), 3) subsets, the model with the smallest
+    // median error wins, the inliers are the points within sigma = 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median) (>= 0.001) of it.
+    // n <= 14: a lane scores its own models (errors, insertion sort, median); thread 0 replays the running minimum in order.
+    __shared__ double s_med[64 * 3];
+    __shared__ double s_lm[2];
+    int niters = ransac_update_num_iters(0.99, 0.45, 7, 1000);
+    niters = niters > 3 ? niters : 3;
+    if (tid == 0) {
+      s_lm[0] = 1.7976931348623157e308;  // minMedian
+      ctl[2] = -1;
+    }
+    __syncthreads();
+    bool stop = false;
+    for (int base = 0; base < niters && !stop; base += 64) {
+      SevenPointMid sp_mid;
+      PolyBracket sp_t;
+      double sp_roots[4];
+      int sp_nr = 0, sp_mode = -1;
+      int nm = -1;
+      double* const xw = spw + lane;
+      if (wv == 0) {
+        draw_batch(base, 64, niters, 1000);
+        const int iter = base + lane;
+        if (iter < niters) {
+          if (s_sub[lane][7]) {
+            double x1[7][2], x2[7][2];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+              const int ik = s_sub[lane][k];
+              x1[k][0] = sm1[2 * ik];
+              x1[k][1] = sm1[2 * ik + 1];
+              x2[k][0] = sm2[2 * ik];
+              x2[k][1] = sm2[2 * ik + 1];
+            }
+            double cc[4];
+            nm = 0;
+            if (seven_point_a<64>(x1, x2, xw, sp_mid, cc)) sp_mode = poly_cubic_prepare(cc, sp_t, sp_roots, sp_nr);
+          } else {
+            nm = -2;
+          }
+        }
+        if (sp_mode == 1) {
+          // (one lane bisects its own intervals here: the LMedS branch is the rare low-feature case, not worth the wave hand-off)
+          bool bis[4] = {false, false, false, false};
+          double mid[4] = {0, 0, 0, 0};
+          poly_bracket_bisect(sp_t, 0, bis[0], mid[0]);
+          poly_bracket_bisect(sp_t, 1, bis[1], mid[1]);
+          poly_bracket_bisect(sp_t, 2, bis[2], mid[2]);
+          sp_nr = poly_bracket_emit(sp_t, bis, mid, sp_roots);
+        }
+        if (sp_mode >= 0) {
+          double F[3][9];
+          nm = seven_point_b(sp_mid, sp_roots, sp_nr, F);
+          for (int m = 0; m < nm; m++) {
+            // `std::sort(errf.ptr<int>(), errf.ptr<int>() + count)`: the float errors ordered through their bit patterns
+            int err[14];
+#pragma unroll
+            for (int i = 0; i < 14; i++)
+              err[i] = i < n ? __float_as_int(f_error(F[m], sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1])) : 0x7fffffff;
+            // (padding sorts last): odd-even transposition network on registers
+#pragma unroll
+            for (int pass = 0; pass < 14; pass++)
+#pragma unroll
+              for (int i = pass & 1; i + 1 < 14; i += 2) {
+                const int a = err[i], b = err[i + 1];
+                err[i] = a < b ? a : b;
+                err[i + 1] = a < b ? b : a;
+              }
+            float e_lo = 0.f, e_hi = 0.f, e_mid = 0.f;
+#pragma unroll
+            for (int i = 0; i < 14; i++) {
+              if (i == n / 2 - 1) e_lo = __int_as_float(err[i]);
+              if (i == n / 2) e_hi = e_mid = __int_as_float(err[i]);
+            }
+            s_med[lane * 3 + m] = (n & 1) ? (double)e_mid : ((double)(float)(e_lo + e_hi)) * 0.5;
+            for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
+          }
+        }
+        hnm[lane] = nm;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        for (int k = 0; k < 64 && base + k < niters; k++) {
+          if (hnm[k] == -2) {  // getSubset failed: `if (iter == 0) return false; break;`
+            stop = true;
+            break;
+          }
+          for (int m = 0; m < hnm[k]; m++)
+            if (s_med[k * 3 + m] < s_lm[0]) {
+              s_lm[0] = s_med[k * 3 + m];
+              ctl[2] = base + k;
+              for (int j = 0; j < 9; j++) bestF[j] = Fm[k * 3 + m][j];
+            }
+        }
+        ctl[3] = stop ? 1 : 0;
+      }
+      __syncthreads();
+      stop = ctl[3] != 0;
+    }
+    if (ctl[2] >= 0) {
+      double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(s_lm[0]);
+      sigma = fmax(sigma, 0.001);
+      const float tl = (float)(sigma * sigma);
+      for (int i = tid; i < n; i += RF_T) {
+        bool in = f_error(bestF, sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1]) <= tl;
+        if (!in) to[i].inlier = 0;  // mask index i applied to to.landmarks[i] (descending order): quirk A1
+      }
+    } else {
+      for (int i = tid; i < n; i += RF_T) to[i].inlier = 0;
+    }
+  } else if (n > 7) {
+    for (int base = 0, B = 16; base < ctl[0]; base += B, B = 64) {
 #ifdef FLVIS_RANSAC_PROF
       if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[24 + 6], 1ull);
 #endif
@@ -462,22 +620,24 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
       int nm = -1;                  // -1: beyond niters, -2: subset impossible (the reference loop stops)
       double* const xw = spw + lane;  // element e of this lane at xw[e * 64]
       if (wv == 0) {
+        draw_batch(base, B, ctl[0], 10000);
         const int iter = base + lane;
-        if (iter < ctl[0]) {
+        if (lane < B && iter < ctl[0]) {
 #ifdef FLVIS_RANSAC_PROF
           if (tid == 0) {
             g_sp_prof = p.counters ? p.counters + 40 : nullptr;
             g_sp_last = (long long)wall_clock64();
           }
 #endif
-          int idx[7];
-          if (ransac_subset(seed, (unsigned)iter, n, 7, idx)) {
+          if (s_sub[lane][7]) {
             double x1[7][2], x2[7][2];
+#pragma unroll
             for (int k = 0; k < 7; k++) {
-              x1[k][0] = sm1[2 * idx[k]];
-              x1[k][1] = sm1[2 * idx[k] + 1];
-              x2[k][0] = sm2[2 * idx[k]];
-              x2[k][1] = sm2[2 * idx[k] + 1];
+              const int ik = s_sub[lane][k];
+              x1[k][0] = sm1[2 * ik];
+              x1[k][1] = sm1[2 * ik + 1];
+              x2[k][0] = sm2[2 * ik];
+              x2[k][1] = sm2[2 * ik + 1];
             }
             double cc[4];
             nm = 0;
@@ -526,7 +686,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
       // score + replay in sub-batches of 16 hypotheses: the adaptive stop usually ends the search within the first few hypotheses
       // (niters drops to ~8 once a model with 90 % inliers is seen), so the later models of the batch are never looked at
       constexpr int SB = 16;
-      for (int sb = 0; sb < 64; sb += SB) {
+      for (int sb = 0; sb < B; sb += SB) {
         if (base + sb >= ctl[0]) break;  // (uniform: ctl[0] was written before the last barrier)
         for (int mi = 3 * sb + wv; mi < 3 * (sb + SB); mi += RF_T / 64) {  // score the models
           const int hyp = mi / 3, m = mi - 3 * hyp;
@@ -608,10 +768,11 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
 }
 
 // ------------------------------------------------------------------------------------------------ PnP RANSAC
-// cv::solvePnPRansac(p3d, p2d, K_rect, 0, r, t, false, 100, 3.0, 0.99, inliers, ITERATIVE|P3P) control flow; hypotheses
-// by Grunert P3P (first 3 sample points, the rest disambiguate), Gauss-Newton refinement on the inliers.
-// cv::solvePnPRansac(p3d, p2d, K_rect, 0, r, t, false, iterations, reprojErr, confidence, inliers, ITERATIVE|P3P) control flow;
-// hypotheses by Grunert P3P (first 3 sample points, the rest disambiguate), Gauss-Newton refinement on the inliers.  The core works on
+// cv::solvePnPRansac(p3d, p2d, K_rect, 0, r, t, false, iterations, reprojErr, confidence, inliers, ITERATIVE|P3P) control flow: the
+// RANSAC registrator of ptsetreg.cpp with 5-point (ITERATIVE: the kernel method is EPNP) or 4-point (P3P) subsets drawn from
+// cv::RNG((uint64)-1) in getSubset's order, serially by wave 0 (16 hypotheses first, then 64 per batch); PnPRansacCallback has no
+// checkSubset.  Hypotheses by Grunert P3P on the first 3 sample points (the rest disambiguate), Gauss-Newton refinement on the
+// inliers (the minimal solver and the final solve are this build's: see DESIGN.md section 2).  The core works on
 // correspondences staged in LDS by the caller (the tracker's kernel gathers a frame's landmarks; the standalone kernel of the loop
 // closing's geometric check loads caller arrays) and is entered by the WHOLE workgroup; only wave 0 returns with the result.
 constexpr int RP_T = 512;
@@ -623,6 +784,7 @@ struct PnpShared {
   int* hcnt;             // [64]
   double (*hpose)[12];   // [64]
   int* ctl;              // [4]
+  int (*sub)[8];         // [64] the batch's subsets (<= 5 indices, [7]: drawn)
   double* bpose;         // [12]
   double* gterms;        // [64 * PNP_GN_ROW]
   double* gn;            // [32]
@@ -658,8 +820,15 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
   __syncthreads();
   const int modelPoints = iterative ? 5 : 4;
   PNP_PROF(0);
+  int(*const s_sub)[8] = sh.sub;
+  CvRng rng = cv_rng_init();  // RANSACPointSetRegistrator::run: RNG rng((uint64)-1)
+  const ModC mc = mod_c_make((uint32_t)(np > 0 ? np : 1));
   if (np >= modelPoints) {
-    for (int base = 0; base < ctl[0]; base += 64) {
+    // exactly model_points correspondences: solvePnPRansac hands them to solvePnP directly -- one hypothesis on the points themselves
+    const int first_limit = np == modelPoints ? 1 : max_iters;
+    if (tid == 0) ctl[0] = first_limit;
+    __syncthreads();
+    for (int base = 0, B = 16; base < ctl[0]; base += B, B = 64) {
       if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[6], 1ull);
       // hypotheses of this batch, one per lane of wave 0: P3P on the first 3 sample points, the rest disambiguate.  The bisections of
       // the quartic's two bracketing levels (its derivative's <= 3 sign-change intervals, then its own <= 4) are handed to waves
@@ -695,9 +864,32 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
         }
       };
       if (wv == 0) {
+        // the batch's subsets, drawn serially (wave-uniform) below the current iteration limit
+        s_sub[lane][7] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < B && base + k < ctl[0]; k++) {
+          int sidx[5];
+          bool ok = true;
+          if (np == modelPoints) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) sidx[j] = j;
+          } else {
+            ok = cv_get_subset<5>(rng, mc, modelPoints, 10000, sidx, [](const int*) { return true; });
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) s_sub[k][j] = sidx[j];
+            s_sub[k][7] = ok ? 1 : 0;
+          }
+          if (!ok) break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int iter = base + lane;
-        if (iter < ctl[0]) {
-          if (ransac_subset(seed, (unsigned)iter, np, modelPoints, idx)) {
+        if (lane < B && iter < ctl[0]) {
+          if (s_sub[lane][7]) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) idx[j] = s_sub[lane][j];
             have = true;
             V3 P[3], f[3];
             for (int k = 0; k < 3; k++) {
@@ -792,7 +984,7 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
       PNP_PROF(1);
       // score + replay in sub-batches of 16 hypotheses (the adaptive stop usually ends the search within the first few)
       constexpr int SB = 16;
-      for (int sb = 0; sb < 64; sb += SB) {
+      for (int sb = 0; sb < B; sb += SB) {
         if (base + sb >= ctl[0]) break;  // (uniform: ctl[0] was written before the last barrier)
         for (int hy = sb + wv; hy < sb + SB; hy += RP_T / 64) {  // score the models: lanes stride the correspondences
           if (hcnt[hy] != -3) continue;
@@ -957,6 +1149,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   __shared__ int hcnt[64];
   __shared__ double hpose[64][12];
   __shared__ int ctl[4];
+  __shared__ int ssub[64][8];
   __shared__ double bpose[12];
   __shared__ double gterms[64 * PNP_GN_ROW];
   __shared__ double gn[32];
@@ -986,8 +1179,8 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   SE3d T;
   int inliers = 0;
   // solvePnPRansac(..., 100, 3.0, 0.99, ...) of LKORBTracking::tracking (lkorb_tracking.cpp:170-177)
-  pnp_ransac_core<kProf>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, bpose, gterms, gn}, np, st.use_guess != 0, load_pose7(st.guess),
-                         p.cam.fx, p.cam.fy, p.cam.cx, p.cam.cy, mix64(p.seeds[s] ^ (unsigned long long)(2 * st.frame_id[cur] + 1)),
+  pnp_ransac_core<kProf>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, ssub, bpose, gterms, gn}, np, st.use_guess != 0, load_pose7(st.guess),
+                         p.cam.fx, p.cam.fy, p.cam.cx, p.cam.cy, 0ull /* no seed: cv::RNG((uint64)-1) per call */,
                          100, 9.0f, 0.99, p.counters ? p.counters + 32 : nullptr, tlast_, T, inliers);
   if (wv != 0) return;
   __syncthreads();
@@ -1018,6 +1211,7 @@ __global__ __launch_bounds__(RP_T) void k_pnp_ransac_sets(const float* __restric
   __shared__ int hcnt[64];
   __shared__ double hpose[64][12];
   __shared__ int ctl[4];
+  __shared__ int ssub[64][8];
   __shared__ double bpose[12];
   __shared__ double gterms[64 * PNP_GN_ROW];
   __shared__ double gn[32];
@@ -1034,7 +1228,7 @@ __global__ __launch_bounds__(RP_T) void k_pnp_ransac_sets(const float* __restric
   SE3d T;
   int inliers = 0;
   long long tl = 0;
-  pnp_ransac_core<false>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, bpose, gterms, gn}, np, iterative != 0,
+  pnp_ransac_core<false>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, ssub, bpose, gterms, gn}, np, iterative != 0,
                          iterative ? load_pose7(guess7 + 7 * b) : se3_identity(), fx, fy, cx, cy, seeds[b], max_iters, t2, conf, nullptr, tl, T,
                          inliers);
   if (wv != 0) return;

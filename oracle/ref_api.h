@@ -56,7 +56,9 @@ void undistort_points(const float* src, int n, const double K[4], const double D
 Vec3 triangulate_dlt(Vec2 pt1, Vec2 pt2, const double P1[12], const double P2[12]);
 Vec3 triangulate_two_view(Vec2 pt1, Vec2 pt2, const SE3& T1, const SE3& T2, double fx, double fy, double cx, double cy);
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
-bool ransac_subset(uint64_t seed, uint32_t hyp, int count, int m, int* idx);
+struct CvRNG;
+bool cv_get_subset(CvRNG& rng, int count, int modelPoints, int maxAttempts, bool (*check)(const int* idx, int m, const void* ctx),
+                   const void* ctx, int* idx);
 int seven_point(const double x1[][2], const double x2[][2], double F[3][9]);
 int find_fundamental_ransac(const float* m1, const float* m2, int n, double thr, double conf, uint64_t seed,
                             uint8_t* mask);

@@ -243,16 +243,50 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) 
   return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)lrint(num / denom);
 }
 
-// draws `m` distinct indices in [0,count) for hypothesis `hyp`; false if it cannot (count too small)
-bool ransac_subset(uint64_t seed, uint32_t hyp, int count, int m, int* idx) {
-  int got = 0;
-  for (uint32_t k = 0; k < 256 && got < m; k++) {
-    int c = (int)(rng_draw(seed, hyp, k) % (uint32_t)count);
-    bool dup = false;
-    for (int j = 0; j < got; j++) dup |= (idx[j] == c);
-    if (!dup) idx[got++] = c;
+// RANSACPointSetRegistrator::getSubset (calib3d/src/ptsetreg.cpp, OpenCV 3.x; checkPartialSubsets is false): per slot an index is
+// drawn with rng.uniform(0, count) and redrawn while it repeats an earlier slot; the complete subset is then offered to the callback's
+// checkSubset and redrawn as a whole (one more attempt) when that refuses it.  `check` may be null (PnPRansacCallback does not override
+// checkSubset: always true).  false after maxAttempts refused subsets.
+bool cv_get_subset(CvRNG& rng, int count, int modelPoints, int maxAttempts, bool (*check)(const int* idx, int m, const void* ctx),
+                   const void* ctx, int* idx) {
+  int iters = 0, i = 0;
+  for (; iters < maxAttempts; iters++) {
+    for (i = 0; i < modelPoints && iters < maxAttempts;) {
+      int idx_i;
+      for (;;) {
+        idx_i = idx[i] = rng.uniform(0, count);
+        int j = 0;
+        for (; j < i; j++)
+          if (idx_i == idx[j]) break;
+        if (j == i) break;
+      }
+      i++;
+    }
+    if (i == modelPoints && check && !check(idx, i, ctx)) continue;
+    break;
   }
-  return got == m;
+  return i == modelPoints && iters < maxAttempts;
+}
+
+// haveCollinearPoints (fundam.cpp): the LAST point of the subset against every pair of earlier ones, on Point2f coordinates
+static bool have_collinear_points(const float* m, const int* idx, int count) {
+  const int i = count - 1;
+  for (int j = 0; j < i; j++) {
+    const double dx1 = m[2 * idx[j]] - m[2 * idx[i]], dy1 = m[2 * idx[j] + 1] - m[2 * idx[i] + 1];
+    for (int k = 0; k < j; k++) {
+      const double dx2 = m[2 * idx[k]] - m[2 * idx[i]], dy2 = m[2 * idx[k] + 1] - m[2 * idx[i] + 1];
+      if (std::fabs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (std::fabs(dx1) + std::fabs(dy1) + std::fabs(dx2) + std::fabs(dy2))) return true;
+    }
+  }
+  return false;
+}
+struct FmCheckCtx {
+  const float *m1, *m2;
+};
+// FMEstimatorCallback::checkSubset
+static bool fm_check_subset(const int* idx, int m, const void* ctx) {
+  const FmCheckCtx* c = (const FmCheckCtx*)ctx;
+  return !have_collinear_points(c->m1, idx, m) && !have_collinear_points(c->m2, idx, m);
 }
 
 // ------------------------------------------------------------------------------------------ 7-point fundamental matrix
@@ -381,29 +415,80 @@ static inline float f_error(const double* F, double x1, double y1, double x2, do
 }
 
 // cv::findFundamentalMat(m1, m2, FM_RANSAC, thr, conf, mask) -> mask only (the reference discards F).  Returns #inliers.
-int find_fundamental_ransac(const float* m1, const float* m2, int n, double thr, double conf, uint64_t seed,
-                            uint8_t* mask) {
+// fundam.cpp: fewer than 7 points: nothing; exactly 7: the 7-point solver alone (all points kept); 8 .. 14 points: the LMedS registrator
+// (`(method & ~3) == FM_RANSAC && npoints >= 15` selects RANSAC); from 15 points on RANSAC with 1000 iterations at most.  `seed` is
+// unused: both registrators draw from their own RNG((uint64)-1).
+static void fm_sample(const float* m1, const float* m2, const int* idx, double x1[7][2], double x2[7][2]) {
+  for (int k = 0; k < 7; k++) {
+    x1[k][0] = m1[2 * idx[k]];
+    x1[k][1] = m1[2 * idx[k] + 1];
+    x2[k][0] = m2[2 * idx[k]];
+    x2[k][1] = m2[2 * idx[k] + 1];
+  }
+}
+
+// LMeDSPointSetRegistrator::run (ptsetreg.cpp): a fixed number of subsets, the model with the smallest median error wins, the inliers
+// are the points within sigma = 2.5 * 1.4826 * (1 + 5 / (count - modelPoints)) * sqrt(median) of it
+static int find_fundamental_lmeds(const float* m1, const float* m2, int n, double conf, uint8_t* mask) {
+  const int modelPoints = 7;
+  CvRNG rng;
+  const FmCheckCtx cc{m1, m2};
+  int niters = ransac_update_num_iters(conf, 0.45, modelPoints, 1000);
+  niters = std::max(niters, 3);
+  double minMedian = DBL_MAX;
+  double best[9] = {0};
+  std::vector<float> err(n);
+  for (int iter = 0; iter < niters; iter++) {
+    int idx[7];
+    if (!cv_get_subset(rng, n, modelPoints, 1000, fm_check_subset, &cc, idx)) {
+      if (iter == 0) return 0;
+      break;
+    }
+    double x1[7][2], x2[7][2], F[3][9];
+    fm_sample(m1, m2, idx, x1, x2);
+    const int nm = seven_point(x1, x2, F);
+    for (int m = 0; m < nm; m++) {
+      for (int i = 0; i < n; i++) err[i] = f_error(F[m], m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]);
+      std::sort((int32_t*)err.data(), (int32_t*)err.data() + n);  // `std::sort(errf.ptr<int>(), ...)`: ordered through the bit patterns
+      const double median = n % 2 != 0 ? (double)err[n / 2] : ((double)(float)(err[n / 2 - 1] + err[n / 2])) * 0.5;
+      if (median < minMedian) {
+        minMedian = median;
+        memcpy(best, F[m], sizeof(best));
+      }
+    }
+  }
+  if (!(minMedian < DBL_MAX)) return 0;
+  double sigma = 2.5 * 1.4826 * (1 + 5. / (n - modelPoints)) * std::sqrt(minMedian);
+  sigma = std::max(sigma, 0.001);
+  const float t = (float)(sigma * sigma);
+  int good = 0;
+  for (int i = 0; i < n; i++) {
+    mask[i] = f_error(best, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]) <= t;
+    good += mask[i];
+  }
+  return good;
+}
+
+int find_fundamental_ransac(const float* m1, const float* m2, int n, double thr, double conf, uint64_t /*seed*/, uint8_t* mask) {
   for (int i = 0; i < n; i++) mask[i] = 0;
   if (n < 7) return 0;
   const int modelPoints = 7;
-  int niters = 1000;
-  const float t = (float)(thr * thr);
-  int maxGood = 0;
-  std::vector<uint8_t> cur(n);
   if (n == 7) {  // OpenCV: exactly 7 points -> no RANSAC, all points kept
     for (int i = 0; i < n; i++) mask[i] = 1;
     return n;
   }
+  if (n < 15) return find_fundamental_lmeds(m1, m2, n, conf, mask);
+  int niters = 1000;
+  const float t = (float)(thr * thr);
+  int maxGood = 0;
+  std::vector<uint8_t> cur(n);
+  CvRNG rng;
+  const FmCheckCtx cc{m1, m2};
   for (int iter = 0; iter < niters; iter++) {
     int idx[7];
-    if (!ransac_subset(seed, (uint32_t)iter, n, modelPoints, idx)) break;
+    if (!cv_get_subset(rng, n, modelPoints, 10000, fm_check_subset, &cc, idx)) break;
     double x1[7][2], x2[7][2];
-    for (int k = 0; k < 7; k++) {
-      x1[k][0] = m1[2 * idx[k]];
-      x1[k][1] = m1[2 * idx[k] + 1];
-      x2[k][0] = m2[2 * idx[k]];
-      x2[k][1] = m2[2 * idx[k] + 1];
-    }
+    fm_sample(m1, m2, idx, x1, x2);
     double F[3][9];
     int nm = seven_point(x1, x2, F);
     for (int m = 0; m < nm; m++) {
@@ -558,7 +643,7 @@ static void pnp_refine(SE3& T, const std::vector<Vec3>& pw, const std::vector<Ve
 // cv::solvePnPRansac(p3d, p2d, K_rect, D=0, r, t, false, iters, reprojErr, conf, inliers, ITERATIVE|P3P).
 // p3d/p2d are the float-cast values (camera_frame.cpp:415-427).  Returns #inliers (0 = no model: T untouched).
 int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, double fy, double cx, double cy,
-                     bool iterative_flag, int iterations, double reproj_err, double conf, uint64_t seed, SE3& T,
+                     bool iterative_flag, int iterations, double reproj_err, double conf, uint64_t /*seed*/, SE3& T,
                      uint8_t* mask) {
   for (int i = 0; i < n; i++) mask[i] = 0;
   const int modelPoints = iterative_flag ? 5 : 4;
@@ -569,9 +654,15 @@ int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, doubl
   Mat3 bestR = mat3_identity();
   Vec3 bestt{0, 0, 0};
   std::vector<uint8_t> cur(n);
+  CvRNG rng;  // RANSACPointSetRegistrator::run: RNG rng((uint64)-1)
+  if (n == modelPoints) niters = 1;  // (solvePnPRansac hands exactly model_points points to solvePnP directly: one hypothesis, no draw)
   for (int iter = 0; iter < niters; iter++) {
     int idx[5];
-    if (!ransac_subset(seed, (uint32_t)iter, n, modelPoints, idx)) break;
+    if (n == modelPoints) {
+      for (int k = 0; k < modelPoints; k++) idx[k] = k;
+    } else if (!cv_get_subset(rng, n, modelPoints, 10000, nullptr, nullptr, idx)) {
+      break;
+    }
     Vec3 P[3], f[3];
     for (int k = 0; k < 3; k++) {
       P[k] = {(double)p3d[3 * idx[k]], (double)p3d[3 * idx[k] + 1], (double)p3d[3 * idx[k] + 2]};
@@ -753,6 +844,15 @@ bool optimize_in_frame(SE3& T_c_w, const Vec3* lm_3d_w, const Vec2* lm_2d, const
 // ------------------------------------------------------------------------------------------ C entry points (ctypes)
 extern "C" {
 int ref_poly_real_roots(const double* a, int deg, double* roots) { return ref::poly_real_roots(a, deg, roots); }
+// the first `nsub` subsets a RANSAC run over `count` points draws (no checkSubset), and the raw generator outputs
+void ref_cv_subsets(int count, int modelPoints, int nsub, int* idx_out) {
+  ref::CvRNG rng;
+  for (int k = 0; k < nsub; k++) ref::cv_get_subset(rng, count, modelPoints, 10000, nullptr, nullptr, idx_out + (size_t)k * modelPoints);
+}
+void ref_cv_rng_outputs(int n, unsigned* out) {
+  ref::CvRNG rng;
+  for (int k = 0; k < n; k++) out[k] = rng.next();
+}
 
 void ref_project_points(const float* p3d, int n, const double* pose7 /*tx ty tz qx qy qz qw*/, const double* K,
                         const double* D, float* out) {

@@ -301,16 +301,17 @@ inline Mat3 rodrigues_to_mat(Vec3 r) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Deterministic counter-based RNG used by both RANSACs (OpenCV's RNG stream cannot be matched).
-// splitmix64 finaliser over (seed, key); the k-th draw of a hypothesis is mix(seed ^ hyp*C1 ^ k*C2).
-inline uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-inline uint32_t rng_draw(uint64_t seed, uint32_t hyp, uint32_t k) {
-  return (uint32_t)(mix64(seed ^ ((uint64_t)hyp * 0xD1B54A32D192ED03ull) ^ ((uint64_t)k * 0x8CB92BA72F3D8DD7ull)) >> 32);
-}
+// cv::RNG (core/operations.hpp): multiply-with-carry, `state = (uint64)(unsigned)state * 4164903690U + (unsigned)(state >> 32)`, output =
+// the low word.  Every RANSAC / LMedS run of OpenCV constructs its own `RNG rng((uint64)-1)` (ptsetreg.cpp), so the sample sequence of a
+// call depends on nothing but the point count.
+struct CvRNG {
+  uint64_t state;
+  explicit CvRNG(uint64_t s = 0xffffffffffffffffull) : state(s ? s : 0xffffffffull) {}
+  uint32_t next() {
+    state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+    return (uint32_t)state;
+  }
+  int uniform(int a, int b) { return a == b ? a : (int)(next() % (uint32_t)(b - a) + a); }
+};
 
 }  // namespace ref

@@ -903,7 +903,7 @@ bool F2FTracking::lk_tracking(CameraFrame& from, CameraFrame& to, const SE3& gue
     m2[2 * k + 1] = tracked_und[2 * surv[k] + 1];
   }
   std::vector<uint8_t> maskF(m);
-  find_fundamental_ransac(m1.data(), m2.data(), m, 5.0, 0.99, mix64(ransac_seed ^ (uint64_t)(2 * to.frame_id)), maskF.data());
+  find_fundamental_ransac(m1.data(), m2.data(), m, 5.0, 0.99, 0, maskF.data());
   for (int i = 0; i < m; i++)
     if (maskF[i] == 0) to.landmarks[i].is_tracking_inlier = false;  // mirrored index (quirk A1)
   int F_inlier_cnt = 0;
@@ -925,7 +925,7 @@ bool F2FTracking::lk_tracking(CameraFrame& from, CameraFrame& to, const SE3& gue
   SE3 T = use_guess ? se3_from_mat(quat_to_mat(guess.q), guess.t) : se3_identity();
   int pnp_inliers = solve_pnp_ransac(p3d.data(), p2d.data(), np, d_camera.cam0_fx, d_camera.cam0_fy, d_camera.cam0_cx,
                                      d_camera.cam0_cy, use_guess, 100, 3.0, 0.99,
-                                     mix64(ransac_seed ^ (uint64_t)(2 * to.frame_id + 1)), T, mask_pnp.data());
+                                     0, T, mask_pnp.data());
   int indexLM = 0;  // CameraFrame::updateLMState
   for (auto& lm : to.landmarks)
     if (lm.has_3d && lm.is_tracking_inlier) {

@@ -94,10 +94,55 @@ def test_fundamental_ransac_rejects_gross_outliers():
     t = np.array([0.3, 0.05, 0.1])
     m2 = G.project(R, t, P, K4) + rng.normal(0, 0.3, (200, 2))
     m2[:25] += rng.uniform(15, 60, (25, 2))
-    n, mask = O.find_fundamental_ransac(uv, m2, seed=3)
-    assert mask[25:].sum() == 175 and mask[:25].sum() <= 2 and n == mask.sum()
-    n2, mask2 = O.find_fundamental_ransac(uv, m2, seed=3)               # deterministic for a given seed
+    n, mask = O.find_fundamental_ransac(uv, m2)
+    # the mask is that of the winning minimal-sample model (seven noisy points): a few borderline inliers may be missed
+    assert mask[25:].sum() >= 160 and mask[:25].sum() <= 2 and n == mask.sum()
+    n2, mask2 = O.find_fundamental_ransac(uv, m2, seed=77)              # cv::RNG((uint64)-1) per call: no seed, always the same draws
     assert n2 == n and np.array_equal(mask, mask2)
+    # 8 .. 14 points: cv::findFundamentalMat switches to the LMedS registrator (fundam.cpp: RANSAC only from 15 points on)
+    sel = np.arange(30, 42)                                              # twelve good pairs
+    n3, mask3 = O.find_fundamental_ransac(uv[sel], m2[sel])
+    # with 8 .. 13 points the median error is that of a point the seven-point model fits exactly (7 > count / 2), sigma bottoms out at
+    # 0.001 and exactly the seven sampled points come back as inliers -- so the reference's "fewer than 10 F-inliers" test fails such
+    # frames; with 14 points the median is a real residual
+    assert n3 == mask3.sum() == 7
+    n5, mask5 = O.find_fundamental_ransac(uv[30:44], m2[30:44])
+    assert 8 <= n5 == mask5.sum() <= 14
+    n4, mask4 = O.find_fundamental_ransac(uv[:7], m2[:7])                # exactly seven points: the solver alone, every point kept
+    assert n4 == 7 and mask4.sum() == 7
+
+
+def test_cv_rng_and_get_subset_restatement():
+    """cv::RNG (multiply-with-carry, state (uint64)-1 per RANSAC run) and RANSACPointSetRegistrator::getSubset's draw order against an
+    independent restatement on Python integers: the raw outputs, and the first subsets for several point counts (a repeated index is
+    redrawn for the same slot)."""
+    import ctypes as C
+
+    def rng_outputs(n):
+        state, out = (1 << 64) - 1, []
+        for _ in range(n):
+            state = ((state & 0xFFFFFFFF) * 4164903690 + (state >> 32)) & ((1 << 64) - 1)
+            out.append(state & 0xFFFFFFFF)
+        return out
+
+    got = np.zeros(64, np.uint32)
+    O.lib().ref_cv_rng_outputs(64, got.ctypes.data_as(C.c_void_p))
+    want = rng_outputs(4096)
+    assert list(got) == want[:64]
+    assert want[0] == ((0xFFFFFFFF * 4164903690 + 0xFFFFFFFF) & 0xFFFFFFFF)
+    for count, m in ((200, 7), (15, 7), (9, 7), (120, 5), (6, 4), (31, 4)):
+        it = iter(want)
+        exp = []
+        for _ in range(40):
+            idx = []
+            while len(idx) < m:
+                c = next(it) % count
+                if c not in idx:
+                    idx.append(c)
+            exp.append(idx)
+        out = np.zeros((40, m), np.int32)
+        O.lib().ref_cv_subsets(count, m, 40, out.ctypes.data_as(C.c_void_p))
+        assert out.tolist() == exp, (count, m)
 
 
 def test_p3p_recovers_pose():
