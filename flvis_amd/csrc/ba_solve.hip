@@ -112,6 +112,7 @@ struct BAShared {
   int hidx_of[BA_WMAX];
   int slot_cnt[BA_WMAX];
   int P, L, E, flag, cnt, W, nitems;
+  int lds_budget;  // dynamic LDS of this launch (Pipe::ba_lds_bytes): sizes the Schur chunk buffers
   int n_trials;  // LM trials (reduced-system solves) of this optimisation: flop accounting of bench.py
   long long t_begin;  // wall_clock64 (100 MHz) at the start of the optimisation
   int NR, LD, off_linv, off_stage;  // reduced system geometry: Hs[NR][LD], Linv, chunk buffers (double offsets)
@@ -332,7 +333,7 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     sh.off_linv = NR * LD;
     sh.off_stage = NR * LD + P * 36;
     // chunk buffers: per item 18 doubles (Z), per landmark 3 doubles (c) + mask word + local item base
-    const int per_buf = (((int)((BA_LDS_BUDGET - BA_SH_BYTES) / 8) - sh.off_stage) / 2) & ~1;
+    const int per_buf = (((int)((sh.lds_budget - BA_SH_BYTES) / 8) - sh.off_stage) / 2) & ~1;
     int CL = 256;
     while (CL > 32 && CL * 4 > per_buf / 4) CL >>= 1;
     int CI = (per_buf - CL * 4) / 18;
@@ -1382,6 +1383,7 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
   const int t = threadIdx.x, lane = t & 63;
   if (t == 0) {
     sh.sc = carve(p.ba_scratch + (size_t)s * p.ba_scratch_stride, L, E, W);
+    sh.lds_budget = p.ba_lds_bytes;
     sh.W = W;
     sh.use_mfma = p.ba_mfma;
     sh.K[0] = p.cam.fx;
@@ -1609,8 +1611,9 @@ __global__ __launch_bounds__(BA_T) void k_ba_worker(Pipe p) {
 }
 
 void launch_ba_worker(hipStream_t st, const Pipe& p) {
-  hipLaunchKernelGGL(k_ba_worker, dim3(p.S), dim3(BA_T), BA_LDS_BUDGET, st, p);
+  hipLaunchKernelGGL(k_ba_worker, dim3(p.S), dim3(BA_T), p.ba_lds_bytes, st, p);
 }
+int ba_lds_budget_max() { return BA_LDS_BUDGET; }
 hipError_t ba_kernels_init() {
   return hipFuncSetAttribute((const void*)k_ba_worker, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
 }

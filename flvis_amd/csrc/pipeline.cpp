@@ -371,7 +371,14 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   p.imu_factor = 0;
   p.imu_sigma_g = 0;
   p.ba_mfma = 0;
-  if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;  // A/B knob, see DESIGN.md section 4
+  if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;
+  // LDS a local-map workgroup claims (FLVIS_BA_LDS_KB, 64 .. 159): whatever it leaves of the CU's 160 KB lets LK / corner-response
+  // waves run on the same CU, whose SIMDs a latency-bound BA workgroup keeps mostly idle
+  p.ba_lds_bytes = ba_lds_budget_max();
+  if (const char* e = getenv("FLVIS_BA_LDS_KB")) {
+    const int kb = atoi(e);
+    if (kb >= 64 && kb * 1024 <= ba_lds_budget_max()) p.ba_lds_bytes = kb * 1024;
+  }  // A/B knob, see DESIGN.md section 4
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
   unsigned long long* seeds = dalloc<unsigned long long>(L->allocs, S);
   ok = ok && seeds;
@@ -1111,6 +1118,25 @@ int flvis_imu_feed_all(flvis_ctx* ctx, const int* h_counts, const double* h_samp
     if (n < 0 || n > samples_per_stream) return ctx->fail(FLVIS_ERR_INVALID_ARG, "imu_feed_all: bad count");
     int rc = flvis_imu_feed_flvis_frame(ctx, s, n, h_samples + (size_t)s * samples_per_stream * 7);
     if (rc) return rc;
+  }
+  return FLVIS_OK;
+}
+
+// The caller's per-frame loop (IMU samples, then the stereo pair) for n_steps frames in ONE call: a driver that feeds frames already
+// resident in HBM -- a replay, bench.py's timed region, one rank of a multi-GPU job -- does not come back to its host language between
+// frames (eight Python interpreters on one host contending for cores are then not on the path).
+int flvis_run_steps(flvis_ctx* ctx, int n_steps, const flvis_step* steps, int with_local_map, double* h_call_ms) {
+  if (!ctx || !ctx->pipe || n_steps < 0 || (n_steps > 0 && !steps)) return FLVIS_ERR_INVALID_ARG;
+  for (int k = 0; k < n_steps; k++) {
+    const flvis_step& f = steps[k];
+    const auto t0 = std::chrono::steady_clock::now();
+    if (f.h_imu_counts) {
+      const int rc = flvis_imu_feed_all(ctx, f.h_imu_counts, f.h_imu_samples, f.imu_samples_per_stream);
+      if (rc != FLVIS_OK) return rc;
+    }
+    const int rc = flvis_image_feed(ctx, f.d_img0, f.d_img1, f.h_times, nullptr, with_local_map);
+    if (rc != FLVIS_OK) return rc;
+    if (h_call_ms) h_call_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   return FLVIS_OK;
 }

@@ -52,6 +52,7 @@ struct Pipe {
   size_t ba_scratch_stride;
   int imu_factor;          // window BA: add the gyro rotation-preintegration edge between consecutive keyframes (off by default)
   double imu_sigma_g;      // its gyro noise density [rad/s/sqrt(Hz)]: information = 1 / (sigma_g^2 dt)
+  int ba_lds_bytes;         // dynamic LDS of a k_ba_worker workgroup: what it leaves of a CU's 160 KB is there for the tracker's waves
   int ba_mfma;              // Schur complement of the window solver on the matrix cores (v_mfma_f64_16x16x4_f64) or as register tiles
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
   // local-map feedback (F2FTracking::correction_feed, dead in the reference's v2)
@@ -63,6 +64,7 @@ struct Pipe {
   CorrectionDev* corr_in;   // [S] correction waiting for the stream's next Tracking frame (valid flag), or nullptr
 };
 
+int ba_lds_budget_max();
 void launch_imu_feed(hipStream_t st, const Pipe& p);
 void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time);
 // cv::solvePnPRansac on caller arrays (one workgroup per correspondence set): the loop closing's geometric check

@@ -297,6 +297,21 @@ int flvis_imu_feed_out(flvis_ctx* ctx, int stream, double t, const double* acc3,
                        double* pos_w_i3, double* vel_w_i3);
 int flvis_get_imu_states(flvis_ctx* ctx, int stream, int cap, double* h_rows11, int* n_out, int* n_dropped);
 
+/* n_steps frames in one call -- the caller's loop `imu_callback ... ; image_input_callback` (vo_tracking.cpp:326-430) for frames whose
+ * images are already in HBM: per step the IMU samples of all streams (h_imu_counts [n_streams], h_imu_samples
+ * [n_streams][imu_samples_per_stream][7] in the FLVIS IMU frame; h_imu_counts NULL: none) and the stereo pair (device pointers as for
+ * flvis_image_feed, h_times [n_streams]).  Equivalent to calling flvis_imu_feed_all + flvis_image_feed n_steps times; h_call_ms (may be
+ * NULL) receives the host milliseconds each step spent enqueuing.  The images of step k must stay untouched as flvis_image_feed says. */
+typedef struct flvis_step {
+  const uint8_t* d_img0;
+  const uint8_t* d_img1;
+  const double* h_times;
+  const int* h_imu_counts;
+  const double* h_imu_samples;
+  int imu_samples_per_stream;
+} flvis_step;
+int flvis_run_steps(flvis_ctx* ctx, int n_steps, const flvis_step* steps, int with_local_map, double* h_call_ms);
+
 /* Optional per-stage timing of flvis_image_feed with HIP events on the context's stream (for bench.py's roofline).
  * flvis_prof_enable(max_steps) arms it for the next max_steps frames; flvis_prof_read sums the elapsed ms per stage. */
 int flvis_prof_enable(flvis_ctx* ctx, int max_steps);

@@ -108,6 +108,18 @@ def test_bench_spawns_two_ranks_and_exchanges_results_on_gloo():
     assert d["ms_per_step"] > 0
 
 
+def test_bench_stub_at_eight_ranks():
+    """BASELINE.json configs[4] has 8 ranks on one node: the spawn / shard / barrier / exchange path at world size 8 (gloo, no GPU work):
+    512 streams in all, global stream ids in order after the all-gather (asserted inside run_stub), one JSON line."""
+    r = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "0", "--stub"], timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["streams_per_gpu"] == 64 and d["config"]["streams_total"] == 512
+    assert d["config"]["frames_exchanged"] == 8 * 64 * 2 and d["config"]["streams_tracking_at_end"] == 512
+
+
 def test_bench_stub_strong_scaling_splits_a_fixed_total():
     r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--stub", "--scaling", "strong", "--total-streams", "16"])
     assert r.returncode == 0, r.stderr.decode()[-2000:]

@@ -176,6 +176,57 @@ def test_frontend_parity_kitti_mode(ctx):
         trk.imu_feed_sensor(0, 0.0, [0, 0, 9.81], [0, 0, 0])
 
 
+def _patch_scene(n_patches, seed=1):
+    rng = np.random.default_rng(seed)
+    xs, ys, Z = rng.uniform(80, 1160, n_patches), rng.uniform(40, 330, n_patches), rng.uniform(6, 20, n_patches)
+    tex = [rng.integers(0, 256, (21, 21)).astype(np.uint8) for _ in range(n_patches)]
+    return xs, ys, Z, tex
+
+
+def _patch_frame(xs, ys, Z, tex, keep, dx, fx=718.856, b=0.12):
+    """rectified stereo pair: textured 21 x 21 patches on gray, patch i at (xs + dx, ys) on the left, shifted by its disparity on the right"""
+    L = np.full((376, 1241), 110, np.uint8)
+    R = L.copy()
+    for i in range(len(xs)):
+        if keep[i]:
+            for img, x in ((L, xs[i] + dx), (R, xs[i] + dx - fx * b / Z[i])):
+                x0, y0 = int(round(x)) - 10, int(round(ys[i])) - 10
+                img[y0:y0 + 21, x0:x0 + 21] = tex[i]
+    return L, R
+
+
+@pytest.mark.parametrize("n_keep", [5, 6, 3])
+def test_frontend_parity_when_the_features_run_out(ctx, n_keep):
+    """A scene of 40 textured patches of which all but a few disappear after three frames: the number of LK survivors falls to
+    8 .. 14, where cv::findFundamentalMat uses its LMedS registrator instead of RANSAC (fundam.cpp; with fewer than 14 points it returns
+    exactly the 7 sampled points as inliers, so the reference's `< 10 F-inliers` test fails the frame), or stays above with very few
+    inliers.  Every frame's state, LK / F / PnP counts, landmark count and pose are those of the oracle."""
+    import flvis_amd
+    import torch
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.KITTI_LIKE_YAML, "kitti_like")
+    trk = flvis_amd.Tracker(ctx, cfg, 1, seed_base=0xF1715)
+    ref = O.Tracker(ocfg, 0xF1715)
+    xs, ys, Z, tex = _patch_scene(40)
+    seen_lmeds = False
+    prev_state = 0
+    for f in range(6):
+        keep = np.ones(40, bool)
+        if f >= 3:
+            keep[n_keep:] = False
+        L, R = _patch_frame(xs, ys, Z, tex, keep, 1.0 * f)
+        got = trk.image_feed(torch.from_numpy(L[None]).cuda(), torch.from_numpy(R[None]).cuda(), [0.1 * f], with_local_map=False)[0]
+        want = ref.image(0.1 * f, L, R)
+        assert got["state"] == want["state"] and got["n_landmarks"] == want["n_landmarks"], (f, got, want)
+        if prev_state == 1:       # the frame ran LKORBTracking::tracking (otherwise the oracle's counters are those of an older frame)
+            assert np.array_equal(got["dbg"], want["dbg"]), (f, got["dbg"], want["dbg"])
+        assert np.array_equal(got["pose7"], want["pose7"]), (f, got["pose7"] - want["pose7"])
+        prev_state = want["state"]
+        seen_lmeds = seen_lmeds or (f >= 3 and 8 <= want["dbg"][0] <= 14 and want["dbg"][1] >= 7)
+    if n_keep == 5:
+        assert seen_lmeds          # (the 12-survivor frame of this scenario: LMedS, exactly 7 inliers)
+
+
 def test_imu_staging_overflow_is_integrated_not_refused(ctx):
     """The reference integrates IMU messages as they arrive, without a limit (vo_tracking.cpp:326-371).  More than IMU_MAX = 64
     samples between two images (an IMU that leads the camera, a dropped image) must be integrated in order, not refused:
