@@ -750,6 +750,19 @@ class Tracker:
         """flvis_set_imu_factor: gyro rotation-preintegration edges between consecutive keyframes in the window BA (off by default)."""
         self.ctx._check(self.lib.flvis_set_imu_factor(self.ctx._h, int(bool(enable)), C.c_double(sigma_gyro)), "set_imu_factor")
 
+    def set_imu_factor_accel(self, sigma_acc):
+        """flvis_set_imu_factor_accel: position rows of the IMU factor (accelerometer noise density; <= 0: rotation rows only)"""
+        self.ctx._check(self.lib.flvis_set_imu_factor_accel(self.ctx._h, C.c_double(sigma_acc)), "set_imu_factor_accel")
+
+    def get_keyframe_imu_pos(self, stream):
+        """flvis_get_keyframe_imu_pos -> (dp, va): displacement preintegrated since the previous keyframe, that keyframe's velocity"""
+        np = self.np
+        dp, va = np.zeros(3), np.zeros(3)
+        r = self.lib.flvis_get_keyframe_imu_pos(self.ctx._h, stream, _P(dp, C.c_double), _P(va, C.c_double))
+        if r < 0:
+            self.ctx._check(r, "get_keyframe_imu_pos")
+        return dp, va
+
     def get_keyframe_imu(self, stream):
         """flvis_get_keyframe_imu -> (valid, dq (w, x, y, z), dt) of the stream's last keyframe"""
         np = self.np
@@ -760,7 +773,7 @@ class Tracker:
             self.ctx._check(r, "get_keyframe_imu")
         return bool(r), dq, dt.value
 
-    def ba_push_keyframe(self, stream, frame_id, pose7, lm_id, lm_2d, lm_3d, cap=8192, imu_dq=None, imu_dt=0.0):
+    def ba_push_keyframe(self, stream, frame_id, pose7, lm_id, lm_2d, lm_3d, cap=8192, imu_dq=None, imu_dt=0.0, imu_dp=None, imu_va=None):
         np = self.np
         p7 = np.ascontiguousarray(pose7, np.float64)
         ids = np.ascontiguousarray(lm_id, np.int64)
@@ -773,7 +786,15 @@ class Tracker:
         o3 = np.zeros((cap, 3))
         oc = C.c_int(0)
         ooid = np.zeros(cap, np.int64)
-        if imu_dq is not None:
+        if imu_dq is not None and imu_dp is not None:
+            dq = np.ascontiguousarray(imu_dq, np.float64)
+            dp, va = np.ascontiguousarray(imu_dp, np.float64), np.ascontiguousarray(imu_va, np.float64)
+            r = self.lib.flvis_ba_push_keyframe_imu_pos(self.ctx._h, stream, C.c_int64(frame_id), _P(p7, C.c_double), _P(dq, C.c_double),
+                                                        C.c_double(imu_dt), _P(dp, C.c_double), _P(va, C.c_double), len(ids),
+                                                        _P(ids, C.c_int64), _P(l2, C.c_double), _P(l3, C.c_double), cap, C.byref(fid),
+                                                        _P(pose, C.c_double), C.byref(cnt), _P(oid_, C.c_int64), _P(o3, C.c_double),
+                                                        C.byref(oc), _P(ooid, C.c_int64))
+        elif imu_dq is not None:
             dq = np.ascontiguousarray(imu_dq, np.float64)
             r = self.lib.flvis_ba_push_keyframe_imu(self.ctx._h, stream, C.c_int64(frame_id), _P(p7, C.c_double), _P(dq, C.c_double),
                                                     C.c_double(imu_dt), len(ids), _P(ids, C.c_int64), _P(l2, C.c_double),

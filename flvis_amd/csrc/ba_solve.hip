@@ -122,7 +122,9 @@ struct BAShared {
   // IMU rotation edges (optional factor): edge k links ring slots imu_a[k] -> imu_b[k]
   int n_imu, imu_a[BA_WMAX], imu_b[BA_WMAX];
   double imu_w[BA_WMAX], imu_dq[BA_WMAX][4], q_c_b[4];
-  double imu_aa[BA_WMAX][9], imu_bb[BA_WMAX][9], imu_ab[BA_WMAX][9], imu_ga[BA_WMAX][3], imu_gb[BA_WMAX][3];
+  // position rows (imu_wp[k] > 0): preintegrated displacement, velocity of keyframe a, interval; t_c_b = body origin in the camera frame
+  double imu_wp[BA_WMAX], imu_dp[BA_WMAX][3], imu_va[BA_WMAX][3], imu_dtk[BA_WMAX], t_c_b[3];
+  double imu_aa[BA_WMAX][36], imu_bb[BA_WMAX][36], imu_ab[BA_WMAX][36], imu_ga[BA_WMAX][6], imu_gb[BA_WMAX][6];
   double imu_chi[BA_WMAX], imu_chit[BA_WMAX];  // w |r|^2 at the accepted / the trial poses
   int wscan[BA_NW];
   int chunk_l0[BA_MAXCHUNK + 1];    // first landmark / first item of every chunk
@@ -717,7 +719,25 @@ FD V3 imu_edge_residual(const double* Ta7, const double* Tb7, Q4 qcb, Q4 dq) {
   if (qr.w < 0) qr = Q4{-qr.w, -qr.x, -qr.y, -qr.z};
   return so3_log(qr);
 }
-// lanes of wave 0, one per edge: linearise at the accepted poses
+// position rows of the factor:
+//   r = R_b(a)^T (p_b(b) - p_b(a) - v_a dt + 1/2 g_w dt^2) - dp,   R_b = R_cw^T R_cb,  p_b = R_cw^T (t_cb - t_cw),  g_w = (0, 0, -9.81)
+// (body attitude and position from the camera pose and the camera-from-body extrinsic; dp, v_a: see KeyFrameDev::imu_dp / imu_va).
+// g2o's update T <- exp((omega, upsilon)) T moves p_b by R_cw^T ([t_cb]x omega - upsilon) and R_b by Exp(-R_cb^T omega) on the right:
+//   dr/d omega_b = R_b(a)^T R_cw(b)^T [t_cb]x          dr/d upsilon_b = -R_b(a)^T R_cw(b)^T
+//   dr/d omega_a = -R_cb^T [t_cb]x - [R_b(a)^T d]x R_cb^T      dr/d upsilon_a = R_cb^T          (d = the bracket of r)
+FD V3 imu_edge_residual_pos(const double* Ta7, const double* Tb7, Q4 qcb, V3 tcb, V3 dp, V3 va, double dt, M3* RbaT_out, V3* d_out) {
+  const SE3d Ta = load_pose7(Ta7), Tb = load_pose7(Tb7);
+  const M3 Rca = q_to_mat(Ta.q), RcaT = transpose(Rca), RcbT = transpose(q_to_mat(Tb.q)), RciT = transpose(q_to_mat(qcb));
+  const V3 pa = RcaT * (tcb - Ta.t), pb = RcbT * (tcb - Tb.t);
+  const V3 gw{0, 0, -9.81};
+  const V3 d = ((pb - pa) - dt * va) + (0.5 * dt * dt) * gw;
+  const M3 RbaT = RciT * Rca;
+  if (RbaT_out) *RbaT_out = RbaT;
+  if (d_out) *d_out = d;
+  return (RbaT * d) - dp;
+}
+// lanes of wave 0, one per edge: linearise at the accepted poses.  Rows 0..2: rotation (weight w), rows 3..5: position (weight wp,
+// present when wp > 0); a rotation-only edge touches the rotation rows / columns of the pose blocks alone
 __device__ __noinline__ void ba_phase_imu_linearize() {
   BAShared& sh = ba_sh();
   const int k = threadIdx.x;
@@ -727,38 +747,81 @@ __device__ __noinline__ void ba_phase_imu_linearize() {
   const Q4 qcb{sh.q_c_b[0], sh.q_c_b[1], sh.q_c_b[2], sh.q_c_b[3]};
   const Q4 dq{sh.imu_dq[k][0], sh.imu_dq[k][1], sh.imu_dq[k][2], sh.imu_dq[k][3]};
   const V3 rv = imu_edge_residual(Ta, Tb, qcb, dq);
-  const double r[3] = {rv.x, rv.y, rv.z};
-  const double w = sh.imu_w[k];
+  const double w = sh.imu_w[k], wp = sh.imu_wp[k];
+  const bool pos = wp > 0;
   const M3 Bt = transpose(q_to_mat(qcb));
   const M3 M = q_to_mat(load_pose7(Ta).q) * transpose(q_to_mat(load_pose7(Tb).q));
   const M3 Ji = so3_jr_inv(rv);
   const M3 A = Ji * (Bt * transpose(M));
-  const M3 Bm = Ji * Bt;  // Jb = -Bm
+  const M3 Bm = Ji * Bt;  // Jb (rotation rows) = -Bm
+  double r[6] = {rv.x, rv.y, rv.z, 0, 0, 0};
+  double Ja[6][6], Jb[6][6];
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) Ja[i][j] = Jb[i][j] = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
+      Ja[i][j] = A.m[i][j];
+      Jb[i][j] = -Bm.m[i][j];
+    }
+  if (pos) {
+    const V3 tcb{sh.t_c_b[0], sh.t_c_b[1], sh.t_c_b[2]};
+    M3 RbaT;
+    V3 d;
+    const V3 rp = imu_edge_residual_pos(Ta, Tb, qcb, tcb, V3{sh.imu_dp[k][0], sh.imu_dp[k][1], sh.imu_dp[k][2]},
+                                        V3{sh.imu_va[k][0], sh.imu_va[k][1], sh.imu_va[k][2]}, sh.imu_dtk[k], &RbaT, &d);
+    r[3] = rp.x, r[4] = rp.y, r[5] = rp.z;
+    const M3 RcbT = transpose(q_to_mat(load_pose7(Tb).q));
+    const M3 Sx = skew(tcb);
+    const M3 RR = RbaT * RcbT;
+    const M3 Job = RR * Sx;
+    const M3 t1 = Bt * Sx, t2 = skew(RbaT * d) * Bt;  // (Bt = R_cb^T)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        Ja[3 + i][j] = (0.0 - t1.m[i][j]) - t2.m[i][j];
+        Ja[3 + i][3 + j] = Bt.m[i][j];
+        Jb[3 + i][j] = Job.m[i][j];
+        Jb[3 + i][3 + j] = 0.0 - RR.m[i][j];
+      }
+  }
+  const int nr = pos ? 6 : 3;
+  const double wr[6] = {w, w, w, wp, wp, wp};
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
       double aa = 0, bb = 0, ab = 0;
 #pragma unroll
-      for (int m = 0; m < 3; m++) {
-        aa += (A.m[m][i] * w) * A.m[m][j];
-        bb += (Bm.m[m][i] * w) * Bm.m[m][j];
-        ab -= (A.m[m][i] * w) * Bm.m[m][j];
+      for (int m = 0; m < 6; m++) {
+        if (m < nr && i < nr && j < nr) {
+          aa += (Ja[m][i] * wr[m]) * Ja[m][j];
+          bb += (Jb[m][i] * wr[m]) * Jb[m][j];
+          ab += (Ja[m][i] * wr[m]) * Jb[m][j];
+        }
       }
-      sh.imu_aa[k][3 * i + j] = aa;
-      sh.imu_bb[k][3 * i + j] = bb;
-      sh.imu_ab[k][3 * i + j] = ab;
+      sh.imu_aa[k][6 * i + j] = aa;
+      sh.imu_bb[k][6 * i + j] = bb;
+      sh.imu_ab[k][6 * i + j] = ab;
     }
     double ga = 0, gb = 0;
 #pragma unroll
-    for (int m = 0; m < 3; m++) {
-      ga += (A.m[m][i] * w) * r[m];
-      gb -= (Bm.m[m][i] * w) * r[m];
+    for (int m = 0; m < 6; m++) {
+      if (m < nr && i < nr) {
+        ga += (Ja[m][i] * wr[m]) * r[m];
+        gb += (Jb[m][i] * wr[m]) * r[m];
+      }
     }
     sh.imu_ga[k][i] = ga;
     sh.imu_gb[k][i] = gb;
   }
-  sh.imu_chi[k] = w * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+  double chi = w * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+  if (pos) chi += wp * ((r[3] * r[3] + r[4] * r[4]) + r[5] * r[5]);
+  sh.imu_chi[k] = chi;
 }
 // one thread per free pose: gather the blocks of its (at most two) edges into Hpp / b, in edge order (call after a barrier)
 __device__ __noinline__ void ba_phase_imu_gather() {
@@ -771,20 +834,21 @@ __device__ __noinline__ void ba_phase_imu_gather() {
     if (!isa && !isb) continue;
     const double* blk = isa ? sh.imu_aa[k] : sh.imu_bb[k];
     const double* g = isa ? sh.imu_ga[k] : sh.imu_gb[k];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-#pragma unroll
-      for (int j = 0; j < 3; j++) sh.Hpp[hi][6 * i + j] += blk[3 * i + j];
+    const int nc = sh.imu_wp[k] > 0 ? 6 : 3;
+    for (int i = 0; i < nc; i++) {
+      for (int j = 0; j < nc; j++) sh.Hpp[hi][6 * i + j] += blk[6 * i + j];
       sh.b[6 * hi + i] -= g[i];
     }
   }
 }
-// off-diagonal pose-pose blocks w Ja^T Jb into the lower triangle of the reduced system (after the Schur phase and a barrier)
+// off-diagonal pose-pose blocks Ja^T W Jb into the lower triangle of the reduced system (after the Schur phase and a barrier)
 __device__ __noinline__ void ba_phase_imu_offdiag() {
   BAShared& sh = ba_sh();
   const int t = threadIdx.x;
-  if (t >= 9 * sh.n_imu) return;
-  const int k = t / 9, e = t - 9 * k, i = e / 3, j = e - 3 * i, LD = sh.LD;
+  if (t >= 36 * sh.n_imu) return;
+  const int k = t / 36, e = t - 36 * k, i = e / 6, j = e - 6 * i, LD = sh.LD;
+  const int nc = sh.imu_wp[k] > 0 ? 6 : 3;
+  if (i >= nc || j >= nc) return;
   const int ia = sh.hidx_of[sh.imu_a[k]], ib = sh.hidx_of[sh.imu_b[k]];
   if (ia < 0 || ib < 0) return;
   double* Hs = ba_dyn();
@@ -801,7 +865,14 @@ FD void ba_phase_imu_trial() {
   const Q4 qcb{sh.q_c_b[0], sh.q_c_b[1], sh.q_c_b[2], sh.q_c_b[3]};
   const Q4 dq{sh.imu_dq[k][0], sh.imu_dq[k][1], sh.imu_dq[k][2], sh.imu_dq[k][3]};
   const V3 r = imu_edge_residual(sh.poseT[sh.imu_a[k]], sh.poseT[sh.imu_b[k]], qcb, dq);
-  sh.imu_chit[k] = sh.imu_w[k] * ((r.x * r.x + r.y * r.y) + r.z * r.z);
+  double chi = sh.imu_w[k] * ((r.x * r.x + r.y * r.y) + r.z * r.z);
+  if (sh.imu_wp[k] > 0) {
+    const V3 rp = imu_edge_residual_pos(sh.poseT[sh.imu_a[k]], sh.poseT[sh.imu_b[k]], qcb, V3{sh.t_c_b[0], sh.t_c_b[1], sh.t_c_b[2]},
+                                        V3{sh.imu_dp[k][0], sh.imu_dp[k][1], sh.imu_dp[k][2]},
+                                        V3{sh.imu_va[k][0], sh.imu_va[k][1], sh.imu_va[k][2]}, sh.imu_dtk[k], nullptr, nullptr);
+    chi += sh.imu_wp[k] * ((rp.x * rp.x + rp.y * rp.y) + rp.z * rp.z);
+  }
+  sh.imu_chit[k] = chi;
 }
 
 // largest diagonal entry of the (unreduced) hessian -> initial lambda (computeLambdaInit); this thread's share
@@ -1401,9 +1472,16 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
         sh.imu_b[ne] = j;
         for (int q = 0; q < 4; q++) sh.imu_dq[ne][q] = w.imu_dq[j][q];
         sh.imu_w[ne] = 1.0 / (p.imu_sigma_g * p.imu_sigma_g * w.imu_dt[j]);
+        sh.imu_wp[ne] = 0.0;
+        if (p.imu_sigma_a > 0) {
+          for (int q = 0; q < 3; q++) sh.imu_dp[ne][q] = w.imu_dp[j][q], sh.imu_va[ne][q] = w.imu_va[j][q];
+          sh.imu_dtk[ne] = w.imu_dt[j];
+          sh.imu_wp[ne] = 1.0 / (p.imu_sigma_a * p.imu_sigma_a * ((w.imu_dt[j] * w.imu_dt[j]) * w.imu_dt[j]) / 3.0);
+        }
         ne++;
       }
       sh.q_c_b[0] = p.cam.T_c_i[6], sh.q_c_b[1] = p.cam.T_c_i[3], sh.q_c_b[2] = p.cam.T_c_i[4], sh.q_c_b[3] = p.cam.T_c_i[5];
+      sh.t_c_b[0] = p.cam.T_c_i[0], sh.t_c_b[1] = p.cam.T_c_i[1], sh.t_c_b[2] = p.cam.T_c_i[2];
     }
     sh.n_imu = ne;
     sh.n_trials = 0;

@@ -190,6 +190,7 @@ __device__ __noinline__ void ba_update_dev(const Pipe& p, int s, const KeyFrameD
       for (int j = 0; j < 4; j++) dst.imu_dq[j] = src.imu_dq[j];
       dst.imu_dt = src.imu_dt;
       dst.imu_valid = src.imu_valid;
+      for (int j = 0; j < 3; j++) dst.imu_dp[j] = src.imu_dp[j], dst.imu_va[j] = src.imu_va[j];
       w.kfs_size++;
       if (p.counters) atomicAdd((unsigned long long*)&p.counters[1], 1ull);
     }
@@ -219,6 +220,7 @@ __device__ __noinline__ void ba_update_dev(const Pipe& p, int s, const KeyFrameD
       for (int j = 0; j < 4; j++) w.imu_dq[tid][j] = kf.imu_dq[j];
       w.imu_dt[tid] = kf.imu_dt;
       w.imu_has[tid] = (tid > 0 && kf.imu_valid) ? 1 : 0;
+      for (int j = 0; j < 3; j++) w.imu_dp[tid][j] = kf.imu_dp[j], w.imu_va[tid][j] = kf.imu_va[j];
     }
     for (int i = tid; i < w.n_lm; i += BU_T)
       for (int j = 0; j < 3; j++) w.lm_est[i][j] = w.lm_p3d[i][j];  // vertex estimate = running mean (quirk A23)
@@ -283,6 +285,7 @@ __device__ __noinline__ void ba_update_dev(const Pipe& p, int s, const KeyFrameD
       for (int j = 0; j < 4; j++) w.imu_dq[w.newest][j] = kn.imu_dq[j];
       w.imu_dt[w.newest] = kn.imu_dt;
       w.imu_has[w.newest] = kn.imu_valid ? 1 : 0;
+      for (int j = 0; j < 3; j++) w.imu_dp[w.newest][j] = kn.imu_dp[j], w.imu_va[w.newest][j] = kn.imu_va[j];
     }
     __syncthreads();
     bag_add_keyframe(w, sid, s_cnt, kn, true, w.newest);

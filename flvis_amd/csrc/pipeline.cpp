@@ -370,6 +370,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   p.ba_scratch_stride = ba_scratch_doubles();
   p.imu_factor = 0;
   p.imu_sigma_g = 0;
+  p.imu_sigma_a = 0;
   p.ba_mfma = 0;
   if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;
   // LDS a local-map workgroup claims (FLVIS_BA_LDS_KB, 64 .. 159): whatever it leaves of the CU's 160 KB lets LK / corner-response
@@ -1497,6 +1498,35 @@ int flvis_set_imu_factor(flvis_ctx* ctx, int enable, double sigma_gyro) {
   return FLVIS_OK;
 }
 
+// Position rows of the factor on top of the rotation rows (flvis_set_imu_factor must be on): sigma_acc = accelerometer noise density
+// [m/s^2/sqrt(Hz)], information I3 / (sigma_acc^2 dt^3 / 3); <= 0 switches the position rows off again.
+int flvis_set_imu_factor_accel(flvis_ctx* ctx, double sigma_acc) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  sync_all(ctx);
+  for (Lane* L : ctx->pipe->lanes) L->pipe.imu_sigma_a = sigma_acc > 0 ? sigma_acc : 0.0;
+  return FLVIS_OK;
+}
+
+// the position part of the last keyframe's preintegration (flvis_get_keyframe_imu gives the rotation part and says whether it links)
+int flvis_get_keyframe_imu_pos(flvis_ctx* ctx, int stream, double* dp3, double* va3) {
+  if (!ctx || !ctx->pipe || !dp3 || !va3) return FLVIS_ERR_INVALID_ARG;
+  Pipeline* pl = ctx->pipe;
+  if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
+  sync_all(ctx);
+  int ls;
+  Lane& L = pl->lane_of(stream, ls);
+  unsigned tl = 0;
+  hipMemcpy(&tl, L.pipe.kfq_tail + ls, sizeof(unsigned), hipMemcpyDeviceToHost);
+  if (tl == 0) return 0;
+  double h[6];
+  static_assert(offsetof(KeyFrameDev, imu_va) == offsetof(KeyFrameDev, imu_dp) + 24, "KeyFrameDev imu position block layout");
+  const char* src = reinterpret_cast<const char*>(L.pipe.kfq + (size_t)ls * KFQ + ((tl - 1) % KFQ)) + offsetof(KeyFrameDev, imu_dp);
+  if (hipMemcpy(h, src, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "get_keyframe_imu_pos");
+  memcpy(dp3, h, 24);
+  memcpy(va3, h + 3, 24);
+  return 1;
+}
+
 int flvis_get_keyframe_imu(flvis_ctx* ctx, int stream, double* dq_wxyz, double* dt) {
   if (!ctx || !ctx->pipe || !dq_wxyz || !dt) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
@@ -1523,7 +1553,8 @@ int flvis_get_keyframe_imu(flvis_ctx* ctx, int stream, double* dq_wxyz, double* 
 
 static int ba_push_impl(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, const double* imu_dq, double imu_dt,
                         int lm_count, const int64_t* h_id, const double* h_2d, const double* h_3d, int cap, int64_t* out_frame_id,
-                        double* out_T7, int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid);
+                        double* out_T7, int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid,
+                        const double* imu_dp = nullptr, const double* imu_va = nullptr);
 
 int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, int lm_count, const int64_t* h_id,
                            const double* h_2d, const double* h_3d, int cap, int64_t* out_frame_id, double* out_T7,
@@ -1539,9 +1570,18 @@ int flvis_ba_push_keyframe_imu(flvis_ctx* ctx, int stream, int64_t frame_id, con
                       out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid);
 }
 
+int flvis_ba_push_keyframe_imu_pos(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, const double* imu_dq_wxyz,
+                                   double imu_dt, const double* imu_dp3, const double* imu_va3, int lm_count, const int64_t* h_id,
+                                   const double* h_2d, const double* h_3d, int cap, int64_t* out_frame_id, double* out_T7,
+                                   int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid) {
+  return ba_push_impl(ctx, stream, frame_id, T7, imu_dq_wxyz, imu_dt, lm_count, h_id, h_2d, h_3d, cap, out_frame_id, out_T7,
+                      out_lm_count, out_lm_id, out_lm_3d, out_oc, out_oid, imu_dp3, imu_va3);
+}
+
 static int ba_push_impl(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T7, const double* imu_dq, double imu_dt,
                         int lm_count, const int64_t* h_id, const double* h_2d, const double* h_3d, int cap, int64_t* out_frame_id,
-                        double* out_T7, int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid) {
+                        double* out_T7, int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_oc, int64_t* out_oid,
+                        const double* imu_dp, const double* imu_va) {
   if (!ctx || !ctx->pipe || !T7 || lm_count < 0 || lm_count > KF_MAXLM) return FLVIS_ERR_INVALID_ARG;
   Pipeline* pl = ctx->pipe;
   if (stream < 0 || stream >= pl->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "bad stream");
@@ -1559,6 +1599,10 @@ static int ba_push_impl(flvis_ctx* ctx, int stream, int64_t frame_id, const doub
     memcpy(kf.imu_dq, imu_dq, 32);
     kf.imu_dt = imu_dt;
     kf.imu_valid = 1;
+    if (imu_dp && imu_va) {
+      memcpy(kf.imu_dp, imu_dp, 24);
+      memcpy(kf.imu_va, imu_va, 24);
+    }
   }
   for (int i = 0; i < lm_count; i++) {
     kf.lm_id[i] = h_id[i];

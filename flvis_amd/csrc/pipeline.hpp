@@ -90,6 +90,9 @@ struct StreamState {
   double dbg_T_pnp[7], dbg_T_lm[7], dbg_T_pre[7];  // pose right after PnP-RANSAC / after the pose LM of the last Tracking frame (tests)
   double kf_dq[4], kf_dt;  // gyro rotation preintegration since the last keyframe (w, x, y, z), see KeyFrameDev::imu_dq
   int feeds;  // image_feed calls seen by this stream (= row of the device-side trajectory the frame is recorded in)
+  // position / velocity preintegration of the bias-corrected accelerometer samples since the last keyframe (body frame of that keyframe)
+  // and the filter's body velocity (world) when that keyframe was made: inputs of the IMU factor's position rows
+  double kf_dp[3], kf_dv[3], kf_va[3];
   long long imu_seen;  // IMU samples integrated so far (= rows ever written to the stream's IMU-state output ring)
 };
 
@@ -111,6 +114,9 @@ struct KeyFrameDev {
   // R_body(previous)^T R_body(this) as integrated from the bias-corrected gyro samples, over imu_dt seconds
   double imu_dq[4], imu_dt;
   int imu_valid, imu_pad;
+  // ... with the position part: dp = preintegrated body displacement over the same interval (body frame of the previous keyframe),
+  // va = the filter's body velocity (world frame) when the previous keyframe was made
+  double imu_dp[3], imu_va[3];
   long long lm_id[KF_MAXLM];
   double lm_2d[KF_MAXLM][2];
   double lm_3d[KF_MAXLM][3];
@@ -150,6 +156,7 @@ struct WindowDev {
   // IMU rotation factor (optional): the preintegration that links ring slot j to its predecessor (j - 1 + W) % W
   double imu_dq[BA_WMAX][4], imu_dt[BA_WMAX];
   int imu_has[BA_WMAX];
+  double imu_dp[BA_WMAX][3], imu_va[BA_WMAX][3];
   // keyframe queue (the `kfs` deque of vo_localmap.cpp:55): ring of the last `window` payloads, storage in Pipe::kfs_ring
   int kfs_head, kfs_size;
   int solve;        // set by the bookkeeping kernel when this keyframe triggers an optimisation

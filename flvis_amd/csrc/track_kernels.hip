@@ -78,10 +78,11 @@ __device__ inline void imu_feed_dev(const Pipe& p, int s) {
     MotionState prev = ring.back();
     Q4 kdq{st.kf_dq[0], st.kf_dq[1], st.kf_dq[2], st.kf_dq[3]};
     double kdt = st.kf_dt;
+    V3 kdp = ld3(st.kf_dp), kdv = ld3(st.kf_dv);
     for (; i < n; i++, seen++) {
       MotionState cur;
       vi_propagate(p.cam, prev, in[7 * i], V3{in[7 * i + 1], in[7 * i + 2], in[7 * i + 3]},
-                   V3{in[7 * i + 4], in[7 * i + 5], in[7 * i + 6]}, acc_bias, gyro_bias, cur, kdq, kdt);
+                   V3{in[7 * i + 4], in[7 * i + 5], in[7 * i + 6]}, acc_bias, gyro_bias, cur, kdq, kdt, kdp, kdv);
       imu_row_store(out + (size_t)(seen % IMU_OUT_CAP) * IMU_ROW, cur.t, ms_q(cur), ld3(cur.pos), ld3(cur.vel));
       ring.base[(head + count) % VI_QUEUE] = cur;  // ViRing::push_back on the local cursor
       count++;
@@ -95,6 +96,8 @@ __device__ inline void imu_feed_dev(const Pipe& p, int s) {
     st.vi_count = count;
     st.kf_dq[0] = kdq.w, st.kf_dq[1] = kdq.x, st.kf_dq[2] = kdq.y, st.kf_dq[3] = kdq.z;
     st.kf_dt = kdt;
+    st3(st.kf_dp, kdp);
+    st3(st.kf_dv, kdv);
   }
   st.imu_seen = seen;
   p.n_imu[s] = 0;
@@ -1881,6 +1884,18 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
       kf.imu_dt = st.kf_dt;
       kf.imu_valid = (s_chain && st.kf_dt > 0) ? 1 : 0;
       kf.imu_pad = 0;
+      // ... and the position part: the displacement preintegrated over the same interval and the filter velocity recorded when the
+      // previous keyframe was made; the velocity at THIS keyframe is kept for the next payload
+      for (int j = 0; j < 3; j++) {
+        kf.imu_dp[j] = st.kf_dp[j];
+        kf.imu_va[j] = st.kf_va[j];
+        st.kf_dp[j] = st.kf_dv[j] = 0.0;
+      }
+      {
+        const bool have = st.has_imu && st.vi_count > 0;
+        const MotionState& mb = p.vi[(size_t)s * VI_QUEUE + (st.vi_head + (st.vi_count > 0 ? st.vi_count - 1 : 0)) % VI_QUEUE];
+        for (int j = 0; j < 3; j++) st.kf_va[j] = have ? mb.vel[j] : 0.0;
+      }
       st.kf_dq[0] = 1.0, st.kf_dq[1] = st.kf_dq[2] = st.kf_dq[3] = 0.0;
       st.kf_dt = 0;
       kf.valid = 1;

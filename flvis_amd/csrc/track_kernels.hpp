@@ -51,6 +51,7 @@ struct Pipe {
   double* ba_scratch;       // [S][ba_scratch_stride]
   size_t ba_scratch_stride;
   int imu_factor;          // window BA: add the gyro rotation-preintegration edge between consecutive keyframes (off by default)
+  double imu_sigma_a;      // accelerometer noise density [m/s^2/sqrt(Hz)] of the factor's position rows (information 1 / (sigma_a^2 dt^3 / 3)); <= 0: rotation rows only
   double imu_sigma_g;      // its gyro noise density [rad/s/sqrt(Hz)]: information = 1 / (sigma_g^2 dt)
   int ba_lds_bytes;         // dynamic LDS of a k_ba_worker workgroup: what it leaves of a CU's 160 KB is there for the tracker's waves
   int ba_mfma;              // Schur complement of the window solver on the matrix cores (v_mfma_f64_16x16x4_f64) or as register tiles

@@ -75,7 +75,7 @@ FD void madgwick_feedback(Q4 q_prev, V3 acc, double acc_norm, double gain, Q4& q
 // VIMOTION::viIMUPropagation (vi_motion.cpp:78-100) on values: the state after one sample from the state before it, plus the gyro
 // rotation preintegration since the last keyframe (an addition, see KeyFrameDev::imu_dq)
 __device__ inline void vi_propagate(const CamParams& cam, const MotionState& s_prev, double t, V3 acc_raw, V3 gyro_raw, V3 acc_bias,
-                                    V3 gyro_bias, MotionState& s_new, Q4& kf_dq, double& kf_dt) {
+                                    V3 gyro_bias, MotionState& s_new, Q4& kf_dq, double& kf_dt, V3& kf_dp, V3& kf_dv) {
   const double g = 9.81;
   const V3 acc = acc_raw - acc_bias, gyro = gyro_raw - gyro_bias;
   const double dt = t - s_prev.t;
@@ -91,6 +91,11 @@ __device__ inline void vi_propagate(const CamParams& cam, const MotionState& s_p
   st3(s_new.acc, acc_raw);
   st3(s_new.gyro, gyro_raw);
   s_new.t = t;
+  {  // position / velocity preintegration in the body frame of the last keyframe (the attitude increment BEFORE this sample's rotation)
+    const V3 a = q_to_mat(kf_dq) * acc;
+    kf_dp = (kf_dp + kf_dv * dt) + a * ((0.5 * dt) * dt);
+    kf_dv = kf_dv + a * dt;
+  }
   kf_dq = q_normalized(q_mul(kf_dq, q_exp(gyro * dt)));
   kf_dt += dt;
 }
@@ -147,9 +152,12 @@ __device__ inline void vi_imu_feed(const CamParams& cam, StreamState& st, const 
     MotionState s_new;
     Q4 kdq{st.kf_dq[0], st.kf_dq[1], st.kf_dq[2], st.kf_dq[3]};
     double kdt = st.kf_dt;
-    vi_propagate(cam, ring.back(), t, acc_raw, gyro_raw, ld3(st.acc_bias), ld3(st.gyro_bias), s_new, kdq, kdt);
+    V3 kdp = ld3(st.kf_dp), kdv = ld3(st.kf_dv);
+    vi_propagate(cam, ring.back(), t, acc_raw, gyro_raw, ld3(st.acc_bias), ld3(st.gyro_bias), s_new, kdq, kdt, kdp, kdv);
     st.kf_dq[0] = kdq.w, st.kf_dq[1] = kdq.x, st.kf_dq[2] = kdq.y, st.kf_dq[3] = kdq.z;
     st.kf_dt = kdt;
+    st3(st.kf_dp, kdp);
+    st3(st.kf_dv, kdv);
     ring.push_back(s_new);
     imu_row_store(row, t, ms_q(s_new), ld3(s_new.pos), ld3(s_new.vel));
   }

@@ -454,6 +454,21 @@ int flvis_ba_push_keyframe(flvis_ctx* ctx, int stream, int64_t frame_id, const d
  *                              the keyframe to its predecessor, 0 otherwise (first keyframe after an initialisation, no IMU)
  *   flvis_ba_push_keyframe_imu flvis_ba_push_keyframe with the preintegration of the pushed keyframe (imu_dt <= 0: none) */
 int flvis_set_imu_factor(flvis_ctx* ctx, int enable, double sigma_gyro);
+/* The factor's position rows (an addition as the rotation rows are; off by default): between consecutive keyframes a -> b
+ *   r_p = R_b(a)^T (p_b(b) - p_b(a) - v_a dt + 1/2 g_w dt^2) - dp,      information I3 / (sigma_acc^2 dt^3 / 3),
+ * with dp = sum (dv dt + 1/2 dR f dt^2), dv = sum dR f dt the position / velocity preintegration of the bias-corrected accelerometer
+ * samples (VIMOTION's convention: world acceleration = R f - g_w, g_w = (0, 0, -9.81)), and v_a the tracker's filter velocity at keyframe a,
+ * a fixed quantity: there is no velocity or bias vertex, the pose blocks stay 6-dimensional.
+ *   flvis_set_imu_factor_accel     sigma_acc > 0 [m/s^2/sqrt(Hz)] adds the rows to every IMU edge (flvis_set_imu_factor must be on); <= 0: off
+ *   flvis_get_keyframe_imu_pos     dp (body frame of the previous keyframe) and v_a (world frame) of the stream's last keyframe; returns 1
+ *   flvis_ba_push_keyframe_imu_pos flvis_ba_push_keyframe_imu with dp / v_a of the pushed keyframe */
+int flvis_set_imu_factor_accel(flvis_ctx* ctx, double sigma_acc);
+int flvis_get_keyframe_imu_pos(flvis_ctx* ctx, int stream, double* dp3, double* va3);
+int flvis_ba_push_keyframe_imu_pos(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T_c_w7, const double* imu_dq_wxyz,
+                                   double imu_dt, const double* imu_dp3, const double* imu_va3, int lm_count, const int64_t* h_lm_id,
+                                   const double* h_lm_2d, const double* h_lm_3d, int out_cap, int64_t* out_frame_id, double* out_T_c_w7,
+                                   int* out_lm_count, int64_t* out_lm_id, double* out_lm_3d, int* out_outlier_count,
+                                   int64_t* out_outlier_id);
 int flvis_get_keyframe_imu(flvis_ctx* ctx, int stream, double* dq_wxyz, double* dt);
 int flvis_ba_push_keyframe_imu(flvis_ctx* ctx, int stream, int64_t frame_id, const double* T_c_w7, const double* imu_dq_wxyz,
                                double imu_dt, int lm_count, const int64_t* h_lm_id, const double* h_lm_2d, const double* h_lm_3d,

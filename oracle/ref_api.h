@@ -88,6 +88,7 @@ struct KeyFrameStruct {
   Quat imu_dq = quat_identity();
   double imu_dt = 0;
   bool imu_valid = false;
+  Vec3 imu_dp{0, 0, 0}, imu_va{0, 0, 0};  // preintegrated displacement (body frame of the previous keyframe), its body velocity (world)
 };
 struct CorrectionInfStruct {
   int64_t frame_id = 0;
@@ -145,9 +146,13 @@ struct BAGraph {
     int a, b;
     Quat dq;
     double w;
+    // position rows (wp > 0): preintegrated body displacement dp in the body frame of a, the body velocity va (world) of a, dt
+    Vec3 dp{0, 0, 0}, va{0, 0, 0};
+    double dt = 0, wp = 0;
   };
   std::vector<ImuEdge> imu_edges;
   Quat q_c_b = quat_identity();  // rotation IMU body -> camera (T_c_i)
+  Vec3 t_c_b{0, 0, 0};           // ... and its translation: the body origin in the camera frame
   double K[4];
   std::vector<PoseV> poses;
   std::map<int64_t, Vec3> lms;
@@ -158,6 +163,8 @@ struct BAGraph {
 };
 
 void imu_edge_linearize(const SE3& Ta, const SE3& Tb, Quat q_c_b, Quat dq, double r[3], double Ja[3][3], double Jb[3][3]);
+void imu_edge_linearize_pos(const SE3& Ta, const SE3& Tb, Quat q_c_b, Vec3 t_c_b, Vec3 dp, Vec3 va, double dt, double r[3], double Ja[3][6],
+                            double Jb[3][6]);
 class LocalMap {
  public:
   enum State { UN_INITIALIZED, SLIDING_WINDOW, OPTIMIZING, FAIL };
@@ -176,7 +183,10 @@ class LocalMap {
   std::vector<Quat> slot_dq;
   std::vector<double> slot_dt;
   std::vector<char> slot_has;
+  std::vector<Vec3> slot_dp, slot_va;
+  double imu_sigma_a = 0;  // accelerometer noise density [m/s^2/sqrt(Hz)]; <= 0: rotation rows only
   void set_imu_factor(bool on, double sigma_g, Quat q_c_b);
+  void set_imu_factor_pos(double sigma_a, Vec3 t_c_b);
   void rebuild_imu_edges();
 };
 

@@ -190,6 +190,43 @@ void imu_edge_linearize(const SE3& Ta, const SE3& Tb, Quat q_c_b, Quat dq, doubl
     }
 }
 
+// Position rows of the IMU factor (an addition like the rotation rows: the reference's window has reprojection edges only).  Body
+// position and attitude from the camera pose and the camera-from-body extrinsic: R_b = R_cw^T R_cb, p_b = R_cw^T (t_cb - t_cw).
+// With the specific-force convention of VIMOTION (world acceleration = R f - g_w, g_w = (0, 0, -9.81); vi_motion.cpp:193-199) the
+// preintegration dp = sum (dv dt + 1/2 dR f dt^2), dv = sum dR f dt over the samples between the keyframes gives
+//   p_b(b) = p_b(a) + v_a dt - 1/2 g_w dt^2 + R_b(a) dp,       r = R_b(a)^T (p_b(b) - p_b(a) - v_a dt + 1/2 g_w dt^2) - dp,
+// v_a = the tracker's filter velocity at keyframe a, a fixed quantity (no velocity vertex: the pose blocks stay 6-dimensional).
+// g2o's update T <- exp((omega, upsilon)) T moves p_b by R_cw^T ([t_cb]x omega - upsilon) and R_b by Exp(-R_cb^T omega) on the right:
+//   dr/d omega_b = R_b(a)^T R_cw(b)^T [t_cb]x          dr/d upsilon_b = -R_b(a)^T R_cw(b)^T
+//   dr/d omega_a = -R_cb^T [t_cb]x - [R_b(a)^T d]x R_cb^T      dr/d upsilon_a = R_cb^T          (d = the bracket above)
+void imu_edge_linearize_pos(const SE3& Ta, const SE3& Tb, Quat q_c_b, Vec3 t_c_b, Vec3 dp, Vec3 va, double dt, double r[3], double Ja[3][6],
+                            double Jb[3][6]) {
+  const Mat3 Rca = quat_to_mat(Ta.q), Rcb = quat_to_mat(Tb.q), Rci = quat_to_mat(q_c_b);
+  const Mat3 RcaT = transpose(Rca), RcbT = transpose(Rcb), RciT = transpose(Rci);
+  const Vec3 pa = RcaT * (t_c_b - Ta.t), pb = RcbT * (t_c_b - Tb.t);
+  const Vec3 gw{0, 0, -9.81};
+  const Vec3 d = ((pb - pa) - dt * va) + (0.5 * dt * dt) * gw;
+  const Mat3 RbaT = RciT * Rca;  // R_b(a)^T = R_cb^T R_cw(a)
+  const Vec3 rv = (RbaT * d) - dp;
+  r[0] = rv.x;
+  r[1] = rv.y;
+  r[2] = rv.z;
+  if (!Ja) return;
+  const Mat3 Sx = skew(t_c_b);
+  const Mat3 Job = (RbaT * RcbT) * Sx;  // omega_b
+  const Mat3 Z = {{{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}};
+  const Mat3 Jub = mat3_add(Z, RbaT * RcbT, -1.0);
+  const Mat3 Joa = mat3_add(mat3_add(Z, RciT * Sx, -1.0), skew(RbaT * d) * RciT, -1.0);
+  const Mat3 Jua = RciT;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      Ja[i][j] = Joa.m[i][j];
+      Ja[i][3 + j] = Jua.m[i][j];
+      Jb[i][j] = Job.m[i][j];
+      Jb[i][3 + j] = Jub.m[i][j];
+    }
+}
+
 // SparseOptimizer::initializeOptimization + optimize(iterations) on the current graph.
 void BAGraph::optimize(int iterations) {
   // active edges in id order; active vertices = those touched by an active edge (all edges are active: landmarks are never fixed)
@@ -224,7 +261,32 @@ void BAGraph::optimize(int iterations) {
     auto it = pose_index.find(slot);
     return (it == pose_index.end() || poses[slot].fixed) ? -1 : it->second;
   };
-  std::vector<double> Hoff((size_t)imu_edges.size() * 9, 0.0);  // w Ja^T Jb of every IMU edge (block (a, b) of Hpp)
+  std::vector<double> Hoff((size_t)imu_edges.size() * 36, 0.0);  // Ja^T W Jb of every IMU edge (6x6 block (a, b) of Hpp)
+  // residual (rotation rows, then position rows; the latter zero without them) and 6 x 6 Jacobians of an IMU edge
+  auto imu_lin = [&](const ImuEdge& e, double r[6], double Ja[6][6], double Jb[6][6]) {
+    double r3[3], A3[3][3], B3[3][3];
+    imu_edge_linearize(poses[e.a].est, poses[e.b].est, q_c_b, e.dq, r3, Ja ? A3 : nullptr, Ja ? B3 : nullptr);
+    for (int i = 0; i < 3; i++) r[i] = r3[i], r[3 + i] = 0;
+    if (Ja)
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) Ja[i][j] = Jb[i][j] = 0;
+    if (Ja)
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Ja[i][j] = A3[i][j], Jb[i][j] = B3[i][j];
+    if (e.wp > 0) {
+      double rp[3], Ap[3][6], Bp[3][6];
+      imu_edge_linearize_pos(poses[e.a].est, poses[e.b].est, q_c_b, t_c_b, e.dp, e.va, e.dt, rp, Ja ? Ap : nullptr, Ja ? Bp : nullptr);
+      for (int i = 0; i < 3; i++) r[3 + i] = rp[i];
+      if (Ja)
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 6; j++) Ja[3 + i][j] = Ap[i][j], Jb[3 + i][j] = Bp[i][j];
+    }
+  };
+  auto imu_chi = [&](const ImuEdge& e, const double r[6]) {
+    double c = e.w * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+    if (e.wp > 0) c += e.wp * ((r[3] * r[3] + r[4] * r[4]) + r[5] * r[5]);
+    return c;
+  };
   auto robustChi2 = [&]() {
     double chi = 0;
     for (int k = 0; k < E; k++) {
@@ -233,9 +295,9 @@ void BAGraph::optimize(int iterations) {
       chi += huber_rho(er[0] * er[0] + er[1] * er[1]);
     }
     for (const ImuEdge& e : imu_edges) {
-      double r[3];
-      imu_edge_linearize(poses[e.a].est, poses[e.b].est, q_c_b, e.dq, r, nullptr, nullptr);
-      chi += e.w * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+      double r[6];
+      imu_lin(e, r, nullptr, nullptr);
+      chi += imu_chi(e, r);
     }
     return chi;
   };
@@ -273,28 +335,30 @@ void BAGraph::optimize(int iterations) {
         }
       }
     }
-    for (size_t k = 0; k < imu_edges.size(); k++) {  // pose-pose edges: rotation rows / columns 0..2 of the 6x6 blocks
+    for (size_t k = 0; k < imu_edges.size(); k++) {  // pose-pose edges: rows 0..2 rotation (weight w), rows 3..5 position (weight wp)
       const ImuEdge& e = imu_edges[k];
-      double r[3], Ja[3][3], Jb[3][3];
-      imu_edge_linearize(poses[e.a].est, poses[e.b].est, q_c_b, e.dq, r, Ja, Jb);
+      double r[6], Ja[6][6], Jb[6][6];
+      imu_lin(e, r, Ja, Jb);
+      const int nrow = e.wp > 0 ? 6 : 3, ncol = e.wp > 0 ? 6 : 3;  // (rotation-only edges touch the rotation rows / columns alone)
+      const double wr[6] = {e.w, e.w, e.w, e.wp, e.wp, e.wp};
       const int ia = hidx(e.a), ib = hidx(e.b);
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) {
+      for (int i = 0; i < ncol; i++)
+        for (int j = 0; j < ncol; j++) {
           double aa = 0, bb = 0, ab = 0;
-          for (int m = 0; m < 3; m++) {
-            aa += (Ja[m][i] * e.w) * Ja[m][j];
-            bb += (Jb[m][i] * e.w) * Jb[m][j];
-            ab += (Ja[m][i] * e.w) * Jb[m][j];
+          for (int m = 0; m < nrow; m++) {
+            aa += (Ja[m][i] * wr[m]) * Ja[m][j];
+            bb += (Jb[m][i] * wr[m]) * Jb[m][j];
+            ab += (Ja[m][i] * wr[m]) * Jb[m][j];
           }
           if (ia >= 0) Hpp[(size_t)ia * 36 + 6 * i + j] += aa;
           if (ib >= 0) Hpp[(size_t)ib * 36 + 6 * i + j] += bb;
-          Hoff[k * 9 + 3 * i + j] = ab;
+          Hoff[k * 36 + 6 * i + j] = ab;
         }
-      for (int i = 0; i < 3; i++) {
+      for (int i = 0; i < ncol; i++) {
         double ga = 0, gb = 0;
-        for (int m = 0; m < 3; m++) {
-          ga += (Ja[m][i] * e.w) * r[m];
-          gb += (Jb[m][i] * e.w) * r[m];
+        for (int m = 0; m < nrow; m++) {
+          ga += (Ja[m][i] * wr[m]) * r[m];
+          gb += (Jb[m][i] * wr[m]) * r[m];
         }
         if (ia >= 0) b[6 * ia + i] -= ga;
         if (ib >= 0) b[6 * ib + i] -= gb;
@@ -327,10 +391,11 @@ void BAGraph::optimize(int iterations) {
       for (size_t k = 0; k < imu_edges.size(); k++) {
         const int ia = hidx(imu_edges[k].a), ib = hidx(imu_edges[k].b);
         if (ia < 0 || ib < 0) continue;
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) {
-            Hs[(size_t)(6 * ia + i) * sizePoses + 6 * ib + j] += Hoff[k * 9 + 3 * i + j];
-            Hs[(size_t)(6 * ib + j) * sizePoses + 6 * ia + i] += Hoff[k * 9 + 3 * i + j];
+        const int nc = imu_edges[k].wp > 0 ? 6 : 3;
+        for (int i = 0; i < nc; i++)
+          for (int j = 0; j < nc; j++) {
+            Hs[(size_t)(6 * ia + i) * sizePoses + 6 * ib + j] += Hoff[k * 36 + 6 * i + j];
+            Hs[(size_t)(6 * ib + j) * sizePoses + 6 * ia + i] += Hoff[k * 36 + 6 * i + j];
           }
       }
       std::vector<Mat3> Dinv(L);
@@ -442,12 +507,20 @@ LocalMap::LocalMap(int window, double fx, double fy, double cx, double cy) : bag
   slot_dq.assign(window, quat_identity());
   slot_dt.assign(window, 0.0);
   slot_has.assign(window, 0);
+  slot_dp.assign(window, Vec3{0, 0, 0});
+  slot_va.assign(window, Vec3{0, 0, 0});
 }
 
 void LocalMap::set_imu_factor(bool on, double sigma_g, Quat q_c_b) {
   imu_factor = on;
   imu_sigma_g = sigma_g;
   graph.q_c_b = q_c_b;
+}
+// position rows on top of the rotation rows: accelerometer noise density sigma_a (information I / (sigma_a^2 dt^3 / 3)), and the
+// translation of the camera-from-body extrinsic
+void LocalMap::set_imu_factor_pos(double sigma_a, Vec3 t_c_b) {
+  imu_sigma_a = sigma_a;
+  graph.t_c_b = t_c_b;
 }
 // the IMU edges of the current window: pose slot j is linked to its chronological predecessor (the previous ring slot) unless j
 // is the oldest pose of the window
@@ -458,7 +531,14 @@ void LocalMap::rebuild_imu_edges() {
   for (int j = 0; j < W; j++) {
     const int i = (j + W - 1) % W;
     if (j == bag.oldest || !slot_has[j] || !(slot_dt[j] > 0) || !graph.poses[i].present || !graph.poses[j].present) continue;
-    graph.imu_edges.push_back({i, j, slot_dq[j], 1.0 / (imu_sigma_g * imu_sigma_g * slot_dt[j])});
+    BAGraph::ImuEdge e{i, j, slot_dq[j], 1.0 / (imu_sigma_g * imu_sigma_g * slot_dt[j])};
+    if (imu_sigma_a > 0) {
+      e.dp = slot_dp[j];
+      e.va = slot_va[j];
+      e.dt = slot_dt[j];
+      e.wp = 1.0 / (imu_sigma_a * imu_sigma_a * ((slot_dt[j] * slot_dt[j]) * slot_dt[j]) / 3.0);
+    }
+    graph.imu_edges.push_back(e);
   }
 }
 
@@ -486,6 +566,8 @@ bool LocalMap::frame_callback(const KeyFrameStruct& kf, CorrectionInfStruct& out
         slot_dq[f] = kfs[f].imu_dq;
         slot_dt[f] = kfs[f].imu_dt;
         slot_has[f] = (f > 0 && kfs[f].imu_valid) ? 1 : 0;
+        slot_dp[f] = kfs[f].imu_dp;
+        slot_va[f] = kfs[f].imu_va;
       }
       int oldest = bag.oldest;
       for (int i = 0; i < window_size; i++) {
@@ -518,6 +600,8 @@ bool LocalMap::frame_callback(const KeyFrameStruct& kf, CorrectionInfStruct& out
       slot_dq[bag.newest] = kfs.back().imu_dq;
       slot_dt[bag.newest] = kfs.back().imu_dt;
       slot_has[bag.newest] = kfs.back().imu_valid ? 1 : 0;
+      slot_dp[bag.newest] = kfs.back().imu_dp;
+      slot_va[bag.newest] = kfs.back().imu_va;
       graph.poses[bag.oldest].fixed = true;
       for (int i = 0; i < kfs.back().lm_count; i++)
         if (bag.addLMObservationSlidingWindow(kfs.back().lm_id[i], kfs.back().lm_3d[i]))
@@ -583,9 +667,32 @@ void ref_localmap_destroy(void* h) { delete (ref::LocalMap*)h; }
 void ref_localmap_set_imu_factor(void* h, int on, double sigma_g, const double* q_c_b_wxyz) {
   ((ref::LocalMap*)h)->set_imu_factor(on != 0, sigma_g, ref::Quat{q_c_b_wxyz[0], q_c_b_wxyz[1], q_c_b_wxyz[2], q_c_b_wxyz[3]});
 }
+void ref_localmap_set_imu_factor_pos(void* h, double sigma_a, const double* t_c_b3) {
+  ((ref::LocalMap*)h)->set_imu_factor_pos(sigma_a, ref::Vec3{t_c_b3[0], t_c_b3[1], t_c_b3[2]});
+}
 static ref::Quat g_next_imu_dq = ref::quat_identity();
 static double g_next_imu_dt = 0;
 static bool g_next_imu_valid = false;
+static ref::Vec3 g_next_imu_dp{0, 0, 0}, g_next_imu_va{0, 0, 0};
+// the position preintegration that comes with the NEXT ref_localmap_push (after ref_localmap_next_imu): dp in the body frame of the
+// previous keyframe, va = that keyframe's body velocity in the world frame
+void ref_localmap_next_imu_pos(const double* dp3, const double* va3) {
+  g_next_imu_dp = ref::Vec3{dp3[0], dp3[1], dp3[2]};
+  g_next_imu_va = ref::Vec3{va3[0], va3[1], va3[2]};
+}
+// residual and Jacobians (3 x 6 each) of the position rows of one IMU edge (tests: central differences)
+void ref_imu_edge_linearize_pos(const double* Ta7, const double* Tb7, const double* q_c_b_wxyz, const double* t_c_b3, const double* dp3,
+                                const double* va3, double dt, double* r3, double* Ja18, double* Jb18) {
+  auto se3 = [](const double* p) { return ref::SE3{{p[6], p[3], p[4], p[5]}, {p[0], p[1], p[2]}}; };
+  double Ja[3][6], Jb[3][6];
+  ref::imu_edge_linearize_pos(se3(Ta7), se3(Tb7), ref::Quat{q_c_b_wxyz[0], q_c_b_wxyz[1], q_c_b_wxyz[2], q_c_b_wxyz[3]},
+                              ref::Vec3{t_c_b3[0], t_c_b3[1], t_c_b3[2]}, ref::Vec3{dp3[0], dp3[1], dp3[2]},
+                              ref::Vec3{va3[0], va3[1], va3[2]}, dt, r3, Ja, Jb);
+  for (int i = 0; i < 18; i++) {
+    Ja18[i] = Ja[i / 6][i % 6];
+    Jb18[i] = Jb[i / 6][i % 6];
+  }
+}
 // the gyro preintegration that comes with the NEXT ref_localmap_push: dq (w, x, y, z) = R_b(previous keyframe)^T R_b(this), dt
 void ref_localmap_next_imu(const double* dq_wxyz, double dt) {
   g_next_imu_dq = ref::Quat{dq_wxyz[0], dq_wxyz[1], dq_wxyz[2], dq_wxyz[3]};
@@ -622,7 +729,10 @@ int ref_localmap_push(void* h, int64_t frame_id, const double* pose7, int n, con
     kf.imu_dq = g_next_imu_dq;
     kf.imu_dt = g_next_imu_dt;
     kf.imu_valid = true;
+    kf.imu_dp = g_next_imu_dp;
+    kf.imu_va = g_next_imu_va;
     g_next_imu_valid = false;
+    g_next_imu_dp = g_next_imu_va = ref::Vec3{0, 0, 0};
   }
   kf.frame_id = frame_id;
   kf.lm_count = n;

@@ -510,6 +510,11 @@ void VIMOTION::viIMUPropagation(const IMUSTATE& imu, Quat& q_w_i, Vec3& pos, Vec
   s_new.pos = s_prev.pos + s_prev.vel * dt;
   s_new.vel = s_prev.vel + ((R_prev * acc) - gravity) * dt;
   s_new.imu_data = imu;
+  {
+    const Vec3 a = quat_to_mat(kf_dq) * acc;  // (the attitude increment BEFORE this sample's rotation)
+    kf_dp = (kf_dp + kf_dv * dt) + a * ((0.5 * dt) * dt);
+    kf_dv = kf_dv + a * dt;
+  }
   kf_dq = quat_normalized(quat_mul(kf_dq, quat_exp(gyro * dt)));
   kf_dt += dt;
   states.push_back(s_new);
@@ -1156,9 +1161,13 @@ void F2FTracking::image_feed(double time, const uint8_t* img0_in, const uint8_t*
     kf_imu_dq = vimotion ? vimotion->kf_dq : quat_identity();
     kf_imu_dt = vimotion ? vimotion->kf_dt : 0.0;
     kf_imu_valid = chained && kf_imu_dt > 0;
+    kf_imu_dp = vimotion ? vimotion->kf_dp : Vec3{0, 0, 0};
+    kf_imu_va = kf_va_next;
     if (vimotion) {
       vimotion->kf_dq = quat_identity();
       vimotion->kf_dt = 0;
+      vimotion->kf_dp = vimotion->kf_dv = Vec3{0, 0, 0};
+      kf_va_next = vimotion->states.empty() ? Vec3{0, 0, 0} : vimotion->states.back().vel;
     }
   }
 }
@@ -1182,6 +1191,8 @@ void F2FTracking::getKeyFrameInf(KeyFrameStruct& kf) const {
   kf.imu_dq = kf_imu_dq;
   kf.imu_dt = kf_imu_dt;
   kf.imu_valid = kf_imu_valid;
+  kf.imu_dp = kf_imu_dp;
+  kf.imu_va = kf_imu_va;
 }
 
 }  // namespace ref
@@ -1271,6 +1282,12 @@ int ref_tracker_keyframe_imu(void* h, double* dq_wxyz, double* dt) {
   dq_wxyz[0] = f->kf_imu_dq.w, dq_wxyz[1] = f->kf_imu_dq.x, dq_wxyz[2] = f->kf_imu_dq.y, dq_wxyz[3] = f->kf_imu_dq.z;
   *dt = f->kf_imu_dt;
   return f->kf_imu_valid ? 1 : 0;
+}
+// ... and the position part: dp (body frame of the previous keyframe) and that keyframe's body velocity (world)
+void ref_tracker_keyframe_imu_pos(void* h, double* dp3, double* va3) {
+  ref::F2FTracking* f = (ref::F2FTracking*)h;
+  dp3[0] = f->kf_imu_dp.x, dp3[1] = f->kf_imu_dp.y, dp3[2] = f->kf_imu_dp.z;
+  va3[0] = f->kf_imu_va.x, va3[1] = f->kf_imu_va.y, va3[2] = f->kf_imu_va.z;
 }
 // F2FTracking::correction_feed (f2f_tracking.cpp:40-44) with the CorrectionInf fields flattened
 void ref_tracker_correction_feed(void* h, int64_t frame_id, const double* pose7, int lm_count, const int64_t* lm_id,

@@ -104,6 +104,9 @@ class VIMOTION {  // src/processing/vi_motion.cpp
   // gyro rotation preintegration since the last keyframe (not in the reference: input of the optional IMU factor of the window BA)
   Quat kf_dq = quat_identity();
   double kf_dt = 0;
+  // ... and the position / velocity preintegration of the bias-corrected accelerometer samples in the body frame of that keyframe:
+  // dp += dv dt + 1/2 (dR f) dt^2, dv += (dR f) dt (before dR advances); input of the factor's position rows
+  Vec3 kf_dp{0, 0, 0}, kf_dv{0, 0, 0};
 };
 
 enum TRACKINGSTATE { UnInit, Tracking, TrackingFail };
@@ -118,6 +121,9 @@ class F2FTracking {  // src/frontend/f2f_tracking.cpp
   Quat kf_imu_dq = quat_identity();  // preintegrated body rotation between the previous keyframe and the last published one
   double kf_imu_dt = 0;
   bool kf_imu_valid = false;
+  Vec3 kf_imu_dp{0, 0, 0};   // preintegrated body displacement over the same interval (body frame of the previous keyframe)
+  Vec3 kf_imu_va{0, 0, 0};   // the filter's body velocity (world) when the previous keyframe was made
+  Vec3 kf_va_next{0, 0, 0};  // ... when the last one was made (becomes kf_imu_va of the next keyframe)
   // local-map feedback (f2f_tracking.cpp:40-44): dead in v2 (vo_tracking.cpp:373-385 unpacks the message and drops it);
   // restated for the SURVEY 8f-2 row, applied at the next Tracking frame (f2f_tracking.cpp:189-219)
   void correction_feed(const CorrectionInfStruct& corr);

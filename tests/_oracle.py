@@ -221,6 +221,15 @@ class LocalMap:
         q = np.ascontiguousarray(q_c_b_wxyz, np.float64)
         lib().ref_localmap_set_imu_factor(self.h, int(bool(on)), C.c_double(sigma_g), _p(q, C.c_double))
 
+    def set_imu_factor_pos(self, sigma_a, t_c_b):
+        t = np.ascontiguousarray(t_c_b, np.float64)
+        lib().ref_localmap_set_imu_factor_pos(self.h, C.c_double(sigma_a), _p(t, C.c_double))
+
+    def next_imu_pos(self, dp, va):
+        """the position preintegration that comes with the NEXT pushed keyframe (after next_imu)"""
+        a, b = np.ascontiguousarray(dp, np.float64), np.ascontiguousarray(va, np.float64)
+        lib().ref_localmap_next_imu_pos(_p(a, C.c_double), _p(b, C.c_double))
+
     def next_imu(self, dq_wxyz, dt):
         """the gyro preintegration that comes with the NEXT pushed keyframe"""
         q = np.ascontiguousarray(dq_wxyz, np.float64)
@@ -333,6 +342,12 @@ class Tracker:
         dt = C.c_double(0)
         v = lib().ref_tracker_keyframe_imu(self.h, _p(dq, C.c_double), C.byref(dt))
         return bool(v), dq, dt.value
+
+    def keyframe_imu_pos(self):
+        """(dp, va): the position preintegration attached to the last keyframe and the previous keyframe's filter velocity"""
+        dp, va = np.zeros(3), np.zeros(3)
+        lib().ref_tracker_keyframe_imu_pos(self.h, _p(dp, C.c_double), _p(va, C.c_double))
+        return dp, va
 
     def correction_feed(self, frame_id, pose7, lm_id, lm_3d, outlier_id):
         """F2FTracking::correction_feed (dead in v2; SURVEY 8f-2)."""

@@ -109,6 +109,9 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
                 gv, gdq, gdt = trk.get_keyframe_imu(i)             # gyro preintegration since the previous keyframe
                 wv, wdq, wdt = refs[i].keyframe_imu()
                 assert gv == wv and gdt == wdt and np.array_equal(gdq, wdq), (where, gdq - wdq, gdt - wdt)
+                gdp, gva = trk.get_keyframe_imu_pos(i)            # ... and the position part (displacement, previous keyframe's velocity)
+                wdp, wva = refs[i].keyframe_imu_pos()
+                assert np.array_equal(gdp, wdp) and np.array_equal(gva, wva), (where, gdp - wdp, gva - wva)
                 n_imu_links += int(wv)
     assert n_kf >= min_kf
     assert (n_imu_rows >= 9 * S * (nframes - 1)) if imu else (n_imu_rows == 0)
@@ -517,6 +520,80 @@ def test_local_map_parity_with_imu_factor(ctx):
         assert produced == len(seq["kfs"]) - cfg.window_size + 1
         if stream == 0:
             assert moved > 1e-4          # the edges do change the solution (the parity above is not vacuous)
+
+
+def test_local_map_parity_with_the_full_imu_factor(ctx):
+    """The window BA with rotation AND position rows (flvis_set_imu_factor + flvis_set_imu_factor_accel, flvis_ba_push_keyframe_imu_pos)
+    against the oracle's BAGraph with the same 6-row edges: every keyframe comes with the true relative body rotation and the true
+    preintegrated displacement (+ noise), for an extrinsic with a lever arm (the D435i's T_imu_cam0)."""
+    import flvis_amd
+    import _geom as G
+    cfg, _ = _cfgs()
+    K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
+    T_i_c = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)
+    Rcb = T_i_c[:3, :3].T                                        # camera <- body
+    tcb = -Rcb @ T_i_c[:3, 3]
+    gw = np.array([0.0, 0.0, -9.81])
+    sigma_g, sigma_a = 0.004, 0.08
+    trk = flvis_amd.Tracker(ctx, cfg, 2, seed_base=1)
+    trk.set_imu_factor(True, sigma_g)
+    trk.set_imu_factor_accel(sigma_a)
+    rot_only = {}
+    for stream, seed in ((0, 21), (1, 22)):
+        seq = B.make_sequence(seed, n_kf=14, n_lm=260, outlier_frac=0.03)
+        rng = np.random.default_rng(seed)
+        ref = O.LocalMap(cfg.window_size, K4)
+        ref.set_imu_factor(True, sigma_g, _quat_wxyz(Rcb))
+        ref.set_imu_factor_pos(sigma_a, tcb)
+
+        def body(k):
+            R, t = seq["gt"][k]
+            return R.T @ Rcb, R.T @ (tcb - t)
+        produced = 0
+        for k, kf in enumerate(seq["kfs"]):
+            dq, dt, dp, va = None, 0.0, None, None
+            if k > 0:
+                Rwa, pa = body(k - 1)
+                Rwb, pb = body(k)
+                dt = 0.1 + 0.02 * (k % 3)
+                dq = _quat_wxyz(Rwa.T @ Rwb @ G.rodrigues(rng.normal(0, 1e-3, 3)))
+                va = (pb - pa) / dt + rng.normal(0, 0.05, 3)
+                dp = Rwa.T @ (pb - pa - va * dt + 0.5 * gw * dt * dt) + rng.normal(0, 2e-3, 3)
+                ref.next_imu(dq, dt)
+                ref.next_imu_pos(dp, va)
+            want = ref.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
+            got = trk.ba_push_keyframe(stream, kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"], imu_dq=dq, imu_dt=dt,
+                                       imu_dp=dp, imu_va=va)
+            assert (want is None) == (got is None), k
+            if want is None:
+                continue
+            produced += 1
+            assert got["frame_id"] == want["frame_id"] and np.array_equal(got["lm_id"], want["lm_id"]), k
+            assert np.array_equal(got["outlier_id"], want["outlier_id"]), k
+            assert np.allclose(got["pose7"], want["pose7"], atol=1e-6, rtol=0), (k, got["pose7"] - want["pose7"])
+            assert np.allclose(got["lm_3d"], want["lm_3d"], atol=1e-6, rtol=0), (k, np.abs(got["lm_3d"] - want["lm_3d"]).max())
+            rot_only[(stream, k)] = got["pose7"]
+        assert produced == len(seq["kfs"]) - cfg.window_size + 1
+    # the position rows do change the solution: the same keyframes with the rotation rows alone end elsewhere
+    trk.set_imu_factor_accel(0.0)
+    del trk
+    trk2 = flvis_amd.Tracker(ctx, cfg, 1, seed_base=1)
+    trk2.set_imu_factor(True, sigma_g)
+    seq = B.make_sequence(21, n_kf=14, n_lm=260, outlier_frac=0.03)
+    rng = np.random.default_rng(21)
+    moved = 0.0
+    for k, kf in enumerate(seq["kfs"]):
+        dq, dt = None, 0.0
+        if k > 0:
+            R0, t0 = seq["gt"][k - 1]
+            R1, t1 = seq["gt"][k]
+            dt = 0.1 + 0.02 * (k % 3)
+            dq = _quat_wxyz((R0.T @ Rcb).T @ (R1.T @ Rcb) @ G.rodrigues(rng.normal(0, 1e-3, 3)))
+            rng.normal(0, 0.05, 3), rng.normal(0, 2e-3, 3)        # (the draws of the run above)
+        got = trk2.ba_push_keyframe(0, kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"], imu_dq=dq, imu_dt=dt)
+        if got is not None:
+            moved = max(moved, np.abs(got["pose7"] - rot_only[(0, k)]).max())
+    assert moved > 1e-5
 
 
 def test_local_map_parity(ctx):
