@@ -518,6 +518,7 @@ class LoopCloser:
     def __init__(self, ctx, cfg, prm, n_streams=1, max_keyframes=2000, orb_pattern=None):
         import numpy as np
         self._ctx, self._lib, self.n_streams = ctx, ctx._lib, n_streams
+        self.cfg, self.max_keyframes = cfg, int(max_keyframes)
         if isinstance(prm, dict):
             prm = LcParams(**prm)
         pat = None
@@ -550,7 +551,11 @@ class LoopCloser:
         T = np.ascontiguousarray(T_c_w_odom, np.float64).reshape(n, 7)
         img0 = img0.contiguous()
         img1 = img1.contiguous() if img1 is not None else None
-        assert img0.shape[0] == n
+        hw = (int(self.cfg.image_height), int(self.cfg.image_width))
+        assert img0.shape[0] == n and tuple(img0.shape[1:]) == hw, "img0 must be [n, image_height, image_width]"
+        if img1 is not None:                                 # a wrong-size tensor would be read out of bounds on the device
+            assert img1.shape[0] == n and tuple(img1.shape[1:]) == hw, "img1 must be [n, image_height, image_width]"
+            assert img1.element_size() == (2 if self.cfg.cam_type == 2 else 1), "img1: uint8 (stereo) or 16-bit depth (depth rig)"
         ids = np.zeros(n, np.int64)
         self._ctx._check(self._lib.flvis_loop_closer_add_keyframes(self._h, n, _P(st, C.c_int), _ptr(img0), _ptr(img1), _P(T, C.c_double),
                                                                    _P(ids, C.c_int64)), "loop_closer_add_keyframes")
@@ -584,11 +589,14 @@ class LoopCloser:
                      n_inliers=e.n_inliers, accepted=bool(e.loop_accepted), optimised=bool(e.optimised), pgo_iterations=e.pgo_iterations,
                      pose=[float(x) for x in e.loop_pose7], chi2_before=e.chi2_before, chi2_after=e.chi2_after) for e in ev]
 
-    def poses(self, stream=0, cap=1 << 16):
+    def poses(self, stream=0, cap=None):
         import numpy as np
+        cap = int(cap) if cap else self.max_keyframes      # (never fewer rows than the sequence can hold: no silent truncation)
         n = C.c_int(0)
         buf = np.zeros((cap, 7))
         self._ctx._check(self._lib.flvis_loop_closer_poses(self._h, int(stream), _P(buf, C.c_double), cap, C.byref(n)), "loop_closer_poses")
+        if n.value > cap:
+            raise FlvisError("loop_closer_poses: %d keyframes, buffer of %d" % (n.value, cap))
         return buf[:n.value].copy()
 
     def keyframe(self, stream, kf, cap=1024):
@@ -609,12 +617,15 @@ class LoopCloser:
         self._ctx._check(self._lib.flvis_loop_closer_drift(self._h, int(stream), _P(T, C.c_double)), "loop_closer_drift")
         return T
 
-    def similarity_row(self, stream=0, cap=1 << 16):
+    def similarity_row(self, stream=0, cap=None):
         import numpy as np
+        cap = int(cap) if cap else self.max_keyframes
         n = C.c_int(0)
         buf = np.zeros(cap)
         self._ctx._check(self._lib.flvis_loop_closer_similarity_row(self._h, int(stream), _P(buf, C.c_double), cap, C.byref(n)),
                          "loop_closer_similarity_row")
+        if n.value > cap:
+            raise FlvisError("loop_closer_similarity_row: %d entries, buffer of %d" % (n.value, cap))
         return buf[:n.value].copy()
 
 

@@ -310,8 +310,17 @@ int flvis_loop_closer_add_keyframes_host(flvis_loop_closer* lc, int n, const int
                                          const double* h_T_c_w_odom7, int64_t* h_kf_id) {
   if (!lc) return FLVIS_ERR_INVALID_ARG;
   flvis_ctx* ctx = lc->ctx;
-  if (n <= 0 || n > lc->S || !h_img0 || !h_img1) return ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_add_keyframes_host: bad args");
+  if (n <= 0 || n > lc->S || !h_img0 || !h_img1 || !h_stream || !h_T_c_w_odom7)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_add_keyframes_host: bad args");
   const int bpp1 = lc->cfg.cam_type == 2 ? 2 : 1;
+  // every argument is checked BEFORE a copy is queued: the caller may free its images as soon as this call returns with an error
+  for (int i = 0; i < n; i++) {
+    const flvis_image &a = h_img0[i], &b = h_img1[i];
+    if (h_stream[i] < 0 || h_stream[i] >= lc->S) return ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_add_keyframes_host: bad stream index");
+    if (!a.data || !b.data || a.width != lc->w || a.height != lc->h || b.width != lc->w || b.height != lc->h || a.channels != 1 || b.channels != 1 ||
+        a.pitch < lc->w || b.pitch < lc->w * bpp1)
+      return ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_add_keyframes_host: images must be mono8 (img1: 16UC1 on a depth rig) of the configured size");
+  }
   const size_t px = (size_t)lc->w * lc->h;
   hipSetDevice(ctx->device);
   uint8_t* d0 = (uint8_t*)ctx->scratch("lc_host_img0", px * (size_t)lc->S);
@@ -320,16 +329,18 @@ int flvis_loop_closer_add_keyframes_host(flvis_loop_closer* lc, int n, const int
   hipError_t e = hipSuccess;
   for (int i = 0; i < n && e == hipSuccess; i++) {
     const flvis_image &a = h_img0[i], &b = h_img1[i];
-    if (!a.data || !b.data || a.width != lc->w || a.height != lc->h || b.width != lc->w || b.height != lc->h || a.channels != 1 || b.channels != 1 ||
-        a.pitch < lc->w || b.pitch < lc->w * bpp1)
-      return ctx->fail(FLVIS_ERR_INVALID_ARG, "loop_closer_add_keyframes_host: images must be mono8 (img1: 16UC1 on a depth rig) of the configured size");
     e = hipMemcpy2DAsync(d0 + px * i, (size_t)lc->w, a.data, (size_t)a.pitch, (size_t)lc->w, (size_t)lc->h, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
       e = hipMemcpy2DAsync(d1 + px * bpp1 * i, (size_t)lc->w * bpp1, b.data, (size_t)b.pitch, (size_t)lc->w * bpp1, (size_t)lc->h,
                            hipMemcpyHostToDevice, ctx->stream);
   }
-  if (e != hipSuccess) return ctx->hip_fail(e, "loop_closer_add_keyframes_host");
-  return flvis_loop_closer_add_keyframes(lc, n, h_stream, d0, d1, h_T_c_w_odom7, h_kf_id);  // (it synchronises before it returns)
+  if (e != hipSuccess) {
+    hipStreamSynchronize(ctx->stream);  // copies from the caller's images may still be in flight
+    return ctx->hip_fail(e, "loop_closer_add_keyframes_host");
+  }
+  const int rc = flvis_loop_closer_add_keyframes(lc, n, h_stream, d0, d1, h_T_c_w_odom7, h_kf_id);  // (synchronises when it succeeds)
+  if (rc != FLVIS_OK) hipStreamSynchronize(ctx->stream);  // ... and on its error paths the uploads are waited for here
+  return rc;
 }
 
 int flvis_loop_closer_process(flvis_loop_closer* lc, flvis_lc_event* h_events) {

@@ -22,6 +22,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -295,6 +297,8 @@ void parse_txt(const std::vector<uint8_t>& file, flvis_voc_file& v) {
     double h[4];
     for (int i = 0; i < 4; i++)
       if (!next_number(p, le, h[i])) bad("vocabulary text file: the first line must read 'k L scoring weighting'");
+    for (int i = 0; i < 4; i++)
+      if (!(h[i] >= -1e6 && h[i] <= 1e6)) bad("vocabulary text file: this is not a vocabulary header");  // (also refuses NaN: the casts below are defined)
     b.k = (int)h[0], b.L = (int)h[1], b.scoring = (int)h[2], b.weighting = (int)h[3];
     if (b.k < 0 || b.k > 20 || b.L < 1 || b.L > 10 || b.scoring < 0 || b.scoring > 5 || b.weighting < 0 || b.weighting > 3)
       bad("vocabulary text file: this is not a vocabulary header");  // Vocabulary.cpp:1271
@@ -314,7 +318,11 @@ void parse_txt(const std::vector<uint8_t>& file, flvis_voc_file& v) {
     r.id = (uint32_t)b.recs.size() + 1;
     if (num[0] < 0 || num[0] >= (double)r.id) bad("vocabulary text file: a node's parent must come before it");
     r.parent = (uint32_t)num[0];
-    for (int i = 0; i < 32; i++) r.desc[i] = (uint8_t)(float)num[2 + i];
+    for (int i = 0; i < 32; i++) {
+      if (!(num[2 + i] >= 0.0 && num[2 + i] < 256.0)) bad("vocabulary text file: a descriptor byte outside 0 .. 255");
+      r.desc[i] = (uint8_t)(float)num[2 + i];
+    }
+    if (!std::isfinite(num[34])) bad("vocabulary text file: a node weight that is not a number");
     r.weight = (double)(float)num[34];  // the reference reads every field of the line as float
     b.recs.push_back(r);
     if (num[1] > 0) b.words.push_back({next_word++, r.id});
@@ -324,6 +332,15 @@ void parse_txt(const std::vector<uint8_t>& file, flvis_voc_file& v) {
 }
 
 // ---- OpenCV FileStorage YAML: just the shapes Vocabulary::save(fs) writes ------------------------------------------------------
+// a decimal node / word id of the FileStorage text: all digits, below 2^32 (strtoul alone would wrap or saturate silently)
+uint32_t parse_id(const std::string& val, const char* what) {
+  errno = 0;
+  char* endp = nullptr;
+  const unsigned long long v = strtoull(val.c_str(), &endp, 10);
+  if (val.empty() || endp == val.c_str() || errno != 0 || v > 0xffffffffull) bad(std::string("vocabulary yaml: bad ") + what);
+  return (uint32_t)v;
+}
+
 struct Yaml {
   const char* p;
   const char* end;
@@ -416,7 +433,10 @@ void parse_descriptor_string(const std::string& s, uint8_t* out) {  // DescManip
     off = 2;
   }
   if (num.size() - off != 32) bad("vocabulary yaml: a descriptor string must hold 32 bytes");
-  for (int i = 0; i < 32; i++) out[i] = (uint8_t)(int)num[off + i];
+  for (int i = 0; i < 32; i++) {
+    if (!(num[off + i] >= 0.0 && num[off + i] < 256.0)) bad("vocabulary yaml: a descriptor byte outside 0 .. 255");
+    out[i] = (uint8_t)(int)num[off + i];
+  }
 }
 
 void parse_yaml(const std::vector<uint8_t>& file, flvis_voc_file& v) {
@@ -448,8 +468,8 @@ void parse_yaml(const std::vector<uint8_t>& file, flvis_voc_file& v) {
     Builder::Rec r{};
     bool have[4] = {false, false, false, false};
     const bool more = y.flow_map([&](const std::string& k, const std::string& val) {
-      if (k == "nodeId") r.id = (uint32_t)strtoul(val.c_str(), nullptr, 10), have[0] = true;
-      else if (k == "parentId") r.parent = (uint32_t)strtoul(val.c_str(), nullptr, 10), have[1] = true;
+      if (k == "nodeId") r.id = parse_id(val, "nodeId"), have[0] = true;
+      else if (k == "parentId") r.parent = parse_id(val, "parentId"), have[1] = true;
       else if (k == "weight") r.weight = strtod(val.c_str(), nullptr), have[2] = true;
       else if (k == "descriptor") parse_descriptor_string(val, r.desc), have[3] = true;
     });
@@ -468,8 +488,8 @@ void parse_yaml(const std::vector<uint8_t>& file, flvis_voc_file& v) {
     uint32_t wid = 0, nid = 0;
     bool have[2] = {false, false};
     const bool more = y.flow_map([&](const std::string& k, const std::string& val) {
-      if (k == "wordId") wid = (uint32_t)strtoul(val.c_str(), nullptr, 10), have[0] = true;
-      else if (k == "nodeId") nid = (uint32_t)strtoul(val.c_str(), nullptr, 10), have[1] = true;
+      if (k == "wordId") wid = parse_id(val, "wordId"), have[0] = true;
+      else if (k == "nodeId") nid = parse_id(val, "nodeId"), have[1] = true;
     });
     if (!more) break;
     if (!(have[0] && have[1])) bad("vocabulary yaml: a word needs wordId and nodeId");

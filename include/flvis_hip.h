@@ -364,7 +364,11 @@ int flvis_get_keyframe(flvis_ctx* ctx, int stream, int cap, int64_t* frame_id, d
  * id / undistorted-pixel / world-point arrays, T_c_w; lm_descriptor_data is empty in the reference (:71-81).  The caller provides
  * the arrays (capacity cap) and, optionally, host buffers for the images (width * height bytes, 2 bytes per pixel for a depth
  * img1; NULL = not wanted).  Call it right after the flvis_image_feed that reported new_keyframe: the images are the
- * tracker's working copies of THAT frame.  Returns lm_count (0: the stream's last frame was no keyframe; < 0: error). */
+ * tracker's working copies of THAT frame.  LIFETIME: img0 is always the tracker's own copy; img1 is read through the pointer that
+ * flvis_image_feed was given when the right / depth image is used in place (depth rigs, and stereo rigs without equalizeHist whose
+ * rows are dword aligned): a caller of flvis_image_feed that wants img1 here must leave that device buffer untouched until this call
+ * has returned (flvis_image_feed_host keeps its own double-buffered staging: nothing to observe there).
+ * Returns lm_count (0: the stream's last frame was no keyframe; < 0: error). */
 typedef struct flvis_keyframe {
   int64_t frame_id;
   int8_t command;

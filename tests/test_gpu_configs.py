@@ -170,7 +170,13 @@ def test_config2_with_imu_rotation_factor():
     _config2_frontend_and_ba(imu_factor=True)
 
 
-def _config2_frontend_and_ba(imu_factor):
+def test_config2_with_the_full_imu_factor():
+    """... and with the factor's position rows (flvis_set_imu_factor_accel): the displacement preintegrated by the front-end and the
+    filter velocity of the previous keyframe travel with every keyframe through the queue into the 6-row edges of the window BA."""
+    _config2_frontend_and_ba(imu_factor=True, sigma_a=0.1)
+
+
+def _config2_frontend_and_ba(imu_factor, sigma_a=0.0):
     """BASELINE configs[2] on the EuRoC-like rig (window 10, <= 480 landmarks per frame): ONE stream through the HIP front-end
     with the HIP local map consuming its keyframe queue, beside the oracle front-end feeding the oracle's LocalMap.  After
     every keyframe the CorrectionInf of both sides is compared: same keyframe, same landmark id list, same outliers while the
@@ -193,6 +199,10 @@ def _config2_frontend_and_ba(imu_factor):
         q = G.pose7(R_c_i, np.zeros(3))
         lmap.set_imu_factor(True, sigma_g, np.array([q[6], q[3], q[4], q[5]]))
         trk.set_imu_factor(True, sigma_g)
+        if sigma_a > 0:
+            T_i_c = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)
+            lmap.set_imu_factor_pos(sigma_a, -R_c_i @ T_i_c[:3, 3])        # body origin in the camera frame (T_c_i's translation)
+            trk.set_imu_factor_accel(sigma_a)
     tr = synth.Trajectory(sid)
     rnd = synth.Renderer("cuda", rig=rig)
     t_prev = -0.05
@@ -219,6 +229,8 @@ def _config2_frontend_and_ba(imu_factor):
         valid, dq, dt = ref.keyframe_imu()
         if imu_factor and valid:
             lmap.next_imu(dq, dt)
+            if sigma_a > 0:
+                lmap.next_imu_pos(*ref.keyframe_imu_pos())
             n_links += 1
         c = lmap.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
         if c is not None:

@@ -180,6 +180,25 @@ def test_refusals(voc, tmp_path):
     refused(t, "a node line must hold")
     open(t, "w").write("99 3 0 0\n")
     refused(t, "not a vocabulary header")
+    open(t, "w").write("1e300 3 0 0\n")                            # values whose casts to int would be undefined behaviour
+    refused(t, "not a vocabulary header")
+    open(t, "w").write("nan 3 0 0\n")
+    refused(t, "not a vocabulary header")
+    line = "0 1 " + " ".join(["7"] * 31)
+    open(t, "w").write("5 1 0 0\n" + line + " 300 0.5\n")          # a descriptor byte that is no byte
+    refused(t, "descriptor byte outside")
+    open(t, "w").write("5 1 0 0\n" + line + " -1 0.5\n")
+    refused(t, "descriptor byte outside")
+    open(t, "w").write("5 1 0 0\n" + line + " 7 inf\n")
+    refused(t, "weight that is not a number")
+    y = str(tmp_path / "v.yml")
+    VF.write_yaml(y, voc, 5, 3)
+    txt = open(y).read()
+    open(y, "w").write(txt.replace("nodeId:1,", "nodeId:99999999999,", 1))        # an id beyond 32 bits: refused, not wrapped
+    refused(y, "bad nodeId")
+    open(y, "w").write(txt.replace(" 32 ", " 32 999 ", 1).replace("dbw3 0 32 999 ", "dbw3 0 32 999 ", 1))
+    with pytest.raises(flvis_amd.FlvisError):                      # 33 numbers or a byte of 999: either way refused
+        flvis_amd.read_vocabulary_file(y)
 
 
 def test_corrupt_compressed_streams_are_refused_not_crashed(voc, tmp_path):
