@@ -172,66 +172,81 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       int a11 = 0, a12 = 0, a22 = 0;
       // every pixel the Scharr stencil is evaluated at lies inside the image -> no border masks (wave-uniform test)
       const bool interior = ipx >= 0 && ipx + 32 <= W - 1 && ipy >= 0 && ipy + 31 <= H - 1;
-      if (r < LK_WIN && interior) {
-        // packed 16-bit path: two columns per instruction (v_pk_*), weights applied with v_dot2c_i32_i16
-        uint32_t d[4][5];
+      if (interior) {
+        // packed 16-bit path: two columns per instruction (v_pk_*), weights applied with v_dot2c_i32_i16.  Every lane (window rows
+        // 0 .. 31: the lanes of row 31 only serve their neighbours) computes the Scharr derivatives of ITS row once; the derivatives
+        // of row r + 1, which the bilinear interpolation also needs, come from the lane two above (same column half) through
+        // ds_bpermute -- 18 exchanges on the LDS pipe instead of computing every derivative row twice on the VALUs
+        uint32_t d[3][5];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 3; j++)
 #pragma unroll
           for (int k = 0; k < 5; k++) d[j][k] = *reinterpret_cast<const uint32_t*>(patch + (r + j) * LK_PS + c0 + 4 * k);
         const lk_s2 wT = lk_s2{(short)iw00, (short)iw01}, wB = lk_s2{(short)iw10, (short)iw11};
         lk_s2 DX[2][9], DY[2][9];  // (v[2j], v[2j+1]) of window row r + dr
-#pragma unroll
-        for (int dr = 0; dr < 2; dr++) {
+        {
           lk_s2 T0[10], T1[10];
 #pragma unroll
           for (int j = 0; j < 10; j++) {
-            const lk_s2 A = __builtin_bit_cast(lk_s2, LK_PAIR(d[dr], 2 * j)), B = __builtin_bit_cast(lk_s2, LK_PAIR(d[dr + 1], 2 * j)),
-                        Cc = __builtin_bit_cast(lk_s2, LK_PAIR(d[dr + 2], 2 * j));
+            const lk_s2 A = __builtin_bit_cast(lk_s2, LK_PAIR(d[0], 2 * j)), B = __builtin_bit_cast(lk_s2, LK_PAIR(d[1], 2 * j)),
+                        Cc = __builtin_bit_cast(lk_s2, LK_PAIR(d[2], 2 * j));
             T0[j] = (A + Cc) * (short)3 + B * (short)10;
             T1[j] = Cc - A;
           }
+          const int up2 = ((lane + 2) & 63) * 4;
 #pragma unroll
           for (int j = 0; j < 9; j++) {
-            DX[dr][j] = T0[j + 1] - T0[j];
+            DX[0][j] = T0[j + 1] - T0[j];
             const lk_s2 T1o = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, T1[j + 1]),
                                                                              __builtin_bit_cast(uint32_t, T1[j]), 0x05040302u));
-            DY[dr][j] = (T1[j + 1] + T1[j]) * (short)3 + T1o * (short)10;
+            DY[0][j] = (T1[j + 1] + T1[j]) * (short)3 + T1o * (short)10;
+            DX[1][j] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_ds_bpermute(up2, __builtin_bit_cast(int, DX[0][j])));
+            DY[1][j] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_ds_bpermute(up2, __builtin_bit_cast(int, DY[0][j])));
           }
         }
+        if (r < LK_WIN) {
+          // (intensity rows r, r + 1 of the window are patch rows r + 1, r + 2: d[1], d[2])
 #pragma unroll
-        for (int c2 = 0; c2 < 8; c2++) {
-          int iv[2], ix[2], iy[2];
+          for (int c2 = 0; c2 < 8; c2++) {
+            int iv[2], ix[2], iy[2];
 #pragma unroll
-          for (int hh = 0; hh < 2; hh++) {
-            const int c = 2 * c2 + hh;
-            lk_s2 x0, x1, y0, y1;  // (v[c], v[c+1]) of rows r, r+1
-            if (hh == 0) {
-              x0 = DX[0][c2]; x1 = DX[1][c2]; y0 = DY[0][c2]; y1 = DY[1][c2];
-            } else {
-              x0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[0][c2 + 1]), __builtin_bit_cast(uint32_t, DX[0][c2]), 0x05040302u));
-              x1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[1][c2 + 1]), __builtin_bit_cast(uint32_t, DX[1][c2]), 0x05040302u));
-              y0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[0][c2 + 1]), __builtin_bit_cast(uint32_t, DY[0][c2]), 0x05040302u));
-              y1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[1][c2 + 1]), __builtin_bit_cast(uint32_t, DY[1][c2]), 0x05040302u));
+            for (int hh = 0; hh < 2; hh++) {
+              const int c = 2 * c2 + hh;
+              lk_s2 x0, x1, y0, y1;  // (v[c], v[c+1]) of rows r, r+1
+              if (hh == 0) {
+                x0 = DX[0][c2]; x1 = DX[1][c2]; y0 = DY[0][c2]; y1 = DY[1][c2];
+              } else {
+                x0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[0][c2 + 1]), __builtin_bit_cast(uint32_t, DX[0][c2]), 0x05040302u));
+                x1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[1][c2 + 1]), __builtin_bit_cast(uint32_t, DX[1][c2]), 0x05040302u));
+                y0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[0][c2 + 1]), __builtin_bit_cast(uint32_t, DY[0][c2]), 0x05040302u));
+                y1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[1][c2 + 1]), __builtin_bit_cast(uint32_t, DY[1][c2]), 0x05040302u));
+              }
+              int ax = 1 << (W_BITS - 1), ay = 1 << (W_BITS - 1), ai = 1 << (W_BITS - 5 - 1);
+              ax = __builtin_amdgcn_sdot2(x0, wT, ax, false);
+              ax = __builtin_amdgcn_sdot2(x1, wB, ax, false);
+              ay = __builtin_amdgcn_sdot2(y0, wT, ay, false);
+              ay = __builtin_amdgcn_sdot2(y1, wB, ay, false);
+              ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[1], c + 1)), wT, ai, false);
+              ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[2], c + 1)), wB, ai, false);
+              const bool on = c0 + c < LK_WIN;  // window column 31 of the second half does not exist
+              ix[hh] = on ? (ax >> W_BITS) : 0;
+              iy[hh] = on ? (ay >> W_BITS) : 0;
+              iv[hh] = on ? (ai >> (W_BITS - 5)) : 0;
             }
-            int ax = 1 << (W_BITS - 1), ay = 1 << (W_BITS - 1), ai = 1 << (W_BITS - 5 - 1);
-            ax = __builtin_amdgcn_sdot2(x0, wT, ax, false);
-            ax = __builtin_amdgcn_sdot2(x1, wB, ax, false);
-            ay = __builtin_amdgcn_sdot2(y0, wT, ay, false);
-            ay = __builtin_amdgcn_sdot2(y1, wB, ay, false);
-            ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[1], c + 1)), wT, ai, false);
-            ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[2], c + 1)), wB, ai, false);
-            const bool on = c0 + c < LK_WIN;  // window column 31 of the second half does not exist
-            ix[hh] = on ? (ax >> W_BITS) : 0;
-            iy[hh] = on ? (ay >> W_BITS) : 0;
-            iv[hh] = on ? (ai >> (W_BITS - 5)) : 0;
+            tI[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iv[1], (uint32_t)iv[0], 0x05040100u));
+            tX[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)ix[1], (uint32_t)ix[0], 0x05040100u));
+            tY[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iy[1], (uint32_t)iy[0], 0x05040100u));
+            a11 = __builtin_amdgcn_sdot2(tX[c2], tX[c2], a11, false);
+            a12 = __builtin_amdgcn_sdot2(tX[c2], tY[c2], a12, false);
+            a22 = __builtin_amdgcn_sdot2(tY[c2], tY[c2], a22, false);
           }
-          tI[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iv[1], (uint32_t)iv[0], 0x05040100u));
-          tX[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)ix[1], (uint32_t)ix[0], 0x05040100u));
-          tY[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iy[1], (uint32_t)iy[0], 0x05040100u));
-          a11 = __builtin_amdgcn_sdot2(tX[c2], tX[c2], a11, false);
-          a12 = __builtin_amdgcn_sdot2(tX[c2], tY[c2], a12, false);
-          a22 = __builtin_amdgcn_sdot2(tY[c2], tY[c2], a22, false);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            tI[c] = lk_s2{0, 0};
+            tX[c] = lk_s2{0, 0};
+            tY[c] = lk_s2{0, 0};
+          }
         }
       } else if (r < LK_WIN) {
         uint32_t d[4][5];
