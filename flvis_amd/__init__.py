@@ -356,6 +356,18 @@ class Context:
                                                    _ptr(mask), _ptr(ninl)), "pnp_ransac")
         return pose, mask, ninl
 
+    def debug_epnp(self, p3d, p2d, count, K4):
+        """flvis_hip_debug_epnp: EPnP alone on correspondence sets (p3d float32 [n,cap,3], p2d float32 [n,cap,2], count int32 [n], device)
+        -> float64 [n,160] (layout in include/flvis_hip.h)."""
+        import numpy as np
+        import torch
+        p3d, p2d = p3d.contiguous(), p2d.contiguous()
+        n, cap, _ = p3d.shape
+        K = np.ascontiguousarray(K4, np.float64)
+        out = torch.zeros((n, 160), dtype=torch.float64, device=p3d.device)
+        self._check(self._lib.flvis_hip_debug_epnp(self._h, _ptr(p3d), _ptr(p2d), _ptr(count), cap, n, _P(K, C.c_double), _ptr(out)), "debug_epnp")
+        return out
+
     def pgo_loop_closure(self, T_c_w_list, present_list, loops_list, loop_poses_list, iterations=100, use_initial_guess=True):
         """flvis_hip_pgo_loop_closure for a batch of pose graphs (lists of per-graph numpy arrays: T_c_w [n,7], present [n], loops
         [m,2], loop poses [m,7]).  Returns (list of optimised T_c_w arrays, drift [g,7], stats [g,5], ran [g])."""

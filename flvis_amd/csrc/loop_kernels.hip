@@ -889,6 +889,18 @@ int flvis_hip_pnp_ransac(flvis_ctx* ctx, const float* d_p3d, const float* d_p2d,
   return FLVIS_OK;
 }
 
+// cv::solvePnP(..., SOLVEPNP_EPNP) alone on n_sets correspondence sets (the solver inside flvis_hip_pnp_ransac and the tracker), with its
+// intermediate values: what the tests compare with the CPU restatement value by value.
+int flvis_hip_debug_epnp(flvis_ctx* ctx, const float* d_p3d, const float* d_p2d, const int* d_count, int cap, int n_sets, const double* h_K4,
+                         double* d_out160) {
+  CHECK_CTX(ctx);
+  if (!d_p3d || !d_p2d || !d_count || !h_K4 || !d_out160 || cap <= 0 || n_sets <= 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "debug_epnp: bad args");
+  hipSetDevice(ctx->device);
+  launch_epnp_sets(ctx->stream, d_p3d, d_p2d, d_count, cap, n_sets, h_K4, d_out160);
+  CHECK_LAUNCH(ctx, "debug_epnp");
+  return FLVIS_OK;
+}
+
 // loopClosureOnCovGraphG2ONew for n_graphs independent sequences in one launch.  Host side: the integer bookkeeping of
 // vo_loopclosing.cpp:747-875 (vertex range, fixed flags, edge list) plus the adjacency lists and the block profile of the normal
 // matrix; everything numeric runs in k_pgo.

@@ -24,6 +24,7 @@ static __device__ long long g_sp_last = 0;
 }
 #endif
 #include "dev_geom.hpp"
+#include "epnp_core.hpp"
 #include "track_kernels.hpp"
 #include "vi_motion.hpp"
 
@@ -773,9 +774,12 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
 // ------------------------------------------------------------------------------------------------ PnP RANSAC
 // cv::solvePnPRansac(p3d, p2d, K_rect, 0, r, t, false, iterations, reprojErr, confidence, inliers, ITERATIVE|P3P) control flow: the
 // RANSAC registrator of ptsetreg.cpp with 5-point (ITERATIVE: the kernel method is EPNP) or 4-point (P3P) subsets drawn from
-// cv::RNG((uint64)-1) in getSubset's order, serially by wave 0 (16 hypotheses first, then 64 per batch); PnPRansacCallback has no
-// checkSubset.  Hypotheses by Grunert P3P on the first 3 sample points (the rest disambiguate), Gauss-Newton refinement on the
-// inliers (the minimal solver and the final solve are this build's: see DESIGN.md section 2).  The core works on
+// cv::RNG((uint64)-1) in getSubset's order, serially by wave 0; PnPRansacCallback has no checkSubset.
+//   ITERATIVE  hypotheses by EPnP on the five sample points (epnp_core.hpp), one per wave, eight per batch; final solve on the inliers:
+//              Gauss-Newton on the reprojection error from the winning model (the minimum cv's Levenberg-Marquardt converges to)
+//   P3P        hypotheses by Grunert P3P on the first three sample points, the fourth picks among the <= 4 solutions (as cv::p3p does),
+//              one per lane, 16 then 64 per batch; final solve on the inliers: EPnP (solvePnPRansac hands SOLVEPNP_EPNP to solvePnP)
+// The core works on
 // correspondences staged in LDS by the caller (the tracker's kernel gathers a frame's landmarks; the standalone kernel of the loop
 // closing's geometric check loads caller arrays) and is entered by the WHOLE workgroup; only wave 0 returns with the result.
 constexpr int RP_T = 512;
@@ -791,6 +795,8 @@ struct PnpShared {
   double* bpose;         // [12]
   double* gterms;        // [64 * PNP_GN_ROW]
   double* gn;            // [32]
+  epnp::Work* ew;        // [RP_T / 64] one EPnP workspace per wave
+  short* inl;            // [n] indices of the inliers, in order (the P3P flag's final EPnP)
 };
 template <bool PROF>
 __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np, const bool iterative, const SE3d guess, const double fx,
@@ -831,8 +837,105 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
     const int first_limit = np == modelPoints ? 1 : max_iters;
     if (tid == 0) ctl[0] = first_limit;
     __syncthreads();
-    for (int base = 0, B = 16; base < ctl[0]; base += B, B = 64) {
+    const epnp::Camera ecam{fx, fy, cx, cy};
+    auto wsync = [] {
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+#ifdef FLVIS_EPNP_WAVES
+    constexpr int NW = FLVIS_EPNP_WAVES;
+#else
+    constexpr int NW = RP_T / 64;
+#endif
+    for (int base = 0, B = iterative ? NW : 16; base < ctl[0]; base += B, B = iterative ? NW : 64) {
       if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[6], 1ull);
+      if (iterative) {
+        // EPnP on the five sample points: wave w solves hypothesis base + w
+        if (wv == 0) {
+          if (lane < NW) s_sub[lane][7] = 0;
+          __builtin_amdgcn_wave_barrier();
+          for (int k = 0; k < B && base + k < ctl[0]; k++) {
+            int sidx[5];
+            bool ok = true;
+            if (np == modelPoints) {
+#pragma unroll
+              for (int j = 0; j < 5; j++) sidx[j] = j;
+            } else {
+              ok = cv_get_subset<5>(rng, mc, modelPoints, 10000, sidx, [](const int*) { return true; });
+            }
+            if (lane == 0) {
+#pragma unroll
+              for (int j = 0; j < 5; j++) s_sub[k][j] = sidx[j];
+              s_sub[k][7] = ok ? 1 : 0;
+            }
+            if (!ok) break;
+          }
+        }
+        __syncthreads();
+        int cnt = -1;  // -1: no model / beyond niters, -2: subset impossible, -3: model in hpose[wv], to be scored
+        if (wv < NW && base + wv < ctl[0]) {
+          if (s_sub[wv][7]) {
+            const int* const sub = s_sub[wv];
+            auto pw = [&](int i, double* q) {
+              const int k = sub[i];
+              q[0] = (double)s3d[3 * k], q[1] = (double)s3d[3 * k + 1], q[2] = (double)s3d[3 * k + 2];
+            };
+            auto uv = [&](int i, double* z) {  // undistortPoints' float, back to pixels as epnp::init_points does
+              const int k = sub[i];
+              z[0] = (double)(float)(((double)s2d[2 * k] - cx) / fx) * fx + cx;
+              z[1] = (double)(float)(((double)s2d[2 * k + 1] - cy) / fy) * fy + cy;
+            };
+#ifdef FLVIS_RANSAC_PROF
+            // phase times of wave 0's solve into prof[8 ..] (= counters[40 ..])
+            long long et_ = (long long)wall_clock64();
+            auto emark = [&](int i) {
+              if (PROF && tid == 0 && prof) {
+                const long long now_ = (long long)wall_clock64();
+                atomicAdd((unsigned long long*)&prof[8 + i], (unsigned long long)(now_ - et_));
+                et_ = now_;
+              }
+            };
+            epnp::Work& ew_ = sh.ew[wv];
+            epnp::solve_head<64>(ew_, 5, pw, uv, ecam, lane, wsync);
+            emark(0);
+            epnp::jacobi12(ew_, lane, 64, wsync);
+            emark(1);
+            epnp::phase_pick_vectors(ew_, lane, 64);
+            wsync();
+            epnp::phase_constraints(ew_, lane, 64);
+            wsync();
+            emark(2);
+            epnp::phase_betas(ew_, lane, 64);
+            wsync();
+            emark(3);
+            epnp::phase_centroids(ew_, 5, pw, lane, 64);
+            wsync();
+            epnp::phase_abt(ew_, 5, pw, lane, 64);
+            wsync();
+            emark(4);
+            epnp::phase_pose(ew_, 5, pw, uv, ecam, lane, 64);
+            wsync();
+            emark(5);
+            const epnp::Pose P = epnp::result(ew_);
+            if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[8 + 6], 1ull);
+#else
+            const epnp::Pose P = epnp::solve<64>(sh.ew[wv], 5, pw, uv, ecam, lane, wsync);
+#endif
+            if (P.ok) {
+              if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < 9; j++) hpose[wv][j] = P.R[j];
+                hpose[wv][9] = P.t[0], hpose[wv][10] = P.t[1], hpose[wv][11] = P.t[2];
+              }
+              cnt = -3;
+            }
+          } else {
+            cnt = -2;
+          }
+        }
+        if (lane == 0 && wv < NW) hcnt[wv] = cnt;
+        __syncthreads();
+      } else {
       // hypotheses of this batch, one per lane of wave 0: P3P on the first 3 sample points, the rest disambiguate.  The bisections of
       // the quartic's two bracketing levels (its derivative's <= 3 sign-change intervals, then its own <= 4) are handed to waves
       // 0..3, one interval each: inside one lane they were most of the generation time (a single wave is VALU-issue bound).  The
@@ -984,9 +1087,10 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
         hcnt[lane] = cnt;
       }
       __syncthreads();
+      }  // (P3P hypotheses)
       PNP_PROF(1);
       // score + replay in sub-batches of 16 hypotheses (the adaptive stop usually ends the search within the first few)
-      constexpr int SB = 16;
+      const int SB = iterative ? NW : 16;
       for (int sb = 0; sb < B; sb += SB) {
         if (base + sb >= ctl[0]) break;  // (uniform: ctl[0] was written before the last barrier)
         for (int hy = sb + wv; hy < sb + SB; hy += RP_T / 64) {  // score the models: lanes stride the correspondences
@@ -1039,25 +1143,85 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
     }
   }
   PNP_PROF(3);
-  if (wv != 0) return;  // mask + final refinement: one wave
-  T = iterative ? guess : se3_identity();
-  if (iterative) T = se3_from_mat(q_to_mat(T.q), T.t);
-  inliers = 0;
-  if (ctl[2] >= 0) {
-    M3 R;
+  // the winning model's mask (whole workgroup)
+  const bool found = ctl[2] >= 0;
+  M3 R;
+  V3 t{0, 0, 0};
+  if (found) {
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
       for (int c = 0; c < 3; c++) R.m[r][c] = bpose[3 * r + c];
-    V3 t{bpose[9], bpose[10], bpose[11]};
-    for (int i = lane; i < np; i += 64) {
+    t = V3{bpose[9], bpose[10], bpose[11]};
+    for (int i = tid; i < np; i += RP_T) {
       V3 Pi{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]};
       V3 X = R * Pi + t;
       double z = X.z ? 1. / X.z : 1;
       float du = (float)(fx * X.x * z + cx) - s2d[2 * i], dv = (float)(fy * X.y * z + cy) - s2d[2 * i + 1];
       smask[i] = (du * du + dv * dv <= t2) ? 1 : 0;
     }
+  } else {
+    for (int i = tid; i < np; i += RP_T) smask[i] = 0;
+  }
+  __syncthreads();
+  bool have_final = false;
+  if (found && !iterative) {
+    // SOLVEPNP_P3P: the final solvePnP on the inliers is EPnP.  The O(n) sums of its head by the whole workgroup, the rest by wave 0.
+    if (wv == 0) {
+      int k0 = 0;
+      for (int b0 = 0; b0 < np; b0 += 64) {
+        const int i = b0 + lane;
+        const bool in = i < np && smask[i];
+        const unsigned long long bal = __ballot(in);
+        if (in) sh.inl[k0 + lane_prefix(bal)] = (short)i;
+        k0 += __popcll(bal);
+      }
+      if (lane == 0) ctl[3] = k0;
+    }
     __syncthreads();
+    const int ni = ctl[3];
+    const short* const inl = sh.inl;
+    auto pw = [&](int i, double* q) {
+      const int k = inl[i];
+      q[0] = (double)s3d[3 * k], q[1] = (double)s3d[3 * k + 1], q[2] = (double)s3d[3 * k + 2];
+    };
+    auto uv = [&](int i, double* z) {
+      const int k = inl[i];
+      z[0] = (double)(float)(((double)s2d[2 * k] - cx) / fx) * fx + cx;
+      z[1] = (double)(float)(((double)s2d[2 * k + 1] - cy) / fy) * fy + cy;
+    };
+    const epnp::Camera ecam{fx, fy, cx, cy};
+    epnp::solve_head<RP_T>(sh.ew[0], ni, pw, uv, ecam, tid, [] { __syncthreads(); });
+    if (wv == 0) {
+      const epnp::Pose P = epnp::solve_tail<64>(sh.ew[0], ni, pw, uv, ecam, lane, [] {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      });
+      if (P.ok) {
+        M3 Rf;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) Rf.m[r][c] = P.R[3 * r + c];
+        const SE3d Te = g2o_from_mat(Rf, V3{P.t[0], P.t[1], P.t[2]});
+        T = se3_from_mat(q_to_mat(Te.q), Te.t);  // SE3_from_rvec_tvec (common.h:151-158)
+        have_final = true;
+      }
+    }
+  }
+  if (wv != 0) return;  // final refinement: one wave
+  if (!have_final) {
+    T = iterative ? guess : se3_identity();
+    if (iterative) T = se3_from_mat(q_to_mat(T.q), T.t);
+  }
+  inliers = 0;
+  if (found && !iterative) {
+    inliers = ctl[1];
+    if (!have_final) {
+      const SE3d Te = g2o_from_mat(R, t);
+      T = se3_from_mat(q_to_mat(Te.q), Te.t);
+    }
+  } else if (found) {
     inliers = ctl[1];
     // Gauss-Newton refinement on the inliers (stand-in for OpenCV's final solvePnP).  The 21 + 6 normal-equation sums are
     // SEQUENTIAL sums over the inliers in index order (as the CPU restatement adds them): lane l computes the terms of
@@ -1124,8 +1288,6 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
       if (nn < 1e-20) break;
     }
     T = se3_from_mat(q_to_mat(Tb.q), Tb.t);
-  } else {
-    for (int i = lane; i < np; i += 64) smask[i] = 0;
   }
 #undef PNP_PROF
 }
@@ -1156,6 +1318,8 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   __shared__ double bpose[12];
   __shared__ double gterms[64 * PNP_GN_ROW];
   __shared__ double gn[32];
+  __shared__ epnp::Work ework[RP_T / 64];
+  __shared__ short sinl[NMAX];
   __shared__ int snp;
   // gather (has3d && inlier) in order (wave 0)
   if (wv == 0) {
@@ -1182,7 +1346,7 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   SE3d T;
   int inliers = 0;
   // solvePnPRansac(..., 100, 3.0, 0.99, ...) of LKORBTracking::tracking (lkorb_tracking.cpp:170-177)
-  pnp_ransac_core<kProf>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, ssub, bpose, gterms, gn}, np, st.use_guess != 0, load_pose7(st.guess),
+  pnp_ransac_core<kProf>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, ssub, bpose, gterms, gn, ework, sinl}, np, st.use_guess != 0, load_pose7(st.guess),
                          p.cam.fx, p.cam.fy, p.cam.cx, p.cam.cy, 0ull /* no seed: cv::RNG((uint64)-1) per call */,
                          100, 9.0f, 0.99, p.counters ? p.counters + 32 : nullptr, tlast_, T, inliers);
   if (wv != 0) return;
@@ -1218,6 +1382,8 @@ __global__ __launch_bounds__(RP_T) void k_pnp_ransac_sets(const float* __restric
   __shared__ double bpose[12];
   __shared__ double gterms[64 * PNP_GN_ROW];
   __shared__ double gn[32];
+  __shared__ epnp::Work ework[RP_T / 64];
+  __shared__ short sinl[PNP_MAXN];
   int np = count[b];
   np = np < 0 ? 0 : (np > cap ? cap : np);
   for (int i = tid; i < np; i += RP_T) {
@@ -1231,7 +1397,7 @@ __global__ __launch_bounds__(RP_T) void k_pnp_ransac_sets(const float* __restric
   SE3d T;
   int inliers = 0;
   long long tl = 0;
-  pnp_ransac_core<false>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, ssub, bpose, gterms, gn}, np, iterative != 0,
+  pnp_ransac_core<false>(PnpShared{s2d, s3d, smask, hcnt, hpose, ctl, ssub, bpose, gterms, gn, ework, sinl}, np, iterative != 0,
                          iterative ? load_pose7(guess7 + 7 * b) : se3_identity(), fx, fy, cx, cy, seeds[b], max_iters, t2, conf, nullptr, tl, T,
                          inliers);
   if (wv != 0) return;
@@ -1241,6 +1407,41 @@ __global__ __launch_bounds__(RP_T) void k_pnp_ransac_sets(const float* __restric
     store_pose7(pose7 + 7 * b, T);  // (identity / the guess when no model was found, n_inliers 0)
     n_inliers[b] = inliers;
   }
+}
+
+// EPnP alone (cv::solvePnP(..., SOLVEPNP_EPNP)) on caller-supplied correspondence sets, one wave per set: the test bench of
+// epnp_core.hpp on the device.  out [set][EPNP_DBG_N]: R (9, row-major), t (3), ok, betas (3 x 4), err (3), v (4 x 12), L (6 x 10), rho (6),
+// the eigenvalues of MtM as the Jacobi left them (12).
+__global__ __launch_bounds__(64) void k_epnp_sets(const float* __restrict__ p3d, const float* __restrict__ p2d, const int* __restrict__ count,
+                                                  int cap, double fx, double fy, double cx, double cy, double* __restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  __shared__ epnp::Work w;
+  const int n = count[b];
+  const float* const P = p3d + (size_t)b * cap * 3;
+  const float* const Z = p2d + (size_t)b * cap * 2;
+  auto pw = [&](int i, double* q) { q[0] = (double)P[3 * i], q[1] = (double)P[3 * i + 1], q[2] = (double)P[3 * i + 2]; };
+  auto uv = [&](int i, double* z) {
+    z[0] = (double)(float)(((double)Z[2 * i] - cx) / fx) * fx + cx;
+    z[1] = (double)(float)(((double)Z[2 * i + 1] - cy) / fy) * fy + cy;
+  };
+  const epnp::Pose R = epnp::solve<64>(w, n, pw, uv, epnp::Camera{fx, fy, cx, cy}, lane, [] {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+  if (lane != 0) return;
+  double* o = out + (size_t)b * EPNP_DBG_N;
+  for (int i = 0; i < 9; i++) o[i] = R.R[i];
+  for (int i = 0; i < 3; i++) o[9 + i] = R.t[i];
+  o[12] = R.ok ? 1.0 : 0.0;
+  for (int i = 0; i < 12; i++) o[13 + i] = w.betas[i / 4][i % 4];
+  for (int i = 0; i < 3; i++) o[25 + i] = w.err[i];
+  for (int i = 0; i < 48; i++) o[28 + i] = w.v[i / 12][i % 12];
+  for (int i = 0; i < 60; i++) o[76 + i] = w.L[i];
+  for (int i = 0; i < 6; i++) o[136 + i] = w.rho[i];
+  for (int i = 0; i < 12; i++) o[142 + i] = w.AV[13 * i];
+}
+void launch_epnp_sets(hipStream_t st, const float* p3d, const float* p2d, const int* count, int cap, int n_sets, const double* K4, double* out) {
+  hipLaunchKernelGGL(k_epnp_sets, dim3(n_sets), dim3(64), 0, st, p3d, p2d, count, cap, K4[0], K4[1], K4[2], K4[3], out);
 }
 
 // ------------------------------------------------------------------------------------------------ after tracking

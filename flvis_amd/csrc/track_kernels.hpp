@@ -70,6 +70,8 @@ void launch_imu_feed(hipStream_t st, const Pipe& p);
 void launch_frame_begin(hipStream_t st, const Pipe& p, const double* d_time);
 // cv::solvePnPRansac on caller arrays (one workgroup per correspondence set): the loop closing's geometric check
 int pnp_ransac_max_points();
+constexpr int EPNP_DBG_N = 160;  // doubles per set of launch_epnp_sets's output
+void launch_epnp_sets(hipStream_t st, const float* p3d, const float* p2d, const int* count, int cap, int n_sets, const double* K4, double* out);
 void launch_pnp_ransac_sets(hipStream_t st, const float* p3d, const float* p2d, const int* count, int cap, int n_sets, const double* K4,
                             int iterative, const double* guess7, const unsigned long long* seeds, int max_iters, double reproj_px,
                             double conf, double* pose7, unsigned char* mask, int* n_inliers);

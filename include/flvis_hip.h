@@ -193,11 +193,19 @@ int flvis_loop_candidate(int g_size, const double* h_row, const uint8_t* h_prese
  * (one workgroup each): d_p3d [n_sets][cap][3] / d_p2d [n_sets][cap][2] float (what the reference casts to), d_count [n_sets]
  * (cap <= 1024), h_K4 = fx fy cx cy, h_seeds: one 64-bit seed of the sample generator per set.  Out: d_pose7 [n_sets][7]
  * (tx ty tz qx qy qz qw of T_c_w; identity when no model was found), d_inlier_mask [n_sets][cap], d_n_inliers [n_sets] (the caller
- * applies the acceptance rule of :677-686).  The tracker's solver on caller arrays: Grunert P3P hypotheses on a counter RNG + ten
- * Gauss-Newton steps on the inliers (inlier sets are statistically, not bitwise, OpenCV's). */
+ * applies the acceptance rule of :677-686).  The tracker's solver on caller arrays, cv::solvePnPRansac's structure: 4-point subsets from
+ * cv::RNG((uint64)-1) in getSubset's order (h_seeds is accepted and ignored: OpenCV seeds every run the same), P3P hypotheses (three
+ * points, the fourth picks among the solutions), RANSACUpdateNumIters, and the final solvePnP(SOLVEPNP_EPNP) on the inliers (DESIGN.md
+ * section 2 lists what is restated and what cannot be bitwise OpenCV's). */
 int flvis_hip_pnp_ransac(flvis_ctx* ctx, const float* d_p3d, const float* d_p2d, const int* d_count, int cap, int n_sets, const double* h_K4,
                          int iterations, double reproj_px, double confidence, const uint64_t* h_seeds, double* d_pose7,
                          uint8_t* d_inlier_mask, int* d_n_inliers);
+/* Test hook: cv::solvePnP(..., SOLVEPNP_EPNP) alone (the solver inside flvis_hip_pnp_ransac and the tracker's PnP RANSAC) on n_sets
+ * correspondence sets laid out as for flvis_hip_pnp_ransac (d_count[i] >= 4 points each), one wavefront per set.  d_out160 [n_sets][160]:
+ * R (9, row-major) t (3) ok (1) | betas of the three approximations (12) | their mean reprojection errors (3) | the four eigenvectors of
+ * MtM (48) | L (60) | rho (6) | the eigenvalues of MtM (12) | unused (6). */
+int flvis_hip_debug_epnp(flvis_ctx* ctx, const float* d_p3d, const float* d_p2d, const int* d_count, int cap, int n_sets, const double* h_K4,
+                         double* d_out160);
 /* loopClosureOnCovGraphG2ONew (vo_loopclosing.cpp:742-944) for n_graphs independent sequences in one launch (one workgroup per
  * pose graph): graph g has h_n_kf[g] keyframes with T_c_w (device, 7 doubles each: tx ty tz qx qy qz qw, graphs concatenated, in/out)
  * and presence flags (host, concatenated; 0 = kf_map_lc[i] == nullptr), h_n_loops[g] recorded loops (host ids: earlier, later

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "ref_api.h"
+#include "../flvis_amd/csrc/epnp_core.hpp"  // EPnP's arithmetic: the very functions the kernel runs, here with one lane
 #include "ref_math.hpp"
 
 namespace ref {
@@ -640,7 +641,32 @@ static void pnp_refine(SE3& T, const std::vector<Vec3>& pw, const std::vector<Ve
   }
 }
 
+// cv::solvePnP(..., SOLVEPNP_EPNP) on the correspondences idx[0..n) (idx == nullptr: all of 0..n): `undistortPoints` to normalised
+// coordinates stored as float (zero distortion here), which epnp::init_points maps back with `x * fu + uc`; epnp::compute_pose.
+static thread_local flvis::epnp::Work g_epnp_last;  // (tests look at the intermediate values of the last solve)
+bool solve_epnp(const float* p3d, const float* p2d, const int* idx, int n, double fx, double fy, double cx, double cy, Mat3& R, Vec3& t) {
+  flvis::epnp::Work& w = g_epnp_last;
+  auto pw = [&](int i, double* p) {
+    const int k = idx ? idx[i] : i;
+    p[0] = (double)p3d[3 * k], p[1] = (double)p3d[3 * k + 1], p[2] = (double)p3d[3 * k + 2];
+  };
+  auto uv = [&](int i, double* z) {
+    const int k = idx ? idx[i] : i;
+    z[0] = (double)(float)(((double)p2d[2 * k] - cx) / fx) * fx + cx;
+    z[1] = (double)(float)(((double)p2d[2 * k + 1] - cy) / fy) * fy + cy;
+  };
+  const flvis::epnp::Pose P = flvis::epnp::solve<1>(w, n, pw, uv, flvis::epnp::Camera{fx, fy, cx, cy}, 0, [] {});
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R.m[i][j] = P.R[3 * i + j];
+  t = {P.t[0], P.t[1], P.t[2]};
+  return P.ok;
+}
+
 // cv::solvePnPRansac(p3d, p2d, K_rect, D=0, r, t, false, iters, reprojErr, conf, inliers, ITERATIVE|P3P).
+// The RANSAC kernel: SOLVEPNP_ITERATIVE -> EPnP on 5-point subsets; SOLVEPNP_P3P -> P3P on 4-point subsets (three points give up to four
+// poses, the fourth picks the one that reprojects it best, as cv::p3p::solve does).  The final solve on the inliers:
+// SOLVEPNP_ITERATIVE -> the iterative minimisation of the reprojection error (here: 10 Gauss-Newton steps from the winning model -- the
+// minimum OpenCV's Levenberg-Marquardt converges to from its own DLT start); SOLVEPNP_P3P -> EPnP on all inliers, unrefined.
 // p3d/p2d are the float-cast values (camera_frame.cpp:415-427).  Returns #inliers (0 = no model: T untouched).
 int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, double fy, double cx, double cy,
                      bool iterative_flag, int iterations, double reproj_err, double conf, uint64_t /*seed*/, SE3& T,
@@ -663,38 +689,46 @@ int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, doubl
     } else if (!cv_get_subset(rng, n, modelPoints, 10000, nullptr, nullptr, idx)) {
       break;
     }
-    Vec3 P[3], f[3];
-    for (int k = 0; k < 3; k++) {
-      P[k] = {(double)p3d[3 * idx[k]], (double)p3d[3 * idx[k] + 1], (double)p3d[3 * idx[k] + 2]};
-      Vec3 d{((double)p2d[2 * idx[k]] - cx) / fx, ((double)p2d[2 * idx[k] + 1] - cy) / fy, 1.0};
-      f[k] = (1.0 / norm(d)) * d;
-    }
-    Mat3 Rs[4];
-    Vec3 ts[4];
-    int ns = p3p_grunert(P, f, Rs, ts);
-    if (ns == 0) continue;
-    int bk = -1;
-    double be = DBL_MAX;
-    for (int k = 0; k < ns; k++) {
-      double e = 0;
-      for (int m = 3; m < modelPoints; m++) {
-        Vec3 Pm{(double)p3d[3 * idx[m]], (double)p3d[3 * idx[m] + 1], (double)p3d[3 * idx[m] + 2]};
-        double u, v;
-        reproj(Rs[k], ts[k], Pm, fx, fy, cx, cy, u, v);
-        double du = u - (double)p2d[2 * idx[m]], dv = v - (double)p2d[2 * idx[m] + 1];
-        e += du * du + dv * dv;
+    Mat3 Rh = mat3_identity();
+    Vec3 th{0, 0, 0};
+    if (iterative_flag) {
+      if (!solve_epnp(p3d, p2d, idx, 5, fx, fy, cx, cy, Rh, th)) continue;
+    } else {
+      Vec3 P[3], f[3];
+      for (int k = 0; k < 3; k++) {
+        P[k] = {(double)p3d[3 * idx[k]], (double)p3d[3 * idx[k] + 1], (double)p3d[3 * idx[k] + 2]};
+        Vec3 d{((double)p2d[2 * idx[k]] - cx) / fx, ((double)p2d[2 * idx[k] + 1] - cy) / fy, 1.0};
+        f[k] = (1.0 / norm(d)) * d;
       }
-      if (e < be) {
-        be = e;
-        bk = k;
+      Mat3 Rs[4];
+      Vec3 ts[4];
+      int ns = p3p_grunert(P, f, Rs, ts);
+      if (ns == 0) continue;
+      int bk = -1;
+      double be = DBL_MAX;
+      for (int k = 0; k < ns; k++) {
+        double e = 0;
+        for (int m = 3; m < modelPoints; m++) {
+          Vec3 Pm{(double)p3d[3 * idx[m]], (double)p3d[3 * idx[m] + 1], (double)p3d[3 * idx[m] + 2]};
+          double u, v;
+          reproj(Rs[k], ts[k], Pm, fx, fy, cx, cy, u, v);
+          double du = u - (double)p2d[2 * idx[m]], dv = v - (double)p2d[2 * idx[m] + 1];
+          e += du * du + dv * dv;
+        }
+        if (e < be) {
+          be = e;
+          bk = k;
+        }
       }
+      if (bk < 0) continue;
+      Rh = Rs[bk];
+      th = ts[bk];
     }
-    if (bk < 0) continue;
     int good = 0;
     for (int i = 0; i < n; i++) {
       Vec3 Pi{(double)p3d[3 * i], (double)p3d[3 * i + 1], (double)p3d[3 * i + 2]};
       double u, v;
-      reproj(Rs[bk], ts[bk], Pi, fx, fy, cx, cy, u, v);
+      reproj(Rh, th, Pi, fx, fy, cx, cy, u, v);
       float du = (float)u - p2d[2 * i], dv = (float)v - p2d[2 * i + 1];  // projectPoints -> Point2f, then L2SQR in float
       float e = du * du + dv * dv;
       cur[i] = (e <= t2);
@@ -703,12 +737,27 @@ int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, doubl
     if (good > std::max(maxGood, modelPoints - 1)) {
       memcpy(mask, cur.data(), n);
       maxGood = good;
-      bestR = Rs[bk];
-      bestt = ts[bk];
+      bestR = Rh;
+      bestt = th;
       niters = ransac_update_num_iters(conf, (double)(n - good) / n, modelPoints, niters);
     }
   }
   if (maxGood == 0) return 0;
+  if (!iterative_flag) {  // SOLVEPNP_P3P: the final solvePnP on the inliers runs SOLVEPNP_EPNP
+    std::vector<int> inl;
+    for (int i = 0; i < n; i++)
+      if (mask[i]) inl.push_back(i);
+    Mat3 Rf;
+    Vec3 tf;
+    if (solve_epnp(p3d, p2d, inl.data(), (int)inl.size(), fx, fy, cx, cy, Rf, tf)) {
+      const SE3 Te = g2o_from_mat(Rf, tf);
+      T = se3_from_mat(quat_to_mat(Te.q), Te.t);  // SE3_from_rvec_tvec (common.h:151-158)
+    } else {
+      const SE3 Te = g2o_from_mat(bestR, bestt);
+      T = se3_from_mat(quat_to_mat(Te.q), Te.t);
+    }
+    return maxGood;
+  }
   SE3 Tb = g2o_from_mat(bestR, bestt);
   std::vector<Vec3> pw;
   std::vector<Vec2> z;
@@ -903,6 +952,36 @@ int ref_p3p(const double* P9, const double* f9, double* R36, double* t12) {
     t12[3 * k + 2] = ts[k].z;
   }
   return n;
+}
+int ref_solve_epnp(const float* p3d, const float* p2d, int n, const double* K4, double* R9, double* t3) {
+  ref::Mat3 R;
+  ref::Vec3 t;
+  const bool ok = ref::solve_epnp(p3d, p2d, nullptr, n, K4[0], K4[1], K4[2], K4[3], R, t);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R9[3 * i + j] = R.m[i][j];
+  t3[0] = t.x, t3[1] = t.y, t3[2] = t.z;
+  return ok ? 1 : 0;
+}
+// the 12 x 12 symmetric eigen-decomposition of epnp_core.hpp on its own: eigenvalues (unsorted) and eigenvectors (columns of V)
+void ref_epnp_last(double* betas12, double* err3, double* v48, double* L60, double* rho6) {
+  const flvis::epnp::Work& w = ref::g_epnp_last;
+  for (int q = 0; q < 3; q++) {
+    err3[q] = w.err[q];
+    for (int i = 0; i < 4; i++) betas12[4 * q + i] = w.betas[q][i];
+  }
+  for (int i = 0; i < 48; i++) v48[i] = w.v[i / 12][i % 12];
+  for (int i = 0; i < 60; i++) L60[i] = w.L[i];
+  for (int i = 0; i < 6; i++) rho6[i] = w.rho[i];
+}
+int ref_epnp_jacobi12(const double* A144, double* evals12, double* V144) {
+  static flvis::epnp::Work w;
+  for (int e = 0; e < 144; e++) w.AV[e] = A144[e], w.AV[144 + e] = (e / 12 == e % 12) ? 1.0 : 0.0;
+  flvis::epnp::jacobi12_setup(w, 0);
+  int steps = 0;
+  flvis::epnp::jacobi12(w, 0, 1, [&] { steps++; });
+  for (int i = 0; i < 12; i++) evals12[i] = w.AV[13 * i];
+  for (int e = 0; e < 144; e++) V144[e] = w.AV[144 + e];
+  return steps / 24;  // sweeps: 24 phase boundaries each
 }
 int ref_solve_pnp_ransac(const float* p3d, const float* p2d, int n, const double* K4, int iterative_flag, int iterations,
                          double reproj_err, double conf, uint64_t seed, double* pose7_inout, uint8_t* mask) {

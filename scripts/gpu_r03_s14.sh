@@ -1,0 +1,17 @@
+#!/bin/bash
+# EPnP in the PnP RANSAC: parity tests first, then the stage times of a short bench
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/r03_s14
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd "$R" || exit 1
+timeout 600 python -m pytest tests/test_gpu_loop.py -x -q -m gpu -k "pnp_ransac or verification_chain" > "$OUT/t1.log" 2>&1; tail -15 "$OUT/t1.log"
+timeout 900 python -m pytest tests/test_gpu_pipeline.py -x -q -m gpu -k "frontend_parity" > "$OUT/t2.log" 2>&1; tail -15 "$OUT/t2.log"
+cd /tmp
+timeout 300 python "$R/bench.py" --gpus 1 --steps 60 --warmup 5 --cpu-frames 0 --cpu-mt-frames 0 --no-h2d < /dev/null > "$OUT/bench.json" 2> "$OUT/bench.err"
+python - "$OUT/bench.json" <<'PY'
+import json, sys
+r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); st = r.get("stages_ms_per_step", {})
+print(r["value"], r["ms_per_step"], {k: st[k] for k in ("ransac_f", "ransac_pnp", "track_post+pose_lm") if k in st})
+PY

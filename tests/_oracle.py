@@ -162,6 +162,36 @@ def p3p(P, f):
     return R[:n], t[:n]
 
 
+def solve_epnp(p3d, p2d, K4):
+    a = np.ascontiguousarray(p3d, np.float32).reshape(-1, 3)
+    b = np.ascontiguousarray(p2d, np.float32).reshape(-1, 2)
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    f = lib().ref_solve_epnp
+    f.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    ok = f(_p(a, C.c_float), _p(b, C.c_float), len(a), _d(K4), _p(R, C.c_double), _p(t, C.c_double))
+    return bool(ok), R, t
+
+
+def epnp_last():
+    """intermediate values of this thread's last solve_epnp: betas [3,4], err [3], v [4,12], L [6,10], rho [6]"""
+    b, e, v, L, rho = np.zeros(12), np.zeros(3), np.zeros(48), np.zeros(60), np.zeros(6)
+    f = lib().ref_epnp_last
+    f.argtypes = [C.POINTER(C.c_double)] * 5
+    f.restype = None
+    f(_p(b, C.c_double), _p(e, C.c_double), _p(v, C.c_double), _p(L, C.c_double), _p(rho, C.c_double))
+    return b.reshape(3, 4), e, v.reshape(4, 12), L.reshape(6, 10), rho
+
+
+def epnp_jacobi12(A):
+    A = np.ascontiguousarray(A, np.float64)
+    ev, V = np.zeros(12), np.zeros((12, 12))
+    f = lib().ref_epnp_jacobi12
+    f.argtypes = [C.POINTER(C.c_double)] * 3
+    f.restype = C.c_int
+    sweeps = f(_p(A, C.c_double), _p(ev, C.c_double), _p(V, C.c_double))
+    return ev, V, sweeps
+
+
 def solve_pnp_ransac(p3d, p2d, K4, iterative, pose7=None, iterations=100, reproj=3.0, conf=0.99, seed=1):
     a = np.ascontiguousarray(p3d, np.float32).reshape(-1, 3)
     b = np.ascontiguousarray(p2d, np.float32).reshape(-1, 2)

@@ -89,7 +89,7 @@ def test_oracle_chain_closes_a_rendered_loop():
     assert len(closing) >= 3 and any(e["optimised"] for e in closing)
     for e in closing:                                                          # the verified pose is the true relative pose
         rel = PS.mul7(gt[e["kf_curr"]], PS.inv7(gt[e["kf_prev"]]))
-        assert np.linalg.norm(e["pose"][:3] - rel[:3]) < 0.02 and e["n_inliers"] >= 100
+        assert np.linalg.norm(e["pose"][:3] - rel[:3]) < 0.03 and e["n_inliers"] >= 100    # (EPnP on the inliers, unrefined: what SOLVEPNP_P3P ends with)
     gap0 = PS.loop_gap(np.array(odom), np.array(gt), 2, n_kf - 1)
     gap1 = PS.loop_gap(np.array(lc.T_c_w), np.array(gt), 2, n_kf - 1)
     assert gap0[0] > 0.05 and gap1[0] < 0.3 * gap0[0], (gap0, gap1)
