@@ -53,7 +53,7 @@ def test_orb_match_pnp_recovers_the_relative_pose_of_two_keyframes():
     R, t = G.pose7_to_Rt(pose)
     ang = np.degrees(np.arccos(np.clip((np.trace(R @ R_gt.T) - 1) / 2, -1, 1)))
     # (SOLVEPNP_P3P ends with EPnP on the RANSAC inliers, unrefined; the 3-D points carry the stereo triangulation's error)
-    assert ang < 1.0 and np.linalg.norm(t - t_gt) < 0.05, (ang, np.linalg.norm(t - t_gt))
+    assert ang < 1.0 and np.linalg.norm(t - t_gt) < 0.08, (ang, np.linalg.norm(t - t_gt))
     # the mutual + ratio test leaves almost only geometrically consistent pairs
     proj = (p3d[pairs[:, 0]] @ R_gt.T + t_gt)
     uv = np.stack([K4[0] * proj[:, 0] / proj[:, 2] + K4[2], K4[1] * proj[:, 1] / proj[:, 2] + K4[3]], 1)
