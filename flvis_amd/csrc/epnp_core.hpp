@@ -51,7 +51,8 @@ struct Work {
                            // rotations (columns = eigenvectors)
   double cs[6][2];         // rotation (c, s) of the six pairs of the current step
   double tol2;             // (1e-7 x mean diagonal of MtM)^2: a rotation above it keeps the sweeps going
-  int active;
+  double skip2;            // (1e-10 x mean diagonal of MtM)^2: an entry below it is not rotated
+  int active, rotated;     // this sweep needs a successor; tag of the last step that rotated something
   double v[4][12];         // the four eigenvectors used (v[0]: smallest eigenvalue)
   double L[60], rho[6];
   double betas[3][4];
@@ -351,22 +352,26 @@ EPNP_FN void jacobi_pair(int k, int m, int& p, int& q) {
   q = a < b ? b : a;
 }
 // One step is A <- J^T A J, V <- V J for the six disjoint rotations J of the step:
-//   (a) six lanes compute the rotations into w.cs.  A rotation that still has something to do (|a_pq| above 1e-7 of the matrix scale)
-//       keeps the sweeps going; a sweep without one is the last (quadratic convergence: what is left is below the matrix's rounding);
+//   (a) six lanes compute the rotations into w.cs (none for an entry below 1e-10 of the matrix scale).  A rotation that still has
+//       something to do (|a_pq| above 1e-7 of the matrix scale) keeps the sweeps going; a sweep without one is the last (quadratic
+//       convergence: what it leaves is below 1e-10 of the scale, orders below the effect of the pixels' float rounding);
 //   (b) the four entries {p, q} x {u, v} of two pairs only mix among themselves, and so do the entries {r, r + 1} x {u, v} of V:
 //       57 independent items, each reading and writing only its own entries,
 //         0..20   the 2 x 2 blocks of A's upper block triangle (row pair R <= column pair C; the lower triangle is mirrored: A stays
 //                 symmetric; in a pair's own block the rotation annihilates a_pq, which is stored as 0)
 //         21..56  two rows of V times one column pair (the rows are not rotated: the same arithmetic with the row rotation (1, 0))
 //       in ONE instruction stream: the three kinds differ in indices and selected values only.
-EPNP_FN void phase_jacobi_angles(Work& w, int k, int lane, int nl) {
+EPNP_FN void phase_jacobi_angles(Work& w, int k, int tag, int lane, int nl) {
   for (int m = lane; m < 6; m += nl) {
     int p, q;
     jacobi_pair(k, m, p, q);
     const double apq = w.AV[12 * p + q];
-    double c, s;
-    jacobi_rotation(w.AV[13 * p], w.AV[13 * q], apq, c, s);
-    if (apq * apq > w.tol2) w.active = 1;
+    double c = 1.0, s = 0.0;
+    if (apq * apq > w.skip2) {  // (threshold Jacobi: an entry below 1e-10 of the matrix scale is left alone)
+      jacobi_rotation(w.AV[13 * p], w.AV[13 * q], apq, c, s);
+      w.rotated = tag;
+      if (apq * apq > w.tol2) w.active = 1;
+    }
     w.cs[m][0] = c;
     w.cs[m][1] = s;
   }
@@ -405,9 +410,11 @@ EPNP_FN void jacobi12(Work& w, int lane, int nl, SYNC sync) {
     if (lane == 0) w.active = 0;
     sync();
     for (int k = 0; k < 11; k++) {
-      phase_jacobi_angles(w, k, lane, nl);
+      const int tag = 11 * sweep + k + 1;
+      phase_jacobi_angles(w, k, tag, lane, nl);
       sync();
-      for (int slot = lane; slot < 57; slot += nl) jacobi_item(w, k, slot);
+      if (w.rotated == tag)  // (a step without a rotation changes nothing)
+        for (int slot = lane; slot < 57; slot += nl) jacobi_item(w, k, slot);
       sync();
     }
     const int active = w.active;
@@ -425,6 +432,8 @@ EPNP_FN void jacobi12_setup(Work& w, int lane) {
 #define EPNP_TOL2 1e-14
 #endif
     w.tol2 = EPNP_TOL2 * tr * tr;
+    w.skip2 = 1e-20 * tr * tr;
+    w.rotated = 0;
   }
 }
 
