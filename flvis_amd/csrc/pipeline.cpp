@@ -74,7 +74,7 @@ struct Lane {
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
-  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr;
+  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_lm = nullptr, ev_tri = nullptr;
   int idx = 0;  // position in Pipeline::lanes
   // multi-lane trackers: ev_end[n % HOLD_RING] follows the lane's n-th frame (the context's stream waits for the frame whose
   // input buffers the caller may reuse next, see flvis_set_input_hold); ev_stagger follows the temporal LK of the lane's first
@@ -244,7 +244,7 @@ static void lane_destroy(Lane* L) {
     hipStreamDestroy(L->det_stream);
   }
   if (L->own_st && L->st) hipStreamDestroy(L->st);
-  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
+  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
                        L->ev_end[4], L->ev_end[5], L->ev_end[6], L->ev_end[7]})
     if (e) hipEventDestroy(e);
   for (int k = 0; k < Lane::BAQ; k++)
@@ -458,7 +458,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   }
   bool evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
   static_assert(Lane::HOLD_RING == 8, "event list below");
-  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
+  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
                         &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
     evok = evok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < Lane::BAQ && evok; k++)
@@ -844,25 +844,36 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // temporal LK instead of the one-workgroup-per-stream RANSAC kernels it would slow down), the right pyramid after it (only
   // the stereo matcher needs it, much later).  FLVIS_DET_ORDER=0 restores the round-1 order (A/B knob).
   static const bool gftt_first = !(getenv("FLVIS_DET_ORDER") && atoi(getenv("FLVIS_DET_ORDER")) == 0);
-  if (gftt_first) {
+  // FLVIS_DET_START (A/B knob) = where the detection stream's work starts: 0 beside the temporal LK (rounds 1-2), 1 when the LK has
+  // finished, 2 when the F-RANSAC has finished, 3 (default) like 2 with the right pyramid behind the corner detection.  Measured in one
+  // session (64 streams, local map on): 0: 1.643 ms/step (the LK is stretched from 0.40 to 0.45 ms by the corner response and the
+  // pyramid kernels), 1: 1.721 (k_ransac_f, 1024 threads per stream, goes from 0.07 to 0.18 ms under k_eig_walk), 2: 1.622, 3: 1.602:
+  // k_ransac_pnp / k_pose_lm / k_reproj_filter are latency chains on 64 CUs and leave the rest of the chip to the detection.
+  static const int gftt_after_lk = getenv("FLVIS_DET_START") ? atoi(getenv("FLVIS_DET_START")) : 3;
+  auto detect_corners = [&] {
     launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
                 (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
                 (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
     hipEventRecord(L->ev_gftt, ds);
-  }
-  if (!depth_cam) {
-    if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
-    else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
-    for (int l = 1; l <= pl->levels; l++)
-      launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
-                      l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
-  }
-  if (!gftt_first) {
-    launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
-                (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
-                (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
-  }
-  hipEventRecord(L->ev_det, ds);
+  };
+  if (gftt_first && !gftt_after_lk) detect_corners();
+  auto right_pyramid = [&] {
+    if (!depth_cam) {
+      if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
+      else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
+      for (int l = 1; l <= pl->levels; l++)
+        launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
+                        l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
+    }
+    if (!gftt_first) {
+      launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
+                  (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
+                  (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
+    }
+    hipEventRecord(L->ev_det, ds);
+  };
+  const bool pyramid_late = gftt_first && gftt_after_lk == 3;  // 3: the right pyramid waits for the F-RANSAC too
+  if (!pyramid_late) right_pyramid();
   // temporal tracking
   PB(4, st);
   {
@@ -874,6 +885,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track, pl->max_pts);
   }
   PE(4, st);
+  if (gftt_first && gftt_after_lk == 1) {
+    hipEventRecord(L->ev_lm, st);
+    hipStreamWaitEvent(ds, L->ev_lm, 0);
+    detect_corners();
+  }
   PB(5, st);
   launch_track_collect(st, p);
   PE(5, st);
@@ -881,6 +897,12 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(6, st);
   launch_ransac_f(st, p);
   PE(6, st);
+  if (gftt_first && gftt_after_lk >= 2) {
+    hipEventRecord(L->ev_lm, st);
+    hipStreamWaitEvent(ds, L->ev_lm, 0);
+    detect_corners();
+    if (pyramid_late) right_pyramid();
+  }
   PB(7, st);
   launch_ransac_pnp(st, p);
   PE(7, st);
@@ -900,8 +922,13 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(13, st);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
   PB(14, st);
-  launch_depth_prepare(st, p);
+  launch_depth_seeds(st, p);
   PE(14, st);
+  // the two-view triangulation that k_depth_innovate consumes: on the detection stream (idle by now), under the stereo LK
+  hipEventRecord(L->ev_lm, st);
+  hipStreamWaitEvent(ds, L->ev_lm, 0);
+  launch_depth_triangulate(ds, p);
+  hipEventRecord(L->ev_tri, ds);
   if (gftt_first) hipStreamWaitEvent(st, L->ev_det, 0);
   PB(15, st);
   if (!depth_cam) {
@@ -916,6 +943,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts);
   }
   PE(15, st);
+  hipStreamWaitEvent(st, L->ev_tri, 0);
   PB(16, st);
   launch_depth_innovate(st, p);
   PE(16, st);

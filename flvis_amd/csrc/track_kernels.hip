@@ -1813,7 +1813,9 @@ __global__ __launch_bounds__(64) void k_add_new(Pipe p) {
 }
 
 // ------------------------------------------------------------------------------------------------ depth: inputs
-__global__ __launch_bounds__(256) void k_depth_prepare(Pipe p) {
+// Two kernels, because only the first is on the critical path: the stereo matcher needs its seeds; the two-view triangulation of
+// recover3DPts_c_FromTriangulation is consumed by k_depth_innovate and runs beside the stereo LK on the detection stream.
+__global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
   const int s = blockIdx.y;
   const StreamState& st = p.st[s];
   if (p.det_mode[s] == 0) return;
@@ -1821,6 +1823,31 @@ __global__ __launch_bounds__(256) void k_depth_prepare(Pipe p) {
   const int n = st.n_lm[cur];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) p.lk_count[s] = n;
+  if (i >= n) return;
+  if (p.cam.cam_type == CAM_DEPTH) return;  // the measurement comes from the depth image, no stereo matching
+  const Landmark& lm = lm_ptr(p, cur, s)[i];
+  // stereo LK seeds (camera_frame.cpp:108-122)
+  float* p0 = p.prev_pts + ((size_t)s * NMAX + i) * 2;
+  float* p1 = p.next_pts + ((size_t)s * NMAX + i) * 2;
+  p0[0] = (float)lm.p2d[0];
+  p0[1] = (float)lm.p2d[1];
+  if (lm.has3d) {
+    const SE3d T = load_pose7(st.T_c_w[cur]);
+    SE3d T1c = se3_mul(load_pose7(p.cam.T_c1_c0), T);
+    float p3[3] = {(float)lm.p3w[0], (float)lm.p3w[1], (float)lm.p3w[2]};
+    project_point(p3, q_to_mat(T1c.q), T1c.t, p.cam.K1, p.cam.D1, p1);
+  } else {
+    p1[0] = p0[0];
+    p1[1] = p0[1];
+  }
+}
+__global__ __launch_bounds__(256) void k_depth_triangulate(Pipe p) {
+  const int s = blockIdx.y;
+  const StreamState& st = p.st[s];
+  if (p.det_mode[s] == 0) return;
+  const int cur = st.cur;
+  const int n = st.n_lm[cur];
+  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const Landmark& lm = lm_ptr(p, cur, s)[i];
   const SE3d T = load_pose7(st.T_c_w[cur]);
@@ -1842,20 +1869,6 @@ __global__ __launch_bounds__(256) void k_depth_prepare(Pipe p) {
     }
   }
   p.tri_mask[(size_t)s * NMAX + i] = tm;
-  if (p.cam.cam_type == CAM_DEPTH) return;  // the measurement comes from the depth image, no stereo matching
-  // stereo LK seeds (camera_frame.cpp:108-122)
-  float* p0 = p.prev_pts + ((size_t)s * NMAX + i) * 2;
-  float* p1 = p.next_pts + ((size_t)s * NMAX + i) * 2;
-  p0[0] = (float)lm.p2d[0];
-  p0[1] = (float)lm.p2d[1];
-  if (lm.has3d) {
-    SE3d T1c = se3_mul(load_pose7(p.cam.T_c1_c0), T);
-    float p3[3] = {(float)lm.p3w[0], (float)lm.p3w[1], (float)lm.p3w[2]};
-    project_point(p3, q_to_mat(T1c.q), T1c.t, p.cam.K1, p.cam.D1, p1);
-  } else {
-    p1[0] = p0[0];
-    p1[1] = p0[1];
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ depth innovation
@@ -2150,8 +2163,11 @@ hipError_t track_kernels_init() {
 }
 void launch_reproj_filter(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_reproj_filter, dim3(p.S), dim3(NMAX), 0, st, p); }
 void launch_add_new(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_add_new, dim3(p.S), dim3(64), 0, st, p); }
-void launch_depth_prepare(hipStream_t st, const Pipe& p) {
-  hipLaunchKernelGGL(k_depth_prepare, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
+void launch_depth_seeds(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_depth_seeds, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
+}
+void launch_depth_triangulate(hipStream_t st, const Pipe& p) {
+  hipLaunchKernelGGL(k_depth_triangulate, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
 }
 void launch_depth_innovate(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_depth_innovate, dim3(p.S), dim3(NMAX), 0, st, p); }
 void launch_frame_end(hipStream_t st, const Pipe& p) {

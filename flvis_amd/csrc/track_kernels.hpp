@@ -86,7 +86,8 @@ void launch_track_post(hipStream_t st, const Pipe& p);
 void launch_pose_lm(hipStream_t st, const Pipe& p);
 void launch_reproj_filter(hipStream_t st, const Pipe& p);
 void launch_add_new(hipStream_t st, const Pipe& p);
-void launch_depth_prepare(hipStream_t st, const Pipe& p);
+void launch_depth_seeds(hipStream_t st, const Pipe& p);        // stereo-LK seeds of the current landmarks (critical path)
+void launch_depth_triangulate(hipStream_t st, const Pipe& p);  // two-view triangulation for k_depth_innovate (beside the stereo LK)
 void launch_depth_innovate(hipStream_t st, const Pipe& p);
 void launch_frame_end(hipStream_t st, const Pipe& p);
 // local map

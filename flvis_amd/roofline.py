@@ -125,7 +125,7 @@ def kernel_table(stages, S, w, h, copy_gbs, pmc=None, ba=None, ms_per_step=None)
     # the one-workgroup-per-stream chain
     chain = [("k_frame_head", ("imu_feed+frame_begin",)), ("k_ransac_f", ("ransac_f",)), ("k_ransac_pnp", ("ransac_pnp",)),
              ("k_track_post + k_pose_lm", ("track_post+pose_lm",)), ("k_reproj_filter", ("reproj_filter",)),
-             ("k_feature_dem + k_add_new", ("feature_dem+add_new",)), ("k_depth_prepare", ("depth_prepare",)),
+             ("k_feature_dem + k_add_new", ("feature_dem+add_new",)), ("k_depth_seeds", ("depth_prepare",)),
              ("k_depth_innovate", ("depth_innovate",)), ("k_frame_end", ("frame_end",))]
     for name, st in chain:
         ms = _ms(stages, *st)
