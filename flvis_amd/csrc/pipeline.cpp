@@ -355,6 +355,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   DA(gftt_act, int, S);
   DA(gftt_maxc, int, S);
   DA(img_slot, int, S);
+  DA(img_slot_in, int, S);
   DA(out, FrameOut, S);
   DA(kfq, KeyFrameDev, (size_t)S * KFQ);
   DA(kfq_tail, unsigned, S);
@@ -436,6 +437,10 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
     hseed[s] = seed_base + (unsigned long long)(s0 + s);  // the seed of a stream does not depend on the lane partition
   }
   hipMemcpy(p.st, hs.data(), sizeof(StreamState) * S, hipMemcpyHostToDevice);
+  {
+    std::vector<int> one(S, 1);  // cur = 0: the first image goes to slot 1
+    hipMemcpy(p.img_slot_in, one.data(), sizeof(int) * S, hipMemcpyHostToDevice);
+  }
   hipMemcpy(seeds, hseed.data(), sizeof(unsigned long long) * S, hipMemcpyHostToDevice);
   L->h_imu.assign((size_t)S * IMU_MAX * 7, 0.0);
   L->h_nimu.assign(S, 0);
@@ -782,11 +787,43 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
 #define PE(i, strm) \
   if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i) + 1], strm)
   PB(19, st);  // the whole main-stream chain of this frame: per-frame GPU latency (p50/p99 in bench.py)
+  const bool skipped = pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs;
+  const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
+  const bool eq = pl->cfg.need_equal_hist != 0;
+  const bool aligned = (w & 15) == 0;  // otherwise (KITTI: 1241 x 376, tightly packed rows) both images are copied into pitch-aligned level 0
+  hipStream_t ds = L->det_stream;
+  ImgSel in0 = img_indirect(L->d_tab + 0), in1 = img_indirect(L->d_tab + 1);
+  ImgSel l0cur{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot, 0, nullptr};
+  if (!skipped) {
+    // left image -> level 0 of the slot this frame is going to use (+ the pyramid), on the detection stream BESIDE k_frame_head: the
+    // slot was fixed when the previous frame ended (img_slot_in), so the image work does not wait for the IMU integration and the
+    // state machine (one thread per stream, 45 us).  Every stream's image is ingested, also that of a stream this frame leaves idle.
+    // Without equalizeHist the first pyrDown reads the caller's image and writes level 0 and level 1 in one pass; with it the
+    // equalised image is level 0.
+    ImgSel l0in{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot_in, 0, nullptr};
+    hipEventRecord(L->ev_lm, st);  // (the frame's input table has been uploaded)
+    hipStreamWaitEvent(ds, L->ev_lm, 0);
+    PB(1, ds);
+    if (eq) launch_equalize_hist(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, nullptr);
+    else if (!aligned) launch_copy_image_any(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
+    PE(1, ds);
+    PB(2, ds);
+    for (int l = 1; l <= pl->levels; l++) {  // left pyramid: needed by the temporal tracker right away
+      ImgSel s0{{L->pyr0[0][l - 1], L->pyr0[1][l - 1]}, p.img_slot_in, 0, nullptr}, d0{{L->pyr0[0][l], L->pyr0[1][l]}, p.img_slot_in, 0, nullptr};
+      if (l == 1 && !eq && aligned)
+        launch_pyr_down_ingest(ds, in0, w, h, w, (size_t)w * h, l0in, pl->lpitch[0], pl->lstride[0], d0, pl->lpitch[1], pl->lstride[1], S, nullptr);
+      else
+        launch_pyr_down(ds, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, nullptr);
+    }
+    if (pl->levels == 0 && !eq && aligned) launch_copy_image(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
+    PE(2, ds);
+    hipEventRecord(L->ev_img, ds);
+  }
   PB(0, st);
   launch_frame_head(st, p, L->d_time, L->d_progress, frame_no);  // the staged IMU samples, then frame_begin
   if (pl->feedback_used) launch_apply_correction(st, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
   PE(0, st);
-  if (pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs) {
+  if (skipped) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
     PB(17, st);
@@ -805,37 +842,14 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // that from then on the image kernels of one lane overlap the one-workgroup-per-stream geometry chain of another
   const bool first_processed = pl->frames_fed == (long long)pl->cfg.skip_first_n_imgs;
   if (first_processed && pl->stagger && L->idx > 0) hipStreamWaitEvent(st, pl->lanes[L->idx - 1]->ev_stagger, 0);
-  const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
-  const bool eq = pl->cfg.need_equal_hist != 0;
-  const bool aligned = (w & 15) == 0;  // otherwise (KITTI: 1241 x 376, tightly packed rows) both images are copied into pitch-aligned level 0
-  // left image -> level 0 of the stream's current slot (+ the pyramid).  Without equalizeHist the first pyrDown reads the
-  // caller's image and writes level 0 and level 1 in one pass; with it the equalised image is level 0.
-  ImgSel in0 = img_indirect(L->d_tab + 0), in1 = img_indirect(L->d_tab + 1);
-  ImgSel l0cur{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot, 0, nullptr};
-  // (the guesses of the temporal tracker only need the state frame_begin left: launched before the chain hands over to the image stream)
+  // (the guesses of the temporal tracker only need the state frame_begin left)
   PB(3, st);
   launch_track_prepare(st, p);
   PE(3, st);
-  PB(1, st);
-  if (eq) launch_equalize_hist(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
-  else if (!aligned) launch_copy_image_any(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
-  PE(1, st);
-  PB(2, st);
-  for (int l = 1; l <= pl->levels; l++) {  // left pyramid: needed by the temporal tracker right away
-    ImgSel s0{{L->pyr0[0][l - 1], L->pyr0[1][l - 1]}, p.img_slot, 0, nullptr}, d0{{L->pyr0[0][l], L->pyr0[1][l]}, p.img_slot, 0, nullptr};
-    if (l == 1 && !eq && aligned)
-      launch_pyr_down_ingest(st, in0, w, h, w, (size_t)w * h, l0cur, pl->lpitch[0], pl->lstride[0], d0, pl->lpitch[1], pl->lstride[1], S, p.act_img);
-    else
-      launch_pyr_down(st, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, p.act_img);
-  }
-  if (pl->levels == 0 && !eq && aligned) launch_copy_image(st, in0, l0cur, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
-  PE(2, st);
+  hipStreamWaitEvent(st, L->ev_img, 0);  // join: the left pyramid
   // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
   // for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain.  The right image is only
   // read within this frame, so without equalizeHist the caller's buffer IS level 0 of the right pyramid (no copy).
-  hipStream_t ds = L->det_stream;
-  hipEventRecord(L->ev_img, st);
-  hipStreamWaitEvent(ds, L->ev_img, 0);
   const bool r_in_place = !eq && aligned;
   ImgSel r0 = r_in_place ? in1 : img_plain(L->pyr1[0]);
   const int r0pitch = r_in_place ? w : pl->lpitch[0];

@@ -2028,6 +2028,7 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
   __syncthreads();
   const int cur = st.cur;  // curr_frame as the caller sees it after image_feed
   if (lane == 0) {
+    p.img_slot_in[s] = cur ^ 1;  // where the next frame's left image goes (frame_begin flips `cur` first thing)
     s_newkf = st.new_kf;
     FrameOut& o = p.out[s];
     o.state = st.state;

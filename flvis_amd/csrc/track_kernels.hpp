@@ -35,6 +35,7 @@ struct Pipe {
   int* gftt_act;            // [S] corner detection planned at frame begin (init frames; tracking frames speculatively)
   int* gftt_maxc;           // [S] its maxCorners
   int* img_slot;            // [S] image slot of the current frame
+  int* img_slot_in;         // [S] image slot the NEXT frame's left image is written to (k_frame_end; known before k_frame_head runs)
   FrameOut* out;            // [S]
   double* traj;             // [S][traj_cap][9]  (t, pose7, state|kf<<4) or nullptr
   int traj_cap;
