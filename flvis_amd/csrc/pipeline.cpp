@@ -921,8 +921,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   launch_ransac_pnp(st, p);
   PE(7, st);
   PB(8, st);
-  launch_track_post(st, p);
-  launch_pose_lm(st, p);
+  launch_pose_lm(st, p);  // (with k_track_post's work in its prologue)
   PE(8, st);
   PB(9, st);
   launch_reproj_filter(st, p);

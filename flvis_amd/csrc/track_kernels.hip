@@ -1445,14 +1445,13 @@ void launch_epnp_sets(hipStream_t st, const float* p3d, const float* p2d, const 
 }
 
 // ------------------------------------------------------------------------------------------------ after tracking
-__global__ void k_track_post(Pipe p) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= p.S) return;
+// LKORBTracking::tracking's tail (lkorb_tracking.cpp:179-199): fewer than 10 PnP inliers fail the frame; otherwise the roll / pitch of
+// the PnP pose are pulled towards the IMU attitude.  One thread per stream; false: the frame has failed.
+__device__ inline bool track_post_dev(const Pipe& p, int s) {
   StreamState& st = p.st[s];
-  if (st.phase != PH_TRACK) return;
   if (!st.ok) {
     track_fail(st);
-    return;
+    return false;
   }
   st.cont_fail = 0;
   if (st.has_imu) {
@@ -1461,6 +1460,13 @@ __global__ void k_track_post(Pipe p) {
     vi_vision_rp_compensation(p.cam, ring, st.frame_time[st.cur], T);
     store_pose7(st.T_c_w[st.cur], T);
   }
+  return true;
+}
+__global__ void k_track_post(Pipe p) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.S) return;
+  if (p.st[s].phase != PH_TRACK) return;
+  track_post_dev(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------ pose-only LM
@@ -1620,6 +1626,9 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
   const int nl = st.n_lm[cur];
   PoseLMShared& sh = *reinterpret_cast<PoseLMShared*>(pl_smem);
   long long* ids = reinterpret_cast<long long*>(sh.terms);
+  // the tail of the tracking step (k_track_post's work) by one lane of wave 1, while wave 0 gathers the edges
+  __shared__ int s_go;
+  if (tid == 64) s_go = track_post_dev(p, s) ? 1 : 0;
   // gather the edges (has3d && inlier) in frame order (wave 0)
   if (tid < 64) {
     int n = 0;
@@ -1639,6 +1648,7 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
     if (lane == 0) sh.n = n < PL_EMAX ? n : PL_EMAX;
   }
   __syncthreads();
+  if (!s_go) return;  // the frame failed before the pose optimisation (track_fail has run)
   const int n = sh.n;
   bool ok = n >= 10;
   if (ok) {
