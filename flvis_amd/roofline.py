@@ -100,13 +100,13 @@ def kernel_table(stages, S, w, h, copy_gbs, pmc=None, ba=None, ms_per_step=None)
         row = {"kernel": "k_lk_track (%s)" % tag, "bound": "valu_issue", "launches_per_step": 1, "avg_launch_ms": round(ms, 4),
                "algorithmic_bytes_per_launch": int(b), "achieved_GBs": round(b / (ms * 1e-3) / 1e9, 1),
                "frac_of_hbm_peak": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-               "note": "one wave per point; the temporal launch shares the chip with the corner response on purpose"}
+               "note": "one wave per point; both launches share the chip with the local-map workers only"}
         counters("k_lk_track", row)
         rows.append(row)
     # corner response
     e = _ms(stages, "gftt:eig_cand")
     if e > 0:
-        row = scan("k_eig_walk", e, img * S, 1, "corner response, one pass over the left image; runs under the temporal LK")
+        row = scan("k_eig_walk", e, img * S, 1, "corner response, one pass over the left image; runs beside the PnP RANSAC / pose LM chain (detection stream)")
         row["bound"] = "valu_issue"
         counters("k_eig_walk", row)
         rows.append(row)
@@ -124,7 +124,7 @@ def kernel_table(stages, S, w, h, copy_gbs, pmc=None, ba=None, ms_per_step=None)
         rows.append(row)
     # the one-workgroup-per-stream chain
     chain = [("k_frame_head", ("imu_feed+frame_begin",)), ("k_ransac_f", ("ransac_f",)), ("k_ransac_pnp", ("ransac_pnp",)),
-             ("k_track_post + k_pose_lm", ("track_post+pose_lm",)), ("k_reproj_filter", ("reproj_filter",)),
+             ("k_pose_lm", ("track_post+pose_lm",)), ("k_reproj_filter", ("reproj_filter",)),
              ("k_feature_dem + k_add_new", ("feature_dem+add_new",)), ("k_depth_seeds", ("depth_prepare",)),
              ("k_depth_innovate", ("depth_innovate",)), ("k_frame_end", ("frame_end",))]
     for name, st in chain:
