@@ -1281,11 +1281,13 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
       if (!solve_spd6(H, b, dx)) break;
+      // CvLevMarq's termination test (relative change of the six parameters below FLT_EPSILON), on the increment
+      const double pn = 4.0 * (Tb.q.x * Tb.q.x + Tb.q.y * Tb.q.y + Tb.q.z * Tb.q.z) + (Tb.t.x * Tb.t.x + Tb.t.y * Tb.t.y + Tb.t.z * Tb.t.z);
       Tb = g2o_mul(g2o_exp(dx), Tb);
       double nn = 0;
 #pragma unroll
       for (int k = 0; k < 6; k++) nn += dx[k] * dx[k];
-      if (nn < 1e-20) break;
+      if (nn < 1e-20 || nn < 1.4210854715202004e-14 * pn) break;  // FLT_EPSILON^2
     }
     T = se3_from_mat(q_to_mat(Tb.q), Tb.t);
   }

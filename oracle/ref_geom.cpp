@@ -634,10 +634,14 @@ static void pnp_refine(SE3& T, const std::vector<Vec3>& pw, const std::vector<Ve
     }
     double dx[6];
     if (!solve_spd6(H, b, dx)) break;
+    // CvLevMarq's termination test of cvFindExtrinsicCameraParams2 (criteria: 20 iterations / FLT_EPSILON): the relative change of
+    // the six parameters (rotation vector, translation) -- evaluated on the increment against the norm of the parameters before
+    // the step, the rotation vector's length taken as 2 |q_v|
+    const double pn = 4.0 * (T.q.x * T.q.x + T.q.y * T.q.y + T.q.z * T.q.z) + (T.t.x * T.t.x + T.t.y * T.t.y + T.t.z * T.t.z);
     T = g2o_mul(g2o_exp(dx), T);
     double nn = 0;
     for (int k = 0; k < 6; k++) nn += dx[k] * dx[k];
-    if (nn < 1e-20) break;
+    if (nn < 1e-20 || nn < 1.4210854715202004e-14 * pn) break;  // FLT_EPSILON^2
   }
 }
 
