@@ -57,6 +57,7 @@ struct Work {
   double L[60], rho[6];
   double betas[3][4];
   double R[3][9], t[3][3], err[3];
+  double sgn[3];           // per approximation: -1 when the first camera-frame point came out behind the camera (solve_for_sign)
   double acc[3][16];       // per approximation: centroid sums / ABt of the absolute orientation
   double ccs[3][4][3];     // per approximation: control points in the camera frame
 };
@@ -271,28 +272,67 @@ EPNP_UNROLL
   }
 }
 
-// ---- the phases.  `lane` of `nl` lanes takes the elements lane, lane + nl, ...; the caller separates the phases by a barrier ----------
-// points: world points pw(i) and pixel coordinates uv(i) through accessors, so that callers keep their own layouts
+// ---- the phases.  `lane` of `nl` lanes takes the elements lane, lane + nl, ...; `sync` separates what one lane writes from what another
+// reads (a no-op for one lane).  Points: world points pw(i) and pixel coordinates uv(i) through accessors, so that callers keep their own
+// layouts.
+//
+// Sums over the correspondences have ONE definition whatever the number of lanes: the sum over i < n is the sum, in chunk order, of the
+// sequential sums over chunks of consecutive correspondences; a chunk is 16 correspondences long up to n = 256, 32 up to 512, 64 up to
+// 1024 (never more than 16 chunks).  For a RANSAC sample (5) that is the plain sequential sum; beyond 16 correspondences (entry, chunk)
+// pairs are independent work items and `part` (entries x chunks doubles, <= 144 x 16) holds the chunk sums.
+// acc(e, i, s): add correspondence i's term(s) of entry e to s;  out(e, s): store entry e's sum.
+constexpr int PART_DOUBLES = 144 * 16;
+EPNP_FN int chunk_len(int n) { return n <= 256 ? 16 : (n <= 512 ? 32 : 64); }
+template <class ACC, class OUT, class SYNC>
+EPNP_FN void chunked_sums(int n, int entries, double* part, int lane, int nl, SYNC sync, ACC acc, OUT out) {
+  const int CHUNK = chunk_len(n), nch = (n + CHUNK - 1) / CHUNK;
+  if (nch <= 1) {
+    for (int e = lane; e < entries; e += nl) {
+      double s = 0;
+      for (int i = 0; i < n; i++) acc(e, i, s);
+      out(e, s);
+    }
+    sync();
+    return;
+  }
+  for (int item = lane; item < entries * nch; item += nl) {
+    const int e = item / nch, c = item - e * nch;
+    const int i1 = (c + 1) * CHUNK < n ? (c + 1) * CHUNK : n;
+    double s = 0;
+    for (int i = c * CHUNK; i < i1; i++) acc(e, i, s);
+    part[item] = s;
+  }
+  sync();
+  for (int e = lane; e < entries; e += nl) {
+    double s = 0;
+    for (int c = 0; c < nch; c++) s += part[e * nch + c];
+    out(e, s);
+  }
+  sync();
+}
 
-// phase 0 (lane 0): control points and the inverse of the control-point basis
-template <class PW>
-EPNP_FN void phase_control_points(Work& w, int n, PW pw, int lane) {
+// control points and the inverse of the control-point basis (the two sums by everybody, the rest by lane 0)
+template <class PW, class SYNC>
+EPNP_FN void phase_control_points(Work& w, int n, PW pw, double* part, int lane, int nl, SYNC sync) {
+  chunked_sums(n, 3, part, lane, nl, sync,
+               [&](int e, int i, double& s) {
+                 double p[3];
+                 pw(i, p);
+                 s += p[e];
+               },
+               [&](int e, double s) { w.cws[0][e] = s / n; });
+  chunked_sums(n, 9, part, lane, nl, sync,
+               [&](int e, int i, double& s) {
+                 double p[3];
+                 pw(i, p);
+                 const int r = e / 3, c = e - 3 * r;
+                 s += (p[r] - w.cws[0][r]) * (p[c] - w.cws[0][c]);
+               },
+               [&](int e, double s) { w.acc[0][e] = s; });
   if (lane != 0) return;
-  double c0[3] = {0, 0, 0};
-  for (int i = 0; i < n; i++) {
-    double p[3];
-    pw(i, p);
-    c0[0] += p[0], c0[1] += p[1], c0[2] += p[2];
-  }
-  for (int j = 0; j < 3; j++) c0[j] /= n, w.cws[0][j] = c0[j];
-  double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < n; i++) {
-    double p[3];
-    pw(i, p);
-    const double d[3] = {p[0] - c0[0], p[1] - c0[1], p[2] - c0[2]};
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) S[3 * r + c] += d[r] * d[c];
-  }
+  const double c0[3] = {w.cws[0][0], w.cws[0][1], w.cws[0][2]};
+  double S[9];
+  for (int e = 0; e < 9; e++) S[e] = w.acc[0][e];
   double dc[3], uct[9];
   sym3_eig_desc(S, dc, uct);
   for (int i = 1; i < 4; i++) {
@@ -316,29 +356,29 @@ EPNP_FN void phase_control_points(Work& w, int n, PW pw, int lane) {
   w.ci[8] = (cc[0] * cc[4] - cc[1] * cc[3]) * id;
 }
 
-// phase 1: MtM (all 144 entries, each summed over the 2 n rows of M in row order) into A; V = identity
-template <class PW, class UV>
-EPNP_FN void phase_mtm(Work& w, int n, PW pw, UV uv, Camera cam, int lane, int nl) {
-  for (int e = lane; e < 144; e += nl) {
-    const int r = e / 12, c = e - 12 * r;
-    const int jr = r / 3, kr = r - 3 * jr, jc = c / 3, kc = c - 3 * jc;
-    double s = 0;
-    for (int i = 0; i < n; i++) {
-      double p[3], a[4], z[2];
-      pw(i, p);
-      uv(i, z);
-      alphas_of(w, p, a);
-      // rows M1 = [a fu, 0, a (uc - u)], M2 = [0, a fv, a (vc - v)] per control point
-      const double m1r = kr == 0 ? a[jr] * cam.fu : (kr == 1 ? 0.0 : a[jr] * (cam.uc - z[0]));
-      const double m1c = kc == 0 ? a[jc] * cam.fu : (kc == 1 ? 0.0 : a[jc] * (cam.uc - z[0]));
-      const double m2r = kr == 0 ? 0.0 : (kr == 1 ? a[jr] * cam.fv : a[jr] * (cam.vc - z[1]));
-      const double m2c = kc == 0 ? 0.0 : (kc == 1 ? a[jc] * cam.fv : a[jc] * (cam.vc - z[1]));
-      s += m1r * m1c;
-      s += m2r * m2c;
-    }
-    w.AV[e] = s;
-    w.AV[144 + e] = r == c ? 1.0 : 0.0;
-  }
+// MtM (all 144 entries, each summed over the 2 n rows of M in row order) into A; V = identity
+template <class PW, class UV, class SYNC>
+EPNP_FN void phase_mtm(Work& w, int n, PW pw, UV uv, Camera cam, double* part, int lane, int nl, SYNC sync) {
+  chunked_sums(n, 144, part, lane, nl, sync,
+               [&](int e, int i, double& s) {
+                 const int r = e / 12, c = e - 12 * r;
+                 const int jr = r / 3, kr = r - 3 * jr, jc = c / 3, kc = c - 3 * jc;
+                 double p[3], a[4], z[2];
+                 pw(i, p);
+                 uv(i, z);
+                 alphas_of(w, p, a);
+                 // rows M1 = [a fu, 0, a (uc - u)], M2 = [0, a fv, a (vc - v)] per control point
+                 const double m1r = kr == 0 ? a[jr] * cam.fu : (kr == 1 ? 0.0 : a[jr] * (cam.uc - z[0]));
+                 const double m1c = kc == 0 ? a[jc] * cam.fu : (kc == 1 ? 0.0 : a[jc] * (cam.uc - z[0]));
+                 const double m2r = kr == 0 ? 0.0 : (kr == 1 ? a[jr] * cam.fv : a[jr] * (cam.vc - z[1]));
+                 const double m2c = kc == 0 ? 0.0 : (kc == 1 ? a[jc] * cam.fv : a[jc] * (cam.vc - z[1]));
+                 s += m1r * m1c;
+                 s += m2r * m2c;
+               },
+               [&](int e, double s) {
+                 w.AV[e] = s;
+                 w.AV[144 + e] = (e / 12 == e % 12) ? 1.0 : 0.0;
+               });
 }
 
 // ---- the 12 x 12 eigen-decomposition -------------------------------------------------------------------------------------------------
@@ -546,77 +586,75 @@ EPNP_FN void pcs_of(const Work& w, int q, const double* a, double* pc) {
   for (int j = 0; j < 3; j++) pc[j] = a[0] * w.ccs[q][0][j] + a[1] * w.ccs[q][1][j] + a[2] * w.ccs[q][2][j] + a[3] * w.ccs[q][3][j];
 }
 
-// sums of the absolute orientation: for approximation q = e / 16, entry k = e % 16: k < 3 centroid of the camera points, k < 6 of the
-// world points, then (after phase_centroids) the nine entries of ABt.  solve_for_sign: all camera points flip when pcs[0].z < 0.
+// sums of the absolute orientation, for the three approximations at once: centroids of the camera points (k < 3) and of the world points
+// (k < 6), then the nine entries of ABt.  solve_for_sign: all camera points flip when pcs[0].z < 0.
 template <class PW>
-EPNP_FN void phase_centroids(Work& w, int n, PW pw, int lane, int nl) {
-  for (int e = lane; e < 18; e += nl) {
-    const int q = e / 6, k = e - 6 * q;
-    double p0[3], a0[4], pc0[3];
-    pw(0, p0);
-    alphas_of(w, p0, a0);
-    pcs_of(w, q, a0, pc0);
-    const double sign = pc0[2] < 0 ? -1.0 : 1.0;
-    double s = 0;
-    for (int i = 0; i < n; i++) {
-      double p[3];
-      pw(i, p);
-      if (k < 3) {
-        double a[4], pc[3];
-        alphas_of(w, p, a);
-        pcs_of(w, q, a, pc);
-        s += sign * pc[k];
-      } else {
-        s += p[k - 3];
-      }
-    }
-    w.acc[q][k] = s / n;
-  }
+EPNP_FN double sign_of(const Work& w, int q, PW pw) {
+  double p0[3], a0[4], pc0[3];
+  pw(0, p0);
+  alphas_of(w, p0, a0);
+  pcs_of(w, q, a0, pc0);
+  return pc0[2] < 0 ? -1.0 : 1.0;
 }
-template <class PW>
-EPNP_FN void phase_abt(Work& w, int n, PW pw, int lane, int nl) {
-  for (int e = lane; e < 27; e += nl) {
-    const int q = e / 9, k = e - 9 * q, r = k / 3, c = k - 3 * r;
-    double p0[3], a0[4], pc0[3];
-    pw(0, p0);
-    alphas_of(w, p0, a0);
-    pcs_of(w, q, a0, pc0);
-    const double sign = pc0[2] < 0 ? -1.0 : 1.0;
-    double s = 0;
-    for (int i = 0; i < n; i++) {
-      double p[3], a[4], pc[3];
-      pw(i, p);
-      alphas_of(w, p, a);
-      pcs_of(w, q, a, pc);
-      s += (sign * pc[r] - w.acc[q][r]) * (p[c] - w.acc[q][3 + c]);
-    }
-    w.acc[q][6 + k] = s;
-  }
+template <class PW, class SYNC>
+EPNP_FN void phase_centroids(Work& w, int n, PW pw, double* part, int lane, int nl, SYNC sync) {
+  for (int q = lane; q < 3; q += nl) w.sgn[q] = sign_of(w, q, pw);
+  sync();
+  chunked_sums(n, 18, part, lane, nl, sync,
+               [&](int e, int i, double& s) {
+                 const int q = e / 6, k = e - 6 * q;
+                 double p[3];
+                 pw(i, p);
+                 if (k < 3) {
+                   double a[4], pc[3];
+                   alphas_of(w, p, a);
+                   pcs_of(w, q, a, pc);
+                   s += w.sgn[q] * pc[k];
+                 } else {
+                   s += p[k - 3];
+                 }
+               },
+               [&](int e, double s) { w.acc[e / 6][e % 6] = s / n; });
 }
-// R, t of approximation q and its mean reprojection error
-template <class PW, class UV>
-EPNP_FN void pose_of(Work& w, int q, int n, PW pw, UV uv, Camera cam) {
-  double* R = w.R[q];
-  arun_rotation(&w.acc[q][6], R);
-  for (int i = 0; i < 3; i++)
-    w.t[q][i] = w.acc[q][i] - (R[3 * i] * w.acc[q][3] + R[3 * i + 1] * w.acc[q][4] + R[3 * i + 2] * w.acc[q][5]);
-  double sum2 = 0;
-  for (int i = 0; i < n; i++) {
-    double p[3], z[2];
-    pw(i, p);
-    uv(i, z);
-    const double Xc = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + w.t[q][0];
-    const double Yc = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + w.t[q][1];
-    const double inv_Zc = 1.0 / (R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + w.t[q][2]);
-    const double ue = cam.uc + cam.fu * Xc * inv_Zc, ve = cam.vc + cam.fv * Yc * inv_Zc;
-    sum2 += sqrt((z[0] - ue) * (z[0] - ue) + (z[1] - ve) * (z[1] - ve));
-  }
-  const double e = sum2 / n;
-  w.err[q] = e == e ? e : 1e300;  // (NaN: a degenerate approximation never wins)
+template <class PW, class SYNC>
+EPNP_FN void phase_abt(Work& w, int n, PW pw, double* part, int lane, int nl, SYNC sync) {
+  chunked_sums(n, 27, part, lane, nl, sync,
+               [&](int e, int i, double& s) {
+                 const int q = e / 9, k = e - 9 * q, r = k / 3, c = k - 3 * r;
+                 double p[3], a[4], pc[3];
+                 pw(i, p);
+                 alphas_of(w, p, a);
+                 pcs_of(w, q, a, pc);
+                 s += (w.sgn[q] * pc[r] - w.acc[q][r]) * (p[c] - w.acc[q][3 + c]);
+               },
+               [&](int e, double s) { w.acc[e / 9][6 + e % 9] = s; });
 }
-template <class PW, class UV>
-EPNP_FN void phase_pose(Work& w, int n, PW pw, UV uv, Camera cam, int lane, int nl) {
-  for (int q = lane; q < 3; q += nl) pose_of(w, q, n, pw, uv, cam);
+// R, t of the three approximations (three lanes) and their mean reprojection errors (everybody)
+template <class PW, class UV, class SYNC>
+EPNP_FN void phase_pose(Work& w, int n, PW pw, UV uv, Camera cam, double* part, int lane, int nl, SYNC sync) {
+  for (int q = lane; q < 3; q += nl) {
+    double* R = w.R[q];
+    arun_rotation(&w.acc[q][6], R);
+    for (int i = 0; i < 3; i++)
+      w.t[q][i] = w.acc[q][i] - (R[3 * i] * w.acc[q][3] + R[3 * i + 1] * w.acc[q][4] + R[3 * i + 2] * w.acc[q][5]);
+  }
+  sync();
+  chunked_sums(n, 3, part, lane, nl, sync,
+               [&](int q, int i, double& s) {
+                 const double* R = w.R[q];
+                 double p[3], z[2];
+                 pw(i, p);
+                 uv(i, z);
+                 const double Xc = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + w.t[q][0];
+                 const double Yc = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + w.t[q][1];
+                 const double inv_Zc = 1.0 / (R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + w.t[q][2]);
+                 const double ue = cam.uc + cam.fu * Xc * inv_Zc, ve = cam.vc + cam.fv * Yc * inv_Zc;
+                 s += sqrt((z[0] - ue) * (z[0] - ue) + (z[1] - ve) * (z[1] - ve));
+               },
+               [&](int q, double s) {
+                 const double e = s / n;
+                 w.err[q] = e == e ? e : 1e300;  // (NaN: a degenerate approximation never wins)
+               });
 }
 // the winner: N = 1 (q = 0) unless N = 2 is better, then N = 3 against that (epnp::compute_pose)
 EPNP_FN Pose result(const Work& w) {
@@ -630,19 +668,19 @@ EPNP_FN Pose result(const Work& w) {
   return P;
 }
 
-// The solve in two parts so that a caller may give them different lane sets: `head` (control points, MtM: O(n) sums, as many lanes as
-// there are) and `tail` (everything after; 64 lanes at most have work).  NL lanes; `sync` separates the phases (a no-op for one lane).
+// The solve in three parts so that a caller may give them different lane sets: `head` (control points, MtM: sums over the
+// correspondences, as many lanes as there are), `mid` (eigen-decomposition .. betas: 64 lanes at most have work) and `sums` (absolute
+// orientation and reprojection errors: sums over the correspondences again).  NL lanes; every part ends synchronised.
 template <int NL, class PW, class UV, class SYNC>
-EPNP_FN void solve_head(Work& w, int n, PW pw, UV uv, Camera cam, int lane, SYNC sync) {
-  phase_control_points(w, n, pw, lane);
+EPNP_FN void solve_head(Work& w, int n, PW pw, UV uv, Camera cam, double* part, int lane, SYNC sync) {
+  phase_control_points(w, n, pw, part, lane, NL, sync);
   sync();
-  phase_mtm(w, n, pw, uv, cam, lane, NL);
-  sync();
+  phase_mtm(w, n, pw, uv, cam, part, lane, NL, sync);
   jacobi12_setup(w, lane);
   sync();
 }
-template <int NL, class PW, class UV, class SYNC>
-EPNP_FN Pose solve_tail(Work& w, int n, PW pw, UV uv, Camera cam, int lane, SYNC sync) {
+template <int NL, class SYNC>
+EPNP_FN void solve_mid(Work& w, int lane, SYNC sync) {
   jacobi12(w, lane, NL, sync);
   phase_pick_vectors(w, lane, NL);
   sync();
@@ -650,18 +688,19 @@ EPNP_FN Pose solve_tail(Work& w, int n, PW pw, UV uv, Camera cam, int lane, SYNC
   sync();
   phase_betas(w, lane, NL);
   sync();
-  phase_centroids(w, n, pw, lane, NL);
-  sync();
-  phase_abt(w, n, pw, lane, NL);
-  sync();
-  phase_pose(w, n, pw, uv, cam, lane, NL);
-  sync();
-  return result(w);
 }
 template <int NL, class PW, class UV, class SYNC>
-EPNP_FN Pose solve(Work& w, int n, PW pw, UV uv, Camera cam, int lane, SYNC sync) {
-  solve_head<NL>(w, n, pw, uv, cam, lane, sync);
-  return solve_tail<NL>(w, n, pw, uv, cam, lane, sync);
+EPNP_FN void solve_sums(Work& w, int n, PW pw, UV uv, Camera cam, double* part, int lane, SYNC sync) {
+  phase_centroids(w, n, pw, part, lane, NL, sync);
+  phase_abt(w, n, pw, part, lane, NL, sync);
+  phase_pose(w, n, pw, uv, cam, part, lane, NL, sync);
+}
+template <int NL, class PW, class UV, class SYNC>
+EPNP_FN Pose solve(Work& w, int n, PW pw, UV uv, Camera cam, double* part, int lane, SYNC sync) {
+  solve_head<NL>(w, n, pw, uv, cam, part, lane, sync);
+  solve_mid<NL>(w, lane, sync);
+  solve_sums<NL>(w, n, pw, uv, cam, part, lane, sync);
+  return result(w);
 }
 
 }  // namespace epnp

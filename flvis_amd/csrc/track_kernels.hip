@@ -896,7 +896,7 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
               }
             };
             epnp::Work& ew_ = sh.ew[wv];
-            epnp::solve_head<64>(ew_, 5, pw, uv, ecam, lane, wsync);
+            epnp::solve_head<64>(ew_, 5, pw, uv, ecam, nullptr, lane, wsync);
             emark(0);
             epnp::jacobi12(ew_, lane, 64, wsync);
             emark(1);
@@ -908,18 +908,15 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
             epnp::phase_betas(ew_, lane, 64);
             wsync();
             emark(3);
-            epnp::phase_centroids(ew_, 5, pw, lane, 64);
-            wsync();
-            epnp::phase_abt(ew_, 5, pw, lane, 64);
-            wsync();
+            epnp::phase_centroids(ew_, 5, pw, nullptr, lane, 64, wsync);
+            epnp::phase_abt(ew_, 5, pw, nullptr, lane, 64, wsync);
             emark(4);
-            epnp::phase_pose(ew_, 5, pw, uv, ecam, lane, 64);
-            wsync();
+            epnp::phase_pose(ew_, 5, pw, uv, ecam, nullptr, lane, 64, wsync);
             emark(5);
             const epnp::Pose P = epnp::result(ew_);
             if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[8 + 6], 1ull);
 #else
-            const epnp::Pose P = epnp::solve<64>(sh.ew[wv], 5, pw, uv, ecam, lane, wsync);
+            const epnp::Pose P = epnp::solve<64>(sh.ew[wv], 5, pw, uv, ecam, nullptr, lane, wsync);  // (a sample is one chunk: no scratch)
 #endif
             if (P.ok) {
               if (lane == 0) {
@@ -1191,12 +1188,21 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
       z[1] = (double)(float)(((double)s2d[2 * k + 1] - cy) / fy) * fy + cy;
     };
     const epnp::Camera ecam{fx, fy, cx, cy};
-    epnp::solve_head<RP_T>(sh.ew[0], ni, pw, uv, ecam, tid, [] { __syncthreads(); });
-    if (wv == 0) {
-      const epnp::Pose P = epnp::solve_tail<64>(sh.ew[0], ni, pw, uv, ecam, lane, [] {
+    // the sums over the inliers (head: control points, MtM; sums: absolute orientation, reprojection errors) by the whole workgroup,
+    // the eigen-decomposition .. betas in between by wave 0; the chunk sums live in the workspaces the hypotheses no longer need
+    double* const part = reinterpret_cast<double*>(&sh.ew[1]);
+    static_assert(sizeof(epnp::Work) * (RP_T / 64 - 1) >= sizeof(double) * epnp::PART_DOUBLES, "chunk-sum scratch");
+    auto bsync = [] { __syncthreads(); };
+    epnp::solve_head<RP_T>(sh.ew[0], ni, pw, uv, ecam, part, tid, bsync);
+    if (wv == 0)
+      epnp::solve_mid<64>(sh.ew[0], lane, [] {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       });
+    __syncthreads();
+    epnp::solve_sums<RP_T>(sh.ew[0], ni, pw, uv, ecam, part, tid, bsync);
+    if (wv == 0) {
+      const epnp::Pose P = epnp::result(sh.ew[0]);
       if (P.ok) {
         M3 Rf;
 #pragma unroll
@@ -1418,6 +1424,7 @@ __global__ __launch_bounds__(64) void k_epnp_sets(const float* __restrict__ p3d,
                                                   int cap, double fx, double fy, double cx, double cy, double* __restrict__ out) {
   const int b = blockIdx.x, lane = threadIdx.x;
   __shared__ epnp::Work w;
+  __shared__ double part[epnp::PART_DOUBLES];
   const int n = count[b];
   const float* const P = p3d + (size_t)b * cap * 3;
   const float* const Z = p2d + (size_t)b * cap * 2;
@@ -1426,7 +1433,7 @@ __global__ __launch_bounds__(64) void k_epnp_sets(const float* __restrict__ p3d,
     z[0] = (double)(float)(((double)Z[2 * i] - cx) / fx) * fx + cx;
     z[1] = (double)(float)(((double)Z[2 * i + 1] - cy) / fy) * fy + cy;
   };
-  const epnp::Pose R = epnp::solve<64>(w, n, pw, uv, epnp::Camera{fx, fy, cx, cy}, lane, [] {
+  const epnp::Pose R = epnp::solve<64>(w, n, pw, uv, epnp::Camera{fx, fy, cx, cy}, part, lane, [] {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   });

@@ -659,7 +659,9 @@ bool solve_epnp(const float* p3d, const float* p2d, const int* idx, int n, doubl
     z[0] = (double)(float)(((double)p2d[2 * k] - cx) / fx) * fx + cx;
     z[1] = (double)(float)(((double)p2d[2 * k + 1] - cy) / fy) * fy + cy;
   };
-  const flvis::epnp::Pose P = flvis::epnp::solve<1>(w, n, pw, uv, flvis::epnp::Camera{fx, fy, cx, cy}, 0, [] {});
+  static thread_local double part[flvis::epnp::PART_DOUBLES];
+  if (n > 1024) return false;  // (the chunk-sum scratch is sized for 1024 correspondences, the product's capacity)
+  const flvis::epnp::Pose P = flvis::epnp::solve<1>(w, n, pw, uv, flvis::epnp::Camera{fx, fy, cx, cy}, part, 0, [] {});
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) R.m[i][j] = P.R[3 * i + j];
   t = {P.t[0], P.t[1], P.t[2]};
