@@ -266,8 +266,13 @@ static int dem_common(flvis_ctx* ctx, const uint8_t* d_img, int w, int h, int n_
   hipStreamSynchronize(ctx->stream);  // hm is a stack-lifetime host buffer
   launch_gftt(ctx->stream, img_plain(d_img), w, h, w, (size_t)w * h, n_img, sc, nullptr, f_para[4], nullptr, maxc,
               (double)(int)f_para[5], corners, ncorners, maxc, nullptr);
-  launch_feature_dem(ctx->stream, img_plain(d_img), w, h, w, (size_t)w * h, n_img, dem_params(w, h, f_para), corners,
-                     ncorners, maxc, modes, d_exist_xy, d_exist_count, exist_cap, d_out_xy, d_out_count, out_cap);
+  float* sorted_xy = (float*)ctx->scratch("dem_sorted", sizeof(float) * 2 * (size_t)maxc * n_img);
+  int* region_off = (int*)ctx->scratch("dem_roff", sizeof(int) * 17 * (size_t)n_img);
+  if (!sorted_xy || !region_off) return ctx->fail(FLVIS_ERR_HIP, "feature_dem: scratch allocation failed");
+  launch_feature_dem_prep(ctx->stream, img_plain(d_img), w, h, w, (size_t)w * h, n_img, dem_params(w, h, f_para), corners, ncorners,
+                          maxc, nullptr, sorted_xy, region_off);
+  launch_feature_dem(ctx->stream, w, h, n_img, dem_params(w, h, f_para), sorted_xy, region_off, maxc, modes, d_exist_xy,
+                     d_exist_count, exist_cap, d_out_xy, d_out_count, out_cap);
   CHECK_LAUNCH(ctx, "feature_dem");
   return FLVIS_OK;
 }

@@ -28,6 +28,11 @@
 #define EPNP_FN inline
 
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EPNP_KEEP(x) asm volatile("" : "+v"(x))  // the value is wanted NOW (keeps a load from sinking behind a branch); no code
+#else
+#define EPNP_KEEP(x) (void)(x)
+#endif
 #if defined(__clang__)
 #define EPNP_UNROLL _Pragma("unroll")
 #else
@@ -405,10 +410,12 @@ EPNP_FN void phase_jacobi_angles(Work& w, int k, int tag, int lane, int nl) {
   for (int m = lane; m < 6; m += nl) {
     int p, q;
     jacobi_pair(k, m, p, q);
-    const double apq = w.AV[12 * p + q];
+    double apq = w.AV[12 * p + q], app = w.AV[13 * p], aqq = w.AV[13 * q];  // (all three at once: one LDS round trip)
+    EPNP_KEEP(app);
+    EPNP_KEEP(aqq);
     double c = 1.0, s = 0.0;
     if (apq * apq > w.skip2) {  // (threshold Jacobi: an entry below 1e-10 of the matrix scale is left alone)
-      jacobi_rotation(w.AV[13 * p], w.AV[13 * q], apq, c, s);
+      jacobi_rotation(app, aqq, apq, c, s);
       w.rotated = tag;
       if (apq * apq > w.tol2) w.active = 1;
     }

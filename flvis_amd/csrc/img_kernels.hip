@@ -825,15 +825,16 @@ __device__ __forceinline__ float dem_harris(const uint8_t* __restrict__ img, int
 }
 
 constexpr int DEM_T = 256;
-__global__ __launch_bounds__(DEM_T) void k_feature_dem(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
-                                                       const float* __restrict__ corners, const int* __restrict__ ncorners,
-                                                       int corner_cap, const int* __restrict__ mode,
-                                                       const double* __restrict__ exist_xy, const int* __restrict__ nexist,
-                                                       int exist_cap, float* __restrict__ out_xy, int* __restrict__ out_n,
-                                                       int out_cap) {
+// Two kernels since round 3.  k_feature_dem_prep needs only the corner list and the image: region and Harris score of every candidate,
+// candidates grouped by region and sorted by score inside a region (stable) -> per stream the sorted coordinates (region-major) and the
+// region offsets.  In the tracker it runs on the detection stream right after k_gftt_pick.  k_feature_dem is what stays on the frame's
+// critical path: the existing landmarks fill their regions, the greedy spacing walk, the output.
+__global__ __launch_bounds__(DEM_T) void k_feature_dem_prep(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
+                                                            const float* __restrict__ corners, const int* __restrict__ ncorners,
+                                                            int corner_cap, const int* __restrict__ active, float* __restrict__ sorted_xy,
+                                                            int* __restrict__ region_off) {
   const int s = blockIdx.x;
-  const int md = mode ? mode[s] : 1;
-  if (md == 0) return;
+  if (active && !active[s]) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // candidate arrays, sized by the corner capacity of the call (dynamic LDS: 18 bytes per corner)
   extern __shared__ __attribute__((aligned(16))) unsigned char dem_smem[];
@@ -843,21 +844,97 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem(ImgSel src, int w, int h,
   float* cscore = cy + cmax;
   short* creg = reinterpret_cast<short*>(cscore + cmax);
   short* bucket = creg + cmax;      // candidate indices grouped by region, index order inside a region
-  short* sorted_idx = bucket + cmax;  // ... sorted by score desc (stable)
   __shared__ int rcount[16], roff[17];
-  __shared__ float kx[16][DEM_MAXR], ky[16][DEM_MAXR];
-  __shared__ int kcount[16], knew0[16], ooff[17];
-  __shared__ int wcnt[DEM_T / 64][16];
   const uint8_t* img = src.ptr(s, sstride);
   int nc = ncorners[s];
   if (nc > corner_cap) nc = corner_cap;
   if (nc > DEM_MAXC) nc = DEM_MAXC;
   const float* C = corners + (size_t)s * corner_cap * 2;
-  if (tid < 16) {
-    rcount[tid] = 0;
-    kcount[tid] = 0;
+  if (tid < 16) rcount[tid] = 0;
+  __syncthreads();
+  // candidates: region + score
+  for (int i = tid; i < nc; i += DEM_T) {
+    float px = C[2 * i], py = C[2 * i + 1];
+    int r = -1;
+    float sc = 0.f;
+    if (px >= 3 && px < (w - 3) && py >= 3 && py < (h - 3)) {
+      r = (int)(4.f * floorf(py / (float)prm.regionHeight) + px / (float)prm.regionWidth);
+      sc = dem_harris(img, pitch, px, py);
+      atomicAdd(&rcount[r], 1);
+    }
+    cx[i] = px;
+    cy[i] = py;
+    cscore[i] = sc;
+    creg[i] = (short)r;
   }
   __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int r = 0; r < 16; r++) {
+      roff[r] = o;
+      o += rcount[r];
+    }
+    roff[16] = o;
+  }
+  __syncthreads();
+  // bucket the candidates by region keeping index order: wave q handles regions q, q+4, ...: ballots over the candidates
+  for (int r = wv; r < 16; r += DEM_T / 64) {
+    int o = roff[r];
+    for (int base = 0; base < nc; base += 64) {
+      const int i = base + lane;
+      const bool in = i < nc && creg[i] == r;
+      const unsigned long long bq = __ballot(in);
+      if (in) bucket[o + lane_prefix(bq)] = (short)i;
+      o += __popcll(bq);
+    }
+  }
+  __syncthreads();
+  // stable rank inside the region: #(score greater) + #(equal score, earlier index); only region members are compared
+  float* const SX = sorted_xy + (size_t)s * corner_cap * 2;
+  for (int j = tid; j < roff[16]; j += DEM_T) {
+    const int i = bucket[j];
+    const int r = creg[i];
+    const float sc = cscore[i];
+    int pos = 0;
+    for (int q = roff[r]; q < roff[r + 1]; q++) {
+      const float sj = cscore[bucket[q]];
+      pos += (sj > sc) || (sj == sc && q < j);
+    }
+    SX[2 * (roff[r] + pos)] = cx[i];
+    SX[2 * (roff[r] + pos) + 1] = cy[i];
+  }
+  if (tid < 17) region_off[(size_t)s * 17 + tid] = roff[tid];
+}
+
+__global__ __launch_bounds__(DEM_T) void k_feature_dem(int w, int h, DemParams prm, const float* __restrict__ sorted_xy,
+                                                       const int* __restrict__ region_off, int corner_cap, const int* __restrict__ mode,
+                                                       const double* __restrict__ exist_xy, const int* __restrict__ nexist,
+                                                       int exist_cap, float* __restrict__ out_xy, int* __restrict__ out_n,
+                                                       int out_cap) {
+  const int s = blockIdx.x;
+  const int md = mode ? mode[s] : 1;
+  if (md == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // the sorted candidates, staged once (dynamic LDS: 8 bytes per corner)
+  extern __shared__ __attribute__((aligned(16))) unsigned char dem_smem[];
+  const int cmax = ((corner_cap < DEM_MAXC ? corner_cap : DEM_MAXC) + 1) & ~1;
+  float* cx = reinterpret_cast<float*>(dem_smem);
+  float* cy = cx + cmax;
+  __shared__ int roff[17];
+  __shared__ float kx[16][DEM_MAXR], ky[16][DEM_MAXR];
+  __shared__ int kcount[16], knew0[16], ooff[17];
+  __shared__ int wcnt[DEM_T / 64][16];
+  if (tid < 17) roff[tid] = region_off[(size_t)s * 17 + tid];
+  if (tid < 16) kcount[tid] = 0;
+  __syncthreads();
+  {
+    const float* const SX = sorted_xy + (size_t)s * corner_cap * 2;
+    const int tot = roff[16] < cmax ? roff[16] : cmax;
+    for (int j = tid; j < tot; j += DEM_T) {
+      cx[j] = SX[2 * j];
+      cy[j] = SX[2 * j + 1];
+    }
+  }
   // existing features (redetect) fill their regions in landmark order: ordered per-region ranks by ballots, chunk by chunk
   if (md == 2) {
     int ne = nexist[s];
@@ -898,55 +975,7 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem(ImgSel src, int w, int h,
       __syncthreads();
     }
   }
-  // candidates: region + score
-  for (int i = tid; i < nc; i += DEM_T) {
-    float px = C[2 * i], py = C[2 * i + 1];
-    int r = -1;
-    float sc = 0.f;
-    if (px >= 3 && px < (w - 3) && py >= 3 && py < (h - 3)) {
-      r = (int)(4.f * floorf(py / (float)prm.regionHeight) + px / (float)prm.regionWidth);
-      sc = dem_harris(img, pitch, px, py);
-      atomicAdd(&rcount[r], 1);
-    }
-    cx[i] = px;
-    cy[i] = py;
-    cscore[i] = sc;
-    creg[i] = (short)r;
-  }
   __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    for (int r = 0; r < 16; r++) {
-      roff[r] = o;
-      o += rcount[r];
-    }
-    roff[16] = o;
-  }
-  __syncthreads();
-  // bucket the candidates by region keeping index order: wave q handles regions q, q+4, ...: ballots over the candidates
-  for (int r = wv; r < 16; r += DEM_T / 64) {
-    int o = roff[r];
-    for (int base = 0; base < nc; base += 64) {
-      const int i = base + lane;
-      const bool in = i < nc && creg[i] == r;
-      const unsigned long long bq = __ballot(in);
-      if (in) bucket[o + lane_prefix(bq)] = (short)i;
-      o += __popcll(bq);
-    }
-  }
-  __syncthreads();
-  // stable rank inside the region: #(score greater) + #(equal score, earlier index); only region members are compared
-  for (int j = tid; j < roff[16]; j += DEM_T) {
-    const int i = bucket[j];
-    const int r = creg[i];
-    const float sc = cscore[i];
-    int pos = 0;
-    for (int q = roff[r]; q < roff[r + 1]; q++) {
-      const float sj = cscore[bucket[q]];
-      pos += (sj > sc) || (sj == sc && q < j);
-    }
-    sorted_idx[roff[r] + pos] = (short)i;
-  }
   if (tid < 16) knew0[tid] = kcount[tid];
   __syncthreads();
   // greedy spacing per region: 16 lanes per region, the lanes split the already kept points of the region
@@ -957,8 +986,7 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem(ImgSel src, int w, int h,
     unsigned count = 0;
     const int j0 = roff[r], j1 = roff[r + 1];
     for (int j = j0; j < j1; j++) {
-      int ci = sorted_idx[j];
-      float px = cx[ci], py = cy[ci];
+      float px = cx[j], py = cy[j];
       if (md == 2) {  // cv::Point pt = Point2f (rounds), feature_dem.cpp:174
         px = (float)__float2int_rn(px);
         py = (float)__float2int_rn(py);
@@ -969,11 +997,9 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem(ImgSel src, int w, int h,
         float dis_y = fabsf(py - ky[r][k]);
         if (dis_x <= (float)bd || dis_y <= (float)bd) bad = 1;
       }
-      // OR over the 16 lanes of this region (they sit in one row of 16 lanes of the wave)
-      bad |= __shfl_xor(bad, 1, 64);
-      bad |= __shfl_xor(bad, 2, 64);
-      bad |= __shfl_xor(bad, 4, 64);
-      bad |= __shfl_xor(bad, 8, 64);
+      // OR over the 16 lanes of this region (one row of 16 lanes of the wave): one ballot of the whole wave, this row's 16 bits
+      // (a row that has left the loop contributes zeros and does not look)
+      bad = (int)((__ballot(bad != 0) >> (lane & 48)) & 0xFFFFull);
       if (!bad) {
         if (kept < DEM_MAXR && sub == 0) {
           kx[r][kept] = px;
@@ -1118,18 +1144,24 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
   if (ev) hipEventRecord(ev[5], st);
 }
 
-void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
-                        const float* corners, const int* ncorners, int corner_cap, const int* mode,
-                        const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,
-                        int out_cap) {
+void launch_feature_dem_prep(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
+                             const float* corners, const int* ncorners, int corner_cap, const int* active, float* sorted_xy,
+                             int* region_off) {
   const int cmax = ((corner_cap < DEM_MAXC ? corner_cap : DEM_MAXC) + 1) & ~1;
-  hipLaunchKernelGGL(k_feature_dem, dim3(S), dim3(DEM_T), (size_t)cmax * 18, st, src, w, h, pitch, sstride, prm, corners, ncorners,
-                     corner_cap, mode, exist_xy, nexist, exist_cap, out_xy, out_n, out_cap);
+  hipLaunchKernelGGL(k_feature_dem_prep, dim3(S), dim3(DEM_T), (size_t)cmax * 16, st, src, w, h, pitch, sstride, prm, corners, ncorners,
+                     corner_cap, active, sorted_xy, region_off);
+}
+void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, const float* sorted_xy, const int* region_off,
+                        int corner_cap, const int* mode, const double* exist_xy, const int* nexist, int exist_cap, float* out_xy,
+                        int* out_n, int out_cap) {
+  const int cmax = ((corner_cap < DEM_MAXC ? corner_cap : DEM_MAXC) + 1) & ~1;
+  hipLaunchKernelGGL(k_feature_dem, dim3(S), dim3(DEM_T), (size_t)cmax * 8, st, w, h, prm, sorted_xy, region_off, corner_cap, mode,
+                     exist_xy, nexist, exist_cap, out_xy, out_n, out_cap);
 }
 
 hipError_t img_kernels_init() {
   // the selection bitmap may exceed the default 64 KB dynamic LDS window only for images > 512K pixels
-  hipError_t e = hipFuncSetAttribute((const void*)k_feature_dem, hipFuncAttributeMaxDynamicSharedMemorySize, DEM_MAXC * 18);
+  hipError_t e = hipFuncSetAttribute((const void*)k_feature_dem_prep, hipFuncAttributeMaxDynamicSharedMemorySize, DEM_MAXC * 16);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_gftt_pick, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }

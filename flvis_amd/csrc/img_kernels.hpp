@@ -76,10 +76,14 @@ void launch_eig_walk(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t
 void launch_corner_response(hipStream_t st, int variant, int rows, ImgSel src, int w, int h, int pitch, size_t sstride, int S, unsigned* maxenc,
                             unsigned long long* keys, int* nkeys, int cap, const int* active);
 void launch_sqrt_check(hipStream_t st, unsigned first_bits, unsigned n, unsigned long long* mismatches);  // test aid, eig_walk.hip
-void launch_feature_dem(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
-                        const float* corners, const int* ncorners, int corner_cap, const int* mode,
-                        const double* exist_xy, const int* nexist, int exist_cap, float* out_xy, int* out_n,
-                        int out_cap);
+// FeatureDEM in two launches: what depends on the corners and the image only (regions, Harris scores, per-region order) -> sorted_xy
+// [S][corner_cap][2], region_off [S][17]; then the part that needs the existing landmarks (fill, greedy spacing, output)
+void launch_feature_dem_prep(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
+                             const float* corners, const int* ncorners, int corner_cap, const int* active, float* sorted_xy,
+                             int* region_off);
+void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, const float* sorted_xy, const int* region_off,
+                        int corner_cap, const int* mode, const double* exist_xy, const int* nexist, int exist_cap, float* out_xy,
+                        int* out_n, int out_cap);
 // pyramidal LK, 31x31 window: one wave per (stream, point)
 // max_pts: upper bound of count[] known to the caller (sizes the grid; any value is correct, the kernel strides), <= 0: nmax
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,

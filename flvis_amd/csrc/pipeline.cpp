@@ -46,6 +46,8 @@ struct Lane {
   uint8_t* pyr1[LK_MAX_LEVELS] = {};
   GfttScratch gftt;
   float* gftt_xy = nullptr;
+  float* dem_sorted = nullptr;  // [S][2 gftt_num][2] FeatureDEM: the corners in region-major, score-sorted order (k_feature_dem_prep)
+  int* dem_roff = nullptr;      // [S][17] ... and the offset of every region in that list
   int* gftt_n = nullptr;
   unsigned* eq_hist = nullptr;
   uint8_t* eq_lut = nullptr;
@@ -414,6 +416,8 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   ok = ok && ((L->gftt.keys = dalloc<unsigned long long>(L->allocs, (size_t)cap * S, false)) != nullptr);
   ok = ok && ((L->gftt_xy = dalloc<float>(L->allocs, (size_t)S * 2 * c.gftt_num * 2)) != nullptr);
   ok = ok && ((L->gftt_n = dalloc<int>(L->allocs, S)) != nullptr);
+  ok = ok && ((L->dem_sorted = dalloc<float>(L->allocs, (size_t)S * 2 * c.gftt_num * 2)) != nullptr);
+  ok = ok && ((L->dem_roff = dalloc<int>(L->allocs, (size_t)S * 17)) != nullptr);
   ok = ok && ((L->eq_hist = dalloc<unsigned>(L->allocs, (size_t)S * 256)) != nullptr);
   ok = ok && ((L->eq_lut = dalloc<uint8_t>(L->allocs, (size_t)S * 256)) != nullptr);
   if (!ok) return false;
@@ -868,6 +872,9 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
                 (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
                 (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
+    // FeatureDEM's image part (regions, Harris scores, per-region order of the corners) follows at once, off the critical path
+    launch_feature_dem_prep(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
+                            p.gftt_act, L->dem_sorted, L->dem_roff);
     hipEventRecord(L->ev_gftt, ds);
   };
   if (gftt_first && !gftt_after_lk) detect_corners();
@@ -883,6 +890,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
                   (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
                   (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
+      launch_feature_dem_prep(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
+                              p.gftt_act, L->dem_sorted, L->dem_roff);
     }
     hipEventRecord(L->ev_det, ds);
   };
@@ -929,8 +938,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners; the right pyramid is joined before the stereo LK
   hipStreamWaitEvent(st, gftt_first ? L->ev_gftt : L->ev_det, 0);
   PB(13, st);
-  launch_feature_dem(st, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
-                     p.det_mode, p.exist_xy, p.n_exist, NMAX, p.new_xy, p.n_new, NEW_MAX);
+  launch_feature_dem(st, w, h, S, p.cam.dem, L->dem_sorted, L->dem_roff, 2 * p.cam.gftt_num, p.det_mode, p.exist_xy, p.n_exist, NMAX,
+                     p.new_xy, p.n_new, NEW_MAX);
   launch_add_new(st, p);
   PE(13, st);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
