@@ -71,7 +71,9 @@ __device__ inline V3 triangulate_dlt(double u1, double v1, double u2, double v2,
           beta += A[i][q] * A[i][q];
           gamma += A[i][p] * A[i][q];
         }
-        if (gamma * gamma <= 1e-32 * (alpha * beta)) continue;
+        // orthogonal to 10 eps (OpenCV's Jacobi SVD test).  Round 2's 1e-16 was below the rounding of the dot product: one problem in
+        // twelve chattered through all 30 sweeps, and a wave runs as long as its slowest lane -- nearly every wave ran 30 sweeps.
+        if (gamma * gamma <= 4.930380657631324e-30 * (alpha * beta)) continue;
         off = 1;
         double zeta = (beta - alpha) / (2.0 * gamma);
         double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));

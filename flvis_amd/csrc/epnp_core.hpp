@@ -214,7 +214,7 @@ EPNP_UNROLL
     be += a[k][Q] * a[k][Q];
     ga += a[k][P] * a[k][Q];
   }
-  if (ga * ga <= 1e-30 * (al * be)) return false;  // the columns are orthogonal to rounding
+  if (ga * ga <= 4.930380657631324e-30 * (al * be)) return false;  // the columns are orthogonal to 10 eps (OpenCV's Jacobi SVD test)
   double c, s;
   jacobi_rotation(al, be, ga, c, s);
 EPNP_UNROLL

@@ -895,6 +895,7 @@ int flvis_hip_debug_epnp(flvis_ctx* ctx, const float* d_p3d, const float* d_p2d,
                          double* d_out160) {
   CHECK_CTX(ctx);
   if (!d_p3d || !d_p2d || !d_count || !h_K4 || !d_out160 || cap <= 0 || n_sets <= 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "debug_epnp: bad args");
+  if (cap > pnp_ransac_max_points()) return ctx->fail(FLVIS_ERR_CAPACITY, "debug_epnp: at most 1024 correspondences per set");
   hipSetDevice(ctx->device);
   launch_epnp_sets(ctx->stream, d_p3d, d_p2d, d_count, cap, n_sets, h_K4, d_out160);
   CHECK_LAUNCH(ctx, "debug_epnp");

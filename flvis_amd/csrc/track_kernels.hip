@@ -1425,7 +1425,14 @@ __global__ __launch_bounds__(64) void k_epnp_sets(const float* __restrict__ p3d,
   const int b = blockIdx.x, lane = threadIdx.x;
   __shared__ epnp::Work w;
   __shared__ double part[epnp::PART_DOUBLES];
-  const int n = count[b];
+  int n = count[b];
+  n = n < 0 ? 0 : (n > cap ? cap : n);  // (cap <= 1024 is the caller's check: the chunk-sum scratch is sized for it)
+  if (n < 4) {                          // fewer than four correspondences: no pose (cv::solvePnP asserts npoints >= 4)
+    if (lane < EPNP_DBG_N) out[(size_t)b * EPNP_DBG_N + lane] = 0.0;
+    if (lane + 64 < EPNP_DBG_N) out[(size_t)b * EPNP_DBG_N + lane + 64] = 0.0;
+    if (lane + 128 < EPNP_DBG_N) out[(size_t)b * EPNP_DBG_N + lane + 128] = 0.0;
+    return;
+  }
   const float* const P = p3d + (size_t)b * cap * 3;
   const float* const Z = p2d + (size_t)b * cap * 2;
   auto pw = [&](int i, double* q) { q[0] = (double)P[3 * i], q[1] = (double)P[3 * i + 1], q[2] = (double)P[3 * i + 2]; };

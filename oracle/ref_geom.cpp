@@ -181,7 +181,9 @@ Vec3 triangulate_dlt(Vec2 pt1, Vec2 pt2, const double P1[12], const double P2[12
           beta += A[i][q] * A[i][q];
           gamma += A[i][p] * A[i][q];
         }
-        if (gamma * gamma <= 1e-32 * (alpha * beta)) continue;  // already orthogonal to working precision
+        // orthogonal to 10 eps: the convergence test of OpenCV's Jacobi SVD, |p| <= 10 DBL_EPSILON sqrt(a b).  (A 1e-16 test is below
+        // the rounding of the dot product itself: one problem in twelve then chatters through all 30 sweeps.)
+        if (gamma * gamma <= 4.930380657631324e-30 * (alpha * beta)) continue;
         off = 1;
         double zeta = (beta - alpha) / (2.0 * gamma);
         double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));

@@ -53,3 +53,21 @@ def test_epnp_device_equals_the_restatement_bit_for_bit(ctx, noise):
         assert np.array_equal(o[13:25].reshape(3, 4), betas), (what, o[13:25].reshape(3, 4) - betas)
         assert np.array_equal(o[25:28], err), what
         assert bool(o[12]) == ok and np.array_equal(o[:9].reshape(3, 3), R) and np.array_equal(o[9:12], t), what
+
+
+def test_epnp_entry_point_refuses_what_it_cannot_hold(ctx):
+    import torch
+    import flvis_amd
+    cnt = torch.tensor([5], dtype=torch.int32, device="cuda")
+    with pytest.raises(flvis_amd.FlvisError):      # more than 1024 correspondences per set: capacity error, no launch
+        ctx.debug_epnp(torch.zeros((1, 2048, 3), dtype=torch.float32, device="cuda"), torch.zeros((1, 2048, 2), dtype=torch.float32, device="cuda"), cnt, K4)
+    rng = np.random.default_rng(3)
+    (P, z), = _sets(rng, [8], 0.0)
+    p3 = torch.zeros((3, 16, 3), dtype=torch.float32, device="cuda")
+    p2 = torch.zeros((3, 16, 2), dtype=torch.float32, device="cuda")
+    p3[:, :8], p2[:, :8] = torch.from_numpy(P).cuda(), torch.from_numpy(z).cuda()
+    out = ctx.debug_epnp(p3, p2, torch.tensor([3, 8, 99], dtype=torch.int32, device="cuda"), K4).cpu().numpy()
+    assert not out[0].any()                        # fewer than four correspondences: no pose, ok = 0
+    ok, R, t = O.solve_epnp(P, z, K4)
+    assert ok and out[1, 12] == 1.0 and np.array_equal(out[1, :9].reshape(3, 3), R)
+    assert np.isfinite(out[2]).all() or out[2, 12] == 0.0   # a count beyond the capacity is clamped to it (16 points, 8 of them zeros)
