@@ -104,6 +104,10 @@ template <int P, int Q>
 EPNP_FN bool sym3_rotate(double (&a)[3][3], double (&v)[3][3]) {
   const double apq = a[P][Q];
   if (apq == 0.0) return false;
+  if (apq * apq <= 4.930380657631324e-30 * fabs(a[P][P] * a[Q][Q])) {  // below 10 eps of the pair's scale: done with it
+    a[P][Q] = 0.0, a[Q][P] = 0.0;
+    return false;
+  }
   double c, s;
   jacobi_rotation(a[P][P], a[Q][Q], apq, c, s);
 EPNP_UNROLL
