@@ -935,6 +935,10 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(9, st);
   launch_reproj_filter(st, p);
   PE(9, st);
+  // the IMU filter's correction from this frame's pose: on the detection stream (joined with the triangulation before the depth innovation)
+  hipEventRecord(L->ev_lm, st);
+  hipStreamWaitEvent(ds, L->ev_lm, 0);
+  launch_vi_correction(ds, p);
   // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners; the right pyramid is joined before the stereo LK
   hipStreamWaitEvent(st, gftt_first ? L->ev_gftt : L->ev_det, 0);
   PB(13, st);

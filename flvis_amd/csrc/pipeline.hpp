@@ -94,6 +94,8 @@ struct StreamState {
   // and the filter's body velocity (world) when that keyframe was made: inputs of the IMU factor's position rows
   double kf_dp[3], kf_dv[3], kf_va[3];
   long long imu_seen;  // IMU samples integrated so far (= rows ever written to the stream's IMU-state output ring)
+  int vi_corr_due;     // k_reproj_filter: this Tracking frame's viCorrectionFromVision is still to run (k_vi_correction)
+  int pad_vi;
 };
 
 struct FrameOut {  // per stream, per image_feed

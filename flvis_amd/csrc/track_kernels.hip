@@ -1786,12 +1786,22 @@ __global__ __launch_bounds__(NMAX) void k_reproj_filter(Pipe p) {
     p.n_exist[s] = kept;
     p.det_mode[s] = 2;
     p.det_maxc[s] = p.cam.gftt_num;
-    if (st.has_imu) {
-      ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
-      vi_correction_from_vision(p.cam, st, ring, st.frame_time[cur], T, st.frame_time[cur ^ 1],
-                                load_pose7(st.T_c_w[cur ^ 1]));
-    }
+    st.vi_corr_due = st.has_imu ? 1 : 0;  // viCorrectionFromVision follows in k_vi_correction (off the critical path)
   }
+}
+// VIMOTION::viCorrectionFromVision of the Tracking branch (f2f_tracking.cpp:256-262, after eraseReprjOutlier): one thread per stream.
+// Nothing on the frame's chain before k_frame_end reads the filter state, and the searches through the IMU ring are dependent global
+// loads (25 us of one thread): the detection stream runs it beside FeatureDEM / the stereo LK.
+__global__ void k_vi_correction(Pipe p) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.S) return;
+  StreamState& st = p.st[s];
+  if (!st.vi_corr_due) return;
+  st.vi_corr_due = 0;
+  const int cur = st.cur;
+  ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
+  vi_correction_from_vision(p.cam, st, ring, st.frame_time[cur], load_pose7(st.T_c_w[cur]), st.frame_time[cur ^ 1],
+                            load_pose7(st.T_c_w[cur ^ 1]));
 }
 
 // ------------------------------------------------------------------------------------------------ new landmarks
@@ -2189,6 +2199,7 @@ hipError_t track_kernels_init() {
   return hipFuncSetAttribute((const void*)k_pose_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLMShared));
 }
 void launch_reproj_filter(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_reproj_filter, dim3(p.S), dim3(NMAX), 0, st, p); }
+void launch_vi_correction(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_vi_correction, dim3((p.S + 63) / 64), dim3(64), 0, st, p); }
 void launch_add_new(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_add_new, dim3(p.S), dim3(64), 0, st, p); }
 void launch_depth_seeds(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_depth_seeds, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);

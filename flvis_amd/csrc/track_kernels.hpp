@@ -86,6 +86,7 @@ void launch_ransac_pnp(hipStream_t st, const Pipe& p);
 void launch_track_post(hipStream_t st, const Pipe& p);
 void launch_pose_lm(hipStream_t st, const Pipe& p);
 void launch_reproj_filter(hipStream_t st, const Pipe& p);
+void launch_vi_correction(hipStream_t st, const Pipe& p);  // viCorrectionFromVision of the streams k_reproj_filter marked
 void launch_add_new(hipStream_t st, const Pipe& p);
 void launch_depth_seeds(hipStream_t st, const Pipe& p);        // stereo-LK seeds of the current landmarks (critical path)
 void launch_depth_triangulate(hipStream_t st, const Pipe& p);  // two-view triangulation for k_depth_innovate (beside the stereo LK)
