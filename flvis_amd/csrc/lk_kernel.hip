@@ -28,9 +28,31 @@ constexpr int LK_RROWS = 33 + 2 * LK_RM;
 
 typedef short lk_s2 __attribute__((ext_vector_type(2)));
 
-// patch[r][c] = img(X0 + c, Y0 + r) for r < nrows, c < 36, REFLECT_101 outside the image
+// patch[r][c] = img(X0 + c, Y0 + r) for r < nrows, c < 36, REFLECT_101 outside the image.  Item i = 9 r + k is dword k of row r; a lane
+// takes items lane, lane + 64, ...  When the whole patch lies inside the image (wave-uniform test; nearly every point) there is nothing to
+// reflect and nothing to divide: a lane's (row, dword) advances by (7, 1) per trip (64 = 7 * 9 + 1) with one wrap test, its byte offset
+// into the image and its LDS address advance by constants, and the address is a uniform base + a 32-bit lane offset.
 __device__ __forceinline__ void lk_load_patch(const uint8_t* __restrict__ img, int w, int h, int pitch, int X0, int Y0,
                                               int nrows, uint8_t* patch) {
+  if (X0 >= 0 && Y0 >= 0 && X0 + 39 < w && Y0 + nrows <= h) {  // (+ 39: the second dword of the last item stays inside the row)
+    const uint8_t* const base = img + (size_t)Y0 * pitch + (X0 & ~3);
+    const int sh = X0 & 3;
+    int r = (int)threadIdx.x / 9, k = (int)threadIdx.x - 9 * r;
+    unsigned off = (unsigned)(r * pitch + 4 * k);
+    unsigned dst = (unsigned)(r * LK_PS + 4 * k);
+    const int n = nrows * 9;
+    for (int i = threadIdx.x; i < n; i += 64) {
+      const uint32_t lo = *reinterpret_cast<const uint32_t*>(base + off);
+      const uint32_t hi = *reinterpret_cast<const uint32_t*>(base + off + 4);
+      *reinterpret_cast<uint32_t*>(patch + dst) = __builtin_amdgcn_alignbyte(hi, lo, sh);
+      k += 1;
+      const bool wrap = k >= 9;
+      k = wrap ? k - 9 : k;
+      off += (unsigned)(7 * pitch + 4) + (wrap ? (unsigned)(pitch - 36) : 0u);
+      dst += (unsigned)(7 * LK_PS + 4) + (wrap ? (unsigned)(LK_PS - 36) : 0u);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < nrows * 9; i += 64) {
     int r = i / 9, k = i - r * 9;
     int Y = Y0 + r, X = X0 + 4 * k;
@@ -51,9 +73,24 @@ __device__ __forceinline__ void lk_load_patch(const uint8_t* __restrict__ img, i
   }
 }
 
-// region[r][c] = img(X0 + c, Y0 + r), r < LK_RROWS, c < 52, X0 a multiple of 4 (aligned dword loads), REFLECT_101 outside
+// region[r][c] = img(X0 + c, Y0 + r), r < LK_RROWS, c < 52, X0 a multiple of 4 (aligned dword loads), REFLECT_101 outside.  Same fast
+// path when the region lies inside the image: (row, dword) advances by (4, 12) per trip (64 = 4 * 13 + 12).
 __device__ __forceinline__ void lk_load_region(const uint8_t* __restrict__ img, int w, int h, int pitch, int X0, int Y0,
                                                uint8_t* region) {
+  if (X0 >= 0 && Y0 >= 0 && X0 + 51 < w && Y0 + LK_RROWS <= h) {
+    const uint8_t* const base = img + (size_t)Y0 * pitch + X0;
+    int r = (int)threadIdx.x / 13, k = (int)threadIdx.x - 13 * r;
+    unsigned off = (unsigned)(r * pitch + 4 * k);
+    static_assert(LK_RS == 52, "the region rows are contiguous in LDS: item i sits at byte 4 i");
+    for (int i = threadIdx.x; i < LK_RROWS * 13; i += 64) {
+      *reinterpret_cast<uint32_t*>(region + 4 * i) = *reinterpret_cast<const uint32_t*>(base + off);
+      k += 12;
+      const bool wrap = k >= 13;
+      k = wrap ? k - 13 : k;
+      off += (unsigned)(4 * pitch + 48) + (wrap ? (unsigned)(pitch - 52) : 0u);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < LK_RROWS * 13; i += 64) {
     int r = i / 13, k = i - r * 13;
     int Y = Y0 + r, X = X0 + 4 * k;
