@@ -7,6 +7,8 @@
 // Every kernel handles all S streams of the batch and masks itself with the stream's phase flags, so the host enqueues
 // the same kernel sequence every frame (no host decisions, graph-capturable).  Latency-bound stages use one wave (or
 // one thread) per stream; the J^T J / J^T r assemblies are wave reductions (DPP/shuffle butterflies).
+#include <vector>
+
 #include "dev_common.hpp"
 #ifdef FLVIS_RANSAC_PROF
 // sub-phase stamps of the 7-point solver (lane 0 of the hypothesis wave), counters[40..]
@@ -784,6 +786,16 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
 // closing's geometric check loads caller arrays) and is entered by the WHOLE workgroup; only wave 0 returns with the result.
 constexpr int RP_T = 512;
 constexpr int PNP_GN_ROW = 29;
+// PnPRansacCallback has no checkSubset and every run starts from cv::RNG((uint64)-1): the subsets of a run depend on the number of
+// correspondences alone.  The first batch of either branch (8 subsets of 5 / 16 subsets of 4) is therefore tabulated per count at start-up
+// (host, the same generator and getSubset loop), together with the generator state behind it, and a kernel whose search ends within the
+// first batch -- the usual case -- never runs the serial draw loop (wave 0 drawing while seven waves wait).
+constexpr int PNP_TAB_N = 1025;        // counts 0 .. 1024 (NMAX and PNP_MAXN)
+constexpr int PNP_TAB_B5 = RP_T / 64;  // first batch of the EPnP branch
+constexpr int PNP_TAB_B4 = 16;         // first batch of the P3P branch
+__device__ unsigned short g_pnp_sub5[PNP_TAB_N][PNP_TAB_B5][5];
+__device__ unsigned short g_pnp_sub4[PNP_TAB_N][PNP_TAB_B4][4];
+__device__ unsigned long long g_pnp_rng5[PNP_TAB_N], g_pnp_rng4[PNP_TAB_N];
 struct PnpShared {
   float* s2d;            // [n][2]
   float* s3d;            // [n][3]
@@ -851,7 +863,14 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
       if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[6], 1ull);
       if (iterative) {
         // EPnP on the five sample points: wave w solves hypothesis base + w
-        if (wv == 0) {
+        if (wv == 0 && base == 0 && np > modelPoints && np < PNP_TAB_N) {
+          if (lane < NW) {  // the tabulated first batch
+#pragma unroll
+            for (int j = 0; j < 5; j++) s_sub[lane][j] = g_pnp_sub5[np][lane][j];
+            s_sub[lane][7] = 1;
+          }
+          rng.state = g_pnp_rng5[np];
+        } else if (wv == 0) {
           if (lane < NW) s_sub[lane][7] = 0;
           __builtin_amdgcn_wave_barrier();
           for (int k = 0; k < B && base + k < ctl[0]; k++) {
@@ -967,9 +986,18 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
         }
       };
       if (wv == 0) {
-        // the batch's subsets, drawn serially (wave-uniform) below the current iteration limit
+        // the batch's subsets: the first batch from the table, later ones drawn serially (wave-uniform) below the current iteration limit
         s_sub[lane][7] = 0;
         __builtin_amdgcn_wave_barrier();
+        if (base == 0 && !iterative && np > modelPoints && np < PNP_TAB_N) {
+          if (lane < PNP_TAB_B4) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) s_sub[lane][j] = g_pnp_sub4[np][lane][j];
+            s_sub[lane][4] = -1;
+            s_sub[lane][7] = 1;
+          }
+          rng.state = g_pnp_rng4[np];
+        } else
         for (int k = 0; k < B && base + k < ctl[0]; k++) {
           int sidx[5];
           bool ok = true;
@@ -2185,9 +2213,11 @@ void launch_track_collect(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_
 void launch_ransac_f(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_f, dim3(p.S), dim3(RF_T), 0, st, p); }
 void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_pnp, dim3(p.S), dim3(RP_T), 0, st, p); }
 int pnp_ransac_max_points() { return PNP_MAXN; }
+static hipError_t pnp_tables_init();
 void launch_pnp_ransac_sets(hipStream_t st, const float* p3d, const float* p2d, const int* count, int cap, int n_sets, const double* K4,
                             int iterative, const double* guess7, const unsigned long long* seeds, int max_iters, double reproj_px,
                             double conf, double* pose7, unsigned char* mask, int* n_inliers) {
+  (void)pnp_tables_init();  // (the loop closing may use the solver without a tracker)
   hipLaunchKernelGGL(k_pnp_ransac_sets, dim3(n_sets), dim3(RP_T), 0, st, p3d, p2d, count, cap, K4[0], K4[1], K4[2], K4[3], iterative,
                      guess7, seeds, max_iters, (float)(reproj_px * reproj_px), conf, pose7, mask, n_inliers);
 }
@@ -2195,7 +2225,47 @@ void launch_track_post(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_track_post, dim3((p.S + 63) / 64), dim3(64), 0, st, p);
 }
 void launch_pose_lm(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_pose_lm, dim3(p.S), dim3(PL_T), sizeof(PoseLMShared), st, p); }
+// the tabulated first batches of the PnP RANSAC (see g_pnp_sub5): once per device, before the first launch that reads them
+static hipError_t pnp_tables_init() {
+  static bool done[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+  std::vector<unsigned short> s5((size_t)PNP_TAB_N * PNP_TAB_B5 * 5, 0), s4((size_t)PNP_TAB_N * PNP_TAB_B4 * 4, 0);
+  std::vector<unsigned long long> r5(PNP_TAB_N, 0), r4(PNP_TAB_N, 0);
+  auto fill = [](int count, int m, int nsub, unsigned short* out, unsigned long long& state_out) {
+    uint64_t st = 0xffffffffffffffffull;  // cv::RNG((uint64)-1)
+    for (int sidx = 0; sidx < nsub; sidx++) {
+      int idx[5] = {-1, -1, -1, -1, -1};
+      for (int i = 0; i < m;) {  // getSubset: rng.uniform(0, count) per slot, redrawn while it repeats an earlier slot
+        st = (uint64_t)(uint32_t)st * 4164903690u + (uint32_t)(st >> 32);
+        const int v = (int)((uint32_t)st % (uint32_t)count);
+        bool dup = false;
+        for (int j = 0; j < i; j++) dup = dup || idx[j] == v;
+        if (dup) continue;
+        idx[i++] = v;
+      }
+      for (int j = 0; j < m; j++) out[(size_t)sidx * m + j] = (unsigned short)idx[j];
+    }
+    state_out = st;
+  };
+  for (int n = 0; n < PNP_TAB_N; n++) {
+    if (n > 5) fill(n, 5, PNP_TAB_B5, &s5[(size_t)n * PNP_TAB_B5 * 5], r5[n]);
+    if (n > 4) fill(n, 4, PNP_TAB_B4, &s4[(size_t)n * PNP_TAB_B4 * 4], r4[n]);
+  }
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_pnp_sub5), s5.data(), s5.size() * sizeof(unsigned short));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_pnp_sub4), s4.data(), s4.size() * sizeof(unsigned short));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_pnp_rng5), r5.data(), r5.size() * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_pnp_rng4), r4.data(), r4.size() * sizeof(unsigned long long));
+  if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+  return e;
+}
 hipError_t track_kernels_init() {
+  {
+    const hipError_t e = pnp_tables_init();
+    if (e != hipSuccess) return e;
+  }
   return hipFuncSetAttribute((const void*)k_pose_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PoseLMShared));
 }
 void launch_reproj_filter(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_reproj_filter, dim3(p.S), dim3(NMAX), 0, st, p); }
