@@ -69,7 +69,7 @@ int poly_real_roots(const double* a_in, int deg, double* roots) {
     roots[1] = std::max(r0, r1);
     return 2;
   }
-  double d[5];
+  double d[5] = {0, 0, 0, 0, 0};
   for (int i = 1; i <= deg; i++) d[i - 1] = a[i] * i;
   double crit[4];
   int nc = poly_real_roots(d, deg - 1, crit);
