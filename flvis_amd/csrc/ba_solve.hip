@@ -844,18 +844,21 @@ __device__ __noinline__ void ba_phase_imu_gather() {
 // off-diagonal pose-pose blocks Ja^T W Jb into the lower triangle of the reduced system (after the Schur phase and a barrier)
 __device__ __noinline__ void ba_phase_imu_offdiag() {
   BAShared& sh = ba_sh();
-  const int t = threadIdx.x;
-  if (t >= 36 * sh.n_imu) return;
-  const int k = t / 36, e = t - 36 * k, i = e / 6, j = e - 6 * i, LD = sh.LD;
-  const int nc = sh.imu_wp[k] > 0 ? 6 : 3;
-  if (i >= nc || j >= nc) return;
-  const int ia = sh.hidx_of[sh.imu_a[k]], ib = sh.hidx_of[sh.imu_b[k]];
-  if (ia < 0 || ib < 0) return;
+  // one item per (edge, entry of its 6x6 block), strided: window_size 16 has up to 15 edges = 540 items > BA_T.  Every item owns
+  // its entry of the reduced system (an edge joins one pair of poses), so the order of the items does not matter
   double* Hs = ba_dyn();
-  if (ia < ib)
-    Hs[(6 * ib + j) * LD + 6 * ia + i] += sh.imu_ab[k][e];
-  else
-    Hs[(6 * ia + i) * LD + 6 * ib + j] += sh.imu_ab[k][e];
+  const int LD = sh.LD;
+  for (int t = threadIdx.x; t < 36 * sh.n_imu; t += BA_T) {
+    const int k = t / 36, e = t - 36 * k, i = e / 6, j = e - 6 * i;
+    const int nc = sh.imu_wp[k] > 0 ? 6 : 3;
+    if (i >= nc || j >= nc) continue;
+    const int ia = sh.hidx_of[sh.imu_a[k]], ib = sh.hidx_of[sh.imu_b[k]];
+    if (ia < 0 || ib < 0) continue;
+    if (ia < ib)
+      Hs[(6 * ib + j) * LD + 6 * ia + i] += sh.imu_ab[k][e];
+    else
+      Hs[(6 * ia + i) * LD + 6 * ib + j] += sh.imu_ab[k][e];
+  }
 }
 // lanes of wave 0: chi2 of the edges at the trial poses
 FD void ba_phase_imu_trial() {

@@ -280,6 +280,41 @@ __global__ __launch_bounds__(256) void k_pyr_down_ingest(ImgSel src, int sw, int
   pyr_down_tile<true>(src, sw, sh, spitch, sstride, dst0, d0pitch, d0stride, dst, dpitch, dstride, active);
 }
 
+// ------------------------------------------------------------------------------------------------ pyramid border
+// The pyramids of the tracker are stored with a physical BORDER_REFLECT_101 border of LK_BORDER_X columns / LK_BORDER_Y rows (what
+// cv::buildOpticalFlowPyramid keeps around its levels, lkpyramid.cpp): k_lk_track's patch and region staging then never reflects an
+// index for a point inside the image.  One launch fills the border of every level of one pyramid: blockIdx.y = level, blockIdx.z =
+// stream; an item is one dword of the padded buffer that is not an image dword.  The values are img(reflect101c(y), reflect101c(x)),
+// the very function the kernels' slow paths evaluate per item, so a staged block is the same bytes either way.
+__global__ __launch_bounds__(256) void k_pyr_border(PyrSel pyr, const int* __restrict__ active) {
+  const int s = blockIdx.z, l = blockIdx.y;
+  if (active && !active[s]) return;
+  const int bx = pyr.bx[l], by = pyr.by[l];
+  if (bx == 0 && by == 0) return;
+  const int w = pyr.w[l], h = pyr.h[l], pitch = pyr.pitch[l];
+  uint8_t* img = const_cast<uint8_t*>(pyr.lvl[l].ptr(s, pyr.stride[l]));
+  const int rowdw = pitch >> 2;            // dwords of a padded row: columns -bx .. pitch - bx - 1
+  const int wdw = w >> 2;                  // image dwords of a row that lie wholly inside the image
+  const int sidedw = rowdw - wdw;          // border dwords of an image row (left border, then right border + row padding)
+  const int n_tb = 2 * by * rowdw, n_side = h * sidedw;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_tb + n_side; i += gridDim.x * 256) {
+    int x, y;
+    if (i < n_tb) {
+      const int r = i / rowdw, k = i - r * rowdw;
+      y = r < by ? r - by : h + (r - by);
+      x = 4 * k - bx;
+    } else {
+      const int j = i - n_tb;
+      y = j / sidedw;
+      const int k = j - y * sidedw;
+      x = 4 * k < bx ? 4 * k - bx : 4 * wdw + (4 * k - bx);
+    }
+    const uint8_t* row = img + (ptrdiff_t)reflect101c(y, h) * pitch;
+    const uint32_t b0 = row[reflect101c(x, w)], b1 = row[reflect101c(x + 1, w)], b2 = row[reflect101c(x + 2, w)], b3 = row[reflect101c(x + 3, w)];
+    *reinterpret_cast<uint32_t*>(img + (ptrdiff_t)y * pitch + x) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ min-eigenvalue map
 // Tile of EG_TH x EG_TW outputs (+HALO ring when HALO=1).  Needs cov on a +1 ring and image on a +2 ring beyond that.
 constexpr int EG_TW = 64, EG_TH = 16;
@@ -1105,6 +1140,12 @@ void launch_pyr_down_ingest(hipStream_t st, ImgSel src, int sw, int sh, int spit
 // false -- k_gftt_pick hands them back zeroed.
 // the corner-response pass on its own: per-stream maximum (maxenc, zeroed by the caller) and the candidate keys (keys / nkeys, zeroed)
 // variant 0: k_eig_cand (LDS tiles), 1: k_eig_cand_strip, 2: k_eig_walk with `rows` rows per chunk
+void launch_pyr_border(hipStream_t st, const PyrSel& pyr, int S, const int* active) {
+  bool any = false;
+  for (int l = 0; l <= pyr.levels; l++) any = any || pyr.bx[l] > 0 || pyr.by[l] > 0;
+  if (!any) return;
+  hipLaunchKernelGGL(k_pyr_border, dim3(8, pyr.levels + 1, S), dim3(256), 0, st, pyr, active);
+}
 void launch_corner_response(hipStream_t st, int variant, int rows, ImgSel src, int w, int h, int pitch, size_t sstride, int S, unsigned* maxenc,
                             unsigned long long* keys, int* nkeys, int cap, const int* active) {
   dim3 grid(div_up(w, EG_TW), div_up(h, EG_TH), S);

@@ -29,7 +29,13 @@ struct PyrSel {
   int w[LK_MAX_LEVELS], h[LK_MAX_LEVELS], pitch[LK_MAX_LEVELS];
   size_t stride[LK_MAX_LEVELS];  // bytes between consecutive streams
   int levels;                    // highest level index (0..levels)
+  // physical BORDER_REFLECT_101 border around each level (0: none): columns -bx .. w + bx - 1 and rows -by .. h + by - 1 of a
+  // level are addressable and hold img(reflect101c(y), reflect101c(x)) once launch_pyr_border has run
+  int bx[LK_MAX_LEVELS] = {}, by[LK_MAX_LEVELS] = {};
 };
+// Border of the tracker's pyramids.  A patch / search region of a point that lies inside the image reaches at most 23 / 32 columns
+// and 17 / 21 rows over the edge (lk_kernel.hip); wider excursions (a point tracked out of the image) take the kernel's slow path.
+constexpr int LK_BORDER_X = 32, LK_BORDER_Y = 24;
 
 struct LKParams {
   int max_iter;     // clamped to [0,100] like cv::calcOpticalFlowPyrLK
@@ -38,7 +44,22 @@ struct LKParams {
   int use_initial;  // OPTFLOW_USE_INITIAL_FLOW
   // optional statistics (nullptr: none): stats[2 l] += Gauss-Newton iterations run at level l, stats[2 l + 1] += points that iterated there
   unsigned long long* stats = nullptr;
+  // ... and (nullptr: none) stats_tc[0] += templates taken from the cache, [1] += template patches and [2] += search regions staged by
+  // the slow (index-reflecting) path
+  unsigned long long* stats_tc = nullptr;
+  // Template cache (lk_kernel.hip).  The stereo matcher of frame t computes, for every landmark, the template -- interpolated I, Ix, Iy
+  // of the 31 x 31 window on every level + the Hessian sums -- at the landmark's pixel in the left image of frame t; the temporal
+  // tracker of frame t + 1 needs exactly that template (previous image = that image, previous point = that pixel).  tc_mode 1: every
+  // point p < tc_cap stores its templates in slot p, with the position bits and tc_tag[s] in the slot's header.  tc_mode 2: point p
+  // looks at slot tc_slot[s * nmax + p] (-1: none) and takes the templates if position bits and tag match, otherwise it computes them.
+  // HBM capacity and bandwidth (idle on this path) spent to save the VALU work that bounds the kernel.
+  uint32_t* tc = nullptr;             // [S][tc_cap][tc_stride]
+  int tc_mode = 0, tc_cap = 0, tc_stride = 0;
+  const int* tc_slot = nullptr;       // [S][nmax]
+  const long long* tc_tag = nullptr;  // [S] identity of the template image (the stream's frame id)
 };
+// dwords of one template-cache slot for a pyramid with levels 0 .. levels
+int lk_tc_slot_dwords(int levels);
 
 struct DemParams {
   int regionWidth, regionHeight, boundary_dis;
@@ -63,6 +84,8 @@ void launch_copy_image_any(hipStream_t st, ImgSel src, ImgSel dst, int w, int h,
                            size_t dstride, int S, const int* active);
 void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,
                      size_t dstride, int S, const int* active);
+// fills the border of every level that has one (one launch; levels without a border are skipped)
+void launch_pyr_border(hipStream_t st, const PyrSel& pyr, int S, const int* active);
 // level 1 of a pyramid fused with the ingest copy: reads the caller's image once, writes level 0 (dst0) and level 1 (dst)
 void launch_pyr_down_ingest(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0, int d0pitch,
                             size_t d0stride, ImgSel dst, int dpitch, size_t dstride, int S, const int* active);
@@ -86,7 +109,9 @@ void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, cons
                         int* out_n, int out_cap);
 // pyramidal LK, 31x31 window: one wave per (stream, point)
 // max_pts: upper bound of count[] known to the caller (sizes the grid; any value is correct, the kernel strides), <= 0: nmax
+// role: 0 stand-alone call, 1 the tracker's temporal launch, 2 its stereo launch (kernel instances k_lk_track<role>: named apart in
+// the profiles; only <1> reads and only <2> writes the template cache)
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
-                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active, int max_pts = 0);
+                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active, int max_pts = 0, int role = 0);
 
 }  // namespace flvis

@@ -25,17 +25,25 @@ constexpr int LK_PROWS = 34;  // rows of the template-source patch
 constexpr int LK_RM = 4;      // search-region margin (pixels)
 constexpr int LK_RS = 52;     // search-region row stride (bytes): 13 dwords (odd -> conflict-free row walks)
 constexpr int LK_RROWS = 33 + 2 * LK_RM;
+// template cache (LKParams::tc): one slot per (stream, point); LK_TC_HDR header dwords -- position bits (2), tag (2), mask of the levels
+// stored (1), 3 unused, then the three Hessian sums of every level as int64 (6 dwords per level) -- followed by LK_TC_LVL dwords per
+// level: the 24 template registers (tI, tX, tY: 8 packed pairs each) of the 64 lanes as six 1 KB rows (one dwordx4 per lane and row)
+constexpr int LK_TC_HDR = 64;
+constexpr int LK_TC_LVL = 64 * 24;
+static_assert(8 + 6 * LK_MAX_LEVELS <= LK_TC_HDR, "header");
 
 typedef short lk_s2 __attribute__((ext_vector_type(2)));
+typedef uint32_t lk_u4 __attribute__((ext_vector_type(4)));  // (a native vector: the non-temporal builtins do not take HIP's uint4 class)
 
 // patch[r][c] = img(X0 + c, Y0 + r) for r < nrows, c < 36, REFLECT_101 outside the image.  Item i = 9 r + k is dword k of row r; a lane
 // takes items lane, lane + 64, ...  When the whole patch lies inside the image (wave-uniform test; nearly every point) there is nothing to
 // reflect and nothing to divide: a lane's (row, dword) advances by (7, 1) per trip (64 = 7 * 9 + 1) with one wrap test, its byte offset
 // into the image and its LDS address advance by constants, and the address is a uniform base + a 32-bit lane offset.
-__device__ __forceinline__ void lk_load_patch(const uint8_t* __restrict__ img, int w, int h, int pitch, int X0, int Y0,
+// (bx, by) = the level's physical REFLECT_101 border: the fast path covers every block that lies inside the bordered storage.
+__device__ __forceinline__ bool lk_load_patch(const uint8_t* __restrict__ img, int w, int h, int pitch, int bx, int by, int X0, int Y0,
                                               int nrows, uint8_t* patch) {
-  if (X0 >= 0 && Y0 >= 0 && X0 + 39 < w && Y0 + nrows <= h) {  // (+ 39: the second dword of the last item stays inside the row)
-    const uint8_t* const base = img + (size_t)Y0 * pitch + (X0 & ~3);
+  if (X0 >= -bx && Y0 >= -by && X0 + 39 < w + bx && Y0 + nrows <= h + by) {  // (+ 39: the second dword of the last item stays inside the row)
+    const uint8_t* const base = img + (ptrdiff_t)Y0 * pitch + (X0 & ~3);
     const int sh = X0 & 3;
     int r = (int)threadIdx.x / 9, k = (int)threadIdx.x - 9 * r;
     unsigned off = (unsigned)(r * pitch + 4 * k);
@@ -51,7 +59,7 @@ __device__ __forceinline__ void lk_load_patch(const uint8_t* __restrict__ img, i
       off += (unsigned)(7 * pitch + 4) + (wrap ? (unsigned)(pitch - 36) : 0u);
       dst += (unsigned)(7 * LK_PS + 4) + (wrap ? (unsigned)(LK_PS - 36) : 0u);
     }
-    return;
+    return false;
   }
   for (int i = threadIdx.x; i < nrows * 9; i += 64) {
     int r = i / 9, k = i - r * 9;
@@ -71,14 +79,15 @@ __device__ __forceinline__ void lk_load_patch(const uint8_t* __restrict__ img, i
     }
     *reinterpret_cast<uint32_t*>(patch + r * LK_PS + 4 * k) = v;
   }
+  return true;
 }
 
 // region[r][c] = img(X0 + c, Y0 + r), r < LK_RROWS, c < 52, X0 a multiple of 4 (aligned dword loads), REFLECT_101 outside.  Same fast
 // path when the region lies inside the image: (row, dword) advances by (4, 12) per trip (64 = 4 * 13 + 12).
-__device__ __forceinline__ void lk_load_region(const uint8_t* __restrict__ img, int w, int h, int pitch, int X0, int Y0,
+__device__ __forceinline__ bool lk_load_region(const uint8_t* __restrict__ img, int w, int h, int pitch, int bx, int by, int X0, int Y0,
                                                uint8_t* region) {
-  if (X0 >= 0 && Y0 >= 0 && X0 + 51 < w && Y0 + LK_RROWS <= h) {
-    const uint8_t* const base = img + (size_t)Y0 * pitch + X0;
+  if (X0 >= -bx && Y0 >= -by && X0 + 51 < w + bx && Y0 + LK_RROWS <= h + by) {
+    const uint8_t* const base = img + (ptrdiff_t)Y0 * pitch + X0;
     int r = (int)threadIdx.x / 13, k = (int)threadIdx.x - 13 * r;
     unsigned off = (unsigned)(r * pitch + 4 * k);
     static_assert(LK_RS == 52, "the region rows are contiguous in LDS: item i sits at byte 4 i");
@@ -89,7 +98,7 @@ __device__ __forceinline__ void lk_load_region(const uint8_t* __restrict__ img, 
       k = wrap ? k - 13 : k;
       off += (unsigned)(4 * pitch + 48) + (wrap ? (unsigned)(pitch - 52) : 0u);
     }
-    return;
+    return false;
   }
   for (int i = threadIdx.x; i < LK_RROWS * 13; i += 64) {
     int r = i / 13, k = i - r * 13;
@@ -105,11 +114,8 @@ __device__ __forceinline__ void lk_load_region(const uint8_t* __restrict__ img, 
     }
     *reinterpret_cast<uint32_t*>(region + r * LK_RS + 4 * k) = v;
   }
+  return true;
 }
-
-__device__ __forceinline__ int descale_i(int x, int n) { return (x + (1 << (n - 1))) >> n; }
-
-#define LK_BYTE(D, K) ((int)(((D)[(K) >> 2] >> (((K)&3) * 8)) & 255u))
 
 // bytes K and K+1 of the dword array D, widened to a pair of 16-bit lanes (one v_perm_b32; K is a compile-time constant)
 #define LK_PAIR(D, K)                                                                                              \
@@ -134,8 +140,114 @@ __device__ __forceinline__ long long lk_wave_sum_wide(int v) {
   return ((long long)hi << 16) + (long long)lo;
 }
 
+// The interpolated template of one level: I, Ix, Iy of the 31 x 31 window as packed int16 pairs in the lane's registers (lane = window
+// row lane >> 1, 16-column half lane & 1) and this lane's share of the three Hessian sums.  Packed 16-bit path: two columns per
+// instruction (v_pk_*), the bilinear weights applied with v_dot2c_i32_i16.  Every lane (window rows 0 .. 31: the lanes of row 31 only
+// serve their neighbours) computes the Scharr derivatives of ITS row once; the derivatives of row r + 1, which the bilinear
+// interpolation also needs, come from the lane two above (same column half) through ds_bpermute -- 18 exchanges on the LDS pipe instead
+// of computing every derivative row twice on the VALUs.  INTERIOR: every pixel the stencil is evaluated at lies inside the image.
+// Otherwise the derivative image is ZERO outside the image (cv::calcOpticalFlowPyrLK's derivative pyramid has a constant border, the
+// intensity pyramid a reflected one): the staged patch holds the reflected intensities, the derivatives of this lane's row are masked
+// per column pair before they are used and exchanged (9 masks from one 18-bit column-validity word).
+template <bool INTERIOR>
+__device__ __forceinline__ void lk_template(const uint8_t* patch, int lane, int ipx, int ipy, int W, int H, lk_s2 wT, lk_s2 wB,
+                                            lk_s2 (&tI)[8], lk_s2 (&tX)[8], lk_s2 (&tY)[8], int& a11, int& a12, int& a22) {
+  constexpr int W_BITS = 14;
+  const int r = lane >> 1, c0 = (lane & 1) * 16;
+  uint32_t d[3][5];
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[j][k] = *reinterpret_cast<const uint32_t*>(patch + (r + j) * LK_PS + c0 + 4 * k);
+  uint32_t bits = 0;
+  if (!INTERIOR) {
+    // window columns c0 .. c0 + 17 of this lane's row: image (ipx + c0 + c, ipy + r)
+    const int xs = ipx + c0, Y = ipy + r;
+    int lo = -xs, hi = W - xs;
+    lo = lo < 0 ? 0 : (lo > 18 ? 18 : lo);
+    hi = hi < 0 ? 0 : (hi > 18 ? 18 : hi);
+    bits = (Y >= 0 && Y < H && hi > lo) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+  }
+  lk_s2 DX[2][9], DY[2][9];  // (v[2j], v[2j+1]) of window row r + dr
+  {
+    lk_s2 T0[10], T1[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+      const lk_s2 A = __builtin_bit_cast(lk_s2, LK_PAIR(d[0], 2 * j)), B = __builtin_bit_cast(lk_s2, LK_PAIR(d[1], 2 * j)),
+                  Cc = __builtin_bit_cast(lk_s2, LK_PAIR(d[2], 2 * j));
+      T0[j] = (A + Cc) * (short)3 + B * (short)10;
+      T1[j] = Cc - A;
+    }
+    const int up2 = ((lane + 2) & 63) * 4;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      DX[0][j] = T0[j + 1] - T0[j];
+      const lk_s2 T1o = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, T1[j + 1]),
+                                                                       __builtin_bit_cast(uint32_t, T1[j]), 0x05040302u));
+      DY[0][j] = (T1[j + 1] + T1[j]) * (short)3 + T1o * (short)10;
+      if (!INTERIOR) {
+        const uint32_t m = ((bits >> (2 * j)) & 1u ? 0x0000ffffu : 0u) | ((bits >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u);
+        DX[0][j] = __builtin_bit_cast(lk_s2, __builtin_bit_cast(uint32_t, DX[0][j]) & m);
+        DY[0][j] = __builtin_bit_cast(lk_s2, __builtin_bit_cast(uint32_t, DY[0][j]) & m);
+      }
+      DX[1][j] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_ds_bpermute(up2, __builtin_bit_cast(int, DX[0][j])));
+      DY[1][j] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_ds_bpermute(up2, __builtin_bit_cast(int, DY[0][j])));
+    }
+  }
+  if (r < LK_WIN) {
+    // (intensity rows r, r + 1 of the window are patch rows r + 1, r + 2: d[1], d[2])
+#pragma unroll
+    for (int c2 = 0; c2 < 8; c2++) {
+      int iv[2], ix[2], iy[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const int c = 2 * c2 + hh;
+        lk_s2 x0, x1, y0, y1;  // (v[c], v[c+1]) of rows r, r+1
+        if (hh == 0) {
+          x0 = DX[0][c2]; x1 = DX[1][c2]; y0 = DY[0][c2]; y1 = DY[1][c2];
+        } else {
+          x0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[0][c2 + 1]), __builtin_bit_cast(uint32_t, DX[0][c2]), 0x05040302u));
+          x1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[1][c2 + 1]), __builtin_bit_cast(uint32_t, DX[1][c2]), 0x05040302u));
+          y0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[0][c2 + 1]), __builtin_bit_cast(uint32_t, DY[0][c2]), 0x05040302u));
+          y1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[1][c2 + 1]), __builtin_bit_cast(uint32_t, DY[1][c2]), 0x05040302u));
+        }
+        int ax = 1 << (W_BITS - 1), ay = 1 << (W_BITS - 1), ai = 1 << (W_BITS - 5 - 1);
+        ax = __builtin_amdgcn_sdot2(x0, wT, ax, false);
+        ax = __builtin_amdgcn_sdot2(x1, wB, ax, false);
+        ay = __builtin_amdgcn_sdot2(y0, wT, ay, false);
+        ay = __builtin_amdgcn_sdot2(y1, wB, ay, false);
+        ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[1], c + 1)), wT, ai, false);
+        ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[2], c + 1)), wB, ai, false);
+        const bool on = c0 + c < LK_WIN;  // window column 31 of the second half does not exist
+        ix[hh] = on ? (ax >> W_BITS) : 0;
+        iy[hh] = on ? (ay >> W_BITS) : 0;
+        iv[hh] = on ? (ai >> (W_BITS - 5)) : 0;
+      }
+      tI[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iv[1], (uint32_t)iv[0], 0x05040100u));
+      tX[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)ix[1], (uint32_t)ix[0], 0x05040100u));
+      tY[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iy[1], (uint32_t)iy[0], 0x05040100u));
+      a11 = __builtin_amdgcn_sdot2(tX[c2], tX[c2], a11, false);
+      a12 = __builtin_amdgcn_sdot2(tX[c2], tY[c2], a12, false);
+      a22 = __builtin_amdgcn_sdot2(tY[c2], tY[c2], a22, false);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      tI[c] = lk_s2{0, 0};
+      tX[c] = lk_s2{0, 0};
+      tY[c] = lk_s2{0, 0};
+    }
+  }
+}
+
+#ifndef FLVIS_LK_WAVES
+#define FLVIS_LK_WAVES 4  // (build-variant knob: waves per SIMD the register allocation aims at)
+#endif
 // 4 waves per SIMD (<= 128 VGPRs): this kernel is latency-bound (PMC: VALU busy ~20%), occupancy is what pays
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lk_track(PyrSel prev, PyrSel next, const float* __restrict__ prev_pts,
+// ROLE names the launch in the profiles and fixes what the template cache may do: 0 the stand-alone entry point (no cache), 1 the
+// tracker's temporal launch (may take templates from the cache), 2 its stereo launch (may store them)
+template <int ROLE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAVES, FLVIS_LK_WAVES))) void k_lk_track(PyrSel prev, PyrSel next, const float* __restrict__ prev_pts,
                                                  float* __restrict__ next_pts, uint8_t* __restrict__ status,
                                                  const int* __restrict__ count, int nmax, LKParams prm,
                                                  const int* __restrict__ active) {
@@ -168,6 +280,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const float ppx0 = prev_pts[pi], ppy0 = prev_pts[pi + 1];
     float nx = next_pts[pi], ny = next_pts[pi + 1];
     int st = 1;
+    // template cache: the slot this point stores its templates in (stereo matcher), or the slot it may take them from (temporal
+    // tracker: valid if it was written for this very position of this very image)
+    uint32_t* tc_ptr = nullptr;
+    bool tc_store = false, tc_hit = false;
+    uint32_t tc_mask = 0;
+    if (ROLE == 2 && prm.tc_mode == 1) {
+      if (p < prm.tc_cap) {
+        tc_store = true;
+        tc_ptr = prm.tc + ((size_t)s * prm.tc_cap + p) * prm.tc_stride;
+      }
+    } else if (ROLE == 1 && prm.tc_mode == 2) {
+      const int slot = prm.tc_slot[(size_t)s * nmax + p];
+      if (slot >= 0 && slot < prm.tc_cap) {
+        tc_ptr = prm.tc + ((size_t)s * prm.tc_cap + slot) * prm.tc_stride;
+        const long long tag = *reinterpret_cast<const long long*>(tc_ptr + 2);
+        const bool ok = tc_ptr[0] == __float_as_uint(ppx0) && tc_ptr[1] == __float_as_uint(ppy0) && tag == prm.tc_tag[s];
+        tc_hit = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+        tc_mask = tc_hit ? (uint32_t)__builtin_amdgcn_readfirstlane((int)tc_ptr[4]) : 0u;
+      }
+    }
     for (int level = prev.levels; level >= 0; level--) {
       const float sc = (float)(1. / (1 << level));
       float ppx = ppx0 * sc, ppy = ppy0 * sc;
@@ -200,157 +332,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       int iw10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
       int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-      // ---- template: stage source patch rows ipy-1..ipy+32, cols ipx-1..ipx+34
-      __syncthreads();
-      lk_load_patch(prev.lvl[level].ptr(s, prev.stride[level]), W, H, prev.pitch[level], ipx - 1, ipy - 1, LK_PROWS,
-                    patch);
-      __syncthreads();
+      // ---- template.  Either from the cache (the stereo matcher of the previous frame made this very template: same image, same
+      // position), or computed: stage source patch rows ipy-1..ipy+32, cols ipx-1..ipx+34, Scharr + bilinear interpolation
       lk_s2 tI[8], tX[8], tY[8];  // pixel pairs (c, c+1)
-      int a11 = 0, a12 = 0, a22 = 0;
-      // every pixel the Scharr stencil is evaluated at lies inside the image -> no border masks (wave-uniform test)
-      const bool interior = ipx >= 0 && ipx + 32 <= W - 1 && ipy >= 0 && ipy + 31 <= H - 1;
-      if (interior) {
-        // packed 16-bit path: two columns per instruction (v_pk_*), weights applied with v_dot2c_i32_i16.  Every lane (window rows
-        // 0 .. 31: the lanes of row 31 only serve their neighbours) computes the Scharr derivatives of ITS row once; the derivatives
-        // of row r + 1, which the bilinear interpolation also needs, come from the lane two above (same column half) through
-        // ds_bpermute -- 18 exchanges on the LDS pipe instead of computing every derivative row twice on the VALUs
-        uint32_t d[3][5];
+      long long iA11, iA12, iA22;
+      const bool cached = ROLE == 1 && tc_hit && ((tc_mask >> level) & 1u);
+      if (cached) {
+        if (prm.stats_tc && lane == 0) atomicAdd(&prm.stats_tc[0], 1ull);
+        const lk_u4* src = reinterpret_cast<const lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
+        lk_u4 q[6];
 #pragma unroll
-        for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 6; k++) q[k] = __builtin_nontemporal_load(src + 64 * k);
+        const long long* sums = reinterpret_cast<const long long*>(tc_ptr + 8 + 6 * level);
+        iA11 = sums[0];
+        iA12 = sums[1];
+        iA22 = sums[2];
 #pragma unroll
-          for (int k = 0; k < 5; k++) d[j][k] = *reinterpret_cast<const uint32_t*>(patch + (r + j) * LK_PS + c0 + 4 * k);
-        const lk_s2 wT = lk_s2{(short)iw00, (short)iw01}, wB = lk_s2{(short)iw10, (short)iw11};
-        lk_s2 DX[2][9], DY[2][9];  // (v[2j], v[2j+1]) of window row r + dr
-        {
-          lk_s2 T0[10], T1[10];
-#pragma unroll
-          for (int j = 0; j < 10; j++) {
-            const lk_s2 A = __builtin_bit_cast(lk_s2, LK_PAIR(d[0], 2 * j)), B = __builtin_bit_cast(lk_s2, LK_PAIR(d[1], 2 * j)),
-                        Cc = __builtin_bit_cast(lk_s2, LK_PAIR(d[2], 2 * j));
-            T0[j] = (A + Cc) * (short)3 + B * (short)10;
-            T1[j] = Cc - A;
-          }
-          const int up2 = ((lane + 2) & 63) * 4;
-#pragma unroll
-          for (int j = 0; j < 9; j++) {
-            DX[0][j] = T0[j + 1] - T0[j];
-            const lk_s2 T1o = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, T1[j + 1]),
-                                                                             __builtin_bit_cast(uint32_t, T1[j]), 0x05040302u));
-            DY[0][j] = (T1[j + 1] + T1[j]) * (short)3 + T1o * (short)10;
-            DX[1][j] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_ds_bpermute(up2, __builtin_bit_cast(int, DX[0][j])));
-            DY[1][j] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_ds_bpermute(up2, __builtin_bit_cast(int, DY[0][j])));
-          }
-        }
-        if (r < LK_WIN) {
-          // (intensity rows r, r + 1 of the window are patch rows r + 1, r + 2: d[1], d[2])
-#pragma unroll
-          for (int c2 = 0; c2 < 8; c2++) {
-            int iv[2], ix[2], iy[2];
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-              const int c = 2 * c2 + hh;
-              lk_s2 x0, x1, y0, y1;  // (v[c], v[c+1]) of rows r, r+1
-              if (hh == 0) {
-                x0 = DX[0][c2]; x1 = DX[1][c2]; y0 = DY[0][c2]; y1 = DY[1][c2];
-              } else {
-                x0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[0][c2 + 1]), __builtin_bit_cast(uint32_t, DX[0][c2]), 0x05040302u));
-                x1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DX[1][c2 + 1]), __builtin_bit_cast(uint32_t, DX[1][c2]), 0x05040302u));
-                y0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[0][c2 + 1]), __builtin_bit_cast(uint32_t, DY[0][c2]), 0x05040302u));
-                y1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[1][c2 + 1]), __builtin_bit_cast(uint32_t, DY[1][c2]), 0x05040302u));
-              }
-              int ax = 1 << (W_BITS - 1), ay = 1 << (W_BITS - 1), ai = 1 << (W_BITS - 5 - 1);
-              ax = __builtin_amdgcn_sdot2(x0, wT, ax, false);
-              ax = __builtin_amdgcn_sdot2(x1, wB, ax, false);
-              ay = __builtin_amdgcn_sdot2(y0, wT, ay, false);
-              ay = __builtin_amdgcn_sdot2(y1, wB, ay, false);
-              ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[1], c + 1)), wT, ai, false);
-              ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[2], c + 1)), wB, ai, false);
-              const bool on = c0 + c < LK_WIN;  // window column 31 of the second half does not exist
-              ix[hh] = on ? (ax >> W_BITS) : 0;
-              iy[hh] = on ? (ay >> W_BITS) : 0;
-              iv[hh] = on ? (ai >> (W_BITS - 5)) : 0;
-            }
-            tI[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iv[1], (uint32_t)iv[0], 0x05040100u));
-            tX[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)ix[1], (uint32_t)ix[0], 0x05040100u));
-            tY[c2] = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((uint32_t)iy[1], (uint32_t)iy[0], 0x05040100u));
-            a11 = __builtin_amdgcn_sdot2(tX[c2], tX[c2], a11, false);
-            a12 = __builtin_amdgcn_sdot2(tX[c2], tY[c2], a12, false);
-            a22 = __builtin_amdgcn_sdot2(tY[c2], tY[c2], a22, false);
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 8; c++) {
-            tI[c] = lk_s2{0, 0};
-            tX[c] = lk_s2{0, 0};
-            tY[c] = lk_s2{0, 0};
-          }
-        }
-      } else if (r < LK_WIN) {
-        uint32_t d[4][5];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int k = 0; k < 5; k++) d[j][k] = *reinterpret_cast<const uint32_t*>(patch + (r + j) * LK_PS + c0 + 4 * k);
-        // Scharr derivatives on window rows r (dr=0) and r+1 (dr=1), window cols c0..c0+16; zero outside the image
-        int dx[2][17], dy[2][17];
-#pragma unroll
-        for (int dr = 0; dr < 2; dr++) {
-          int t0[19], t1[19];
-#pragma unroll
-          for (int k = 0; k < 19; k++) {
-            int va = LK_BYTE(d[dr], k), vb = LK_BYTE(d[dr + 1], k), vc = LK_BYTE(d[dr + 2], k);
-            t0[k] = (va + vc) * 3 + vb * 10;
-            t1[k] = vc - va;
-          }
-          const int Y = ipy + r + dr;
-          const bool yin = (Y >= 0 && Y < H);
-#pragma unroll
-          for (int c = 0; c < 17; c++) {
-            const int X = ipx + c0 + c;
-            const bool in = yin && X >= 0 && X < W;
-            dx[dr][c] = in ? (t0[c + 2] - t0[c]) : 0;
-            dy[dr][c] = in ? ((t1[c + 2] + t1[c]) * 3 + t1[c + 1] * 10) : 0;
-          }
-        }
-        short sI[16], sX[16], sY[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-          if (c0 + c < LK_WIN) {
-            int i00 = LK_BYTE(d[1], c + 1), i01 = LK_BYTE(d[1], c + 2), i10 = LK_BYTE(d[2], c + 1),
-                i11 = LK_BYTE(d[2], c + 2);
-            // all factors fit 24 bits (pixels 8, weights 15, Scharr sums 13): full-rate 24-bit multiplies
-            int ival = descale_i(__mul24(i00, iw00) + __mul24(i01, iw01) + __mul24(i10, iw10) + __mul24(i11, iw11), W_BITS - 5);
-            int ixval = descale_i(__mul24(dx[0][c], iw00) + __mul24(dx[0][c + 1], iw01) + __mul24(dx[1][c], iw10) +
-                                      __mul24(dx[1][c + 1], iw11), W_BITS);
-            int iyval = descale_i(__mul24(dy[0][c], iw00) + __mul24(dy[0][c + 1], iw01) + __mul24(dy[1][c], iw10) +
-                                      __mul24(dy[1][c + 1], iw11), W_BITS);
-            sI[c] = (short)ival;
-            sX[c] = (short)ixval;
-            sY[c] = (short)iyval;
-            a11 += __mul24(ixval, ixval);
-            a12 += __mul24(ixval, iyval);
-            a22 += __mul24(iyval, iyval);
-          } else {
-            sI[c] = 0;
-            sX[c] = 0;
-            sY[c] = 0;
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          tI[c] = lk_s2{sI[2 * c], sI[2 * c + 1]};
-          tX[c] = lk_s2{sX[2 * c], sX[2 * c + 1]};
-          tY[c] = lk_s2{sY[2 * c], sY[2 * c + 1]};
+        for (int k = 0; k < 2; k++) {
+          tI[4 * k + 0] = __builtin_bit_cast(lk_s2, q[k].x); tI[4 * k + 1] = __builtin_bit_cast(lk_s2, q[k].y);
+          tI[4 * k + 2] = __builtin_bit_cast(lk_s2, q[k].z); tI[4 * k + 3] = __builtin_bit_cast(lk_s2, q[k].w);
+          tX[4 * k + 0] = __builtin_bit_cast(lk_s2, q[2 + k].x); tX[4 * k + 1] = __builtin_bit_cast(lk_s2, q[2 + k].y);
+          tX[4 * k + 2] = __builtin_bit_cast(lk_s2, q[2 + k].z); tX[4 * k + 3] = __builtin_bit_cast(lk_s2, q[2 + k].w);
+          tY[4 * k + 0] = __builtin_bit_cast(lk_s2, q[4 + k].x); tY[4 * k + 1] = __builtin_bit_cast(lk_s2, q[4 + k].y);
+          tY[4 * k + 2] = __builtin_bit_cast(lk_s2, q[4 + k].z); tY[4 * k + 3] = __builtin_bit_cast(lk_s2, q[4 + k].w);
         }
       } else {
+        __syncthreads();
+        const bool slow = lk_load_patch(prev.lvl[level].ptr(s, prev.stride[level]), W, H, prev.pitch[level], prev.bx[level], prev.by[level],
+                                        ipx - 1, ipy - 1, LK_PROWS, patch);
+        __syncthreads();
+        if (prm.stats_tc && slow && lane == 0) atomicAdd(&prm.stats_tc[1], 1ull);
+        int a11 = 0, a12 = 0, a22 = 0;
+        // every pixel the Scharr stencil is evaluated at lies inside the image -> no border masks (wave-uniform test)
+        const bool interior = ipx >= 0 && ipx + 32 <= W - 1 && ipy >= 0 && ipy + 31 <= H - 1;
+        const lk_s2 wT = lk_s2{(short)iw00, (short)iw01}, wB = lk_s2{(short)iw10, (short)iw11};
+        if (interior)
+          lk_template<true>(patch, lane, ipx, ipy, W, H, wT, wB, tI, tX, tY, a11, a12, a22);
+        else
+          lk_template<false>(patch, lane, ipx, ipy, W, H, wT, wB, tI, tX, tY, a11, a12, a22);
+        iA11 = lk_wave_sum_wide(a11);
+        iA12 = lk_wave_sum_wide(a12);
+        iA22 = lk_wave_sum_wide(a22);
+        if (ROLE == 2 && tc_store) {
+          lk_u4* dst = reinterpret_cast<lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-          tI[c] = lk_s2{0, 0};
-          tX[c] = lk_s2{0, 0};
-          tY[c] = lk_s2{0, 0};
+          for (int k = 0; k < 2; k++) {
+            __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tI[4 * k]), __builtin_bit_cast(uint32_t, tI[4 * k + 1]),
+                                              __builtin_bit_cast(uint32_t, tI[4 * k + 2]), __builtin_bit_cast(uint32_t, tI[4 * k + 3])}, dst + 64 * k);
+            __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tX[4 * k]), __builtin_bit_cast(uint32_t, tX[4 * k + 1]),
+                                              __builtin_bit_cast(uint32_t, tX[4 * k + 2]), __builtin_bit_cast(uint32_t, tX[4 * k + 3])}, dst + 64 * (2 + k));
+            __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tY[4 * k]), __builtin_bit_cast(uint32_t, tY[4 * k + 1]),
+                                              __builtin_bit_cast(uint32_t, tY[4 * k + 2]), __builtin_bit_cast(uint32_t, tY[4 * k + 3])}, dst + 64 * (4 + k));
+          }
+          if (lane == 0) {
+            long long* sums = reinterpret_cast<long long*>(tc_ptr + 8 + 6 * level);
+            sums[0] = iA11;
+            sums[1] = iA12;
+            sums[2] = iA22;
+          }
+          tc_mask |= 1u << level;
         }
       }
-      const long long iA11 = lk_wave_sum_wide(a11), iA12 = lk_wave_sum_wide(a12), iA22 = lk_wave_sum_wide(a22);
       const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
       float D = A11 * A22 - A12 * A12;
       const float minEig = __fdiv_rn(A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12),
@@ -385,8 +427,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           RX0 = (inx - LK_RM) & ~3;
           RY0 = iny - LK_RM;
           __syncthreads();
-          lk_load_region(Jimg, JW, JH, next.pitch[level], RX0, RY0, patch);
+          const bool slow = lk_load_region(Jimg, JW, JH, next.pitch[level], next.bx[level], next.by[level], RX0, RY0, patch);
           __syncthreads();
+          if (prm.stats_tc && slow && lane == 0) atomicAdd(&prm.stats_tc[2], 1ull);
           region_ok = true;
         }
         int b1 = 0, b2 = 0;
@@ -453,20 +496,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       next_pts[pi] = nx;
       next_pts[pi + 1] = ny;
       status[(size_t)s * nmax + p] = (uint8_t)st;
+      if (ROLE == 2 && tc_store) {
+        tc_ptr[0] = __float_as_uint(ppx0);
+        tc_ptr[1] = __float_as_uint(ppy0);
+        *reinterpret_cast<long long*>(tc_ptr + 2) = prm.tc_tag[s];
+        tc_ptr[4] = tc_mask;
+      }
     }
   }
 }
 
+int lk_tc_slot_dwords(int levels) { return LK_TC_HDR + (levels + 1) * LK_TC_LVL; }
+
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
-                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active, int max_pts) {
+                     uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active, int max_pts, int role) {
   // one wave per point; the kernel strides by the grid width, so any width is correct.  Sized by the caller's bound on
   // the point count (the tracker holds <= 16 regions x max_region_feature_num landmarks), rounded so that the XCD-aware
   // renumbering stays a bijection (grid size a multiple of 8)
   int gx = nmax < 512 ? nmax : 512;
   if (max_pts > 0 && max_pts < gx) gx = (max_pts + 7) & ~7;
   if (gx > nmax) gx = nmax;
-  hipLaunchKernelGGL(k_lk_track, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm,
-                     active);
+  if (role == 1)
+    hipLaunchKernelGGL(k_lk_track<1>, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+  else if (role == 2)
+    hipLaunchKernelGGL(k_lk_track<2>, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+  else
+    hipLaunchKernelGGL(k_lk_track<0>, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
 }
 
 }  // namespace flvis

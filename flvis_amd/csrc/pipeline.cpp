@@ -44,6 +44,8 @@ struct Lane {
   // images
   uint8_t* pyr0[2][LK_MAX_LEVELS] = {};
   uint8_t* pyr1[LK_MAX_LEVELS] = {};
+  uint32_t* tc = nullptr;  // LK template cache [S][pipe.tc_cap][tc_stride dwords] (LKParams::tc), or nullptr
+  int tc_stride = 0;
   GfttScratch gftt;
   float* gftt_xy = nullptr;
   float* dem_sorted = nullptr;  // [S][2 gftt_num][2] FeatureDEM: the corners in region-major, score-sorted order (k_feature_dem_prep)
@@ -76,7 +78,7 @@ struct Lane {
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
-  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_lm = nullptr, ev_tri = nullptr;
+  hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_lm = nullptr, ev_tri = nullptr, ev_head = nullptr;
   int idx = 0;  // position in Pipeline::lanes
   // multi-lane trackers: ev_end[n % HOLD_RING] follows the lane's n-th frame (the context's stream waits for the frame whose
   // input buffers the caller may reuse next, see flvis_set_input_hold); ev_stagger follows the temporal LK of the lane's first
@@ -99,6 +101,7 @@ struct Pipeline {
   int levels_t = 0, levels_s = 0, levels = 0;
   int lw[LK_MAX_LEVELS], lh[LK_MAX_LEVELS], lpitch[LK_MAX_LEVELS];
   size_t lstride[LK_MAX_LEVELS];
+  int lbx = 0, lby = 0;  // physical border of every pyramid level (columns / rows on each side)
   int max_pts = 0;  // bound on the landmarks of a frame (16 regions x max_region_feature_num): sizes the LK grid
   long long frames_fed = 0;
   std::vector<void*> allocs;  // context-level device allocations (host-feed staging)
@@ -246,7 +249,7 @@ static void lane_destroy(Lane* L) {
     hipStreamDestroy(L->det_stream);
   }
   if (L->own_st && L->st) hipStreamDestroy(L->st);
-  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
+  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_head, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
                        L->ev_end[4], L->ev_end[5], L->ev_end[6], L->ev_end[7]})
     if (e) hipEventDestroy(e);
   for (int k = 0; k < Lane::BAQ; k++)
@@ -342,6 +345,8 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   DA(next_pts, float, (size_t)S * NMAX * 2);
   DA(lk_status, uint8_t, (size_t)S * NMAX);
   DA(lk_count, int, S);
+  DA(lk_slot, int, (size_t)S * NMAX);
+  DA(lk_tag, long long, S);
   DA(m1, float, (size_t)S * NMAX * 2);
   DA(m2, float, (size_t)S * NMAX * 2);
   DA(tri, double, (size_t)S * NMAX * 3);
@@ -406,6 +411,31 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   for (int l = 0; l <= pl->levels; l++) {
     for (int k = 0; k < 2; k++) ok = ok && ((L->pyr0[k][l] = dalloc<uint8_t>(L->allocs, pl->lstride[l] * S + 256)) != nullptr);
     ok = ok && ((L->pyr1[l] = dalloc<uint8_t>(L->allocs, pl->lstride[l] * S + 256)) != nullptr);
+    if (ok) {  // the level pointers address pixel (0, 0) of stream 0 inside the padded buffers
+      const size_t org = (size_t)pl->lby * pl->lpitch[l] + pl->lbx;
+      for (int k = 0; k < 2; k++) L->pyr0[k][l] += org;
+      L->pyr1[l] += org;
+    }
+  }
+  // LK template cache: the stereo matcher's templates of frame t are the temporal tracker's templates of frame t + 1 (LKParams::tc).
+  // Only rigs with a stereo matcher have one; FLVIS_LK_TCACHE=0 turns it off (A/B knob, and the reference point of the cache's test).
+  p.tc_cap = 0;
+  L->tc = nullptr;
+  {
+    const char* e = getenv("FLVIS_LK_TCACHE");
+    const bool on = !(e && atoi(e) == 0) && pl->cfg.cam_type != CAM_DEPTH && pl->levels_s == pl->levels_t;
+    if (ok && on) {
+      const int cap = std::min(NMAX, (pl->max_pts + 63) / 64 * 64);
+      L->tc_stride = lk_tc_slot_dwords(pl->levels_t);
+      const size_t n = (size_t)S * cap * L->tc_stride;
+      L->tc = dalloc<uint32_t>(L->allocs, n, false);
+      if (L->tc) {
+        hipMemset(L->tc, 0xff, n * sizeof(uint32_t));  // no header matches a position or a frame id
+        p.tc_cap = cap;
+      } else {
+        (void)hipGetLastError();  // no memory for it: run without
+      }
+    }
   }
   // GFTT scratch
   int cap = 1;
@@ -467,7 +497,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   }
   bool evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
   static_assert(Lane::HOLD_RING == 8, "event list below");
-  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
+  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
                         &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
     evok = evok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < Lane::BAQ && evok; k++)
@@ -501,12 +531,20 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   pl->levels_s = lk_levels(w, h, 31, 5);
   pl->levels = std::max(pl->levels_t, pl->levels_s);
   if (pl->levels >= LK_MAX_LEVELS) pl->levels = LK_MAX_LEVELS - 1;
+  {
+    const char* e = getenv("FLVIS_LK_BORDER");
+    const bool on = !(e && atoi(e) == 0);
+    pl->lbx = on ? LK_BORDER_X : 0;
+    pl->lby = on ? LK_BORDER_Y : 0;
+  }
   int lw = w, lh = h;
   for (int l = 0; l <= pl->levels; l++) {
     pl->lw[l] = lw;
     pl->lh[l] = lh;
-    pl->lpitch[l] = align_up(lw, 16);
-    pl->lstride[l] = (size_t)pl->lpitch[l] * lh + 64;
+    // levels are stored with a physical BORDER_REFLECT_101 border (img_kernels.hpp: LK_BORDER_X / LK_BORDER_Y; FLVIS_LK_BORDER=0: none,
+    // A/B knob): the level pointers address pixel (0, 0), rows -lby .. lh + lby - 1 and columns -lbx .. pitch - lbx - 1 are storage
+    pl->lpitch[l] = align_up(lw, 16) + 2 * pl->lbx;
+    pl->lstride[l] = (size_t)pl->lpitch[l] * (lh + 2 * pl->lby) + 64;
     pl->lstride[l] = (pl->lstride[l] + 63) / 64 * 64;
     lw = (lw + 1) / 2;
     lh = (lh + 1) / 2;
@@ -707,6 +745,8 @@ static void fill_pyr(Pipeline* pl, PyrSel& ps, uint8_t* const* l0, uint8_t* cons
     ps.h[l] = pl->lh[l];
     ps.pitch[l] = pl->lpitch[l];
     ps.stride[l] = pl->lstride[l];
+    ps.bx[l] = pl->lbx;
+    ps.by[l] = pl->lby;
   }
 }
 
@@ -820,6 +860,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
         launch_pyr_down(ds, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, nullptr);
     }
     if (pl->levels == 0 && !eq && aligned) launch_copy_image(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
+    if (pl->lbx) {
+      PyrSel pb;
+      fill_pyr(pl, pb, L->pyr0[0], L->pyr0[1], p.img_slot_in, 0, pl->levels);
+      launch_pyr_border(ds, pb, S, nullptr);
+    }
     PE(2, ds);
     hipEventRecord(L->ev_img, ds);
   }
@@ -827,6 +872,9 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   launch_frame_head(st, p, L->d_time, L->d_progress, frame_no);  // the staged IMU samples, then frame_begin
   if (pl->feedback_used) launch_apply_correction(st, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
   PE(0, st);
+  // the detection stream's kernels that read what k_frame_head decides (act_img, gftt_act, gftt_maxc, img_slot) wait for this event:
+  // the corner detection and the right pyramid in every FLVIS_DET_START mode (in the default mode they start behind the F-RANSAC anyway)
+  hipEventRecord(L->ev_head, st);
   if (skipped) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
@@ -854,7 +902,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
   // for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain.  The right image is only
   // read within this frame, so without equalizeHist the caller's buffer IS level 0 of the right pyramid (no copy).
-  const bool r_in_place = !eq && aligned;
+  const bool r_in_place = !eq && aligned && !pl->lbx;  // (a bordered level 0 is a copy: the first pyrDown writes it in the same pass)
   ImgSel r0 = r_in_place ? in1 : img_plain(L->pyr1[0]);
   const int r0pitch = r_in_place ? w : pl->lpitch[0];
   const size_t r0stride = r_in_place ? (size_t)w * h : pl->lstride[0];
@@ -869,6 +917,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // k_ransac_pnp / k_pose_lm / k_reproj_filter are latency chains on 64 CUs and leave the rest of the chip to the detection.
   static const int gftt_after_lk = getenv("FLVIS_DET_START") ? atoi(getenv("FLVIS_DET_START")) : 3;
   auto detect_corners = [&] {
+    hipStreamWaitEvent(ds, L->ev_head, 0);
     launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
                 (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
                 (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
@@ -879,12 +928,26 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   };
   if (gftt_first && !gftt_after_lk) detect_corners();
   auto right_pyramid = [&] {
+    hipStreamWaitEvent(ds, L->ev_head, 0);
     if (!depth_cam) {
       if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
       else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
-      for (int l = 1; l <= pl->levels; l++)
-        launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
-                        l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
+      const bool ingest = !r_in_place && !eq && aligned;  // level 0 = a copy of the caller's image, written by the first pyrDown
+      for (int l = 1; l <= pl->levels; l++) {
+        if (l == 1 && ingest)
+          launch_pyr_down_ingest(ds, in1, w, h, w, (size_t)w * h, img_plain(L->pyr1[0]), pl->lpitch[0], pl->lstride[0], img_plain(L->pyr1[1]),
+                                 pl->lpitch[1], pl->lstride[1], S, p.act_img);
+        else
+          launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
+                          l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
+      }
+      if (pl->levels == 0 && ingest)
+        launch_copy_image(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
+      if (pl->lbx) {
+        PyrSel pb;
+        fill_pyr(pl, pb, L->pyr1, nullptr, nullptr, 0, pl->levels);
+        launch_pyr_border(ds, pb, S, p.act_img);
+      }
     }
     if (!gftt_first) {
       launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
@@ -905,7 +968,16 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     fill_pyr(pl, next, L->pyr0[0], L->pyr0[1], p.img_slot, 0, pl->levels_t);
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
     if (pl->lk_stats) prm.stats = reinterpret_cast<unsigned long long*>(p.counters) + 36;  // temporal: counters[36 .. 47]
-    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track, pl->max_pts);
+    if (pl->lk_stats) prm.stats_tc = reinterpret_cast<unsigned long long*>(p.counters) + 61;  // both launches: counters[61 .. 63]
+    if (L->tc) {  // templates the stereo matcher of the previous frame stored (same image, same pixel): taken instead of computed
+      prm.tc = L->tc;
+      prm.tc_mode = 2;
+      prm.tc_cap = p.tc_cap;
+      prm.tc_stride = L->tc_stride;
+      prm.tc_slot = p.lk_slot;
+      prm.tc_tag = p.lk_tag;
+    }
+    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track, pl->max_pts, 1);
   }
   PE(4, st);
   if (gftt_first && gftt_after_lk == 1) {
@@ -964,9 +1036,18 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     next.lvl[0] = r0;
     next.pitch[0] = r0pitch;
     next.stride[0] = r0stride;
+    if (r_in_place) next.bx[0] = next.by[0] = 0;  // the caller's buffer has no border
     LKParams prm{30, 1e-3 * 1e-3, 1e-4f, 1};
     if (pl->lk_stats) prm.stats = reinterpret_cast<unsigned long long*>(p.counters) + 48;  // stereo: counters[48 .. 59]
-    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts);
+    if (pl->lk_stats) prm.stats_tc = reinterpret_cast<unsigned long long*>(p.counters) + 61;
+    if (L->tc) {  // ... which stores its templates for the next frame's temporal tracker
+      prm.tc = L->tc;
+      prm.tc_mode = 1;
+      prm.tc_cap = p.tc_cap;
+      prm.tc_stride = L->tc_stride;
+      prm.tc_tag = p.lk_tag;
+    }
+    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts, 2);
   }
   PE(15, st);
   hipStreamWaitEvent(st, L->ev_tri, 0);
@@ -1453,11 +1534,14 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first, int n, const c
 int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, double min_dt, int append) {
   if (!path || n < 0 || (n > 0 && !h_rows11)) return FLVIS_ERR_INVALID_ARG;
   FILE* f = fopen(path, append ? "a" : "w");
-  if (!f) return FLVIS_ERR_INVALID_ARG;
+  if (!f) return FLVIS_ERR_CONFIG;
   int written = 0;
+  // the recorder's `last_time` is the stamp of the first message of the RUN (vo_repub_rec.cpp:77-78): the batch that creates the file
+  // carries it; appended batches belong to the same run and are past it
+  const bool throttle = min_dt > 0 && !append;
   for (int i = 0; i < n; i++) {
     const double* r = h_rows11 + (size_t)i * 11;
-    if (min_dt > 0 && !(r[0] - h_rows11[0] > min_dt)) continue;
+    if (throttle && !(r[0] - h_rows11[0] > min_dt)) continue;
     fprintf(f, "%.9f %.6g %.6g %.6g %.6g %.6g %.6g %.6g\n", r[0], r[5], r[6], r[7], r[1], r[2], r[3], r[4]);
     written++;
   }

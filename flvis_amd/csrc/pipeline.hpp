@@ -37,8 +37,11 @@ struct Landmark {
   double p3c[3];
   double first2d[2];
   double first_pose[7];  // tx ty tz qx qy qz qw
-  unsigned char has3d, inlier, pad[6];
+  unsigned char has3d, inlier;
+  short tslot;  // slot of the LK template cache that holds this landmark's templates at p2d in its frame's left image (k_depth_seeds), -1: none
+  unsigned char pad[4];
 };
+static_assert(sizeof(Landmark) == 21 * 8, "Landmark layout");
 
 struct MotionState {  // MOTION_STATE (vi_motion.h:12-17)
   double pos[3], vel[3], q[4] /*w x y z*/, acc[3], gyro[3], t;

@@ -310,9 +310,13 @@ __global__ __launch_bounds__(256) void k_track_prepare(Pipe p) {
   const int last = st.cur ^ 1;
   const int n = st.n_lm[last];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) p.lk_count[s] = n;
+  if (i == 0) {
+    p.lk_count[s] = n;
+    p.lk_tag[s] = st.frame_id[last];  // the templates come from the last frame's left image
+  }
   if (i >= n) return;
   const Landmark& lm = lm_ptr(p, last, s)[i];
+  p.lk_slot[(size_t)s * NMAX + i] = lm.tslot;
   float px = (float)lm.p2d[0], py = (float)lm.p2d[1];
   float* pp = p.prev_pts + ((size_t)s * NMAX + i) * 2;
   float* np = p.next_pts + ((size_t)s * NMAX + i) * 2;
@@ -1672,6 +1676,9 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
   long long* ids = reinterpret_cast<long long*>(sh.terms);
   // the tail of the tracking step (k_track_post's work) by one lane of wave 1, while wave 0 gathers the edges
   __shared__ int s_go;
+  // (track_post_dev may end the frame -- track_fail sets phase = PH_IDLE and flips cur: every wave has read phase / cur / n_lm above
+  // before one lane is allowed to change them)
+  __syncthreads();
   if (tid == 64) s_go = track_post_dev(p, s) ? 1 : 0;
   // gather the edges (has3d && inlier) in frame order (wave 0)
   if (tid < 64) {
@@ -1865,7 +1872,8 @@ __global__ __launch_bounds__(64) void k_add_new(Pipe p) {
     for (int j = 0; j < 7; j++) lm.first_pose[j] = st.T_c_w[cur][j];
     lm.has3d = 0;
     lm.inlier = as_inlier ? 1 : 0;
-    for (int j = 0; j < 6; j++) lm.pad[j] = 0;
+    lm.tslot = -1;
+    for (int j = 0; j < 4; j++) lm.pad[j] = 0;
     lms[n0 + k] = lm;
   }
   __syncthreads();
@@ -1886,10 +1894,14 @@ __global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
   const int cur = st.cur;
   const int n = st.n_lm[cur];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) p.lk_count[s] = n;
+  if (i == 0) {
+    p.lk_count[s] = n;
+    p.lk_tag[s] = st.frame_id[cur];  // the stereo matcher's templates come from this frame's left image
+  }
   if (i >= n) return;
   if (p.cam.cam_type == CAM_DEPTH) return;  // the measurement comes from the depth image, no stereo matching
-  const Landmark& lm = lm_ptr(p, cur, s)[i];
+  Landmark& lm = lm_ptr(p, cur, s)[i];
+  lm.tslot = i < p.tc_cap ? (short)i : (short)-1;  // where the stereo LK stores point i's templates (read back by the next frame's temporal LK)
   // stereo LK seeds (camera_frame.cpp:108-122)
   float* p0 = p.prev_pts + ((size_t)s * NMAX + i) * 2;
   float* p1 = p.next_pts + ((size_t)s * NMAX + i) * 2;

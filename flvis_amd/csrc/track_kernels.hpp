@@ -20,6 +20,9 @@ struct Pipe {
   float* next_pts;          // [S][NMAX][2]
   uint8_t* lk_status;       // [S][NMAX]
   int* lk_count;            // [S]
+  int* lk_slot;             // [S][NMAX] temporal LK: template-cache slot of each previous point (Landmark::tslot), -1: none
+  long long* lk_tag;        // [S] identity of the LK launch's template image (frame id of the stream's current / last frame)
+  int tc_cap;               // slots per stream of the lane's template cache (0: no cache)
   float* m1;                // [S][NMAX][2]  F-RANSAC inputs (ascending survivors)
   float* m2;
   double* tri;              // [S][NMAX][3]

@@ -101,7 +101,7 @@ def kernel_table(stages, S, w, h, copy_gbs, pmc=None, ba=None, ms_per_step=None)
                "algorithmic_bytes_per_launch": int(b), "achieved_GBs": round(b / (ms * 1e-3) / 1e9, 1),
                "frac_of_hbm_peak": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "note": "one wave per point; both launches share the chip with the local-map workers only"}
-        counters("k_lk_track", row)
+        counters("k_lk_track_%s" % tag if ("k_lk_track_%s" % tag) in pk else "k_lk_track", row)   # (instances k_lk_track<1> / <2> since round 4)
         rows.append(row)
     # corner response
     e = _ms(stages, "gftt:eig_cand")

@@ -419,8 +419,10 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_fr
                            double min_dt);
 /* The recorder on /imu_pose (launch/flvis_euroc_mav.launch:83-103: vo_repub_rec, sub_type PoseStamped, sub_topic /imu_pose -> est.txt,
  * the trajectory the reference scores on EuRoC): writes rows of flvis_get_imu_states as `stamp x y z qw qx qy qz` (position pos_w_i,
- * attitude q_w_i; vo_repub_rec.cpp:74-91).  min_dt > 0: the throttle as written (rows within min_dt of the first row are dropped).
- * append != 0 appends to the file.  Returns the number of lines written or a negative error code. */
+ * attitude q_w_i; vo_repub_rec.cpp:74-91).  min_dt > 0: the throttle as written -- rows within min_dt of the FIRST row of the run are
+ * dropped, every later one is written.  The run starts with the call that creates the file (append == 0): the throttle applies to that
+ * call only; a batch that is appended (append != 0; flvis_get_imu_states hands out at most 512 rows per fetch) is written in full.
+ * Returns the number of lines written, FLVIS_ERR_INVALID_ARG for bad arguments or FLVIS_ERR_CONFIG when the file cannot be opened. */
 int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, double min_dt, int append);
 /* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
@@ -432,7 +434,9 @@ int flvis_get_local_map_counts(flvis_ctx* ctx, int64_t* h_keyframes, int64_t* h_
 int flvis_debug_stage_poses(flvis_ctx* ctx, int stream, double* h_out21);
 /* Measurement aid (bench.py's LK instruction budget): enable != 0 makes the tracker's two LK launches per frame count their Gauss-Newton
  * iterations and the points that iterated, per pyramid level, into flvis_debug_counters: [36 + 2 l], [37 + 2 l] temporal LK at level l,
- * [48 + 2 l], [49 + 2 l] stereo LK. */
+ * [48 + 2 l], [49 + 2 l] stereo LK; and, over both launches, [61] templates the temporal LK took from the template cache (written by
+ * the previous frame's stereo LK), [62] template patches and [63] search regions staged by the slow (index-reflecting) path, i.e.
+ * blocks that leave the pyramids' physical border. */
 int flvis_debug_lk_stats(flvis_ctx* ctx, int enable);
 /* Test aid: the corner-response pass of flvis_hip_gftt alone (cornerMinEigenVal + the 3x3 local maxima), with the kernel variant chosen
  * (0: LDS tiles, 1: strip-mined tiles, 2: wave walk with `rows` rows per chunk): per image the ordered bits of the maximum response, the

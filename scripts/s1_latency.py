@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2] as a latency line: ONE 640x480 stereo+IMU stream, images handed over as HOST buffers the way the nodelet gets
+them (flvis_image_feed_host, vo_tracking.cpp:396-430), full HIP front-end + HIP sliding-window BA with a window of 10 keyframes.
+Per frame: wall time from the call to the frame's output being in host memory (upload + frame chain + read-back: what a caller that
+publishes the pose waits for).  Beside it the CPU port (oracle/ref_runner.cpp, one thread) on the very same frames.
+
+usage: python scripts/s1_latency.py <out.json> [timed_frames]"""
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the CPU leg's runner and the percentile helper)
+from flvis_amd import bench_plan as plan  # noqa: E402
+
+
+def main():
+    import torch
+    import flvis_amd
+    from flvis_amd import synth
+    out_path = sys.argv[1]
+    n_timed = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    ypath = os.path.join(tempfile.gettempdir(), "flvis_s1_d435_stereo.yaml")
+    open(ypath, "w").write(synth.D435I_STEREO_YAML)
+    cfg = flvis_amd.load_config(ypath)
+    cfg.window_size = 10
+    skip = cfg.skip_first_n_imgs
+    n_warm = 60                                   # init + the frames that fill the window (a keyframe per ~3 frames)
+    n_frames = skip + n_warm + n_timed
+    ctx = flvis_amd.Context(0)
+    trk = flvis_amd.Tracker(ctx, cfg, 1, seed_base=0xF1715, traj_capacity=n_frames)
+    lib = ctx._lib
+    tr = synth.Trajectory(0)
+    rnd = synth.Renderer(torch.device("cuda", 0))
+    SPF = 16
+    imu = np.zeros((n_frames, 1, SPF, 7))
+    imu_cnt = np.zeros((n_frames, 1), np.int32)
+    t_prev = -1.0 / synth.FRAME_HZ
+    for f in range(n_frames):
+        t = f / synth.FRAME_HZ
+        smp = synth.imu_samples(tr, 0, t_prev, t)
+        imu[f, 0, :len(smp)] = smp
+        imu_cnt[f, 0] = len(smp)
+        t_prev = t
+    host = {}
+    for f in range(skip, n_frames):
+        fr = rnd.stereo_frame([tr], f / synth.FRAME_HZ, f)
+        host[f] = (fr[0].cpu().pin_memory(), fr[1].cpu().pin_memory())
+    torch.cuda.synchronize()
+    img_t = bench.flvis_image_struct()
+    out_buf = (flvis_amd.FrameOut * 1)()
+    lat, states, kf = [], [], 0
+    for f in range(n_frames):
+        h = host[max(f, skip)]
+        a, b = (img_t * 1)(), (img_t * 1)()
+        for arr, t in ((a, h[0]), (b, h[1])):
+            arr[0].data = t.data_ptr()
+            arr[0].width, arr[0].height, arr[0].pitch, arr[0].channels, arr[0].t = 640, 480, 640, 1, f / synth.FRAME_HZ
+        rc = lib.flvis_imu_feed_all(ctx._h, imu_cnt[f].ctypes.data_as(C.POINTER(C.c_int)), imu[f].ctypes.data_as(C.POINTER(C.c_double)), SPF)
+        if rc:
+            ctx._check(rc, "imu_feed_all")
+        t0 = time.perf_counter()
+        rc = lib.flvis_image_feed_host(ctx._h, a, b, C.cast(out_buf, C.c_void_p), 1, 0)
+        dt = (time.perf_counter() - t0) * 1e3
+        if rc:
+            ctx._check(rc, "image_feed_host")
+        if f >= skip + n_warm:
+            lat.append(dt)
+            states.append(out_buf[0].state)
+            kf += int(out_buf[0].new_keyframe)
+    ctx._check(lib.flvis_hip_synchronize(ctx._h), "synchronize")
+    kfs, bas = trk.local_map_counts()
+    res = {"workload": "BASELINE configs[2]: one 640x480 synthetic stereo+IMU stream, host images (flvis_image_feed_host), HIP front-end + "
+                       "HIP sliding-window BA, window 10",
+           "frames_timed": len(lat), "frames_tracking": int(sum(1 for s in states if s == 1)), "keyframes_in_timed_frames": kf,
+           "keyframes_total": int(kfs[0]), "ba_runs_total": int(bas[0]),
+           "gpu_ms_per_frame": {"p50": round(plan.percentile(lat, 50), 4), "p99": round(plan.percentile(lat, 99), 4),
+                                "mean": round(sum(lat) / len(lat), 4), "max": round(max(lat), 4),
+                                "note": "wall time of flvis_image_feed_host with the frame's output requested: pinned host images -> H2D -> "
+                                        "frame chain -> FrameOut in host memory; the local map runs beside it on its own stream"}}
+    # the CPU port on the same frames (one thread, front-end + local map)
+    try:
+        olib, build = bench.load_oracle_lib()
+        first = skip
+        n_cpu = min(n_warm + n_timed, 160)
+        hf = [(host[first + j][0].numpy(), host[first + j][1].numpy()) for j in range(n_cpu)]
+        tc, _, st, fms = bench.cpu_run_streams(olib, cfg, 1, 1, first, n_cpu, hf, imu, imu_cnt, 0xF1715, synth.FRAME_HZ, 1)
+        l = list(fms[0][n_warm:]) if n_cpu > n_warm + 20 else list(fms[0])
+        res["cpu_port_ms_per_frame"] = {"p50": round(plan.percentile(l, 50), 3), "p99": round(plan.percentile(l, 99), 3),
+                                        "frames": len(l), "build": build, "cores": 1}
+    except Exception as e:  # noqa: BLE001
+        res["cpu_port_error"] = "%s: %s" % (type(e).__name__, e)
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps(res))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

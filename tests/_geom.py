@@ -41,3 +41,83 @@ def random_scene(rng, n, K4, w=640, h=480, zmin=1.5, zmax=8.0):
     z = rng.uniform(zmin, zmax, n)
     P = np.stack([(uv[:, 0] - K4[2]) / K4[0] * z, (uv[:, 1] - K4[3]) / K4[1] * z, z], 1)
     return P, uv
+
+
+def epnp_numpy(Pw, z, K, signs=(1, 1, 1)):
+    """EPnP (Lepetit, Moreno-Noguer, Fua 2009) as published, with LAPACK decompositions -- independent of csrc/epnp_core.hpp, which the
+    device and the CPU checker share; `signs`: orientation of the three principal axes that carry the control points
+    (an eigenvector's sign is the decomposition's choice)"""
+    n = len(Pw)
+    fu, fv, uc, vc = K
+    z = ((z - K[2:]) / K[:2]).astype(np.float32).astype(np.float64) * K[:2] + K[2:]   # undistortPoints -> float, then x * fu + uc
+    c0 = Pw.mean(0)
+    d = Pw - c0
+    ev, U = np.linalg.eigh(d.T @ d)
+    cws = np.vstack([c0] + [c0 + sg * np.sqrt(max(ev[i], 0) / n) * U[:, i] for sg, i in zip(signs, (2, 1, 0))])
+    al = np.linalg.solve((cws[1:] - cws[0]).T, (Pw - cws[0]).T).T
+    al = np.hstack([1 - al.sum(1, keepdims=True), al])
+    M = np.zeros((2 * n, 12))
+    for j in range(4):
+        M[0::2, 3 * j] = al[:, j] * fu
+        M[0::2, 3 * j + 2] = al[:, j] * (uc - z[:, 0])
+        M[1::2, 3 * j + 1] = al[:, j] * fv
+        M[1::2, 3 * j + 2] = al[:, j] * (vc - z[:, 1])
+    w, E = np.linalg.eigh(M.T @ M)
+    v = E[:, :4].T.reshape(4, 4, 3)                     # v[i][control point]
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    dv = np.array([[v[i, a] - v[i, b] for a, b in pairs] for i in range(4)])
+    L = np.zeros((6, 10))
+    for r in range(6):
+        D = dv[:, r] @ dv[:, r].T
+        L[r] = [D[0, 0], 2 * D[0, 1], D[1, 1], 2 * D[0, 2], 2 * D[1, 2], D[2, 2], 2 * D[0, 3], 2 * D[1, 3], 2 * D[2, 3], D[3, 3]]
+    rho = np.array([((cws[a] - cws[b]) ** 2).sum() for a, b in pairs])
+
+    def gauss_newton(b):
+        b = b.copy()
+        for _ in range(5):
+            J = np.stack([2 * L[:, 0] * b[0] + L[:, 1] * b[1] + L[:, 3] * b[2] + L[:, 6] * b[3],
+                          L[:, 1] * b[0] + 2 * L[:, 2] * b[1] + L[:, 4] * b[2] + L[:, 7] * b[3],
+                          L[:, 3] * b[0] + L[:, 4] * b[1] + 2 * L[:, 5] * b[2] + L[:, 8] * b[3],
+                          L[:, 6] * b[0] + L[:, 7] * b[1] + L[:, 8] * b[2] + 2 * L[:, 9] * b[3]], 1)
+            bb = np.array([b[0] * b[0], b[0] * b[1], b[1] * b[1], b[0] * b[2], b[1] * b[2], b[2] * b[2], b[0] * b[3], b[1] * b[3], b[2] * b[3], b[3] * b[3]])
+            Q_, R_ = np.linalg.qr(J)
+            b += np.linalg.solve(R_, Q_.T @ (rho - L @ bb))
+        return b
+
+    def pose(b):
+        ccs = np.einsum("i,ijk->jk", b, v)
+        pcs = al @ ccs
+        if pcs[0, 2] < 0:
+            pcs = -pcs
+        pc0, pw0 = pcs.mean(0), Pw.mean(0)
+        Uu, _, Vt = np.linalg.svd((pcs - pc0).T @ (Pw - pw0))
+        R = Uu @ Vt
+        if np.linalg.det(R) < 0:
+            R[2] = -R[2]
+        t = pc0 - R @ pw0
+        X = Pw @ R.T + t
+        e = np.hypot(uc + fu * X[:, 0] / X[:, 2] - z[:, 0], vc + fv * X[:, 1] / X[:, 2] - z[:, 1]).mean()
+        return e, R, t
+
+    cands = []
+    x = np.linalg.lstsq(L[:, [0, 1, 3, 6]], rho, rcond=None)[0]                      # N = 4
+    b = np.array([np.sqrt(abs(x[0])), 0, 0, 0])
+    b[1:] = np.sign(x[0] if x[0] != 0 else 1) * x[1:] / b[0]
+    cands.append(pose(gauss_newton(b)))
+    for cols in ([0, 1, 2], [0, 1, 2, 3, 4]):                                        # N = 2, N = 3
+        x = np.linalg.lstsq(L[:, cols], rho, rcond=None)[0]
+        if x[0] < 0:
+            b = np.array([np.sqrt(-x[0]), np.sqrt(-x[2]) if x[2] < 0 else 0.0, 0, 0])
+        else:
+            b = np.array([np.sqrt(x[0]), np.sqrt(x[2]) if x[2] > 0 else 0.0, 0, 0])
+        if x[1] < 0:
+            b[0] = -b[0]
+        if len(cols) == 5:
+            b[2] = x[3] / b[0]
+        cands.append(pose(gauss_newton(b)))
+    best = cands[0]
+    if cands[1][0] < best[0]:
+        best = cands[1]
+    if cands[2][0] < best[0]:
+        best = cands[2]
+    return best[1], best[2]

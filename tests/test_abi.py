@@ -160,3 +160,27 @@ def test_header_is_plain_c_and_cxx():
         r = subprocess.run([cc, std, "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.dirname(hdr), src], stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT)
         assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+def test_imu_trajectory_recorder_throttle_is_per_run_not_per_batch(tmp_path):
+    """flvis_write_imu_trajectory (host code of the boundary, no GPU involved): the recorder drops what lies within min_dt of the first
+    message of the RUN (vo_repub_rec.cpp:77-78, `last_time` is set once).  flvis_get_imu_states hands the rows out in batches of at most
+    512: the batch that creates the file is throttled, appended batches are written in full -- the file equals the one a single call
+    with all rows writes."""
+    import flvis_amd
+    lib = flvis_amd.load_library()
+    lib.flvis_write_imu_trajectory.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_char_p, C.c_double, C.c_int]
+    rows = np.zeros((900, 11))
+    rows[:, 0] = 100.0 + np.arange(900) * 0.005          # 200 Hz
+    rows[:, 1] = 1.0                                     # q_w_i = identity
+    rows[:, 5:8] = np.arange(2700).reshape(900, 3) * 1e-3
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    one = str(tmp_path / "one.txt").encode()
+    two = str(tmp_path / "two.txt").encode()
+    n_one = lib.flvis_write_imu_trajectory(ptr(rows), 900, one, 0.1, 0)
+    a, b = np.ascontiguousarray(rows[:512]), np.ascontiguousarray(rows[512:])
+    n_a = lib.flvis_write_imu_trajectory(ptr(a), 512, two, 0.1, 0)
+    n_b = lib.flvis_write_imu_trajectory(ptr(b), 388, two, 0.1, 1)
+    assert n_one == 900 - 21 and n_a == 512 - 21 and n_b == 388      # stamps 0.000 .. 0.100 s after the first are dropped once
+    assert open(one).read() == open(two).read()
+    assert lib.flvis_write_imu_trajectory(ptr(rows), 900, str(tmp_path / "no" / "such" / "dir.txt").encode(), 0.1, 0) == -5      # FLVIS_ERR_CONFIG

@@ -127,7 +127,7 @@ def test_config3_batch_of_64_streams_with_local_map():
     for i in sampled:
         assert _compare_stream(a["got"][i], a["want"][i], "stream %d" % i) == 22
         gc, wc = a["corr"][i], a["ref_corr"][i]                                 # the last CorrectionInf of the stream
-        assert (gc is None) == (wc is None)
+        assert (gc is None) == (wc is None)                                     # (22 frames rarely fill a window: the 40-frame test below compares the optimiser)
         if gc is not None:      # same keyframes in (bit-identical front-ends), same bookkeeping; the optimiser sums in another order
             assert gc["frame_id"] == wc["frame_id"]
             assert np.array_equal(gc["lm_id"], wc["lm_id"]) and np.array_equal(gc["outlier_id"], wc["outlier_id"])
@@ -149,7 +149,7 @@ def test_config3_batch_of_64_streams_local_map_optimises():
     from flvis_amd import synth
     cfg, ocfg = _cfgs_yaml(synth.D435I_STEREO_YAML, "d435_stereo")
     S, nframes = 64, cfg.skip_first_n_imgs + 40
-    a = _run_batch(cfg, S, nframes, [0, 63])
+    a = _run_batch(cfg, S, nframes, [0, 63], ocfg)
     states = a["rows"][:, :, 8].astype(int) & 15
     assert np.all(states[:, cfg.skip_first_n_imgs:] == 1) and a["dropped"] == 0
     assert a["counters"][2] >= S, a["counters"]                                 # at least one optimisation per stream
@@ -158,6 +158,16 @@ def test_config3_batch_of_64_streams_local_map_optimises():
         assert c is not None and len(c["lm_id"]) > 100
         fid = c["frame_id"]                                                     # frame ids count image_feed calls from 1
         assert np.abs(a["rows"][i, fid - 1, 1:4] - c["pose7"][:3]).max() < 0.05
+        # configs[3]'s optimiser against the oracle AT S = 64 (not only the one-stream tests): the front-ends are in lockstep for all
+        # 40 frames, so both local maps get the same keyframes; the window has optimised on both sides, and the last CorrectionInf names
+        # the same keyframe, landmarks and outliers (exact) with the values of the fp64 LM chain within 1e-6
+        assert _compare_stream(a["got"][i], a["want"][i], "stream %d" % i) == 40
+        wc = a["ref_corr"][i]
+        assert wc is not None, "the oracle's window of stream %d never optimised: nothing was compared" % i
+        assert c["frame_id"] == wc["frame_id"]
+        assert np.array_equal(c["lm_id"], wc["lm_id"]) and np.array_equal(c["outlier_id"], wc["outlier_id"])
+        assert np.allclose(c["pose7"], wc["pose7"], atol=1e-6, rtol=0), c["pose7"] - wc["pose7"]
+        assert np.allclose(c["lm_3d"], wc["lm_3d"], atol=1e-6, rtol=0), np.abs(c["lm_3d"] - wc["lm_3d"]).max()
 
 
 def test_config2_single_stream_frontend_and_ba_together():

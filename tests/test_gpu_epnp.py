@@ -55,6 +55,37 @@ def test_epnp_device_equals_the_restatement_bit_for_bit(ctx, noise):
         assert bool(o[12]) == ok and np.array_equal(o[:9].reshape(3, 3), R) and np.array_equal(o[9:12], t), what
 
 
+@pytest.mark.parametrize("noise", [0.2, 0.5])
+def test_epnp_device_agrees_with_the_independent_lapack_writeup(ctx, noise):
+    """The device against a write-up that shares NO code with it (tests/_geom.py: numpy + LAPACK eigh / qr / svd / lstsq, the published
+    algorithm): the bit-for-bit test above proves the device compile of epnp_core.hpp, this one proves the algorithm on the device.
+    8 .. 700 correspondences (the chunk sums of 16 / 32 / 64 per chunk), tolerance 1e-8 on R and t.  Mirroring a control point along
+    its principal axis is an equally valid configuration (an eigenvector's sign is the decomposition's choice), so the device pose has
+    to coincide with ONE of the eight write-up poses."""
+    import itertools
+    import torch
+    rng = np.random.default_rng(23)
+    sizes = [8, 12, 30, 33, 64, 65, 200, 200, 300, 511, 700]
+    sets = _sets(rng, sizes, noise)
+    cap = 704
+    p3 = np.zeros((len(sets), cap, 3), np.float32)
+    p2 = np.zeros((len(sets), cap, 2), np.float32)
+    cnt = np.zeros(len(sets), np.int32)
+    for k, (P, z) in enumerate(sets):
+        p3[k, :len(P)], p2[k, :len(P)], cnt[k] = P, z, len(P)
+    out = ctx.debug_epnp(torch.from_numpy(p3).cuda(), torch.from_numpy(p2).cuda(), torch.from_numpy(cnt).cuda(), K4).cpu().numpy()
+    for k, (P, z) in enumerate(sets):
+        o = out[k]
+        assert o[12] == 1.0, k
+        Rg, tg = o[:9].reshape(3, 3), o[9:12]
+        assert abs(np.linalg.det(Rg) - 1) < 1e-9
+        d = []
+        for sg in itertools.product((1, -1), repeat=3):
+            Rn, tn = G.epnp_numpy(P.astype(np.float64), z.astype(np.float64), K4, sg)
+            d.append(max(np.abs(Rg - Rn).max(), np.abs(tg - tn).max()))
+        assert min(d) < 1e-8, ("set %d (n = %d)" % (k, len(P)), min(d))
+
+
 def test_epnp_entry_point_refuses_what_it_cannot_hold(ctx):
     import torch
     import flvis_amd

@@ -179,6 +179,68 @@ def test_frontend_parity_kitti_mode(ctx):
         trk.imu_feed_sensor(0, 0.0, [0, 0, 9.81], [0, 0, 0])
 
 
+def _run_plain(ctx, cfg, streams, nframes, env):
+    """One tracker run under the given environment knobs (read when the tracker is created): per frame the outputs that the LK feeds
+    (pose, inlier counts, landmark count, landmark pixels) + the LK statistics of the run."""
+    import flvis_amd
+    from flvis_amd import synth
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        trk = flvis_amd.Tracker(ctx, cfg, len(streams), seed_base=0xF1715)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    trajs = [synth.Trajectory(s) for s in streams]
+    rnd = synth.Renderer("cuda")
+    ctx._check(ctx._lib.flvis_debug_lk_stats(ctx._h, 1), "lk_stats")
+    t_prev = -0.05
+    rec = []
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        for i, s in enumerate(streams):
+            trk.imu_feed_flvis(i, synth.imu_samples(trajs[i], s, t_prev, t))
+        t_prev = t
+        i0, i1 = rnd.stereo_frame(trajs, t, f)
+        outs = trk.image_feed(i0, i1, [t] * len(streams), with_local_map=False)
+        for i in range(len(streams)):
+            lm = trk.landmarks(i)
+            rec.append((outs[i]["state"], outs[i]["n_landmarks"], outs[i]["dbg"].copy(), outs[i]["pose7"].copy(), lm["ids"].copy(),
+                        lm["p2d"].copy(), lm["p3w"].copy()))
+    dbg = (C.c_int64 * 64)()
+    ctx._check(ctx._lib.flvis_debug_counters(ctx._h, dbg), "debug_counters")
+    ctx._check(ctx._lib.flvis_debug_lk_stats(ctx._h, 0), "lk_stats")
+    del trk
+    return rec, [int(v) for v in dbg]
+
+
+def test_lk_template_cache_and_pyramid_border_are_transparent(ctx):
+    """The temporal LK takes its templates from the cache the previous frame's stereo LK wrote, and both stage their blocks from
+    pyramids with a physical REFLECT_101 border.  Neither may change a bit: the run with both (the default) equals the run that
+    computes every template and reflects every index (FLVIS_LK_TCACHE=0 FLVIS_LK_BORDER=0), frame by frame.  And the knobs do what
+    they say: with the cache nearly every temporal template is taken from it, with the border almost no staging reflects indices."""
+    cfg, _ = _cfgs()
+    streams, nframes = [3, 140], 50 + 30
+    a, ca = _run_plain(ctx, cfg, streams, nframes, {"FLVIS_LK_TCACHE": "1", "FLVIS_LK_BORDER": "1"})
+    b, cb = _run_plain(ctx, cfg, streams, nframes, {"FLVIS_LK_TCACHE": "0", "FLVIS_LK_BORDER": "0"})
+    assert len(a) == len(b)
+    tracked = 0
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert x[0] == y[0] and x[1] == y[1], k
+        for u, v in zip(x[2:], y[2:]):
+            assert np.array_equal(u, v), k
+        tracked += x[0] == 1
+    assert tracked >= 40
+    t_points = sum(ca[36 + 2 * l + 1] for l in range(6))          # temporal (point, level) pairs that iterated
+    assert ca[61] >= 0.9 * t_points and ca[61] > 1000, (ca[61], t_points)
+    assert cb[61] == 0
+    # without the border a third of the stagings reflect indices (coarse levels: a 36 x 34 patch rarely fits an 80 x 60 image)
+    assert cb[62] + cb[63] > 20 * (ca[62] + ca[63] + 1), (ca[62:64], cb[62:64])
+
+
 def _patch_scene(n_patches, seed=1):
     rng = np.random.default_rng(seed)
     xs, ys, Z = rng.uniform(80, 1160, n_patches), rng.uniform(40, 330, n_patches), rng.uniform(6, 20, n_patches)
@@ -594,6 +656,63 @@ def test_local_map_parity_with_the_full_imu_factor(ctx):
         if got is not None:
             moved = max(moved, np.abs(got["pose7"] - rot_only[(0, k)]).max())
     assert moved > 1e-5
+
+
+@pytest.mark.parametrize("pos_rows", [False, True])
+def test_local_map_imu_factor_at_window_size_16(ctx, pos_rows):
+    """The largest window the solver holds (BA_WMAX = 16) with the IMU factor on: 15 edges between consecutive keyframes, i.e. 15 x 36 =
+    540 entries of off-diagonal 6 x 6 blocks in the reduced system -- more than the workgroup has threads.  Every one of them must
+    arrive (the mapping strides), for the rotation rows alone (9 live entries per block) and with the position rows (36)."""
+    import flvis_amd
+    import _geom as G
+    cfg, _ = _cfgs()
+    cfg.window_size = 16
+    K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
+    T_i_c = np.array(list(cfg.T_imu_cam0)).reshape(4, 4)
+    Rcb = T_i_c[:3, :3].T
+    tcb = -Rcb @ T_i_c[:3, 3]
+    gw = np.array([0.0, 0.0, -9.81])
+    sigma_g, sigma_a = 0.004, 0.08
+    trk = flvis_amd.Tracker(ctx, cfg, 1, seed_base=1)
+    trk.set_imu_factor(True, sigma_g)
+    if pos_rows:
+        trk.set_imu_factor_accel(sigma_a)
+    seq = B.make_sequence(31, n_kf=21, n_lm=220, outlier_frac=0.03)
+    rng = np.random.default_rng(31)
+    ref = O.LocalMap(16, K4)
+    ref.set_imu_factor(True, sigma_g, _quat_wxyz(Rcb))
+    if pos_rows:
+        ref.set_imu_factor_pos(sigma_a, tcb)
+
+    def body(k):
+        R, t = seq["gt"][k]
+        return R.T @ Rcb, R.T @ (tcb - t)
+    produced = 0
+    for k, kf in enumerate(seq["kfs"]):
+        dq, dt, dp, va = None, 0.0, None, None
+        if k > 0:
+            Rwa, pa = body(k - 1)
+            Rwb, pb = body(k)
+            dt = 0.1 + 0.02 * (k % 3)
+            dq = _quat_wxyz(Rwa.T @ Rwb @ G.rodrigues(rng.normal(0, 1e-3, 3)))
+            ref.next_imu(dq, dt)
+            if pos_rows:
+                va = (pb - pa) / dt + rng.normal(0, 0.05, 3)
+                dp = Rwa.T @ (pb - pa - va * dt + 0.5 * gw * dt * dt) + rng.normal(0, 2e-3, 3)
+                ref.next_imu_pos(dp, va)
+        want = ref.push(kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"])
+        got = trk.ba_push_keyframe(0, kf["frame_id"], kf["pose7"], kf["lm_id"], kf["lm_2d"], kf["lm_3d"], imu_dq=dq, imu_dt=dt, imu_dp=dp, imu_va=va)
+        assert (want is None) == (got is None), k
+        if want is None:
+            continue
+        produced += 1
+        assert got["frame_id"] == want["frame_id"] and np.array_equal(got["lm_id"], want["lm_id"]), k
+        assert np.array_equal(got["outlier_id"], want["outlier_id"]), k
+        assert np.allclose(got["pose7"], want["pose7"], atol=1e-6, rtol=0), (k, got["pose7"] - want["pose7"])
+        assert np.allclose(got["lm_3d"], want["lm_3d"], atol=1e-6, rtol=0), (k, np.abs(got["lm_3d"] - want["lm_3d"]).max())
+    assert produced == len(seq["kfs"]) - 16 + 1
+    if pos_rows:
+        trk.set_imu_factor_accel(0.0)
 
 
 def test_local_map_parity(ctx):
