@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "dev_common.hpp"
+#include "dem_sort.hpp"
 #include "eig_strip.hpp"
 #include "img_kernels.hpp"
 
@@ -924,19 +925,39 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem_prep(ImgSel src, int w, i
     }
   }
   __syncthreads();
-  // stable rank inside the region: #(score greater) + #(equal score, earlier index); only region members are compared
+  // Order inside a region = what the reference's std::sort(..., sortbysecdesc) leaves (feature_dem.cpp:170,230).  Where all scores of
+  // a region differ that is THE descending order: position = #(score greater), one candidate per thread.  std::sort is not stable,
+  // though, and the quirky score is built from two small integers, so ties happen: a region with a tie is sorted once more by ONE lane
+  // that walks through libstdc++'s introsort (dem_sort.hpp) on the region's candidates in their input order -- the order of equal
+  // scores then is the one the reference's binary produces, which decides whom the greedy spacing walk meets first.
   float* const SX = sorted_xy + (size_t)s * corner_cap * 2;
+  __shared__ int rtie[16];
+  if (tid < 16) rtie[tid] = 0;
+  __syncthreads();
   for (int j = tid; j < roff[16]; j += DEM_T) {
     const int i = bucket[j];
     const int r = creg[i];
     const float sc = cscore[i];
     int pos = 0;
+    bool tie = false;
     for (int q = roff[r]; q < roff[r + 1]; q++) {
       const float sj = cscore[bucket[q]];
       pos += (sj > sc) || (sj == sc && q < j);
+      tie = tie || (sj == sc && q != j);
     }
+    if (tie) rtie[r] = 1;
     SX[2 * (roff[r] + pos)] = cx[i];
     SX[2 * (roff[r] + pos) + 1] = cy[i];
+  }
+  __syncthreads();
+  if (tid < 16 && rtie[tid]) demsort::sort_desc(bucket + roff[tid], roff[tid + 1] - roff[tid], cscore);
+  __syncthreads();
+  for (int j = tid; j < roff[16]; j += DEM_T) {
+    const int i = bucket[j];
+    if (rtie[creg[i]]) {
+      SX[2 * j] = cx[i];
+      SX[2 * j + 1] = cy[i];
+    }
   }
   if (tid < 17) region_off[(size_t)s * 17 + tid] = roff[tid];
 }

@@ -34,6 +34,8 @@ static_assert(8 + 6 * LK_MAX_LEVELS <= LK_TC_HDR, "header");
 
 typedef short lk_s2 __attribute__((ext_vector_type(2)));
 typedef uint32_t lk_u4 __attribute__((ext_vector_type(4)));  // (a native vector: the non-temporal builtins do not take HIP's uint4 class)
+// (by value: __builtin_bit_cast applied directly to a vector-element expression such as q.y reads element 0 with this compiler)
+__device__ __forceinline__ lk_s2 lk_as_s2(uint32_t v) { return __builtin_bit_cast(lk_s2, v); }
 
 // patch[r][c] = img(X0 + c, Y0 + r) for r < nrows, c < 36, REFLECT_101 outside the image.  Item i = 9 r + k is dword k of row r; a lane
 // takes items lane, lane + 64, ...  When the whole patch lies inside the image (wave-uniform test; nearly every point) there is nothing to
@@ -349,12 +351,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
         iA22 = sums[2];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          tI[4 * k + 0] = __builtin_bit_cast(lk_s2, q[k].x); tI[4 * k + 1] = __builtin_bit_cast(lk_s2, q[k].y);
-          tI[4 * k + 2] = __builtin_bit_cast(lk_s2, q[k].z); tI[4 * k + 3] = __builtin_bit_cast(lk_s2, q[k].w);
-          tX[4 * k + 0] = __builtin_bit_cast(lk_s2, q[2 + k].x); tX[4 * k + 1] = __builtin_bit_cast(lk_s2, q[2 + k].y);
-          tX[4 * k + 2] = __builtin_bit_cast(lk_s2, q[2 + k].z); tX[4 * k + 3] = __builtin_bit_cast(lk_s2, q[2 + k].w);
-          tY[4 * k + 0] = __builtin_bit_cast(lk_s2, q[4 + k].x); tY[4 * k + 1] = __builtin_bit_cast(lk_s2, q[4 + k].y);
-          tY[4 * k + 2] = __builtin_bit_cast(lk_s2, q[4 + k].z); tY[4 * k + 3] = __builtin_bit_cast(lk_s2, q[4 + k].w);
+          tI[4 * k + 0] = lk_as_s2(q[k].x); tI[4 * k + 1] = lk_as_s2(q[k].y);
+          tI[4 * k + 2] = lk_as_s2(q[k].z); tI[4 * k + 3] = lk_as_s2(q[k].w);
+          tX[4 * k + 0] = lk_as_s2(q[2 + k].x); tX[4 * k + 1] = lk_as_s2(q[2 + k].y);
+          tX[4 * k + 2] = lk_as_s2(q[2 + k].z); tX[4 * k + 3] = lk_as_s2(q[2 + k].w);
+          tY[4 * k + 0] = lk_as_s2(q[4 + k].x); tY[4 * k + 1] = lk_as_s2(q[4 + k].y);
+          tY[4 * k + 2] = lk_as_s2(q[4 + k].z); tY[4 * k + 3] = lk_as_s2(q[4 + k].w);
         }
       } else {
         __syncthreads();

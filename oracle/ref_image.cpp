@@ -19,7 +19,7 @@
 //   (1) LK window sums (A11,A12,A22,b1,b2) are accumulated EXACTLY in int64 and converted to float once; OpenCV
 //       accumulates in float (scalar path) or in SIMD lanes (order differs per build), so its last bits are not defined.
 //   (2) Sort ties: GFTT candidates are ordered by (response desc, pixel offset desc) -- OpenCV >=3.4.2 greaterThanPtr;
-//       FeatureDEM's per-region std::sort (unstable in the reference) is taken as stable.
+//       FeatureDEM's per-region std::sort is the real std::sort of this toolchain (libstdc++, as the reference's GCC build): ties end where its introsort leaves them.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -445,7 +445,7 @@ void FeatureDEM::detect(const uint8_t* img, std::vector<Pt2f>& newPts) const {
   std::vector<Scored> region[16];
   fillIntoRegion(img, features, region, false);
   for (int i = 0; i < 16; i++) {
-    std::stable_sort(region[i].begin(), region[i].end(), sortbysecdesc);
+    std::sort(region[i].begin(), region[i].end(), sortbysecdesc);  // the reference's very call (feature_dem.cpp:230): ties end where libstdc++'s introsort leaves them
     std::vector<Scored> tmp = region[i];
     region[i].clear();
     unsigned count = 0;
@@ -478,7 +478,7 @@ void FeatureDEM::redetect(const uint8_t* img, const std::vector<Pt2f>& existedPt
   std::vector<Scored> prepare[16];
   fillIntoRegion(img, features, prepare, false);
   for (int i = 0; i < 16; i++) {
-    std::stable_sort(prepare[i].begin(), prepare[i].end(), sortbysecdesc);
+    std::sort(prepare[i].begin(), prepare[i].end(), sortbysecdesc);  // (feature_dem.cpp:170)
     for (size_t j = 0; j < prepare[i].size(); j++) {
       int noFeatureNearby = 1;
       // cv::Point pt = Point2f  (rounds; GFTT output is integral already), feature_dem.cpp:174

@@ -37,7 +37,7 @@ KNOWN = {
 def norm(name):
     n = name.split("(")[0].replace("void ", "").strip()
     n = n.replace("HIP_vector_type<unsigned int, 4u>", "uint4").replace("HIP_vector_type<unsigned int, 2u>", "uint2")
-    return n
+    return n.replace(" >", ">")
 
 
 env = dict(os.environ, TMPDIR="/tmp")

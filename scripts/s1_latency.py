@@ -55,7 +55,12 @@ def main():
     torch.cuda.synchronize()
     img_t = bench.flvis_image_struct()
     out_buf = (flvis_amd.FrameOut * 1)()
-    lat, states, kf = [], [], 0
+    # two passes over the same kind of frames: "paced" -- the frame arrives when the previous frame's work (including its local-map
+    # optimisation) has finished, as at a camera's 20-30 Hz where a 2.5 ms optimisation never overlaps the next frame (the device is
+    # drained before the clock starts) -- and "back to back": frames fed as fast as the call returns, where a frame can queue behind
+    # the optimiser's back-pressure (a keyframe nearly every frame at this speed)
+    n_half = n_timed // 2
+    lat, lat_b2b, states, kf = [], [], [], 0
     for f in range(n_frames):
         h = host[max(f, skip)]
         a, b = (img_t * 1)(), (img_t * 1)()
@@ -65,25 +70,34 @@ def main():
         rc = lib.flvis_imu_feed_all(ctx._h, imu_cnt[f].ctypes.data_as(C.POINTER(C.c_int)), imu[f].ctypes.data_as(C.POINTER(C.c_double)), SPF)
         if rc:
             ctx._check(rc, "imu_feed_all")
+        paced = f < skip + n_warm + n_half
+        if paced:
+            ctx._check(lib.flvis_hip_synchronize(ctx._h), "synchronize")
         t0 = time.perf_counter()
         rc = lib.flvis_image_feed_host(ctx._h, a, b, C.cast(out_buf, C.c_void_p), 1, 0)
         dt = (time.perf_counter() - t0) * 1e3
         if rc:
             ctx._check(rc, "image_feed_host")
         if f >= skip + n_warm:
-            lat.append(dt)
+            (lat if paced else lat_b2b).append(dt)
             states.append(out_buf[0].state)
             kf += int(out_buf[0].new_keyframe)
     ctx._check(lib.flvis_hip_synchronize(ctx._h), "synchronize")
     kfs, bas = trk.local_map_counts()
     res = {"workload": "BASELINE configs[2]: one 640x480 synthetic stereo+IMU stream, host images (flvis_image_feed_host), HIP front-end + "
                        "HIP sliding-window BA, window 10",
-           "frames_timed": len(lat), "frames_tracking": int(sum(1 for s in states if s == 1)), "keyframes_in_timed_frames": kf,
+           "frames_timed": len(lat) + len(lat_b2b), "frames_tracking": int(sum(1 for s in states if s == 1)), "keyframes_in_timed_frames": kf,
            "keyframes_total": int(kfs[0]), "ba_runs_total": int(bas[0]),
            "gpu_ms_per_frame": {"p50": round(plan.percentile(lat, 50), 4), "p99": round(plan.percentile(lat, 99), 4),
                                 "mean": round(sum(lat) / len(lat), 4), "max": round(max(lat), 4),
-                                "note": "wall time of flvis_image_feed_host with the frame's output requested: pinned host images -> H2D -> "
-                                        "frame chain -> FrameOut in host memory; the local map runs beside it on its own stream"}}
+                                "frames": len(lat),
+                                "note": "paced frames (the device is idle when the frame arrives, as at camera rate): wall time of "
+                                        "flvis_image_feed_host with the frame's output requested: pinned host images -> H2D -> frame chain -> "
+                                        "FrameOut in host memory; the local map runs beside it on its own stream"},
+           "gpu_ms_per_frame_back_to_back": {"p50": round(plan.percentile(lat_b2b, 50), 4), "p99": round(plan.percentile(lat_b2b, 99), 4),
+                                             "mean": round(sum(lat_b2b) / len(lat_b2b), 4), "max": round(max(lat_b2b), 4), "frames": len(lat_b2b),
+                                             "note": "the same call with the next frame fed the moment the call returns (faster than any camera): "
+                                                     "includes waiting behind the local map's back-pressure; mean = the single-stream throughput bound"}}
     # the CPU port on the same frames (one thread, front-end + local map)
     try:
         olib, build = bench.load_oracle_lib()

@@ -121,3 +121,106 @@ def epnp_numpy(Pw, z, K, signs=(1, 1, 1)):
     if cands[2][0] < best[0]:
         best = cands[2]
     return best[1], best[2]
+
+
+def gnu_sort(v, less):
+    """std::sort as GNU libstdc++ implements it (introsort: 2 floor(log2 n) quicksort levels with a median-of-three pivot and an
+    unguarded Hoare partition on ranges longer than 16, heap sort beyond that budget, one final insertion sort), in place on the
+    Python list v.  Not stable: this is where the reference's `sort(..., sortbysecdesc)` (feature_dem.cpp:170,230) leaves candidates
+    whose scores tie."""
+    n = len(v)
+    if n == 0:
+        return v
+
+    def adjust_heap(first, hole, length, value):
+        top = hole
+        child = hole
+        while child < (length - 1) // 2:
+            child = 2 * (child + 1)
+            if less(v[first + child], v[first + child - 1]):
+                child -= 1
+            v[first + hole] = v[first + child]
+            hole = child
+        if (length & 1) == 0 and child == (length - 2) // 2:
+            child = 2 * (child + 1)
+            v[first + hole] = v[first + child - 1]
+            hole = child - 1
+        parent = int((hole - 1) / 2)
+        while hole > top and less(v[first + parent], value):
+            v[first + hole] = v[first + parent]
+            hole = parent
+            parent = int((hole - 1) / 2)
+        v[first + hole] = value
+
+    def heap_sort(first, last):
+        length = last - first
+        if length >= 2:
+            parent = (length - 2) // 2
+            while True:
+                adjust_heap(first, parent, length, v[first + parent])
+                if parent == 0:
+                    break
+                parent -= 1
+        while last - first > 1:
+            last -= 1
+            value = v[last]
+            v[last] = v[first]
+            adjust_heap(first, 0, last - first, value)
+
+    def linear_insert(last):
+        val = v[last]
+        nxt = last - 1
+        while less(val, v[nxt]):
+            v[last] = v[nxt]
+            last = nxt
+            nxt -= 1
+        v[last] = val
+
+    def insertion_sort(first, last):
+        for i in range(first + 1, last):
+            if less(v[i], v[first]):
+                val = v[i]
+                v[first + 1:i + 1] = v[first:i]
+                v[first] = val
+            else:
+                linear_insert(i)
+
+    def loop(first, last, depth):
+        while last - first > 16:
+            if depth == 0:
+                heap_sort(first, last)
+                return
+            depth -= 1
+            a, b, c = first + 1, first + (last - first) // 2, last - 1
+            if less(v[a], v[b]):
+                m = b if less(v[b], v[c]) else (c if less(v[a], v[c]) else a)
+            elif less(v[a], v[c]):
+                m = a
+            elif less(v[b], v[c]):
+                m = c
+            else:
+                m = b
+            v[first], v[m] = v[m], v[first]
+            f, l = first + 1, last
+            while True:
+                while less(v[f], v[first]):
+                    f += 1
+                l -= 1
+                while less(v[first], v[l]):
+                    l -= 1
+                if not f < l:
+                    break
+                v[f], v[l] = v[l], v[f]
+                f += 1
+            loop(f, last, depth)
+            last = f
+
+    loop(0, n, 2 * (n.bit_length() - 1))
+    if n > 16:
+        insertion_sort(0, 16)
+        for i in range(16, n):
+            linear_insert(i)
+    else:
+        insertion_sort(0, n)
+    return v
+

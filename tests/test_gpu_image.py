@@ -110,6 +110,44 @@ def test_feature_dem_redetect_parity(ctx, h, w, fp):
         assert np.array_equal(xy[i, :cnt[i]], want)
 
 
+def _tiled(h, w, seed, period=16):
+    """one 16 x 16 texture patch repeated over the image: every corner recurs with the same 3 x 3 neighbourhood, so FeatureDEM's
+    integer-built Harris scores tie by the dozen inside a region"""
+    t = S.texture_u8(3 * period, 3 * period, seed)[period:2 * period, period:2 * period]
+    return np.tile(t, (h // period + 1, w // period + 1))[:h, :w].copy()
+
+
+def test_feature_dem_orders_tied_scores_as_std_sort_does(ctx):
+    """feature_dem.cpp:170,230 sort the candidates of a region with std::sort, which is not stable: where scores tie, the order is
+    what libstdc++'s introsort leaves, and the greedy spacing walk depends on it.  The oracle calls the real std::sort; the device
+    restates the algorithm (csrc/dem_sort.hpp, checked against std::sort on the CPU by tests/test_dem_sort.py).  Tiled images make
+    regions of 30 .. 80 candidates in a handful of score classes -- a stable order gives another feature set on them."""
+    import torch
+    fp = [15, 30, 5, 500, 0.001, 5]
+    imgs = np.stack([_tiled(480, 640, 7), _tiled(480, 640, 8, 24), _tiled(480, 640, 9, 12)])
+    xy, cnt = ctx.feature_dem_detect(_cuda(imgs), fp)
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    first = []
+    for i in range(len(imgs)):
+        want = O.dem_detect(imgs[i], fp)
+        first.append(want)
+        assert cnt[i] == len(want) and len(want) > 40, (i, cnt[i], len(want))
+        assert np.array_equal(xy[i, :cnt[i]], want), i
+    cap = 512
+    ex = np.zeros((len(imgs), cap, 2), np.float64)
+    nex = np.zeros(len(imgs), np.int32)
+    for i in range(len(imgs)):
+        sel = first[i][::3].astype(np.float64) + np.array([0.37, -0.21])
+        ex[i, :len(sel)] = sel
+        nex[i] = len(sel)
+    xy, cnt = ctx.feature_dem_redetect(_cuda(imgs), fp, _cuda(ex), _cuda(nex))
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(len(imgs)):
+        want = O.dem_redetect(imgs[i], fp, ex[i, :nex[i]])
+        assert cnt[i] == len(want) and len(want) > 10, (i, cnt[i], len(want))
+        assert np.array_equal(xy[i, :cnt[i]], want), i
+
+
 def _lk_case(h, w, n, seed, shifts, npts, max_level=10):
     prev = np.zeros((n, h, w), np.uint8)
     nxt = np.zeros((n, h, w), np.uint8)

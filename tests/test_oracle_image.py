@@ -3,6 +3,7 @@ closed-form properties.  The reference ships no golden vectors for these stages 
 import numpy as np
 import pytest
 
+import _geom as G
 import _oracle as O
 import _synth as S
 
@@ -233,7 +234,7 @@ def np_dem_detect(img, f_para):
     corners = O.gftt(img, 2 * int(f_para[3]), f_para[4], int(f_para[5]))
     out = []
     for reg in np_fill_regions(img, corners, w, h, False):
-        reg = sorted(reg, key=lambda e: -float(e[1]))          # stable: ties keep the GFTT rank order
+        reg = G.gnu_sort(list(reg), lambda a, b: a[1] > b[1])  # std::sort(..., sortbysecdesc): ties where libstdc++'s introsort leaves them
         kept = []
         for (pt, _) in reg:
             ok = all(not (abs(pt[0] - k[0]) <= bd or abs(pt[1] - k[1]) <= bd) for k in kept)
@@ -253,7 +254,7 @@ def np_dem_redetect(img, f_para, existed):
     corners = O.gftt(img, int(f_para[3]), f_para[4], int(f_para[5]))
     new = []
     for i, reg in enumerate(np_fill_regions(img, corners, w, h, False)):
-        for (pt, _) in sorted(reg, key=lambda e: -float(e[1])):
+        for (pt, _) in G.gnu_sort(list(reg), lambda a, b: a[1] > b[1]):
             ip = (int(np.rint(pt[0])), int(np.rint(pt[1])))     # cv::Point pt = Point2f: rounds half to even
             near = any(abs(np.float32(ip[0]) - k[0]) <= bd or abs(np.float32(ip[1]) - k[1]) <= bd for k in regions[i])
             if not near:
