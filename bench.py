@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 from flvis_amd import bench_plan as plan  # noqa: E402  (pure python, no GPU)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
-ROUND_TAG = "r03"
+ROUND_TAG = "r04"
 
 # algorithmic HBM bytes per launch of the image-scan kernels for ONE stream, 640x480:
 PYR_BYTES = 307200 + 76800 + 19200 + 4800          # one pyramid (levels 0..3)
@@ -270,11 +270,20 @@ def run_pmc(args):
         for k, v in per.items():
             t = second_half(v)
             kern.setdefault(k, {})[key] = sum(t) / len(t)
+    cal = read_calibration()
+    if cal:   # known-byte probes on this hardware (scripts/pmc_calibrate.py): counter reading x factor = bytes
+        for k in kern.values():
+            if k.get("fetch_kb") is not None:
+                k["fetch_kb_calibrated"] = k["fetch_kb"] * cal["fetch_factor"]
+            if k.get("write_kb") is not None:
+                k["write_kb_calibrated"] = k["write_kb"] * cal["write_factor"]
     out = {"source_sha": csrc_hash(), "steps": args.steps, "warmup": args.warmup, "streams": args.streams, "kernels": kern,
+           "calibration": cal,
            "note": "rocprofv3, four passes of `bench.py --steps %d --warmup %d --no-epilogue --no-h2d`: kernel trace (avg_ns), --pmc "
-                   "FETCH_SIZE, --pmc WRITE_SIZE (KB; uncorrected: the gfx950 factor 2 of MI355X_MICROARCH.md's HBM section is calibrated "
-                   "for 16 B/lane streaming reads only), --pmc SQ_INSTS_VALU (wave instructions); per kernel the average over the second "
-                   "half of its launches (the timed region)" % (args.steps, args.warmup)}
+                   "FETCH_SIZE, --pmc WRITE_SIZE (KB as the counters report them; *_calibrated = x the factors of the known-byte probes in "
+                   "`calibration`: on gfx950 FETCH_SIZE reports half of the bytes read at every access width probed, WRITE_SIZE the bytes "
+                   "written), --pmc SQ_INSTS_VALU (wave instructions); per kernel the average over the second half of its launches (the "
+                   "timed region)" % (args.steps, args.warmup)}
     # the headline roofline object prices "k_lk_track" as one kernel with two launches per step: the mean of its two instances
     inst = [kern[k] for k in ("k_lk_track_temporal", "k_lk_track_stereo") if k in kern]
     if inst and "k_lk_track" not in kern:
@@ -282,13 +291,29 @@ def run_pmc(args):
     lk = kern.get("k_lk_track", {})
     lkout = {"kernel": "k_lk_track", "lk_source_sha": lk_source_hash(), "steps": args.steps, "streams": args.streams,
              "fetch_size_kb_per_launch": lk.get("fetch_kb"), "write_size_kb_per_launch": lk.get("write_kb"),
-             "traffic_bytes_per_launch": (lk.get("fetch_kb", 0) + lk.get("write_kb", 0)) * 1024.0 if lk else None,
-             "note": "from %s_kernel_pmc.json" % ROUND_TAG}
+             "traffic_bytes_per_launch": (lk.get("fetch_kb_calibrated", lk.get("fetch_kb", 0)) + lk.get("write_kb_calibrated", lk.get("write_kb", 0))) * 1024.0 if lk else None,
+             "calibrated": bool(cal), "note": "from %s_kernel_pmc.json" % ROUND_TAG}
     for dst in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
         os.makedirs(dst, exist_ok=True)
         json.dump(out, open(os.path.join(dst, "%s_kernel_pmc.json" % ROUND_TAG), "w"), indent=1)
         json.dump(lkout, open(os.path.join(dst, "%s_lk_pmc.json" % ROUND_TAG), "w"), indent=1)
     print(json.dumps(out))
+
+
+def read_calibration():
+    """factors of the newest committed counter calibration (profiles/rNN_counter_calibration.json): mean over the probes"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counter_calibration.json")), reverse=True):
+        try:
+            c = json.load(open(path))
+            ff = [p["fetch_factor"] for p in c["probes"].values() if p.get("fetch_factor")]
+            wf = [p["write_factor"] for p in c["probes"].values() if p.get("write_factor")]
+            if ff and wf:
+                return {"file": os.path.basename(path), "fetch_factor": round(sum(ff) / len(ff), 4), "write_factor": round(sum(wf) / len(wf), 4),
+                        "fetch_factor_range": [round(min(ff), 4), round(max(ff), 4)], "write_factor_range": [round(min(wf), 4), round(max(wf), 4)]}
+        except Exception:
+            continue
+    return None
 
 
 def read_kernel_pmc(S):

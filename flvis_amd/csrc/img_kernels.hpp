@@ -50,8 +50,9 @@ struct LKParams {
   // Template cache (lk_kernel.hip).  The stereo matcher of frame t computes, for every landmark, the template -- interpolated I, Ix, Iy
   // of the 31 x 31 window on every level + the Hessian sums -- at the landmark's pixel in the left image of frame t; the temporal
   // tracker of frame t + 1 needs exactly that template (previous image = that image, previous point = that pixel).  tc_mode 1: every
-  // point p < tc_cap stores its templates in slot p, with the position bits and tc_tag[s] in the slot's header.  tc_mode 2: point p
-  // looks at slot tc_slot[s * nmax + p] (-1: none) and takes the templates if position bits and tag match, otherwise it computes them.
+  // point p < tc_cap stores its templates in slot p, with the position bits and tc_tag[s] in the slot's header.  tc_mode 2: the caller
+  // has compared the headers already (lk_tc_lookup): tc_slot[s * nmax + p] = slot | (mask of the levels stored << 16) if the slot was
+  // written for this very position of the image tagged tc_tag[s], else -1 (the point computes its templates).
   // HBM capacity and bandwidth (idle on this path) spent to save the VALU work that bounds the kernel.
   uint32_t* tc = nullptr;             // [S][tc_cap][tc_stride]
   int tc_mode = 0, tc_cap = 0, tc_stride = 0;
@@ -60,6 +61,13 @@ struct LKParams {
 };
 // dwords of one template-cache slot for a pyramid with levels 0 .. levels
 int lk_tc_slot_dwords(int levels);
+// tc_mode 2's per-point code for the point at (px, py) of the image tagged `tag` whose landmark remembers `slot` (device side)
+__device__ inline int lk_tc_lookup(const uint32_t* tc, int tc_cap, int tc_stride, int s, int slot, float px, float py, long long tag) {
+  if (!tc || slot < 0 || slot >= tc_cap) return -1;
+  const uint32_t* h = tc + ((size_t)s * tc_cap + slot) * tc_stride;
+  if (h[0] != __float_as_uint(px) || h[1] != __float_as_uint(py) || *reinterpret_cast<const long long*>(h + 2) != tag) return -1;
+  return slot | (int)((h[4] & 0x7fffu) << 16);
+}
 
 struct DemParams {
   int regionWidth, regionHeight, boundary_dis;

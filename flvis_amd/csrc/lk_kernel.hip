@@ -26,13 +26,14 @@ constexpr int LK_RM = 4;      // search-region margin (pixels)
 constexpr int LK_RS = 52;     // search-region row stride (bytes): 13 dwords (odd -> conflict-free row walks)
 constexpr int LK_RROWS = 33 + 2 * LK_RM;
 // template cache (LKParams::tc): one slot per (stream, point); LK_TC_HDR header dwords -- position bits (2), tag (2), mask of the levels
-// stored (1), 3 unused, then the three Hessian sums of every level as int64 (6 dwords per level) -- followed by LK_TC_LVL dwords per
-// level: the 24 template registers (tI, tX, tY: 8 packed pairs each) of the 64 lanes as six 1 KB rows (one dwordx4 per lane and row)
+// stored (1), the rest unused -- followed by LK_TC_LVL dwords per level: the 24 template registers (tI, tX, tY: 8 packed pairs each) of
+// the 64 lanes as six 1 KB rows (one dwordx4 per lane and row); lane 63, which holds no template (window row 31), carries the level's
+// three Hessian sums (int64) in its first six dwords
 constexpr int LK_TC_HDR = 64;
 constexpr int LK_TC_LVL = 64 * 24;
-static_assert(8 + 6 * LK_MAX_LEVELS <= LK_TC_HDR, "header");
 
 typedef short lk_s2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) uint32_t lk_gu32;  // a dword in global memory (global_load instead of flat_load)
 typedef uint32_t lk_u4 __attribute__((ext_vector_type(4)));  // (a native vector: the non-temporal builtins do not take HIP's uint4 class)
 // (by value: __builtin_bit_cast applied directly to a vector-element expression such as q.y reads element 0 with this compiler)
 __device__ __forceinline__ lk_s2 lk_as_s2(uint32_t v) { return __builtin_bit_cast(lk_s2, v); }
@@ -45,20 +46,38 @@ __device__ __forceinline__ lk_s2 lk_as_s2(uint32_t v) { return __builtin_bit_cas
 __device__ __forceinline__ bool lk_load_patch(const uint8_t* __restrict__ img, int w, int h, int pitch, int bx, int by, int X0, int Y0,
                                               int nrows, uint8_t* patch) {
   if (X0 >= -bx && Y0 >= -by && X0 + 39 < w + bx && Y0 + nrows <= h + by) {  // (+ 39: the second dword of the last item stays inside the row)
-    const uint8_t* const base = img + (ptrdiff_t)Y0 * pitch + (X0 & ~3);
+    // ALL loads of the lane are issued before the first one is consumed: one memory round trip for the patch instead of one per trip
+    // (the loop form waited for every load before it issued the next -- five dependent round trips of ~1 us under load)
+    const lk_gu32* const base = (const lk_gu32*)(img + (ptrdiff_t)Y0 * pitch + (X0 & ~3));
     const int sh = X0 & 3;
     int r = (int)threadIdx.x / 9, k = (int)threadIdx.x - 9 * r;
     unsigned off = (unsigned)(r * pitch + 4 * k);
-    unsigned dst = (unsigned)(r * LK_PS + 4 * k);
+    static_assert(LK_PROWS * 9 <= 5 * 64, "five trips");
     const int n = nrows * 9;
-    for (int i = threadIdx.x; i < n; i += 64) {
-      const uint32_t lo = *reinterpret_cast<const uint32_t*>(base + off);
-      const uint32_t hi = *reinterpret_cast<const uint32_t*>(base + off + 4);
-      *reinterpret_cast<uint32_t*>(patch + dst) = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    uint32_t lo[5], hi[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      const bool on = (int)threadIdx.x + 64 * t < n;
+      const unsigned o = on ? off : 0u;   // (a lane past the end re-reads item 0 of the patch: in bounds, never stored)
+      lo[t] = *(const lk_gu32*)((const __attribute__((address_space(1))) uint8_t*)base + o);
+      hi[t] = *(const lk_gu32*)((const __attribute__((address_space(1))) uint8_t*)base + o + 4);
       k += 1;
       const bool wrap = k >= 9;
       k = wrap ? k - 9 : k;
       off += (unsigned)(7 * pitch + 4) + (wrap ? (unsigned)(pitch - 36) : 0u);
+    }
+    // (every loaded value is "used" here, so the compiler cannot sink the last, predicated trip's loads behind the wait for the others)
+#pragma unroll
+    for (int t = 0; t < 5; t++) asm volatile("" : "+v"(lo[t]), "+v"(hi[t]));
+    r = (int)threadIdx.x / 9;
+    k = (int)threadIdx.x - 9 * r;
+    unsigned dst = (unsigned)(r * LK_PS + 4 * k);
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      if ((int)threadIdx.x + 64 * t < n) *reinterpret_cast<uint32_t*>(patch + dst) = __builtin_amdgcn_alignbyte(hi[t], lo[t], sh);
+      k += 1;
+      const bool wrap = k >= 9;
+      k = wrap ? k - 9 : k;
       dst += (unsigned)(7 * LK_PS + 4) + (wrap ? (unsigned)(LK_PS - 36) : 0u);
     }
     return false;
@@ -89,17 +108,27 @@ __device__ __forceinline__ bool lk_load_patch(const uint8_t* __restrict__ img, i
 __device__ __forceinline__ bool lk_load_region(const uint8_t* __restrict__ img, int w, int h, int pitch, int bx, int by, int X0, int Y0,
                                                uint8_t* region) {
   if (X0 >= -bx && Y0 >= -by && X0 + 51 < w + bx && Y0 + LK_RROWS <= h + by) {
-    const uint8_t* const base = img + (ptrdiff_t)Y0 * pitch + X0;
+    // nine loads per lane in flight at once, then nine LDS stores (see lk_load_patch)
+    const __attribute__((address_space(1))) uint8_t* const base = (const __attribute__((address_space(1))) uint8_t*)(img + (ptrdiff_t)Y0 * pitch + X0);
     int r = (int)threadIdx.x / 13, k = (int)threadIdx.x - 13 * r;
     unsigned off = (unsigned)(r * pitch + 4 * k);
     static_assert(LK_RS == 52, "the region rows are contiguous in LDS: item i sits at byte 4 i");
-    for (int i = threadIdx.x; i < LK_RROWS * 13; i += 64) {
-      *reinterpret_cast<uint32_t*>(region + 4 * i) = *reinterpret_cast<const uint32_t*>(base + off);
+    constexpr int N = LK_RROWS * 13, T = (N + 63) / 64;
+    uint32_t v[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const bool on = 64 * (t + 1) <= N || (int)threadIdx.x + 64 * t < N;
+      v[t] = *(const lk_gu32*)(base + (on ? off : 0u));
       k += 12;
       const bool wrap = k >= 13;
       k = wrap ? k - 13 : k;
       off += (unsigned)(4 * pitch + 48) + (wrap ? (unsigned)(pitch - 52) : 0u);
     }
+#pragma unroll
+    for (int t = 0; t < T; t++) asm volatile("" : "+v"(v[t]));
+#pragma unroll
+    for (int t = 0; t < T; t++)
+      if (64 * (t + 1) <= N || (int)threadIdx.x + 64 * t < N) *reinterpret_cast<uint32_t*>(region + 4 * ((int)threadIdx.x + 64 * t)) = v[t];
     return false;
   }
   for (int i = threadIdx.x; i < LK_RROWS * 13; i += 64) {
@@ -242,6 +271,18 @@ __device__ __forceinline__ void lk_template(const uint8_t* patch, int lane, int 
   }
 }
 
+// Base address of one pyramid level for stream s.  The slot choice cur[s] (a global load the compiler may not hoist: memory could have
+// changed) is read ONCE per wave and passed in: every level of a pyramid that selects by slot shares one slot array (fill_pyr); ind0 =
+// the already loaded base of an indirect level 0.  A level then costs kernel-argument reads only, no dependent global round trip.
+__device__ __forceinline__ const uint8_t* lk_level_ptr(const PyrSel& P, int level, int s, int kc, const uint8_t* ind0) {
+  const ImgSel& I = P.lvl[level];
+  if (I.ind) return (level == 0 ? ind0 : *I.ind) + (size_t)s * P.stride[level];
+  return I.b[I.cur ? (kc ^ I.flip) : 0] + (size_t)s * P.stride[level];
+}
+
+#ifndef FLVIS_LK_PREFETCH
+#define FLVIS_LK_PREFETCH 1  // (build-variant knob)
+#endif
 #ifndef FLVIS_LK_WAVES
 #define FLVIS_LK_WAVES 4  // (build-variant knob: waves per SIMD the register allocation aims at)
 #endif
@@ -271,6 +312,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
   if (n > nmax) n = nmax;
   __shared__ __attribute__((aligned(16))) uint8_t patch[LK_RROWS * LK_RS + 12];  // template patch, then search region
   const int lane = threadIdx.x;
+  int kc_prev = 0, kc_next = 0;
+#pragma unroll
+  for (int l = LK_MAX_LEVELS - 1; l >= 0; l--) {  // (the slot array of the lowest level that has one; all levels share it)
+    if (l <= prev.levels && prev.lvl[l].cur) kc_prev = prev.lvl[l].cur[s];
+    if (l <= next.levels && next.lvl[l].cur) kc_next = next.lvl[l].cur[s];
+  }
+  const uint8_t* const ind_prev0 = prev.lvl[0].ind ? *prev.lvl[0].ind : nullptr;
+  const uint8_t* const ind_next0 = next.lvl[0].ind ? *next.lvl[0].ind : nullptr;
   const int r = lane >> 1;
   const int c0 = (lane & 1) * 16;
   const int W_BITS = 14;
@@ -293,15 +342,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
         tc_ptr = prm.tc + ((size_t)s * prm.tc_cap + p) * prm.tc_stride;
       }
     } else if (ROLE == 1 && prm.tc_mode == 2) {
-      const int slot = prm.tc_slot[(size_t)s * nmax + p];
-      if (slot >= 0 && slot < prm.tc_cap) {
-        tc_ptr = prm.tc + ((size_t)s * prm.tc_cap + slot) * prm.tc_stride;
-        const long long tag = *reinterpret_cast<const long long*>(tc_ptr + 2);
-        const bool ok = tc_ptr[0] == __float_as_uint(ppx0) && tc_ptr[1] == __float_as_uint(ppy0) && tag == prm.tc_tag[s];
-        tc_hit = __builtin_amdgcn_readfirstlane((int)ok) != 0;
-        tc_mask = tc_hit ? (uint32_t)__builtin_amdgcn_readfirstlane((int)tc_ptr[4]) : 0u;
+      // the caller has compared the slot's header (position bits, tag) with this point: code = slot | (mask of stored levels << 16), or -1
+      const int code = __builtin_amdgcn_readfirstlane(prm.tc_slot[(size_t)s * nmax + p]);
+      if (code >= 0 && (code & 0xffff) < prm.tc_cap) {
+        tc_ptr = prm.tc + ((size_t)s * prm.tc_cap + (code & 0xffff)) * prm.tc_stride;
+        tc_hit = true;
+        tc_mask = (uint32_t)code >> 16;
       }
     }
+    lk_u4 pq[6] = {};  // templates of level pq_level, in flight or arrived (-1: none)
+    int pq_level = -1;
     for (int level = prev.levels; level >= 0; level--) {
       const float sc = (float)(1. / (1 << level));
       float ppx = ppx0 * sc, ppy = ppy0 * sc;
@@ -341,14 +391,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
       const bool cached = ROLE == 1 && tc_hit && ((tc_mask >> level) & 1u);
       if (cached) {
         if (prm.stats_tc && lane == 0) atomicAdd(&prm.stats_tc[0], 1ull);
-        const lk_u4* src = reinterpret_cast<const lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
+        if (pq_level != level) {  // (the top level, or the level above did not get this far)
+          const lk_u4* src = reinterpret_cast<const lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
+#pragma unroll
+          for (int k = 0; k < 6; k++) pq[k] = __builtin_nontemporal_load(src + 64 * k);
+        }
         lk_u4 q[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) q[k] = __builtin_nontemporal_load(src + 64 * k);
-        const long long* sums = reinterpret_cast<const long long*>(tc_ptr + 8 + 6 * level);
-        iA11 = sums[0];
-        iA12 = sums[1];
-        iA22 = sums[2];
+        for (int k = 0; k < 6; k++) q[k] = pq[k];
+        pq_level = -1;
+#if FLVIS_LK_PREFETCH
+        // the next level's templates are requested now: they travel while this level iterates, together with the search region's loads
+        // (one memory round trip per level instead of two)
+        if (level > 0 && ((tc_mask >> (level - 1)) & 1u)) {
+          const lk_u4* src = reinterpret_cast<const lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)(level - 1) * LK_TC_LVL) + lane;
+#pragma unroll
+          for (int k = 0; k < 6; k++) pq[k] = __builtin_nontemporal_load(src + 64 * k);
+          pq_level = level - 1;
+        }
+#endif
+        // (the three Hessian sums ride in lane 63's registers: the lanes of window row 31 hold no template)
+        iA11 = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)q[0].y, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)q[0].x, 63));
+        iA12 = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)q[0].w, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)q[0].z, 63));
+        iA22 = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)q[1].y, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)q[1].x, 63));
 #pragma unroll
         for (int k = 0; k < 2; k++) {
           tI[4 * k + 0] = lk_as_s2(q[k].x); tI[4 * k + 1] = lk_as_s2(q[k].y);
@@ -360,7 +425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
         }
       } else {
         __syncthreads();
-        const bool slow = lk_load_patch(prev.lvl[level].ptr(s, prev.stride[level]), W, H, prev.pitch[level], prev.bx[level], prev.by[level],
+        const bool slow = lk_load_patch(lk_level_ptr(prev, level, s, kc_prev, ind_prev0), W, H, prev.pitch[level], prev.bx[level], prev.by[level],
                                         ipx - 1, ipy - 1, LK_PROWS, patch);
         __syncthreads();
         if (prm.stats_tc && slow && lane == 0) atomicAdd(&prm.stats_tc[1], 1ull);
@@ -377,20 +442,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
         iA22 = lk_wave_sum_wide(a22);
         if (ROLE == 2 && tc_store) {
           lk_u4* dst = reinterpret_cast<lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
+          // lane 63 (window row 31: no template) carries the three Hessian sums in the place of its tI registers
+          uint32_t wI[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) wI[k] = __builtin_bit_cast(uint32_t, tI[k]);
+          if (lane == 63) {
+            wI[0] = (uint32_t)iA11; wI[1] = (uint32_t)((unsigned long long)iA11 >> 32);
+            wI[2] = (uint32_t)iA12; wI[3] = (uint32_t)((unsigned long long)iA12 >> 32);
+            wI[4] = (uint32_t)iA22; wI[5] = (uint32_t)((unsigned long long)iA22 >> 32);
+          }
 #pragma unroll
           for (int k = 0; k < 2; k++) {
-            __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tI[4 * k]), __builtin_bit_cast(uint32_t, tI[4 * k + 1]),
-                                              __builtin_bit_cast(uint32_t, tI[4 * k + 2]), __builtin_bit_cast(uint32_t, tI[4 * k + 3])}, dst + 64 * k);
+            __builtin_nontemporal_store(lk_u4{wI[4 * k], wI[4 * k + 1], wI[4 * k + 2], wI[4 * k + 3]}, dst + 64 * k);
             __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tX[4 * k]), __builtin_bit_cast(uint32_t, tX[4 * k + 1]),
                                               __builtin_bit_cast(uint32_t, tX[4 * k + 2]), __builtin_bit_cast(uint32_t, tX[4 * k + 3])}, dst + 64 * (2 + k));
             __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tY[4 * k]), __builtin_bit_cast(uint32_t, tY[4 * k + 1]),
                                               __builtin_bit_cast(uint32_t, tY[4 * k + 2]), __builtin_bit_cast(uint32_t, tY[4 * k + 3])}, dst + 64 * (4 + k));
-          }
-          if (lane == 0) {
-            long long* sums = reinterpret_cast<long long*>(tc_ptr + 8 + 6 * level);
-            sums[0] = iA11;
-            sums[1] = iA12;
-            sums[2] = iA22;
           }
           tc_mask |= 1u << level;
         }
@@ -408,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
       npy -= halfWin;
       float pdx = 0.f, pdy = 0.f;
       const int JW = next.w[level], JH = next.h[level];
-      const uint8_t* Jimg = next.lvl[level].ptr(s, next.stride[level]);
+      const uint8_t* Jimg = lk_level_ptr(next, level, s, kc_next, ind_next0);
       bool region_ok = false;
       int RX0 = 0, RY0 = 0;
       int iters_run = 0;

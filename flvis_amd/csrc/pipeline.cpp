@@ -420,6 +420,8 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   // LK template cache: the stereo matcher's templates of frame t are the temporal tracker's templates of frame t + 1 (LKParams::tc).
   // Only rigs with a stereo matcher have one; FLVIS_LK_TCACHE=0 turns it off (A/B knob, and the reference point of the cache's test).
   p.tc_cap = 0;
+  p.tc = nullptr;
+  p.tc_stride = 0;
   L->tc = nullptr;
   {
     const char* e = getenv("FLVIS_LK_TCACHE");
@@ -432,6 +434,8 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
       if (L->tc) {
         hipMemset(L->tc, 0xff, n * sizeof(uint32_t));  // no header matches a position or a frame id
         p.tc_cap = cap;
+        p.tc = L->tc;
+        p.tc_stride = L->tc_stride;
       } else {
         (void)hipGetLastError();  // no memory for it: run without
       }

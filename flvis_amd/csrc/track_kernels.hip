@@ -316,8 +316,10 @@ __global__ __launch_bounds__(256) void k_track_prepare(Pipe p) {
   }
   if (i >= n) return;
   const Landmark& lm = lm_ptr(p, last, s)[i];
-  p.lk_slot[(size_t)s * NMAX + i] = lm.tslot;
   float px = (float)lm.p2d[0], py = (float)lm.p2d[1];
+  // template cache: was the landmark's slot written for this very pixel of the last frame's left image? (the LK wave then needs one
+  // load instead of a chain of dependent ones)
+  p.lk_slot[(size_t)s * NMAX + i] = lk_tc_lookup(p.tc, p.tc_cap, p.tc_stride, s, lm.tslot, px, py, st.frame_id[last]);
   float* pp = p.prev_pts + ((size_t)s * NMAX + i) * 2;
   float* np = p.next_pts + ((size_t)s * NMAX + i) * 2;
   pp[0] = px;

@@ -23,6 +23,8 @@ struct Pipe {
   int* lk_slot;             // [S][NMAX] temporal LK: template-cache slot of each previous point (Landmark::tslot), -1: none
   long long* lk_tag;        // [S] identity of the LK launch's template image (frame id of the stream's current / last frame)
   int tc_cap;               // slots per stream of the lane's template cache (0: no cache)
+  const uint32_t* tc;       // the cache itself (k_track_prepare compares the slot headers) and its slot size in dwords
+  int tc_stride;
   float* m1;                // [S][NMAX][2]  F-RANSAC inputs (ascending survivors)
   float* m2;
   double* tri;              // [S][NMAX][3]

@@ -75,8 +75,12 @@ def kernel_table(stages, S, w, h, copy_gbs, pmc=None, ba=None, ms_per_step=None)
                 rate = k["valu_insts"] / (row["avg_launch_ms"] * 1e-3) / 1e9
                 row["valu_ginst_per_s"] = round(rate, 1)
                 row["valu_issue_frac"] = round(rate / VALU_ISSUE_PEAK_GINST, 4)
-        if k.get("fetch_kb") is not None and k.get("write_kb") is not None:
+        if k.get("fetch_kb_calibrated") is not None and k.get("write_kb_calibrated") is not None:   # counter x probe factor (round 4)
+            row["traffic_bytes_per_launch"] = int((k["fetch_kb_calibrated"] + k["write_kb_calibrated"]) * 1024)
+            row["traffic_calibrated"] = True
+        elif k.get("fetch_kb") is not None and k.get("write_kb") is not None:
             row["traffic_bytes_per_launch"] = int((k["fetch_kb"] + k["write_kb"]) * 1024)
+            row["traffic_calibrated"] = False
         if k.get("avg_ns") is not None:
             row["rocprof_avg_launch_ms"] = round(k["avg_ns"] * 1e-6, 4)
 
