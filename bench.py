@@ -223,9 +223,7 @@ def csrc_hash():
 def short_kernel_name(full):
     n = full.split("(")[0]
     n = n.split("::")[-1].strip()
-    if n.startswith("k_lk_track<"):   # the tracker's two LK launches are instances of one kernel template (role 1 / 2)
-        return {"k_lk_track<1>": "k_lk_track_temporal", "k_lk_track<2>": "k_lk_track_stereo"}.get(n, "k_lk_track")
-    return n.split("<")[0].strip()
+    return n.split("<")[0].strip()   # (the tracker's two LK launches are kernels of their own: k_lk_track_temporal / k_lk_track_stereo)
 
 
 def run_pmc(args):

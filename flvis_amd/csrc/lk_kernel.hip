@@ -271,6 +271,50 @@ __device__ __forceinline__ void lk_template(const uint8_t* patch, int lane, int 
   }
 }
 
+// One level's template from the image: stage the source patch (rows ipy-1 .. ipy+32, columns ipx-1 .. ipx+34), Scharr + bilinear
+// interpolation, the three Hessian sums over the wave.  Returns whether the staging took the index-reflecting path.
+__device__ __forceinline__ bool lk_template_level(const uint8_t* img, int W, int H, int pitch, int bx, int by, int ipx, int ipy, int iw00,
+                                                  int iw01, int iw10, int iw11, uint8_t* patch, int lane, lk_s2 (&tI)[8], lk_s2 (&tX)[8],
+                                                  lk_s2 (&tY)[8], long long& iA11, long long& iA12, long long& iA22) {
+  __syncthreads();
+  const bool slow = lk_load_patch(img, W, H, pitch, bx, by, ipx - 1, ipy - 1, LK_PROWS, patch);
+  __syncthreads();
+  int a11 = 0, a12 = 0, a22 = 0;
+  // every pixel the Scharr stencil is evaluated at lies inside the image -> no border masks (wave-uniform test)
+  const bool interior = ipx >= 0 && ipx + 32 <= W - 1 && ipy >= 0 && ipy + 31 <= H - 1;
+  const lk_s2 wT = lk_s2{(short)iw00, (short)iw01}, wB = lk_s2{(short)iw10, (short)iw11};
+  if (interior)
+    lk_template<true>(patch, lane, ipx, ipy, W, H, wT, wB, tI, tX, tY, a11, a12, a22);
+  else
+    lk_template<false>(patch, lane, ipx, ipy, W, H, wT, wB, tI, tX, tY, a11, a12, a22);
+  iA11 = lk_wave_sum_wide(a11);
+  iA12 = lk_wave_sum_wide(a12);
+  iA22 = lk_wave_sum_wide(a22);
+  return slow;
+}
+// The same as a CALL, for the temporal launch: there nearly every template comes from the cache, and with the computation out of line
+// (its own register allocation, results handed over through the caller's stack) the kernel's hot path -- cache loads, region staging,
+// iterations -- fits a register budget that lets twice as many waves share a SIMD.
+struct LKTmpl {
+  uint32_t w[24];
+  long long a11, a12, a22;
+};
+__device__ __noinline__ void lk_template_level_cold(const uint8_t* img, int W, int H, int pitch, int bx, int by, int ipx, int ipy, int iw00,
+                                                    int iw01, int iw10, int iw11, uint8_t* patch, int lane, LKTmpl* out) {
+  lk_s2 tI[8], tX[8], tY[8];
+  long long a11, a12, a22;
+  lk_template_level(img, W, H, pitch, bx, by, ipx, ipy, iw00, iw01, iw10, iw11, patch, lane, tI, tX, tY, a11, a12, a22);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    out->w[k] = __builtin_bit_cast(uint32_t, tI[k]);
+    out->w[8 + k] = __builtin_bit_cast(uint32_t, tX[k]);
+    out->w[16 + k] = __builtin_bit_cast(uint32_t, tY[k]);
+  }
+  out->a11 = a11;
+  out->a12 = a12;
+  out->a22 = a22;
+}
+
 // Base address of one pyramid level for stream s.  The slot choice cur[s] (a global load the compiler may not hoist: memory could have
 // changed) is read ONCE per wave and passed in: every level of a pyramid that selects by slot shares one slot array (fill_pyr); ind0 =
 // the already loaded base of an indirect level 0.  A level then costs kernel-argument reads only, no dependent global round trip.
@@ -281,19 +325,22 @@ __device__ __forceinline__ const uint8_t* lk_level_ptr(const PyrSel& P, int leve
 }
 
 #ifndef FLVIS_LK_PREFETCH
-#define FLVIS_LK_PREFETCH 1  // (build-variant knob)
+#define FLVIS_LK_PREFETCH 0  // (build-variant knob; measured: the 24 registers it holds cost more than the round trip it saves)
 #endif
 #ifndef FLVIS_LK_WAVES
 #define FLVIS_LK_WAVES 4  // (build-variant knob: waves per SIMD the register allocation aims at)
+#endif
+#ifndef FLVIS_LK_WAVES_T
+#define FLVIS_LK_WAVES_T 4  // ... of the temporal launch (its template computation is out of line)
 #endif
 // 4 waves per SIMD (<= 128 VGPRs): this kernel is latency-bound (PMC: VALU busy ~20%), occupancy is what pays
 // ROLE names the launch in the profiles and fixes what the template cache may do: 0 the stand-alone entry point (no cache), 1 the
 // tracker's temporal launch (may take templates from the cache), 2 its stereo launch (may store them)
 template <int ROLE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAVES, FLVIS_LK_WAVES))) void k_lk_track(PyrSel prev, PyrSel next, const float* __restrict__ prev_pts,
-                                                 float* __restrict__ next_pts, uint8_t* __restrict__ status,
-                                                 const int* __restrict__ count, int nmax, LKParams prm,
-                                                 const int* __restrict__ active) {
+__device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& next, const float* __restrict__ prev_pts,
+                                              float* __restrict__ next_pts, uint8_t* __restrict__ status,
+                                              const int* __restrict__ count, int nmax, const LKParams& prm,
+                                              const int* __restrict__ active) {
   // XCD-aware workgroup -> (stream, point) map: workgroup b is observed to run on XCD b % 8 (each XCD has its own 4 MiB
   // L2), so a stream's workgroups are renumbered onto one XCD and its two pyramids (~0.8 MB) are fetched from HBM once
   // instead of once per XCD.  A bijection whenever the grid size is a multiple of 8; speed only, never correctness.
@@ -423,23 +470,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
           tY[4 * k + 0] = lk_as_s2(q[4 + k].x); tY[4 * k + 1] = lk_as_s2(q[4 + k].y);
           tY[4 * k + 2] = lk_as_s2(q[4 + k].z); tY[4 * k + 3] = lk_as_s2(q[4 + k].w);
         }
+      } else if (ROLE == 1) {
+        LKTmpl T;
+        lk_template_level_cold(lk_level_ptr(prev, level, s, kc_prev, ind_prev0), W, H, prev.pitch[level], prev.bx[level], prev.by[level], ipx, ipy, iw00,
+                               iw01, iw10, iw11, patch, lane, &T);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          tI[k] = lk_as_s2(T.w[k]);
+          tX[k] = lk_as_s2(T.w[8 + k]);
+          tY[k] = lk_as_s2(T.w[16 + k]);
+        }
+        iA11 = T.a11;
+        iA12 = T.a12;
+        iA22 = T.a22;
       } else {
-        __syncthreads();
-        const bool slow = lk_load_patch(lk_level_ptr(prev, level, s, kc_prev, ind_prev0), W, H, prev.pitch[level], prev.bx[level], prev.by[level],
-                                        ipx - 1, ipy - 1, LK_PROWS, patch);
-        __syncthreads();
+        const bool slow = lk_template_level(lk_level_ptr(prev, level, s, kc_prev, ind_prev0), W, H, prev.pitch[level], prev.bx[level], prev.by[level], ipx,
+                                            ipy, iw00, iw01, iw10, iw11, patch, lane, tI, tX, tY, iA11, iA12, iA22);
         if (prm.stats_tc && slow && lane == 0) atomicAdd(&prm.stats_tc[1], 1ull);
-        int a11 = 0, a12 = 0, a22 = 0;
-        // every pixel the Scharr stencil is evaluated at lies inside the image -> no border masks (wave-uniform test)
-        const bool interior = ipx >= 0 && ipx + 32 <= W - 1 && ipy >= 0 && ipy + 31 <= H - 1;
-        const lk_s2 wT = lk_s2{(short)iw00, (short)iw01}, wB = lk_s2{(short)iw10, (short)iw11};
-        if (interior)
-          lk_template<true>(patch, lane, ipx, ipy, W, H, wT, wB, tI, tX, tY, a11, a12, a22);
-        else
-          lk_template<false>(patch, lane, ipx, ipy, W, H, wT, wB, tI, tX, tY, a11, a12, a22);
-        iA11 = lk_wave_sum_wide(a11);
-        iA12 = lk_wave_sum_wide(a12);
-        iA22 = lk_wave_sum_wide(a22);
         if (ROLE == 2 && tc_store) {
           lk_u4* dst = reinterpret_cast<lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
           // lane 63 (window row 31: no template) carries the three Hessian sums in the place of its tI registers
@@ -575,6 +622,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
   }
 }
 
+// the three launches (named apart in the profiles; the register budget is per launch kind)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAVES, FLVIS_LK_WAVES))) void k_lk_track(
+    PyrSel prev, PyrSel next, const float* __restrict__ prev_pts, float* __restrict__ next_pts, uint8_t* __restrict__ status,
+    const int* __restrict__ count, int nmax, LKParams prm, const int* __restrict__ active) {
+  lk_track_body<0>(prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAVES_T, FLVIS_LK_WAVES_T))) void k_lk_track_temporal(
+    PyrSel prev, PyrSel next, const float* __restrict__ prev_pts, float* __restrict__ next_pts, uint8_t* __restrict__ status,
+    const int* __restrict__ count, int nmax, LKParams prm, const int* __restrict__ active) {
+  lk_track_body<1>(prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAVES, FLVIS_LK_WAVES))) void k_lk_track_stereo(
+    PyrSel prev, PyrSel next, const float* __restrict__ prev_pts, float* __restrict__ next_pts, uint8_t* __restrict__ status,
+    const int* __restrict__ count, int nmax, LKParams prm, const int* __restrict__ active) {
+  lk_track_body<2>(prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+}
+
 int lk_tc_slot_dwords(int levels) { return LK_TC_HDR + (levels + 1) * LK_TC_LVL; }
 
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
@@ -586,11 +650,11 @@ void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, con
   if (max_pts > 0 && max_pts < gx) gx = (max_pts + 7) & ~7;
   if (gx > nmax) gx = nmax;
   if (role == 1)
-    hipLaunchKernelGGL(k_lk_track<1>, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+    hipLaunchKernelGGL(k_lk_track_temporal, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
   else if (role == 2)
-    hipLaunchKernelGGL(k_lk_track<2>, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+    hipLaunchKernelGGL(k_lk_track_stereo, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
   else
-    hipLaunchKernelGGL(k_lk_track<0>, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+    hipLaunchKernelGGL(k_lk_track, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
 }
 
 }  // namespace flvis

@@ -62,12 +62,13 @@ FD void track_fail(StreamState& st) {  // f2f_tracking.cpp:235-247 / 257-269
 // the staged samples of stream s, in order.  Once the filter is initialised the samples are integrated on REGISTER-resident state
 // (the previous state, the ring cursor, the keyframe preintegration are loaded once and written back once; only the new ring
 // entries are stored) -- per sample the same arithmetic as vi_imu_feed, without a store -> load round trip through HBM per sample
-__device__ inline void imu_feed_dev(const Pipe& p, int s) {
+// `in`: the stream's staged samples (7 doubles each) -- p.imu_in's rows, or a copy of them in LDS (k_frame_head: a sample's values then
+// cost an LDS read instead of a global round trip in front of every step of the sequential integration)
+__device__ inline void imu_feed_dev(const Pipe& p, int s, const double* in) {
   StreamState& st = p.st[s];
   ViRing ring{p.vi + (size_t)s * VI_QUEUE, &st};
   int n = p.n_imu[s];
   if (n > IMU_MAX) n = IMU_MAX;
-  const double* in = p.imu_in + (size_t)s * IMU_MAX * 7;
   // F2FTracking::imu_feed's per-sample outputs go to the stream's output ring (row = sample number % IMU_OUT_CAP)
   double* const out = p.imu_out + (size_t)s * IMU_OUT_CAP * IMU_ROW;
   long long seen = st.imu_seen;
@@ -108,7 +109,7 @@ __device__ inline void imu_feed_dev(const Pipe& p, int s) {
 __global__ void k_imu_feed(Pipe p) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= p.S) return;
-  imu_feed_dev(p, s);
+  imu_feed_dev(p, s, p.imu_in + (size_t)s * IMU_MAX * 7);
 }
 
 // pose_records.push_back(...) (+ pop_front once 1000 entries are reached on a tracking frame, f2f_tracking.cpp:334-337)
@@ -207,14 +208,24 @@ __global__ void k_frame_begin(Pipe p, const double* __restrict__ frame_time) {
   frame_begin_dev(p, s, frame_time[s]);
 }
 // the head of a frame in one launch: the staged IMU samples (F2FTracking::imu_feed), then the frame set-up
-__global__ void k_frame_head(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress, long long frame_no) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per stream: the integration itself is sequential (a sample's state follows from the previous one: lane 0 runs it), but
+// its inputs need not arrive one global round trip at a time -- the wave copies the stream's staged samples into LDS first.
+__global__ __launch_bounds__(64) void k_frame_head(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
+                                                   long long frame_no) {
+  const int s = blockIdx.x, tid = threadIdx.x;
   // tell the host that this frame's inputs have been uploaded (this kernel follows the upload in stream order): the pinned
   // staging slot of the frame may be refilled (a store to host-mapped memory; the host polls it, see lane_frame)
-  if (s == 0 && host_progress) __hip_atomic_store(host_progress, frame_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (s >= p.S) return;
-  imu_feed_dev(p, s);
-  frame_begin_dev(p, s, frame_time[s]);
+  if (s == 0 && tid == 0 && host_progress) __hip_atomic_store(host_progress, frame_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __shared__ double s_in[IMU_MAX * 7];
+  int n = p.n_imu[s];
+  if (n > IMU_MAX) n = IMU_MAX;
+  const double* in = p.imu_in + (size_t)s * IMU_MAX * 7;
+  for (int i = tid; i < 7 * n; i += 64) s_in[i] = in[i];
+  const double t_frame = frame_time[s];
+  __syncthreads();
+  if (tid != 0) return;
+  imu_feed_dev(p, s, s_in);
+  frame_begin_dev(p, s, t_frame);
 }
 __device__ inline void frame_begin_dev(const Pipe& p, int s, double time) {
   StreamState& st = p.st[s];
@@ -2215,7 +2226,7 @@ void launch_store_progress(hipStream_t st, long long* host_word, long long v) {
   hipLaunchKernelGGL(k_store_progress, dim3(1), dim3(1), 0, st, host_word, v);
 }
 void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time, long long* host_progress, long long frame_no) {
-  hipLaunchKernelGGL(k_frame_head, dim3((p.S + 63) / 64), dim3(64), 0, st, p, d_time, host_progress, frame_no);
+  hipLaunchKernelGGL(k_frame_head, dim3(p.S), dim3(64), 0, st, p, d_time, host_progress, frame_no);
 }
 void launch_apply_correction(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_apply_correction, dim3(p.S), dim3(AC_T), 0, st, p);
