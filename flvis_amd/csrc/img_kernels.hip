@@ -27,9 +27,35 @@ namespace flvis {
 // into LDS `tile` with row stride TS.  x0 must be a multiple of 4 (dword path for interior dwords).
 template <int TH, int TW, int TS>
 __device__ __forceinline__ void load_tile_u8(const uint8_t* __restrict__ img, int w, int h, int pitch, int x0, int y0,
-                                             uint8_t* tile) {
+                                             uint8_t* tile, int bx = 0, int by = 0) {
   static_assert(TW % 4 == 0, "tile width must be a multiple of 4");
   constexpr int DW = TW / 4;
+  // A tile that lies inside the image (block-uniform test; all but the edge tiles): nothing to reflect, and ALL of a thread's loads are
+  // issued before the first LDS store -- one memory round trip for the tile instead of one per trip of the loop below (which waits
+  // for its load before it issues the next).  256 threads assumed for the trip count (more trips than needed are predicated off).
+  // (bx, by): physical REFLECT_101 border of the source image (a pyramid level whose border is complete): "inside" then includes it.
+  if (x0 >= -bx && y0 >= -by && x0 + TW <= w + bx && y0 + TH <= h + by && blockDim.x == 256) {
+    constexpr int N = TH * DW, T = (N + 255) / 256;
+    const __attribute__((address_space(1))) uint8_t* const base =
+        (const __attribute__((address_space(1))) uint8_t*)(img + (ptrdiff_t)y0 * pitch + x0);
+    uint32_t v[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int i = (int)threadIdx.x + 256 * t;
+      const int r = i / DW, c = i - r * DW;
+      const bool on = 256 * (t + 1) <= N || i < N;
+      v[t] = *(const __attribute__((address_space(1))) uint32_t*)(base + (on ? (size_t)r * pitch + 4 * c : 0));
+    }
+#pragma unroll
+    for (int t = 0; t < T; t++) asm volatile("" : "+v"(v[t]));
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int i = (int)threadIdx.x + 256 * t;
+      const int r = i / DW, c = i - r * DW;
+      if (256 * (t + 1) <= N || i < N) *reinterpret_cast<uint32_t*>(tile + r * TS + 4 * c) = v[t];
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < TH * DW; i += blockDim.x) {
     int r = i / DW, c = i - r * DW;
     int gy = reflect101c(y0 + r, h);
@@ -199,10 +225,49 @@ constexpr int PD_TW = 64, PD_TH = 16;
 constexpr int PD_SW = 2 * PD_TW + 8;  // 136: starts at 2*x0-4 (dword aligned), covers 2*x0-2 .. 2*x0+2*TW
 constexpr int PD_SH = 2 * PD_TH + 3;  // 35
 
+// Stores the pixels (x .. x + nv - 1, y) of a level (bytes of v, low byte first; x % 4 == 0) and, for a level with a physical
+// BORDER_REFLECT_101 border (bx columns, by rows; see k_pyr_border), every border pixel that mirrors one of them: a pixel at column X in
+// 1 .. bx is also the border pixel at -X, one in w-1-bx .. w-2 the one at 2 (w - 1) - X, the same for rows, and both together for the
+// corners.  The kernel that produces a level thus leaves it with its border complete -- no extra pass over the edges, no extra launch.
+// (Needs bx < w and by < h: reflect-then-clamp, which the border is defined by, is then the plain mirror.)
+__device__ __forceinline__ void store4_mirrored(uint8_t* img, int pitch, int w, int h, int bx, int by, int x, int y, uint32_t v, int nv) {
+  uint8_t* const row = img + (ptrdiff_t)y * pitch;
+  if (nv == 4) {
+    *reinterpret_cast<uint32_t*>(row + x) = v;
+  } else {
+    for (int k = 0; k < nv; k++) row[x + k] = (uint8_t)(v >> (8 * k));
+  }
+  if (bx == 0 && by == 0) return;
+  const bool xl = x <= bx && x + nv - 1 >= 1, xr = x + nv - 1 >= w - 1 - bx && x <= w - 2;
+  const int ty0 = (y >= 1 && y <= by) ? -y : 0x7fffffff, ty1 = (y >= h - 1 - by && y <= h - 2) ? 2 * (h - 1) - y : 0x7fffffff;
+  if (!xl && !xr && ty0 == 0x7fffffff && ty1 == 0x7fffffff) return;
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const int ty = t == 0 ? y : (t == 1 ? ty0 : ty1);
+    if (ty == 0x7fffffff) continue;
+    uint8_t* const r2 = img + (ptrdiff_t)ty * pitch;
+    if (t > 0) {
+      if (nv == 4) {
+        *reinterpret_cast<uint32_t*>(r2 + x) = v;
+      } else {
+        for (int k = 0; k < nv; k++) r2[x + k] = (uint8_t)(v >> (8 * k));
+      }
+    }
+    if (xl || xr) {
+      for (int k = 0; k < nv; k++) {
+        const int X = x + k;
+        const uint8_t b = (uint8_t)(v >> (8 * k));
+        if (X >= 1 && X <= bx) r2[-X] = b;
+        if (X >= w - 1 - bx && X <= w - 2) r2[2 * (w - 1) - X] = b;
+      }
+    }
+  }
+}
+
 template <bool INGEST>
 __device__ __forceinline__ void pyr_down_tile(ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0, int d0pitch,
                                               size_t d0stride, ImgSel dst, int dpitch, size_t dstride,
-                                              const int* __restrict__ active) {
+                                              const int* __restrict__ active, int bx, int by, int sbx, int sby) {
   const int s = blockIdx.z;
   if (active && !active[s]) return;
   const int dw = (sw + 1) >> 1, dh = (sh + 1) >> 1;
@@ -210,7 +275,7 @@ __device__ __forceinline__ void pyr_down_tile(ImgSel src, int sw, int sh, int sp
   __shared__ __attribute__((aligned(16))) uint8_t tile[PD_SH * PD_SW];
   __shared__ __attribute__((aligned(16))) uint16_t hrow[PD_SH * PD_TW];
   const uint8_t* img = src.ptr(s, sstride);
-  load_tile_u8<PD_SH, PD_SW, PD_SW>(img, sw, sh, spitch, 2 * x0 - 4, 2 * y0 - 2, tile);
+  load_tile_u8<PD_SH, PD_SW, PD_SW>(img, sw, sh, spitch, 2 * x0 - 4, 2 * y0 - 2, tile, sbx, sby);
   __syncthreads();
   if (INGEST) {
     // level 0 = a copy of the caller's image (it must outlive the caller's buffer: it is the "previous image" of the next
@@ -220,7 +285,7 @@ __device__ __forceinline__ void pyr_down_tile(ImgSel src, int sw, int sh, int sp
       const int r = i / (2 * PD_TW / 4), k = i - r * (2 * PD_TW / 4);
       const int y = 2 * y0 + r, x = 2 * x0 + 4 * k;
       if (y < sh && x + 3 < sw)
-        *reinterpret_cast<uint32_t*>(o0 + (size_t)y * d0pitch + x) = *reinterpret_cast<const uint32_t*>(tile + (r + 2) * PD_SW + 4 + 4 * k);
+        store4_mirrored(o0, d0pitch, sw, sh, bx, by, x, y, *reinterpret_cast<const uint32_t*>(tile + (r + 2) * PD_SW + 4 + 4 * k), 4);
     }
   }
   // horizontal [1 4 6 4 1] at every second column: a thread makes 4 consecutive outputs of a row from four aligned dwords of
@@ -256,29 +321,23 @@ __device__ __forceinline__ void pyr_down_tile(ImgSel src, int sw, int sh, int sp
         v3 += wgt * (q.y >> 16);
       }
       const uint32_t o0b = (v0 + 128) >> 8, o1b = (v1 + 128) >> 8, o2b = (v2 + 128) >> 8, o3b = (v3 + 128) >> 8;
-      uint8_t* o = out + (size_t)y * dpitch + x;
-      if (x + 3 < dw) {
-        *reinterpret_cast<uint32_t*>(o) = o0b | (o1b << 8) | (o2b << 16) | (o3b << 24);
-      } else {  // right edge of an image whose width is not a multiple of 4
-        o[0] = (uint8_t)o0b;
-        if (x + 1 < dw) o[1] = (uint8_t)o1b;
-        if (x + 2 < dw) o[2] = (uint8_t)o2b;
-      }
+      // (nv < 4: right edge of an image whose width is not a multiple of 4)
+      store4_mirrored(out, dpitch, dw, dh, bx, by, x, y, o0b | (o1b << 8) | (o2b << 16) | (o3b << 24), dw - x < 4 ? dw - x : 4);
     }
   }
 }
 
 __global__ __launch_bounds__(256) void k_pyr_down(ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst,
-                                                  int dpitch, size_t dstride, const int* __restrict__ active) {
-  pyr_down_tile<false>(src, sw, sh, spitch, sstride, dst, 0, 0, dst, dpitch, dstride, active);
+                                                  int dpitch, size_t dstride, const int* __restrict__ active, int bx, int by, int sbx, int sby) {
+  pyr_down_tile<false>(src, sw, sh, spitch, sstride, dst, 0, 0, dst, dpitch, dstride, active, bx, by, sbx, sby);
 }
 
 // The first pyramid level fused with the ingest copy (modes without equalizeHist): the caller's image is read ONCE and
 // written out as level 0 and level 1 (the former k_copy_image16 + k_pyr_down pair read it twice).  Needs sw % 4 == 0.
 __global__ __launch_bounds__(256) void k_pyr_down_ingest(ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0,
                                                          int d0pitch, size_t d0stride, ImgSel dst, int dpitch, size_t dstride,
-                                                         const int* __restrict__ active) {
-  pyr_down_tile<true>(src, sw, sh, spitch, sstride, dst0, d0pitch, d0stride, dst, dpitch, dstride, active);
+                                                         const int* __restrict__ active, int bx, int by) {
+  pyr_down_tile<true>(src, sw, sh, spitch, sstride, dst0, d0pitch, d0stride, dst, dpitch, dstride, active, bx, by, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------ pyramid border
@@ -287,9 +346,10 @@ __global__ __launch_bounds__(256) void k_pyr_down_ingest(ImgSel src, int sw, int
 // index for a point inside the image.  One launch fills the border of every level of one pyramid: blockIdx.y = level, blockIdx.z =
 // stream; an item is one dword of the padded buffer that is not an image dword.  The values are img(reflect101c(y), reflect101c(x)),
 // the very function the kernels' slow paths evaluate per item, so a staged block is the same bytes either way.
-__global__ __launch_bounds__(256) void k_pyr_border(PyrSel pyr, const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_pyr_border(PyrSel pyr, const int* __restrict__ active, unsigned level_mask) {
   const int s = blockIdx.z, l = blockIdx.y;
   if (active && !active[s]) return;
+  if (!((level_mask >> l) & 1u)) return;
   const int bx = pyr.bx[l], by = pyr.by[l];
   if (bx == 0 && by == 0) return;
   const int w = pyr.w[l], h = pyr.h[l], pitch = pyr.pitch[l];
@@ -1142,18 +1202,20 @@ void launch_copy_image_any(hipStream_t st, ImgSel src, ImgSel dst, int w, int h,
                      sstride, dstride, active);
 }
 
+bool pyr_border_fusable(int w, int h, int bx, int by) { return bx < w && by < h; }
+
 void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,
-                     size_t dstride, int S, const int* active) {
+                     size_t dstride, int S, const int* active, int bx, int by, int sbx, int sby) {
   int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
   hipLaunchKernelGGL(k_pyr_down, dim3(div_up(dw, PD_TW), div_up(dh, PD_TH), S), dim3(256), 0, st, src, sw, sh, spitch,
-                     sstride, dst, dpitch, dstride, active);
+                     sstride, dst, dpitch, dstride, active, bx, by, sbx, sby);
 }
 
 void launch_pyr_down_ingest(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0, int d0pitch,
-                            size_t d0stride, ImgSel dst, int dpitch, size_t dstride, int S, const int* active) {
+                            size_t d0stride, ImgSel dst, int dpitch, size_t dstride, int S, const int* active, int bx, int by) {
   int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
   hipLaunchKernelGGL(k_pyr_down_ingest, dim3(div_up(dw, PD_TW), div_up(dh, PD_TH), S), dim3(256), 0, st, src, sw, sh, spitch,
-                     sstride, dst0, d0pitch, d0stride, dst, dpitch, dstride, active);
+                     sstride, dst0, d0pitch, d0stride, dst, dpitch, dstride, active, bx, by);
 }
 
 // stage_events (optional): 6 events = (begin, end) for eig_max, eig_nms, gftt_pick.
@@ -1161,11 +1223,11 @@ void launch_pyr_down_ingest(hipStream_t st, ImgSel src, int sw, int sh, int spit
 // false -- k_gftt_pick hands them back zeroed.
 // the corner-response pass on its own: per-stream maximum (maxenc, zeroed by the caller) and the candidate keys (keys / nkeys, zeroed)
 // variant 0: k_eig_cand (LDS tiles), 1: k_eig_cand_strip, 2: k_eig_walk with `rows` rows per chunk
-void launch_pyr_border(hipStream_t st, const PyrSel& pyr, int S, const int* active) {
+void launch_pyr_border(hipStream_t st, const PyrSel& pyr, int S, const int* active, unsigned level_mask) {
   bool any = false;
-  for (int l = 0; l <= pyr.levels; l++) any = any || pyr.bx[l] > 0 || pyr.by[l] > 0;
+  for (int l = 0; l <= pyr.levels; l++) any = any || (((level_mask >> l) & 1u) && (pyr.bx[l] > 0 || pyr.by[l] > 0));
   if (!any) return;
-  hipLaunchKernelGGL(k_pyr_border, dim3(8, pyr.levels + 1, S), dim3(256), 0, st, pyr, active);
+  hipLaunchKernelGGL(k_pyr_border, dim3(8, pyr.levels + 1, S), dim3(256), 0, st, pyr, active, level_mask);
 }
 void launch_corner_response(hipStream_t st, int variant, int rows, ImgSel src, int w, int h, int pitch, size_t sstride, int S, unsigned* maxenc,
                             unsigned long long* keys, int* nkeys, int cap, const int* active) {

@@ -90,13 +90,17 @@ void launch_copy_image(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int
 // any width / source pitch (rows need not be dword aligned); dpitch % 4 == 0
 void launch_copy_image_any(hipStream_t st, ImgSel src, ImgSel dst, int w, int h, int spitch, int dpitch, size_t sstride,
                            size_t dstride, int S, const int* active);
+// (bx, by): physical border of the DESTINATION level, written by the same kernel (every produced pixel also goes to the border
+// positions that mirror it); 0: none.  Needs pyr_border_fusable(dst w, dst h, bx, by), otherwise pass 0 and use launch_pyr_border.
 void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst, int dpitch,
-                     size_t dstride, int S, const int* active);
-// fills the border of every level that has one (one launch; levels without a border are skipped)
-void launch_pyr_border(hipStream_t st, const PyrSel& pyr, int S, const int* active);
+                     size_t dstride, int S, const int* active, int bx = 0, int by = 0, int sbx = 0, int sby = 0);
+// (sbx, sby: physical border of the SOURCE level, complete when the kernel runs: its tiles are then staged without index reflection)
+bool pyr_border_fusable(int w, int h, int bx, int by);
+// fills the border of the levels in level_mask that have one (one launch): for levels whose producer did not write it
+void launch_pyr_border(hipStream_t st, const PyrSel& pyr, int S, const int* active, unsigned level_mask = ~0u);
 // level 1 of a pyramid fused with the ingest copy: reads the caller's image once, writes level 0 (dst0) and level 1 (dst)
 void launch_pyr_down_ingest(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, ImgSel dst0, int d0pitch,
-                            size_t d0stride, ImgSel dst, int dpitch, size_t dstride, int S, const int* active);
+                            size_t d0stride, ImgSel dst, int dpitch, size_t dstride, int S, const int* active, int bx = 0, int by = 0);
 void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, GfttScratch sc,
                  const double* qual_s, double quality, const int* maxc_s, int max_corners, double min_distance,
                  float* out_xy, int* out_n, int out_cap, const int* active, hipEvent_t* stage_events = nullptr,

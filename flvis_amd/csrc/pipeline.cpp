@@ -856,18 +856,29 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     else if (!aligned) launch_copy_image_any(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
     PE(1, ds);
     PB(2, ds);
+    // the borders of the levels: written by the pyrDown kernel that produces the level (every pixel also goes to the border positions
+    // that mirror it); k_pyr_border only for what is left (level 0 when another kernel makes it, levels smaller than the border)
+    unsigned border_left = pl->lbx ? (1u << (pl->levels + 1)) - 1u : 0u;
+    auto fused = [&](int l) { return pl->lbx && pyr_border_fusable(pl->lw[l], pl->lh[l], pl->lbx, pl->lby); };
     for (int l = 1; l <= pl->levels; l++) {  // left pyramid: needed by the temporal tracker right away
       ImgSel s0{{L->pyr0[0][l - 1], L->pyr0[1][l - 1]}, p.img_slot_in, 0, nullptr}, d0{{L->pyr0[0][l], L->pyr0[1][l]}, p.img_slot_in, 0, nullptr};
-      if (l == 1 && !eq && aligned)
-        launch_pyr_down_ingest(ds, in0, w, h, w, (size_t)w * h, l0in, pl->lpitch[0], pl->lstride[0], d0, pl->lpitch[1], pl->lstride[1], S, nullptr);
-      else
-        launch_pyr_down(ds, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, nullptr);
+      if (l == 1 && !eq && aligned) {
+        const bool f = fused(0) && fused(1);
+        launch_pyr_down_ingest(ds, in0, w, h, w, (size_t)w * h, l0in, pl->lpitch[0], pl->lstride[0], d0, pl->lpitch[1], pl->lstride[1], S, nullptr,
+                               f ? pl->lbx : 0, f ? pl->lby : 0);
+        if (f) border_left &= ~3u;
+      } else {
+        const bool f = fused(l), sf = !((border_left >> (l - 1)) & 1u) && pl->lbx;  // (the source level's border is complete)
+        launch_pyr_down(ds, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, nullptr,
+                        f ? pl->lbx : 0, f ? pl->lby : 0, sf ? pl->lbx : 0, sf ? pl->lby : 0);
+        if (f) border_left &= ~(1u << l);
+      }
     }
     if (pl->levels == 0 && !eq && aligned) launch_copy_image(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
-    if (pl->lbx) {
+    if (border_left) {
       PyrSel pb;
       fill_pyr(pl, pb, L->pyr0[0], L->pyr0[1], p.img_slot_in, 0, pl->levels);
-      launch_pyr_border(ds, pb, S, nullptr);
+      launch_pyr_border(ds, pb, S, nullptr, border_left);
     }
     PE(2, ds);
     hipEventRecord(L->ev_img, ds);
@@ -937,20 +948,28 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
       else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
       const bool ingest = !r_in_place && !eq && aligned;  // level 0 = a copy of the caller's image, written by the first pyrDown
+      unsigned border_left = pl->lbx ? (1u << (pl->levels + 1)) - 1u : 0u;
+      auto fused = [&](int l) { return pl->lbx && pyr_border_fusable(pl->lw[l], pl->lh[l], pl->lbx, pl->lby); };
       for (int l = 1; l <= pl->levels; l++) {
-        if (l == 1 && ingest)
+        if (l == 1 && ingest) {
+          const bool f = fused(0) && fused(1);
           launch_pyr_down_ingest(ds, in1, w, h, w, (size_t)w * h, img_plain(L->pyr1[0]), pl->lpitch[0], pl->lstride[0], img_plain(L->pyr1[1]),
-                                 pl->lpitch[1], pl->lstride[1], S, p.act_img);
-        else
+                                 pl->lpitch[1], pl->lstride[1], S, p.act_img, f ? pl->lbx : 0, f ? pl->lby : 0);
+          if (f) border_left &= ~3u;
+        } else {
+          const bool f = fused(l), sf = !((border_left >> (l - 1)) & 1u) && pl->lbx && !(l == 1 && r_in_place);
           launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
-                          l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img);
+                          l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img,
+                          f ? pl->lbx : 0, f ? pl->lby : 0, sf ? pl->lbx : 0, sf ? pl->lby : 0);
+          if (f) border_left &= ~(1u << l);
+        }
       }
       if (pl->levels == 0 && ingest)
         launch_copy_image(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
-      if (pl->lbx) {
+      if (border_left) {
         PyrSel pb;
         fill_pyr(pl, pb, L->pyr1, nullptr, nullptr, 0, pl->levels);
-        launch_pyr_border(ds, pb, S, p.act_img);
+        launch_pyr_border(ds, pb, S, p.act_img, border_left);
       }
     }
     if (!gftt_first) {

@@ -1688,6 +1688,9 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
   PoseLMShared& sh = *reinterpret_cast<PoseLMShared*>(pl_smem);
   long long* ids = reinterpret_cast<long long*>(sh.terms);
   // the tail of the tracking step (k_track_post's work) by one lane of wave 1, while wave 0 gathers the edges
+#ifdef FLVIS_RANSAC_PROF
+  long long tlast_ = (long long)wall_clock64();
+#endif
   __shared__ int s_go;
   // (track_post_dev may end the frame -- track_fail sets phase = PH_IDLE and flips cur: every wave has read phase / cur / n_lm above
   // before one lane is allowed to change them)
@@ -1712,6 +1715,7 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
     if (lane == 0) sh.n = n < PL_EMAX ? n : PL_EMAX;
   }
   __syncthreads();
+  RPROF(48, 0);  // track_post (one lane) beside the edge gathering (wave 0)
   if (!s_go) return;  // the frame failed before the pose optimisation (track_fail has run)
   const int n = sh.n;
   bool ok = n >= 10;
@@ -1734,7 +1738,9 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
     SE3d T0 = load_pose7(st.T_c_w[cur]);
     if (tid == 0) store_pose7(st.dbg_T_pre, T0);
     SE3d T = g2o_from_mat(q_to_mat(T0.q), T0.t);
+    RPROF(48, 1);  // ranks + staging
     pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
+    RPROF(48, 2);  // first optimisation (2 iterations)
     __shared__ int s_alive[PL_T / 64];
     int alive = 0;
     for (int base = 0; base < n; base += PL_T) {
@@ -1751,10 +1757,12 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
       alive += tot;
     }
     __syncthreads();
+    RPROF(48, 3);  // chi2 cull
     if (alive < 10) {
       ok = false;
     } else {
       pose_lm_optimize(T, sh, n, 2, fx, fy, cx, cy);
+      RPROF(48, 4);  // second optimisation
       if (tid == 0) {
         store_pose7(st.T_c_w[cur], se3_from_mat(q_to_mat(T.q), T.t));
         store_pose7(st.dbg_T_lm, load_pose7(st.T_c_w[cur]));
@@ -1762,6 +1770,9 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
     }
   }
   if (!ok && tid == 0) track_fail(st);
+#ifdef FLVIS_RANSAC_PROF
+  if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[48 + 7], 1ull);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ reprojection filter

@@ -66,3 +66,8 @@ if c[24 + 7]:
         n = c[40 + 6]
         print("EPnP (wave 0's hypotheses, %d solves): " % n + "  ".join("%s=%.1fus" % (nm, c[40 + i] / n / 100.0) for i, nm in enumerate(
             ["head", "jacobi12", "pick+constraints", "betas", "centroids+abt", "pose"])))
+
+if c[48 + 7]:
+    n = max(c[48 + 7], 1)
+    print("pose_lm: %d calls: " % c[48 + 7] + "  ".join("%s=%.1fus" % (nm, c[48 + i] / n / 100.0) for i, nm in enumerate(
+        ["track_post|gather", "rank+stage", "optimise 1", "cull", "optimise 2"])))
