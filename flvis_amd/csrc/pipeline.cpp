@@ -78,10 +78,6 @@ struct Lane {
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
-  // a third stream for the two small jobs that only need the frame's filtered landmarks and final pose (the IMU filter's vision
-  // correction, the two-view triangulation): they start right behind the reprojection filter, beside FeatureDEM, instead of queueing
-  // behind the detection stream's image work and then running under the stereo LK
-  hipStream_t aux_stream = nullptr;
   hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_lm = nullptr, ev_tri = nullptr, ev_head = nullptr;
   int idx = 0;  // position in Pipeline::lanes
   // multi-lane trackers: ev_end[n % HOLD_RING] follows the lane's n-th frame (the context's stream waits for the frame whose
@@ -251,10 +247,6 @@ static void lane_destroy(Lane* L) {
   if (L->det_stream) {
     hipStreamSynchronize(L->det_stream);
     hipStreamDestroy(L->det_stream);
-  }
-  if (L->aux_stream) {
-    hipStreamSynchronize(L->aux_stream);
-    hipStreamDestroy(L->aux_stream);
   }
   if (L->own_st && L->st) hipStreamDestroy(L->st);
   for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_head, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
@@ -508,7 +500,6 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
     L->st = ctx->stream;
   }
   bool evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
-  evok = evok && hipStreamCreateWithFlags(&L->aux_stream, hipStreamNonBlocking) == hipSuccess;
   static_assert(Lane::HOLD_RING == 8, "event list below");
   for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
                         &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
@@ -770,7 +761,6 @@ static void sync_streams(flvis_ctx* ctx) {
   for (Lane* L : pl->lanes) {
     hipStreamSynchronize(L->st);
     hipStreamSynchronize(L->det_stream);
-    hipStreamSynchronize(L->aux_stream);
   }
   for (int k = 0; k < Pipeline::NBA; k++)
     if (pl->ba_stream[k]) hipStreamSynchronize(pl->ba_stream[k]);
@@ -1040,14 +1030,10 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(9, st);
   launch_reproj_filter(st, p);
   PE(9, st);
-  // the IMU filter's correction from this frame's pose and the two-view triangulation that k_depth_innovate consumes (landmarks that
-  // survived the filter; the ones k_add_new appends have no baseline yet: k_depth_seeds writes their empty result): on the auxiliary
-  // stream, beside FeatureDEM -- joined before the depth innovation
+  // the IMU filter's correction from this frame's pose: on the detection stream (joined with the triangulation before the depth innovation)
   hipEventRecord(L->ev_lm, st);
-  hipStreamWaitEvent(L->aux_stream, L->ev_lm, 0);
-  launch_vi_correction(L->aux_stream, p);
-  launch_depth_triangulate(L->aux_stream, p);
-  hipEventRecord(L->ev_tri, L->aux_stream);
+  hipStreamWaitEvent(ds, L->ev_lm, 0);
+  launch_vi_correction(ds, p);
   // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners; the right pyramid is joined before the stereo LK
   hipStreamWaitEvent(st, gftt_first ? L->ev_gftt : L->ev_det, 0);
   PB(13, st);
@@ -1059,6 +1045,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(14, st);
   launch_depth_seeds(st, p);
   PE(14, st);
+  // the two-view triangulation that k_depth_innovate consumes: on the detection stream (idle by now), under the stereo LK
+  hipEventRecord(L->ev_lm, st);
+  hipStreamWaitEvent(ds, L->ev_lm, 0);
+  launch_depth_triangulate(ds, p);
+  hipEventRecord(L->ev_tri, ds);
   if (gftt_first) hipStreamWaitEvent(st, L->ev_det, 0);
   PB(15, st);
   if (!depth_cam) {

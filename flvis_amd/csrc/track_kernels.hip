@@ -1923,11 +1923,6 @@ __global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
     p.lk_tag[s] = st.frame_id[cur];  // the stereo matcher's templates come from this frame's left image
   }
   if (i >= n) return;
-  if (i >= (p.det_mode[s] == 2 ? st.orig_size : 0)) {  // added in this frame: no baseline for recover3DPts_c_FromTriangulation (norm < 0.2)
-    double* tri = p.tri + ((size_t)s * NMAX + i) * 3;
-    tri[0] = tri[1] = tri[2] = 0;
-    p.tri_mask[(size_t)s * NMAX + i] = 0;
-  }
   if (p.cam.cam_type == CAM_DEPTH) return;  // the measurement comes from the depth image, no stereo matching
   Landmark& lm = lm_ptr(p, cur, s)[i];
   lm.tslot = i < p.tc_cap ? (short)i : (short)-1;  // where the stereo LK stores point i's templates (read back by the next frame's temporal LK)
@@ -1949,11 +1944,9 @@ __global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
 __global__ __launch_bounds__(256) void k_depth_triangulate(Pipe p) {
   const int s = blockIdx.y;
   const StreamState& st = p.st[s];
-  if (p.det_mode[s] != 2) return;  // (an initialisation frame's landmarks are all new: k_depth_seeds writes their empty results)
+  if (p.det_mode[s] == 0) return;
   const int cur = st.cur;
-  // the landmarks that survived the reprojection filter (orig_size; k_add_new, which may run beside this kernel, appends behind them and
-  // changes n_lm): a landmark added in this frame has first_pose = this frame's pose, i.e. no baseline and no result
-  const int n = st.orig_size;
+  const int n = st.n_lm[cur];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const Landmark& lm = lm_ptr(p, cur, s)[i];
