@@ -39,6 +39,14 @@ namespace flvis {
 #define FLVIS_BA_IT2 8
 #endif
 constexpr int BA_T = 512;
+// (build-variant knob: waves per SIMD the kernel's register allocation aims at -- the backend hands the budget on to the out-of-line
+// phases.  By default (2: the workgroup's own two waves per SIMD) a local-map workgroup may take the whole register file of its CU, so
+// that no wave of another kernel fits beside it)
+#ifdef FLVIS_BA_WAVES
+#define BA_ATTR __attribute__((amdgpu_waves_per_eu(FLVIS_BA_WAVES, FLVIS_BA_WAVES)))
+#else
+#define BA_ATTR
+#endif
 constexpr int BA_NW = BA_T / 64;
 constexpr int BA_PMAX = BA_WMAX - 1;   // free poses
 constexpr int BA_NRMAX = 6 * BA_PMAX;  // 90
@@ -1645,7 +1653,7 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
 // stream's window owned by a workgroup of an earlier launch leaves at once -- the owner re-checks the queue before and
 // after releasing the window, so a keyframe is picked up at the latest by the launch that follows it.  The tracker
 // therefore never waits for the optimiser unless the queue (KFQ keyframes) is full.
-__global__ __launch_bounds__(BA_T) void k_ba_worker(Pipe p) {
+__global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p) {
   const int s = blockIdx.x;
   const int t = threadIdx.x;
   __shared__ int s_go;
