@@ -922,12 +922,12 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
               z[1] = (double)(float)(((double)s2d[2 * k + 1] - cy) / fy) * fy + cy;
             };
 #ifdef FLVIS_RANSAC_PROF
-            // phase times of wave 0's solve into prof[8 ..] (= counters[40 ..])
+            // phase times of wave 0's solve into prof[24 ..] (= counters[56 ..]; 40 .. 46 are the 7-point solver's)
             long long et_ = (long long)wall_clock64();
             auto emark = [&](int i) {
               if (PROF && tid == 0 && prof) {
                 const long long now_ = (long long)wall_clock64();
-                atomicAdd((unsigned long long*)&prof[8 + i], (unsigned long long)(now_ - et_));
+                atomicAdd((unsigned long long*)&prof[24 + i], (unsigned long long)(now_ - et_));
                 et_ = now_;
               }
             };
@@ -950,7 +950,7 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
             epnp::phase_pose(ew_, 5, pw, uv, ecam, nullptr, lane, 64, wsync);
             emark(5);
             const epnp::Pose P = epnp::result(ew_);
-            if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[8 + 6], 1ull);
+            if (PROF && tid == 0 && prof) atomicAdd((unsigned long long*)&prof[24 + 6], 1ull);
 #else
             const epnp::Pose P = epnp::solve<64>(sh.ew[wv], 5, pw, uv, ecam, nullptr, lane, wsync);  // (a sample is one chunk: no scratch)
 #endif

@@ -62,9 +62,9 @@ if c[24 + 7] or c[32 + 7]:
 if c[24 + 7]:
     n = max(c[24 + 7], 1)
     print("seven_point (thread 0): " + "  ".join("%s=%.1fus" % (nm, c[40 + i] / n / 100.0) for i, nm in enumerate(["subset+normalise", "eliminate", "nullspace+cubic coeffs", "cubic roots", "denormalise"])))
-    if c[40 + 6]:
-        n = c[40 + 6]
-        print("EPnP (wave 0's hypotheses, %d solves): " % n + "  ".join("%s=%.1fus" % (nm, c[40 + i] / n / 100.0) for i, nm in enumerate(
+    if c[56 + 6]:
+        n = c[56 + 6]
+        print("EPnP (wave 0's hypotheses, %d solves): " % n + "  ".join("%s=%.1fus" % (nm, c[56 + i] / n / 100.0) for i, nm in enumerate(
             ["head", "jacobi12", "pick+constraints", "betas", "centroids+abt", "pose"])))
 
 if c[48 + 7]:
