@@ -925,7 +925,47 @@ constexpr int DEM_T = 256;
 // candidates grouped by region and sorted by score inside a region (stable) -> per stream the sorted coordinates (region-major) and the
 // region offsets.  In the tracker it runs on the detection stream right after k_gftt_pick.  k_feature_dem is what stays on the frame's
 // critical path: the existing landmarks fill their regions, the greedy spacing walk, the output.
-__global__ __launch_bounds__(DEM_T) void k_feature_dem_prep(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
+constexpr int DEMP_T = 1024;  // k_feature_dem_prep: 16 waves, one per region where a region is sorted once more (ties)
+// Accessor of dem_sort.hpp for an array of up to 64 NREG elements that lives in NREG (1 or 2) vector registers ACROSS the lanes of the
+// wave (element e in lane e & 63 of register e >> 6): every index is wave-uniform, so get / set are v_readlane / v_writelane and the sequential
+// algorithm runs on the scalar unit.  An element is (class << 16) | position, class = number of candidates of the region with a
+// strictly greater score: a greater score <=> a smaller class, equal scores <=> equal classes (sortbysecdesc through integers).
+template <int NREG>
+struct LaneArray {
+  typedef int value_type;
+  int& r0;
+  int& r1;  // (NREG == 1: unused)
+  // v_writelane_b32 with the value in an SGPR and the lane in M0 (a VOP3 reads one SGPR on gfx9); M0 is saved and restored
+  static __device__ __forceinline__ int writelane(int old, int val, int lane) {
+    int tmp;
+    val = __builtin_amdgcn_readfirstlane(val);    // (wave-uniform by construction; the constraint "s" needs the compiler to know it)
+    lane = __builtin_amdgcn_readfirstlane(lane);
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(old), "=&s"(tmp)
+                 : "s"(val), "s"(lane));
+    return old;
+  }
+  __device__ __forceinline__ int get(int i) const {
+    i = __builtin_amdgcn_readfirstlane(i);
+    const int a = __builtin_amdgcn_readlane(r0, i & 63);
+    if (NREG == 1) return a;
+    const int b = __builtin_amdgcn_readlane(r1, i & 63);
+    return i < 64 ? a : b;
+  }
+  __device__ __forceinline__ void set(int i, int x) const {
+    i = __builtin_amdgcn_readfirstlane(i);
+    if (NREG == 1) {
+      r0 = writelane(r0, x, i);
+    } else {  // (both registers are written, one result is kept: no pointer selects, the array stays in registers)
+      const int n0 = writelane(r0, x, i & 63), n1 = writelane(r1, x, i & 63);
+      r0 = i < 64 ? n0 : r0;
+      r1 = i < 64 ? r1 : n1;
+    }
+  }
+  __device__ __forceinline__ bool before(int a, int b) const { return (a >> 16) < (b >> 16); }
+};
+
+__global__ __launch_bounds__(DEMP_T) void k_feature_dem_prep(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
                                                             const float* __restrict__ corners, const int* __restrict__ ncorners,
                                                             int corner_cap, const int* __restrict__ active, float* __restrict__ sorted_xy,
                                                             int* __restrict__ region_off) {
@@ -949,7 +989,7 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem_prep(ImgSel src, int w, i
   if (tid < 16) rcount[tid] = 0;
   __syncthreads();
   // candidates: region + score
-  for (int i = tid; i < nc; i += DEM_T) {
+  for (int i = tid; i < nc; i += DEMP_T) {
     float px = C[2 * i], py = C[2 * i + 1];
     int r = -1;
     float sc = 0.f;
@@ -974,7 +1014,7 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem_prep(ImgSel src, int w, i
   }
   __syncthreads();
   // bucket the candidates by region keeping index order: wave q handles regions q, q+4, ...: ballots over the candidates
-  for (int r = wv; r < 16; r += DEM_T / 64) {
+  for (int r = wv; r < 16; r += DEMP_T / 64) {
     int o = roff[r];
     for (int base = 0; base < nc; base += 64) {
       const int i = base + lane;
@@ -992,31 +1032,60 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem_prep(ImgSel src, int w, i
   // scores then is the one the reference's binary produces, which decides whom the greedy spacing walk meets first.
   float* const SX = sorted_xy + (size_t)s * corner_cap * 2;
   __shared__ int rtie[16];
+  __shared__ int sstack[16][3 * demsort::STACK];
+  int* const ccls = reinterpret_cast<int*>(cx + 3 * cmax) + cmax;  // (behind creg / bucket: class of every bucket position; 4 more bytes per corner)
   if (tid < 16) rtie[tid] = 0;
   __syncthreads();
-  for (int j = tid; j < roff[16]; j += DEM_T) {
+  for (int j = tid; j < roff[16]; j += DEMP_T) {
     const int i = bucket[j];
     const int r = creg[i];
     const float sc = cscore[i];
-    int pos = 0;
+    int greater = 0, earlier = 0;
     bool tie = false;
     for (int q = roff[r]; q < roff[r + 1]; q++) {
       const float sj = cscore[bucket[q]];
-      pos += (sj > sc) || (sj == sc && q < j);
+      greater += sj > sc;
+      earlier += sj == sc && q < j;
       tie = tie || (sj == sc && q != j);
     }
     if (tie) rtie[r] = 1;
+    ccls[j] = greater;
+    const int pos = greater + earlier;
     SX[2 * (roff[r] + pos)] = cx[i];
     SX[2 * (roff[r] + pos) + 1] = cy[i];
   }
   __syncthreads();
-  if (tid < 16 && rtie[tid]) demsort::sort_desc(bucket + roff[tid], roff[tid + 1] - roff[tid], cscore);
-  __syncthreads();
-  for (int j = tid; j < roff[16]; j += DEM_T) {
-    const int i = bucket[j];
-    if (rtie[creg[i]]) {
-      SX[2 * j] = cx[i];
-      SX[2 * j + 1] = cy[i];
+  // one wave per region with a tie: libstdc++'s introsort on the region's candidates in their input order.  Up to 128 candidates the
+  // array is held in one or two registers across the lanes (LaneArray: scalar-unit speed); larger regions (a detect call's 2 x gftt_num
+  // corners crowding one region) are sorted by lane 0 on the index array in LDS
+  if (wv < 16 && rtie[wv]) {
+    const int r0 = roff[wv], n = roff[wv + 1] - r0;
+    if (n <= 128) {
+      int a0 = lane < n ? ((ccls[r0 + lane] << 16) | lane) : 0;
+      int a1 = 64 + lane < n ? ((ccls[r0 + 64 + lane] << 16) | (64 + lane)) : 0;
+      if (n <= 64)
+        demsort::sort_with(LaneArray<1>{a0, a1}, n, sstack[wv]);
+      else
+        demsort::sort_with(LaneArray<2>{a0, a1}, n, sstack[wv]);
+      // element e of the sorted array = the input position of the candidate that comes e-th
+      const int i0 = lane < n ? bucket[r0 + (a0 & 0xffff)] : 0, i1 = 64 + lane < n ? bucket[r0 + (a1 & 0xffff)] : 0;
+      if (lane < n) {
+        SX[2 * (r0 + lane)] = cx[i0];
+        SX[2 * (r0 + lane) + 1] = cy[i0];
+      }
+      if (64 + lane < n) {
+        SX[2 * (r0 + 64 + lane)] = cx[i1];
+        SX[2 * (r0 + 64 + lane) + 1] = cy[i1];
+      }
+    } else {
+      if (lane == 0) demsort::sort_with(demsort::IndexArray<short>{bucket + r0, cscore}, n, sstack[wv]);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int e = lane; e < n; e += 64) {
+        const int i = bucket[r0 + e];
+        SX[2 * (r0 + e)] = cx[i];
+        SX[2 * (r0 + e) + 1] = cy[i];
+      }
     }
   }
   if (tid < 17) region_off[(size_t)s * 17 + tid] = roff[tid];
@@ -1272,7 +1341,7 @@ void launch_feature_dem_prep(hipStream_t st, ImgSel src, int w, int h, int pitch
                              const float* corners, const int* ncorners, int corner_cap, const int* active, float* sorted_xy,
                              int* region_off) {
   const int cmax = ((corner_cap < DEM_MAXC ? corner_cap : DEM_MAXC) + 1) & ~1;
-  hipLaunchKernelGGL(k_feature_dem_prep, dim3(S), dim3(DEM_T), (size_t)cmax * 16, st, src, w, h, pitch, sstride, prm, corners, ncorners,
+  hipLaunchKernelGGL(k_feature_dem_prep, dim3(S), dim3(DEMP_T), (size_t)cmax * 20, st, src, w, h, pitch, sstride, prm, corners, ncorners,
                      corner_cap, active, sorted_xy, region_off);
 }
 void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, const float* sorted_xy, const int* region_off,
@@ -1285,7 +1354,7 @@ void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, cons
 
 hipError_t img_kernels_init() {
   // the selection bitmap may exceed the default 64 KB dynamic LDS window only for images > 512K pixels
-  hipError_t e = hipFuncSetAttribute((const void*)k_feature_dem_prep, hipFuncAttributeMaxDynamicSharedMemorySize, DEM_MAXC * 16);
+  hipError_t e = hipFuncSetAttribute((const void*)k_feature_dem_prep, hipFuncAttributeMaxDynamicSharedMemorySize, DEM_MAXC * 20);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute((const void*)k_gftt_pick, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }
