@@ -315,10 +315,10 @@ FD uint32_t mod_c(uint32_t x, ModC m) {
 // repeats an earlier slot; the complete subset is redrawn (one more attempt) while `check` refuses it.  Control flow and draws are
 // wave-uniform: a whole wave may run it redundantly and let `check` spread its work over the lanes.
 template <int MAXM, class Check>
-FD bool cv_get_subset(CvRng& rng, ModC mc, int m, int maxAttempts, int* idx, Check check) {
+FD bool cv_get_subset(CvRng& rng, ModC mc, int m, int maxAttempts, int* idx, Check check, int iters0 = 0) {
 #pragma unroll
   for (int j = 0; j < MAXM; j++) idx[j] = -1;
-  int iters = 0, i = 0;
+  int iters = iters0, i = 0;  // (iters0: attempts of this slot already made by the caller -- a tabulated candidate that `check` refused)
   for (; iters < maxAttempts; iters++) {
     for (i = 0; i < m;) {
       int idx_i;

@@ -930,6 +930,17 @@ constexpr int DEMP_T = 1024;  // k_feature_dem_prep: 16 waves, one per region wh
 // wave (element e in lane e & 63 of register e >> 6): every index is wave-uniform, so get / set are v_readlane / v_writelane and the sequential
 // algorithm runs on the scalar unit.  An element is (class << 16) | position, class = number of candidates of the region with a
 // strictly greater score: a greater score <=> a smaller class, equal scores <=> equal classes (sortbysecdesc through integers).
+#ifndef FLVIS_DEM_SORT_LANES
+#define FLVIS_DEM_SORT_LANES 0
+#endif
+// ... and for the same packed elements as a plain array (LDS)
+struct PackedArray {
+  typedef int value_type;
+  int* v;
+  __device__ __forceinline__ int get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, int x) const { v[i] = x; }
+  __device__ __forceinline__ bool before(int a, int b) const { return (a >> 16) < (b >> 16); }
+};
 template <int NREG>
 struct LaneArray {
   typedef int value_type;
@@ -1049,43 +1060,40 @@ __global__ __launch_bounds__(DEMP_T) void k_feature_dem_prep(ImgSel src, int w, 
       tie = tie || (sj == sc && q != j);
     }
     if (tie) rtie[r] = 1;
-    ccls[j] = greater;
+    ccls[j] = (greater << 16) | (j - roff[r]);  // (class, input position in the region): the element the region's sort moves around
     const int pos = greater + earlier;
     SX[2 * (roff[r] + pos)] = cx[i];
     SX[2 * (roff[r] + pos) + 1] = cy[i];
   }
   __syncthreads();
-  // one wave per region with a tie: libstdc++'s introsort on the region's candidates in their input order.  Up to 128 candidates the
-  // array is held in one or two registers across the lanes (LaneArray: scalar-unit speed); larger regions (a detect call's 2 x gftt_num
-  // corners crowding one region) are sorted by lane 0 on the index array in LDS
-  if (wv < 16 && rtie[wv]) {
+  // one wave per region with a tie: libstdc++'s introsort on the region's candidates in their input order, as packed (class, position)
+  // integers.  Up to 16 candidates std::sort IS an insertion sort, i.e. stable: the ranks above are its result already.  Two forms of
+  // the array (FLVIS_DEM_SORT_LANES, build-variant knob): in LDS, sorted by lane 0 of the region's wave (the default: ~100 cycles per
+  // element access, sixteen regions side by side on sixteen waves), or in one or two registers across the lanes (LaneArray).
+  if (wv < 16 && rtie[wv] && roff[wv + 1] - roff[wv] > demsort::THRESHOLD) {
     const int r0 = roff[wv], n = roff[wv + 1] - r0;
+#if FLVIS_DEM_SORT_LANES
     if (n <= 128) {
-      int a0 = lane < n ? ((ccls[r0 + lane] << 16) | lane) : 0;
-      int a1 = 64 + lane < n ? ((ccls[r0 + 64 + lane] << 16) | (64 + lane)) : 0;
+      int a0 = lane < n ? ccls[r0 + lane] : 0;
+      int a1 = 64 + lane < n ? ccls[r0 + 64 + lane] : 0;
       if (n <= 64)
         demsort::sort_with(LaneArray<1>{a0, a1}, n, sstack[wv]);
       else
         demsort::sort_with(LaneArray<2>{a0, a1}, n, sstack[wv]);
-      // element e of the sorted array = the input position of the candidate that comes e-th
-      const int i0 = lane < n ? bucket[r0 + (a0 & 0xffff)] : 0, i1 = 64 + lane < n ? bucket[r0 + (a1 & 0xffff)] : 0;
-      if (lane < n) {
-        SX[2 * (r0 + lane)] = cx[i0];
-        SX[2 * (r0 + lane) + 1] = cy[i0];
-      }
-      if (64 + lane < n) {
-        SX[2 * (r0 + 64 + lane)] = cx[i1];
-        SX[2 * (r0 + 64 + lane) + 1] = cy[i1];
-      }
-    } else {
-      if (lane == 0) demsort::sort_with(demsort::IndexArray<short>{bucket + r0, cscore}, n, sstack[wv]);
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int e = lane; e < n; e += 64) {
-        const int i = bucket[r0 + e];
-        SX[2 * (r0 + e)] = cx[i];
-        SX[2 * (r0 + e) + 1] = cy[i];
-      }
+      if (lane < n) ccls[r0 + lane] = a0;
+      if (64 + lane < n) ccls[r0 + 64 + lane] = a1;
+    } else
+#endif
+    {
+      if (lane == 0) demsort::sort_with(PackedArray{ccls + r0}, n, sstack[wv]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // element e of the sorted array names the input position of the candidate that comes e-th
+    for (int e = lane; e < n; e += 64) {
+      const int i = bucket[r0 + (ccls[r0 + e] & 0xffff)];
+      SX[2 * (r0 + e)] = cx[i];
+      SX[2 * (r0 + e) + 1] = cy[i];
     }
   }
   if (tid < 17) region_off[(size_t)s * 17 + tid] = roff[tid];

@@ -425,6 +425,16 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
 // spread over 30 lanes); wave 0 then solves the 7-point systems (one per lane, up to 3 models each -> LDS), ALL waves score the
 // models (a wave takes a model, its lanes stride the correspondences, ballot-popcount counts the inliers) and the adaptive stop is
 // replayed sequentially over the batch.  Only the mask is used (lkorb_tracking.cpp:133-158).
+// The subsets FMEstimatorCallback's RANSAC draws depend on the correspondences only through checkSubset (a collinear last point, rare):
+// every run starts from cv::RNG((uint64)-1), so the CANDIDATES of the first batch -- 16 subsets of 7, each drawn as if every earlier
+// one had been accepted -- are a function of the point count alone.  They are tabulated at start-up (host, the same generator and
+// getSubset loop) with the generator state behind each; the kernel tests the 16 candidates and only falls back to the serial draw
+// loop (wave 0 drawing, fifteen waves waiting: 40 us of a 70 us kernel) from the first refused candidate on.
+constexpr int F_TAB_N = 1025;  // counts 0 .. 1024 (NMAX)
+constexpr int F_TAB_B = 16;
+__device__ unsigned short g_f_sub7[F_TAB_N][F_TAB_B][7];
+__device__ unsigned long long g_f_rng7[F_TAB_N][F_TAB_B];
+
 #ifdef FLVIS_RANSAC_PROF
 #define RPROF(base, i)                                                                                   \
   do {                                                                                                   \
@@ -478,12 +488,8 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
   // FMEstimatorCallback::checkSubset = !haveCollinearPoints(m1) && !haveCollinearPoints(m2) (fundam.cpp): the LAST point of the subset
   // against the 15 pairs of earlier ones, on the Point2f coordinates; lanes 0 .. 29 take one (pair, image) each
   int* s_chk = s_sub[0];
-  auto fm_check = [&](const int* idx) -> bool {
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-#pragma unroll
-      for (int j = 0; j < 7; j++) s_chk[j] = idx[j];
-    }
+  // (the subset to be tested is in s_chk)
+  auto fm_check_staged = [&]() -> bool {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bool bad = false;
@@ -502,15 +508,42 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
     }
     return __ballot(bad) == 0ull;
   };
+  auto fm_check = [&](const int* idx) -> bool {
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) s_chk[j] = idx[j];
+    }
+    return fm_check_staged();
+  };
   // draws the subsets of hypotheses [base, base + B) that lie below the current iteration limit into s_sub (wave 0, uniform);
   // a failed draw (10000 refused subsets) marks the hypothesis and ends the batch -- the reference loop stops there
-  auto draw_batch = [&](int base, int B, int limit, int max_attempts) {
+  auto draw_batch = [&](int base, int B, int limit, int max_attempts, bool tabulated) {
     s_sub[lane][7] = 0;
     __builtin_amdgcn_wave_barrier();
-    for (int k = 0; k < B && base + k < limit; k++) {
+    int k = 0, first_attempts = 0;
+    if (tabulated) {
+      // the tabulated candidates of the first batch: all of them are tested; up to the first refused one they ARE the run's subsets
+      if (lane < B) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) s_sub[lane][j] = g_f_sub7[n][lane][j];
+      }
+      for (k = 0; k < B && base + k < limit; k++) {
+        s_chk = s_sub[k];
+        if (!fm_check_staged()) break;
+        if (lane == 0) s_sub[k][7] = 1;
+      }
+      if (k > 0) rng.state = g_f_rng7[n][k - 1];
+      if (k < B && base + k < limit) {  // slot k: its candidate was attempt 0, refused; the generator is behind it
+        rng.state = g_f_rng7[n][k];
+        first_attempts = 1;
+      }
+    }
+    for (; k < B && base + k < limit; k++) {
       int idx[7];
       s_chk = s_sub[k];
-      const bool ok = cv_get_subset<7>(rng, mc, 7, max_attempts, idx, fm_check);
+      const bool ok = cv_get_subset<7>(rng, mc, 7, max_attempts, idx, fm_check, first_attempts);
+      first_attempts = 0;
       if (lane == 0) s_sub[k][7] = ok ? 1 : 0;
       if (!ok) break;
     }
@@ -539,7 +572,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
       int nm = -1;
       double* const xw = spw + lane;
       if (wv == 0) {
-        draw_batch(base, 64, niters, 1000);
+        draw_batch(base, 64, niters, 1000, false);
         const int iter = base + lane;
         if (iter < niters) {
           if (s_sub[lane][7]) {
@@ -643,7 +676,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
       int nm = -1;                  // -1: beyond niters, -2: subset impossible (the reference loop stops)
       double* const xw = spw + lane;  // element e of this lane at xw[e * 64]
       if (wv == 0) {
-        draw_batch(base, B, ctl[0], 10000);
+        draw_batch(base, B, ctl[0], 10000, base == 0 && B == F_TAB_B && n < F_TAB_N);
         const int iter = base + lane;
         if (lane < B && iter < ctl[0]) {
 #ifdef FLVIS_RANSAC_PROF
@@ -1544,6 +1577,7 @@ __global__ void k_track_post(Pipe p) {
 constexpr int PL_T = 256;    // 4 waves compute the per-edge terms; wave 0 owns the 28 sequential sums
 constexpr int PL_ROW = 29;   // 28 sums per edge, padded: thread t writes row t (stride 29 doubles: 2-way bank conflicts at most)
 constexpr int PL_NS = 28;    // 21 (upper H) + 6 (b) + 1 (robust chi2)
+constexpr int PL_CH = 32;    // edges per chunk of a sum: 32 consecutive active edges are summed in order, then the chunk sums in order
 constexpr int PL_EMAX = 512; // edges of one pose LM (16 regions x 30 landmarks is the largest configured frame: 480)
 struct PoseLMShared {
   double pw[3][PL_EMAX];     // edges in id order
@@ -1552,6 +1586,7 @@ struct PoseLMShared {
   short src[PL_EMAX];        // landmark index of the k-th gathered edge (frame order)
   double terms[PL_T * PL_ROW]; // one chunk of per-edge terms; holds the ids (long long[PL_EMAX]) while the edges are ranked
   double tot[PL_NS];
+  double part[PL_T / PL_CH][PL_NS];  // chunk sums of the current round
   int n;
 };
 static_assert(sizeof(double) * PL_T * PL_ROW >= sizeof(long long) * PL_EMAX, "the id scratch must fit the terms buffer");
@@ -1586,20 +1621,31 @@ __device__ inline void pose_pass(const SE3d& T, PoseLMShared& sh, int n, bool wa
       for (int k = 0; k < PL_NS; k++) row[k] = 0.0;  // adding +0.0 is exact: the same as skipping the edge
     }
     __syncthreads();
-    if (tid < PL_NS && (want_H || tid == 27)) {
-      const double* col = sh.terms + tid;
-      const int m = (n - c0 < PL_T) ? n - c0 : PL_T;
-      int k = 0;
-      for (; k + 8 <= m; k += 8) {
-        double v[8];
+    // every sum = the sum, in edge order, of the sums of chunks of PL_CH consecutive active edges, each chunk summed in edge order (the
+    // oracle's definition: a dependent chain of 32 + 8 additions per round instead of 256; one thread per (chunk, term))
+    const int m = (n - c0 < PL_T) ? n - c0 : PL_T;
+    const int nch = (m + PL_CH - 1) / PL_CH;
+    {
+      const int c = tid / PL_NS, col = tid - c * PL_NS;
+      if (c < nch && (want_H || col == 27)) {
+        const double* colp = sh.terms + col;
+        const int k0 = c * PL_CH, k1 = k0 + PL_CH < m ? k0 + PL_CH : m;
+        double ps = 0;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+          double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = col[(k + u) * PL_ROW];
+          for (int u = 0; u < 8; u++) v[u] = colp[(k + u) * PL_ROW];
 #pragma unroll
-        for (int u = 0; u < 8; u++) sum += v[u];
+          for (int u = 0; u < 8; u++) ps += v[u];
+        }
+        for (; k < k1; k++) ps += colp[k * PL_ROW];
+        sh.part[c][col] = ps;
       }
-      for (; k < m; k++) sum += col[k * PL_ROW];
     }
     __syncthreads();
+    if (tid < PL_NS && (want_H || tid == 27))
+      for (int c = 0; c < nch; c++) sum += sh.part[c][tid];
   }
   if (tid < PL_NS) sh.tot[tid] = sum;
   __syncthreads();
@@ -2289,6 +2335,29 @@ static hipError_t pnp_tables_init() {
   for (int n = 0; n < PNP_TAB_N; n++) {
     if (n > 5) fill(n, 5, PNP_TAB_B5, &s5[(size_t)n * PNP_TAB_B5 * 5], r5[n]);
     if (n > 4) fill(n, 4, PNP_TAB_B4, &s4[(size_t)n * PNP_TAB_B4 * 4], r4[n]);
+  }
+  {  // the F-matrix RANSAC's candidates (see g_f_sub7): 16 subsets of 7 per count, no checkSubset, the state behind each
+    std::vector<unsigned short> s7((size_t)F_TAB_N * F_TAB_B * 7, 0);
+    std::vector<unsigned long long> r7((size_t)F_TAB_N * F_TAB_B, 0);
+    for (int n = 8; n < F_TAB_N; n++) {
+      uint64_t st = 0xffffffffffffffffull;
+      for (int k = 0; k < F_TAB_B; k++) {
+        int idx[7] = {-1, -1, -1, -1, -1, -1, -1};
+        for (int i = 0; i < 7;) {
+          st = (uint64_t)(uint32_t)st * 4164903690u + (uint32_t)(st >> 32);
+          const int v = (int)((uint32_t)st % (uint32_t)n);
+          bool dup = false;
+          for (int j = 0; j < i; j++) dup = dup || idx[j] == v;
+          if (dup) continue;
+          idx[i++] = v;
+        }
+        for (int j = 0; j < 7; j++) s7[((size_t)n * F_TAB_B + k) * 7 + j] = (unsigned short)idx[j];
+        r7[(size_t)n * F_TAB_B + k] = st;
+      }
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_f_sub7), s7.data(), s7.size() * sizeof(unsigned short));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_f_rng7), r7.data(), r7.size() * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
   }
   e = hipMemcpyToSymbol(HIP_SYMBOL(g_pnp_sub5), s5.data(), s5.size() * sizeof(unsigned short));
   if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_pnp_sub4), s4.data(), s4.size() * sizeof(unsigned short));

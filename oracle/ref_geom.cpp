@@ -789,18 +789,30 @@ struct PoseEdge {
   bool alive;
 };
 
+// Sums over the active edges (chi2, H, b): g2o adds edge after edge; here -- an fp64 rounding-order choice, stated as a deviation in
+// DESIGN.md -- 32 consecutive edges of the active-edge list (positions 32 c .. 32 c + 31, dead edges counted) are summed in order, then
+// the chunk sums in order: the same minimum to rounding, and a dependent chain an order of magnitude shorter on the device, which
+// follows this very definition (k_pose_lm, PL_CH).
+constexpr int POSE_CHUNK = 32;
+
 static double robust_chi2(const SE3& T, const std::vector<PoseEdge>& E, double fx, double fy, double cx, double cy) {
-  double chi = 0;
-  for (auto& e : E) {
+  double chi = 0, part = 0;
+  for (size_t k = 0; k < E.size(); k++) {
+    if (k > 0 && k % POSE_CHUNK == 0) {
+      chi += part;
+      part = 0;
+    }
+    const PoseEdge& e = E[k];
     if (!e.alive) continue;
     double er[2];
     proj_edge(T, e.pw, e.z, fx, fy, cx, cy, er, nullptr);
     double c2 = er[0] * er[0] + er[1] * er[1];
     if (c2 <= 1.0)
-      chi += c2;
+      part += c2;
     else
-      chi += 2 * std::sqrt(c2) * 1.0 - 1.0;
+      part += 2 * std::sqrt(c2) * 1.0 - 1.0;
   }
+  if (!E.empty()) chi += part;
   return chi;
 }
 
@@ -809,8 +821,13 @@ static void g2o_pose_optimize(SE3& T, const std::vector<PoseEdge>& E, int iterat
   double lambda = -1, ni = 2;
   for (int iteration = 0; iteration < iterations; iteration++) {
     double currentChi = robust_chi2(T, E, fx, fy, cx, cy);
-    double H[36] = {0}, b[6] = {0};
-    for (auto& e : E) {
+    double H[36] = {0}, b[6] = {0}, Hp[36] = {0}, bp[6] = {0};  // totals and the running chunk (see POSE_CHUNK)
+    for (size_t k = 0; k < E.size(); k++) {
+      if (k > 0 && k % POSE_CHUNK == 0) {
+        for (int j = 0; j < 36; j++) H[j] += Hp[j], Hp[j] = 0;
+        for (int j = 0; j < 6; j++) b[j] += bp[j], bp[j] = 0;
+      }
+      const PoseEdge& e = E[k];
       if (!e.alive) continue;
       double er[2], J[2][6];
       proj_edge(T, e.pw, e.z, fx, fy, cx, cy, er, J);
@@ -818,9 +835,13 @@ static void g2o_pose_optimize(SE3& T, const std::vector<PoseEdge>& E, int iterat
       double w = (c2 <= 1.0) ? 1.0 : 1.0 / std::sqrt(c2);  // rho'
       double o0 = -er[0] * w, o1 = -er[1] * w;               // omega_r * rho[1]
       for (int r = 0; r < 6; r++) {
-        b[r] += J[0][r] * o0 + J[1][r] * o1;
-        for (int c = 0; c < 6; c++) H[6 * r + c] += (J[0][r] * w) * J[0][c] + (J[1][r] * w) * J[1][c];
+        bp[r] += J[0][r] * o0 + J[1][r] * o1;
+        for (int c = 0; c < 6; c++) Hp[6 * r + c] += (J[0][r] * w) * J[0][c] + (J[1][r] * w) * J[1][c];
       }
+    }
+    if (!E.empty()) {
+      for (int j = 0; j < 36; j++) H[j] += Hp[j];
+      for (int j = 0; j < 6; j++) b[j] += bp[j];
     }
     // the linear solver reads ONE triangle: g2o's LinearSolverEigen factorises SimplicialLDLT<SparseMatrix, Eigen::Upper>
     // (solvers/eigen/linear_solver_eigen.h:44).  With a robust weight w != 1 the two triangles of A^T (w Omega) A differ in
