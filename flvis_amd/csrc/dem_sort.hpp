@@ -190,6 +190,16 @@ FLVIS_DS_HD int floor_log2(int n) {
   return k;
 }
 
+// std::sort's FIRST phase alone (the quicksort levels, heap sort where the budget runs out): what is left is one insertion sort over
+// the whole array, and an insertion sort is STABLE -- so std::sort's result is the stable sort of the array this function leaves.  A
+// caller that can rank in parallel (position = number of elements that sort before + number of equal elements earlier in THIS array)
+// runs only this phase sequentially: n log2(n / 16) element visits instead of the insertion sort's n^2 / 64 on top.
+template <class A>
+FLVIS_DS_HD void quicksort_phase(const A& a, int n, int* stack, int depth = -1) {
+  if (n <= 0) return;
+  introsort_loop(a, 0, n, depth < 0 ? 2 * floor_log2(n) : depth, stack);
+}
+
 // a[0 .. n) sorted by a.before, ties where libstdc++'s std::sort leaves them.  depth < 0: std::sort's own budget.
 template <class A>
 FLVIS_DS_HD void sort_with(const A& a, int n, int* stack, int depth = -1) {

@@ -1067,9 +1067,11 @@ __global__ __launch_bounds__(DEMP_T) void k_feature_dem_prep(ImgSel src, int w, 
   }
   __syncthreads();
   // one wave per region with a tie: libstdc++'s introsort on the region's candidates in their input order, as packed (class, position)
-  // integers.  Up to 16 candidates std::sort IS an insertion sort, i.e. stable: the ranks above are its result already.  Two forms of
-  // the array (FLVIS_DEM_SORT_LANES, build-variant knob): in LDS, sorted by lane 0 of the region's wave (the default: ~100 cycles per
-  // element access, sixteen regions side by side on sixteen waves), or in one or two registers across the lanes (LaneArray).
+  // integers.  Up to 16 candidates std::sort IS an insertion sort, i.e. stable: the ranks above are its result already.  Beyond that
+  // only std::sort's first phase -- the quicksort levels on ranges longer than 16 -- is walked through sequentially (lane 0 of the
+  // region's wave, array in LDS; FLVIS_DEM_SORT_LANES: in registers across the lanes): the insertion sort that follows is stable, so its
+  // result is the STABLE order of what the first phase leaves, and that is a rank every lane computes for its own elements (position =
+  // class + equal classes earlier in the array): n log2(n / 16) sequential element visits instead of n log2 n + n^2 / 64.
   if (wv < 16 && rtie[wv] && roff[wv + 1] - roff[wv] > demsort::THRESHOLD) {
     const int r0 = roff[wv], n = roff[wv + 1] - r0;
 #if FLVIS_DEM_SORT_LANES
@@ -1077,23 +1079,25 @@ __global__ __launch_bounds__(DEMP_T) void k_feature_dem_prep(ImgSel src, int w, 
       int a0 = lane < n ? ccls[r0 + lane] : 0;
       int a1 = 64 + lane < n ? ccls[r0 + 64 + lane] : 0;
       if (n <= 64)
-        demsort::sort_with(LaneArray<1>{a0, a1}, n, sstack[wv]);
+        demsort::quicksort_phase(LaneArray<1>{a0, a1}, n, sstack[wv]);
       else
-        demsort::sort_with(LaneArray<2>{a0, a1}, n, sstack[wv]);
+        demsort::quicksort_phase(LaneArray<2>{a0, a1}, n, sstack[wv]);
       if (lane < n) ccls[r0 + lane] = a0;
       if (64 + lane < n) ccls[r0 + 64 + lane] = a1;
     } else
 #endif
     {
-      if (lane == 0) demsort::sort_with(PackedArray{ccls + r0}, n, sstack[wv]);
+      if (lane == 0) demsort::quicksort_phase(PackedArray{ccls + r0}, n, sstack[wv]);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // element e of the sorted array names the input position of the candidate that comes e-th
     for (int e = lane; e < n; e += 64) {
-      const int i = bucket[r0 + (ccls[r0 + e] & 0xffff)];
-      SX[2 * (r0 + e)] = cx[i];
-      SX[2 * (r0 + e) + 1] = cy[i];
+      const int key = ccls[r0 + e], cls = key >> 16;
+      int earlier = 0;
+      for (int q = 0; q < e; q++) earlier += (ccls[r0 + q] >> 16) == cls;
+      const int i = bucket[r0 + (key & 0xffff)];
+      SX[2 * (r0 + cls + earlier)] = cx[i];
+      SX[2 * (r0 + cls + earlier) + 1] = cy[i];
     }
   }
   if (tid < 17) region_off[(size_t)s * 17 + tid] = roff[tid];

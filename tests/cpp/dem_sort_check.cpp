@@ -46,6 +46,15 @@ int main() {
           same = same && ref[i].first == (int)idx[i];
           ties = ties || (i > 0 && ref[i].second == ref[i - 1].second);
         }
+        // the device's form: the quicksort phase alone, then a STABLE sort of what it leaves (the final insertion sort is stable)
+        {
+          std::vector<short> part(n);
+          for (int i = 0; i < n; i++) part[i] = (short)i;
+          int stack[3 * flvis::demsort::STACK];
+          flvis::demsort::quicksort_phase(flvis::demsort::IndexArray<short>{part.data(), score.data()}, n, stack, depth);
+          std::stable_sort(part.begin(), part.end(), [&](short a, short b) { return score[a] > score[b]; });
+          for (int i = 0; i < n; i++) same = same && ref[i].first == (int)part[i];
+        }
         cases++;
         with_ties += ties;
         bad += !same;
