@@ -917,7 +917,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
   // for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain.  The right image is only
   // read within this frame, so without equalizeHist the caller's buffer IS level 0 of the right pyramid (no copy).
-  const bool r_in_place = !eq && aligned && !pl->lbx;  // (a bordered level 0 is a copy: the first pyrDown writes it in the same pass)
+  // The right image is only read within this frame: without equalizeHist the caller's buffer IS level 0 of the right pyramid (no copy;
+  // that level then has no border, and the few stereo search regions that leave the image at level 0 are staged by the kernel's
+  // index-reflecting path).  FLVIS_RIGHT_COPY=1 (A/B knob): a bordered copy instead, written by the first pyrDown.
+  static const bool right_copy = getenv("FLVIS_RIGHT_COPY") && atoi(getenv("FLVIS_RIGHT_COPY")) != 0;
+  const bool r_in_place = !eq && aligned && !(pl->lbx && right_copy);
   ImgSel r0 = r_in_place ? in1 : img_plain(L->pyr1[0]);
   const int r0pitch = r_in_place ? w : pl->lpitch[0];
   const size_t r0stride = r_in_place ? (size_t)w * h : pl->lstride[0];
@@ -949,6 +953,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
       const bool ingest = !r_in_place && !eq && aligned;  // level 0 = a copy of the caller's image, written by the first pyrDown
       unsigned border_left = pl->lbx ? (1u << (pl->levels + 1)) - 1u : 0u;
+      if (r_in_place) border_left &= ~1u;  // (level 0 is the caller's buffer: no border to fill)
       auto fused = [&](int l) { return pl->lbx && pyr_border_fusable(pl->lw[l], pl->lh[l], pl->lbx, pl->lby); };
       for (int l = 1; l <= pl->levels; l++) {
         if (l == 1 && ingest) {
