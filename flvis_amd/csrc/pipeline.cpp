@@ -987,7 +987,10 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     hipEventRecord(L->ev_det, ds);
   };
   const bool pyramid_late = gftt_first && gftt_after_lk == 3;  // 3: the right pyramid waits for the F-RANSAC too
-  if (!pyramid_late) right_pyramid();
+  // 4 (round 4): like 3 for the corners, but the right pyramid -- a light, memory-bound pass that only the stereo matcher needs -- runs
+  // when the temporal LK has finished, beside the F-RANSAC, instead of behind the corner detection where the stereo LK waited for it
+  const bool pyramid_mid = gftt_first && gftt_after_lk == 4;
+  if (!pyramid_late && !pyramid_mid) right_pyramid();
   // temporal tracking
   PB(4, st);
   {
@@ -1012,6 +1015,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     hipEventRecord(L->ev_lm, st);
     hipStreamWaitEvent(ds, L->ev_lm, 0);
     detect_corners();
+  }
+  if (pyramid_mid) {
+    hipEventRecord(L->ev_lm, st);
+    hipStreamWaitEvent(ds, L->ev_lm, 0);
+    right_pyramid();
   }
   PB(5, st);
   launch_track_collect(st, p);
