@@ -79,8 +79,6 @@ struct Lane {
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
   hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_lm = nullptr, ev_tri = nullptr, ev_head = nullptr;
-  // gates of the host-image uploads (flvis_image_feed_host): the start of the frame's stereo LK, the end of the frame
-  hipEvent_t ev_gate_l = nullptr, ev_gate_r = nullptr;
   int idx = 0;  // position in Pipeline::lanes
   // multi-lane trackers: ev_end[n % HOLD_RING] follows the lane's n-th frame (the context's stream waits for the frame whose
   // input buffers the caller may reuse next, see flvis_set_input_hold); ev_stagger follows the temporal LK of the lane's first
@@ -134,8 +132,7 @@ struct Pipeline {
     uint8_t* raw[2][2] = {};   // [slot][camera]: the images as handed over (tightly packed rows of w * bytes-per-pixel)
     uint8_t* gray[2][2] = {};  // [slot][camera]: cvtColor output for 3/4-channel input
     size_t raw_bytes[2] = {}, gray_bytes = 0;
-    hipEvent_t ev_done[2] = {}, ev_done_r[2] = {}, ev_free[2] = {};
-    hipEvent_t wait_right = nullptr;  // set while flvis_image_feed_host enqueues a frame: the right pyramid waits for the right image's upload
+    hipEvent_t ev_done[2] = {}, ev_free[2] = {};
     long long n = 0;
     volatile long long* h_up = nullptr;  // host-mapped: number of calls whose uploads have finished (stored by the copy stream)
     long long* d_up = nullptr;
@@ -252,7 +249,7 @@ static void lane_destroy(Lane* L) {
     hipStreamDestroy(L->det_stream);
   }
   if (L->own_st && L->st) hipStreamDestroy(L->st);
-  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_head, L->ev_gate_l, L->ev_gate_r, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
+  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_head, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
                        L->ev_end[4], L->ev_end[5], L->ev_end[6], L->ev_end[7]})
     if (e) hipEventDestroy(e);
   for (int k = 0; k < Lane::BAQ; k++)
@@ -283,7 +280,6 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
     hipStreamDestroy(pl->hf.strm);
     for (int k = 0; k < 2; k++) {
       if (pl->hf.ev_done[k]) hipEventDestroy(pl->hf.ev_done[k]);
-      if (pl->hf.ev_done_r[k]) hipEventDestroy(pl->hf.ev_done_r[k]);
       if (pl->hf.ev_free[k]) hipEventDestroy(pl->hf.ev_free[k]);
     }
     if (pl->hf.h_up) hipHostFree((void*)pl->hf.h_up);
@@ -505,7 +501,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   }
   bool evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
   static_assert(Lane::HOLD_RING == 8, "event list below");
-  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_gate_l, &L->ev_gate_r, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
+  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
                         &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
     evok = evok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (int k = 0; k < Lane::BAQ && evok; k++)
@@ -952,7 +948,6 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   if (gftt_first && !gftt_after_lk) detect_corners();
   auto right_pyramid = [&] {
     hipStreamWaitEvent(ds, L->ev_head, 0);
-    if (pl->hf.wait_right) hipStreamWaitEvent(ds, pl->hf.wait_right, 0);  // (host images: the right image's upload)
     if (!depth_cam) {
       if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
       else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
@@ -1069,7 +1064,6 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   launch_depth_triangulate(ds, p);
   hipEventRecord(L->ev_tri, ds);
   if (gftt_first) hipStreamWaitEvent(st, L->ev_det, 0);
-  hipEventRecord(L->ev_gate_l, st);  // (gate of the next frame's left-image upload: under the stereo LK)
   PB(15, st);
   if (!depth_cam) {
     PyrSel prev, next;
@@ -1111,7 +1105,6 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   launch_frame_end(st, p);
   PE(17, st);
   PE(19, st);
-  hipEventRecord(L->ev_gate_r, st);  // (gate of the next frame's right-image upload)
   if (with_local_map && (pl->frames_fed % pl->ba_every) == 0) {
     hipStream_t bs = pl->ba_stream[(L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba];
     hipEventRecord(L->ev_fe, st);
@@ -1204,7 +1197,6 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
     bool ok = hipStreamCreateWithFlags(&hf.strm, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++)
       ok = hipEventCreateWithFlags(&hf.ev_done[k], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&hf.ev_done_r[k], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&hf.ev_free[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: cannot create the copy stream");
     void* hp = nullptr;
@@ -1246,17 +1238,12 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   };
   if (hf.n >= 1) wait_uploads(hf.n);
   if (hf.n >= 2) hipStreamWaitEvent(hf.strm, hf.ev_free[slot], 0);  // the frame that used this slot has been consumed
-  // When the uploads run matters (round 4, profiles/r04_h2d_full_timeline.txt): while the SDMA engine writes an image into HBM the
-  // chain's latency-bound kernels -- one workgroup per stream chasing the landmark arrays -- run 2-3 x slower (k_pose_lm 90 -> 170 us,
-  // k_reproj_filter 22 -> 58, k_add_new 8 -> 49 ...), the LK launches do not.  So the left image of frame n + 1 is uploaded under the
-  // stereo LK of frame n (gate: the event in front of that launch) and the right image under frame n + 1's own head / pyramid /
-  // temporal LK (gate: the end of frame n; only the right pyramid, much later, reads it).  A caller that comes late finds the gates
-  // passed and the copies start at once, as before.  Rigs whose second image is read by the chain itself (depth image) or converted
-  // first (colour) keep both uploads in front of the frame.
-  const bool split_right = !depth_cam && ch1 == 1;
+  // (Measured in round 4, profiles/r04_h2d_full_timeline_*.txt: beside an SDMA upload the chain's latency-bound kernels run 2-3 x slower,
+  // the LK launches do not.  Gating the uploads under LK launches -- left image under the previous frame's stereo LK, right image under
+  // the frame's own head / temporal LK -- made the leg slower, 40k -> 31k frames/s: k_frame_head / k_track_prepare are latency-bound too
+  // and the later start of the copies costs host lead.  The uploads start as soon as their staging slot is free.)
   hipError_t e = hipSuccess;
   for (int c = 0; c < 2 && e == hipSuccess; c++) {
-    for (Lane* L : pl->lanes) hipStreamWaitEvent(hf.strm, c == 0 || !split_right ? L->ev_gate_l : L->ev_gate_r, 0);
     const flvis_image* im = c ? h_img1 : h_img0;
     const size_t row = (size_t)w * bpp[c], img_bytes = row * h;
     bool contiguous = true;  // one block [S][h][w*bpp]: a single copy
@@ -1269,9 +1256,8 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
         e = hipMemcpy2DAsync(hf.raw[slot][c] + (size_t)s * img_bytes, row, im[s].data, (size_t)im[s].pitch, row, h,
                              hipMemcpyHostToDevice, hf.strm);
     }
-    if (e == hipSuccess && c == 0 && split_right) e = hipEventRecord(hf.ev_done[slot], hf.strm);  // the frame starts on the left image
   }
-  if (e == hipSuccess) e = hipEventRecord(split_right ? hf.ev_done_r[slot] : hf.ev_done[slot], hf.strm);
+  if (e == hipSuccess) e = hipEventRecord(hf.ev_done[slot], hf.strm);
   if (e != hipSuccess) return ctx->hip_fail(e, "image_feed_host upload");
   launch_store_progress(hf.strm, hf.d_up, hf.n + 1);
   hipStream_t st = ctx->stream;
@@ -1290,9 +1276,7 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   // one frame of lead in this mode: with two, the uploads' copies and events push the queued commands over what the HIP runtime
   // accepts without blocking the caller for milliseconds (measured: 16k vs 28k frames/s when that happened mid-run)
   pl->host_lead_cap = 1;
-  hf.wait_right = split_right ? hf.ev_done_r[slot] : nullptr;
   const int rc = flvis_image_feed(ctx, d0, d1, hf.times.data(), h_out, with_local_map);
-  hf.wait_right = nullptr;
   pl->host_lead_cap = 4;
   hipEventRecord(hf.ev_free[slot], st);
   hf.n++;
