@@ -38,7 +38,10 @@ namespace flvis {
 #define FLVIS_BA_IT1 12
 #define FLVIS_BA_IT2 8
 #endif
-constexpr int BA_T = 512;
+#ifndef FLVIS_BA_T
+#define FLVIS_BA_T 512  // (build-variant knob: threads of a local-map workgroup)
+#endif
+constexpr int BA_T = FLVIS_BA_T;
 // (build-variant knob: waves per SIMD the kernel's register allocation aims at -- the backend hands the budget on to the out-of-line
 // phases.  By default (2: the workgroup's own two waves per SIMD) a local-map workgroup may take the whole register file of its CU, so
 // that no wave of another kernel fits beside it)
