@@ -120,6 +120,32 @@ class Context:
         self._check(self._lib.flvis_hip_pyr_down(self._h, _ptr(img), w, h, w, _ptr(out), dw, n), "pyr_down")
         return out
 
+    def debug_pyramid(self, img, levels, bx=32, by=24, ingest=True):
+        """Test aid (flvis_debug_pyramid): the tracker's pyramid construction.  img uint8 [n,h,w] on the GPU; returns the list of the
+        levels 0 .. levels as uint8 [n, h_l + 2 by, w_l + 2 bx] (border included; level 0 is None when ingest is False)."""
+        import torch
+        assert img.dtype == torch.uint8 and img.is_cuda and img.is_contiguous() and img.dim() == 3
+        n, h, w = img.shape
+        geo, off = [], 0
+        lw, lh = w, h
+        for _ in range(levels + 1):
+            pitch = ((lw + 15) & ~15) + 2 * bx
+            rows = lh + 2 * by
+            geo.append((off, pitch, rows, lw, lh))
+            off += (pitch * rows * n + 63) & ~63
+            lw, lh = (lw + 1) // 2, (lh + 1) // 2
+        out = torch.zeros(off + 64, dtype=torch.uint8, device=img.device)
+        pad = (-out.data_ptr()) % 64
+        buf = out[pad:pad + off]
+        self._check(self._lib.flvis_debug_pyramid(self._h, _ptr(img), w, h, n, levels, bx, by, 1 if ingest else 0, _ptr(buf), C.c_size_t(off)), "debug_pyramid")
+        res = []
+        for l, (o, pitch, rows, lw, lh) in enumerate(geo):
+            if l == 0 and not ingest:
+                res.append(None)
+                continue
+            res.append(buf[o:o + pitch * rows * n].view(n, rows, pitch)[:, :, :lw + 2 * bx].clone())
+        return res
+
     def lk_track(self, prev, nxt, prev_pts, next_pts, count, max_level=10, max_iter=30, eps=1e-3, use_initial=True):
         """prev/nxt uint8 [n,h,w]; prev_pts/next_pts float32 [n,nmax,2]; count int32 [n].
         Returns (next_pts_out, status uint8 [n,nmax])."""

@@ -124,8 +124,18 @@ int flvis_hip_pyr_down(flvis_ctx* ctx, const uint8_t* d_src, int w, int h, int s
   CHECK_CTX(ctx);
   if (!d_src || !d_dst || w < 2 || h < 2 || n_img <= 0 || (src_pitch & 3) || src_pitch < w || dst_pitch < (w + 1) / 2)
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "pyr_down: bad args (src_pitch % 4 must be 0)");
-  launch_pyr_down(ctx->stream, img_plain(d_src), w, h, src_pitch, (size_t)src_pitch * h, img_plain(d_dst), dst_pitch,
-                  (size_t)dst_pitch * ((h + 1) / 2), n_img, nullptr);
+  const int nob[2] = {0, 0};
+  if (pyr_walk_ok(w, h, 1, nob, nob, false) && !(dst_pitch & 7) && !((uintptr_t)d_dst & 7)) {  // (the tracker's own choice of kernel)
+    PyrSel q{};
+    q.levels = 1;
+    q.lvl[1] = img_plain(d_dst);
+    q.w[0] = w, q.h[0] = h, q.w[1] = (w + 1) / 2, q.h[1] = (h + 1) / 2;
+    q.pitch[1] = dst_pitch, q.stride[1] = (size_t)dst_pitch * ((h + 1) / 2);
+    launch_pyr_walk(ctx->stream, img_plain(d_src), w, h, src_pitch, (size_t)src_pitch * h, q, 0, 1, false, n_img, nullptr);
+  } else {
+    launch_pyr_down(ctx->stream, img_plain(d_src), w, h, src_pitch, (size_t)src_pitch * h, img_plain(d_dst), dst_pitch,
+                    (size_t)dst_pitch * ((h + 1) / 2), n_img, nullptr);
+  }
   CHECK_LAUNCH(ctx, "pyr_down");
   return FLVIS_OK;
 }

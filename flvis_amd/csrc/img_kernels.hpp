@@ -96,6 +96,13 @@ void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, siz
                      size_t dstride, int S, const int* active, int bx = 0, int by = 0, int sbx = 0, int sby = 0);
 // (sbx, sby: physical border of the SOURCE level, complete when the kernel runs: its tiles are then staged without index reflection)
 bool pyr_border_fusable(int w, int h, int bx, int by);
+// The same levels by walking waves (pyr_walk.hip; needs pyr_walk_ok): ONE launch reads level `first` of a pyramid from `src` (the level
+// itself or, with copy0, the caller's image, which is then also stored as pyr.lvl[first] -- the ingest copy) and produces the levels
+// first + 1 .. first + nout (nout = 1 or 2) with their physical borders (pyr.bx / by of each stored level; 0: none) complete.
+// bx / by of pyr_walk_ok: those of the levels first .. first + nout.
+bool pyr_walk_ok(int sw, int sh, int nout, const int* bx, const int* by, bool copy0);
+void launch_pyr_walk(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, const PyrSel& pyr, int first, int nout, bool copy0,
+                     int S, const int* active);
 // fills the border of the levels in level_mask that have one (one launch): for levels whose producer did not write it
 void launch_pyr_border(hipStream_t st, const PyrSel& pyr, int S, const int* active, unsigned level_mask = ~0u);
 // level 1 of a pyramid fused with the ingest copy: reads the caller's image once, writes level 0 (dst0) and level 1 (dst)

@@ -754,6 +754,60 @@ static void fill_pyr(Pipeline* pl, PyrSel& ps, uint8_t* const* l0, uint8_t* cons
   }
 }
 
+// Levels 1 .. levels of the pyramid `pyr` (level 0 too when `ingest` is set: the copy of the caller's image src0).  Level 0 is read from
+// src0 (the caller's image when ingest or in place, else pyr.lvl[0] itself, which another kernel wrote).  The levels' physical borders are
+// written by the kernel that produces the level wherever it can; the return value is the mask of the levels whose border is still to
+// fill (k_pyr_border).  level0_todo: level 0 has a border that nobody has written yet (equalizeHist / the unaligned copy made it).
+// Walking kernels (pyr_walk.hip) where the geometry allows -- 16-pixel lanes: widths that are multiples of 16 up to 1024 --, else the
+// LDS-tile kernels level by level.  FLVIS_PYR_PLAN (A/B knob): levels per walking launch, first launch first ("12": default).
+static unsigned pyramid_levels(hipStream_t ds, bool bordered, ImgSel src0, int spitch0, size_t sstride0, bool ingest, bool level0_is_buffer,
+                               const PyrSel& pyr, int S, const int* active) {
+  const int levels = pyr.levels;
+  unsigned border_left = bordered ? (1u << (levels + 1)) - 1u : 0u;
+  if (!level0_is_buffer && !ingest) border_left &= ~1u;  // (level 0 is the caller's buffer: no border to fill)
+  static const char* plan_env = getenv("FLVIS_PYR_PLAN");
+  const char* plan = plan_env && *plan_env ? plan_env : "12";
+  int step = 0, l = 0;
+  while (l < levels) {
+    int nout = plan[step] ? plan[step] - '0' : 1;
+    if (plan[step]) step++;
+    if (nout < 1) nout = 1;
+    if (nout > 2) nout = 2;
+    if (nout > levels - l) nout = levels - l;
+    const bool from0 = l == 0 && (ingest || !level0_is_buffer);
+    ImgSel src = from0 ? src0 : pyr.lvl[l];
+    const int spitch = from0 ? spitch0 : pyr.pitch[l];
+    const size_t sstride = from0 ? sstride0 : pyr.stride[l];
+    const bool copy0 = l == 0 && ingest;
+    PyrSel q = pyr;
+    for (int j = 0; j <= nout; j++)  // a level too small to mirror into its border in one pass keeps it for k_pyr_border
+      if (!(bordered && pyr_border_fusable(pyr.w[l + j], pyr.h[l + j], pyr.bx[l + j], pyr.by[l + j]))) q.bx[l + j] = q.by[l + j] = 0;
+    if (pyr_walk_ok(pyr.w[l], pyr.h[l], nout, q.bx + l, q.by + l, copy0)) {
+      launch_pyr_walk(ds, src, pyr.w[l], pyr.h[l], spitch, sstride, q, l, nout, copy0, S, active);
+      for (int j = copy0 ? 0 : 1; j <= nout; j++)
+        if (q.bx[l + j]) border_left &= ~(1u << (l + j));
+      l += nout;
+      continue;
+    }
+    // one level by the tile kernels
+    const int d = l + 1;
+    if (copy0) {
+      const bool f = q.bx[0] && q.bx[1];
+      launch_pyr_down_ingest(ds, src, pyr.w[0], pyr.h[0], spitch, sstride, pyr.lvl[0], pyr.pitch[0], pyr.stride[0], pyr.lvl[1], pyr.pitch[1],
+                             pyr.stride[1], S, active, f ? pyr.bx[1] : 0, f ? pyr.by[1] : 0);
+      if (f) border_left &= ~3u;
+    } else {
+      const bool f = q.bx[d] != 0;
+      const bool sf = !from0 && bordered && !((border_left >> l) & 1u);  // (the source level's border is complete)
+      launch_pyr_down(ds, src, pyr.w[l], pyr.h[l], spitch, sstride, pyr.lvl[d], pyr.pitch[d], pyr.stride[d], S, active, f ? pyr.bx[d] : 0,
+                      f ? pyr.by[d] : 0, sf ? pyr.bx[l] : 0, sf ? pyr.by[l] : 0);
+      if (f) border_left &= ~(1u << d);
+    }
+    l = d;
+  }
+  return border_left;
+}
+
 static void sync_streams(flvis_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   Pipeline* pl = ctx->pipe;
@@ -826,6 +880,9 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   ptab[1] = d_img1;
   memcpy(pn, L->h_nimu.data(), sizeof(int) * S);
   std::fill(L->h_nimu.begin(), L->h_nimu.end(), 0);
+  // (round 4, measured: uploading the block on the detection stream into a per-frame device slot -- so that k_frame_head(n + 1) follows
+  // k_frame_end(n) without the copy between them -- shortens the gap between two frames by ~19 us and lengthens the chain by ~16 us
+  // (1.1914 against 1.1943 ms per step): not kept.  profiles/r04_lk_ab.md)
   hipMemcpyAsync(L->d_inputs, pin, L->input_bytes, hipMemcpyHostToDevice, st);
   // ---- fixed kernel sequence
   const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
@@ -858,28 +915,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     PB(2, ds);
     // the borders of the levels: written by the pyrDown kernel that produces the level (every pixel also goes to the border positions
     // that mirror it); k_pyr_border only for what is left (level 0 when another kernel makes it, levels smaller than the border)
-    unsigned border_left = pl->lbx ? (1u << (pl->levels + 1)) - 1u : 0u;
-    auto fused = [&](int l) { return pl->lbx && pyr_border_fusable(pl->lw[l], pl->lh[l], pl->lbx, pl->lby); };
-    for (int l = 1; l <= pl->levels; l++) {  // left pyramid: needed by the temporal tracker right away
-      ImgSel s0{{L->pyr0[0][l - 1], L->pyr0[1][l - 1]}, p.img_slot_in, 0, nullptr}, d0{{L->pyr0[0][l], L->pyr0[1][l]}, p.img_slot_in, 0, nullptr};
-      if (l == 1 && !eq && aligned) {
-        const bool f = fused(0) && fused(1);
-        launch_pyr_down_ingest(ds, in0, w, h, w, (size_t)w * h, l0in, pl->lpitch[0], pl->lstride[0], d0, pl->lpitch[1], pl->lstride[1], S, nullptr,
-                               f ? pl->lbx : 0, f ? pl->lby : 0);
-        if (f) border_left &= ~3u;
-      } else {
-        const bool f = fused(l), sf = !((border_left >> (l - 1)) & 1u) && pl->lbx;  // (the source level's border is complete)
-        launch_pyr_down(ds, s0, pl->lw[l - 1], pl->lh[l - 1], pl->lpitch[l - 1], pl->lstride[l - 1], d0, pl->lpitch[l], pl->lstride[l], S, nullptr,
-                        f ? pl->lbx : 0, f ? pl->lby : 0, sf ? pl->lbx : 0, sf ? pl->lby : 0);
-        if (f) border_left &= ~(1u << l);
-      }
-    }
+    PyrSel pyl;
+    fill_pyr(pl, pyl, L->pyr0[0], L->pyr0[1], p.img_slot_in, 0, pl->levels);
+    unsigned border_left = pyramid_levels(ds, pl->lbx != 0, in0, w, (size_t)w * h, !eq && aligned, true, pyl, S, nullptr);
     if (pl->levels == 0 && !eq && aligned) launch_copy_image(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
-    if (border_left) {
-      PyrSel pb;
-      fill_pyr(pl, pb, L->pyr0[0], L->pyr0[1], p.img_slot_in, 0, pl->levels);
-      launch_pyr_border(ds, pb, S, nullptr, border_left);
-    }
+    if (border_left) launch_pyr_border(ds, pyl, S, nullptr, border_left);
     PE(2, ds);
     hipEventRecord(L->ev_img, ds);
   }
@@ -952,30 +992,12 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
       else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
       const bool ingest = !r_in_place && !eq && aligned;  // level 0 = a copy of the caller's image, written by the first pyrDown
-      unsigned border_left = pl->lbx ? (1u << (pl->levels + 1)) - 1u : 0u;
-      if (r_in_place) border_left &= ~1u;  // (level 0 is the caller's buffer: no border to fill)
-      auto fused = [&](int l) { return pl->lbx && pyr_border_fusable(pl->lw[l], pl->lh[l], pl->lbx, pl->lby); };
-      for (int l = 1; l <= pl->levels; l++) {
-        if (l == 1 && ingest) {
-          const bool f = fused(0) && fused(1);
-          launch_pyr_down_ingest(ds, in1, w, h, w, (size_t)w * h, img_plain(L->pyr1[0]), pl->lpitch[0], pl->lstride[0], img_plain(L->pyr1[1]),
-                                 pl->lpitch[1], pl->lstride[1], S, p.act_img, f ? pl->lbx : 0, f ? pl->lby : 0);
-          if (f) border_left &= ~3u;
-        } else {
-          const bool f = fused(l), sf = !((border_left >> (l - 1)) & 1u) && pl->lbx && !(l == 1 && r_in_place);
-          launch_pyr_down(ds, l == 1 ? r0 : img_plain(L->pyr1[l - 1]), pl->lw[l - 1], pl->lh[l - 1], l == 1 ? r0pitch : pl->lpitch[l - 1],
-                          l == 1 ? r0stride : pl->lstride[l - 1], img_plain(L->pyr1[l]), pl->lpitch[l], pl->lstride[l], S, p.act_img,
-                          f ? pl->lbx : 0, f ? pl->lby : 0, sf ? pl->lbx : 0, sf ? pl->lby : 0);
-          if (f) border_left &= ~(1u << l);
-        }
-      }
+      PyrSel pyr_r;
+      fill_pyr(pl, pyr_r, L->pyr1, nullptr, nullptr, 0, pl->levels);
+      unsigned border_left = pyramid_levels(ds, pl->lbx != 0, in1, w, (size_t)w * h, ingest, !r_in_place, pyr_r, S, p.act_img);
       if (pl->levels == 0 && ingest)
         launch_copy_image(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
-      if (border_left) {
-        PyrSel pb;
-        fill_pyr(pl, pb, L->pyr1, nullptr, nullptr, 0, pl->levels);
-        launch_pyr_border(ds, pb, S, p.act_img, border_left);
-      }
+      if (border_left) launch_pyr_border(ds, pyr_r, S, p.act_img, border_left);
     }
     if (!gftt_first) {
       launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
@@ -1622,6 +1644,34 @@ int flvis_get_local_map_counts(flvis_ctx* ctx, int64_t* h_keyframes, int64_t* h_
       for (int i = 0; i < L->S; i++) h_ba_runs[L->s0 + i] = r[i];
     }
   }
+  return FLVIS_OK;
+}
+
+// test aid: the tracker's pyramid construction on its own (see include/flvis_hip.h for the layout of d_out)
+int flvis_debug_pyramid(flvis_ctx* ctx, const uint8_t* d_src, int w, int h, int n_img, int levels, int bx, int by, int ingest, uint8_t* d_out,
+                        size_t out_bytes) {
+  if (!ctx) return FLVIS_ERR_INVALID_ARG;
+  if (!d_src || !d_out || w < 2 || h < 2 || (w & 3) || n_img <= 0 || levels < 1 || levels >= LK_MAX_LEVELS || bx < 0 || by < 0 || (bx & 15) ||
+      ((uintptr_t)d_src & 3) || ((uintptr_t)d_out & 63))
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "debug_pyramid: bad args (w % 4 == 0, 1 <= levels <= 5, bx % 16 == 0, d_out 64-byte aligned)");
+  PyrSel q{};
+  q.levels = levels;
+  size_t off = 0;
+  int lw = w, lh = h;
+  for (int l = 0; l <= levels; l++) {
+    q.w[l] = lw, q.h[l] = lh, q.bx[l] = bx, q.by[l] = by;
+    q.pitch[l] = ((lw + 15) & ~15) + 2 * bx;
+    q.stride[l] = (size_t)q.pitch[l] * (lh + 2 * by);
+    q.lvl[l] = img_plain(d_out + off + (size_t)by * q.pitch[l] + bx);
+    off += (q.stride[l] * n_img + 63) & ~(size_t)63;
+    lw = (lw + 1) / 2, lh = (lh + 1) / 2;
+  }
+  if (off > out_bytes) return ctx->fail(FLVIS_ERR_CAPACITY, "debug_pyramid: d_out too small");
+  const bool bordered = bx > 0 || by > 0;
+  unsigned left = pyramid_levels(ctx->stream, bordered, img_plain(d_src), w, (size_t)w * h, ingest != 0, ingest != 0, q, n_img, nullptr);
+  if (left) launch_pyr_border(ctx->stream, q, n_img, nullptr, left);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, hipGetErrorString(e));
   return FLVIS_OK;
 }
 

@@ -438,6 +438,14 @@ int flvis_debug_stage_poses(flvis_ctx* ctx, int stream, double* h_out21);
  * the previous frame's stereo LK), [62] template patches and [63] search regions staged by the slow (index-reflecting) path, i.e.
  * blocks that leave the pyramids' physical border. */
 int flvis_debug_lk_stats(flvis_ctx* ctx, int enable);
+/* Test aid: the tracker's pyramid construction on its own (the kernels F2FTracking's frames go through: the walking kernels of
+ * pyr_walk.hip where the image geometry allows, else the LDS-tile kernels, then k_pyr_border for what is left).  Builds levels 1 .. levels
+ * of n_img images (w x h, tightly packed) with a physical BORDER_REFLECT_101 border of bx columns / by rows around every level, as
+ * cv::buildOpticalFlowPyramid keeps it.  d_out: level l = 0 .. levels at consecutive offsets (each level block rounded up to 64 bytes),
+ * a block being [n_img][h_l + 2 by][pitch_l] bytes with pitch_l = ((w_l + 15) & ~15) + 2 bx and pixel (0, 0) at row by, column bx.
+ * ingest != 0: level 0 of d_out is the copy of the source (with border); 0: level 0 is read in place and its block is left untouched. */
+int flvis_debug_pyramid(flvis_ctx* ctx, const uint8_t* d_src, int w, int h, int n_img, int levels, int bx, int by, int ingest, uint8_t* d_out,
+                        size_t out_bytes);
 /* Test aid: the corner-response pass of flvis_hip_gftt alone (cornerMinEigenVal + the 3x3 local maxima), with the kernel variant chosen
  * (0: LDS tiles, 1: strip-mined tiles, 2: wave walk with `rows` rows per chunk): per image the ordered bits of the maximum response, the
  * number of local maxima and their sort keys ~((ordered(response) << 32) | pixel offset), unsorted, in h_keys [n_img][key_cap]. */

@@ -56,6 +56,46 @@ def test_pyr_down_parity(ctx, h, w, n):
         assert np.array_equal(out[i], O.pyr_down(imgs[i]))
 
 
+def _bordered(img, bx, by):
+    return np.pad(img, ((by, by), (bx, bx)), mode="reflect")  # numpy's "reflect" is BORDER_REFLECT_101
+
+
+@pytest.mark.parametrize("h,w,n,levels,ingest", [(480, 640, 3, 3, True), (480, 640, 2, 3, False), (480, 752, 2, 3, True), (376, 1248, 1, 3, True),
+                                                 (200, 320, 2, 2, True), (131, 208, 2, 2, False), (97, 144, 1, 1, True), (376, 1241, 1, 3, False),
+                                                 (480, 1024, 1, 3, True), (64, 64, 2, 1, True)])
+def test_pyramid_with_border_parity(ctx, h, w, n, levels, ingest):
+    """The tracker's pyramid construction (walking kernels where the geometry allows, tile kernels otherwise, k_pyr_border for the rest):
+    every level equals the checker's pyrDown chain, and the physical border around it is its BORDER_REFLECT_101 continuation."""
+    if w % 4:
+        pytest.skip("flvis_debug_pyramid takes packed rows of w % 4 == 0 (the tracker copies other widths into pitched level-0 buffers first)")
+    imgs = np.stack([S.texture_u8(h, w, 70 + i) for i in range(n)])
+    got = ctx.debug_pyramid(_cuda(imgs), levels, 32, 24, ingest)
+    for i in range(n):
+        lvl = imgs[i]
+        for l in range(levels + 1):
+            if l:
+                lvl = O.pyr_down(lvl)
+            if got[l] is None:
+                continue
+            g = got[l][i].cpu().numpy()
+            if lvl.shape[0] > 24 and lvl.shape[1] > 32:
+                assert np.array_equal(g, _bordered(lvl, 32, 24)), (i, l)
+            else:
+                assert np.array_equal(g[24:-24, 32:-32], lvl), (i, l)
+
+
+@pytest.mark.parametrize("h,w", [(480, 640), (96, 128), (35, 64), (17, 80), (480, 1024)])
+def test_pyramid_without_border_parity(ctx, h, w):
+    imgs = np.stack([S.texture_u8(h, w, 90 + i) for i in range(2)])
+    got = ctx.debug_pyramid(_cuda(imgs), 2 if h >= 32 else 1, 0, 0, True)
+    for i in range(2):
+        lvl = imgs[i]
+        for l in range(len(got)):
+            if l:
+                lvl = O.pyr_down(lvl)
+            assert np.array_equal(got[l][i].cpu().numpy(), lvl), (i, l)
+
+
 @pytest.mark.parametrize("h,w,maxc,q,md", [(96, 128, 50, 0.01, 5), (480, 640, 500, 0.001, 5), (480, 640, 1000, 0.001, 5),
                                           (480, 752, 1000, 0.01, 10), (100, 132, 40, 0.05, 3)])
 def test_gftt_parity(ctx, h, w, maxc, q, md):
