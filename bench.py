@@ -223,6 +223,8 @@ def csrc_hash():
 def short_kernel_name(full):
     n = full.split("(")[0]
     n = n.split("::")[-1].strip()
+    if n.startswith("k_pyr_walk<"):   # (instances kept apart: <levels produced, with the ingest copy>)
+        return n.replace(" ", "")
     return n.split("<")[0].strip()   # (the tracker's two LK launches are kernels of their own: k_lk_track_temporal / k_lk_track_stereo)
 
 

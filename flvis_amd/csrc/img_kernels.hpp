@@ -98,7 +98,7 @@ void launch_pyr_down(hipStream_t st, ImgSel src, int sw, int sh, int spitch, siz
 bool pyr_border_fusable(int w, int h, int bx, int by);
 // The same levels by walking waves (pyr_walk.hip; needs pyr_walk_ok): ONE launch reads level `first` of a pyramid from `src` (the level
 // itself or, with copy0, the caller's image, which is then also stored as pyr.lvl[first] -- the ingest copy) and produces the levels
-// first + 1 .. first + nout (nout = 1 or 2) with their physical borders (pyr.bx / by of each stored level; 0: none) complete.
+// first + 1 .. first + nout (nout = 1, 2 or 3) with their physical borders (pyr.bx / by of each stored level; 0: none) complete.
 // bx / by of pyr_walk_ok: those of the levels first .. first + nout.
 bool pyr_walk_ok(int sw, int sh, int nout, const int* bx, const int* by, bool copy0);
 void launch_pyr_walk(hipStream_t st, ImgSel src, int sw, int sh, int spitch, size_t sstride, const PyrSel& pyr, int first, int nout, bool copy0,

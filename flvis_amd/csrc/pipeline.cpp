@@ -772,7 +772,7 @@ static unsigned pyramid_levels(hipStream_t ds, bool bordered, ImgSel src0, int s
     int nout = plan[step] ? plan[step] - '0' : 1;
     if (plan[step]) step++;
     if (nout < 1) nout = 1;
-    if (nout > 2) nout = 2;
+    if (nout > 3) nout = 3;
     if (nout > levels - l) nout = levels - l;
     const bool from0 = l == 0 && (ingest || !level0_is_buffer);
     ImgSel src = from0 ? src0 : pyr.lvl[l];
@@ -924,7 +924,12 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     hipEventRecord(L->ev_img, ds);
   }
   PB(0, st);
-  launch_frame_head(st, p, L->d_time, L->d_progress, frame_no);  // the staged IMU samples, then frame_begin
+  // the staged IMU samples, then frame_begin -- and, unless the local-map feedback has to be applied in between, the temporal tracker's
+  // inputs in the same launch (FLVIS_HEAD_PREPARE=0, A/B knob: two launches)
+  static const bool head_prepare_knob = !(getenv("FLVIS_HEAD_PREPARE") && atoi(getenv("FLVIS_HEAD_PREPARE")) == 0);
+  const bool head_prepare = head_prepare_knob && !pl->feedback_used && !skipped;
+  if (head_prepare) launch_frame_head_prepare(st, p, L->d_time, L->d_progress, frame_no);
+  else launch_frame_head(st, p, L->d_time, L->d_progress, frame_no);
   if (pl->feedback_used) launch_apply_correction(st, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
   PE(0, st);
   // the detection stream's kernels that read what k_frame_head decides (act_img, gftt_act, gftt_maxc, img_slot) wait for this event:
@@ -951,7 +956,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   if (first_processed && pl->stagger && L->idx > 0) hipStreamWaitEvent(st, pl->lanes[L->idx - 1]->ev_stagger, 0);
   // (the guesses of the temporal tracker only need the state frame_begin left)
   PB(3, st);
-  launch_track_prepare(st, p);
+  if (!head_prepare) launch_track_prepare(st, p);
   PE(3, st);
   hipStreamWaitEvent(st, L->ev_img, 0);  // join: the left pyramid
   // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
@@ -1263,7 +1268,9 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   // (Measured in round 4, profiles/r04_h2d_full_timeline_*.txt: beside an SDMA upload the chain's latency-bound kernels run 2-3 x slower,
   // the LK launches do not.  Gating the uploads under LK launches -- left image under the previous frame's stereo LK, right image under
   // the frame's own head / temporal LK -- made the leg slower, 40k -> 31k frames/s: k_frame_head / k_track_prepare are latency-bound too
-  // and the later start of the copies costs host lead.  The uploads start as soon as their staging slot is free.)
+  // and the later start of the copies costs host lead.  A copy KERNEL of 8 .. 128 workgroups reading the caller's page-locked buffer over
+  // PCIe instead of the SDMA engine: 19-34k frames/s against 35.3k (profiles/r04_lk_ab.md).  The uploads start as soon as their
+  // staging slot is free, on the SDMA engine.)
   hipError_t e = hipSuccess;
   for (int c = 0; c < 2 && e == hipSuccess; c++) {
     const flvis_image* im = c ? h_img1 : h_img0;

@@ -314,13 +314,11 @@ __device__ inline void frame_begin_dev(const Pipe& p, int s, double time) {
 }
 
 // ------------------------------------------------------------------------------------------------ temporal LK inputs
-__global__ __launch_bounds__(256) void k_track_prepare(Pipe p) {
-  const int s = blockIdx.y;
+__device__ __forceinline__ void track_prepare_dev(const Pipe& p, int s, int i) {
   const StreamState& st = p.st[s];
   if (st.phase != PH_TRACK) return;
   const int last = st.cur ^ 1;
   const int n = st.n_lm[last];
-  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) {
     p.lk_count[s] = n;
     p.lk_tag[s] = st.frame_id[last];  // the templates come from the last frame's left image
@@ -349,6 +347,28 @@ __global__ __launch_bounds__(256) void k_track_prepare(Pipe p) {
     np[0] = px;
     np[1] = py;
   }
+}
+
+__global__ __launch_bounds__(256) void k_track_prepare(Pipe p) { track_prepare_dev(p, blockIdx.y, blockIdx.x * 256 + threadIdx.x); }
+// k_frame_head and k_track_prepare in one launch (one workgroup of 256 threads per stream): the tracker's inputs follow the frame set-up
+// after a barrier instead of after a launch -- one dependent launch less at the head of every frame's chain
+__global__ __launch_bounds__(256) void k_frame_head_prepare(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
+                                                            long long frame_no) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (s == 0 && tid == 0 && host_progress) __hip_atomic_store(host_progress, frame_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __shared__ double s_in[IMU_MAX * 7];
+  int n = p.n_imu[s];
+  if (n > IMU_MAX) n = IMU_MAX;
+  const double* in = p.imu_in + (size_t)s * IMU_MAX * 7;
+  for (int i = tid; i < 7 * n; i += 256) s_in[i] = in[i];
+  const double t_frame = frame_time[s];
+  __syncthreads();
+  if (tid == 0) {
+    imu_feed_dev(p, s, s_in);
+    frame_begin_dev(p, s, t_frame);
+  }
+  __syncthreads();  // (workgroup-scope release / acquire: the stream's state as thread 0 left it)
+  for (int i = tid; i < NMAX; i += 256) track_prepare_dev(p, s, i);
 }
 
 // ------------------------------------------------------------------------------------------------ LK survivors
@@ -2284,6 +2304,9 @@ void launch_store_progress(hipStream_t st, long long* host_word, long long v) {
 }
 void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time, long long* host_progress, long long frame_no) {
   hipLaunchKernelGGL(k_frame_head, dim3(p.S), dim3(64), 0, st, p, d_time, host_progress, frame_no);
+}
+void launch_frame_head_prepare(hipStream_t st, const Pipe& p, const double* d_time, long long* host_progress, long long frame_no) {
+  hipLaunchKernelGGL(k_frame_head_prepare, dim3(p.S), dim3(256), 0, st, p, d_time, host_progress, frame_no);
 }
 void launch_apply_correction(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_apply_correction, dim3(p.S), dim3(AC_T), 0, st, p);

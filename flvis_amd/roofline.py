@@ -12,6 +12,7 @@ Every kernel that takes more than 5 % of a frame gets one line, priced against t
 Times are HIP-event stage times measured live by bench.py (epilogue frames); `rocprof_avg_launch_ms` is the average of the same kernel in
 the rocprofv3 kernel trace that `bench.py --pmc` stores next to the counters -- the two must agree (the stage of a kernel that runs under
 another kernel is longer than its trace time; the table says which)."""
+import os
 
 HBM_PEAK_GBS = 8000.0
 SIMDS = 1024
@@ -119,15 +120,38 @@ def kernel_table(stages, S, w, h, copy_gbs, pmc=None, ba=None, ms_per_step=None)
         row = {"kernel": "k_gftt_pick", "bound": "latency (one workgroup per stream)", "launches_per_step": 1, "avg_launch_ms": round(p, 4)}
         counters("k_gftt_pick", row)
         rows.append(row)
-    # left pyramid: ingest (level 0 copy + level 1) and two k_pyr_down launches in one stage
+    # left pyramid: the ingest launch (level 0 copy + level 1) and the launch that makes levels 2 and 3, in one stage
     pl = _ms(stages, "pyr_down(left)")
     if pl > 0:
         b = (img + pyramid_bytes(w, h)) * S  # the ingest also writes level 0
-        row = scan("k_pyr_down_ingest + 2 x k_pyr_down (left pyramid)", pl, b, 1, "three launches in one stage: level 0 copy + levels 1..3")
-        counters("k_pyr_down_ingest", row)
+        walk = os.environ.get("FLVIS_PYR_TILES", "0") in ("", "0")   # (the A/B knob that selects the LDS-tile kernels)
+        name = "k_pyr_walk<1,true> + k_pyr_walk<2,false> (left pyramid)" if walk else "k_pyr_down_ingest + 2 x k_pyr_down (left pyramid)"
+        row = scan(name, pl, b, 1, "both launches in one stage (HIP events on the detection stream, beside k_frame_head and the local map's workgroups): "
+                   "level 0 copy + levels 1..3; the borders of the levels (not counted) are written as well")
+        if walk and pk:
+            # the two launches' own durations and counters (rocprofv3 passes): what the kernels do when the stage's waits are left out
+            a, c = pk.get("k_pyr_walk<1,true>") or {}, pk.get("k_pyr_walk<2,false>") or {}
+            if a.get("avg_ns") and c.get("avg_ns"):
+                ms = (a["avg_ns"] + c["avg_ns"]) * 1e-6
+                row["rocprof_launches_ms"] = [round(a["avg_ns"] * 1e-6, 4), round(c["avg_ns"] * 1e-6, 4)]
+                row["achieved_GBs_kernels_only"] = round(b / (ms * 1e-3) / 1e9, 1)
+            for key in ("valu_insts", "fetch_kb", "write_kb", "fetch_kb_calibrated", "write_kb_calibrated"):
+                if a.get(key) is not None and c.get(key) is not None:
+                    row.setdefault("_sum", {})[key] = a[key] + c[key]
+            sm = row.pop("_sum", {})
+            if "valu_insts" in sm:
+                row["valu_insts_per_launch"] = int(sm["valu_insts"])
+            if "fetch_kb_calibrated" in sm and "write_kb_calibrated" in sm:
+                row["traffic_bytes_per_launch"] = int((sm["fetch_kb_calibrated"] + sm["write_kb_calibrated"]) * 1024)
+                row["traffic_calibrated"] = True
+            elif "fetch_kb" in sm and "write_kb" in sm:
+                row["traffic_bytes_per_launch"] = int((sm["fetch_kb"] + sm["write_kb"]) * 1024)
+                row["traffic_calibrated"] = False
+        else:
+            counters("k_pyr_down_ingest", row)
         rows.append(row)
     # the one-workgroup-per-stream chain
-    chain = [("k_frame_head", ("imu_feed+frame_begin",)), ("k_ransac_f", ("ransac_f",)), ("k_ransac_pnp", ("ransac_pnp",)),
+    chain = [("k_frame_head_prepare" if os.environ.get("FLVIS_HEAD_PREPARE", "1") != "0" else "k_frame_head", ("imu_feed+frame_begin",)), ("k_ransac_f", ("ransac_f",)), ("k_ransac_pnp", ("ransac_pnp",)),
              ("k_pose_lm", ("track_post+pose_lm",)), ("k_reproj_filter", ("reproj_filter",)),
              ("k_feature_dem + k_add_new", ("feature_dem+add_new",)), ("k_depth_seeds", ("depth_prepare",)),
              ("k_depth_innovate", ("depth_innovate",)), ("k_frame_end", ("frame_end",))]

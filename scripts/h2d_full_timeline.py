@@ -18,7 +18,7 @@ for x in rows:
     b = int(float(x[size_key])) if size_key and x[size_key] not in ("", None) else -1
     ev.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), "COPY %.3f MB" % (b / 1e6), "dma"))
 ev.sort()
-heads = [i for i, e in enumerate(ev) if e[2] == "k_frame_head"]
+heads = [i for i, e in enumerate(ev) if e[2] in ("k_frame_head", "k_frame_head_prepare")]
 nf = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 a = heads[-nf - 1] if len(heads) > nf else 0
 ev = ev[a:]

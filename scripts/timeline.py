@@ -8,7 +8,7 @@ for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     r["k"] = r["Kernel_Name"].split("flvis::")[1].split("(")[0]
 rows.sort(key=lambda r: r["s"])
-fb = [i for i, r in enumerate(rows) if r["k"] in ("k_frame_head", "k_frame_begin")]  # first kernel of a frame
+fb = [i for i, r in enumerate(rows) if r["k"] in ("k_frame_head", "k_frame_head_prepare", "k_frame_begin")]  # first kernel of a frame
 which = int(sys.argv[2]) if len(sys.argv) > 2 else len(fb) - 5
 a, b = fb[which], fb[which + 1]
 t0 = rows[a]["s"]

@@ -9,7 +9,7 @@ for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     r["k"] = r["Kernel_Name"].split("flvis::")[1].split("(")[0]
 rows.sort(key=lambda r: r["s"])
-fb = [r for r in rows if r["k"] in ("k_frame_head", "k_frame_begin")]
+fb = [r for r in rows if r["k"] in ("k_frame_head", "k_frame_head_prepare", "k_frame_begin")]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 fb = fb[-(n + 1):]
 spans = [(fb[i + 1]["s"] - fb[i]["s"], i) for i in range(len(fb) - 1)]

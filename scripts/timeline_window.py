@@ -16,7 +16,7 @@ for r in rows:
 rows.sort(key=lambda r: r["s"])
 win_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-fb = [r for r in rows if r["k"] in ("k_frame_head", "k_frame_begin")]  # first kernel of a frame
+fb = [r for r in rows if r["k"] in ("k_frame_head", "k_frame_head_prepare", "k_frame_begin")]  # first kernel of a frame
 t0 = fb[max(0, len(fb) - back)]["s"]
 t1 = t0 + int(win_ms * 1e6)
 qs = {q: i for i, q in enumerate(sorted(set(r["Queue_Id"] for r in rows), key=lambda x: int(x)))}

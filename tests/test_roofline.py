@@ -28,7 +28,9 @@ def test_kernel_table_prices_every_kernel_against_its_bound():
           "track_post+pose_lm": 0.12, "reproj_filter": 0.03, "gftt:eig_cand": 0.2, "gftt:pick": 0.25, "feature_dem+add_new": 0.05,
           "depth_prepare": 0.07, "lk_track(stereo)": 0.3, "depth_innovate": 0.1, "frame_end": 0.02, "ba_worker(launch)": 2.0}
     pmc = {"kernels": {"k_lk_track": {"valu_insts": 122.88e6, "fetch_kb": 24000.0, "write_kb": 1000.0, "avg_ns": 310000.0},
-                       "k_eig_walk": {"valu_insts": 18e6}}}
+                       "k_eig_walk": {"valu_insts": 18e6},
+                       "k_pyr_walk<1,true>": {"valu_insts": 1e6, "fetch_kb_calibrated": 19200.0, "write_kb_calibrated": 28000.0, "avg_ns": 19000.0},
+                       "k_pyr_walk<2,false>": {"valu_insts": 0.5e6, "fetch_kb_calibrated": 4800.0, "write_kb_calibrated": 2000.0, "avg_ns": 11000.0}}}
     ba = {"runs": 10, "trials": 200, "trials_items": 200 * 1000, "trials_landmarks": 200 * 400, "trials_poses": 200 * 7,
           "ms_per_optimisation": 1.5, "worker_ms_per_launch": 2.0}
     rows = rf.kernel_table(st, 64, 640, 480, 5000.0, pmc, ba, 1.5)
@@ -40,8 +42,10 @@ def test_kernel_table_prices_every_kernel_against_its_bound():
     e = by["k_eig_walk"]
     assert e["algorithmic_bytes_per_launch"] == 307200 * 64 and abs(e["achieved_GBs"] - 98.3) < 0.1
     assert abs(e["frac_of_measured_copy"] - 98.304 / 5000) < 1e-3 and abs(e["valu_issue_frac"] - (18e6 / 0.2e-3 / 1e9) / 614.4) < 1e-3
-    p = by["k_pyr_down_ingest + 2 x k_pyr_down (left pyramid)"]
+    p = by["k_pyr_walk<1,true> + k_pyr_walk<2,false> (left pyramid)"]
     assert p["algorithmic_bytes_per_launch"] == (307200 + rf.pyramid_bytes(640, 480)) * 64
+    assert p["traffic_bytes_per_launch"] == 54000 * 1024 and p["traffic_calibrated"] and p["rocprof_launches_ms"] == [0.019, 0.011]
+    assert abs(p["achieved_GBs_kernels_only"] - p["algorithmic_bytes_per_launch"] / 30e-6 / 1e9) < 0.1
     b = by["k_ba_worker"]
     per_opt = rf.ba_flops(200, 200000, 80000, 1400) / 10
     assert abs(b["mflop_per_optimisation"] - per_opt / 1e6) < 0.01 and b["lm_trials_per_optimisation"] == 20
