@@ -598,6 +598,10 @@ def main():
                          "path (one optimisation per keyframe)" % (csum[4], csum[5]))
     if csum[3] == 0:
         raise SystemExit("bench.py: no stream is tracking at the end of the run -- the measured region is not the hot path")
+    dbg_end = (C.c_int64 * 64)()
+    ctx._check(lib.flvis_debug_counters(ctx._h, dbg_end), "debug_counters")
+    if wlm and dbg_end[3]:   # (a stream's keyframe queue was full: the local map did not see every keyframe the tracker made)
+        raise SystemExit("bench.py: %d keyframes were dropped between the tracker and the local map -- not the reference's path" % dbg_end[3])
 
     if rank == 0:
         total_frames = world * S * K

@@ -50,6 +50,11 @@ constexpr int BA_T = FLVIS_BA_T;
 #else
 #define BA_ATTR
 #endif
+// (build-variant knob: the per-trial phases as calls -- each with a register allocation of its own, and ~110 callee-saved VGPRs stored and
+// reloaded around every call -- or inlined into ba_optimize)
+#ifndef FLVIS_BA_PHASE_FN
+#define FLVIS_BA_PHASE_FN __noinline__
+#endif
 constexpr int BA_NW = BA_T / 64;
 constexpr int BA_PMAX = BA_WMAX - 1;   // free poses
 constexpr int BA_NRMAX = 6 * BA_PMAX;  // 90
@@ -439,7 +444,7 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
 
 // blocked (6x6) left-looking Cholesky of the lower triangle of Hs (leading dimension LD) by ONE wave, then the two
 // triangular solves on sh.x; Linv receives the inverted diagonal blocks.  Returns false on a non-positive pivot.
-__device__ __noinline__ bool ba_chol_solve() {
+__device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
   BAShared& sh = ba_sh();
   double* Hs = ba_dyn();
   double* Linv = Hs + sh.off_linv;
@@ -603,7 +608,7 @@ __device__ __noinline__ bool ba_chol_solve() {
 // together): Hll / bl per landmark, the B blocks per item, and per free pose the 21 + 6 entries of Hpp / bp, reduced over
 // the wave with a scattered butterfly and accumulated per wave in LDS (fixed order -> reproducible).  Returns this
 // thread's share of the robust chi2.  ba_phase_finish_poses() folds the per-wave partials afterwards.
-__device__ __noinline__ double ba_phase_linearize() {
+__device__ FLVIS_BA_PHASE_FN double ba_phase_linearize() {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, L = sh.L, Lc = sc.Lc, Ec = sc.Ec, W = sh.W, P = sh.P;
@@ -890,7 +895,7 @@ FD void ba_phase_imu_trial() {
 }
 
 // largest diagonal entry of the (unreduced) hessian -> initial lambda (computeLambdaInit); this thread's share
-__device__ __noinline__ double ba_phase_max_diag() {
+__device__ FLVIS_BA_PHASE_FN double ba_phase_max_diag() {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
   const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, P = sh.P;
@@ -904,7 +909,7 @@ __device__ __noinline__ double ba_phase_max_diag() {
 
 // reduced camera system S = Hpp + lambda I - sum_l Z Z^T (lower triangle into Hs) and rhs = bp - sum_l Z c (into sh.x),
 // streaming the observed blocks through double-buffered LDS chunks
-__device__ __noinline__ void ba_phase_schur(double lambda) {
+__device__ FLVIS_BA_PHASE_FN void ba_phase_schur(double lambda) {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
   const int t = threadIdx.x, Lc = sc.Lc, Ec = sc.Ec, P = sh.P;
@@ -1237,7 +1242,7 @@ __device__ __noinline__ void ba_phase_schur_mfma(double lambda) {
 
 // wave 0: factor + solve the reduced system, then form the trial poses x (+) pose (unchanged poses if the factorisation
 // failed) and their (R | t) tables
-__device__ __noinline__ void ba_phase_solve_poses() {
+__device__ FLVIS_BA_PHASE_FN void ba_phase_solve_poses() {
   BAShared& sh = ba_sh();
   const int lane = threadIdx.x & 63;
   const bool okc = ba_chol_solve();
@@ -1265,7 +1270,7 @@ __device__ __noinline__ void ba_phase_solve_poses() {
 // are re-linearised at the accepted state (B^T dx_pose = w Jl^T (Jp dx_pose) needs no stored block), the step is solved
 // with the landmark's 3x3 factor, the trial landmark goes to lmB and its reprojection errors against the trial poses
 // are summed.  out[0] = share of the gain-ratio denominator, out[1] = share of the trial chi2.
-__device__ __noinline__ void ba_phase_update_chi2(double lambda, int ok2, double* out) {
+__device__ FLVIS_BA_PHASE_FN void ba_phase_update_chi2(double lambda, int ok2, double* out) {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
   const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, W = sh.W;
@@ -1674,6 +1679,8 @@ __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p) {
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     // only the owner advances the head: it is read once (after the acquire above) and then kept in a register
     unsigned my_head = __hip_atomic_load(&p.kfq_head[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    int taken = 0;
+    bool capped = false;
     while (true) {
       if (t == 0) {
         s_head = my_head;
@@ -1686,18 +1693,32 @@ __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p) {
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       const KeyFrameDev& kf = p.kfq[(size_t)s * KFQ + (hd % KFQ)];
       const long long frame_id = kf.frame_id;
+#ifdef FLVIS_BA_PROF
+      const long long tu0 = (long long)wall_clock64();
+#endif
       ba_update_dev(p, s, kf, reinterpret_cast<long long*>(ba_dyn()), s_cnt);
       __syncthreads();
+#ifdef FLVIS_BA_PROF
+      if (t == 0 && p.counters) {  // (counter 26 / 27: ticks in the bookkeeping of a keyframe, keyframes)
+        atomicAdd((unsigned long long*)&p.counters[26], (unsigned long long)((long long)wall_clock64() - tu0));
+        atomicAdd((unsigned long long*)&p.counters[27], 1ull);
+      }
+#endif
       if (p.win[s].solve) ba_solve_dev(p, s, frame_id);
       __atomic_thread_fence(__ATOMIC_RELEASE);
       __syncthreads();
       if (t == 0) __hip_atomic_store(&p.kfq_head[s], hd + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       my_head = hd + 1u;
+      if (p.ba_drain > 0 && ++taken >= p.ba_drain) {  // (the next launch goes on: one follows every frame, and flvis_hip_synchronize launches until the queues are empty)
+        capped = true;
+        break;
+      }
     }
     __atomic_thread_fence(__ATOMIC_RELEASE);
     __syncthreads();
     if (t == 0) __hip_atomic_store(&p.ba_busy[s], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    if (capped) return;
     // a keyframe may have arrived between the emptiness test and the release: look again
   }
 }

@@ -88,7 +88,7 @@ struct Lane {
   hipEvent_t ev_stagger = nullptr;
   // back-pressure on the keyframe queues in stream order: ev_ba_done[i % BAQ] follows the lane's i-th local-map launch; the
   // tracking stream waits for the launches of KFQ-3 frames ago before it appends new keyframes (see lane_frame)
-  static constexpr int BAQ = 32;
+  static constexpr int BAQ = 64;
   hipEvent_t ev_ba_done[BAQ] = {};
   long long ba_launches = 0;
 };
@@ -379,6 +379,15 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   p.imu_factor = 0;
   p.imu_sigma_g = 0;
   p.imu_sigma_a = 0;
+  // Keyframes a local-map workgroup takes from its stream's queue per launch.  A workgroup that kept draining a busy stream's queue
+  // (0: the behaviour up to round 4) made its LAUNCH last as long as that stream stayed busy, the launches behind it on the same HIP
+  // stream -- with every other stream's keyframes -- waited, and the tracker either met the back-pressure below (5-8 ms frame chains in
+  // one run of three at KFQ = 16) or left the local map a backlog at the end of the run (7-18 ms at KFQ = 32), although no queue was
+  // near full.  With one keyframe per launch every launch is one optimisation long, the launch that follows every frame takes the
+  // stream's next keyframe, and the two local-map streams never fall behind: 54.2-54.3k frames/s in four runs of four, against
+  // 36.8-54.1k (profiles/r04_local_map_and_streams_ab.md).
+  p.ba_drain = 1;
+  if (const char* e = getenv("FLVIS_BA_DRAIN")) p.ba_drain = std::max(0, atoi(e));
   p.ba_mfma = 0;
   if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;
   // LDS a local-map workgroup claims (FLVIS_BA_LDS_KB, 64 .. 159): whatever it leaves of the CU's 160 KB lets LK / corner-response

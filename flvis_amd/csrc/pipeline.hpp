@@ -18,7 +18,7 @@ constexpr int IMU_MAX = 64;       // IMU samples accepted per stream between two
 constexpr int IMU_OUT_CAP = 512;  // rows of the per-stream ring behind F2FTracking::imu_feed's outputs (flvis_get_imu_states)
 constexpr int VI_QUEUE = 400;     // STATES_QUEUE_SIZE (src/processing/include/vi_motion.h:10)
 constexpr int KF_MAXLM = 1024;    // landmarks per keyframe payload
-constexpr int KFQ = 16;            // per-stream keyframe queue between the tracker and the local map
+constexpr int KFQ = 32;            // per-stream keyframe queue between the tracker and the local map (48 KB per entry)
 constexpr int BA_WMAX = 16;       // window sizes supported by the LDS-resident solver
 constexpr int BA_LMAX = 4096;     // landmarks in the window
 constexpr int BA_EMAX = 8192;     // observations (edges) in the window

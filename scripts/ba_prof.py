@@ -51,6 +51,8 @@ tot = sum(c[8:8 + 13])
 for i, n in enumerate(names):
     print("%-16s %8.1f us/run  %5.1f%%" % (n, c[8 + i] / runs / 100.0, 100.0 * c[8 + i] / max(tot, 1)))
 print("total %.1f us/run (100 MHz counter assumed)" % (tot / runs / 100.0))
+if c[27]:
+    print("keyframe bookkeeping (ba_update_dev): %.1f us per keyframe (%d keyframes)" % (c[26] / c[27] / 100.0, c[27]))
 
 if c[24 + 7] or c[32 + 7]:
     for base, name, ph in ((24, "ransac_f", ["load", "generate", "score", "replay", "mask+count"]),
