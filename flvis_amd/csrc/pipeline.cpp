@@ -1313,7 +1313,8 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   for (int s = 0; s < S; s++) hf.times[s] = h_img0[s].t;
   // one frame of lead in this mode: with two, the uploads' copies and events push the queued commands over what the HIP runtime
   // accepts without blocking the caller for milliseconds (measured: 16k vs 28k frames/s when that happened mid-run)
-  pl->host_lead_cap = 1;
+  static const int h2d_lead = getenv("FLVIS_H2D_LEAD") ? std::max(1, std::min(atoi(getenv("FLVIS_H2D_LEAD")), 4)) : 1;  // (A/B knob)
+  pl->host_lead_cap = h2d_lead;
   const int rc = flvis_image_feed(ctx, d0, d1, hf.times.data(), h_out, with_local_map);
   pl->host_lead_cap = 4;
   hipEventRecord(hf.ev_free[slot], st);
