@@ -775,7 +775,10 @@ static unsigned pyramid_levels(hipStream_t ds, bool bordered, ImgSel src0, int s
   unsigned border_left = bordered ? (1u << (levels + 1)) - 1u : 0u;
   if (!level0_is_buffer && !ingest) border_left &= ~1u;  // (level 0 is the caller's buffer: no border to fill)
   static const char* plan_env = getenv("FLVIS_PYR_PLAN");
-  const char* plan = plan_env && *plan_env ? plan_env : "12";
+  // default: one level, then two ("12": the fastest for 640-pixel rows, profiles/r04_lk_ab.md) -- unless level 1 is not a whole number of
+  // 16-pixel lanes while level 0 is (752-pixel rows: 376): then the first launch takes two levels ("21") and only the last one is left
+  // to the tile kernels
+  const char* plan = plan_env && *plan_env ? plan_env : ((pyr.w[0] & 15) == 0 && (((pyr.w[0] + 1) >> 1) & 15) != 0 ? "21" : "12");
   int step = 0, l = 0;
   while (l < levels) {
     int nout = plan[step] ? plan[step] - '0' : 1;
