@@ -65,7 +65,10 @@ struct Lane {
   // waits for the previous frame -- the host runs several frames ahead of the GPU and a frame's launches are already queued
   // when the GPU gets to them.
   static constexpr int PIN_RING = 4;
-  void* pinned[PIN_RING] = {};
+  void* pinned[PIN_RING] = {};      // page-locked staging of a frame's inputs (host view) ...
+  uint8_t* pinned_dev[PIN_RING] = {};  // ... and the same memory as the device sees it (FLVIS_INPUT_ZEROCOPY: k_frame_head reads it in place)
+  const uint8_t* h_tab[2] = {nullptr, nullptr};  // the image bases of the last frame fed (host copy of the table)
+  size_t in_off_imu = 0, in_off_tab = 0, in_off_n = 0;
   // the slot of frame n may be refilled once frame n's upload is done: k_frame_head (the first kernel after the upload) stores the
   // frame number into this host-mapped word and the host polls it.  (hipEventSynchronize on an event recorded after the upload
   // returned only when EVERYTHING enqueued so far had finished -- measured: the host then slept through four queued frames and the
@@ -408,6 +411,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   const size_t off_imu = sizeof(double) * S, off_tab = off_imu + sizeof(double) * (size_t)S * IMU_MAX * 7,
                off_n = off_tab + 2 * sizeof(void*);
   L->input_bytes = off_n + sizeof(int) * S;
+  L->in_off_imu = off_imu, L->in_off_tab = off_tab, L->in_off_n = off_n;
   ok = ok && ((L->d_inputs = dalloc<uint8_t>(L->allocs, L->input_bytes)) != nullptr);
   if (ok) {
     L->d_time = reinterpret_cast<double*>(L->d_inputs);
@@ -493,7 +497,15 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   L->h_nimu.assign(S, 0);
   L->imu_read.assign(S, 0);
   for (int k = 0; k < Lane::PIN_RING; k++)
-    if (hipHostMalloc(&L->pinned[k], L->input_bytes, hipHostMallocDefault) != hipSuccess) return false;
+    if (hipHostMalloc(&L->pinned[k], L->input_bytes, hipHostMallocMapped) != hipSuccess) return false;
+  for (int k = 0; k < Lane::PIN_RING; k++) {
+    void* dv = nullptr;
+    if (hipHostGetDevicePointer(&dv, L->pinned[k], 0) != hipSuccess) {
+      (void)hipGetLastError();
+      dv = nullptr;
+    }
+    L->pinned_dev[k] = (uint8_t*)dv;
+  }
   {
     void* hp = nullptr;
     void* dp = nullptr;
@@ -620,6 +632,9 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
 // image -- the staged samples of the lane are integrated at once (blocking upload + k_imu_feed: a rare path) and staging goes on.
 static int lane_flush_imu(flvis_ctx* ctx, Lane& L) {
   hipError_t e = hipStreamSynchronize(L.st);
+  // (the device block of the copying mode: idle after the synchronisation whichever mode the frames use)
+  L.pipe.imu_in = reinterpret_cast<double*>(L.d_inputs + L.in_off_imu);
+  L.pipe.n_imu = reinterpret_cast<int*>(L.d_inputs + L.in_off_n);
   if (e == hipSuccess) e = hipMemcpy(L.pipe.imu_in, L.h_imu.data(), sizeof(double) * L.h_imu.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(L.pipe.n_imu, L.h_nimu.data(), sizeof(int) * L.S, hipMemcpyHostToDevice);
   if (e != hipSuccess) return ctx->hip_fail(e, "imu_feed (flush)");
@@ -895,7 +910,20 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // (round 4, measured: uploading the block on the detection stream into a per-frame device slot -- so that k_frame_head(n + 1) follows
   // k_frame_end(n) without the copy between them -- shortens the gap between two frames by ~19 us and lengthens the chain by ~16 us
   // (1.1914 against 1.1943 ms per step): not kept.  profiles/r04_lk_ab.md)
-  hipMemcpyAsync(L->d_inputs, pin, L->input_bytes, hipMemcpyHostToDevice, st);
+  // FLVIS_INPUT_ZEROCOPY (default 1): no copy at all -- k_frame_head reads the block where the host staged it (page-locked, mapped into
+  // the device's address space: a few KB per stream over PCIe, in parallel over the streams), and the image bases travel as kernel
+  // arguments.  A staging slot is rewritten PIN_RING frames later, when the frame that read it is long over (the host-lead wait above).
+  static const bool zerocopy_knob = !(getenv("FLVIS_INPUT_ZEROCOPY") && atoi(getenv("FLVIS_INPUT_ZEROCOPY")) == 0);
+  const bool zerocopy = zerocopy_knob && L->pinned_dev[pslot] != nullptr;
+  L->h_tab[0] = d_img0, L->h_tab[1] = d_img1;
+  p.in_img1 = d_img1;
+  {
+    uint8_t* din = zerocopy ? L->pinned_dev[pslot] : L->d_inputs;
+    L->d_time = reinterpret_cast<double*>(din);
+    p.imu_in = reinterpret_cast<double*>(din + L->in_off_imu);
+    p.n_imu = reinterpret_cast<int*>(din + L->in_off_n);
+  }
+  if (!zerocopy) hipMemcpyAsync(L->d_inputs, pin, L->input_bytes, hipMemcpyHostToDevice, st);
   // ---- fixed kernel sequence
   const bool prof = pl->prof_cap > 0 && pl->prof_step < pl->prof_cap;
   hipEvent_t* pev = prof ? &L->prof_ev[(size_t)pl->prof_step * (2 * PROF_STAGES)] : nullptr;
@@ -909,7 +937,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   const bool eq = pl->cfg.need_equal_hist != 0;
   const bool aligned = (w & 15) == 0;  // otherwise (KITTI: 1241 x 376, tightly packed rows) both images are copied into pitch-aligned level 0
   hipStream_t ds = L->det_stream;
-  ImgSel in0 = img_indirect(L->d_tab + 0), in1 = img_indirect(L->d_tab + 1);
+  ImgSel in0 = img_plain(d_img0), in1 = img_plain(d_img1);  // (kernel arguments: no graph is captured)
   ImgSel l0cur{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot, 0, nullptr};
   if (!skipped) {
     // left image -> level 0 of the slot this frame is going to use (+ the pyramid), on the detection stream BESIDE k_frame_head: the
@@ -1513,7 +1541,7 @@ int flvis_get_keyframe_msg(flvis_ctx* ctx, int stream, int cap, flvis_keyframe* 
     const bool eq = pl->cfg.need_equal_hist != 0, aligned = (w & 15) == 0;
     const uint8_t* tab[2] = {nullptr, nullptr};
     if (depth_cam || (!eq && aligned)) {  // read in place from the caller's buffer of that frame (still the table's entry)
-      e = hipMemcpy(tab, L.d_tab, sizeof(tab), hipMemcpyDeviceToHost);
+      tab[0] = L.h_tab[0], tab[1] = L.h_tab[1];
       const size_t bpp = depth_cam ? 2 : 1;
       if (e == hipSuccess) e = hipMemcpy(h_img1, tab[1] + (size_t)ls * w * h * bpp, (size_t)w * h * bpp, hipMemcpyDeviceToHost);
     } else {

@@ -2070,7 +2070,7 @@ __global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
       pty = (float)round(lm.p2d[1]);
       // (landmarks live in the open box (0, W-1) x (0, H-1), lkorb_tracking.cpp:95-102; the clamp only guards the read)
       const int ix = min(max(__float2int_rn(ptx), 0), p.cam.w - 1), iy = min(max(__float2int_rn(pty), 0), p.cam.h - 1);
-      const uint16_t d16 = reinterpret_cast<const uint16_t*>(p.in_tab[1])[(size_t)s * p.cam.w * p.cam.h + (size_t)iy * p.cam.w + ix];
+      const uint16_t d16 = reinterpret_cast<const uint16_t*>(p.in_img1)[(size_t)s * p.cam.w * p.cam.h + (size_t)iy * p.cam.w + ix];
       const float z = (float)((double)d16 / p.cam.depth_scale);
       if ((double)z >= 0.3 && z <= p.cam.range) {
         meas = V3{((double)ptx - p.cam.cx) * (double)z / p.cam.fx, ((double)pty - p.cam.cy) * (double)z / p.cam.fy, (double)z};

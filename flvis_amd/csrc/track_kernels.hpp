@@ -69,6 +69,8 @@ struct Pipe {
   // device table of this frame's input image bases (entry 0: img0, entry 1: img1 or, on DEPTH_D435 rigs, the Z16 depth image
   // [S][h][w]); uploaded per frame so that the kernel arguments never change (the frame's launches are a captured graph)
   const uint8_t* const* in_tab;
+  // ... and the second image's base itself (a kernel argument: it changes from frame to frame with the caller's buffer)
+  const uint8_t* in_img1;
   CorrectionDev* corr_in;   // [S] correction waiting for the stream's next Tracking frame (valid flag), or nullptr
 };
 
