@@ -147,6 +147,8 @@ struct BAShared {
   int chunk_i0[BA_MAXCHUNK + 1];
   long long* prof;  // optional phase timers (FLVIS_BA_PROF builds)
   long long tlast;
+  // (FLVIS_BA_PROF) per call of the Schur phase: the slowest and the summed accumulate time / block products over the pair threads
+  int pf_tmax, pf_tsum, pf_nmax, pf_nsum, pf_threads;
   // followed in dynamic LDS by: Hs[NR][NR+1], Linv[P][36], then the two chunk buffers
 };
 
@@ -943,7 +945,8 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_schur(double lambda) {
   double rB[18], rH[6], rH2[6], rb[3];
   bool it_on = false, lm_on = false;
   unsigned rmask = 0;
-  int rbase = 0;
+  int rbase = 0, rbase_i0 = 0;  // (the chunk's first item is subtracted at commit time: nothing may USE a prefetched value before the
+                                // chunk's arithmetic, or the wait for it -- and for every load issued before it -- lands in front of that arithmetic)
   auto prefetch = [&](int c) {
     const int l0 = sh.chunk_l0[c], nl = sh.chunk_l0[c + 1] - l0;
     const int i0 = sh.chunk_i0[c], ni = sh.chunk_i0[c + 1] - i0;
@@ -960,7 +963,8 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_schur(double lambda) {
     if (lm_on) {
       const int l = l0 + t;
       rmask = sc.fmask[l];
-      rbase = sc.ibase[l] - i0;
+      rbase = sc.ibase[l];
+      rbase_i0 = i0;
 #pragma unroll
       for (int k = 0; k < 6; k++) rH2[k] = sc.Hll[(size_t)k * Lc + l];
 #pragma unroll
@@ -987,7 +991,7 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_schur(double lambda) {
     }
     if (lm_on) {
       mb[t] = rmask;
-      lb[t] = rbase;
+      lb[t] = rbase - rbase_i0;
       if (rmask) {  // c = G^-1 bl
         const Chol3 g = chol3(rH2, lambda);
         const double c0 = rb[0] * g.i00;
@@ -999,6 +1003,11 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_schur(double lambda) {
       }
     }
   };
+#ifdef FLVIS_BA_PROF
+  long long pf_ticks = 0;
+  int pf_prod = 0;
+  if (t == 0) sh.pf_tmax = sh.pf_tsum = sh.pf_nmax = sh.pf_nsum = sh.pf_threads = 0;  // (published by the first chunk's barrier)
+#endif
   if (nchunk > 0) prefetch(0);
   for (int c = 0; c < nchunk; c++) {
     const int buf = c & 1;
@@ -1012,25 +1021,38 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_schur(double lambda) {
     const unsigned* mb = reinterpret_cast<const unsigned*>(cb + (size_t)CL * 3);
     const int* lb = reinterpret_cast<const int*>(mb + CL);
     const double2* z2 = reinterpret_cast<const double2*>(zb);
+#ifdef FLVIS_BA_PROF
+    const long long pf_t0 = (long long)wall_clock64();
+#endif
     if (my_i1 >= 0) {
       const unsigned need = (1u << my_i1) | (1u << my_i2);
       const unsigned lt1 = (1u << my_i1) - 1u, lt2 = (1u << my_i2) - 1u;
-      // the masks / item bases of this thread's landmarks are fetched 8 at a time before the arithmetic: a dependent LDS
-      // read per landmark (most of them only to find the pair unobserved) was a large part of this loop
-      for (int g0 = my_sl; g0 < nl; g0 += 8 * slices) {
-        unsigned mk[8];
-        int bs[8];
+      // Two passes over this thread's landmarks of the chunk (my_sl, my_sl + slices, ...).  First the masks only, 8 LDS reads in flight at
+      // a time: which landmarks are seen by both poses -> one bit each.  Then the block products, every lane walking the set bits of
+      // ITS word: a wave runs the product body as often as its busiest lane has landmarks (~10), not once per landmark ANY of its 64
+      // lanes has (~31 of 31: the lanes' hits fall on different landmarks, and the one-pass loop spent 4/5 of its issue slots masked
+      // off -- 13 us per call for 6.7 products per thread, scripts/ba_prof.py).  Same landmarks in the same order: the sums are unchanged.
+      const int nmine = nl > my_sl ? (nl - my_sl + slices - 1) / slices : 0;
+      for (int jb = 0; jb < nmine; jb += 32) {
+        unsigned hit = 0;
+        const int jn = nmine - jb < 32 ? nmine - jb : 32;
+        for (int j0 = 0; j0 < jn; j0 += 8) {
+          unsigned mk[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int ll = g0 + q * slices;
-          mk[q] = ll < nl ? mb[ll] : 0u;
-          bs[q] = ll < nl ? lb[ll] : 0;
+          for (int q = 0; q < 8; q++) mk[q] = j0 + q < jn ? mb[my_sl + (jb + j0 + q) * slices] : 0u;
+#pragma unroll
+          for (int q = 0; q < 8; q++)
+            if ((mk[q] & need) == need) hit |= 1u << (j0 + q);
         }
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const unsigned m = mk[q];
-          if ((m & need) != need) continue;
-          const int base = bs[q];
+        while (hit) {
+          const int j = __builtin_ctz(hit);
+          hit &= hit - 1u;
+          const int ll = my_sl + (jb + j) * slices;
+          const unsigned m = mb[ll];
+#ifdef FLVIS_BA_PROF
+          pf_prod++;
+#endif
+          const int base = lb[ll];
           const double2* zi = z2 + base + __popc(m & lt1);
           const double2* zj = z2 + base + __popc(m & lt2);
           double a[18];
@@ -1072,8 +1094,20 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_schur(double lambda) {
         for (int r = 0; r < 6; r++) accr[r] = fma(a[3 * r + 2], c2, fma(a[3 * r + 1], c1, fma(a[3 * r], c0, accr[r])));
       }
     }
+#ifdef FLVIS_BA_PROF
+    pf_ticks += (long long)wall_clock64() - pf_t0;
+#endif
     BAPROF(12);
   }
+#ifdef FLVIS_BA_PROF
+  if (my_i1 >= 0) {
+    atomicMax(&sh.pf_tmax, (int)pf_ticks);
+    atomicAdd(&sh.pf_tsum, (int)pf_ticks);
+    atomicMax(&sh.pf_nmax, pf_prod);
+    atomicAdd(&sh.pf_nsum, pf_prod);
+    atomicAdd(&sh.pf_threads, 1);
+  }
+#endif
   // combine the slices (fixed butterfly order) and write S / rhs
   for (int off = slices >> 1; off > 0; off >>= 1) {
 #pragma unroll
@@ -1406,6 +1440,15 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
       else
         ba_phase_schur(lambda);
       __syncthreads();
+#ifdef FLVIS_BA_PROF
+      if (t == 0 && sh.prof && !sh.use_mfma && sh.pf_threads) {  // counters 28 .. 32: slowest / mean thread's accumulate ticks, most / mean block products, calls
+        atomicAdd((unsigned long long*)&sh.prof[20], (unsigned long long)sh.pf_tmax);
+        atomicAdd((unsigned long long*)&sh.prof[21], (unsigned long long)(sh.pf_tsum / sh.pf_threads));
+        atomicAdd((unsigned long long*)&sh.prof[22], (unsigned long long)sh.pf_nmax);
+        atomicAdd((unsigned long long*)&sh.prof[23], (unsigned long long)((sh.pf_nsum * 16) / sh.pf_threads));  // (x 16: fixed point)
+        atomicAdd((unsigned long long*)&sh.prof[24], 1ull);
+      }
+#endif
       if (sh.n_imu) {
         ba_phase_imu_offdiag();
         __syncthreads();

@@ -51,6 +51,10 @@ tot = sum(c[8:8 + 13])
 for i, n in enumerate(names):
     print("%-16s %8.1f us/run  %5.1f%%" % (n, c[8 + i] / runs / 100.0, 100.0 * c[8 + i] / max(tot, 1)))
 print("total %.1f us/run (100 MHz counter assumed)" % (tot / runs / 100.0))
+if c[32]:
+    n = c[32]
+    print("Schur accumulate per call, over the pair threads: slowest %.2f us, mean %.2f us; block products: most %.1f, mean %.2f per thread (%d calls)"
+          % (c[28] / n / 100.0, c[29] / n / 100.0, c[30] / n, c[31] / n / 16.0, n))
 if c[27]:
     print("keyframe bookkeeping (ba_update_dev): %.1f us per keyframe (%d keyframes)" % (c[26] / c[27] / 100.0, c[27]))
 
