@@ -67,7 +67,8 @@ struct Pipe {
   int* rec_id;              // [S][POSE_REC]  ID_POSE::frame_id (an int in the reference)
   double* rec_T;            // [S][POSE_REC][7]
   // device table of this frame's input image bases (entry 0: img0, entry 1: img1 or, on DEPTH_D435 rigs, the Z16 depth image
-  // [S][h][w]); uploaded per frame so that the kernel arguments never change (the frame's launches are a captured graph)
+  // [S][h][w]).  Rounds 1-3 uploaded it per frame and read the images through it; since round 4 the image bases are kernel arguments
+  // (img_plain, in_img1) and the table is only filled by the copying mode of the inputs (FLVIS_INPUT_ZEROCOPY=0)
   const uint8_t* const* in_tab;
   // ... and the second image's base itself (a kernel argument: it changes from frame to frame with the caller's buffer)
   const uint8_t* in_img1;
