@@ -771,10 +771,50 @@ def leg_h2d(L):
     t_loop = time.perf_counter() - t0
     ctx._check(lib.flvis_hip_synchronize(ctx._h), "synchronize")
     dt = time.perf_counter() - t0
+    n_all = n
     n -= WU
     out["with_h2d"] = {"value": round(L["world"] * S * n / dt, 1), "unit": "frames/s", "steps": n,
                        "note": "images handed over as pinned host buffers (flvis_image_feed_host, 614,400 B per stereo frame over "
                                "PCIe); %d untimed calls in front; rank 0's rate x n_gpus; never `value`" % WU}
+    # ---- what the leg computed: the poses of ALL its frames and streams against a re-run of the whole sequence through the resident
+    # path (flvis_image_feed on a second context, same seeds, same frames; that path is the one the lockstep tests hold against the
+    # oracle).  An upload that raced a frame, or a staging slot refilled too early, shows as a differing pose.
+    import flvis_amd
+    trk = L["trk"]
+    rows_h = np.stack([trk.trajectory(i, f0, n_all) for i in range(S)])
+    ctx2 = flvis_amd.Context(L["local_rank"])
+    try:
+        trk2 = flvis_amd.Tracker(ctx2, L["cfg"], S, seed_base=0xF1715 + L["rank"] * S, traj_capacity=f0 + n_all)
+        skip, standin = L["skip"], None
+        for f in range(f0 + n_all):
+            if f >= f0:
+                fr = (host[f - f0][0].to(L["dev"]), host[f - f0][1].to(L["dev"]))
+            elif f in frames:
+                fr = frames[f]
+            elif f <= skip:
+                standin = standin if standin is not None else rnd.stereo_frame(trajs, skip / synth.FRAME_HZ, skip)
+                fr = standin
+            else:
+                fr = rnd.stereo_frame(trajs, f / synth.FRAME_HZ, f)
+            rc = lib.flvis_imu_feed_all(ctx2._h, imu_cnt[f].ctypes.data_as(C.POINTER(C.c_int)), imu[f].ctypes.data_as(C.POINTER(C.c_double)), SPF)
+            if rc:
+                ctx2._check(rc, "imu_feed_all")
+            trk2.image_feed(fr[0], fr[1], times[f], want_out=False, with_local_map=False)
+            ctx2.synchronize()
+        rows_r = np.stack([trk2.trajectory(i, f0, n_all) for i in range(S)])
+        del trk2
+    finally:
+        ctx2.close()
+    same = bool(np.array_equal(rows_h, rows_r))
+    tracked = int(((rows_h[:, :, 8].astype(int) & 15) == 1).sum())
+    out["with_h2d"]["poses_bit_identical"] = same
+    out["with_h2d"]["poses_compared"] = {"streams": S, "frames": n_all, "tracked_poses": tracked,
+                                         "against": "a resident re-run of the whole sequence (flvis_image_feed, second context)"}
+    if not same or tracked == 0:
+        bad = np.argwhere(np.any(rows_h != rows_r, axis=2))
+        out["with_h2d"]["value"] = None      # a rate of wrong results is not a measurement (the line itself survives: leg_errors)
+        raise RuntimeError("the host-image leg's poses differ from the resident re-run (first at stream %d, frame %d; %d tracked poses)"
+                           % (tuple(int(v) for v in bad[0]) + (tracked,) if len(bad) else (-1, -1, tracked)))
     if os.environ.get("FLVIS_BENCH_FRAMES"):
         out["with_h2d"]["host_call_ms"] = [round(v, 3) for v in calls]
         out["with_h2d"]["loop_ms"] = round(t_loop * 1e3, 3)

@@ -720,11 +720,18 @@ class Tracker:
         self.ctx._check(self.lib.flvis_get_local_map_counts(self.ctx._h, _P(kf, C.c_int64), _P(ba, C.c_int64)), "get_local_map_counts")
         return kf, ba
 
-    def write_imu_trajectory(self, rows11, path, min_dt=0.0, append=False):
-        """The recorder on /imu_pose: rows of imu_states() as `stamp x y z qw qx qy qz` lines; returns the lines written."""
+    def write_imu_trajectory(self, rows11, path, min_dt=0.0, append=False, t_first=None):
+        """The recorder on /imu_pose: rows of imu_states() as `stamp x y z qw qx qy qz` lines; returns the lines written.
+        t_first: the stamp of the run's first row (flvis_write_imu_trajectory_run) -- pass it with every batch of a run whose first
+        batch may cover less than min_dt."""
         np = self.np
         r = np.ascontiguousarray(rows11, np.float64).reshape(-1, 11)
-        n = self.lib.flvis_write_imu_trajectory(_P(r, C.c_double), len(r), path.encode(), C.c_double(min_dt), int(append))
+        if t_first is not None:
+            self.lib.flvis_write_imu_trajectory_run.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_char_p, C.c_double, C.c_int, C.c_double]
+            n = self.lib.flvis_write_imu_trajectory_run(_P(r, C.c_double), len(r), path.encode(), C.c_double(min_dt), int(append),
+                                                        C.c_double(t_first))
+        else:
+            n = self.lib.flvis_write_imu_trajectory(_P(r, C.c_double), len(r), path.encode(), C.c_double(min_dt), int(append))
         if n < 0:
             raise FlvisError("write_imu_trajectory failed (%d)" % n)
         return n
@@ -746,6 +753,36 @@ class Tracker:
                             dbg=np.array([o.of_inliers, o.f_inliers, o.pnp_inliers]),
                             reprojection_error=o.reprojection_error))
         return res
+
+    def _frame_outs(self):
+        np = self.np
+        return [dict(state=o.state, new_keyframe=bool(o.new_keyframe), reset_cmd=bool(o.reset_cmd),
+                     n_landmarks=o.n_landmarks, frame_id=o.frame_id, pose7=np.array(o.T_c_w[:]),
+                     dbg=np.array([o.of_inliers, o.f_inliers, o.pnp_inliers]),
+                     reprojection_error=o.reprojection_error) for o in self._out]
+
+    def image_feed_host(self, imgs0, imgs1, times, want_out=True, with_local_map=True, hold_buffers=False):
+        """flvis_image_feed_host: the frame handed over as HOST images, the call a nodelet makes (vo_tracking.cpp:396-430).
+        imgs0 / imgs1: one numpy array per stream, [H, W] (mono8; uint16 for the depth image of a depth rig) or [H, W, 3|4]
+        (BGR / BGRA); rows may be padded (a strided view whose pixels are contiguous).  With hold_buffers the arrays must stay
+        untouched until the next call on this context has returned."""
+        np = self.np
+        assert len(imgs0) == self.S and len(imgs1) == self.S
+        a = (FlvisImage * self.S)()
+        b = (FlvisImage * self.S)()
+        for arr, imgs in ((a, imgs0), (b, imgs1)):
+            for s, im in enumerate(imgs):
+                px = im.itemsize * (im.shape[2] if im.ndim == 3 else 1)
+                assert im.strides[1] == px and (im.ndim == 2 or im.strides[2] == im.itemsize), "pixels of a row must be contiguous"
+                arr[s].data = C.cast(im.ctypes.data, C.POINTER(C.c_uint8))
+                arr[s].width, arr[s].height, arr[s].pitch = im.shape[1], im.shape[0], im.strides[0]
+                arr[s].channels = im.shape[2] if im.ndim == 3 else 1
+                arr[s].t = float(times[s])
+        out = C.cast(self._out, C.c_void_p) if want_out else C.c_void_p(0)
+        self.lib.flvis_image_feed_host.argtypes = [C.c_void_p, C.POINTER(FlvisImage), C.POINTER(FlvisImage), C.c_void_p, C.c_int, C.c_int]
+        self.ctx._check(self.lib.flvis_image_feed_host(self.ctx._h, a, b, out, int(with_local_map), int(hold_buffers)),
+                        "image_feed_host")
+        return self._frame_outs() if want_out else None
 
     def landmarks(self, stream, cap=2048):
         np = self.np
@@ -901,6 +938,13 @@ class Tracker:
         return rows[:min(n, cap)].copy()
 
     def counters(self):
+        """[frames fed, keyframes, local-map optimisations]"""
         c = (C.c_int64 * 3)()
         self.ctx._check(self.lib.flvis_get_counters(self.ctx._h, c), "get_counters")
         return list(c)
+
+    def dropped_keyframes(self):
+        """keyframes that met a full keyframe queue (flvis_get_counters_n [3]; 0 under the tracker's back-pressure)"""
+        c = (C.c_int64 * 4)()
+        self.ctx._check(self.lib.flvis_get_counters_n(self.ctx._h, 4, c), "get_counters_n")
+        return int(c[3])

@@ -1702,8 +1702,9 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
 // Local-map worker: one workgroup per stream drains the stream's keyframe queue (bookkeeping + optimisation per keyframe,
 // strictly in order).  It is launched after every frame on one of the local-map HIP streams; a workgroup that finds the
 // stream's window owned by a workgroup of an earlier launch leaves at once -- the owner re-checks the queue before and
-// after releasing the window, so a keyframe is picked up at the latest by the launch that follows it.  The tracker
-// therefore never waits for the optimiser unless the queue (KFQ keyframes) is full.
+// after releasing the window, so a keyframe is picked up at the latest by the launch that follows it.  An owner takes ba_drain
+// keyframes (one) and leaves the rest to the next launch unless ba_backlog or more are waiting.  The tracker therefore never waits
+// for the optimiser unless a stream has fallen behind by half a queue (KFQ keyframes).
 __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p) {
   const int s = blockIdx.x;
   const int t = threadIdx.x;
@@ -1752,9 +1753,18 @@ __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p) {
       __syncthreads();
       if (t == 0) __hip_atomic_store(&p.kfq_head[s], hd + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       my_head = hd + 1u;
-      if (p.ba_drain > 0 && ++taken >= p.ba_drain) {  // (the next launch goes on: one follows every frame, and flvis_hip_synchronize launches until the queues are empty)
-        capped = true;
-        break;
+      if (p.ba_drain > 0 && ++taken >= p.ba_drain) {
+        // the next launch goes on (one follows every frame, and flvis_hip_synchronize launches until the queues are empty) -- unless
+        // the stream has fallen behind by ba_backlog keyframes: then the owner stays, so that a finished launch has left less than
+        // ba_backlog keyframes of the frames before it in every queue (what the tracker's back-pressure counts on, pipeline.cpp)
+        if (t == 0) s_tail = __hip_atomic_load(&p.kfq_tail[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned left = s_tail - my_head;
+        __syncthreads();
+        if (left < (unsigned)p.ba_backlog) {
+          capped = true;
+          break;
+        }
       }
     }
     __atomic_thread_fence(__ATOMIC_RELEASE);

@@ -125,7 +125,8 @@ int flvis_hip_pyr_down(flvis_ctx* ctx, const uint8_t* d_src, int w, int h, int s
   if (!d_src || !d_dst || w < 2 || h < 2 || n_img <= 0 || (src_pitch & 3) || src_pitch < w || dst_pitch < (w + 1) / 2)
     return ctx->fail(FLVIS_ERR_INVALID_ARG, "pyr_down: bad args (src_pitch % 4 must be 0)");
   const int nob[2] = {0, 0};
-  if (pyr_walk_ok(w, h, 1, nob, nob, false) && !(dst_pitch & 7) && !((uintptr_t)d_dst & 7)) {  // (the tracker's own choice of kernel)
+  // the tracker's own choice of kernel -- when the walking kernel's 16-byte row loads and 8-byte stores are aligned (else the tile kernels)
+  if (pyr_walk_ok(w, h, 1, nob, nob, false) && !(dst_pitch & 7) && !((uintptr_t)d_dst & 7) && !(src_pitch & 15) && !((uintptr_t)d_src & 15)) {
     PyrSel q{};
     q.levels = 1;
     q.lvl[1] = img_plain(d_dst);

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <limits>
 #include <vector>
 
 #include "../../include/flvis_hip.h"
@@ -391,6 +392,11 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   // 36.8-54.1k (profiles/r04_local_map_and_streams_ab.md).
   p.ba_drain = 1;
   if (const char* e = getenv("FLVIS_BA_DRAIN")) p.ba_drain = std::max(0, atoi(e));
+  // ... with a bound: an owner that finds KFQ / 2 or more keyframes still waiting after its share stays and goes on (a stream whose
+  // optimisations take longer than its keyframes arrive -- every frame a keyframe -- would otherwise grow a backlog that only ends at
+  // the full queue, where k_frame_end drops keyframes).  A launch takes at least the keyframes of the frames between two launches.
+  if (p.ba_drain > 0) p.ba_drain = std::max(p.ba_drain, pl->ba_every);
+  p.ba_backlog = KFQ / 2;
   p.ba_mfma = 0;
   if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;
   // LDS a local-map workgroup claims (FLVIS_BA_LDS_KB, 64 .. 159): whatever it leaves of the CU's 160 KB lets LK / corner-response
@@ -596,7 +602,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   if (const char* e = getenv("FLVIS_SYNC_EACH_FRAME")) pl->sync_each_frame = atoi(e) != 0;
   if (const char* e = getenv("FLVIS_BA_EVERY")) {
     int v = atoi(e);
-    if (v >= 1 && v <= KFQ / 2) pl->ba_every = v;
+    if (v >= 1 && v <= KFQ / 4) pl->ba_every = v;  // (the back-pressure in lane_frame needs (D + 2) * ba_every <= KFQ / 2)
   }
   bool ok = true;
   for (int k = 0; k < n_lanes && ok; k++) {
@@ -882,7 +888,10 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // run at most host_lead frames ahead of the GPU (<= PIN_RING: the staging slot of frame N - PIN_RING must be free).  Not further:
   // beyond ~5 queued frames (~300 commands) the HIP runtime itself blocks the enqueuing thread for 7-9 ms at a time and the GPU
   // then runs dry while the queue is refilled (measured)
-  const long long lead = std::min(pl->host_lead, pl->host_lead_cap);
+  // (zero-copy inputs: k_frame_head publishes its progress word when it STARTS, while its other workgroups may still be reading the
+  // slot -- one slot of slack, so that the slot the host refills belongs to a frame whose successor has started, i.e. that is over)
+  static const bool zc_lead = !(getenv("FLVIS_INPUT_ZEROCOPY") && atoi(getenv("FLVIS_INPUT_ZEROCOPY")) == 0);
+  const long long lead = std::min(std::min(pl->host_lead, pl->host_lead_cap), (int)Lane::PIN_RING - (zc_lead ? 1 : 0));
   if (frame_no > lead && *L->h_progress < frame_no - lead) {
     const auto tw = std::chrono::steady_clock::now();
     int polls = 0;
@@ -935,7 +944,9 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   const bool skipped = pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs;
   const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
   const bool eq = pl->cfg.need_equal_hist != 0;
-  const bool aligned = (w & 15) == 0;  // otherwise (KITTI: 1241 x 376, tightly packed rows) both images are copied into pitch-aligned level 0
+  // rows of whole 16-byte lanes at 16-byte aligned bases (the walking kernels' dwordx4 loads); otherwise (KITTI: 1241 x 376 tightly packed
+  // rows, or a caller's buffer at an odd offset) both images are copied into pitch-aligned level 0
+  const bool aligned = (w & 15) == 0 && !(((uintptr_t)d_img0 | (depth_cam ? (uintptr_t)0 : (uintptr_t)d_img1)) & 15);
   hipStream_t ds = L->det_stream;
   ImgSel in0 = img_plain(d_img0), in1 = img_plain(d_img1);  // (kernel arguments: no graph is captured)
   ImgSel l0cur{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot, 0, nullptr};
@@ -1158,11 +1169,14 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   launch_depth_innovate(st, p);
   PE(16, st);
   if (with_local_map) {
-    // Keyframe-queue back-pressure, expressed in stream order (never by spinning inside a kernel): once every local-map
-    // launch of this lane up to index j has finished, the keyframes of all frames up to j*ba_every are consumed (a launch
-    // drains the queues of the windows it owns; a window owned by an earlier launch is drained by that one), so waiting
-    // for the launches of D frames ago bounds the backlog of a stream by (D + 2) * ba_every <= KFQ keyframes.
-    const long long D = std::max(0, KFQ / pl->ba_every - 3);
+    // Keyframe-queue back-pressure, expressed in stream order (never by spinning inside a kernel).  Once every local-map launch of
+    // this lane up to index j has finished, less than ba_backlog = KFQ / 2 keyframes of the frames up to j * ba_every are left in any
+    // queue: the last workgroup that owned the stream's window among those launches stayed until fewer were waiting (k_ba_worker),
+    // and every launch behind it found the queue empty.  The frames since then add at most (D + nba_lane) * ba_every keyframes, so
+    // waiting for the launches of D frames ago (the last one on each of the lane's local-map streams) keeps a queue at
+    // KFQ / 2 - 1 + (D + 2) * ba_every < KFQ when k_frame_end appends: no keyframe is dropped, whatever the optimiser's pace.
+    // (ba_every <= KFQ / 4, flvis_tracker_create.)
+    const long long D = std::max(0, KFQ / 2 / pl->ba_every - 2);
     for (int k = 0; k < pl->nba_lane; k++) {
       const long long j = L->ba_launches - 1 - D - k;
       if (j >= 0 && L->ba_launches - j <= Lane::BAQ) hipStreamWaitEvent(st, L->ev_ba_done[j % Lane::BAQ], 0);
@@ -1641,17 +1655,17 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first, int n, const c
 // The recorder on /imu_pose (launch/flvis_euroc_mav.launch:83-103: vo_repub_rec with sub_type PoseStamped, sub_topic /imu_pose,
 // output est.txt): pubPose(q_w_i, pos_w_i, stamp) of every IMU sample, `stamp x y z qw qx qy qz` (vo_repub_rec.cpp:74-91), with
 // the throttle as written there (see flvis_write_trajectory).  Rows as flvis_get_imu_states returns them.
-int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, double min_dt, int append) {
+int flvis_write_imu_trajectory_run(const double* h_rows11, int n, const char* path, double min_dt, int append, double t_first) {
   if (!path || n < 0 || (n > 0 && !h_rows11)) return FLVIS_ERR_INVALID_ARG;
   FILE* f = fopen(path, append ? "a" : "w");
   if (!f) return FLVIS_ERR_CONFIG;
   int written = 0;
-  // the recorder's `last_time` is the stamp of the first message of the RUN (vo_repub_rec.cpp:77-78): the batch that creates the file
-  // carries it; appended batches belong to the same run and are past it
-  const bool throttle = min_dt > 0 && !append;
+  // the recorder's `last_time` is the stamp of the first message of the RUN (vo_repub_rec.cpp:77-78) and is never updated: rows within
+  // min_dt of THAT stamp are dropped, whichever batch they arrive in
+  const bool throttle = min_dt > 0 && (t_first == t_first);
   for (int i = 0; i < n; i++) {
     const double* r = h_rows11 + (size_t)i * 11;
-    if (throttle && !(r[0] - h_rows11[0] > min_dt)) continue;
+    if (throttle && !(r[0] - t_first > min_dt)) continue;
     fprintf(f, "%.9f %.6g %.6g %.6g %.6g %.6g %.6g %.6g\n", r[0], r[5], r[6], r[7], r[1], r[2], r[3], r[4]);
     written++;
   }
@@ -1659,19 +1673,28 @@ int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, 
   return written;
 }
 
-int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) {
-  if (!ctx || !ctx->pipe || !h3) return FLVIS_ERR_INVALID_ARG;
+// (the two-argument form of the run: the batch that creates the file carries the run's first stamp; a batch that is appended without
+// naming it is written in full -- callers whose first batch may be shorter than min_dt use flvis_write_imu_trajectory_run)
+int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, double min_dt, int append) {
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  return flvis_write_imu_trajectory_run(h_rows11, n, path, min_dt, append, (!append && n > 0 && h_rows11) ? h_rows11[0] : nan);
+}
+
+int flvis_get_counters_n(flvis_ctx* ctx, int n, int64_t* h) {
+  if (!ctx || !ctx->pipe || !h || n < 1 || n > 4) return FLVIS_ERR_INVALID_ARG;
   sync_all(ctx);
-  h3[0] = ctx->pipe->frames_fed * ctx->pipe->S;
-  h3[1] = h3[2] = 0;
+  int64_t v[4] = {ctx->pipe->frames_fed * ctx->pipe->S, 0, 0, 0};
   for (Lane* L : ctx->pipe->lanes) {
     long long c[8];
-    hipMemcpy(c, L->pipe.counters, sizeof(c), hipMemcpyDeviceToHost);
-    h3[1] += c[1];
-    h3[2] += c[2];
+    hipError_t e = hipMemcpy(c, L->pipe.counters, sizeof(c), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return ctx->hip_fail(e, "get_counters");
+    for (int k = 1; k < 4; k++) v[k] += c[k];
   }
+  for (int k = 0; k < n; k++) h[k] = v[k];
   return FLVIS_OK;
 }
+
+int flvis_get_counters(flvis_ctx* ctx, int64_t* h3) { return flvis_get_counters_n(ctx, 3, h3); }
 
 // per stream: keyframes the tracker has emitted (KeyFrame messages of /vo_kf) and optimisations its local map has run
 int flvis_get_local_map_counts(flvis_ctx* ctx, int64_t* h_keyframes, int64_t* h_ba_runs) {

@@ -60,7 +60,8 @@ struct Pipe {
   double imu_sigma_a;      // accelerometer noise density [m/s^2/sqrt(Hz)] of the factor's position rows (information 1 / (sigma_a^2 dt^3 / 3)); <= 0: rotation rows only
   double imu_sigma_g;      // its gyro noise density [rad/s/sqrt(Hz)]: information = 1 / (sigma_g^2 dt)
   int ba_lds_bytes;         // dynamic LDS of a k_ba_worker workgroup: what it leaves of a CU's 160 KB is there for the tracker's waves
-  int ba_drain;             // keyframes a local-map workgroup takes from its stream's queue per launch at most (0: until the queue is empty)
+  int ba_drain;             // keyframes a local-map workgroup takes from its stream's queue per launch (0: until the queue is empty) ...
+  int ba_backlog;           // ... and it goes on while the queue still holds this many or more: the bound the back-pressure relies on
   int ba_mfma;              // Schur complement of the window solver on the matrix cores (v_mfma_f64_16x16x4_f64) or as register tiles
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
   // local-map feedback (F2FTracking::correction_feed, dead in the reference's v2)

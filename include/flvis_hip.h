@@ -424,8 +424,17 @@ int flvis_write_trajectory(flvis_ctx* ctx, int stream, int first_frame, int n_fr
  * call only; a batch that is appended (append != 0; flvis_get_imu_states hands out at most 512 rows per fetch) is written in full.
  * Returns the number of lines written, FLVIS_ERR_INVALID_ARG for bad arguments or FLVIS_ERR_CONFIG when the file cannot be opened. */
 int flvis_write_imu_trajectory(const double* h_rows11, int n, const char* path, double min_dt, int append);
+/* The same with the run's first stamp named by the caller (t_first = h_rows11[0] of the run's first batch; NaN: no throttle): rows
+ * within min_dt of t_first are dropped in EVERY batch, also when the batch that created the file was shorter than min_dt
+ * (the recorder's last_time is set once and never updated, vo_repub_rec.cpp:77-78). */
+int flvis_write_imu_trajectory_run(const double* h_rows11, int n, const char* path, double min_dt, int append, double t_first);
 /* Counters: [0] frames fed, [1] keyframes, [2] BA runs. */
 int flvis_get_counters(flvis_ctx* ctx, int64_t* h_counters3);
+/* The first n (1 .. 4) of: [0] frames fed, [1] keyframes, [2] BA runs, [3] keyframes dropped at a full keyframe queue -- what the
+ * reference's /vo_kf subscriber (queue size 10, src/backend/vo_localmap.cpp:452-456) does when the local map is slower than the tracker.
+ * The tracker's stream-ordered back-pressure keeps a queue below its capacity, so [3] stays 0 unless a caller pushes keyframes itself
+ * (flvis_ba_push_keyframe) faster than it lets the local map run. */
+int flvis_get_counters_n(flvis_ctx* ctx, int n, int64_t* h_counters);
 /* Per stream (arrays of n_streams, either may be NULL): keyframes the tracker has emitted and optimisations the stream's local map has
  * run (one per keyframe once the window holds window_size keyframes, vo_localmap.cpp:211-214,292-366).  Drains the queues first. */
 int flvis_get_local_map_counts(flvis_ctx* ctx, int64_t* h_keyframes, int64_t* h_ba_runs);

@@ -184,3 +184,31 @@ def test_imu_trajectory_recorder_throttle_is_per_run_not_per_batch(tmp_path):
     assert n_one == 900 - 21 and n_a == 512 - 21 and n_b == 388      # stamps 0.000 .. 0.100 s after the first are dropped once
     assert open(one).read() == open(two).read()
     assert lib.flvis_write_imu_trajectory(ptr(rows), 900, str(tmp_path / "no" / "such" / "dir.txt").encode(), 0.1, 0) == -5      # FLVIS_ERR_CONFIG
+
+
+def test_imu_trajectory_recorder_first_batch_shorter_than_the_throttle(tmp_path):
+    """flvis_write_imu_trajectory_run: a run fetched in small batches (an early flvis_get_imu_states after 8 samples = 0.035 s, less
+    than min_dt) -- with the run's first stamp named in every call the appended batches are throttled against THAT stamp too, and the
+    file equals the one a single call with all rows writes."""
+    import flvis_amd
+    lib = flvis_amd.load_library()
+    lib.flvis_write_imu_trajectory.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_char_p, C.c_double, C.c_int]
+    lib.flvis_write_imu_trajectory_run.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_char_p, C.c_double, C.c_int, C.c_double]
+    rows = np.zeros((300, 11))
+    rows[:, 0] = 1403636579.0 + np.arange(300) * 0.005
+    rows[:, 1] = 1.0
+    rows[:, 5:8] = np.arange(900).reshape(300, 3) * 1e-3
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    one = str(tmp_path / "one.txt").encode()
+    many = str(tmp_path / "many.txt").encode()
+    n_one = lib.flvis_write_imu_trajectory(ptr(rows), 300, one, 0.1, 0)
+    t0 = float(rows[0, 0])
+    n_many, first = 0, True
+    for lo, hi in ((0, 8), (8, 15), (15, 40), (40, 300)):
+        part = np.ascontiguousarray(rows[lo:hi])
+        n_many += lib.flvis_write_imu_trajectory_run(ptr(part), hi - lo, many, 0.1, 0 if first else 1, t0)
+        first = False
+    assert n_one == n_many == 300 - 21
+    assert open(one).read() == open(many).read()
+    # NaN as the first stamp: no throttle
+    assert lib.flvis_write_imu_trajectory_run(ptr(rows), 300, many, 0.1, 0, float("nan")) == 300

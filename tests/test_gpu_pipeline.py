@@ -46,7 +46,87 @@ def _cfgs_yaml(text, tag):
     return cfg, ocfg
 
 
-def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf, depth_range=None, imu=True, t_offset=0.0):
+class _HostFeeder:
+    """The caller's side of flvis_image_feed_host (what image_input_callback holds: two cv::Mat per frame, vo_tracking.cpp:396-430):
+    host buffers in the layout a test asks for, handed over and then deliberately overwritten as soon as the contract allows it --
+    right after the call with hold_buffers = 0, after the NEXT call has returned with hold_buffers = 1 -- so that an upload still in
+    flight when the buffer is reused, or a frame that reads the staging slot of its successor, breaks the lockstep comparison.
+    layout: "block" (one [S][H][W*c] block: a single copy), "separate" (one allocation per image), "padded" (rows padded by 64 B);
+    pinned: page-locked memory (truly asynchronous uploads) or pageable."""
+
+    def __init__(self, S, channels=1, hold=0, layout="block", pinned=True, scribble=True):
+        self.S, self.ch, self.hold, self.layout, self.pinned, self.scribble = S, channels, hold, layout, pinned, scribble
+        self.sets = {}
+        self.n = 0
+        self.prev = None
+        self.rng = np.random.default_rng(99)
+
+    def _alloc(self, nbytes):
+        import torch
+        t = torch.empty(nbytes, dtype=torch.uint8, pin_memory=self.pinned)
+        return t, t.numpy()
+
+    def _views(self, key, shape, dtype):
+        """S per-stream views [H, W(, c)] of this set's buffers (allocated once per set and camera)."""
+        if key not in self.sets:
+            H, W = shape[0], shape[1]
+            c = shape[2] if len(shape) == 3 else 1
+            row = W * c * np.dtype(dtype).itemsize
+            pitch = row + (64 if self.layout == "padded" else 0)
+            keep, views = [], []
+            if self.layout == "separate":
+                for s in range(self.S):
+                    t, a = self._alloc(H * pitch + 4096 * (s % 3))      # (different sizes: never one contiguous block)
+                    keep.append(t)
+                    views.append(a[:H * pitch])
+            else:
+                t, a = self._alloc(self.S * H * pitch)
+                keep.append(t)
+                views = [a[s * H * pitch:(s + 1) * H * pitch] for s in range(self.S)]
+            out = []
+            for v in views:
+                v = v.reshape(H, pitch)[:, :row]
+                v = v.view(dtype)
+                out.append(v.reshape(H, W, c) if c > 1 else v.reshape(H, W))
+            self.sets[key] = (keep, out)
+        return self.sets[key][1]
+
+    def colour(self, gray):
+        """A BGR(A) image whose channels differ (so that the conversion's weights matter), from a rendered mono image."""
+        g = gray.astype(np.int16)
+        d = self.rng.integers(-12, 13, size=gray.shape + (3,), dtype=np.int16)
+        bgr = np.clip(g[..., None] + d, 0, 255).astype(np.uint8)
+        if self.ch == 4:
+            bgr = np.concatenate([bgr, self.rng.integers(0, 256, size=gray.shape + (1,), dtype=np.uint8)], axis=-1)
+        return bgr
+
+    def feed(self, trk, h0, h1, times, depth, **kw):
+        """h0 / h1: [S, H, W] mono (h1 uint16 on depth rigs).  Returns (outs, the mono images the tracker must have worked on)."""
+        k = self.n % 2 if self.hold else 0
+        src0 = [self.colour(h0[s]) for s in range(self.S)] if self.ch > 1 else list(h0)
+        src1 = [self.colour(h1[s]) for s in range(self.S)] if (self.ch > 1 and not depth) else list(h1)
+        v0 = self._views((k, 0), src0[0].shape, src0[0].dtype)
+        v1 = self._views((k, 1), src1[0].shape, src1[0].dtype)
+        for s in range(self.S):
+            v0[s][...] = src0[s]
+            v1[s][...] = src1[s]
+        outs = trk.image_feed_host(v0, v1, times, hold_buffers=bool(self.hold), **kw)
+        if self.scribble:
+            if not self.hold:
+                for v in v0 + v1:
+                    v[...] = 0xA5        # "the caller may reuse its buffers immediately"
+            elif self.prev is not None:
+                for v in self.prev:
+                    v[...] = 0x5A        # the previous call's buffers are free now that this call has returned
+        self.prev = v0 + v1
+        self.n += 1
+        g0 = np.stack([O.cvt_bgr_to_gray(x) for x in src0]) if self.ch > 1 else h0
+        g1 = np.stack([O.cvt_bgr_to_gray(x) for x in src1]) if (self.ch > 1 and not depth) else h1
+        return outs, g0, g1
+
+
+def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf, depth_range=None, imu=True, t_offset=0.0, host=None,
+                         check=None):
     import flvis_amd
     from flvis_amd import synth
     S = len(streams)
@@ -54,7 +134,9 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
     rnd = synth.Renderer("cuda", rig=rig)
     seed_base = 0xF1715
     trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=seed_base, traj_capacity=nframes)
-    refs = [O.Tracker(ocfg, seed_base + i) for i in range(S)]
+    check = list(range(S)) if check is None else list(check)     # the streams run beside the oracle (all of them by default)
+    refs = {i: O.Tracker(ocfg, seed_base + i) for i in check}
+    feeder = _HostFeeder(S, **host) if host is not None else None
     t_prev = -0.05
     n_kf = n_imu_links = n_imu_rows = 0
     lock_frames = [0] * S      # tracked frames (all compared exactly)
@@ -67,8 +149,9 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
             smp = synth.imu_samples(trajs[i], s, t_prev, t)
             smp[:, 0] += t_offset                      # stamps as a dataset carries them (EuRoC: seconds since 1970)
             trk.imu_feed_flvis(i, smp)
-            for r in smp:
-                imu_want[i].append(np.concatenate([[r[0]], refs[i].imu(r[0], r[1:4], r[4:7])]))
+            if i in refs:
+                for r in smp:
+                    imu_want[i].append(np.concatenate([[r[0]], refs[i].imu(r[0], r[1:4], r[4:7])]))
         t_prev = t
         if depth_range is None:
             i0, i1 = rnd.stereo_frame(trajs, t, f)
@@ -76,8 +159,11 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
         else:  # depth-camera mode: the second image is the Z16 depth image aligned to cam0
             i0, i1 = rnd.depth_frame(trajs, t, f, max_range=depth_range)
             h0, h1 = i0.cpu().numpy(), i1.cpu().numpy().view(np.uint16)
-        outs = trk.image_feed(i0, i1, [t + t_offset] * S, with_local_map=False)
-        for i in range(S):
+        if feeder is None:
+            outs = trk.image_feed(i0, i1, [t + t_offset] * S, with_local_map=False)
+        else:   # the nodelet's entry: host images in (and, for colour input, the mono images cvtColor makes of them for the oracle)
+            outs, h0, h1 = feeder.feed(trk, h0, h1, [t + t_offset] * S, depth_range is not None, with_local_map=False)
+        for i in check:
             # the IMU-rate trajectory (/imu_pose, what the reference records on EuRoC): every sample's q / p / v bit-identical;
             # fetched every third frame so that a fetch spans several image feeds (and the vision corrections between them)
             if imu and (f % 3 == 2 or f == nframes - 1):
@@ -114,9 +200,9 @@ def _run_frontend_parity(ctx, cfg, ocfg, rig, streams, nframes, min_lock, min_kf
                 assert np.array_equal(gdp, wdp) and np.array_equal(gva, wva), (where, gdp - wdp, gva - wva)
                 n_imu_links += int(wv)
     assert n_kf >= min_kf
-    assert (n_imu_rows >= 9 * S * (nframes - 1)) if imu else (n_imu_rows == 0)
-    assert (n_imu_links >= (min_kf - S) // 2) if imu else (n_imu_links == 0)
-    assert min(lock_frames) >= min_lock, lock_frames
+    assert (n_imu_rows >= 9 * len(check) * (nframes - 1)) if imu else (n_imu_rows == 0)
+    assert (n_imu_links >= (min_kf - len(check)) // 2) if imu else (n_imu_links == 0)
+    assert min(lock_frames[i] for i in check) >= min_lock, lock_frames
     rows = trk.trajectory(0, 0, nframes)
     assert np.allclose(rows[:, 0], np.arange(nframes) / synth.FRAME_HZ + t_offset, rtol=0, atol=1e-6)
 
@@ -177,6 +263,148 @@ def test_frontend_parity_kitti_mode(ctx):
     trk = flvis_amd.Tracker(ctx, cfg, 1)
     with pytest.raises(flvis_amd.FlvisError):          # imu_callback has no remap for imu_type NONE
         trk.imu_feed_sensor(0, 0.0, [0, 0, 9.81], [0, 0, 0])
+
+
+# ---- the boundary's real entry: flvis_image_feed_host (what ros/src/tracking_nodelet.cpp and INTEGRATION.md call) in lockstep ----
+
+def test_host_feed_parity_two_streams_buffers_reused_at_once(ctx):
+    """The two-stream lockstep run through flvis_image_feed_host: page-locked mono8 images in one block, hold_buffers = 0, and the
+    caller overwrites its buffers the moment the call returns.  Same asserts as test_frontend_parity_two_streams (state, keyframe
+    flag, ids, flags, pixels, 3-D points, fp64 pose bit-identical, every frame)."""
+    cfg, ocfg = _cfgs()
+    _run_frontend_parity(ctx, cfg, ocfg, None, [3, 140], 100, 49, 4, host=dict(channels=1, hold=0, layout="block", pinned=True))
+
+
+def test_host_feed_parity_batch_of_64_held_buffers(ctx):
+    """S = 64 (BASELINE configs[3]'s batch) through the host entry with hold_buffers = 1: the call returns while the 39 MB of uploads
+    are still in flight, the caller alternates two buffer sets and overwrites a set only after the NEXT call has returned.  Streams
+    0, 31 and 63 run beside the oracle in lockstep."""
+    cfg, ocfg = _cfgs()
+    streams = [3 + 7 * i for i in range(64)]
+    _run_frontend_parity(ctx, cfg, ocfg, None, streams, 50 + 30, 29, 6, host=dict(channels=1, hold=1, layout="block", pinned=True),
+                         check=[0, 31, 63])
+
+
+def test_host_feed_parity_batch_of_64_pageable_reused_at_once(ctx):
+    """The same batch from pageable memory in one allocation per image (64 + 64 copies per frame), hold_buffers = 0, overwritten at once."""
+    cfg, ocfg = _cfgs()
+    streams = [3 + 7 * i for i in range(64)]
+    _run_frontend_parity(ctx, cfg, ocfg, None, streams, 50 + 16, 15, 3, host=dict(channels=1, hold=0, layout="separate", pinned=False),
+                         check=[0, 63])
+
+
+def test_host_feed_parity_euroc_mode_bgr_padded_rows(ctx):
+    """EuRoC mode (752 x 480, equalizeHist) from 3-channel BGR images with padded rows in pageable memory: the conversion
+    (cv::cvtColor at f2f_tracking.cpp:74-111) runs on the device, the oracle gets the restated conversion's mono images."""
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
+    _run_frontend_parity(ctx, cfg, ocfg, synth.euroc_rig(), [9], 60, 50, 2, host=dict(channels=3, hold=0, layout="padded", pinned=False))
+
+
+def test_host_feed_parity_depth_camera_mode_bgra_and_z16(ctx):
+    """Depth rig: img0 as BGRA, img1 the 16UC1 depth image (2 bytes per pixel), separate allocations, held buffers."""
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.D435I_DEPTH_YAML, "d435i_depth")
+    _run_frontend_parity(ctx, cfg, ocfg, None, [3, 77], 50 + 36, 35, 3, depth_range=3.3,
+                         host=dict(channels=4, hold=1, layout="separate", pinned=True))
+
+
+def test_host_feed_parity_kitti_mode_unaligned_rows(ctx):
+    """KITTI-like rig: 1241-pixel rows (not dword aligned) from page-locked memory, padded, reused at once."""
+    from flvis_amd import synth
+    cfg, ocfg = _cfgs_yaml(synth.KITTI_LIKE_YAML, "kitti_like")
+    _run_frontend_parity(ctx, cfg, ocfg, synth.kitti_like_rig(), [5, 77], 26, 26, 3, imu=False,
+                         host=dict(channels=1, hold=0, layout="padded", pinned=True))
+
+
+@pytest.mark.parametrize("hold", [0, 1])
+def test_host_feed_without_readback_equals_the_resident_run(ctx, hold):
+    """The throughput form of the host entry (h_out = NULL: the call never synchronises, so uploads, staging slots and frames really
+    overlap -- bench.py's with_h2d leg) with the local map on, buffers overwritten as early as the contract allows: the whole
+    trajectory of every stream, the last landmarks and the last CorrectionInf are bit-identical to a run of the same frames through
+    flvis_image_feed with device-resident images.  An upload racing the previous frame's ingest, or a staging slot refilled before
+    its frame has consumed it, shows here."""
+    import flvis_amd
+    from flvis_amd import synth
+    cfg, _ = _cfgs()
+    S, nframes = 64, 50 + 30
+    streams = [5 + 3 * i for i in range(S)]
+    res = []
+    for mode in ("resident", "host"):
+        trajs = [synth.Trajectory(s) for s in streams]
+        rnd = synth.Renderer("cuda")
+        trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715, traj_capacity=nframes)
+        feeder = _HostFeeder(S, channels=1, hold=hold, layout="block", pinned=True)
+        t_prev = -0.05
+        for f in range(nframes):
+            t = f / synth.FRAME_HZ
+            for i, s in enumerate(streams):
+                trk.imu_feed_flvis(i, synth.imu_samples(trajs[i], s, t_prev, t))
+            t_prev = t
+            i0, i1 = rnd.stereo_frame(trajs, t, f)
+            if mode == "resident":
+                trk.image_feed(i0, i1, [t] * S, want_out=False, with_local_map=True)
+                ctx.synchronize()           # (the renderer reuses nothing, but keep the resident run simple: one frame at a time)
+            else:
+                feeder.feed(trk, i0.cpu().numpy(), i1.cpu().numpy(), [t] * S, False, want_out=False, with_local_map=True)
+        rows = np.stack([trk.trajectory(i, 0, nframes) for i in range(S)])
+        lms = [trk.landmarks(i) for i in (0, S - 1)]
+        corr = [trk.correction(i) for i in (0, S - 1)]
+        cnt = trk.counters()
+        res.append((rows, lms, corr, cnt))
+        del trk
+    (ra, la, ca, na), (rb, lb, cb, nb) = res
+    assert np.all((ra[:, 50:, 8].astype(int) & 15) == 1)                        # every stream tracked after the skipped frames
+    assert np.array_equal(ra, rb), np.abs(ra - rb).max()
+    for x, y in zip(la, lb):
+        for k in ("ids", "flags", "p2d", "p2u", "p3w"):
+            assert np.array_equal(x[k], y[k]), k
+    for x, y in zip(ca, cb):
+        assert x is not None and y is not None and x["frame_id"] == y["frame_id"]
+        assert np.array_equal(x["lm_id"], y["lm_id"]) and np.array_equal(x["outlier_id"], y["outlier_id"])
+        assert np.array_equal(x["pose7"], y["pose7"]) and np.array_equal(x["lm_3d"], y["lm_3d"])
+    assert list(na) == list(nb), (na, nb)
+
+
+def test_keyframe_queue_is_bounded_when_the_local_map_lags(ctx):
+    """The local-map worker is launched every 8th frame only (FLVIS_BA_EVERY=8) while the batch runs flat out without readback: a
+    launch that took one keyframe per stream (round 4's default) would consume a keyframe per 8 frames where the tracker makes one
+    every second frame, and k_frame_end would drop keyframes at the full queue.  A launch takes at least the keyframes of the frames
+    between two launches and stays while half a queue is waiting; the tracker waits in stream order: nothing is dropped, and every
+    keyframe is optimised exactly once."""
+    import flvis_amd
+    from flvis_amd import synth
+    cfg, _ = _cfgs()
+    S, nframes = 16, 50 + 120
+    streams = [11 + 5 * i for i in range(S)]
+    old = os.environ.get("FLVIS_BA_EVERY")
+    os.environ["FLVIS_BA_EVERY"] = "8"
+    try:
+        trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715)
+    finally:
+        if old is None:
+            os.environ.pop("FLVIS_BA_EVERY", None)
+        else:
+            os.environ["FLVIS_BA_EVERY"] = old
+    trajs = [synth.Trajectory(s) for s in streams]
+    rnd = synth.Renderer("cuda")
+    frames = []
+    for f in range(nframes):        # rendered up front (kept on the device) so that the frames really run back to back
+        frames.append(rnd.stereo_frame(trajs, f / synth.FRAME_HZ, f))
+    t_prev = -0.05
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        for i, s in enumerate(streams):
+            trk.imu_feed_flvis(i, synth.imu_samples(trajs[i], s, t_prev, t))
+        t_prev = t
+        trk.image_feed(frames[f][0], frames[f][1], [t] * S, want_out=False, with_local_map=True)
+    ctx.synchronize()
+    kf, ba = trk.local_map_counts()
+    assert trk.dropped_keyframes() == 0
+    assert kf.min() >= 30, kf                      # a keyframe every second or third tracked frame
+    # flvis_hip_synchronize drained the queues: one optimisation per keyframe once the window is full (vo_localmap.cpp:122-124)
+    assert np.array_equal(ba, kf - (cfg.window_size - 1)), (kf, ba)
+    del trk
 
 
 def _run_plain(ctx, cfg, streams, nframes, env):
