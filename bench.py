@@ -664,6 +664,7 @@ def main():
                 ctx._check(lib.flvis_debug_counters(ctx._h, dbg), "debug_counters")
                 ba = {"runs": int(dbg[2]), "trials": int(dbg[4]), "trials_items": int(dbg[5]), "trials_landmarks": int(dbg[6]),
                       "trials_poses": int(dbg[7]), "ms_per_optimisation": (dbg[60] * 1e-5 / dbg[2]) if dbg[2] else None,
+                      "chunked_runs": int(dbg[28]), "ms_per_chunked_optimisation": (dbg[29] * 1e-5 / dbg[28]) if dbg[28] else None,
                       "worker_ms_per_launch": stages.get("ba_worker(launch)")}
                 kpmc, kpmc_src = read_kernel_pmc(S)
                 copy_gbs = out["roofline"].get("hbm_copy_measured", {}).get("GB/s")

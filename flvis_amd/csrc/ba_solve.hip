@@ -68,24 +68,26 @@ typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) int gint;
 typedef __attribute__((address_space(1))) unsigned guint;
 
-struct BAScratch {  // carved out of Pipe::ba_scratch per stream; Lc / Ec = landmark / item strides (multiples of 64)
+struct BAScratch {  // carved out of Pipe::ba_scratch per stream; Lc = landmark stride (a multiple of 64)
   gdouble* lmA;     // [3][Lc]  accepted landmark estimates
   gdouble* lmB;     // [3][Lc]  trial estimates (roles swap on acceptance)
   gdouble* Hll;     // [6][Lc]  xx xy xz yy yz zz
   gdouble* bl;      // [3][Lc]
   gdouble* uv;      // [W][2][Lc]
-  gdouble* BdI;     // [18][Ec]  w Jp^T Jl (6x3, row-major) per item
-  gdouble* HllI;    // [6][Ec]   the owning landmark's Hll, replicated per item (saves the staging a dependent load)
   gint* eid;        // [W][Lc]  edge index or -1
   guint* omask;     // [Lc]  bit slot: landmark has an alive edge to the pose in ring slot `slot`
   guint* fmask;     // [Lc]  bit h: ... to FREE pose h (hessian index)
   gint* ibase;      // [Lc + 64]  first item of landmark l (exclusive prefix of popc(fmask)), ibase[L] = item count
   gint* e_alive;    // [E]
-  int Lc, Ec;
+  int Lc;
 };
+// (Rounds 1-4 also kept, per observation by a free pose, the 6x3 block B = w Jp^T Jl and a copy of its landmark's Hll in HBM: written by
+// every linearisation, read back by every trial -- 164 MB per launch, ~100 x the keyframes' own bytes (round-4 counters).  B has rank 2:
+// Z = B G^-T = Jp^T (w Jl G^-T) = Jp^T M with Jp a function of three numbers (x/z, y/z, 1/z).  The Schur phase now rebuilds (x/z, y/z,
+// 1/z, M) per observation from the landmark, the pose and the pixel -- 9 doubles in LDS instead of 24 through HBM.)
 
 size_t ba_scratch_doubles() {
-  size_t d = (size_t)BA_LMAX * (3 + 3 + 6 + 3) + (size_t)BA_LMAX * BA_WMAX * 2 + (size_t)BA_EMAX * (18 + 6);
+  size_t d = (size_t)BA_LMAX * (3 + 3 + 6 + 3) + (size_t)BA_LMAX * BA_WMAX * 2;
   size_t ints = (size_t)BA_LMAX * BA_WMAX + (size_t)BA_LMAX * 3 + 64 + BA_EMAX + 64;
   return ((d + (ints + 1) / 2 + 64) + 1) & ~(size_t)1;  // even: 16-byte alignment of every stream's slice
 }
@@ -93,23 +95,20 @@ size_t ba_scratch_doubles() {
 FD BAScratch carve(double* base, int L, int E, int W) {
   BAScratch s;
   const int Lc = ((L > 0 ? L : 1) + 63) & ~63;
-  const int Ec = ((E > 0 ? E : 1) + 63) & ~63;
   s.Lc = Lc;
-  s.Ec = Ec;
   gdouble* q = (gdouble*)base;
   s.lmA = q; q += (size_t)3 * Lc;
   s.lmB = q; q += (size_t)3 * Lc;
   s.Hll = q; q += (size_t)6 * Lc;
   s.bl = q; q += (size_t)3 * Lc;
   s.uv = q; q += (size_t)2 * W * Lc;
-  s.BdI = q; q += (size_t)18 * Ec;
-  s.HllI = q; q += (size_t)6 * Ec;
   gint* ii = (gint*)q;
   s.eid = ii; ii += (size_t)W * Lc;
   s.omask = (guint*)ii; ii += Lc;
   s.fmask = (guint*)ii; ii += Lc;
   s.ibase = ii; ii += Lc + 64;
   s.e_alive = ii;
+  (void)E;
   return s;
 }
 
@@ -119,7 +118,8 @@ struct BAShared {
   double RT[BA_WMAX][12];    // rotation matrix (row-major) + translation of pose / poseT
   double RTt[BA_WMAX][12];
   double Hpp[BA_PMAX][36];
-  double b[BA_NRMAX];
+  double b[BA_NRMAX];      // pose gradient (-J^T W r) of the linearised system; "inline" iterations: its IMU part only (see ba_phase_schur)
+  double bfull[BA_NRMAX];  // ... always the whole gradient (written by the Schur phase): what the gain ratio's scale is formed with
   double x[BA_NRMAX];
   double red[2][BA_NW];
   double K[4];
@@ -131,7 +131,9 @@ struct BAShared {
   int lds_budget;  // dynamic LDS of this launch (Pipe::ba_lds_bytes): sizes the Schur chunk buffers
   int n_trials;  // LM trials (reduced-system solves) of this optimisation: flop accounting of bench.py
   long long t_begin;  // wall_clock64 (100 MHz) at the start of the optimisation
-  int NR, LD, off_linv, off_stage;  // reduced system geometry: Hs[NR][LD], Linv, chunk buffers (double offsets)
+  int NR, LD, off_linv, off_imu, off_stage;  // reduced system geometry: Hs[NR][LD], Linv, IMU blocks, chunk buffers (double offsets)
+  int fused;       // the window's items fit ONE chunk: their records stay in LDS for the whole optimisation (see ba_phase_linearize)
+  int fixed_slot;  // ring slot of the fixed pose if it has observations (its pixels are the only ones read from HBM per phase then), else -1
   int CI, CL, bufd, nchunk;         // chunk capacities (items, landmarks), doubles per buffer, chunk count
   int npairs, slices, rs;           // role partition of the Schur phase
   int use_mfma, NRp, CLm, nchunk_m;  // MFMA variant of the Schur phase: padded system size, landmarks per dense chunk
@@ -140,16 +142,17 @@ struct BAShared {
   double imu_w[BA_WMAX], imu_dq[BA_WMAX][4], q_c_b[4];
   // position rows (imu_wp[k] > 0): preintegrated displacement, velocity of keyframe a, interval; t_c_b = body origin in the camera frame
   double imu_wp[BA_WMAX], imu_dp[BA_WMAX][3], imu_va[BA_WMAX][3], imu_dtk[BA_WMAX], t_c_b[3];
-  double imu_aa[BA_WMAX][36], imu_bb[BA_WMAX][36], imu_ab[BA_WMAX][36], imu_ga[BA_WMAX][6], imu_gb[BA_WMAX][6];
+  // (the edges' linearised blocks -- Ja^T W Ja, Jb^T W Jb, Ja^T W Jb, the two gradients: 120 doubles per edge -- live in dynamic LDS at
+  // off_imu, only when the factor is on: 17 KB of static LDS otherwise taken from the Schur buffers of every window)
   double imu_chi[BA_WMAX], imu_chit[BA_WMAX];  // w |r|^2 at the accepted / the trial poses
   int wscan[BA_NW];
   int chunk_l0[BA_MAXCHUNK + 1];    // first landmark / first item of every chunk
   int chunk_i0[BA_MAXCHUNK + 1];
   long long* prof;  // optional phase timers (FLVIS_BA_PROF builds)
   long long tlast;
-  // (FLVIS_BA_PROF) per call of the Schur phase: the slowest and the summed accumulate time / block products over the pair threads
-  int pf_tmax, pf_tsum, pf_nmax, pf_nsum, pf_threads;
-  // followed in dynamic LDS by: Hs[NR][NR+1], Linv[P][36], then the two chunk buffers
+  long long prof_acc[16];
+  // followed in dynamic LDS by: Hs[NR][NR+1], Linv[P][36], the IMU blocks, then the chunk buffer(s); the per-wave partial sums of the
+  // linearisation lie over Hs (dead until the Schur phase writes it)
 };
 
 // all per-window working state lives in dynamic LDS; the phase functions re-derive it from this symbol so that the
@@ -158,15 +161,41 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ba_smem[];
 constexpr size_t BA_SH_BYTES = ((sizeof(BAShared) + 15) / 16) * 16;
 FD BAShared& ba_sh() { return *reinterpret_cast<BAShared*>(ba_smem); }
 FD double* ba_dyn() { return reinterpret_cast<double*>(ba_smem + BA_SH_BYTES); }
+// IMU edge k's blocks: which = 0 Ja^T W Ja, 1 Jb^T W Jb, 2 Ja^T W Jb (36 doubles each), 3 / 4 the gradients Ja^T W r / Jb^T W r (6 each)
+// Chunk buffer `buf` of the Schur phase.  Per item (an observation by a free pose) a record of three 16-byte pairs [3][CI]:
+//   (xn, yn) (iz, w) (u, v)  -- the point in the camera (x/z, y/z, 1/z) at the linearisation point, the Huber weight, the pixel;
+// per landmark [CL]: G (the factor of Hll + lambda I: i00 g10 g20 i11 g21 i22), c = G^-1 bl, its free-pose mask, its first local item.
+struct SchurBuf {
+  double2* z;
+  double *gb, *cb;
+  unsigned* mb;
+  int* lb;
+};
+FD SchurBuf ba_schur_buf(int buf);
+FD double* ba_imu_blk(int k, int which) { return ba_dyn() + ba_sh().off_imu + k * 120 + (which < 3 ? 36 * which : 108 + 6 * (which - 3)); }
+
+FD SchurBuf ba_schur_buf(int buf) {
+  BAShared& sh = ba_sh();
+  SchurBuf b;
+  double* zb = ba_dyn() + sh.off_stage + (size_t)buf * sh.bufd;
+  b.z = reinterpret_cast<double2*>(zb);
+  b.gb = zb + (size_t)6 * sh.CI;
+  b.cb = b.gb + (size_t)6 * sh.CL;
+  b.mb = reinterpret_cast<unsigned*>(b.cb + (size_t)3 * sh.CL);
+  b.lb = reinterpret_cast<int*>(b.mb + sh.CL);
+  return b;
+}
 
 #ifdef FLVIS_BA_PROF
-#define BAPROF(i)                                                                          \
-  do {                                                                                     \
-    if (threadIdx.x == 0 && sh.prof) {                                                     \
-      long long now_ = (long long)wall_clock64();                                          \
-      atomicAdd((unsigned long long*)&sh.prof[i], (unsigned long long)(now_ - sh.tlast)); \
-      sh.tlast = now_;                                                                     \
-    }                                                                                      \
+// (the phase timers are summed in LDS and written out once per optimisation: a global atomic per mark had to drain before the next
+// barrier and added a microsecond or two to whatever phase followed it)
+#define BAPROF(i)                                  \
+  do {                                             \
+    if (threadIdx.x == 0 && sh.prof) {             \
+      long long now_ = (long long)wall_clock64();  \
+      sh.prof_acc[i] += now_ - sh.tlast;           \
+      sh.tlast = now_;                             \
+    }                                              \
   } while (0)
 #else
 #define BAPROF(i) \
@@ -347,20 +376,26 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
       }
     }
     sh.P = P;
-    const int NR = 6 * P, LD = NR + 1;
+    // the poses that are not free but observed: the fixed (oldest) one.  More than one (more than BA_PMAX free poses) rules out the
+    // resident records below, whose phases read one such pose's pixels per landmark
+    int fs = -1, nfs = 0;
+    for (int slot = 0; slot < W; slot++)
+      if (sh.hidx_of[slot] < 0 && sh.slot_cnt[slot] > 0) {
+        fs = slot;
+        nfs++;
+      }
+    sh.fixed_slot = nfs == 1 ? fs : -1;
+    sh.fused = nfs <= 1 ? 1 : 0;  // (and one chunk, not the matrix-core variant: decided with the chunk table below)
+    // leading dimension of the reduced system: rows 16-byte aligned (128-bit LDS reads of a row's 6-column blocks) and LD / 2 odd
+    // (the rows a wave's lanes read together fall into different bank groups)
+    const int NR = 6 * P, LD = (P & 1) ? NR + 4 : NR + 2;
     sh.NR = NR;
     sh.LD = LD;
     sh.off_linv = NR * LD;
-    sh.off_stage = NR * LD + P * 36;
-    // chunk buffers: per item 18 doubles (Z), per landmark 3 doubles (c) + mask word + local item base
-    const int per_buf = (((int)((sh.lds_budget - BA_SH_BYTES) / 8) - sh.off_stage) / 2) & ~1;
-    int CL = 256;
-    while (CL > 32 && CL * 4 > per_buf / 4) CL >>= 1;
-    int CI = (per_buf - CL * 4) / 18;
-    if (CI > BA_T) CI = BA_T;  // one staged item per thread
-    sh.CL = CL;
-    sh.CI = CI;
-    sh.bufd = per_buf;
+    // the per-wave partials of the linearisation (BA_NW x P x 27) lie over Hs / Linv: nothing behind them may start inside
+    const int wacc_end = BA_NW * 27 * P;
+    sh.off_imu = NR * LD + P * 36 > wacc_end ? NR * LD + P * 36 : wacc_end;
+    sh.off_stage = sh.off_imu + (sh.n_imu > 0 ? 120 * W : 0);
     const int npairs = P * (P + 1) / 2;
     int slices = 64;
     while (slices > 1 && slices * npairs > BA_T) slices >>= 1;
@@ -371,7 +406,8 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     sh.rs = rs;
     // MFMA variant: the chunk is the DENSE (NR + 1 rows padded to 16) x (3 columns per landmark) slice of Z' = [Z; c^T]
     const int NRp = (NR + 1 + 15) & ~15;
-    int CLm = ((2 * per_buf) / (3 * NRp)) & ~3;  // 3 * CLm columns, a multiple of the MFMA's K = 4
+    const int avail_m = ((int)((sh.lds_budget - BA_SH_BYTES) / 8) - sh.off_stage) & ~1;
+    int CLm = (avail_m / (3 * NRp)) & ~3;  // 3 * CLm columns, a multiple of the MFMA's K = 4
     if (CLm > 252) CLm = 252;
     sh.NRp = NRp;
     sh.CLm = CLm;
@@ -421,8 +457,27 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     }
   }
   __syncthreads();
-  if (t == 0) {  // greedy chunking: as many landmarks as fit both capacities
-    const int CI = sh.CI, CL = sh.CL;
+  if (t == 0) {
+    // Chunk buffers of the Schur phase (ba_schur_buf): 6 doubles per item, 10 per landmark.  A window whose items all fit (~1900 at
+    // 159 KB, 7 free poses and 550 landmarks: the D435 windows) is ONE chunk in one buffer -- its records stay resident, no barrier
+    // inside the phase; larger windows stream through two buffers.
+    const int avail = ((int)((sh.lds_budget - BA_SH_BYTES) / 8) - sh.off_stage) & ~1;
+    const int nit = lbase[L];
+    int CI, CL, bufd;
+    if (6 * ((nit + 1) & ~1) + 10 * ((L + 1) & ~1) <= avail) {
+      CI = nit > 0 ? ((nit + 1) & ~1) : 2;
+      CL = L > 0 ? ((L + 1) & ~1) : 2;
+      bufd = avail;
+    } else {
+      bufd = (avail / 2) & ~1;
+      CL = 256;
+      while (CL > 32 && CL * 10 > bufd / 4) CL >>= 1;  // (the landmark arrays take at most a quarter of a buffer)
+      CI = ((bufd - 10 * CL) / 6) & ~1;
+    }
+    sh.CL = CL;
+    sh.CI = CI;
+    sh.bufd = bufd;
+    // greedy chunking: as many landmarks as fit both capacities
     int c = 0, l0 = 0;
     while (l0 < L && c < BA_MAXCHUNK) {
       int lo = l0 + 1, hi = (l0 + CL < L) ? l0 + CL : L;  // invariant: [l0, lo) always fits (one landmark has <= P items)
@@ -440,8 +495,24 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     sh.chunk_l0[c] = L;
     sh.chunk_i0[c] = lbase[L];
     sh.nchunk = c;
+    if (c != 1 || sh.use_mfma) sh.fused = 0;
   }
   __syncthreads();
+  if (sh.fused) {
+    // resident records: the pixels of the items are written once per optimize() call (nothing rewrites the (u, v) pair); the phases then
+    // read no per-observation data from HBM any more.  (lbase, at the start of the same buffer, is dead now.)
+    double2* z = reinterpret_cast<double2*>(ba_dyn() + sh.off_stage);
+    const int CI = sh.CI;
+    for (int e = t; e < E; e += BA_T) {
+      if (!sc.e_alive[e]) continue;
+      const int hi = sh.hidx_of[w.e_pose[e]];
+      if (hi < 0) continue;
+      const int l = w.e_lidx[e];
+      const int idx = sc.ibase[l] + __popc(sc.fmask[l] & ((1u << hi) - 1u));
+      z[2 * CI + idx] = double2{w.e_uv[e][0], w.e_uv[e][1]};
+    }
+    __syncthreads();
+  }
 }
 
 // blocked (6x6) left-looking Cholesky of the lower triangle of Hs (leading dimension LD) by ONE wave, then the two
@@ -460,20 +531,21 @@ __device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
     // panel rows (including the diagonal block's rows): subtract the contributions of the finished block columns
     for (int rr = lane; rr < NR; rr += 64) {
       if (rr < c0) continue;
-      double a[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) a[c] = Hs[rr * LD + c0 + c];
+      double2* own = reinterpret_cast<double2*>(Hs + rr * LD);  // (rows are 16-byte aligned: three 128-bit accesses per 6-column block)
+      double2 a0 = own[c0 / 2], a1 = own[c0 / 2 + 1], a2 = own[c0 / 2 + 2];
+      double a[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
       for (int kb = 0; kb < jb; kb++) {
-        double lr[6];
+        const double2 l0 = own[3 * kb], l1 = own[3 * kb + 1], l2 = own[3 * kb + 2];
 #pragma unroll
-        for (int k = 0; k < 6; k++) lr[k] = Hs[rr * LD + 6 * kb + k];
-#pragma unroll
-        for (int c = 0; c < 6; c++)
-#pragma unroll
-          for (int k = 0; k < 6; k++) a[c] = fma(-lr[k], Hs[(c0 + c) * LD + 6 * kb + k], a[c]);
+        for (int c = 0; c < 6; c++) {
+          const double2* dr = reinterpret_cast<const double2*>(Hs + (c0 + c) * LD) + 3 * kb;  // (the same address in every lane: a broadcast)
+          const double2 d0 = dr[0], d1 = dr[1], d2 = dr[2];
+          a[c] = fma(-l2.y, d2.y, fma(-l2.x, d2.x, fma(-l1.y, d1.y, fma(-l1.x, d1.x, fma(-l0.y, d0.y, fma(-l0.x, d0.x, a[c]))))));
+        }
       }
-#pragma unroll
-      for (int c = 0; c < 6; c++) Hs[rr * LD + c0 + c] = a[c];
+      own[c0 / 2] = double2{a[0], a[1]};
+      own[c0 / 2 + 1] = double2{a[2], a[3]};
+      own[c0 / 2 + 2] = double2{a[4], a[5]};
     }
     wave_lds_fence();
     // diagonal block: every lane factors it redundantly in registers and inverts the factor
@@ -606,16 +678,211 @@ __device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
 // ---- phases of one LM iteration.  Each is a separate (non-inlined) function so that its register allocation is its own:
 // the phases share state only through LDS (BAShared) and the HBM scratch.
 
-// computeActiveErrors + buildSystem in one pass over the observations (thread per landmark, a wave walks the ring slots
-// together): Hll / bl per landmark, the B blocks per item, and per free pose the 21 + 6 entries of Hpp / bp, reduced over
+// ---- the factored observation blocks of the Schur phase.  For an observation of landmark l by free pose h, with the projection
+// Jacobians Jp (2x6) and Jl (2x3), the Huber weight w and (Hll + lambda I) = G G^T:
+//   Z = w Jp^T Jl G^-T = Jp^T M,  M = w Jl G^-T (2x3),   Z c = Jp^T (M c) = Jp^T r,   Z_i Z_j^T = Jp_i^T (M_i M_j^T) Jp_j,
+// and Jp is a function of (x/z, y/z, 1/z) of the point in the camera (types_six_dof_expmap.cpp:389-433): the record of an item is
+// (xn, yn, iz, M[6]) and the pixel (u, v) -- 11 doubles, stored as six 16-byte pairs [6][CI]:
+//   (xn, yn) (iz, M00) (M01, M02) (M10, M11) (M12, u) (v, -);   c = G^-1 bl is kept per landmark.
+struct JpRows {
+  double a0, a1, a2, a3, a5;  // row 0 (entry 4 is zero)
+  double b0, b1, b2, b4, b5;  // row 1 (entry 3 is zero)
+};
+FD JpRows jp_rows(double xn, double yn, double iz, double fx, double fy) {
+  JpRows J;
+  const double xy = xn * yn;
+  J.a0 = xy * fx;
+  J.a1 = -(1 + xn * xn) * fx;
+  J.a2 = yn * fx;
+  J.a3 = -iz * fx;
+  J.a5 = xn * iz * fx;
+  J.b0 = (1 + yn * yn) * fy;
+  J.b1 = -xy * fy;
+  J.b2 = -xn * fy;
+  J.b4 = -iz * fy;
+  J.b5 = yn * iz * fy;
+  return J;
+}
+// M = (w Jl) G^-T row by row (G lower, inverted diagonal)
+FD void ba_item_scale(const double (&wJl)[6], const Chol3& g, double (&M)[6]) {
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    M[3 * a] = wJl[3 * a] * g.i00;
+    M[3 * a + 1] = (wJl[3 * a + 1] - M[3 * a] * g.g10) * g.i11;
+    M[3 * a + 2] = (wJl[3 * a + 2] - M[3 * a] * g.g20 - M[3 * a + 1] * g.g21) * g.i22;
+  }
+}
+
+// One observation at the linearisation point (EdgeSE3ProjectXYZ::computeError + linearizeOplus, types_six_dof_expmap.cpp:389-433, and
+// RobustKernelHuber): normalised point (xn, yn, 1/z), residual, Huber weight, Jl (2x3, wrt the landmark) and w Jl.  The pose Jacobian
+// Jp follows from (xn, yn, iz) alone (jp_rows).
+struct BAObs {
+  double xn, yn, iz, e0, e1, wgt;
+  double Jl[6], wJl[6];
+};
+FD BAObs ba_obs(const double* rt, double px, double py, double pz, double u, double v, const double* K) {
+  BAObs o;
+  const double x = rt[0] * px + rt[1] * py + rt[2] * pz + rt[9];
+  const double y = rt[3] * px + rt[4] * py + rt[5] * pz + rt[10];
+  const double z = rt[6] * px + rt[7] * py + rt[8] * pz + rt[11];
+  o.iz = rcp_nr(z);
+  o.xn = x * o.iz;
+  o.yn = y * o.iz;
+  const double fx = K[0], fy = K[1];
+  o.e0 = u - (o.xn * fx + K[2]);
+  o.e1 = v - (o.yn * fy + K[3]);
+  o.wgt = ba_huber_w(o.e0 * o.e0 + o.e1 * o.e1);
+  const double ax = -o.iz * fx, ay = -o.iz * fy;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    o.Jl[c] = ax * (rt[c] - o.xn * rt[6 + c]);
+    o.Jl[3 + c] = ay * (rt[3 + c] - o.yn * rt[6 + c]);
+    o.wJl[c] = o.Jl[c] * o.wgt;
+    o.wJl[3 + c] = o.Jl[3 + c] * o.wgt;
+  }
+  return o;
+}
+// the observation's share of its landmark's Hll (xx xy xz yy yz zz) / bl and of the robust chi2
+FD double ba_obs_landmark(const BAObs& o, double (&h)[6], double (&bb)[3]) {
+  const double o0 = -o.e0 * o.wgt, o1 = -o.e1 * o.wgt;
+  int q = 0;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    bb[r] += o.Jl[r] * o0 + o.Jl[3 + r] * o1;
+#pragma unroll
+    for (int c = r; c < 3; c++) h[q++] += o.wJl[r] * o.Jl[c] + o.wJl[3 + r] * o.Jl[3 + c];
+  }
+  return ba_huber_rho(o.e0 * o.e0 + o.e1 * o.e1);
+}
+// ... and of its pose's Hpp (21 upper entries, row-major) / bp (6): pv[0 .. 26]
+FD void ba_obs_pose(const BAObs& o, const double* K, double (&pv)[32]) {
+  const JpRows J = jp_rows(o.xn, o.yn, o.iz, K[0], K[1]);
+  const double ja[6] = {J.a0, J.a1, J.a2, J.a3, 0.0, J.a5}, jb[6] = {J.b0, J.b1, J.b2, 0.0, J.b4, J.b5};
+  const double o0 = -o.e0 * o.wgt, o1 = -o.e1 * o.wgt;
+  int q = 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    pv[21 + r] = ja[r] * o0 + jb[r] * o1;
+#pragma unroll
+    for (int c = r; c < 6; c++) pv[q++] = (ja[r] * o.wgt) * ja[c] + (jb[r] * o.wgt) * jb[c];
+  }
+}
+
+// computeActiveErrors + buildSystem in one pass over the observations (thread per landmark, a wave walks the poses
+// together): Hll / bl per landmark and per free pose the 21 + 6 entries of Hpp / bp, reduced over
 // the wave with a scattered butterfly and accumulated per wave in LDS (fixed order -> reproducible).  Returns this
 // thread's share of the robust chi2.  ba_phase_finish_poses() folds the per-wave partials afterwards.
-__device__ FLVIS_BA_PHASE_FN double ba_phase_linearize() {
+// Resident records (sh.fused): the pixels come from the items' records in LDS (only the fixed pose's from HBM), and with lam > 0 --
+// the lambda of the trial that follows is known from the second iteration on -- the landmark's thread also leaves the SCALED records
+// and c = G^-1 bl behind, i.e. the staging of the Schur phase: that phase then starts with its products.
+// the linearisation over resident records (sh.fused).  POSE_SUMS: also Hpp / bp, a wave walking the poses together (reduce-scatter
+// per pose); without them every lane walks its own observations and nothing crosses lanes.  The records get the point in the camera
+// and the Huber weight; with lam > 0 (the lambda of the trial that follows is known from the second iteration on) the landmark's thread
+// also leaves G = chol(Hll + lam I) and c = G^-1 bl behind, i.e. the whole staging of the Schur phase.
+template <bool POSE_SUMS>
+FD double ba_linearize_resident(double lam) {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, L = sh.L, Lc = sc.Lc, Ec = sc.Ec, W = sh.W, P = sh.P;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, L = sh.L, Lc = sc.Lc, P = sh.P;
   const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
-  double* wacc = ba_dyn() + sh.off_stage + (size_t)wv * P * 27;  // [P][27] of this wave (chunk buffers are idle here)
+  double* wacc = ba_dyn() + (size_t)wv * P * 27;  // [P][27] of this wave, over Hs (dead until the Schur phase's combine)
+  if (POSE_SUMS) {
+    for (int i = lane; i < P * 27; i += 64) wacc[i] = 0.0;
+    wave_lds_fence();
+  }
+  double chi = 0;
+  const int CI = sh.CI, CL = sh.CL, fs = sh.fixed_slot;
+  const SchurBuf B = ba_schur_buf(0);
+  double2* z = B.z;
+  for (int l0 = wv * 64; l0 < L; l0 += BA_T) {
+    const int l = l0 + lane;
+    const unsigned m = l < L ? sc.omask[l] : 0u;
+    double px = 0, py = 0, pz = 1, uf = 0, vf = 0;
+    unsigned fm = 0;
+    int ib = 0;
+    const bool hf = fs >= 0 && ((m >> fs) & 1u);
+    if (m) {
+      px = sc.lmA[l];
+      py = sc.lmA[Lc + l];
+      pz = sc.lmA[2 * Lc + l];
+      fm = sc.fmask[l];
+      ib = sc.ibase[l];
+      if (hf) {
+        uf = sc.uv[(size_t)(2 * fs) * Lc + l];
+        vf = sc.uv[(size_t)(2 * fs + 1) * Lc + l];
+      }
+    }
+    double h[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+    if (hf) {
+      const BAObs o = ba_obs(sh.RT[fs], px, py, pz, uf, vf, K);
+      chi += ba_obs_landmark(o, h, bb);
+    }
+    int idx = ib;
+    if (!POSE_SUMS) {
+      unsigned rem = fm;
+#pragma unroll 1
+      while (rem) {
+        const int hi = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        const double2 uv = z[2 * CI + idx];
+        const BAObs o = ba_obs(sh.RT[sh.slot_of[hi]], px, py, pz, uv.x, uv.y, K);
+        chi += ba_obs_landmark(o, h, bb);
+        z[idx] = double2{o.xn, o.yn};
+        z[CI + idx] = double2{o.iz, o.wgt};
+        idx++;
+      }
+    } else {
+#pragma unroll 1
+      for (int hi = 0; hi < P; hi++) {  // (not unrolled: instruction-cache footprint)
+        const bool has = (fm >> hi) & 1u;
+        if (__ballot(has) == 0ull) continue;
+        double pv[32];
+#pragma unroll
+        for (int k = 0; k < 32; k++) pv[k] = 0;
+        if (has) {
+          const double2 uv = z[2 * CI + idx];
+          const BAObs o = ba_obs(sh.RT[sh.slot_of[hi]], px, py, pz, uv.x, uv.y, K);
+          chi += ba_obs_landmark(o, h, bb);
+          ba_obs_pose(o, K, pv);
+          z[idx] = double2{o.xn, o.yn};
+          z[CI + idx] = double2{o.iz, o.wgt};
+          idx++;
+        }
+        int k;
+        const double tot = wave_reduce_scatter32(pv, k);
+        if (!(lane & 1) && k < 27) wacc[hi * 27 + k] += tot;
+        wave_lds_fence();
+      }
+    }
+    if (m) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) sc.Hll[(size_t)j * Lc + l] = h[j];
+#pragma unroll
+      for (int j = 0; j < 3; j++) sc.bl[(size_t)j * Lc + l] = bb[j];
+    }
+    if (lam > 0 && fm) {  // the Schur staging for the trial at `lam`
+      const Chol3 g = chol3(h, lam);
+      const double c0 = bb[0] * g.i00;
+      const double c1 = (bb[1] - g.g10 * c0) * g.i11;
+      const double c2 = (bb[2] - g.g20 * c0 - g.g21 * c1) * g.i22;
+      B.cb[l] = c0, B.cb[CL + l] = c1, B.cb[2 * CL + l] = c2;
+      B.gb[l] = g.i00, B.gb[CL + l] = g.g10, B.gb[2 * CL + l] = g.g20, B.gb[3 * CL + l] = g.i11, B.gb[4 * CL + l] = g.g21, B.gb[5 * CL + l] = g.i22;
+    }
+  }
+  return chi;
+}
+
+// pose_sums == 0 (resident records only): Hpp / bp are not formed here at all -- the Schur phase sums them inside its own walk over the
+// records (ba_schur_accumulate, inl).  A function of its own: few registers, no callee-saved ones to store and reload per call.
+__device__ FLVIS_BA_PHASE_FN double ba_phase_linearize_rec(double lam) { return ba_linearize_resident<false>(lam); }
+
+__device__ FLVIS_BA_PHASE_FN double ba_phase_linearize(double lam) {
+  BAShared& sh = ba_sh();
+  if (sh.fused) return ba_linearize_resident<true>(lam);
+  const BAScratch sc = sh.sc;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, L = sh.L, Lc = sc.Lc, W = sh.W, P = sh.P;
+  const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
+  double* wacc = ba_dyn() + (size_t)wv * P * 27;  // [P][27] of this wave, over Hs (dead until the Schur phase's combine)
   for (int i = lane; i < P * 27; i += 64) wacc[i] = 0.0;
   wave_lds_fence();
   double chi = 0;
@@ -623,14 +890,10 @@ __device__ FLVIS_BA_PHASE_FN double ba_phase_linearize() {
     const int l = l0 + lane;
     const unsigned m = l < L ? sc.omask[l] : 0u;
     double px = 0, py = 0, pz = 1;
-    unsigned fm = 0;
-    int ib = 0;
     if (m) {
       px = sc.lmA[l];
       py = sc.lmA[Lc + l];
       pz = sc.lmA[2 * Lc + l];
-      fm = sc.fmask[l];
-      ib = sc.ibase[l];
     }
     double h[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
     // the loop body is deliberately NOT unrolled (instruction-cache footprint); the next slot's observation is loaded
@@ -651,32 +914,9 @@ __device__ FLVIS_BA_PHASE_FN double ba_phase_linearize() {
 #pragma unroll
       for (int k = 0; k < 32; k++) pv[k] = 0;
       if (has) {
-        double er[2], Ji[2][3], Jj[2][6];
-        ba_linearize(sh.RT[slot], px, py, pz, u, v, K, er, Ji, Jj);
-        const double e2 = er[0] * er[0] + er[1] * er[1];
-        chi += ba_huber_rho(e2);
-        const double wgt = ba_huber_w(e2);
-        const double o0 = -er[0] * wgt, o1 = -er[1] * wgt;
-        int q = 0;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          bb[r] += Ji[0][r] * o0 + Ji[1][r] * o1;
-#pragma unroll
-          for (int c = r; c < 3; c++) h[q++] += (Ji[0][r] * wgt) * Ji[0][c] + (Ji[1][r] * wgt) * Ji[1][c];
-        }
-        if (hi >= 0) {
-          gdouble* dst = sc.BdI + ib + __popc(fm & ((1u << hi) - 1u));
-          q = 0;
-#pragma unroll
-          for (int r = 0; r < 6; r++) {
-            pv[21 + r] = Jj[0][r] * o0 + Jj[1][r] * o1;
-#pragma unroll
-            for (int c = r; c < 6; c++) pv[q++] = (Jj[0][r] * wgt) * Jj[0][c] + (Jj[1][r] * wgt) * Jj[1][c];
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-              dst[(size_t)(3 * r + c) * Ec] = (Jj[0][r] * wgt) * Ji[0][c] + (Jj[1][r] * wgt) * Ji[1][c];
-          }
-        }
+        const BAObs o = ba_obs(sh.RT[slot], px, py, pz, u, v, K);
+        chi += ba_obs_landmark(o, h, bb);
+        if (hi >= 0) ba_obs_pose(o, K, pv);
       }
       if (hi >= 0) {
         int idx;
@@ -690,11 +930,6 @@ __device__ FLVIS_BA_PHASE_FN double ba_phase_linearize() {
       for (int j = 0; j < 6; j++) sc.Hll[(size_t)j * Lc + l] = h[j];
 #pragma unroll
       for (int j = 0; j < 3; j++) sc.bl[(size_t)j * Lc + l] = bb[j];
-      const int ni = __popc(fm);
-      for (int r = 0; r < ni; r++) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) sc.HllI[(size_t)j * Ec + ib + r] = h[j];
-      }
     }
   }
   return chi;
@@ -704,7 +939,7 @@ __device__ FLVIS_BA_PHASE_FN double ba_phase_linearize() {
 __device__ __noinline__ void ba_phase_finish_poses() {
   BAShared& sh = ba_sh();
   const int t = threadIdx.x, P = sh.P;
-  const double* wacc = ba_dyn() + sh.off_stage;
+  const double* wacc = ba_dyn();
   for (int i = t; i < P * 27; i += BA_T) {
     double a = 0;
 #pragma unroll
@@ -723,6 +958,15 @@ __device__ __noinline__ void ba_phase_finish_poses() {
       sh.Hpp[pi][6 * c + r] = a;
     }
   }
+}
+
+// "inline" iterations: Hpp / b hold the IMU edges' share only (ba_phase_imu_gather adds it); the observations' share is summed by the
+// Schur phase
+__device__ __noinline__ void ba_phase_zero_poses() {
+  BAShared& sh = ba_sh();
+  const int t = threadIdx.x, P = sh.P;
+  for (int i = t; i < P * 36; i += BA_T) sh.Hpp[i / 36][i % 36] = 0.0;
+  for (int i = t; i < P * 6; i += BA_T) sh.b[i] = 0.0;
 }
 
 // ---- optional IMU rotation factor between consecutive keyframes (north_star: "reprojection + IMU-preintegration factors"; the
@@ -822,9 +1066,9 @@ __device__ __noinline__ void ba_phase_imu_linearize() {
           ab += (Ja[m][i] * wr[m]) * Jb[m][j];
         }
       }
-      sh.imu_aa[k][6 * i + j] = aa;
-      sh.imu_bb[k][6 * i + j] = bb;
-      sh.imu_ab[k][6 * i + j] = ab;
+      ba_imu_blk(k, 0)[6 * i + j] = aa;
+      ba_imu_blk(k, 1)[6 * i + j] = bb;
+      ba_imu_blk(k, 2)[6 * i + j] = ab;
     }
     double ga = 0, gb = 0;
 #pragma unroll
@@ -834,8 +1078,8 @@ __device__ __noinline__ void ba_phase_imu_linearize() {
         gb += (Jb[m][i] * wr[m]) * r[m];
       }
     }
-    sh.imu_ga[k][i] = ga;
-    sh.imu_gb[k][i] = gb;
+    ba_imu_blk(k, 3)[i] = ga;
+    ba_imu_blk(k, 4)[i] = gb;
   }
   double chi = w * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
   if (pos) chi += wp * ((r[3] * r[3] + r[4] * r[4]) + r[5] * r[5]);
@@ -850,8 +1094,8 @@ __device__ __noinline__ void ba_phase_imu_gather() {
   for (int k = 0; k < sh.n_imu; k++) {
     const bool isa = sh.imu_a[k] == slot, isb = sh.imu_b[k] == slot;
     if (!isa && !isb) continue;
-    const double* blk = isa ? sh.imu_aa[k] : sh.imu_bb[k];
-    const double* g = isa ? sh.imu_ga[k] : sh.imu_gb[k];
+    const double* blk = ba_imu_blk(k, isa ? 0 : 1);
+    const double* g = ba_imu_blk(k, isa ? 3 : 4);
     const int nc = sh.imu_wp[k] > 0 ? 6 : 3;
     for (int i = 0; i < nc; i++) {
       for (int j = 0; j < nc; j++) sh.Hpp[hi][6 * i + j] += blk[6 * i + j];
@@ -873,9 +1117,9 @@ __device__ __noinline__ void ba_phase_imu_offdiag() {
     const int ia = sh.hidx_of[sh.imu_a[k]], ib = sh.hidx_of[sh.imu_b[k]];
     if (ia < 0 || ib < 0) continue;
     if (ia < ib)
-      Hs[(6 * ib + j) * LD + 6 * ia + i] += sh.imu_ab[k][e];
+      Hs[(6 * ib + j) * LD + 6 * ia + i] += ba_imu_blk(k, 2)[e];
     else
-      Hs[(6 * ia + i) * LD + 6 * ib + j] += sh.imu_ab[k][e];
+      Hs[(6 * ia + i) * LD + 6 * ib + j] += ba_imu_blk(k, 2)[e];
   }
 }
 // lanes of wave 0: chi2 of the edges at the trial poses
@@ -909,228 +1153,355 @@ __device__ FLVIS_BA_PHASE_FN double ba_phase_max_diag() {
   return md;
 }
 
-// reduced camera system S = Hpp + lambda I - sum_l Z Z^T (lower triangle into Hs) and rhs = bp - sum_l Z c (into sh.x),
-// streaming the observed blocks through double-buffered LDS chunks
-__device__ FLVIS_BA_PHASE_FN void ba_phase_schur(double lambda) {
-  BAShared& sh = ba_sh();
-  const BAScratch sc = sh.sc;
-  const int t = threadIdx.x, Lc = sc.Lc, Ec = sc.Ec, P = sh.P;
-  const int CI = sh.CI, CL = sh.CL, bufd = sh.bufd, slices = sh.slices, rs = sh.rs, npairs = sh.npairs, LD = sh.LD;
-  const int nchunk = sh.nchunk;
-  double* Hs = ba_dyn();
-  double* stage = Hs + sh.off_stage;
-  // this thread's role in the accumulation
-  int my_i1 = -1, my_i2 = -1, my_sl = 0, my_rp = -1, my_rsl = 0;
+// reduced camera system S = Hpp + lambda I - sum_l Z Z^T (lower triangle into Hs) and rhs = bp - sum_l Z c (into sh.x).
+// Per chunk of landmarks (the whole window when its items fit one buffer):
+//   stage       thread per landmark: G = chol(Hll + lambda I), c = G^-1 bl, then one record per observation by a free pose (re-linearised
+//               at the accepted state from the landmark, the pose table in LDS and the pixel) straight into LDS -- no HBM scratch;
+//   accumulate  thread = (pose pair, landmark slice): 6x6 register tiles from the factored products, fixed slice partition and fixed
+//               butterfly order => bit-reproducible run to run, no atomics; the rhs threads sum Jp^T r likewise.
+// ---- The Schur phase is split into functions with small register footprints: a called function that needs more than the ~140
+// caller-saved VGPRs saves and reloads every callee-saved one it touches through scratch memory on each call, and the stores have to
+// drain before its first barrier (measured in round 5: 65 registers, ~9 us per call).  The accumulation alone stays below that.
+
+// this thread's role in the accumulation: pose pair (i1, i2) and landmark slice sl -- the diagonal pairs first (pr < P: (pr, pr)), then
+// the pairs i1 < i2 row by row.  A diagonal pair walks every observation of its pose: it also sums the pose's right-hand side.
+struct SchurRole {
+  int i1, i2, sl;
+};
+FD SchurRole ba_schur_role(int t, int P, int npairs, int slices) {
+  SchurRole r{-1, -1, 0};
   if (t < npairs * slices) {
     const int pr = t / slices;
-    my_sl = t - pr * slices;
-    int i1 = 0, rem = pr;
-    while (rem >= P - i1) {
-      rem -= P - i1;
-      i1++;
+    r.sl = t - pr * slices;
+    if (pr < P) {
+      r.i1 = r.i2 = pr;
+    } else {
+      int i1 = 0, rem = pr - P;
+      while (rem >= P - 1 - i1) {
+        rem -= P - 1 - i1;
+        i1++;
+      }
+      r.i1 = i1;
+      r.i2 = i1 + 1 + rem;
     }
-    my_i1 = i1;
-    my_i2 = i1 + rem;
-  } else if (t - npairs * slices < P * rs) {
-    const int tr = t - npairs * slices;
-    my_rp = tr / rs;
-    my_rsl = tr - my_rp * rs;
   }
-  double acc[36], accr[6];
-#pragma unroll
-  for (int k = 0; k < 36; k++) acc[k] = 0;
-#pragma unroll
-  for (int k = 0; k < 6; k++) accr[k] = 0;
-  // staging registers: one item (B block + its landmark's Hll) and one landmark entry (Hll, bl, mask, item base)
-  double rB[18], rH[6], rH2[6], rb[3];
-  bool it_on = false, lm_on = false;
-  unsigned rmask = 0;
-  int rbase = 0, rbase_i0 = 0;  // (the chunk's first item is subtracted at commit time: nothing may USE a prefetched value before the
-                                // chunk's arithmetic, or the wait for it -- and for every load issued before it -- lands in front of that arithmetic)
-  auto prefetch = [&](int c) {
-    const int l0 = sh.chunk_l0[c], nl = sh.chunk_l0[c + 1] - l0;
-    const int i0 = sh.chunk_i0[c], ni = sh.chunk_i0[c + 1] - i0;
-    it_on = t < ni;
-    lm_on = t < nl;
-    if (it_on) {
-      const gdouble* src = sc.BdI + i0 + t;
-#pragma unroll
-      for (int k = 0; k < 18; k++) rB[k] = src[(size_t)k * Ec];
-      const gdouble* hs = sc.HllI + i0 + t;
-#pragma unroll
-      for (int k = 0; k < 6; k++) rH[k] = hs[(size_t)k * Ec];
+  return r;
+}
+
+// staging of one chunk, thread per landmark: G = chol(Hll + lambda I) and c = G^-1 bl.  Resident records (fused) are current from the
+// linearisation: nothing per observation is left to do.  Otherwise the chunk's records are rebuilt here -- every observation by a free
+// pose re-linearised at the accepted state from the landmark, the pose table in LDS and the pixel in the observation table (HBM), the
+// next pose's in flight while this one is processed.
+FD void ba_stage_chunk(int c, int buf, double lambda) {
+  BAShared& sh = ba_sh();
+  const BAScratch sc = sh.sc;
+  const int t = threadIdx.x, Lc = sc.Lc, P = sh.P, CI = sh.CI, CL = sh.CL;
+  const bool fused = sh.fused != 0;
+  const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
+  const int l0 = sh.chunk_l0[c], nl = sh.chunk_l0[c + 1] - l0, i0 = sh.chunk_i0[c];
+  const SchurBuf B = ba_schur_buf(buf);
+  double2* z = B.z;
+  for (int b0 = 0; b0 < nl; b0 += BA_T) {  // (wave-uniform trip count: the pose walk below votes)
+    const int ll = b0 + t, l = l0 + ll;
+    const bool in = ll < nl;
+    const unsigned fm = in ? sc.fmask[l] : 0u;
+    int base = 0;
+    if (in) {
+      base = sc.ibase[l] - i0;
+      B.mb[ll] = fm;
+      B.lb[ll] = base;
     }
-    if (lm_on) {
-      const int l = l0 + t;
-      rmask = sc.fmask[l];
-      rbase = sc.ibase[l];
-      rbase_i0 = i0;
+    double px = 0, py = 0, pz = 1;
+    if (fm) {
+      double H[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) rH2[k] = sc.Hll[(size_t)k * Lc + l];
-#pragma unroll
-      for (int k = 0; k < 3; k++) rb[k] = sc.bl[(size_t)k * Lc + l];
-    }
-  };
-  auto commit = [&](int buf) {
-    double* zb = stage + (size_t)buf * bufd;
-    double* cb = zb + (size_t)CI * 18;
-    unsigned* mb = reinterpret_cast<unsigned*>(cb + (size_t)CL * 3);
-    int* lb = reinterpret_cast<int*>(mb + CL);
-    if (it_on) {
-      const Chol3 g = chol3(rH, lambda);
-      double zz[18];
-#pragma unroll
-      for (int r = 0; r < 6; r++) {  // Z G^T = B, row by row
-        zz[3 * r] = rB[3 * r] * g.i00;
-        zz[3 * r + 1] = (rB[3 * r + 1] - zz[3 * r] * g.g10) * g.i11;
-        zz[3 * r + 2] = (rB[3 * r + 2] - zz[3 * r] * g.g20 - zz[3 * r + 1] * g.g21) * g.i22;
+      for (int k = 0; k < 6; k++) H[k] = sc.Hll[(size_t)k * Lc + l];
+      const double b0l = sc.bl[l], b1l = sc.bl[(size_t)Lc + l], b2l = sc.bl[(size_t)2 * Lc + l];
+      if (!fused) {
+        px = sc.lmA[l];
+        py = sc.lmA[Lc + l];
+        pz = sc.lmA[2 * Lc + l];
       }
-      double2* z = reinterpret_cast<double2*>(zb) + t;  // element pairs [9][CI]: 16-byte LDS accesses
-#pragma unroll
-      for (int kp = 0; kp < 9; kp++) z[kp * CI] = double2{zz[2 * kp], zz[2 * kp + 1]};
+      const Chol3 g = chol3(H, lambda);
+      const double c0 = b0l * g.i00;  // c = G^-1 bl
+      const double c1 = (b1l - g.g10 * c0) * g.i11;
+      const double c2 = (b2l - g.g20 * c0 - g.g21 * c1) * g.i22;
+      B.cb[ll] = c0, B.cb[CL + ll] = c1, B.cb[2 * CL + ll] = c2;
+      B.gb[ll] = g.i00, B.gb[CL + ll] = g.g10, B.gb[2 * CL + ll] = g.g20, B.gb[3 * CL + ll] = g.i11, B.gb[4 * CL + ll] = g.g21, B.gb[5 * CL + ll] = g.i22;
     }
-    if (lm_on) {
-      mb[t] = rmask;
-      lb[t] = rbase - rbase_i0;
-      if (rmask) {  // c = G^-1 bl
-        const Chol3 g = chol3(rH2, lambda);
-        const double c0 = rb[0] * g.i00;
-        const double c1 = (rb[1] - g.g10 * c0) * g.i11;
-        const double c2 = (rb[2] - g.g20 * c0 - g.g21 * c1) * g.i22;
-        cb[t] = c0;
-        cb[CL + t] = c1;
-        cb[2 * CL + t] = c2;
+    if (fused) continue;
+    int idx = base;
+    double un = 0, vn = 0;
+    if (fm & 1u) {
+      const int s0 = sh.slot_of[0];
+      un = sc.uv[(size_t)(2 * s0) * Lc + l];
+      vn = sc.uv[(size_t)(2 * s0 + 1) * Lc + l];
+    }
+#pragma unroll 1
+    for (int h = 0; h < P; h++) {
+      const double u = un, v = vn;
+      const bool has = (fm >> h) & 1u;
+      if (h + 1 < P && ((fm >> (h + 1)) & 1u)) {
+        const int sn = sh.slot_of[h + 1];
+        un = sc.uv[(size_t)(2 * sn) * Lc + l];
+        vn = sc.uv[(size_t)(2 * sn + 1) * Lc + l];
+      }
+      if (__ballot(has) == 0ull) continue;
+      if (has) {
+        const BAObs o = ba_obs(sh.RT[sh.slot_of[h]], px, py, pz, u, v, K);
+        z[idx] = double2{o.xn, o.yn};
+        z[CI + idx] = double2{o.iz, o.wgt};
+        z[2 * CI + idx] = double2{u, v};
+        idx++;
       }
     }
-  };
-#ifdef FLVIS_BA_PROF
-  long long pf_ticks = 0;
-  int pf_prod = 0;
-  if (t == 0) sh.pf_tmax = sh.pf_tsum = sh.pf_nmax = sh.pf_nsum = sh.pf_threads = 0;  // (published by the first chunk's barrier)
-#endif
-  if (nchunk > 0) prefetch(0);
-  for (int c = 0; c < nchunk; c++) {
-    const int buf = c & 1;
-    commit(buf);
-    __syncthreads();
-    BAPROF(2);
-    if (c + 1 < nchunk) prefetch(c + 1);
-    const int nl = sh.chunk_l0[c + 1] - sh.chunk_l0[c];
-    const double* zb = stage + (size_t)buf * bufd;
-    const double* cb = zb + (size_t)CI * 18;
-    const unsigned* mb = reinterpret_cast<const unsigned*>(cb + (size_t)CL * 3);
-    const int* lb = reinterpret_cast<const int*>(mb + CL);
-    const double2* z2 = reinterpret_cast<const double2*>(zb);
-#ifdef FLVIS_BA_PROF
-    const long long pf_t0 = (long long)wall_clock64();
-#endif
-    if (my_i1 >= 0) {
-      const unsigned need = (1u << my_i1) | (1u << my_i2);
-      const unsigned lt1 = (1u << my_i1) - 1u, lt2 = (1u << my_i2) - 1u;
-      // Two passes over this thread's landmarks of the chunk (my_sl, my_sl + slices, ...).  First the masks only, 8 LDS reads in flight at
-      // a time: which landmarks are seen by both poses -> one bit each.  Then the block products, every lane walking the set bits of
-      // ITS word: a wave runs the product body as often as its busiest lane has landmarks (~10), not once per landmark ANY of its 64
-      // lanes has (~31 of 31: the lanes' hits fall on different landmarks, and the one-pass loop spent 4/5 of its issue slots masked
-      // off -- 13 us per call for 6.7 products per thread, scripts/ba_prof.py).  Same landmarks in the same order: the sums are unchanged.
-      const int nmine = nl > my_sl ? (nl - my_sl + slices - 1) / slices : 0;
-      for (int jb = 0; jb < nmine; jb += 32) {
-        unsigned hit = 0;
-        const int jn = nmine - jb < 32 ? nmine - jb : 32;
-        for (int j0 = 0; j0 < jn; j0 += 8) {
-          unsigned mk[8];
+  }
+}
+
+// M = w Jl G^-T (2x3) of a record for the pose whose rotation rows are R (row-major 3x3): Jl = -1/z [fx (r0 - xn r2); fy (r1 - yn r2)]
+// (types_six_dof_expmap.cpp:389-433), rebuilt from four numbers instead of being stored
+FD void ba_record_M(const double2 p0, const double2 p1, const double* R, const double* g6, double fx, double fy, double (&M)[6]) {
+  const double s = -p1.x * p1.y, sx = s * fx, sy = s * fy;
+  double A[6];
 #pragma unroll
-          for (int q = 0; q < 8; q++) mk[q] = j0 + q < jn ? mb[my_sl + (jb + j0 + q) * slices] : 0u;
+  for (int c = 0; c < 3; c++) {
+    A[c] = sx * (R[c] - p0.x * R[6 + c]);
+    A[3 + c] = sy * (R[3 + c] - p0.y * R[6 + c]);
+  }
 #pragma unroll
-          for (int q = 0; q < 8; q++)
-            if ((mk[q] & need) == need) hit |= 1u << (j0 + q);
+  for (int a = 0; a < 2; a++) {
+    M[3 * a] = A[3 * a] * g6[0];
+    M[3 * a + 1] = (A[3 * a + 1] - M[3 * a] * g6[1]) * g6[3];
+    M[3 * a + 2] = (A[3 * a + 2] - M[3 * a] * g6[2] - M[3 * a + 1] * g6[4]) * g6[5];
+  }
+}
+
+// sum over one DPP row (16 lanes) into its lane 0, in a fixed order; the other lanes end with partial sums
+template <int CTRL>
+FD double ba_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+FD double ba_row16_sum_to_lane0(double v) {
+  v += ba_dpp<0x108>(v);  // row_shl:8  (lane i += lane i + 8; out-of-row sources read as 0)
+  v += ba_dpp<0x104>(v);  // row_shl:4
+  v += ba_dpp<0x102>(v);  // row_shl:2
+  v += ba_dpp<0x101>(v);  // row_shl:1
+  return v;
+}
+
+// accumulation over one staged chunk, acc = this thread's 36 accumulators:
+//   pair i1 < i2   acc[6 r + c] = - sum Z_i1 Z_i2^T, the 6x6 tile;
+//   pair (h, h)    acc[r (r + 1) / 2 + c], c <= r: the lower triangle of (Hpp share) - Z_h Z_h^T (21), acc[21 .. 26] = sum Z_h c,
+//                  acc[27 .. 32] = the bp share -- the diagonal pair walks every observation of pose h, so the right-hand side rides along.
+// inl: Hpp and bp are summed here too: the tile accumulates Jp^T (w I - M M^T) Jp and Jp^T (-w e); sh.Hpp / sh.b then hold the IMU
+// edges' share only.
+FD void ba_schur_accumulate(const SchurRole& ro, int buf, int nl, int inl, double (&acc)[36]) {
+  BAShared& sh = ba_sh();
+  if (ro.i1 < 0) return;
+  const int CI = sh.CI, CL = sh.CL, slices = sh.slices;
+  const double fx = sh.K[0], fy = sh.K[1], cx = sh.K[2], cy = sh.K[3];
+  const SchurBuf B = ba_schur_buf(buf);
+  const double2* z2 = B.z;
+  const unsigned* mb = B.mb;
+  const int* lb = B.lb;
+  const bool diag = ro.i1 == ro.i2;
+  const unsigned need = (1u << ro.i1) | (1u << ro.i2);
+  const unsigned lt1 = (1u << ro.i1) - 1u, lt2 = (1u << ro.i2) - 1u;
+  double Ri[9], Rj[9];  // the two poses' rotations: fixed per thread
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    Ri[k] = sh.RT[sh.slot_of[ro.i1]][k];
+    Rj[k] = sh.RT[sh.slot_of[ro.i2]][k];
+  }
+  // Two passes over this thread's landmarks of the chunk (sl, sl + slices, ...).  First the masks only, 8 LDS reads in flight at
+  // a time: which landmarks are seen by both poses -> one bit each.  Then the block products, every lane walking the set bits of
+  // ITS word: a wave runs the product body as often as its busiest lane has landmarks, not once per landmark ANY of its 64 lanes has.
+  const int nmine = nl > ro.sl ? (nl - ro.sl + slices - 1) / slices : 0;
+  for (int jb = 0; jb < nmine; jb += 32) {
+    unsigned hit = 0;
+    const int jn = nmine - jb < 32 ? nmine - jb : 32;
+    for (int j0 = 0; j0 < jn; j0 += 8) {
+      unsigned mk[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) mk[q] = j0 + q < jn ? mb[ro.sl + (jb + j0 + q) * slices] : 0u;
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if ((mk[q] & need) == need) hit |= 1u << (j0 + q);
+    }
+#pragma unroll 1
+    while (hit) {
+      const int j = __builtin_ctz(hit);
+      hit &= hit - 1u;
+      const int ll = ro.sl + (jb + j) * slices;
+      const unsigned m = mb[ll];
+      const int base = lb[ll];
+      const double g6[6] = {B.gb[ll], B.gb[CL + ll], B.gb[2 * CL + ll], B.gb[3 * CL + ll], B.gb[4 * CL + ll], B.gb[5 * CL + ll]};
+      const double2* zi = z2 + base + __popc(m & lt1);
+      const double2 p0 = zi[0], p1 = zi[CI];
+      double Mi[6];
+      ba_record_M(p0, p1, Ri, g6, fx, fy, Mi);
+      const JpRows Ji = jp_rows(p0.x, p0.y, p1.x, fx, fy);
+      const double ia[6] = {Ji.a0, Ji.a1, Ji.a2, Ji.a3, 0.0, Ji.a5}, ib[6] = {Ji.b0, Ji.b1, Ji.b2, 0.0, Ji.b4, Ji.b5};
+      if (diag) {
+        // N = -M M^T (+ w I on an inline iteration), symmetric; T = Jp^T N; lower triangle += T Jp
+        double n00 = -fma(Mi[2], Mi[2], fma(Mi[1], Mi[1], Mi[0] * Mi[0])), n01 = -fma(Mi[2], Mi[5], fma(Mi[1], Mi[4], Mi[0] * Mi[3]));
+        double n11 = -fma(Mi[5], Mi[5], fma(Mi[4], Mi[4], Mi[3] * Mi[3]));
+        if (inl) {
+          n00 += p1.y;
+          n11 += p1.y;
         }
-        while (hit) {
-          const int j = __builtin_ctz(hit);
-          hit &= hit - 1u;
-          const int ll = my_sl + (jb + j) * slices;
-          const unsigned m = mb[ll];
-#ifdef FLVIS_BA_PROF
-          pf_prod++;
-#endif
-          const int base = lb[ll];
-          const double2* zi = z2 + base + __popc(m & lt1);
-          const double2* zj = z2 + base + __popc(m & lt2);
-          double a[18];
 #pragma unroll
-          for (int kp = 0; kp < 9; kp++) {
-            const double2 v2 = zi[kp * CI];
-            a[2 * kp] = v2.x;
-            a[2 * kp + 1] = v2.y;
+        for (int r = 0; r < 6; r++) {
+          double t0, t1;
+          if (r == 3) {
+            t0 = ia[3] * n00, t1 = ia[3] * n01;
+          } else if (r == 4) {
+            t0 = ib[4] * n01, t1 = ib[4] * n11;
+          } else {
+            t0 = fma(ib[r], n01, ia[r] * n00), t1 = fma(ib[r], n11, ia[r] * n01);
           }
 #pragma unroll
-          for (int cp = 0; cp < 3; cp++) {  // two columns of the tile (6 elements of Z_i2) per step
-            const double2 q0 = zj[(3 * cp) * CI], q1 = zj[(3 * cp + 1) * CI], q2 = zj[(3 * cp + 2) * CI];
-            const double bq[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
-#pragma unroll
-            for (int h2 = 0; h2 < 2; h2++) {
-              const int cc = 2 * cp + h2;
-#pragma unroll
-              for (int r = 0; r < 6; r++)
-                acc[6 * r + cc] = fma(a[3 * r + 2], bq[3 * h2 + 2], fma(a[3 * r + 1], bq[3 * h2 + 1], fma(a[3 * r], bq[3 * h2], acc[6 * r + cc])));
-            }
+          for (int c = 0; c <= r; c++) {
+            const int k = r * (r + 1) / 2 + c;
+            if (c == 3)
+              acc[k] = fma(t0, ia[3], acc[k]);
+            else if (c == 4)
+              acc[k] = fma(t1, ib[4], acc[k]);
+            else
+              acc[k] = fma(t1, ib[c], fma(t0, ia[c], acc[k]));
           }
         }
-      }
-    } else if (my_rp >= 0) {
-      const unsigned ltp = (1u << my_rp) - 1u;
-      for (int ll = my_rsl; ll < nl; ll += rs) {
-        const unsigned m = mb[ll];
-        if (!((m >> my_rp) & 1u)) continue;
-        const double2* zi = z2 + lb[ll] + __popc(m & ltp);
-        const double c0 = cb[ll], c1 = cb[CL + ll], c2 = cb[2 * CL + ll];
-        double a[18];
-#pragma unroll
-        for (int kp = 0; kp < 9; kp++) {
-          const double2 v2 = zi[kp * CI];
-          a[2 * kp] = v2.x;
-          a[2 * kp + 1] = v2.y;
+        // right-hand side: Z c = Jp^T (M c), and on an inline iteration the bp share Jp^T (-w e)
+        const double c0 = B.cb[ll], c1 = B.cb[CL + ll], c2 = B.cb[2 * CL + ll];
+        const double r0 = fma(Mi[2], c2, fma(Mi[1], c1, Mi[0] * c0)), r1 = fma(Mi[5], c2, fma(Mi[4], c1, Mi[3] * c0));
+        acc[21] = fma(Ji.b0, r1, fma(Ji.a0, r0, acc[21]));
+        acc[22] = fma(Ji.b1, r1, fma(Ji.a1, r0, acc[22]));
+        acc[23] = fma(Ji.b2, r1, fma(Ji.a2, r0, acc[23]));
+        acc[24] = fma(Ji.a3, r0, acc[24]);
+        acc[25] = fma(Ji.b4, r1, acc[25]);
+        acc[26] = fma(Ji.b5, r1, fma(Ji.a5, r0, acc[26]));
+        if (inl) {
+          const double2 uv = zi[2 * CI];
+          const double e0 = uv.x - (p0.x * fx + cx), e1 = uv.y - (p0.y * fy + cy);
+          const double o0 = -e0 * p1.y, o1 = -e1 * p1.y;
+          acc[27] = fma(Ji.b0, o1, fma(Ji.a0, o0, acc[27]));
+          acc[28] = fma(Ji.b1, o1, fma(Ji.a1, o0, acc[28]));
+          acc[29] = fma(Ji.b2, o1, fma(Ji.a2, o0, acc[29]));
+          acc[30] = fma(Ji.a3, o0, acc[30]);
+          acc[31] = fma(Ji.b4, o1, acc[31]);
+          acc[32] = fma(Ji.b5, o1, fma(Ji.a5, o0, acc[32]));
         }
+      } else {
+        const double2* zj = z2 + base + __popc(m & lt2);
+        const double2 q0 = zj[0], q1 = zj[CI];
+        double Mj[6];
+        ba_record_M(q0, q1, Rj, g6, fx, fy, Mj);
+        const JpRows Jj = jp_rows(q0.x, q0.y, q1.x, fx, fy);
+        // N = -M_i M_j^T; T = Jp_i^T N (6x2); tile += T Jp_j
+        const double n00 = -fma(Mi[2], Mj[2], fma(Mi[1], Mj[1], Mi[0] * Mj[0])), n01 = -fma(Mi[2], Mj[5], fma(Mi[1], Mj[4], Mi[0] * Mj[3]));
+        const double n10 = -fma(Mi[5], Mj[2], fma(Mi[4], Mj[1], Mi[3] * Mj[0])), n11 = -fma(Mi[5], Mj[5], fma(Mi[4], Mj[4], Mi[3] * Mj[3]));
 #pragma unroll
-        for (int r = 0; r < 6; r++) accr[r] = fma(a[3 * r + 2], c2, fma(a[3 * r + 1], c1, fma(a[3 * r], c0, accr[r])));
+        for (int r = 0; r < 6; r++) {
+          double t0, t1;
+          if (r == 3) {
+            t0 = ia[3] * n00, t1 = ia[3] * n01;
+          } else if (r == 4) {
+            t0 = ib[4] * n10, t1 = ib[4] * n11;
+          } else {
+            t0 = fma(ib[r], n10, ia[r] * n00), t1 = fma(ib[r], n11, ia[r] * n01);
+          }
+          acc[6 * r + 0] = fma(t1, Jj.b0, fma(t0, Jj.a0, acc[6 * r + 0]));
+          acc[6 * r + 1] = fma(t1, Jj.b1, fma(t0, Jj.a1, acc[6 * r + 1]));
+          acc[6 * r + 2] = fma(t1, Jj.b2, fma(t0, Jj.a2, acc[6 * r + 2]));
+          acc[6 * r + 3] = fma(t0, Jj.a3, acc[6 * r + 3]);
+          acc[6 * r + 4] = fma(t1, Jj.b4, acc[6 * r + 4]);
+          acc[6 * r + 5] = fma(t1, Jj.b5, fma(t0, Jj.a5, acc[6 * r + 5]));
+        }
       }
     }
-#ifdef FLVIS_BA_PROF
-    pf_ticks += (long long)wall_clock64() - pf_t0;
-#endif
-    BAPROF(12);
   }
-#ifdef FLVIS_BA_PROF
-  if (my_i1 >= 0) {
-    atomicMax(&sh.pf_tmax, (int)pf_ticks);
-    atomicAdd(&sh.pf_tsum, (int)pf_ticks);
-    atomicMax(&sh.pf_nmax, pf_prod);
-    atomicAdd(&sh.pf_nsum, pf_prod);
-    atomicAdd(&sh.pf_threads, 1);
-  }
-#endif
-  // combine the slices (fixed butterfly order) and write S / rhs
-  for (int off = slices >> 1; off > 0; off >>= 1) {
+}
+
+// combine the slices (fixed order) and write S (lower triangle + the full diagonal blocks) / rhs
+FD void ba_schur_combine(const SchurRole& ro, double lambda, double (&acc)[36]) {
+  BAShared& sh = ba_sh();
+  double* Hs = ba_dyn();
+  const int LD = sh.LD, slices = sh.slices;
+  // (the lanes of one pair are contiguous and aligned to `slices`; 16 slices -- the usual partition -- are one DPP row: summed into
+  // the row's lane 0 without touching LDS)
+  if (slices == 16) {
 #pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] += __shfl_xor(acc[k], off, 64);
+    for (int k = 0; k < 36; k++) acc[k] = ba_row16_sum_to_lane0(acc[k]);
+  } else {
+    for (int off = slices >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 36; k++) acc[k] += __shfl_xor(acc[k], off, 64);
+    }
   }
-  if (my_i1 >= 0 && my_sl == 0) {
+  if (ro.i1 < 0 || ro.sl != 0) return;
+  if (ro.i1 != ro.i2) {
 #pragma unroll
     for (int r = 0; r < 6; r++)
 #pragma unroll
-      for (int cc = 0; cc < 6; cc++) {
-        double v = -acc[6 * r + cc];
-        if (my_i1 == my_i2) v += sh.Hpp[my_i1][6 * r + cc] + (r == cc ? lambda : 0.0);
-        Hs[(6 * my_i2 + cc) * LD + 6 * my_i1 + r] = v;  // lower triangle (and the full diagonal blocks)
-      }
+      for (int cc = 0; cc < 6; cc++) Hs[(6 * ro.i2 + cc) * LD + 6 * ro.i1 + r] = acc[6 * r + cc];
+    return;
   }
-  for (int off = rs >> 1; off > 0; off >>= 1) {
+  const int h = ro.i1;
 #pragma unroll
-    for (int k = 0; k < 6; k++) accr[k] += __shfl_xor(accr[k], off, 64);
-  }
-  if (my_rp >= 0 && my_rsl == 0) {
+  for (int r = 0; r < 6; r++)
 #pragma unroll
-    for (int r = 0; r < 6; r++) sh.x[6 * my_rp + r] = sh.b[6 * my_rp + r] - accr[r];  // bschur
+    for (int c = 0; c <= r; c++) {
+      const double v = acc[r * (r + 1) / 2 + c] + sh.Hpp[h][6 * r + c] + (r == c ? lambda : 0.0);
+      Hs[(6 * h + r) * LD + 6 * h + c] = v;
+      Hs[(6 * h + c) * LD + 6 * h + r] = v;
+    }
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const double bf = sh.b[6 * h + r] + acc[27 + r];  // (the bp share is zero unless inl)
+    sh.bfull[6 * h + r] = bf;
+    sh.x[6 * h + r] = bf - acc[21 + r];  // bschur
   }
+}
+
+// reduced camera system S = Hpp + lambda I - sum_l Z Z^T (lower triangle into Hs) and rhs = bp - sum_l Z c (into sh.x):
+// accumulate -- thread = (pose pair, landmark slice): 6x6 register tiles from the factored products, fixed slice partition and fixed
+// butterfly order => bit-reproducible run to run, no atomics; the rhs threads sum Jp^T r likewise.
+
+// resident records, staged by the caller (ba_phase_stage) or by the linearisation: one chunk, no barrier inside
+__device__ FLVIS_BA_PHASE_FN void ba_phase_schur_resident(double lambda, int inl) {
+  BAShared& sh = ba_sh();
+  const SchurRole ro = ba_schur_role(threadIdx.x, sh.P, sh.npairs, sh.slices);
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; k++) acc[k] = 0;
+  ba_schur_accumulate(ro, 0, sh.chunk_l0[1] - sh.chunk_l0[0], inl, acc);
+  BAPROF(12);
+  ba_schur_combine(ro, lambda, acc);
+  BAPROF(13);
+}
+// the staging of the resident chunk on its own (the first trial of an optimize() call, and a trial that follows a rejected one)
+__device__ FLVIS_BA_PHASE_FN void ba_phase_stage(double lambda) { ba_stage_chunk(0, 0, lambda); }
+
+// windows whose items do not fit one buffer: staged chunk by chunk through two buffers, one barrier per chunk
+__device__ FLVIS_BA_PHASE_FN void ba_phase_schur_chunked(double lambda) {
+  BAShared& sh = ba_sh();
+  const int nchunk = sh.nchunk;
+  const SchurRole ro = ba_schur_role(threadIdx.x, sh.P, sh.npairs, sh.slices);
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; k++) acc[k] = 0;
+  if (nchunk > 0) ba_stage_chunk(0, 0, lambda);
+  for (int c = 0; c < nchunk; c++) {
+    __syncthreads();
+    BAPROF(2);
+    ba_schur_accumulate(ro, c & 1, sh.chunk_l0[c + 1] - sh.chunk_l0[c], 0, acc);
+    BAPROF(12);
+    if (c + 1 < nchunk) ba_stage_chunk(c + 1, (c + 1) & 1, lambda);
+  }
+  ba_schur_combine(ro, lambda, acc);
+  BAPROF(13);
 }
 
 // The same reduced system through the matrix cores (north_star: "an MFMA dense solve only for the reduced camera block").
@@ -1143,7 +1514,7 @@ typedef double ba_d4 __attribute__((ext_vector_type(4)));
 __device__ __noinline__ void ba_phase_schur_mfma(double lambda) {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, Lc = sc.Lc, Ec = sc.Ec, P = sh.P, L = sh.L;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, Lc = sc.Lc, P = sh.P, L = sh.L;
   const int NR = sh.NR, NRp = sh.NRp, CLm = sh.CLm, LD = sh.LD;
   double* Hs = ba_dyn();
   double* Zt = Hs + sh.off_stage;
@@ -1178,20 +1549,21 @@ __device__ __noinline__ void ba_phase_schur_mfma(double lambda) {
       const int ll = idx / P, h = idx - ll * P, l = l0 + ll;
       const unsigned fm = sc.fmask[l];
       double zz[18];
-      if ((fm >> h) & 1u) {
-        const int it = sc.ibase[l] + __popc(fm & ((1u << h) - 1u));
-        double rB[18], rH[6];
+      if ((fm >> h) & 1u) {  // Z = Jp^T M from the factors (see ba_phase_schur)
+        const int slot = sh.slot_of[h];
+        double rH[6], M[6];
 #pragma unroll
-        for (int k = 0; k < 18; k++) rB[k] = sc.BdI[(size_t)k * Ec + it];
-#pragma unroll
-        for (int k = 0; k < 6; k++) rH[k] = sc.HllI[(size_t)k * Ec + it];
+        for (int k = 0; k < 6; k++) rH[k] = sc.Hll[(size_t)k * Lc + l];
         const Chol3 g = chol3(rH, lambda);
+        const BAObs o = ba_obs(sh.RT[slot], sc.lmA[l], sc.lmA[Lc + l], sc.lmA[2 * Lc + l], sc.uv[(size_t)(2 * slot) * Lc + l],
+                               sc.uv[(size_t)(2 * slot + 1) * Lc + l], sh.K);
+        ba_item_scale(o.wJl, g, M);
+        const JpRows J = jp_rows(o.xn, o.yn, o.iz, sh.K[0], sh.K[1]);
+        const double ja[6] = {J.a0, J.a1, J.a2, J.a3, 0.0, J.a5}, jb[6] = {J.b0, J.b1, J.b2, 0.0, J.b4, J.b5};
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-          zz[3 * r] = rB[3 * r] * g.i00;
-          zz[3 * r + 1] = (rB[3 * r + 1] - zz[3 * r] * g.g10) * g.i11;
-          zz[3 * r + 2] = (rB[3 * r + 2] - zz[3 * r] * g.g20 - zz[3 * r + 1] * g.g21) * g.i22;
-        }
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) zz[3 * r + j] = ja[r] * M[j] + jb[r] * M[3 + j];
       } else {
 #pragma unroll
         for (int k = 0; k < 18; k++) zz[k] = 0.0;
@@ -1262,7 +1634,10 @@ __device__ __noinline__ void ba_phase_schur_mfma(double lambda) {
     for (int v = 0; v < 4; v++) {
       const int row = 16 * ti[q] + (lane >> 4) + 4 * v, col = 16 * tj[q] + (lane & 15);
       const double a = acc[q][v];
-      if (row == NR && col < NR) sh.x[col] = sh.b[col] - a;  // bschur = bp - sum Z c
+      if (row == NR && col < NR) {
+        sh.bfull[col] = sh.b[col];
+        sh.x[col] = sh.b[col] - a;  // bschur = bp - sum Z c
+      }
       if (row < NR && col <= row) {
         const bool same_block = (row / 6) == (col / 6);
         double val = -a;
@@ -1376,7 +1751,90 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_update_chi2(double lambda, int ok2, d
     }
   }
   if (ok2)
-    for (int i = t; i < 6 * sh.P; i += BA_T) scale_part += sh.x[i] * (lambda * sh.x[i] + sh.b[i]);
+    for (int i = t; i < 6 * sh.P; i += BA_T) scale_part += sh.x[i] * (lambda * sh.x[i] + sh.bfull[i]);
+  out[0] = scale_part;
+  out[1] = chit;
+}
+
+// The same with resident records (sh.fused): no per-observation HBM traffic.  The landmark's step is
+// (Hll + lambda I)^-1 (bl - sum_h (w Jl_h)^T (Jp_h dx_h)) with Jp and w Jl rebuilt from the records; the pixels for the trial chi2 come
+// from the records, the fixed pose's from the observation table.
+__device__ FLVIS_BA_PHASE_FN void ba_phase_update_rec(double lambda, int ok2, double* out) {
+  BAShared& sh = ba_sh();
+  const BAScratch sc = sh.sc;
+  const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, CI = sh.CI, fs = sh.fixed_slot;
+  const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
+  const double2* z = ba_schur_buf(0).z;
+  double scale_part = 0, chit = 0;
+  for (int l = t; l < L; l += BA_T) {
+    const unsigned m = sc.omask[l];
+    double p[3] = {sc.lmA[l], sc.lmA[Lc + l], sc.lmA[2 * Lc + l]};
+    unsigned fm = 0;
+    int ib = 0;
+    double uf = 0, vf = 0;
+    const bool hf = fs >= 0 && ((m >> fs) & 1u);
+    if (m) {
+      fm = sc.fmask[l];
+      ib = sc.ibase[l];
+      if (hf) {
+        uf = sc.uv[(size_t)(2 * fs) * Lc + l];
+        vf = sc.uv[(size_t)(2 * fs + 1) * Lc + l];
+      }
+    }
+    if (m && ok2) {
+      double H[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) H[k] = sc.Hll[(size_t)k * Lc + l];
+      const double bl[3] = {sc.bl[l], sc.bl[Lc + l], sc.bl[2 * Lc + l]};
+      double v[3] = {bl[0], bl[1], bl[2]};
+      int idx = ib;
+      unsigned rem = fm;
+#pragma unroll 1
+      while (rem) {
+        const int hi = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        const double2 p0 = z[idx], p1 = z[CI + idx];
+        idx++;
+        const JpRows J = jp_rows(p0.x, p0.y, p1.x, K[0], K[1]);
+        const double* xp = sh.x + 6 * hi;
+        const double q0 = fma(J.a5, xp[5], fma(J.a3, xp[3], fma(J.a2, xp[2], fma(J.a1, xp[1], J.a0 * xp[0]))));
+        const double q1 = fma(J.b5, xp[5], fma(J.b4, xp[4], fma(J.b2, xp[2], fma(J.b1, xp[1], J.b0 * xp[0]))));
+        const double* R = sh.RT[sh.slot_of[hi]];
+        const double s = -p1.x * p1.y, j0 = (s * K[0]) * q0, j1 = (s * K[1]) * q1;  // (w Jl)^T q, Jl = -1/z [fx (r0 - xn r2); fy (r1 - yn r2)]
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] -= (R[c] - p0.x * R[6 + c]) * j0 + (R[3 + c] - p0.y * R[6 + c]) * j1;
+      }
+      const Chol3 g = chol3(H, lambda);
+      const double y0 = v[0] * g.i00;
+      const double y1 = (v[1] - g.g10 * y0) * g.i11;
+      const double y2 = (v[2] - g.g20 * y0 - g.g21 * y1) * g.i22;
+      const double d2 = y2 * g.i22;
+      const double d1 = (y1 - g.g21 * d2) * g.i11;
+      const double d0 = (y0 - g.g10 * d1 - g.g20 * d2) * g.i00;
+      p[0] += d0;
+      p[1] += d1;
+      p[2] += d2;
+      scale_part += d0 * (lambda * d0 + bl[0]) + d1 * (lambda * d1 + bl[1]) + d2 * (lambda * d2 + bl[2]);
+    }
+    sc.lmB[l] = p[0];
+    sc.lmB[Lc + l] = p[1];
+    sc.lmB[2 * Lc + l] = p[2];
+    if (m) {
+      if (hf) chit += ba_huber_rho(ba_err2(sh.RTt[fs], p[0], p[1], p[2], uf, vf, K));
+      int idx = ib;
+      unsigned rem = fm;
+#pragma unroll 1
+      while (rem) {
+        const int hi = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        const double2 uv = z[2 * CI + idx];
+        idx++;
+        chit += ba_huber_rho(ba_err2(sh.RTt[sh.slot_of[hi]], p[0], p[1], p[2], uv.x, uv.y, K));
+      }
+    }
+  }
+  if (ok2)
+    for (int i = t; i < 6 * sh.P; i += BA_T) scale_part += sh.x[i] * (lambda * sh.x[i] + sh.bfull[i]);
   out[0] = scale_part;
   out[1] = chit;
 }
@@ -1414,10 +1872,17 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
   double lambda = -1, ni = 2;
   for (int iteration = 0; iteration < iterations; iteration++) {
     BAPROF(0);
-    const double chi = ba_phase_linearize();
+    // (resident records: from the second iteration on the lambda of the first trial is known here, and the linearisation leaves the
+    // Schur phase's staging behind)
+    const int inl = (sh.fused && iteration > 0) ? 1 : 0;  // (the first iteration needs Hpp itself: lambda's initial value)
+    const double chi = inl ? ba_phase_linearize_rec(lambda) : ba_phase_linearize(-1.0);
+    int staged = inl;
     BAPROF(3);
-    double currentChi = block_sum(chi, sh.red[0]);  // (its barriers also publish the per-wave partials / Hll / bl / B)
-    ba_phase_finish_poses();
+    double currentChi = block_sum(chi, sh.red[0]);  // (its barriers also publish the per-wave partials / Hll / bl / the records)
+    if (inl)
+      ba_phase_zero_poses();
+    else
+      ba_phase_finish_poses();
     if (sh.n_imu && t < 64) ba_phase_imu_linearize();
     __syncthreads();
     if (sh.n_imu) {
@@ -1435,20 +1900,20 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
     bool lambda_bad = false;
     do {
       BAPROF(0);
-      if (sh.use_mfma)
+      if (sh.use_mfma) {
         ba_phase_schur_mfma(lambda);
-      else
-        ba_phase_schur(lambda);
-      __syncthreads();
-#ifdef FLVIS_BA_PROF
-      if (t == 0 && sh.prof && !sh.use_mfma && sh.pf_threads) {  // counters 28 .. 32: slowest / mean thread's accumulate ticks, most / mean block products, calls
-        atomicAdd((unsigned long long*)&sh.prof[20], (unsigned long long)sh.pf_tmax);
-        atomicAdd((unsigned long long*)&sh.prof[21], (unsigned long long)(sh.pf_tsum / sh.pf_threads));
-        atomicAdd((unsigned long long*)&sh.prof[22], (unsigned long long)sh.pf_nmax);
-        atomicAdd((unsigned long long*)&sh.prof[23], (unsigned long long)((sh.pf_nsum * 16) / sh.pf_threads));  // (x 16: fixed point)
-        atomicAdd((unsigned long long*)&sh.prof[24], 1ull);
+      } else if (sh.fused) {
+        if (!staged) {
+          ba_phase_stage(lambda);
+        }
+        __syncthreads();
+        BAPROF(2);
+        ba_phase_schur_resident(lambda, inl);
+      } else {
+        ba_phase_schur_chunked(lambda);
       }
-#endif
+      staged = 0;  // a further trial of this iteration has another lambda: the records are rebuilt from the accepted state
+      __syncthreads();
       if (sh.n_imu) {
         ba_phase_imu_offdiag();
         __syncthreads();
@@ -1459,14 +1924,17 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
       BAPROF(8);
       const int ok2 = sh.flag;
       double parts[2];
-      ba_phase_update_chi2(lambda, ok2, parts);
+      if (sh.fused)
+        ba_phase_update_rec(lambda, ok2, parts);
+      else
+        ba_phase_update_chi2(lambda, ok2, parts);
       double scale = parts[0], tempChi = parts[1];
       block_sum2(scale, tempChi, sh.red);
       for (int k = 0; k < sh.n_imu; k++) tempChi += sh.imu_chit[k];
       scale += 1e-3;
       BAPROF(9);
 #ifdef FLVIS_BA_PROF
-      if (t == 0 && sh.prof) atomicAdd((unsigned long long*)&sh.prof[14], 1ull);
+      if (t == 0 && sh.prof) sh.prof_acc[14] += 1;
 #endif
       if (!ok2) tempChi = 1.7976931348623157e308;
       rho = (currentChi - tempChi) / scale;
@@ -1552,6 +2020,7 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
 #ifdef FLVIS_BA_PROF
     sh.prof = p.counters ? p.counters + 8 : nullptr;
     sh.tlast = (long long)wall_clock64();
+    for (int i = 0; i < 16; i++) sh.prof_acc[i] = 0;
     if (sh.prof) {
       atomicAdd((unsigned long long*)&sh.prof[15], 1ull);
       atomicAdd((unsigned long long*)&sh.prof[16], (unsigned long long)E);
@@ -1692,11 +2161,22 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
         atomicAdd((unsigned long long*)&p.counters[5], nt * (unsigned long long)sh.nitems);
         atomicAdd((unsigned long long*)&p.counters[6], nt * (unsigned long long)sh.L);
         atomicAdd((unsigned long long*)&p.counters[7], nt * (unsigned long long)sh.P);
-        atomicAdd((unsigned long long*)&p.counters[60], (unsigned long long)((long long)wall_clock64() - sh.t_begin));  // 10 ns ticks
+        const unsigned long long ticks = (unsigned long long)((long long)wall_clock64() - sh.t_begin);  // 10 ns ticks
+        atomicAdd((unsigned long long*)&p.counters[60], ticks);
+#ifndef FLVIS_BA_PROF
+        if (!sh.fused) {  // (counters 28 / 29: windows whose records did not stay resident -- streamed in chunks -- and their ticks)
+          atomicAdd((unsigned long long*)&p.counters[28], 1ull);
+          atomicAdd((unsigned long long*)&p.counters[29], ticks);
+        }
+#endif
       }
     }
   }
   BAPROF(11);
+#ifdef FLVIS_BA_PROF
+  if (t == 0 && sh.prof)
+    for (int i = 0; i < 15; i++) atomicAdd((unsigned long long*)&sh.prof[i], (unsigned long long)sh.prof_acc[i]);
+#endif
 }
 
 // Local-map worker: one workgroup per stream drains the stream's keyframe queue (bookkeeping + optimisation per keyframe,

@@ -175,6 +175,9 @@ def kernel_table(stages, S, w, h, copy_gbs, pmc=None, ba=None, ms_per_step=None)
         if ba.get("ms_per_optimisation"):
             g = fl / ba["runs"] / (ba["ms_per_optimisation"] * 1e-3) / 1e9
             row["ms_per_optimisation"] = round(ba["ms_per_optimisation"], 4)
+            if ba.get("chunked_runs") is not None:   # windows too large for resident records (streamed in chunks), and what they cost
+                row["chunked_optimisations"] = ba["chunked_runs"]
+                row["ms_per_chunked_optimisation"] = round(ba["ms_per_chunked_optimisation"], 4) if ba.get("ms_per_chunked_optimisation") else None
             row["gflops_per_workgroup"] = round(g, 2)
             row["frac_of_cu_fp64_peak"] = round(g / (FP64_PEAK_TFLOPS * 1e3 / CUS), 4)
         if ba.get("worker_ms_per_launch"):

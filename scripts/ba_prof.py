@@ -42,12 +42,12 @@ for f in range(N):
 c = (C.c_int64 * 64)()
 lib.flvis_debug_counters(ctx._h, c)
 c = np.array(c[:])
-names = ["misc", "structure", "schur:commit+barrier", "linearize_lm", "linearize_pose+chi2", "chol_factor", "tri_solves", "schur", "trial_poses",
+names = ["misc", "structure", "schur:stage+barrier", "linearize_lm", "linearize_pose+chi2", "chol_factor", "tri_solves", "schur", "trial_poses",
          "update", "chi2_trial", "cull/finish"]
 runs, trials = max(c[8 + 15], 1), max(c[8 + 14], 1)
 print("ba runs %d  trials %d (%.1f/run)  edges/run %.0f  landmarks/run %.0f" % (runs, trials, trials / runs, c[8 + 16] / runs, c[8 + 17] / runs))
-print("schur:compute(+prefetch issue) %.1f us/run" % (c[8 + 12] / runs / 100.0))
-tot = sum(c[8:8 + 13])
+print("schur:accumulate %.1f us/run   schur:combine+write %.1f us/run  (then `schur` = waiting for the slowest wave + IMU blocks)" % (c[8 + 12] / runs / 100.0, c[8 + 13] / runs / 100.0))
+tot = sum(c[8:8 + 14])
 for i, n in enumerate(names):
     print("%-16s %8.1f us/run  %5.1f%%" % (n, c[8 + i] / runs / 100.0, 100.0 * c[8 + i] / max(tot, 1)))
 print("total %.1f us/run (100 MHz counter assumed)" % (tot / runs / 100.0))

@@ -47,6 +47,7 @@ for step in "$@"; do
       T=$(find /tmp/gs_trace -name "*kernel_trace.csv" | head -1)
       [ -n "$T" ] && python scripts/rocprof_summary.py "$T" 60 "$OUT/${name}_kernel_summary.md" < /dev/null > /dev/null
       [ -n "$T" ] && python scripts/timeline.py "$T" < /dev/null > "$OUT/${name}_timeline.txt"
+      [ -n "$T" ] && python scripts/ba_launches.py "$T" < /dev/null > "$OUT/${name}_ba_launches.txt" && tail -12 "$OUT/${name}_ba_launches.txt"
       [ -f "$OUT/${name}_kernel_summary.md" ] && head -30 "$OUT/${name}_kernel_summary.md" ;;
     evidence)
       timeout 2700 python -m pytest tests -q -m gpu < /dev/null > "$OUT/${val}_gpu_tests.log" 2>&1; tail -5 "$OUT/${val}_gpu_tests.log"
