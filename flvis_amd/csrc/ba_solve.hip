@@ -396,14 +396,17 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     const int wacc_end = BA_NW * 27 * P;
     sh.off_imu = NR * LD + P * 36 > wacc_end ? NR * LD + P * 36 : wacc_end;
     sh.off_stage = sh.off_imu + (sh.n_imu > 0 ? 120 * W : 0);
-    const int npairs = P * (P + 1) / 2;
-    int slices = 64;
-    while (slices > 1 && slices * npairs > BA_T) slices >>= 1;
-    int rs = slices;  // <= slices keeps the rhs groups aligned to their butterfly width
-    while (rs > 1 && rs * P > BA_T - slices * npairs) rs >>= 1;
+    // pair groups of the Schur accumulate: the P diagonal pairs first, padded to whole waves -- a wave that held both kinds of pairs
+    // would run the two product bodies one after the other --, then the P (P - 1) / 2 pairs i1 < i2
+    int slices = 64, npairs = 0;
+    for (;; slices >>= 1) {
+      const int ppw = 64 / slices;
+      npairs = ((P + ppw - 1) / ppw) * ppw + P * (P - 1) / 2;
+      if (slices == 1 || slices * npairs <= BA_T) break;
+    }
     sh.npairs = npairs;
     sh.slices = slices;
-    sh.rs = rs;
+    sh.rs = 1;
     // MFMA variant: the chunk is the DENSE (NR + 1 rows padded to 16) x (3 columns per landmark) slice of Z' = [Z; c^T]
     const int NRp = (NR + 1 + 15) & ~15;
     const int avail_m = ((int)((sh.lds_budget - BA_SH_BYTES) / 8) - sh.off_stage) & ~1;
@@ -638,10 +641,9 @@ __device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
     }
     for (int rr = lane; rr < NR; rr += 64) {
       if (rr < c0 + 6) continue;
-      double v = xs[rr];
-#pragma unroll
-      for (int k = 0; k < 6; k++) v = fma(-Hs[rr * LD + c0 + k], y[k], v);
-      xs[rr] = v;
+      const double2* own = reinterpret_cast<const double2*>(Hs + rr * LD) + c0 / 2;
+      const double2 l0 = own[0], l1 = own[1], l2 = own[2];
+      xs[rr] = fma(-l2.y, y[5], fma(-l2.x, y[4], fma(-l1.y, y[3], fma(-l1.x, y[2], fma(-l0.y, y[1], fma(-l0.x, y[0], xs[rr]))))));
     }
     wave_lds_fence();
   }
@@ -1171,12 +1173,12 @@ struct SchurRole {
 FD SchurRole ba_schur_role(int t, int P, int npairs, int slices) {
   SchurRole r{-1, -1, 0};
   if (t < npairs * slices) {
-    const int pr = t / slices;
+    const int pr = t / slices, ppw = 64 / slices, dpad = ((P + ppw - 1) / ppw) * ppw;  // (diagonal pairs padded to whole waves)
     r.sl = t - pr * slices;
     if (pr < P) {
       r.i1 = r.i2 = pr;
-    } else {
-      int i1 = 0, rem = pr - P;
+    } else if (pr >= dpad) {
+      int i1 = 0, rem = pr - dpad;
       while (rem >= P - 1 - i1) {
         rem -= P - 1 - i1;
         i1++;
@@ -1762,9 +1764,10 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_update_chi2(double lambda, int ok2, d
 __device__ FLVIS_BA_PHASE_FN void ba_phase_update_rec(double lambda, int ok2, double* out) {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
-  const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, CI = sh.CI, fs = sh.fixed_slot;
+  const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, CI = sh.CI, CL = sh.CL, fs = sh.fixed_slot;
   const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
-  const double2* z = ba_schur_buf(0).z;
+  const SchurBuf B = ba_schur_buf(0);
+  const double2* z = B.z;
   double scale_part = 0, chit = 0;
   for (int l = t; l < L; l += BA_T) {
     const unsigned m = sc.omask[l];
@@ -1782,9 +1785,6 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_update_rec(double lambda, int ok2, do
       }
     }
     if (m && ok2) {
-      double H[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) H[k] = sc.Hll[(size_t)k * Lc + l];
       const double bl[3] = {sc.bl[l], sc.bl[Lc + l], sc.bl[2 * Lc + l]};
       double v[3] = {bl[0], bl[1], bl[2]};
       int idx = ib;
@@ -1804,7 +1804,15 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_update_rec(double lambda, int ok2, do
 #pragma unroll
         for (int c = 0; c < 3; c++) v[c] -= (R[c] - p0.x * R[6 + c]) * j0 + (R[3 + c] - p0.y * R[6 + c]) * j1;
       }
-      const Chol3 g = chol3(H, lambda);
+      Chol3 g;
+      if (fm) {  // the factor of Hll + lambda I the staging left in LDS (landmarks seen by the fixed pose only have none)
+        g = Chol3{B.gb[l], B.gb[CL + l], B.gb[2 * CL + l], B.gb[3 * CL + l], B.gb[4 * CL + l], B.gb[5 * CL + l]};
+      } else {
+        double H[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) H[k] = sc.Hll[(size_t)k * Lc + l];
+        g = chol3(H, lambda);
+      }
       const double y0 = v[0] * g.i00;
       const double y1 = (v[1] - g.g10 * y0) * g.i11;
       const double y2 = (v[2] - g.g20 * y0 - g.g21 * y1) * g.i22;
