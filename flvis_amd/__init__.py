@@ -161,6 +161,35 @@ class Context:
                                                  C.c_double(eps), int(use_initial)), "lk_track")
         return out, status
 
+    def rand_seed(self, seed, n_sets):
+        """flvis_hip_rand_seed: the glibc rand() state of n_sets sets after srand(seed) (int32 [n_sets, 35] on the device)."""
+        import torch
+        st = torch.zeros((n_sets, 35), dtype=torch.int32, device=self.device)
+        self._check(self._lib.flvis_hip_rand_seed(self._h, C.c_uint32(seed), _ptr(st), n_sets), "rand_seed")
+        return st
+
+    def stereo_depth(self, cfg, img0, img1, pt2d_plane, pt2d_undistort, pt3d_w, has_depth, count, poses7, rng, rand_state):
+        """flvis_hip_stereo_depth = CameraFrame::recover3DPts_c_FromStereo (camera_frame.cpp:93-180) for n_sets frames in one call.
+        img0 / img1 uint8 [n,h,w]; pt2d_* float32 [n,cap,2]; pt3d_w float32 [n,cap,3]; has_depth uint8 [n,cap]; count int32 [n] (all on
+        the device); poses7 host [n,7]; rand_state from rand_seed() (updated in place).  Returns (pt3ds float64 [n,cap,3], mask uint8)."""
+        import numpy as np
+        import torch
+        n, cap = pt2d_plane.shape[0], pt2d_plane.shape[1]
+        for a, dt in ((pt2d_plane, torch.float32), (pt2d_undistort, torch.float32), (pt3d_w, torch.float32), (has_depth, torch.uint8),
+                      (count, torch.int32), (img0, torch.uint8), (img1, torch.uint8), (rand_state, torch.int32)):
+            assert a.is_cuda and a.is_contiguous() and a.dtype == dt
+        T = np.ascontiguousarray(poses7, np.float64).reshape(n, 7)
+        out = torch.zeros((n, cap, 3), dtype=torch.float64, device=self.device)
+        mask = torch.zeros((n, cap), dtype=torch.uint8, device=self.device)
+        self._lib.flvis_hip_stereo_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p]
+        self._check(self._lib.flvis_hip_stereo_depth(self._h, C.byref(cfg), _ptr(img0), _ptr(img1), n, _ptr(pt2d_plane),
+                                                     _ptr(pt2d_undistort), _ptr(pt3d_w), _ptr(has_depth), _ptr(count), cap,
+                                                     T.ctypes.data, C.c_float(rng), _ptr(rand_state), _ptr(out), _ptr(mask)),
+                    "stereo_depth")
+        return out, mask
+
     def gftt(self, img, max_corners, quality, min_distance):
         import torch
         img = img.contiguous()

@@ -8,6 +8,7 @@
 
 #include "../../include/flvis_hip.h"
 #include "ctx.hpp"
+#include "pipeline.hpp"
 
 using namespace flvis;
 
@@ -218,6 +219,68 @@ int flvis_hip_lk_track(flvis_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_n
   prm.use_initial = use_initial_flow ? 1 : 0;
   launch_lk_track(ctx->stream, pp, pn, d_prev_pts, d_next_pts, d_status, d_count, nmax, n_img, prm, nullptr);
   CHECK_LAUNCH(ctx, "lk_track");
+  return FLVIS_OK;
+}
+
+// srand(seed) for flvis_hip_stereo_depth's dummy depths: 35 words per set (glibc's r[34] ring + its position)
+int flvis_hip_rand_seed(flvis_ctx* ctx, uint32_t seed, int32_t* d_state35, int n_sets) {
+  CHECK_CTX(ctx);
+  if (!d_state35 || n_sets <= 0) return ctx->fail(FLVIS_ERR_INVALID_ARG, "rand_seed: bad args");
+  std::vector<int> h((size_t)35 * n_sets);
+  glibc_seed(seed, h.data());
+  h[34] = 0;
+  for (int s = 1; s < n_sets; s++) memcpy(&h[(size_t)35 * s], h.data(), sizeof(int) * 35);
+  hipError_t e = hipMemcpyAsync(d_state35, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (h is a local)
+  if (e != hipSuccess) return ctx->hip_fail(e, "rand_seed");
+  return FLVIS_OK;
+}
+
+// CameraFrame::recover3DPts_c_FromStereo (src/processing/camera_frame.cpp:93-180) in one call: seeds -> calcOpticalFlowPyrLK(img0, img1,
+// 31 x 31, maxLevel 5, 30 iterations / 0.001, OPTFLOW_USE_INITIAL_FLOW) -> undistortPoints + DLT + validity + dummy depths
+int flvis_hip_stereo_depth(flvis_ctx* ctx, const flvis_cfg* cfg, const uint8_t* d_img0, const uint8_t* d_img1, int n_sets,
+                           const float* d_pt2d_plane, const float* d_pt2d_undistort, const float* d_pt3d_w, const uint8_t* d_has_depth,
+                           const int* d_count, int cap, const double* h_T_c_w7, float range, int32_t* d_rand_state35, double* d_pt3d_c,
+                           uint8_t* d_mask_has_3d) {
+  CHECK_CTX(ctx);
+  if (!cfg || !d_img0 || !d_img1 || !d_pt2d_plane || !d_pt2d_undistort || !d_pt3d_w || !d_has_depth || !d_count || !h_T_c_w7 ||
+      !d_rand_state35 || !d_pt3d_c || !d_mask_has_3d || n_sets <= 0 || cap <= 0)
+    return ctx->fail(FLVIS_ERR_INVALID_ARG, "stereo_depth: bad args");
+  if (cfg->cam_type == CAM_DEPTH) return ctx->fail(FLVIS_ERR_CONFIG, "stereo_depth: the rig has a depth camera (recover3DPts_c_FromDepthImg), no stereo pair");
+  const int w = cfg->image_width, h = cfg->image_height;
+  if (w < 32 || h < 32) return ctx->fail(FLVIS_ERR_CONFIG, "stereo_depth: image too small");
+  flvis_sd_cam cam;
+  memcpy(cam.K1, cfg->cam1_intrinsics, 32);
+  memcpy(cam.D1, cfg->cam1_distortion, 32);
+  memcpy(cam.R1, cfg->R1, 72);
+  memcpy(cam.P0, cfg->P0, 96);
+  memcpy(cam.P1, cfg->P1, 96);
+  pose7_from_mat44(cfg->T_cam0_cam1, cam.T_c1_c0, true);
+  cam.fx = cfg->P0[0], cam.fy = cfg->P0[5], cam.cx = cfg->P0[2], cam.cy = cfg->P0[6];
+  float* seeds = (float*)ctx->scratch("sd_seeds", sizeof(float) * 2 * (size_t)n_sets * cap);
+  uint8_t* status = (uint8_t*)ctx->scratch("sd_status", (size_t)n_sets * cap);
+  double* d_T = (double*)ctx->scratch("sd_pose", sizeof(double) * 7 * (size_t)n_sets);
+  if (!seeds || !status || !d_T) return ctx->fail(FLVIS_ERR_HIP, "stereo_depth: scratch allocation failed");
+  hipError_t e = hipMemcpyAsync(d_T, h_T_c_w7, sizeof(double) * 7 * (size_t)n_sets, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (the caller's pose array may be reused when this call returns)
+  if (e != hipSuccess) return ctx->hip_fail(e, "stereo_depth pose upload");
+  launch_stereo_depth_seeds(ctx->stream, cam, d_pt2d_plane, d_pt3d_w, d_has_depth, d_count, cap, n_sets, d_T, seeds);
+  int L = lk_levels(w, h, 31, 5);
+  if (L >= LK_MAX_LEVELS) L = LK_MAX_LEVELS - 1;
+  PyrSel pp, pn;
+  int rc = build_pyramid(ctx, "lk_pyr_prev", d_img0, w, h, n_sets, L, pp);
+  if (rc) return rc;
+  rc = build_pyramid(ctx, "lk_pyr_next", d_img1, w, h, n_sets, L, pn);
+  if (rc) return rc;
+  LKParams prm;
+  prm.max_iter = 30;
+  prm.eps2 = 1e-3 * 1e-3;
+  prm.min_eig = 1e-4f;
+  prm.use_initial = 1;
+  launch_lk_track(ctx->stream, pp, pn, d_pt2d_plane, seeds, status, d_count, cap, n_sets, prm, nullptr);
+  launch_stereo_depth_post(ctx->stream, cam, d_pt2d_undistort, seeds, status, d_count, cap, n_sets, range, d_rand_state35, d_pt3d_c,
+                           d_mask_has_3d);
+  CHECK_LAUNCH(ctx, "stereo_depth");
   return FLVIS_OK;
 }
 

@@ -133,4 +133,14 @@ void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, cons
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
                      uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active, int max_pts = 0, int role = 0);
 
+// recover3DPts_c_FromStereo on caller arrays (stereo_depth.hip): the rig constants the two kernels need, and their launchers
+struct flvis_sd_cam {
+  double K1[4], D1[4], R1[9], P0[12], P1[12], T_c1_c0[7];
+  double fx, fy, cx, cy;
+};
+void launch_stereo_depth_seeds(hipStream_t st, const flvis_sd_cam& c, const float* pt2d_plane, const float* pt3d_w, const uint8_t* has_depth,
+                               const int* count, int cap, int n_sets, const double* d_T_c_w7, float* seeds);
+void launch_stereo_depth_post(hipStream_t st, const flvis_sd_cam& c, const float* pt2d_undistort, const float* matched, const uint8_t* status,
+                              const int* count, int cap, int n_sets, float range, int* rand_state35, double* pt3d_c, uint8_t* mask);
+
 }  // namespace flvis

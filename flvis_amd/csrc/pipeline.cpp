@@ -174,6 +174,8 @@ int lk_levels(int w, int h, int win, int max_level) {
   return max_level;
 }
 
+}  // namespace
+namespace flvis {
 // SE3 from a row-major 4x4 as Sophus builds it (SO3(Matrix3d): Eigen's matrix -> quaternion, no normalisation) and, with
 // `inverse`, Sophus' SE3::inverse() (se3.cpp:76-83): q^-1 = normalised conjugate, t^-1 = q^-1 * (-t) by the quaternion
 // rotation formula -- the same operations in the same order as the CPU restatement, so that T_c_i / T_c1_c0 are bit-identical
@@ -242,6 +244,8 @@ void glibc_seed(unsigned s, int* r34) {
   for (int i = 0; i < 34; i++) r34[i] = v[344 - 34 + i];
 }
 
+}  // namespace flvis
+namespace {
 }  // namespace
 
 

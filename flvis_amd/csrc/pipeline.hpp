@@ -169,4 +169,8 @@ struct WindowDev {
   long long ba_runs;
 };
 
+// host helpers shared by the tracker set-up and the one-call entry points (pipeline.cpp)
+void pose7_from_mat44(const double* m44, double* out7, bool inverse);
+void glibc_seed(unsigned s, int* r34);  // the state srand(s) leaves: the last 34 words of glibc's TYPE_3 table
+
 }  // namespace flvis

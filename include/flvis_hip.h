@@ -9,6 +9,7 @@
  * Kernel-level entry points (what a maintainer binds at the reference's OpenCV call sites):
  *   flvis_hip_equalize_hist      <- cv::equalizeHist            src/frontend/f2f_tracking.cpp:127,143-144
  *   flvis_hip_pyr_down           <- pyramid level of cv::calcOpticalFlowPyrLK (buildOpticalFlowPyramid)
+ *   flvis_hip_stereo_depth       <- CameraFrame::recover3DPts_c_FromStereo   src/processing/camera_frame.cpp:93-180
  *   flvis_hip_lk_track           <- cv::calcOpticalFlowPyrLK    src/processing/lkorb_tracking.cpp:64-73,
  *                                                               src/processing/camera_frame.cpp:124-128
  *   flvis_hip_gftt               <- cv::goodFeaturesToTrack     src/processing/feature_dem.cpp:160,221
@@ -262,6 +263,27 @@ typedef struct flvis_frame_out {
 
 int flvis_config_load(const char* yaml_path, flvis_cfg* cfg, char* err, int errlen);
 int flvis_config_finalize(flvis_cfg* cfg);
+
+/* CameraFrame::recover3DPts_c_FromStereo (src/processing/camera_frame.cpp:93-180) in ONE call -- the kernel-level drop-in a
+ * configs[1] integrator (the reference's own frame loop, HIP pieces underneath) puts in its place: the stereo matcher's seeds
+ * (the pixel itself, or for landmarks with depth the world point projected into camera 1 with T_cam1_cam0 * T_c_w, :108-122),
+ * cv::calcOpticalFlowPyrLK(img0, img1, 31 x 31, maxLevel 5, 30 iterations / 0.001, OPTFLOW_USE_INITIAL_FLOW, :124-128),
+ * cv::undistortPoints(K1, D1, R1, P1) (:130-131), Triangulation::trignaulationPtFromStereo with the rig's P0 / P1 (valid unless
+ * z < 0 or z > range) and, for every landmark whose match or triangulation failed, the rand()-drawn dummy depth 0.3 + rand() / (RAND_MAX
+ * / 0.4) through its undistorted pixel (:149-176) -- drawn in landmark order, as the reference's loop calls rand().
+ * A "set" is one frame (n_sets frames of independent streams are matched in one launch).  Per set s, landmark i < d_count[s] (arrays
+ * [n_sets][cap]...): d_pt2d_plane / d_pt2d_undistort / d_pt3d_w / d_has_depth = what getAll2dPlaneUndistort3d_cvPf and hasDepthInf()
+ * hand the reference (cv::Point2f / Point3f: float); h_T_c_w7 (host, [n_sets][7], tx ty tz qx qy qz qw) the frame's pose.
+ * d_img0 / d_img1: device [n_sets][h][w] mono8 of cfg's image size.  range: the float the reference passes (dr_para2).
+ * d_rand_state35: the glibc generator of each set, [n_sets][35] int32 on the device, in / out -- flvis_hip_rand_seed(seed) initialises it
+ * like srand(seed) (seed 1: a process that never called srand, which is what the reference is); consecutive calls continue the sequence.
+ * Outputs: d_pt3d_c [n_sets][cap][3] (pt3ds, camera frame) and d_mask_has_3d [n_sets][cap] (maskHas3DInf).
+ * Returns FLVIS_ERR_CONFIG for a depth-camera rig (recover3DPts_c_FromDepthImg is the tracker's own, flvis_image_feed). */
+int flvis_hip_rand_seed(flvis_ctx* ctx, uint32_t seed, int32_t* d_state35, int n_sets);
+int flvis_hip_stereo_depth(flvis_ctx* ctx, const flvis_cfg* cfg, const uint8_t* d_img0, const uint8_t* d_img1, int n_sets,
+                           const float* d_pt2d_plane, const float* d_pt2d_undistort, const float* d_pt3d_w, const uint8_t* d_has_depth,
+                           const int* d_count, int cap, const double* h_T_c_w7, float range, int32_t* d_rand_state35, double* d_pt3d_c,
+                           uint8_t* d_mask_has_3d);
 
 /* Creates the batched tracker (and local map) for n_streams independent streams inside `ctx`.  seed_base + stream is the
  * RANSAC seed of each stream.  traj_capacity > 0 keeps a device-side trajectory of that many frames per stream. */

@@ -698,6 +698,44 @@ LandMarkInFrame F2FTracking::make_landmark(Vec2 pt2d, Vec2 pt2d_undist, const SE
 static inline Vec3 world2cameraT_c_w(Vec3 p, const SE3& T) { return se3_act(T, p); }
 static inline Vec3 camera2worldT_c_w(Vec3 p, const SE3& T) { return se3_act(se3_inverse(T), p); }
 
+// CameraFrame::recover3DPts_c_FromStereo (camera_frame.cpp:93-180) on the arrays getAll2dPlaneUndistort3d_cvPf hands it: the matcher's
+// seeds, calcOpticalFlowPyrLK img0 -> img1, undistortPoints(K1, D1, R1, P1), trignaulationPtFromStereo and the rand()-drawn dummy depth
+// of every failure, in landmark order.  meas = pt3ds, mask = maskHas3DInf.
+void F2FTracking::recover3DPts_c_FromStereo(const uint8_t* img0, const uint8_t* img1, int n_, const float* p0, const float* p0u, const float* p3,
+                                            const uint8_t* has_3d, const SE3& T_c_w, float rng, Vec3* meas, uint8_t* meas_mask) {
+  const size_t n = (size_t)n_;
+  std::vector<float> p1(p0, p0 + 2 * n), proj(2 * n), p1u(2 * n);
+  std::vector<uint8_t> status(n);
+  if (n) {
+    project_points(p3, (int)n, se3_mul(d_camera.T_cam1_cam0, T_c_w), d_camera.K1, d_camera.D1, proj.data());
+    for (size_t i = 0; i < n; i++)
+      if (has_3d[i]) {
+        p1[2 * i] = proj[2 * i];
+        p1[2 * i + 1] = proj[2 * i + 1];
+      }
+    calc_optical_flow_pyr_lk(img0, img1, d_camera.img_w, d_camera.img_h, p0, p1.data(), status.data(), (int)n, 31, 5, 30, 0.001, 1, 1e-4f);
+    undistort_points(p1.data(), (int)n, d_camera.K1, d_camera.D1, d_camera.R1, d_camera.P1_, p1u.data());
+  }
+  for (size_t i = 0; i < n; i++) {
+    bool ok = false;
+    if (status[i] == 1) {
+      Vec3 pc = triangulate_dlt({(double)p0u[2 * i], (double)p0u[2 * i + 1]}, {(double)p1u[2 * i], (double)p1u[2 * i + 1]},
+                                d_camera.P0_, d_camera.P1_);
+      if (!(pc.z < 0 || pc.z > rng)) {  // quirk A13
+        meas[i] = pc;
+        ok = true;
+      }
+    }
+    if (!ok) {  // quirk A11: rand()-drawn dummy depth
+      float d_rand = (float)(0.3 + (float)rnd.next() / ((float)(2147483647 / (0.4))));
+      double depth = d_rand;
+      meas[i] = {((double)p0u[2 * i] - d_camera.cam0_cx) * depth / d_camera.cam0_fx,
+                 ((double)p0u[2 * i + 1] - d_camera.cam0_cy) * depth / d_camera.cam0_fy, depth};
+    }
+    meas_mask[i] = ok;
+  }
+}
+
 void F2FTracking::depthInnovation(CameraFrame& f) {  // camera_frame.cpp:93-180,236-330
   const size_t n = f.landmarks.size();
   std::vector<Vec3> tri(n), meas(n);
@@ -741,9 +779,9 @@ void F2FTracking::depthInnovation(CameraFrame& f) {  // camera_frame.cpp:93-180,
     }
   } else {
     // recover3DPts_c_FromStereo
-    std::vector<float> p0(2 * n), p1(2 * n), p0u(2 * n), p3(3 * n), proj(2 * n), p1u(2 * n);
-    std::vector<uint8_t> status(n);
-    for (size_t i = 0; i < n; i++) {
+    std::vector<float> p0(2 * n), p0u(2 * n), p3(3 * n);
+    std::vector<uint8_t> has(n);
+    for (size_t i = 0; i < n; i++) {  // getAll2dPlaneUndistort3d_cvPf: cv::Point2f / Point3f copies of the landmarks
       const LandMarkInFrame& lm = f.landmarks[i];
       p0[2 * i] = (float)lm.lm_2d_plane.x;
       p0[2 * i + 1] = (float)lm.lm_2d_plane.y;
@@ -752,37 +790,10 @@ void F2FTracking::depthInnovation(CameraFrame& f) {  // camera_frame.cpp:93-180,
       p3[3 * i] = (float)lm.lm_3d_w.x;
       p3[3 * i + 1] = (float)lm.lm_3d_w.y;
       p3[3 * i + 2] = (float)lm.lm_3d_w.z;
+      has[i] = lm.has_3d ? 1 : 0;
     }
-    p1 = p0;
-    if (n) {
-      project_points(p3.data(), (int)n, se3_mul(d_camera.T_cam1_cam0, f.T_c_w), d_camera.K1, d_camera.D1, proj.data());
-      for (size_t i = 0; i < n; i++)
-        if (f.landmarks[i].has_3d) {
-          p1[2 * i] = proj[2 * i];
-          p1[2 * i + 1] = proj[2 * i + 1];
-        }
-      calc_optical_flow_pyr_lk(f.img0.data(), f.img1.data(), d_camera.img_w, d_camera.img_h, p0.data(), p1.data(),
-                               status.data(), (int)n, 31, 5, 30, 0.001, 1, 1e-4f);
-      undistort_points(p1.data(), (int)n, d_camera.K1, d_camera.D1, d_camera.R1, d_camera.P1_, p1u.data());
-    }
-    for (size_t i = 0; i < n; i++) {
-      bool ok = false;
-      if (status[i] == 1) {
-        Vec3 pc = triangulate_dlt({(double)p0u[2 * i], (double)p0u[2 * i + 1]}, {(double)p1u[2 * i], (double)p1u[2 * i + 1]},
-                                  d_camera.P0_, d_camera.P1_);
-        if (!(pc.z < 0 || pc.z > range)) {  // quirk A13
-          meas[i] = pc;
-          ok = true;
-        }
-      }
-      if (!ok) {  // quirk A11: rand()-drawn dummy depth
-        float d_rand = (float)(0.3 + (float)rnd.next() / ((float)(2147483647 / (0.4))));
-        double depth = d_rand;
-        meas[i] = {((double)p0u[2 * i] - d_camera.cam0_cx) * depth / d_camera.cam0_fx,
-                   ((double)p0u[2 * i + 1] - d_camera.cam0_cy) * depth / d_camera.cam0_fy, depth};
-      }
-      meas_mask[i] = ok;
-    }
+    recover3DPts_c_FromStereo(f.img0.data(), f.img1.data(), (int)n, p0.data(), p0u.data(), p3.data(), has.data(), f.T_c_w, range, meas.data(),
+                              meas_mask.data());
   }
   for (size_t i = 0; i < n; i++) {
     LandMarkInFrame& lm = f.landmarks[i];
@@ -1211,6 +1222,18 @@ int ref_config_load_yaml(const char* path, ref::Config* c, char* err, int errlen
 int ref_config_finalize(ref::Config* c) { return ref::config_finalize(*c) ? 1 : 0; }
 
 void* ref_tracker_create(const ref::Config* cfg, uint64_t seed) { return new ref::F2FTracking(*cfg, seed); }
+// CameraFrame::recover3DPts_c_FromStereo alone, on a tracker's rig and rand() generator; out3 = pt3ds [n][3], mask = maskHas3DInf
+void ref_tracker_stereo_depth(void* h, const uint8_t* img0, const uint8_t* img1, int n, const float* pt2d_plane, const float* pt2d_undistort,
+                              const float* pt3d_w, const uint8_t* has_depth, const double* T_c_w7, float range, double* out3, uint8_t* mask) {
+  ref::F2FTracking* f = (ref::F2FTracking*)h;
+  ref::SE3 T;
+  T.t = {T_c_w7[0], T_c_w7[1], T_c_w7[2]};
+  T.q.x = T_c_w7[3], T.q.y = T_c_w7[4], T.q.z = T_c_w7[5], T.q.w = T_c_w7[6];
+  std::vector<ref::Vec3> meas((size_t)n);
+  f->recover3DPts_c_FromStereo(img0, img1, n, pt2d_plane, pt2d_undistort, pt3d_w, has_depth, T, range, meas.data(), mask);
+  for (int i = 0; i < n; i++) out3[3 * i] = meas[i].x, out3[3 * i + 1] = meas[i].y, out3[3 * i + 2] = meas[i].z;
+}
+
 void ref_tracker_destroy(void* h) { delete (ref::F2FTracking*)h; }
 // acc/gyro already remapped to the FLVIS IMU frame (vo_tracking.cpp:331-357); out10 = q(wxyz) p(3) v(3)
 void ref_tracker_imu(void* h, double t, const double* acc, const double* gyro, double* out10) {

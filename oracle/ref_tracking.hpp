@@ -154,6 +154,9 @@ class F2FTracking {  // src/frontend/f2f_tracking.cpp
   // per-frame diagnostics (tests): counts printed by lkorb_tracking.cpp:191
   int dbg_of_inlier, dbg_F_inlier, dbg_pnp_inlier;
   SE3 dbg_T_pnp = se3_identity(), dbg_T_lm = se3_identity(), dbg_T_pre = se3_identity();  // pose right after solvePnPRansac / after OptimizeInFrame (tests)
+  // CameraFrame::recover3DPts_c_FromStereo on the arrays getAll2dPlaneUndistort3d_cvPf hands it (also called on its own by the tests)
+  void recover3DPts_c_FromStereo(const uint8_t* img0, const uint8_t* img1, int n, const float* p0, const float* p0u, const float* p3,
+                                 const uint8_t* has_3d, const SE3& T_c_w, float rng, Vec3* meas, uint8_t* meas_mask);
 
  private:
   bool init_frame();

@@ -346,6 +346,24 @@ class Tracker:
         return dict(new_keyframe=bool(fl & 1), reset_cmd=bool(fl & 2), state=st.value, pose7=pose, n_landmarks=n.value,
                     dbg=dbg)
 
+    def stereo_depth(self, img0, img1, pt2d_plane, pt2d_undistort, pt3d_w, has_depth, pose7, rng):
+        """CameraFrame::recover3DPts_c_FromStereo alone (camera_frame.cpp:93-180) on this tracker's rig and rand() generator:
+        returns (pt3ds [n,3] float64, maskHas3DInf [n] uint8)."""
+        n = len(pt2d_plane)
+        p0 = np.ascontiguousarray(pt2d_plane, np.float32).reshape(-1, 2)
+        p0u = np.ascontiguousarray(pt2d_undistort, np.float32).reshape(-1, 2)
+        p3 = np.ascontiguousarray(pt3d_w, np.float32).reshape(-1, 3)
+        has = np.ascontiguousarray(has_depth, np.uint8)
+        T = np.ascontiguousarray(pose7, np.float64)
+        out = np.zeros((n, 3))
+        mask = np.zeros(n, np.uint8)
+        img0, img1 = np.ascontiguousarray(img0), np.ascontiguousarray(img1)
+        lib().ref_tracker_stereo_depth.restype = None
+        lib().ref_tracker_stereo_depth.argtypes = [C.c_void_p] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_void_p, C.c_void_p]
+        lib().ref_tracker_stereo_depth(self.h, img0.ctypes.data, img1.ctypes.data, n, p0.ctypes.data, p0u.ctypes.data, p3.ctypes.data,
+                                       has.ctypes.data, T.ctypes.data, C.c_float(rng), out.ctypes.data, mask.ctypes.data)
+        return out, mask
+
     def landmarks(self, cap=2048):
         ids = np.zeros(cap, np.int64)
         p2d = np.zeros((cap, 2))

@@ -262,3 +262,38 @@ def test_oracle_tracks_depth_camera_stream():
     ate = _umeyama_ate(np.array(est), np.array(gt))
     path = np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum()
     assert ate < 0.05 * path + 0.01, (ate, path)
+
+
+def test_oracle_stereo_depth_alone_agrees_with_the_tracker_and_draws_dummy_depths():
+    """CameraFrame::recover3DPts_c_FromStereo restated as a function of its own (the checker of flvis_hip_stereo_depth): on a tracked frame
+    of the synthetic D435 stream the triangulated points agree with the tracker's own landmarks (which went through the same function
+    plus the IIR), a landmark that loses its depth flag is still matched from its pixel, and every failure gets a rand()-drawn depth in
+    [0.3, 0.7) through its undistorted pixel -- the generator consumed in landmark order."""
+    import _stereo_inputs as SI
+    from flvis_amd import synth
+    p = os.path.join(tempfile.gettempdir(), "flvis_test_sd.yaml")
+    open(p, "w").write(synth.D435I_STEREO_YAML)
+    cfg = O.load_config(p)
+    d = SI.tracked_frame(cfg, None, 5, 50 + 4)
+    n = len(d["p2d"])
+    assert n > 100
+    fx, fy, cx, cy = cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]
+    a3, am = O.Tracker(cfg, 1).stereo_depth(d["img0"], d["img1"], d["p2d"], d["p2u"], d["p3w"], d["has"], d["pose7"], 10.0)
+    b3, bm = O.Tracker(cfg, 1).stereo_depth(d["img0"], d["img1"], d["p2d"], d["p2u"], d["p3w"], d["has"], d["pose7"], 10.0)
+    assert np.array_equal(a3, b3) and np.array_equal(am, bm)                      # a function of its inputs and the generator's state
+    assert am.mean() > 0.9
+    R, t = G.pose7_to_Rt(d["pose7"])
+    pc = (R @ d["p3w_exact"].T).T + t                                               # the tracker's landmarks in the camera frame
+    ok = am == 1
+    assert np.median(np.abs(a3[ok, 2] - pc[ok, 2]) / pc[ok, 2]) < 0.02             # same depths (the tracker's are IIR-filtered)
+    # a short range turns the far points into failures; their dummy depths follow glibc's rand() from seed 1, in landmark order
+    c3, cm = O.Tracker(cfg, 1).stereo_depth(d["img0"], d["img1"], d["p2d"], d["p2u"], d["p3w"], d["has"], d["pose7"], 2.0)
+    fail = np.flatnonzero(cm == 0)
+    assert len(fail) > 10 and np.all(cm[a3[:, 2] > 2.0] == 0)
+    z = c3[fail, 2]
+    assert np.all((z >= 0.3) & (z < 0.7000001)) and len(np.unique(z)) == len(z)
+    # rand() after srand(1) is 1804289383; d_rand = 0.3 + float(rand()) / float(RAND_MAX / 0.4) narrowed to float (camera_frame.cpp:153)
+    first = np.float32(0.3 + np.float64(np.float32(1804289383) / np.float32(2147483647 / 0.4)))
+    assert z[0] == np.float64(first)
+    assert np.allclose(c3[fail, 0], (d["p2u"][fail, 0].astype(np.float64) - cx) * z / fx, rtol=0, atol=1e-12)
+    assert np.allclose(c3[fail, 1], (d["p2u"][fail, 1].astype(np.float64) - cy) * z / fy, rtol=0, atol=1e-12)
