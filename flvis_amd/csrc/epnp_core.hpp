@@ -291,7 +291,12 @@ EPNP_UNROLL
 // pairs are independent work items and `part` (entries x chunks doubles, <= 144 x 16) holds the chunk sums.
 // acc(e, i, s): add correspondence i's term(s) of entry e to s;  out(e, s): store entry e's sum.
 constexpr int PART_DOUBLES = 144 * 16;
+#ifdef FLVIS_REF_ORDER_G2O  // (the CPU checker's reference-order build, REF_ORDER=g2o: one chunk = the plain sequential sums of
+                            //  OpenCV's epnp.cpp loops; never defined for the product)
+EPNP_FN int chunk_len(int n) { return n > 0 ? n : 1; }
+#else
 EPNP_FN int chunk_len(int n) { return n <= 256 ? 16 : (n <= 512 ? 32 : 64); }
+#endif
 template <class ACC, class OUT, class SYNC>
 EPNP_FN void chunked_sums(int n, int entries, double* part, int lane, int nl, SYNC sync, ACC acc, OUT out) {
   const int CHUNK = chunk_len(n), nch = (n + CHUNK - 1) / CHUNK;

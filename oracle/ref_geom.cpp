@@ -793,7 +793,15 @@ struct PoseEdge {
 // DESIGN.md -- 32 consecutive edges of the active-edge list (positions 32 c .. 32 c + 31, dead edges counted) are summed in order, then
 // the chunk sums in order: the same minimum to rounding, and a dependent chain an order of magnitude shorter on the device, which
 // follows this very definition (k_pose_lm, PL_CH).
+// `make -C oracle REF_ORDER=g2o` (-DFLVIS_REF_ORDER_G2O -> libflvis_ref_g2o.so) keeps the reference's own order buildable: edge after edge
+// over the id-sorted active edges, as g2o's BaseBinaryEdge::constructQuadraticForm adds them (base_binary_edge.hpp:61-134, sparse_optimizer.cpp:
+// 493-498) -- one "chunk" holds every edge.  tests/test_oracle_tracking.py runs the lockstep sequences on both builds: identical discrete
+// outputs, poses within 1e-12.
+#ifdef FLVIS_REF_ORDER_G2O
+constexpr int POSE_CHUNK = 1 << 30;
+#else
 constexpr int POSE_CHUNK = 32;
+#endif
 
 static double robust_chi2(const SE3& T, const std::vector<PoseEdge>& E, double fx, double fy, double cx, double cy) {
   double chi = 0, part = 0;
@@ -921,6 +929,15 @@ bool optimize_in_frame(SE3& T_c_w, const Vec3* lm_3d_w, const Vec2* lm_2d, const
 
 // ------------------------------------------------------------------------------------------ C entry points (ctypes)
 extern "C" {
+// which summation order this build of the checker uses: 0 = the product's chunk sums (the default, what the lockstep tests compare
+// with), 1 = the reference's (REF_ORDER=g2o)
+int ref_sum_order(void) {
+#ifdef FLVIS_REF_ORDER_G2O
+  return 1;
+#else
+  return 0;
+#endif
+}
 int ref_poly_real_roots(const double* a, int deg, double* roots) { return ref::poly_real_roots(a, deg, roots); }
 // the first `nsub` subsets a RANSAC run over `count` points draws (no checkSubset), and the raw generator outputs
 void ref_cv_subsets(int count, int modelPoints, int nsub, int* idx_out) {

@@ -25,6 +25,17 @@ def lib():
     return _LIB
 
 
+def use_sum_order(order):
+    """Switches every later call of this module to another build of the checker: "product" (the default: libflvis_ref.so, whose pose-LM /
+    EPnP sums are the product's chunk sums) or "g2o" (libflvis_ref_g2o.so, `make -C oracle REF_ORDER=g2o`: the reference's own edge-by-
+    edge / point-by-point order).  Objects created under one build must not be used under the other."""
+    global _LIB
+    lib()                                             # (builds both libraries when stale)
+    name = {"product": "libflvis_ref.so", "g2o": "libflvis_ref_g2o.so"}[order]
+    _LIB = C.CDLL(os.path.join(ROOT, "oracle", name))
+    assert _LIB.ref_sum_order() == (1 if order == "g2o" else 0)
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
