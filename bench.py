@@ -386,7 +386,7 @@ def main():
     nmax = plan.max_frames(K, Wm, skip, epilogue=epi)
     # multi-lane trackers run on their own streams: a private context stream keeps torch's (null) stream out of the frame loop;
     # the rendered inputs are synchronised explicitly below
-    own_stream = int(os.environ.get("FLVIS_LANES", "1") or 1) > 1
+    own_stream = int(os.environ.get("FLVIS_LANES", "1") or 1) > 1 or os.environ.get("FLVIS_BENCH_OWN_STREAM", "0") != "0"   # (A/B knob)
     ctx = flvis_amd.Context(local_rank, own_stream=own_stream)
     trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715 + rank * S, traj_capacity=nmax)
     lib = ctx._lib
@@ -738,9 +738,13 @@ def leg_h2d(L):
     if n <= WU:
         return
     host = []
+    huge = os.environ.get("FLVIS_H2D_HUGEPAGES", "0") != "0"   # (A/B knob: the caller's page-locked images on 2 MB pages)
     for f in range(f0, f0 + n):
         fr = rnd.stereo_frame(trajs, f / synth.FRAME_HZ, f)
-        host.append((fr[0].cpu().pin_memory(), fr[1].cpu().pin_memory()))
+        if huge:
+            host.append(tuple(_pinned_on_huge_pages(x.cpu()) for x in fr))
+        else:
+            host.append((fr[0].cpu().pin_memory(), fr[1].cpu().pin_memory()))
     torch.cuda.synchronize()
     img_t = flvis_image_struct()
     descs = []   # the flvis_image descriptors of every frame (what a caller's capture loop holds anyway), built outside the clock
@@ -756,9 +760,15 @@ def leg_h2d(L):
         descs.append((a, b))
     t0 = 0.0
     calls = []
+    hft0, ht0 = (C.c_double * 4)(), (C.c_double * 3)()
+    names, chain_idx = L["names"], L["chain_idx"]
     for j, f in enumerate(range(f0, f0 + n)):
         if j == WU:
             ctx._check(lib.flvis_hip_synchronize(ctx._h), "synchronize")
+            # the same HIP events as in the timed region: the LK launches and the whole main-stream chain of every frame of the leg
+            ctx._check(lib.flvis_prof_enable_stages(ctx._h, n - WU, C.c_uint64(L["timed_mask"])), "prof_enable")
+            lib.flvis_debug_host_feed_times(ctx._h, hft0)
+            lib.flvis_debug_host_times(ctx._h, ht0)
             t0 = time.perf_counter()
         rc = lib.flvis_imu_feed_all(ctx._h, imu_cnt[f].ctypes.data_as(C.POINTER(C.c_int)), imu[f].ctypes.data_as(C.POINTER(C.c_double)), SPF)
         if rc:
@@ -770,6 +780,9 @@ def leg_h2d(L):
         if rc:
             ctx._check(rc, "image_feed_host")
     t_loop = time.perf_counter() - t0
+    hft1, ht1 = (C.c_double * 4)(), (C.c_double * 3)()
+    lib.flvis_debug_host_feed_times(ctx._h, hft1)
+    lib.flvis_debug_host_times(ctx._h, ht1)
     ctx._check(lib.flvis_hip_synchronize(ctx._h), "synchronize")
     dt = time.perf_counter() - t0
     n_all = n
@@ -777,6 +790,21 @@ def leg_h2d(L):
     out["with_h2d"] = {"value": round(L["world"] * S * n / dt, 1), "unit": "frames/s", "steps": n,
                        "note": "images handed over as pinned host buffers (flvis_image_feed_host, 614,400 B per stereo frame over "
                                "PCIe); %d untimed calls in front; rank 0's rate x n_gpus; never `value`" % WU}
+    ncall = max(hft1[3] - hft0[3], 1)
+    try:
+        leg_stages = L["read_stages"]()
+        leg_chain = L["read_steps"](chain_idx, n)
+        out["with_h2d"]["gpu_frame_chain_p50_ms"] = round(plan.percentile(leg_chain, 50), 4)
+        out["with_h2d"]["lk_ms"] = {k: round(v, 4) for k, v in leg_stages.items() if k.startswith("lk_track")}
+        if os.environ.get("FLVIS_BENCH_FRAMES"):   # (every stage carries events then)
+            out["with_h2d"]["stages_ms"] = {k: round(v, 4) for k, v in leg_stages.items()}
+    except Exception as e:  # noqa: BLE001
+        out["with_h2d"]["stage_error"] = str(e)
+    out["with_h2d"]["host_ms_per_call"] = {"loop": round(t_loop * 1e3 / ncall, 3),
+                                           "waiting_for_the_previous_uploads": round((hft1[0] - hft0[0]) / ncall, 3),
+                                           "issuing_uploads": round((hft1[1] - hft0[1]) / ncall, 3),
+                                           "in_image_feed": round((hft1[2] - hft0[2]) / ncall, 3),
+                                           "of_it_waiting_for_the_host_lead": round((ht1[1] - ht0[1]) / ncall, 3)}
     # ---- what the leg computed: the poses of ALL its frames and streams against a re-run of the whole sequence through the resident
     # path (flvis_image_feed on a second context, same seeds, same frames; that path is the one the lockstep tests hold against the
     # oracle).  An upload that raced a frame, or a staging slot refilled too early, shows as a differing pose.
@@ -813,6 +841,7 @@ def leg_h2d(L):
                                          "against": "a resident re-run of the whole sequence (flvis_image_feed, second context)"}
     if not same or tracked == 0:
         bad = np.argwhere(np.any(rows_h != rows_r, axis=2))
+        out["with_h2d"]["rate_of_the_wrong_results"] = out["with_h2d"]["value"]
         out["with_h2d"]["value"] = None      # a rate of wrong results is not a measurement (the line itself survives: leg_errors)
         raise RuntimeError("the host-image leg's poses differ from the resident re-run (first at stream %d, frame %d; %d tracked poses)"
                            % (tuple(int(v) for v in bad[0]) + (tracked,) if len(bad) else (-1, -1, tracked)))
@@ -820,6 +849,36 @@ def leg_h2d(L):
         out["with_h2d"]["host_call_ms"] = [round(v, 3) for v in calls]
         out["with_h2d"]["loop_ms"] = round(t_loop * 1e3, 3)
         out["with_h2d"]["total_ms"] = round(dt * 1e3, 3)
+
+
+_HUGE_KEEP = []
+
+
+def _pinned_on_huge_pages(t):
+    """A copy of the host tensor t in anonymous memory on 2 MB pages (madvise(MADV_HUGEPAGE)), page-locked with hipHostRegister: what a
+    capture loop that allocates its frame buffers that way hands to flvis_image_feed_host."""
+    import mmap
+    import torch
+    HUGE = 2 << 20
+    nbytes = t.numel() * t.element_size()
+    size = (nbytes + HUGE - 1) // HUGE * HUGE
+    m = mmap.mmap(-1, size + HUGE, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    raw = (C.c_char * (size + HUGE)).from_buffer(m)
+    base = (C.addressof(raw) + HUGE - 1) // HUGE * HUGE
+    libc = C.CDLL(None, use_errno=True)
+    libc.madvise.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
+    libc.madvise(C.c_void_p(base), size, 14)          # MADV_HUGEPAGE
+    C.memset(C.c_void_p(base), 0, size)               # fault the pages in (as huge pages where the kernel has them)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    rc = hip.hipHostRegister(C.c_void_p(base), size, 0)
+    if rc != 0:
+        raise RuntimeError("hipHostRegister failed (%d)" % rc)
+    arr = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(base))
+    out = torch.from_numpy(arr).view(t.dtype).view(t.shape)
+    out.copy_(t)
+    _HUGE_KEEP.append((m, raw))
+    return out
 
 
 def flvis_image_struct():

@@ -141,6 +141,7 @@ struct Pipeline {
     volatile long long* h_up = nullptr;  // host-mapped: number of calls whose uploads have finished (stored by the copy stream)
     long long* d_up = nullptr;
     std::vector<double> times;
+    double ms_wait_uploads = 0, ms_issue = 0, ms_feed = 0;  // host time of the calls: blocked on the previous uploads, issuing, in flvis_image_feed
   } hf;
   Lane& lane_of(int stream, int& local) {
     const int k = stream / lane_size;
@@ -530,7 +531,16 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   } else {
     L->st = ctx->stream;
   }
-  bool evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
+  // (FLVIS_DET_PRIO=1, A/B knob: the detection stream at the lowest queue priority, so that corner-response workgroups that start beside
+  // the tracking chain's kernels do not take a compute unit one of those is waiting for)
+  bool evok;
+  if (getenv("FLVIS_DET_PRIO") && atoi(getenv("FLVIS_DET_PRIO")) != 0) {
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    evok = hipStreamCreateWithPriority(&L->det_stream, hipStreamNonBlocking, lo) == hipSuccess;
+  } else {
+    evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
+  }
   static_assert(Lane::HOLD_RING == 8, "event list below");
   for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
                         &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
@@ -1321,8 +1331,13 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
       std::this_thread::sleep_for(std::chrono::microseconds(30));
     }
   };
+  const auto th0 = std::chrono::steady_clock::now();
   if (hf.n >= 1) wait_uploads(hf.n);
-  if (hf.n >= 2) hipStreamWaitEvent(hf.strm, hf.ev_free[slot], 0);  // the frame that used this slot has been consumed
+  const auto th1 = std::chrono::steady_clock::now();
+  // the frame that used this slot has been consumed.  (NOT implied by the host lead: the uploads are issued before this call waits for the
+  // previous frame to start, i.e. while the frame before that may still be reading the slot -- without this wait the leg's poses differ from
+  // the resident run's, bench.py's check caught it in round 5)
+  if (hf.n >= 2) hipStreamWaitEvent(hf.strm, hf.ev_free[slot], 0);
   // (Measured in round 4, profiles/r04_h2d_full_timeline_*.txt: beside an SDMA upload the chain's latency-bound kernels run 2-3 x slower,
   // the LK launches do not.  Gating the uploads under LK launches -- left image under the previous frame's stereo LK, right image under
   // the frame's own head / temporal LK -- made the leg slower, 40k -> 31k frames/s: k_frame_head / k_track_prepare are latency-bound too
@@ -1336,7 +1351,17 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
     bool contiguous = true;  // one block [S][h][w*bpp]: a single copy
     for (int s = 0; s < S && contiguous; s++)
       contiguous = (size_t)im[s].pitch == row && im[s].data == im[0].data + (size_t)s * img_bytes;
-    if (contiguous) {
+    // (FLVIS_H2D_CHUNK_MB, A/B knob of round 5: the block in chunks with a tiny kernel between two of them -- the engine switch leaves the
+    // link idle for a few microseconds, a window for the command processor's own traffic.  Measured, lost: 32.6k frames/s at 4 and 8 MB,
+    // 22.7k at 2 MB against 28.7-37k in one piece: the uploads take longer and the chain is as long, profiles/r05_h2d.md)
+    static const size_t h2d_chunk = getenv("FLVIS_H2D_CHUNK_MB") ? (size_t)atoi(getenv("FLVIS_H2D_CHUNK_MB")) << 20 : 0;
+    if (contiguous && h2d_chunk) {
+      const size_t total = img_bytes * S;
+      for (size_t off = 0; off < total && e == hipSuccess; off += h2d_chunk) {
+        e = hipMemcpyAsync(hf.raw[slot][c] + off, im[0].data + off, std::min(h2d_chunk, total - off), hipMemcpyHostToDevice, hf.strm);
+        if (off + h2d_chunk < total) launch_store_progress(hf.strm, hf.d_up + 1, (long long)off);  // (a scratch word beside the progress word)
+      }
+    } else if (contiguous) {
       e = hipMemcpyAsync(hf.raw[slot][c], im[0].data, img_bytes * S, hipMemcpyHostToDevice, hf.strm);
     } else {
       for (int s = 0; s < S && e == hipSuccess; s++)
@@ -1364,7 +1389,12 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   // accepts without blocking the caller for milliseconds (measured: 16k vs 28k frames/s when that happened mid-run)
   static const int h2d_lead = getenv("FLVIS_H2D_LEAD") ? std::max(1, std::min(atoi(getenv("FLVIS_H2D_LEAD")), 4)) : 1;  // (A/B knob)
   pl->host_lead_cap = h2d_lead;
+  const auto th2 = std::chrono::steady_clock::now();
   const int rc = flvis_image_feed(ctx, d0, d1, hf.times.data(), h_out, with_local_map);
+  const auto th3 = std::chrono::steady_clock::now();
+  hf.ms_wait_uploads += std::chrono::duration<double, std::milli>(th1 - th0).count();
+  hf.ms_issue += std::chrono::duration<double, std::milli>(th2 - th1).count();
+  hf.ms_feed += std::chrono::duration<double, std::milli>(th3 - th2).count();
   pl->host_lead_cap = 4;
   hipEventRecord(hf.ev_free[slot], st);
   hf.n++;
@@ -1786,6 +1816,14 @@ int flvis_debug_host_times(flvis_ctx* ctx, double* h_out3) {
   h_out3[0] = ctx->pipe->host_ms_total;
   h_out3[1] = ctx->pipe->host_ms_wait;
   h_out3[2] = (double)ctx->pipe->frames_fed;
+  return FLVIS_OK;
+}
+// ... of flvis_image_feed_host: [0] blocked on the previous call's uploads, [1] issuing this call's uploads, [2] inside flvis_image_feed
+// (whose share blocked on the host lead is flvis_debug_host_times [1]), [3] calls
+int flvis_debug_host_feed_times(flvis_ctx* ctx, double* h_out4) {
+  if (!ctx || !ctx->pipe || !h_out4) return FLVIS_ERR_INVALID_ARG;
+  const Pipeline::HostFeed& hf = ctx->pipe->hf;
+  h_out4[0] = hf.ms_wait_uploads, h_out4[1] = hf.ms_issue, h_out4[2] = hf.ms_feed, h_out4[3] = (double)hf.n;
   return FLVIS_OK;
 }
 

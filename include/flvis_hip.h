@@ -301,6 +301,9 @@ int flvis_set_input_hold(flvis_ctx* ctx, int n_frames);
 /* Tuning aid: host milliseconds inside flvis_image_feed since flvis_tracker_create: [0] total, [1] of it blocked on the pinned
  * upload ring, [2] calls. */
 int flvis_debug_host_times(flvis_ctx* ctx, double* h_out3);
+/* ... and of flvis_image_feed_host since the tracker was created: [0] ms blocked on the previous call's uploads (the hold_buffers contract),
+ * [1] ms issuing this call's uploads, [2] ms inside flvis_image_feed, [3] calls. */
+int flvis_debug_host_feed_times(flvis_ctx* ctx, double* h_out4);
 
 /* One IMU sample of stream `stream` in the SENSOR frame; remapped per type_of_vi like imu_callback does.  Samples are
  * staged on the host and consumed by the next flvis_image_feed (feed samples with t <= image time before the image). */

@@ -11,6 +11,8 @@
 #   baprof[=<frames>]            scripts/ba_prof.py (needs a -DFLVIS_BA_PROF variant selected by lib=)  -> ba_prof_<n>.txt
 #   py=<script and args>         python <script and args>                               -> py_<n>.log
 #   trace=<name>[,ENV=V...]      rocprofv3 --kernel-trace --stats of bench.py (60 steps) -> <name>_kernel_summary.md, <name>_timeline.txt
+#   traceh2d=<name>[,ENV=V...]   rocprofv3 kernel + memory-copy trace of bench.py with its host-image leg -> <name>_h2d_kernels.txt (per-kernel
+#                                durations, resident frames vs host-image frames), <name>_h2d_timeline.txt
 #   evidence=<rNN>               the whole GPU suite + smoke + scripts/collect_profiles.sh rNN (the round's last session)
 # After the steps a table of every b_*.json of the session is printed.
 set -u
@@ -49,6 +51,21 @@ for step in "$@"; do
       [ -n "$T" ] && python scripts/timeline.py "$T" < /dev/null > "$OUT/${name}_timeline.txt"
       [ -n "$T" ] && python scripts/ba_launches.py "$T" < /dev/null > "$OUT/${name}_ba_launches.txt" && tail -12 "$OUT/${name}_ba_launches.txt"
       [ -f "$OUT/${name}_kernel_summary.md" ] && head -30 "$OUT/${name}_kernel_summary.md" ;;
+    traceh2d)
+      split_env "$val"
+      rm -rf /tmp/gs_trace
+      (cd /tmp && env "${envs[@]}" timeout 400 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/gs_trace -o b -- python "$R/bench.py" --steps 40 --warmup 10 \
+        --cpu-frames 0 --cpu-mt-frames 0 --no-epilogue < /dev/null > "$OUT/trace_$name.log" 2>&1)
+      T=$(find /tmp/gs_trace -name "*kernel_trace.csv" | head -1); M=$(find /tmp/gs_trace -name "*memory_copy_trace.csv" | head -1)
+      [ -n "$T" ] && [ -n "$M" ] && python scripts/h2d_kernel_compare.py "$T" "$M" < /dev/null > "$OUT/${name}_h2d_kernels.txt" 2>&1 && cat "$OUT/${name}_h2d_kernels.txt"
+      [ -n "$T" ] && [ -n "$M" ] && python scripts/h2d_full_timeline.py "$T" "$M" 2 < /dev/null > "$OUT/${name}_h2d_timeline.txt" 2>&1 ;;
+    traceapi)
+      split_env "$val"
+      rm -rf /tmp/gs_trace
+      (cd /tmp && env "${envs[@]}" timeout 400 rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d /tmp/gs_trace -o b -- python "$R/bench.py" --steps 20 --warmup 5 \
+        --cpu-frames 0 --cpu-mt-frames 0 --no-epilogue < /dev/null > "$OUT/trace_$name.log" 2>&1)
+      A=$(find /tmp/gs_trace -name "*hip_api_trace.csv" | head -1); T=$(find /tmp/gs_trace -name "*kernel_trace.csv" | head -1); M=$(find /tmp/gs_trace -name "*memory_copy_trace.csv" | head -1)
+      [ -n "$A" ] && python scripts/h2d_api_timeline.py "$A" "$T" "$M" < /dev/null > "$OUT/${name}_h2d_api.txt" 2>&1; head -80 "$OUT/${name}_h2d_api.txt" ;;
     evidence)
       timeout 2700 python -m pytest tests -q -m gpu < /dev/null > "$OUT/${val}_gpu_tests.log" 2>&1; tail -5 "$OUT/${val}_gpu_tests.log"
       timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" < /dev/null > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log"
