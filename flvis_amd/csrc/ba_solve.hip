@@ -71,8 +71,10 @@ typedef __attribute__((address_space(1))) unsigned guint;
 struct BAScratch {  // carved out of Pipe::ba_scratch per stream; Lc = landmark stride (a multiple of 64)
   gdouble* lmA;     // [3][Lc]  accepted landmark estimates
   gdouble* lmB;     // [3][Lc]  trial estimates (roles swap on acceptance)
-  gdouble* Hll;     // [6][Lc]  xx xy xz yy yz zz
+  gdouble* Hll;     // [6][Lc]  xx xy xz yy yz zz (at the accepted estimates)
   gdouble* bl;      // [3][Lc]
+  gdouble* Hll2;    // ... at the trial estimates, written by the trial's own evaluation (resident records); swapped in on acceptance
+  gdouble* bl2;
   gdouble* uv;      // [W][2][Lc]
   gint* eid;        // [W][Lc]  edge index or -1
   guint* omask;     // [Lc]  bit slot: landmark has an alive edge to the pose in ring slot `slot`
@@ -87,7 +89,7 @@ struct BAScratch {  // carved out of Pipe::ba_scratch per stream; Lc = landmark 
 // 1/z, M) per observation from the landmark, the pose and the pixel -- 9 doubles in LDS instead of 24 through HBM.)
 
 size_t ba_scratch_doubles() {
-  size_t d = (size_t)BA_LMAX * (3 + 3 + 6 + 3) + (size_t)BA_LMAX * BA_WMAX * 2;
+  size_t d = (size_t)BA_LMAX * (3 + 3 + 6 + 3 + 6 + 3) + (size_t)BA_LMAX * BA_WMAX * 2;
   size_t ints = (size_t)BA_LMAX * BA_WMAX + (size_t)BA_LMAX * 3 + 64 + BA_EMAX + 64;
   return ((d + (ints + 1) / 2 + 64) + 1) & ~(size_t)1;  // even: 16-byte alignment of every stream's slice
 }
@@ -101,6 +103,8 @@ FD BAScratch carve(double* base, int L, int E, int W) {
   s.lmB = q; q += (size_t)3 * Lc;
   s.Hll = q; q += (size_t)6 * Lc;
   s.bl = q; q += (size_t)3 * Lc;
+  s.Hll2 = q; q += (size_t)6 * Lc;
+  s.bl2 = q; q += (size_t)3 * Lc;
   s.uv = q; q += (size_t)2 * W * Lc;
   gint* ii = (gint*)q;
   s.eid = ii; ii += (size_t)W * Lc;
@@ -1759,15 +1763,19 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_update_chi2(double lambda, int ok2, d
 }
 
 // The same with resident records (sh.fused): no per-observation HBM traffic.  The landmark's step is
-// (Hll + lambda I)^-1 (bl - sum_h (w Jl_h)^T (Jp_h dx_h)) with Jp and w Jl rebuilt from the records; the pixels for the trial chi2 come
-// from the records, the fixed pose's from the observation table.
-__device__ FLVIS_BA_PHASE_FN void ba_phase_update_rec(double lambda, int ok2, double* out) {
+// (Hll + lambda I)^-1 (bl - sum_h (w Jl_h)^T (Jp_h dx_h)) with Jp and w Jl rebuilt from the records; the pixels come from the records, the
+// fixed pose's from the observation table.  The evaluation of the trial state IS the next iteration's linearisation when the trial is
+// accepted (g2o: the errors computed for the gain ratio are the ones the next buildSystem starts from): every observation is linearised
+// at the trial state here -- chi2, the landmark's Hll / bl (into Hll2 / bl2, swapped in on acceptance) and the record's (x/z, y/z, 1/z, w),
+// overwritten in place (the landmark's own thread has consumed them).  A rejected trial (rare: none in the benchmark's windows) leaves
+// records of a state that is not kept: the caller rebuilds them (ba_phase_linearize_rec).
+__device__ FLVIS_BA_PHASE_FN void ba_phase_update_lin(double lambda, int ok2, double* out) {
   BAShared& sh = ba_sh();
   const BAScratch sc = sh.sc;
   const int t = threadIdx.x, L = sh.L, Lc = sc.Lc, CI = sh.CI, CL = sh.CL, fs = sh.fixed_slot;
   const double K[4] = {sh.K[0], sh.K[1], sh.K[2], sh.K[3]};
   const SchurBuf B = ba_schur_buf(0);
-  const double2* z = B.z;
+  double2* z = B.z;
   double scale_part = 0, chit = 0;
   for (int l = t; l < L; l += BA_T) {
     const unsigned m = sc.omask[l];
@@ -1828,7 +1836,11 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_update_rec(double lambda, int ok2, do
     sc.lmB[Lc + l] = p[1];
     sc.lmB[2 * Lc + l] = p[2];
     if (m) {
-      if (hf) chit += ba_huber_rho(ba_err2(sh.RTt[fs], p[0], p[1], p[2], uf, vf, K));
+      double h[6] = {0, 0, 0, 0, 0, 0}, bb[3] = {0, 0, 0};
+      if (hf) {
+        const BAObs o = ba_obs(sh.RTt[fs], p[0], p[1], p[2], uf, vf, K);
+        chit += ba_obs_landmark(o, h, bb);
+      }
       int idx = ib;
       unsigned rem = fm;
 #pragma unroll 1
@@ -1836,9 +1848,16 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_update_rec(double lambda, int ok2, do
         const int hi = __builtin_ctz(rem);
         rem &= rem - 1u;
         const double2 uv = z[2 * CI + idx];
+        const BAObs o = ba_obs(sh.RTt[sh.slot_of[hi]], p[0], p[1], p[2], uv.x, uv.y, K);
+        chit += ba_obs_landmark(o, h, bb);
+        z[idx] = double2{o.xn, o.yn};
+        z[CI + idx] = double2{o.iz, o.wgt};
         idx++;
-        chit += ba_huber_rho(ba_err2(sh.RTt[sh.slot_of[hi]], p[0], p[1], p[2], uv.x, uv.y, K));
       }
+#pragma unroll
+      for (int j = 0; j < 6; j++) sc.Hll2[(size_t)j * Lc + l] = h[j];
+#pragma unroll
+      for (int j = 0; j < 3; j++) sc.bl2[(size_t)j * Lc + l] = bb[j];
     }
   }
   if (ok2)
@@ -1878,15 +1897,20 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
   BAPROF(1);
   if (sh.cnt == 0) return;
   double lambda = -1, ni = 2;
+  double currentChi = 0;
+  bool have_lin = false;  // resident records: the accepted trial's evaluation left the linearisation of the state it produced behind
   for (int iteration = 0; iteration < iterations; iteration++) {
     BAPROF(0);
-    // (resident records: from the second iteration on the lambda of the first trial is known here, and the linearisation leaves the
-    // Schur phase's staging behind)
+    // (resident records: from the second iteration on Hpp / bp are summed by the Schur phase, and the linearisation -- when one is
+    // still needed -- leaves the Schur phase's staging for the known lambda behind)
     const int inl = (sh.fused && iteration > 0) ? 1 : 0;  // (the first iteration needs Hpp itself: lambda's initial value)
-    const double chi = inl ? ba_phase_linearize_rec(lambda) : ba_phase_linearize(-1.0);
-    int staged = inl;
-    BAPROF(3);
-    double currentChi = block_sum(chi, sh.red[0]);  // (its barriers also publish the per-wave partials / Hll / bl / the records)
+    int staged = 0;
+    if (!have_lin) {
+      const double chi = inl ? ba_phase_linearize_rec(lambda) : ba_phase_linearize(-1.0);
+      staged = inl;
+      BAPROF(3);
+      currentChi = block_sum(chi, sh.red[0]);  // (its barriers also publish the per-wave partials / Hll / bl / the records)
+    }
     if (inl)
       ba_phase_zero_poses();
     else
@@ -1895,9 +1919,11 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
     __syncthreads();
     if (sh.n_imu) {
       ba_phase_imu_gather();
-      for (int k = 0; k < sh.n_imu; k++) currentChi += sh.imu_chi[k];
+      if (!have_lin)  // (carried over from the accepted trial otherwise: its chi2 included the edges at the state it produced)
+        for (int k = 0; k < sh.n_imu; k++) currentChi += sh.imu_chi[k];
       __syncthreads();
     }
+    have_lin = false;
     BAPROF(4);
     if (iteration == 0) {
       lambda = 1e-5 * block_max(ba_phase_max_diag(), sh.red[0]);
@@ -1933,7 +1959,7 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
       const int ok2 = sh.flag;
       double parts[2];
       if (sh.fused)
-        ba_phase_update_rec(lambda, ok2, parts);
+        ba_phase_update_lin(lambda, ok2, parts);
       else
         ba_phase_update_chi2(lambda, ok2, parts);
       double scale = parts[0], tempChi = parts[1];
@@ -1958,7 +1984,12 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
           gdouble* tmp = sh.sc.lmA;
           sh.sc.lmA = sh.sc.lmB;
           sh.sc.lmB = tmp;
+          if (sh.fused) {  // ... and the trial's evaluation the linearisation of the next iteration
+            tmp = sh.sc.Hll, sh.sc.Hll = sh.sc.Hll2, sh.sc.Hll2 = tmp;
+            tmp = sh.sc.bl, sh.sc.bl = sh.sc.bl2, sh.sc.bl2 = tmp;
+          }
         }
+        have_lin = sh.fused != 0;
         if (t < sh.W) {
 #pragma unroll
           for (int j = 0; j < 7; j++) sh.pose[t][j] = sh.poseT[t][j];
@@ -1972,6 +2003,11 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
         if (!isfinite(lambda)) {
           lambda_bad = true;
           break;
+        }
+        if (sh.fused) {  // the records hold the rejected state: rebuilt from the accepted one, staged for the next trial's lambda
+          __syncthreads();
+          (void)ba_phase_linearize_rec(lambda);
+          staged = 1;
         }
       }
       qmax++;
