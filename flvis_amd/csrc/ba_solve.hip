@@ -7,26 +7,29 @@
 //   EdgeSE3ProjectXYZ + RobustKernelHuber               types/sba/types_six_dof_expmap.cpp:389-433, core/robust_kernel_impl.cpp:65-78
 // as ONE kernel launch per keyframe (12 + 8 LM iterations and the chi2 > 3 cull in between, all in-kernel).
 //
-// Mapping (BA_T threads per window).  HBM scratch is structure-of-arrays so that thread l touches element l of every
-// landmark array and thread i element i of every item array -> coalesced:
-//   * observation table: omask[l] (bit per ring slot), uv[slot][l], edge index [slot][l]; the observations by FREE poses
-//     are numbered landmark-major as "items" (ibase[l] = exclusive prefix of their count) -- rebuilt when edges change;
-//   * linearisation: thread per landmark; a wave walks the ring slots together (fp64 residual, 2x3 / 2x6 Jacobians,
-//     Huber weight): Hll / bl stay in registers, the 6x3 blocks B = w Jp^T Jl go to the item arrays, and the 21 + 6
-//     entries of each pose's Hpp / bp are reduced over the wave with a scattered butterfly (fixed order);
-//   * LM trial: (Hll + lambda I) = G G^T per landmark (3x3 Cholesky in registers); Z = B G^-T and c = G^-1 bl are formed
-//     on the way into LDS.  Only OBSERVED (landmark, pose) blocks are staged (compact, item order), in double-buffered
-//     chunks of a few hundred items: one barrier per chunk, the next chunk's global loads are in flight during the
-//     current chunk's arithmetic.  The reduced system S = Hpp + lambda I - sum_l Z Z^T is accumulated as 6x6 register
-//     tiles: thread = (pose pair, landmark slice), fixed slice partition + fixed butterfly order => bit-reproducible
-//     run to run, no atomics.  rhs = bp - sum_l Z c likewise;
-//   * the reduced camera system (6P x 6P, P <= 15) lives in LDS and is factored by ONE wave: left-looking Cholesky over
-//     6x6 blocks (diagonal blocks factored + inverted in registers), block forward / backward substitution; the same wave
-//     then forms the trial poses;
-//   * back-substitution + trial chi2 in one pass: thread per landmark re-linearises its observations (cheaper than
-//     re-reading the B blocks), solves for its step and evaluates the robust error at the trial state.
-// The accepted / trial landmark sets are two SoA buffers whose roles swap on acceptance (no backup copies).
-// This is latency-bound fp64 on a tiny problem (S is at most 90x90): MFMA is deliberately not used.
+// Mapping (BA_T = 512 threads per window; round 5).  Everything a trial touches per OBSERVATION lives in LDS:
+//   * observation table (HBM, structure of arrays, rebuilt when edges change): omask[l] (bit per ring slot), uv[slot][l], edge index
+//     [slot][l]; the observations by FREE poses are numbered landmark-major as "items" (ibase[l] = exclusive prefix of their count);
+//   * records: per item three 16-byte pairs in LDS -- (x/z, y/z) (1/z, w) (u, v): the point in the camera at the linearisation point,
+//     the Huber weight, the pixel.  The 6x3 block of the classical formulation, B = w Jp^T Jl, has rank 2 and is never formed:
+//     Z = B G^-T = Jp^T M with M = w Jl G^-T (2x3), Jp a function of (x/z, y/z, 1/z) and Jl of those and the pose's rotation rows;
+//     Z_i Z_j^T = Jp_i^T (M_i M_j^T) Jp_j.  A window whose items fit one buffer (~1900 items at 550 landmarks: the D435 windows)
+//     keeps its records RESIDENT for the whole optimisation; larger windows rebuild them chunk by chunk through two buffers;
+//   * per landmark in LDS: G (the 3x3 Cholesky factor of Hll + lambda I, inverted diagonal), c = G^-1 bl, its free-pose mask and
+//     item base; in HBM (coalesced, one latency per phase): the estimate (accepted / trial buffers), Hll, bl (accepted / trial);
+//   * linearisation: thread per landmark walking ITS observations; Hll / bl stay in registers.  Hpp / bp are needed as such only once
+//     per optimize() call (lambda's initial value: a wave walks the poses together and reduce-scatters the 27 entries); afterwards
+//     the Schur phase sums them inside its own walk over the records (the diagonal pair of a pose visits exactly its observations);
+//   * LM trial: [staging: G, c per landmark] -> Schur accumulate: thread = (pose pair, landmark slice of 16), 6x6 register tiles from
+//     the factored products (diagonal pairs: the lower triangle + the pose's right-hand side), fixed slice partition, slices summed
+//     with DPP row shifts => bit-reproducible run to run, no atomics -> the reduced system (6P x 6P, P <= 15) in LDS, factored by
+//     ONE wave: left-looking Cholesky over 6x6 blocks (16-byte aligned rows, 128-bit reads), block substitutions, trial poses ->
+//     update: thread per landmark, the step from the records, and the trial state's evaluation AS a linearisation (chi2, Hll / bl
+//     into the trial buffers, the records overwritten): an accepted trial -- the rule -- leaves the next iteration nothing to linearise.
+// The phase functions are kept small enough to live in the caller-saved registers: a called function that needs more stores and
+// reloads every callee-saved register it touches through scratch memory, per call.
+// This is latency-bound fp64 on a tiny problem (S is at most 90x90); the matrix cores were measured for the Schur complement (slower:
+// FLVIS_BA_MFMA=1, ba_phase_schur_mfma) and are not used.
 #include "dev_common.hpp"
 #include "dev_geom.hpp"
 #include "track_kernels.hpp"
@@ -536,7 +539,34 @@ __device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
   for (int jb = 0; jb < P; jb++) {
     const int c0 = 6 * jb;
     // panel rows (including the diagonal block's rows): subtract the contributions of the finished block columns
+#ifdef FLVIS_BA_SOLVE_MFMA
+    // (build variant, round 5: this update -- panel -= L[rows, 0 : c0] L[c0 : c0 + 6, 0 : c0]^T -- on the matrix cores: 16-row tiles x the 6
+    // columns padded to 16 x c0 / 4 k-steps of v_mfma_f64_16x16x4_f64; north_star names "an MFMA dense solve only for the reduced
+    // camera block", this is the A/B that settles it.  profiles/r05_ba_phases.md)
+    if (jb > 0) {
+      typedef double mf_d4 __attribute__((ext_vector_type(4)));
+      const int ar = lane & 15, ak = lane >> 4, ksteps = (c0 + 3) >> 2;
+      for (int ti = 0; 16 * ti < NR; ti++) {
+        if (16 * ti + 15 < c0) continue;
+        const int row = 16 * ti + ar;
+        mf_d4 acc = {0, 0, 0, 0};
+        for (int ks = 0; ks < ksteps; ks++) {
+          const int k = 4 * ks + ak;
+          const double a = (row < NR && k < c0) ? Hs[row * LD + k] : 0.0;
+          const double b = (ar < 6 && k < c0) ? Hs[(c0 + ar) * LD + k] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {  // D[(lane >> 4) + 4 v][lane & 15]
+          const int r = 16 * ti + (lane >> 4) + 4 * v, c = lane & 15;
+          if (r >= c0 && r < NR && c < 6) Hs[r * LD + c0 + c] -= acc[v];
+        }
+      }
+    }
+    for (int rr = lane; false && rr < NR; rr += 64) {
+#else
     for (int rr = lane; rr < NR; rr += 64) {
+#endif
       if (rr < c0) continue;
       double2* own = reinterpret_cast<double2*>(Hs + rr * LD);  // (rows are 16-byte aligned: three 128-bit accesses per 6-column block)
       double2 a0 = own[c0 / 2], a1 = own[c0 / 2 + 1], a2 = own[c0 / 2 + 2];
@@ -688,8 +718,8 @@ __device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
 // Jacobians Jp (2x6) and Jl (2x3), the Huber weight w and (Hll + lambda I) = G G^T:
 //   Z = w Jp^T Jl G^-T = Jp^T M,  M = w Jl G^-T (2x3),   Z c = Jp^T (M c) = Jp^T r,   Z_i Z_j^T = Jp_i^T (M_i M_j^T) Jp_j,
 // and Jp is a function of (x/z, y/z, 1/z) of the point in the camera (types_six_dof_expmap.cpp:389-433): the record of an item is
-// (xn, yn, iz, M[6]) and the pixel (u, v) -- 11 doubles, stored as six 16-byte pairs [6][CI]:
-//   (xn, yn) (iz, M00) (M01, M02) (M10, M11) (M12, u) (v, -);   c = G^-1 bl is kept per landmark.
+// (xn, yn, iz, w) and the pixel (u, v): three 16-byte pairs (ba_schur_buf); M is rebuilt per product from the record, the pose's
+// rotation rows and the landmark's factor G (ba_record_M); c = G^-1 bl is kept per landmark.
 struct JpRows {
   double a0, a1, a2, a3, a5;  // row 0 (entry 4 is zero)
   double b0, b1, b2, b4, b5;  // row 1 (entry 3 is zero)
