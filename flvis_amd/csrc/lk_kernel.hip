@@ -487,6 +487,8 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
         const bool slow = lk_template_level(lk_level_ptr(prev, level, s, kc_prev, ind_prev0), W, H, prev.pitch[level], prev.bx[level], prev.by[level], ipx,
                                             ipy, iw00, iw01, iw10, iw11, patch, lane, tI, tX, tY, iA11, iA12, iA22);
         if (prm.stats_tc && slow && lane == 0) atomicAdd(&prm.stats_tc[1], 1ull);
+#ifndef FLVIS_LK_NO_TC_STORE  // (timing-only build variant: is the stereo launch bound by its template-cache stores?  the next frame's temporal
+                              //  launch then finds no templates; results unchanged -- profiles/r05_lk_ab.md)
         if (ROLE == 2 && tc_store) {
           lk_u4* dst = reinterpret_cast<lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
           // lane 63 (window row 31: no template) carries the three Hessian sums in the place of its tI registers
@@ -508,6 +510,7 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
           }
           tc_mask |= 1u << level;
         }
+#endif
       }
       const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
       float D = A11 * A22 - A12 * A12;
