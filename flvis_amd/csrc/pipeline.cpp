@@ -1056,8 +1056,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     hipEventRecord(L->ev_gftt, ds);
   };
   if (gftt_first && !gftt_after_lk) detect_corners();
-  auto right_pyramid = [&] {
-    hipStreamWaitEvent(ds, L->ev_head, 0);
+  auto right_pyramid_on = [&](hipStream_t ds, bool on_main) {  // (ds: the stream it runs on -- the detection stream, or the main one)
+    if (!on_main) hipStreamWaitEvent(ds, L->ev_head, 0);
     if (!depth_cam) {
       if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
       else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
@@ -1076,13 +1076,18 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       launch_feature_dem_prep(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
                               p.gftt_act, L->dem_sorted, L->dem_roff);
     }
-    hipEventRecord(L->ev_det, ds);
+    if (!on_main) hipEventRecord(L->ev_det, ds);
   };
+  auto right_pyramid = [&] { right_pyramid_on(ds, false); };
+  // 5 (round 5, A/B knob): the corners as in 3; the right pyramid -- two light launches, 36 us -- on the MAIN stream behind the reprojection
+  // filter, where that stream waits ~50 us for the corner detection anyway, and no join in front of the stereo LK.  Measured (two runs
+  // each, one box): 56.2k / 56.4k frames/s against 56.6k / 56.7k for 3 -- the stereo LK stage does not get shorter: not adopted
+  const bool pyramid_main = gftt_first && gftt_after_lk == 5;
   const bool pyramid_late = gftt_first && gftt_after_lk == 3;  // 3: the right pyramid waits for the F-RANSAC too
   // 4 (round 4): like 3 for the corners, but the right pyramid -- a light, memory-bound pass that only the stereo matcher needs -- runs
   // when the temporal LK has finished, beside the F-RANSAC, instead of behind the corner detection where the stereo LK waited for it
   const bool pyramid_mid = gftt_first && gftt_after_lk == 4;
-  if (!pyramid_late && !pyramid_mid) right_pyramid();
+  if (!pyramid_late && !pyramid_mid && !pyramid_main) right_pyramid();
   // temporal tracking
   PB(4, st);
   {
@@ -1135,6 +1140,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(9, st);
   launch_reproj_filter(st, p);
   PE(9, st);
+  if (pyramid_main) right_pyramid_on(st, true);
   // the IMU filter's correction from this frame's pose: on the detection stream (joined with the triangulation before the depth innovation)
   hipEventRecord(L->ev_lm, st);
   hipStreamWaitEvent(ds, L->ev_lm, 0);
@@ -1155,7 +1161,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   hipStreamWaitEvent(ds, L->ev_lm, 0);
   launch_depth_triangulate(ds, p);
   hipEventRecord(L->ev_tri, ds);
-  if (gftt_first) hipStreamWaitEvent(st, L->ev_det, 0);
+  if (gftt_first && !pyramid_main) hipStreamWaitEvent(st, L->ev_det, 0);
   PB(15, st);
   if (!depth_cam) {
     PyrSel prev, next;
