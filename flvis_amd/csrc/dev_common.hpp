@@ -31,6 +31,17 @@ __device__ __forceinline__ float f32_unordered(uint32_t u) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// The one-workgroup-per-stream kernels of the frame chain run beside full-chip kernels of the other stream (corner response, LK): with
+// FLVIS_CHAIN_PRIO = 1 .. 3 (build knob) their waves ask for the SIMD's issue slots first (s_setprio).  Measured in round 5 (session
+// s40: 56.9k / 56.7k frames/s at 0, 56.6k at 1, 56.5k / 56.5k at 3; every stage time unchanged to the microsecond): the chain's kernels
+// are not held up by their neighbours' instruction issue -- the default stays 0.
+#ifndef FLVIS_CHAIN_PRIO
+#define FLVIS_CHAIN_PRIO 0
+#endif
+__device__ __forceinline__ void chain_priority() {
+  if (FLVIS_CHAIN_PRIO > 0) __builtin_amdgcn_s_setprio(FLVIS_CHAIN_PRIO);
+}
+
 // wave64 reductions over all 64 lanes (result valid in every lane)
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
 #pragma unroll

@@ -212,6 +212,7 @@ __global__ void k_frame_begin(Pipe p, const double* __restrict__ frame_time) {
 // its inputs need not arrive one global round trip at a time -- the wave copies the stream's staged samples into LDS first.
 __global__ __launch_bounds__(64) void k_frame_head(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
                                                    long long frame_no) {
+  chain_priority();
   const int s = blockIdx.x, tid = threadIdx.x;
   // tell the host that this frame's inputs have been uploaded (this kernel follows the upload in stream order): the pinned
   // staging slot of the frame may be refilled (a store to host-mapped memory; the host polls it, see lane_frame)
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(256) void k_track_prepare(Pipe p) { track_prepare_d
 // after a barrier instead of after a launch -- one dependent launch less at the head of every frame's chain
 __global__ __launch_bounds__(256) void k_frame_head_prepare(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
                                                             long long frame_no) {
+  chain_priority();
   const int s = blockIdx.x, tid = threadIdx.x;
   if (s == 0 && tid == 0 && host_progress) __hip_atomic_store(host_progress, frame_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   __shared__ double s_in[IMU_MAX * 7];
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(256) void k_frame_head_prepare(Pipe p, const double
 // lkorb_tracking.cpp:93-125: survivors are appended in DESCENDING index order (quirk A1); the parallel from_* arrays
 // keep ascending order.  One wave per stream.
 __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
+  chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK) return;
@@ -470,6 +473,7 @@ __device__ unsigned long long g_f_rng7[F_TAB_N][F_TAB_B];
 
 constexpr int RF_T = 1024;
 __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
+  chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK || !st.ok) return;
@@ -1399,6 +1403,7 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
 }
 
 __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
+  chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK || !st.ok) return;
@@ -1744,6 +1749,7 @@ __device__ inline void pose_lm_optimize(SE3d& T, PoseLMShared& sh, int n, int it
 }
 
 __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
+  chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK) return;
@@ -1845,6 +1851,7 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
 // calReprjInlierOutlier(1.5) + eraseReprjOutlier + viCorrectionFromVision; prepares the redetect inputs.
 // One workgroup of NMAX threads per stream, one landmark per thread.
 __global__ __launch_bounds__(NMAX) void k_reproj_filter(Pipe p) {
+  chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (st.phase != PH_TRACK) return;
@@ -1931,6 +1938,7 @@ __global__ void k_vi_correction(Pipe p) {
 
 // ------------------------------------------------------------------------------------------------ new landmarks
 __global__ __launch_bounds__(64) void k_add_new(Pipe p) {
+  chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   const int mode = p.det_mode[s];
@@ -1978,6 +1986,7 @@ __global__ __launch_bounds__(64) void k_add_new(Pipe p) {
 // Two kernels, because only the first is on the critical path: the stereo matcher needs its seeds; the two-view triangulation of
 // recover3DPts_c_FromTriangulation is consumed by k_depth_innovate and runs beside the stereo LK on the detection stream.
 __global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
+  chain_priority();
   const int s = blockIdx.y;
   const StreamState& st = p.st[s];
   if (p.det_mode[s] == 0) return;
@@ -2008,6 +2017,7 @@ __global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
   }
 }
 __global__ __launch_bounds__(256) void k_depth_triangulate(Pipe p) {
+  chain_priority();
   const int s = blockIdx.y;
   const StreamState& st = p.st[s];
   if (p.det_mode[s] == 0) return;
@@ -2043,6 +2053,7 @@ __global__ __launch_bounds__(256) void k_depth_triangulate(Pipe p) {
 // depths (quirk A11) are consumed in landmark order: failures are ranked with a workgroup prefix, thread 0 advances the
 // stream's glibc generator by the number of failures.
 __global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
+  chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   if (p.det_mode[s] == 0) return;
@@ -2147,6 +2158,7 @@ __global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
 // init_frame's success test, keyframe decision (f2f_tracking.cpp:329-354,442-452), outputs, KeyFrame payload.
 constexpr int FE_T = 256;
 __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
+  chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
   const int lane = threadIdx.x;  // (first wave does the scalar bookkeeping)
