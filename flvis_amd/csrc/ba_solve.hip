@@ -2259,12 +2259,51 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
 // after releasing the window, so a keyframe is picked up at the latest by the launch that follows it.  An owner takes ba_drain
 // keyframes (one) and leaves the rest to the next launch unless ba_backlog or more are waiting.  The tracker therefore never waits
 // for the optimiser unless a stream has fallen behind by half a queue (KFQ keyframes).
-__global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p) {
-  const int s = blockIdx.x;
+//
+// Which stream a workgroup serves (round 5).  A working workgroup takes its CU whole (512 threads at 253 registers, 159 KB of LDS), and
+// the dispatcher deals the workgroups of a launch to the eight XCDs in turn -- so with workgroup s serving stream s, the streams that
+// happen to have a keyframe decide how many CUs each XCD loses for the next 1.2 ms, while the tracker's kernels are dealt to the XCDs
+// evenly and finish with the XCD that has the fewest CUs left.  With p.ba_remap the FIRST workgroup of a launch to arrive (an arrival
+// counter per local-map HIP stream; launches on one HIP stream do not overlap) writes the list of the streams whose queue holds a
+// keyframe, publishes it under the launch's tag, and workgroup r serves the r-th stream of the list: the working workgroups are the
+// first n of the launch, n / 8 per XCD.  Every stream is still either found empty (when the list is made), found owned, or served: the
+// argument above and the back-pressure bound (pipeline.cpp) hold as before.  The others wait for the list in a sleep loop: the
+// workgroup they wait for is running by construction.  Off by default: measured, no effect on the LK launches (pipeline.cpp).
+__global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p, int plan_slot, unsigned launch_tag) {
   const int t = threadIdx.x;
-  __shared__ int s_go;
+  __shared__ int s_go, s_pick;
   __shared__ unsigned s_head, s_tail;
   __shared__ int s_cnt[BA_NW];
+  if (p.ba_remap) {
+    if (t < 64) {
+      unsigned* plan = p.ba_plan + (size_t)plan_slot * (3 + p.S);
+      unsigned ticket = 0;
+      if (t == 0) ticket = atomicAdd(&plan[0], 1u);
+      ticket = __shfl(ticket, 0);
+      if (ticket % gridDim.x == 0) {
+        unsigned n = 0;
+        for (int j0 = 0; j0 < p.S; j0 += 64) {
+          const int j = j0 + t;
+          const bool waiting = j < p.S && __hip_atomic_load(&p.kfq_tail[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) !=
+                                              __hip_atomic_load(&p.kfq_head[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long m = __ballot(waiting);
+          if (waiting) plan[3 + n + __popcll(m & ((1ull << t) - 1ull))] = (unsigned)j;
+          n += (unsigned)__popcll(m);
+        }
+        if (t == 0) plan[2] = n;
+        __threadfence();
+        if (t == 0) __hip_atomic_store(&plan[1], launch_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (t == 0) {
+        while (__hip_atomic_load(&plan[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != launch_tag) __builtin_amdgcn_s_sleep(4);
+        const unsigned n = __hip_atomic_load(&plan[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_pick = blockIdx.x < n ? (int)__hip_atomic_load(&plan[3 + blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+      }
+    }
+    __syncthreads();
+    if (s_pick < 0) return;
+  }
+  const int s = p.ba_remap ? s_pick : (int)blockIdx.x;
   while (true) {
     if (t == 0) {
       s_go = 0;
@@ -2330,8 +2369,8 @@ __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p) {
   }
 }
 
-void launch_ba_worker(hipStream_t st, const Pipe& p) {
-  hipLaunchKernelGGL(k_ba_worker, dim3(p.S), dim3(BA_T), p.ba_lds_bytes, st, p);
+void launch_ba_worker(hipStream_t st, const Pipe& p, int plan_slot, unsigned launch_tag) {
+  hipLaunchKernelGGL(k_ba_worker, dim3(p.S), dim3(BA_T), p.ba_lds_bytes, st, p, plan_slot, launch_tag);
 }
 int ba_lds_budget_max() { return BA_LDS_BUDGET; }
 hipError_t ba_kernels_init() {

@@ -95,6 +95,7 @@ struct Lane {
   static constexpr int BAQ = 64;
   hipEvent_t ev_ba_done[BAQ] = {};
   long long ba_launches = 0;
+  unsigned ba_tag = 0;           // tag of the lane's last local-map launch (k_ba_worker's stream list is valid for one tag; 0 is never used)
 };
 
 struct Pipeline {
@@ -115,6 +116,7 @@ struct Pipeline {
   // launch per lane and frame on one of the shared local-map streams, round-robin) drains them.  Its output is never fed
   // back into the tracker in the reference (src/frontend/vo_tracking.cpp:373-385).
   static constexpr int NBA = 8;
+  static_assert(NBA == BA_PLAN_SLOTS, "one stream list per local-map HIP stream");
   int nba = 2;                   // local-map streams in use: 2 per lane (FLVIS_BA_STREAMS per lane, tuning knob)
   int nba_lane = 2;              // ... of which every lane uses its own nba_lane
   int host_lead = 2;             // frames the host may run ahead of the GPU (FLVIS_HOST_LEAD, 1 .. PIN_RING)
@@ -377,6 +379,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   DA(kfq_tail, unsigned, S);
   DA(kfq_head, unsigned, S);
   DA(ba_busy, int, S);
+  DA(ba_plan, unsigned, (size_t)BA_PLAN_SLOTS * (3 + S));
   DA(win, WindowDev, S);
   DA(kfs_ring, KeyFrameDev, (size_t)S * BA_WMAX);
   DA(corr, CorrectionDev, S);
@@ -402,6 +405,10 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   // the full queue, where k_frame_end drops keyframes).  A launch takes at least the keyframes of the frames between two launches.
   if (p.ba_drain > 0) p.ba_drain = std::max(p.ba_drain, pl->ba_every);
   p.ba_backlog = KFQ / 2;
+  // FLVIS_BA_REMAP=1 (round 5, A/B knob): workgroup r of a local-map launch serves the r-th stream with a keyframe waiting, not stream r,
+  // so that the working workgroups -- a CU each -- are dealt to the XCDs evenly (k_ba_worker).  Measured (one box, two runs each): 57.3k /
+  // 57.0k frames/s against 57.4k / 57.3k, LK launches 0.226 / 0.264 ms either way: which XCD loses the CUs is not what the LK pays for
+  p.ba_remap = getenv("FLVIS_BA_REMAP") && atoi(getenv("FLVIS_BA_REMAP")) == 1;
   p.ba_mfma = 0;
   if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;
   // LDS a local-map workgroup claims (FLVIS_BA_LDS_KB, 64 .. 159): whatever it leaves of the CU's 160 KB lets LK / corner-response
@@ -880,7 +887,7 @@ static void sync_all(flvis_ctx* ctx) {
       bool pending = false;
       for (int i = 0; i < L->S; i++) pending = pending || hd[i] != tl[i];
       if (!pending) break;
-      launch_ba_worker(pl->ba_stream[0], L->pipe);
+      launch_ba_worker(pl->ba_stream[0], L->pipe, 0, ++L->ba_tag);
       hipStreamSynchronize(pl->ba_stream[0]);
     }
   }
@@ -962,6 +969,16 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // rows, or a caller's buffer at an odd offset) both images are copied into pitch-aligned level 0
   const bool aligned = (w & 15) == 0 && !(((uintptr_t)d_img0 | (depth_cam ? (uintptr_t)0 : (uintptr_t)d_img1)) & 15);
   hipStream_t ds = L->det_stream;
+  // FLVIS_HEAD_STREAM=1 (round 5, A/B knob): the two halves of the frame's head change streams -- the left pyramid on the MAIN stream,
+  // straight behind k_frame_end of the previous frame, k_frame_head on the detection stream; the temporal LK then waits for one event
+  // (the head's) instead of following the head and waiting for the pyramid's.  Only with the detection behind the F-RANSAC (modes >= 2).
+  // Measured (one box, two runs each): 57.1k / 57.3k frames/s against 57.3k / 57.4k; the temporal LK starts 75 us after the head either
+  // way -- the pyramid's two launches take 46 + 22 us beside the local map's workgroups (19 + 12 us alone), and they are what it waits for
+  static const bool head_stream_knob = getenv("FLVIS_HEAD_STREAM") && atoi(getenv("FLVIS_HEAD_STREAM")) == 1 &&
+                                       !(getenv("FLVIS_DET_START") && atoi(getenv("FLVIS_DET_START")) < 2) &&
+                                       !(getenv("FLVIS_DET_ORDER") && atoi(getenv("FLVIS_DET_ORDER")) == 0);
+  const bool head_on_det = head_stream_knob && !skipped;
+  hipStream_t s_img = head_on_det ? st : ds, s_head = head_on_det ? ds : st;
   ImgSel in0 = img_plain(d_img0), in1 = img_plain(d_img1);  // (kernel arguments: no graph is captured)
   ImgSel l0cur{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot, 0, nullptr};
   if (!skipped) {
@@ -973,33 +990,34 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     ImgSel l0in{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot_in, 0, nullptr};
     hipEventRecord(L->ev_lm, st);  // (the frame's input table has been uploaded)
     hipStreamWaitEvent(ds, L->ev_lm, 0);
-    PB(1, ds);
-    if (eq) launch_equalize_hist(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, nullptr);
-    else if (!aligned) launch_copy_image_any(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
-    PE(1, ds);
-    PB(2, ds);
+    PB(1, s_img);
+    if (eq) launch_equalize_hist(s_img, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, nullptr);
+    else if (!aligned) launch_copy_image_any(s_img, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
+    PE(1, s_img);
+    PB(2, s_img);
     // the borders of the levels: written by the pyrDown kernel that produces the level (every pixel also goes to the border positions
     // that mirror it); k_pyr_border only for what is left (level 0 when another kernel makes it, levels smaller than the border)
     PyrSel pyl;
     fill_pyr(pl, pyl, L->pyr0[0], L->pyr0[1], p.img_slot_in, 0, pl->levels);
-    unsigned border_left = pyramid_levels(ds, pl->lbx != 0, in0, w, (size_t)w * h, !eq && aligned, true, pyl, S, nullptr);
-    if (pl->levels == 0 && !eq && aligned) launch_copy_image(ds, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
-    if (border_left) launch_pyr_border(ds, pyl, S, nullptr, border_left);
-    PE(2, ds);
-    hipEventRecord(L->ev_img, ds);
+    unsigned border_left = pyramid_levels(s_img, pl->lbx != 0, in0, w, (size_t)w * h, !eq && aligned, true, pyl, S, nullptr);
+    if (pl->levels == 0 && !eq && aligned) launch_copy_image(s_img, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
+    if (border_left) launch_pyr_border(s_img, pyl, S, nullptr, border_left);
+    PE(2, s_img);
+    if (!head_on_det) hipEventRecord(L->ev_img, ds);
   }
-  PB(0, st);
+  PB(0, s_head);
   // the staged IMU samples, then frame_begin -- and, unless the local-map feedback has to be applied in between, the temporal tracker's
   // inputs in the same launch (FLVIS_HEAD_PREPARE=0, A/B knob: two launches)
   static const bool head_prepare_knob = !(getenv("FLVIS_HEAD_PREPARE") && atoi(getenv("FLVIS_HEAD_PREPARE")) == 0);
   const bool head_prepare = head_prepare_knob && !pl->feedback_used && !skipped;
-  if (head_prepare) launch_frame_head_prepare(st, p, L->d_time, L->d_progress, frame_no);
-  else launch_frame_head(st, p, L->d_time, L->d_progress, frame_no);
-  if (pl->feedback_used) launch_apply_correction(st, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
-  PE(0, st);
+  if (head_prepare) launch_frame_head_prepare(s_head, p, L->d_time, L->d_progress, frame_no);
+  else launch_frame_head(s_head, p, L->d_time, L->d_progress, frame_no);
+  if (pl->feedback_used) launch_apply_correction(s_head, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
+  PE(0, s_head);
   // the detection stream's kernels that read what k_frame_head decides (act_img, gftt_act, gftt_maxc, img_slot) wait for this event:
   // the corner detection and the right pyramid in every FLVIS_DET_START mode (in the default mode they start behind the F-RANSAC anyway)
-  hipEventRecord(L->ev_head, st);
+  hipEventRecord(L->ev_head, s_head);
+  if (head_on_det) hipStreamWaitEvent(st, L->ev_head, 0);  // join: the head (the left pyramid is on this stream)
   if (skipped) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
@@ -1023,7 +1041,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(3, st);
   if (!head_prepare) launch_track_prepare(st, p);
   PE(3, st);
-  hipStreamWaitEvent(st, L->ev_img, 0);  // join: the left pyramid
+  if (!head_on_det) hipStreamWaitEvent(st, L->ev_img, 0);  // join: the left pyramid
   // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
   // for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain.  The right image is only
   // read within this frame, so without equalizeHist the caller's buffer IS level 0 of the right pyramid (no copy).
@@ -1046,7 +1064,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // k_ransac_pnp / k_pose_lm / k_reproj_filter are latency chains on 64 CUs and leave the rest of the chip to the detection.
   static const int gftt_after_lk = getenv("FLVIS_DET_START") ? atoi(getenv("FLVIS_DET_START")) : 3;
   auto detect_corners = [&] {
-    hipStreamWaitEvent(ds, L->ev_head, 0);
+    if (!head_on_det) hipStreamWaitEvent(ds, L->ev_head, 0);
     launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
                 (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
                 (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
@@ -1057,7 +1075,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   };
   if (gftt_first && !gftt_after_lk) detect_corners();
   auto right_pyramid_on = [&](hipStream_t ds, bool on_main) {  // (ds: the stream it runs on -- the detection stream, or the main one)
-    if (!on_main) hipStreamWaitEvent(ds, L->ev_head, 0);
+    if (!on_main && !head_on_det) hipStreamWaitEvent(ds, L->ev_head, 0);
     if (!depth_cam) {
       if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
       else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
@@ -1207,11 +1225,12 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(17, st);
   PE(19, st);
   if (with_local_map && (pl->frames_fed % pl->ba_every) == 0) {
-    hipStream_t bs = pl->ba_stream[(L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba];
+    const int bi = (L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba;
+    hipStream_t bs = pl->ba_stream[bi];
     hipEventRecord(L->ev_fe, st);
     hipStreamWaitEvent(bs, L->ev_fe, 0);
     PB(18, bs);
-    launch_ba_worker(bs, p);
+    launch_ba_worker(bs, p, bi, ++L->ba_tag);
     PE(18, bs);
     hipEventRecord(L->ev_ba_done[L->ba_launches % Lane::BAQ], bs);
     L->ba_launches++;
@@ -1965,7 +1984,7 @@ static int ba_push_impl(flvis_ctx* ctx, int stream, int64_t frame_id, const doub
   tl++;
   hipMemcpy(L.pipe.kfq_tail + ls, &tl, sizeof(unsigned), hipMemcpyHostToDevice);
   hipMemcpy(&L.pipe.corr[ls].valid, &zero, sizeof(int), hipMemcpyHostToDevice);
-  launch_ba_worker(pl->ba_stream[0], L.pipe);
+  launch_ba_worker(pl->ba_stream[0], L.pipe, 0, ++L.ba_tag);
   hipError_t e = hipStreamSynchronize(pl->ba_stream[0]);
   if (e != hipSuccess) return ctx->hip_fail(e, "ba_push_keyframe");
   sync_all(ctx);

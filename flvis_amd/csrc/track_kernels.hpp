@@ -50,6 +50,9 @@ struct Pipe {
   unsigned* kfq_tail;       // [S] keyframes produced
   unsigned* kfq_head;       // [S] keyframes consumed
   int* ba_busy;             // [S] a worker workgroup owns the stream's window
+  unsigned* ba_plan;        // [BA_PLAN_SLOTS][3 + S] per local-map HIP stream: arrival counter, tag of the launch whose list is valid, count, the streams
+                            // with a keyframe waiting (written by the first workgroup of a launch to arrive, k_ba_worker)
+  int ba_remap;             // workgroup r of a local-map launch serves the r-th stream of that list (1) or stream r (0)
   // local map
   WindowDev* win;           // [S]
   KeyFrameDev* kfs_ring;    // [S][BA_WMAX]
@@ -105,7 +108,8 @@ void launch_depth_triangulate(hipStream_t st, const Pipe& p);  // two-view trian
 void launch_depth_innovate(hipStream_t st, const Pipe& p);
 void launch_frame_end(hipStream_t st, const Pipe& p);
 // local map
-void launch_ba_worker(hipStream_t st, const Pipe& p);
+constexpr int BA_PLAN_SLOTS = 8;  // (= Pipeline::NBA: one list per local-map HIP stream, launches on one stream do not overlap)
+void launch_ba_worker(hipStream_t st, const Pipe& p, int plan_slot, unsigned launch_tag);
 hipError_t ba_kernels_init();
 hipError_t track_kernels_init();
 size_t ba_scratch_doubles();
