@@ -2304,6 +2304,77 @@ __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p, int plan_slo
     if (s_pick < 0) return;
   }
   const int s = p.ba_remap ? s_pick : (int)blockIdx.x;
+#ifndef FLVIS_BA_WG_FENCES
+  // Cache maintenance of the hand-over (round 5).  Every XCD has its own L2: an acquire at agent scope is a `buffer_inv sc1` (the XCD's L2
+  // and the CU's L1 drop their lines), a release a `buffer_wbl2 sc1` (the L2 writes its dirty lines back) -- for EVERY wave that executes
+  // one, and the tracker's kernels on the same XCD lose their cached pyramid rows and templates with it.  Up to round 4 the eight waves
+  // of the workgroup each executed four system-scope fences per keyframe beside thread 0's acquire loads and release stores (~40 L2
+  // operations per keyframe, ~1200 per frame of 64 streams).  One wave is enough: thread 0 reads the queue counters with relaxed loads,
+  // and only when it has taken the window does it execute ONE acquire fence; the other threads are ordered behind it by the workgroup
+  // barrier (scoped happens-before is transitive), and they share its CU's L1 and its XCD's L2.  On the way out: barrier, ONE release
+  // fence by thread 0, then the head counter, then (release store) the ownership flag.  -DFLVIS_BA_WG_FENCES: the old form (A/B).
+  while (true) {
+    if (t == 0) {
+      s_go = 0;
+      const unsigned tl = __hip_atomic_load(&p.kfq_tail[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned hd = __hip_atomic_load(&p.kfq_head[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tl != hd && atomicCAS(&p.ba_busy[s], 0, 1) == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the previous owner's window and head, the tracker's keyframes
+        s_go = 1;
+        s_head = __hip_atomic_load(&p.kfq_head[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // only the owner advances the head
+        s_tail = __hip_atomic_load(&p.kfq_tail[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    if (!s_go) return;
+    int taken = 0;
+    bool capped = false;
+    while (true) {
+      const unsigned hd = s_head, tl = s_tail;
+      __syncthreads();  // (everybody has read the two words before thread 0 rewrites them below)
+      if (hd == tl) break;
+      const KeyFrameDev& kf = p.kfq[(size_t)s * KFQ + (hd % KFQ)];
+      const long long frame_id = kf.frame_id;
+#ifdef FLVIS_BA_PROF
+      const long long tu0 = (long long)wall_clock64();
+#endif
+      ba_update_dev(p, s, kf, reinterpret_cast<long long*>(ba_dyn()), s_cnt);
+      __syncthreads();
+#ifdef FLVIS_BA_PROF
+      if (t == 0 && p.counters) {  // (counter 26 / 27: ticks in the bookkeeping of a keyframe, keyframes)
+        atomicAdd((unsigned long long*)&p.counters[26], (unsigned long long)((long long)wall_clock64() - tu0));
+        atomicAdd((unsigned long long*)&p.counters[27], 1ull);
+      }
+#endif
+      if (p.win[s].solve) ba_solve_dev(p, s, frame_id);
+      __syncthreads();
+      if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the window, the landmarks, CorrectionInf: before the head moves
+        __hip_atomic_store(&p.kfq_head[s], hd + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_head = hd + 1u;
+        const unsigned tl2 = __hip_atomic_load(&p.kfq_tail[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tl2 != tl) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // keyframes appended since the last look: their slots are read afresh
+        s_tail = tl2;
+      }
+      __syncthreads();
+      if (p.ba_drain > 0 && ++taken >= p.ba_drain) {
+        // the next launch goes on (one follows every frame, and flvis_hip_synchronize launches until the queues are empty) -- unless
+        // the stream has fallen behind by ba_backlog keyframes: then the owner stays, so that a finished launch has left less than
+        // ba_backlog keyframes of the frames before it in every queue (what the tracker's back-pressure counts on, pipeline.cpp)
+        if (s_tail - s_head < (unsigned)p.ba_backlog) {
+          capped = true;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    // (the head store above is ordered before this one by the release; nothing of the window was written since the last release fence)
+    if (t == 0) __hip_atomic_store(&p.ba_busy[s], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (capped) return;
+    // a keyframe may have arrived between the emptiness test and the release: look again
+  }
+#else
   while (true) {
     if (t == 0) {
       s_go = 0;
@@ -2367,6 +2438,7 @@ __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p, int plan_slo
     if (capped) return;
     // a keyframe may have arrived between the emptiness test and the release: look again
   }
+#endif
 }
 
 void launch_ba_worker(hipStream_t st, const Pipe& p, int plan_slot, unsigned launch_tag) {
