@@ -2293,7 +2293,8 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
       st.kf_dt = 0;
       kf.valid = 1;
     }
-    __atomic_thread_fence(__ATOMIC_RELEASE);
+    // (one release, by the thread that publishes: the barrier orders the other threads' stores before it, and a `buffer_wbl2` per wave
+    // -- what a fence executed by every thread costs -- writes the XCD's L2 back once per wave, k_ba_worker)
     __syncthreads();
     if (lane == 0) __hip_atomic_store(&p.kfq_tail[s], s_tail + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
