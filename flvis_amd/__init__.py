@@ -783,6 +783,33 @@ class Tracker:
                             reprojection_error=o.reprojection_error))
         return res
 
+    def run_steps(self, steps, with_local_map=True):
+        """flvis_run_steps: a batch of frames whose images are already in HBM, one C call (what bench.py times).  steps: a sequence of
+        (img0, img1, times[, imu_counts, imu_samples]) -- uint8 cuda tensors [S,H,W], S floats, and optionally the IMU samples of the
+        step for all streams (int32 [S], float64 [S, n, 7]).  The tensors must stay alive until the context is synchronised."""
+        np = self.np
+
+        class Step(C.Structure):
+            _fields_ = [("d_img0", C.c_void_p), ("d_img1", C.c_void_p), ("h_times", C.c_void_p), ("h_imu_counts", C.c_void_p),
+                        ("h_imu_samples", C.c_void_p), ("imu_samples_per_stream", C.c_int)]
+        arr = (Step * len(steps))()
+        keep = []
+        for j, st in enumerate(steps):
+            img0, img1, times = st[0], st[1], st[2]
+            assert img0.is_cuda and img0.is_contiguous() and img1.is_contiguous() and img0.shape[0] == self.S
+            t = np.ascontiguousarray(times, np.float64)
+            keep.append(t)
+            arr[j].d_img0, arr[j].d_img1, arr[j].h_times = img0.data_ptr(), img1.data_ptr(), t.ctypes.data
+            if len(st) > 3 and st[3] is not None:
+                cnt = np.ascontiguousarray(st[3], np.int32)
+                smp = np.ascontiguousarray(st[4], np.float64)
+                assert cnt.shape == (self.S,) and smp.ndim == 3 and smp.shape[0] == self.S and smp.shape[2] == 7
+                keep += [cnt, smp]
+                arr[j].h_imu_counts, arr[j].h_imu_samples, arr[j].imu_samples_per_stream = cnt.ctypes.data, smp.ctypes.data, smp.shape[1]
+        self.lib.flvis_run_steps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        self.ctx._check(self.lib.flvis_run_steps(self.ctx._h, len(steps), C.cast(arr, C.c_void_p), int(with_local_map), C.c_void_p(0)),
+                        "run_steps")
+
     def _frame_outs(self):
         np = self.np
         return [dict(state=o.state, new_keyframe=bool(o.new_keyframe), reset_cmd=bool(o.reset_cmd),

@@ -95,6 +95,7 @@ struct Lane {
   static constexpr int BAQ = 64;
   hipEvent_t ev_ba_done[BAQ] = {};
   long long ba_launches = 0;
+  bool ba_pending = false;       // FLVIS_BA_START > 0: the local-map launch for the last frame's keyframes has not been enqueued yet
   unsigned ba_tag = 0;           // tag of the lane's last local-map launch (k_ba_worker's stream list is valid for one tag; 0 is never used)
 };
 
@@ -130,6 +131,7 @@ struct Pipeline {
   hipStream_t ba_stream[NBA] = {};
   long long ba_rr = 0;           // round-robin counter over the local-map streams
   hipEvent_t ev_in = nullptr;    // the caller's inputs are ready (recorded on the context's stream)
+  bool defer_ba = false;         // inside flvis_run_steps, not its last step: the local-map launch of this frame may wait for the next frame (FLVIS_BA_START)
   bool feedback_used = false;    // flvis_correction_feed was called: k_apply_correction runs after every frame_begin
   // flvis_image_feed_host: double-buffered device staging filled by async H2D copies on a copy stream, so that the upload of
   // frame N+1 overlaps the kernels of frame N (allocated by the first call)
@@ -862,6 +864,21 @@ static unsigned pyramid_levels(hipStream_t ds, bool bordered, ImgSel src0, int s
   return border_left;
 }
 
+// One local-map launch for the lane (a workgroup per stream takes the stream's next keyframe): on the lane's next local-map HIP stream,
+// behind `ev` of the tracking stream (recorded here when `record` is set), its completion event kept for the back-pressure.
+static void launch_local_map(Pipeline* pl, Lane* L, hipEvent_t ev, bool record, hipEvent_t* prof_begin_end) {
+  const int bi = (L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba;
+  hipStream_t bs = pl->ba_stream[bi];
+  if (record) hipEventRecord(ev, L->st);
+  hipStreamWaitEvent(bs, ev, 0);
+  if (prof_begin_end) hipEventRecord(prof_begin_end[0], bs);
+  launch_ba_worker(bs, L->pipe, bi, ++L->ba_tag);
+  if (prof_begin_end) hipEventRecord(prof_begin_end[1], bs);
+  hipEventRecord(L->ev_ba_done[L->ba_launches % Lane::BAQ], bs);
+  L->ba_launches++;
+  L->ba_pending = false;
+}
+
 static void sync_streams(flvis_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   Pipeline* pl = ctx->pipe;
@@ -876,6 +893,9 @@ static void sync_streams(flvis_ctx* ctx) {
 // waits for everything that was enqueued AND for the local map to have consumed every queued keyframe (a keyframe that
 // slipped in while a worker workgroup was releasing its window is picked up by one more worker launch)
 static void sync_all(flvis_ctx* ctx) {
+  if (ctx->pipe)
+    for (Lane* L : ctx->pipe->lanes)
+      if (L->ba_pending) launch_local_map(ctx->pipe, L, L->ev_fe, true, nullptr);  // (a launch deferred into the next frame: there is none)
   sync_streams(ctx);
   Pipeline* pl = ctx->pipe;
   if (!pl) return;
@@ -962,6 +982,16 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
 #define PE(i, strm) \
   if (prof && ((pl->prof_mask >> (i)) & 1ull)) hipEventRecord(pev[2 * (i) + 1], strm)
   PB(19, st);  // the whole main-stream chain of this frame: per-frame GPU latency (p50/p99 in bench.py)
+  // FLVIS_BA_START (round 5): where the local-map launch for the keyframes of frame n is enqueued.  A launch lasts ~1.4 ms, a frame 1.1 ms:
+  // for 0.3 ms of every frame TWO launches hold their workgroups' CUs (2 x ~31 of 256), for the rest one.  0: straight behind
+  // k_frame_end(n) -- the 0.3 ms are then the head of frame n + 1 and its temporal LK, a kernel that wants every CU.  1 / 2: inside frame
+  // n + 1, behind its F-RANSAC / its PnP RANSAC -- the 0.3 ms fall on the one-workgroup-per-stream kernels of the geometry chain.
+  // Measured (one box, two runs each): 57.80k / 57.86k frames/s with 0, 58.03k / 58.21k with 1 (the 0.3 ms then fall on the corner response,
+  // which is on the critical path of the detection stream), 58.74k / 58.58k with 2 (default; temporal LK 0.212 -> 0.196 ms, frame chain
+  // p50 1.065 -> 1.048 ms).  Only between the steps of one flvis_run_steps call -- the next frame is known to follow at once; a
+  // per-frame caller (the ROS wrapper) gets its local-map launch when its frame ends, as before, and so does the last step of a batch.
+  static const int ba_start = getenv("FLVIS_BA_START") ? atoi(getenv("FLVIS_BA_START")) : 2;
+  hipEvent_t* prof18 = (prof && ((pl->prof_mask >> 18) & 1ull)) ? &pev[2 * 18] : nullptr;
   const bool skipped = pl->frames_fed < (long long)pl->cfg.skip_first_n_imgs;
   const bool depth_cam = pl->cfg.cam_type == CAM_DEPTH;  // the second image is the Z16 depth map, read in place
   const bool eq = pl->cfg.need_equal_hist != 0;
@@ -1148,10 +1178,12 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     hipStreamWaitEvent(ds, L->ev_lm, 0);
     detect_corners();
     if (pyramid_late) right_pyramid();
+    if (ba_start == 1 && L->ba_pending) launch_local_map(pl, L, L->ev_lm, false, prof18);
   }
   PB(7, st);
   launch_ransac_pnp(st, p);
   PE(7, st);
+  if (ba_start == 2 && L->ba_pending) launch_local_map(pl, L, L->ev_fe, true, prof18);
   PB(8, st);
   launch_pose_lm(st, p);  // (with k_track_post's work in its prologue)
   PE(8, st);
@@ -1214,7 +1246,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     // waiting for the launches of D frames ago (the last one on each of the lane's local-map streams) keeps a queue at
     // KFQ / 2 - 1 + (D + 2) * ba_every < KFQ when k_frame_end appends: no keyframe is dropped, whatever the optimiser's pace.
     // (ba_every <= KFQ / 4, flvis_tracker_create.)
-    const long long D = std::max(0, KFQ / 2 / pl->ba_every - 2);
+    const long long D = std::max(0, KFQ / 2 / pl->ba_every - 2 - (ba_start != 0 ? 1 : 0));  // (a deferred launch is one frame late)
     for (int k = 0; k < pl->nba_lane; k++) {
       const long long j = L->ba_launches - 1 - D - k;
       if (j >= 0 && L->ba_launches - j <= Lane::BAQ) hipStreamWaitEvent(st, L->ev_ba_done[j % Lane::BAQ], 0);
@@ -1225,15 +1257,9 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(17, st);
   PE(19, st);
   if (with_local_map && (pl->frames_fed % pl->ba_every) == 0) {
-    const int bi = (L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba;
-    hipStream_t bs = pl->ba_stream[bi];
-    hipEventRecord(L->ev_fe, st);
-    hipStreamWaitEvent(bs, L->ev_fe, 0);
-    PB(18, bs);
-    launch_ba_worker(bs, p, bi, ++L->ba_tag);
-    PE(18, bs);
-    hipEventRecord(L->ev_ba_done[L->ba_launches % Lane::BAQ], bs);
-    L->ba_launches++;
+    if (L->ba_pending) launch_local_map(pl, L, L->ev_fe, true, nullptr);  // (a deferred launch this frame had no place for: skipped frames)
+    if (ba_start != 0 && pl->defer_ba) L->ba_pending = true;
+    else launch_local_map(pl, L, L->ev_fe, true, prof18);
   } else if (!with_local_map) {
     // without a local map nobody consumes the keyframe queue: drop what frame_end appended
     hipMemcpyAsync(p.kfq_head, p.kfq_tail, sizeof(unsigned) * S, hipMemcpyDeviceToDevice, st);
@@ -1453,7 +1479,9 @@ int flvis_run_steps(flvis_ctx* ctx, int n_steps, const flvis_step* steps, int wi
       const int rc = flvis_imu_feed_all(ctx, f.h_imu_counts, f.h_imu_samples, f.imu_samples_per_stream);
       if (rc != FLVIS_OK) return rc;
     }
+    ctx->pipe->defer_ba = k + 1 < n_steps;
     const int rc = flvis_image_feed(ctx, f.d_img0, f.d_img1, f.h_times, nullptr, with_local_map);
+    ctx->pipe->defer_ba = false;
     if (rc != FLVIS_OK) return rc;
     if (h_call_ms) h_call_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
@@ -1501,7 +1529,11 @@ int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps) {
       for (int i = 0; i < PROF_STAGES; i++) {
         float ms = 0;
         if (!prof_stage_timed(pl, i)) continue;
-        hipEventElapsedTime(&ms, L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i], L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i + 1]);
+        // (a stage that was not enqueued in this frame -- a deferred local-map launch, FLVIS_BA_START -- has no recorded events: it counts 0)
+        if (hipEventElapsedTime(&ms, L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i], L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i + 1]) != hipSuccess) {
+          (void)hipGetLastError();
+          ms = 0;
+        }
         h_ms_per_stage[i] += ms / (double)pl->lanes.size();
       }
   *n_steps = pl->prof_step;
@@ -1519,7 +1551,10 @@ int flvis_prof_read_steps(flvis_ctx* ctx, int stage, double* h_ms, int cap) {
     double worst = 0;
     for (Lane* L : pl->lanes) {
       float ms = 0;
-      hipEventElapsedTime(&ms, L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage], L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage + 1]);
+      if (hipEventElapsedTime(&ms, L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage], L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * stage + 1]) != hipSuccess) {
+        (void)hipGetLastError();
+        ms = 0;
+      }
       worst = std::max(worst, (double)ms);
     }
     h_ms[n] = worst;

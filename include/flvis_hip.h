@@ -334,7 +334,10 @@ int flvis_get_imu_states(flvis_ctx* ctx, int stream, int cap, double* h_rows11, 
  * images are already in HBM: per step the IMU samples of all streams (h_imu_counts [n_streams], h_imu_samples
  * [n_streams][imu_samples_per_stream][7] in the FLVIS IMU frame; h_imu_counts NULL: none) and the stereo pair (device pointers as for
  * flvis_image_feed, h_times [n_streams]).  Equivalent to calling flvis_imu_feed_all + flvis_image_feed n_steps times; h_call_ms (may be
- * NULL) receives the host milliseconds each step spent enqueuing.  The images of step k must stay untouched as flvis_image_feed says. */
+ * NULL) receives the host milliseconds each step spent enqueuing.  The images of step k must stay untouched as flvis_image_feed says.
+ * One scheduling difference, none in the results: between two steps of a call the local-map launch for a step's keyframes is enqueued
+ * inside the NEXT step (behind its PnP RANSAC) instead of behind the step itself, so that the ~0.3 ms in which two local-map launches
+ * overlap do not fall on the temporal LK (FLVIS_BA_START=0: as flvis_image_feed).  The last step of a call launches at its end. */
 typedef struct flvis_step {
   const uint8_t* d_img0;
   const uint8_t* d_img1;

@@ -5,7 +5,7 @@
 #   tests=<pytest args>          python -m pytest -q -m gpu <args> (eval'ed: -k 'a or b' may be quoted)  -> tests_<n>.log
 #   smoke                        __graft_entry__.smoke()                                -> smoke.log
 #   lib=<path|->                 FLVIS_LIB_PATH for the steps that follow (a build of scripts/build_variant.sh; "-": the in-tree library)
-#   bench=<name>[,ENV=V...]      bench.py without the CPU / host-image legs             -> b_<name>.json
+#   bench=<name>[,ENV=V...][,--flag...]  bench.py without the CPU / host-image legs (entries starting with -- go to bench.py) -> b_<name>.json
 #   benchh2d=<name>[,ENV=V...]   bench.py with the host-image leg, without the CPU legs -> b_<name>.json
 #   benchfull=<name>[,ENV=V...]  bench.py with every leg (the driver's arguments)       -> b_<name>.json
 #   baprof[=<frames>]            scripts/ba_prof.py (needs a -DFLVIS_BA_PROF variant selected by lib=)  -> ba_prof_<n>.txt
@@ -23,7 +23,10 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$R"
 n=0
-split_env() { IFS=',' read -r -a parts <<< "$1"; name=${parts[0]}; envs=("${parts[@]:1}"); }
+split_env() {  # name[,ENV=V...][,--bench-flag...]: entries that start with "--" are passed to bench.py, the others to env
+  IFS=',' read -r -a parts <<< "$1"; name=${parts[0]}; envs=(); xargs=()
+  for q in "${parts[@]:1}"; do case "$q" in --*) xargs+=("$q") ;; *) envs+=("$q") ;; esac; done
+}
 for step in "$@"; do
   n=$((n + 1))
   key=${step%%=*}; val=""; [ "$key" != "$step" ] && val=${step#*=}
@@ -38,7 +41,7 @@ for step in "$@"; do
         benchh2d) B="--cpu-frames 0 --cpu-mt-frames 0" ;;
         *) B="--gpus 1 --steps 20 --warmup 5" ;;
       esac
-      env "${envs[@]}" timeout 420 python bench.py $B < /dev/null > "$OUT/b_$name.json" 2> "$OUT/b_$name.err" || tail -3 "$OUT/b_$name.err" ;;
+      env "${envs[@]}" timeout 420 python bench.py $B "${xargs[@]}" < /dev/null > "$OUT/b_$name.json" 2> "$OUT/b_$name.err" || tail -3 "$OUT/b_$name.err" ;;
     baprof) timeout 600 python scripts/ba_prof.py ${val:-110} < /dev/null > "$OUT/ba_prof_$n.txt" 2>&1; cat "$OUT/ba_prof_$n.txt" ;;
     py) timeout 900 python $val < /dev/null > "$OUT/py_$n.log" 2>&1; tail -30 "$OUT/py_$n.log" ;;
     trace)

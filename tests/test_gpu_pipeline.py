@@ -366,6 +366,68 @@ def test_host_feed_without_readback_equals_the_resident_run(ctx, hold):
     assert list(na) == list(nb), (na, nb)
 
 
+def test_run_steps_batches_equal_frame_by_frame_feeds(ctx):
+    """flvis_run_steps (what bench.py times) against flvis_imu_feed_all + flvis_image_feed frame by frame, local map on: between the
+    steps of a batch the local-map launch of a step is enqueued inside the NEXT step (FLVIS_BA_START, pipeline.cpp), the last step of
+    a batch launches at its end -- batches of 1, 2 and many steps, back to back without a synchronise, must leave the same
+    trajectories, landmarks, CorrectionInf and counters, bit for bit."""
+    import flvis_amd
+    from flvis_amd import synth
+    cfg, _ = _cfgs()
+    S, nframes = 16, 50 + 34
+    streams = [7 + 5 * i for i in range(S)]
+    trajs = [synth.Trajectory(s) for s in streams]
+    rnd = synth.Renderer("cuda")
+    frames, t_prev = [], -0.05
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        smp = [synth.imu_samples(trajs[i], s, t_prev, t) for i, s in enumerate(streams)]
+        t_prev = t
+        n = max(len(x) for x in smp)
+        cnt = np.array([len(x) for x in smp], np.int32)
+        blk = np.zeros((S, max(n, 1), 7))
+        for i, x in enumerate(smp):
+            blk[i, :len(x)] = x
+        i0, i1 = rnd.stereo_frame(trajs, t, f)
+        frames.append((i0.clone(), i1.clone(), [t] * S, cnt, blk))
+    res = []
+    for mode in ("frames", "batches"):
+        trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715, traj_capacity=nframes)
+        if mode == "frames":
+            for (i0, i1, ts, cnt, blk) in frames:
+                for i in range(S):
+                    trk.imu_feed_flvis(i, blk[i, :cnt[i]])
+                trk.image_feed(i0, i1, ts, want_out=False, with_local_map=True)
+        else:
+            f = 0
+            for nb in (50, 1, 1, 2, 7, 1, 3, nframes):
+                nb = min(nb, nframes - f)
+                if nb > 0:
+                    trk.run_steps(frames[f:f + nb], with_local_map=True)
+                f += nb
+            assert f == nframes
+        ctx.synchronize()
+        rows = np.stack([trk.trajectory(i, 0, nframes) for i in range(S)])
+        lms = [trk.landmarks(i) for i in (0, S - 1)]
+        corr = [trk.correction(i) for i in (0, S - 1)]
+        kf, ba = trk.local_map_counts()
+        res.append((rows, lms, corr, trk.counters(), kf, ba))
+        del trk
+    (ra, la, ca, na, ka, ba_a), (rb, lb, cb, nb_, kb, ba_b) = res
+    assert np.all((ra[:, 50:, 8].astype(int) & 15) == 1)
+    assert ka.sum() > 4 * S and np.array_equal(ka, ba_a)                         # every keyframe was optimised over ...
+    assert np.array_equal(ka, kb) and np.array_equal(ba_a, ba_b)                 # ... in both runs
+    assert np.array_equal(ra, rb), np.abs(ra - rb).max()
+    for x, y in zip(la, lb):
+        for k in ("ids", "flags", "p2d", "p2u", "p3w"):
+            assert np.array_equal(x[k], y[k]), k
+    for x, y in zip(ca, cb):
+        assert x is not None and y is not None and x["frame_id"] == y["frame_id"]
+        assert np.array_equal(x["lm_id"], y["lm_id"]) and np.array_equal(x["outlier_id"], y["outlier_id"])
+        assert np.array_equal(x["pose7"], y["pose7"]) and np.array_equal(x["lm_3d"], y["lm_3d"])
+    assert list(na) == list(nb_), (na, nb_)
+
+
 def test_keyframe_queue_is_bounded_when_the_local_map_lags(ctx):
     """The local-map worker is launched every 8th frame only (FLVIS_BA_EVERY=8) while the batch runs flat out without readback: a
     launch that took one keyframe per stream (round 4's default) would consume a keyframe per 8 frames where the tracker makes one
