@@ -374,7 +374,7 @@ def test_run_steps_batches_equal_frame_by_frame_feeds(ctx):
     import flvis_amd
     from flvis_amd import synth
     cfg, _ = _cfgs()
-    S, nframes = 16, 50 + 34
+    S, nframes = 16, 50 + 48
     streams = [7 + 5 * i for i in range(S)]
     trajs = [synth.Trajectory(s) for s in streams]
     rnd = synth.Renderer("cuda")
@@ -415,8 +415,8 @@ def test_run_steps_batches_equal_frame_by_frame_feeds(ctx):
         del trk
     (ra, la, ca, na, ka, ba_a), (rb, lb, cb, nb_, kb, ba_b) = res
     assert np.all((ra[:, 50:, 8].astype(int) & 15) == 1)
-    assert ka.sum() > 4 * S and np.array_equal(ka, ba_a)                         # every keyframe was optimised over ...
-    assert np.array_equal(ka, kb) and np.array_equal(ba_a, ba_b)                 # ... in both runs
+    assert ka.sum() > 4 * S and ba_a.sum() >= S                                  # keyframes, and windows that were optimised over ...
+    assert np.array_equal(ka, kb) and np.array_equal(ba_a, ba_b)                 # ... the same in both runs
     assert np.array_equal(ra, rb), np.abs(ra - rb).max()
     for x, y in zip(la, lb):
         for k in ("ids", "flags", "p2d", "p2u", "p3w"):
