@@ -146,7 +146,16 @@ struct Pipeline {
     long long* d_up = nullptr;
     std::vector<double> times;
     double ms_wait_uploads = 0, ms_issue = 0, ms_feed = 0;  // host time of the calls: blocked on the previous uploads, issuing, in flvis_image_feed
+    // flvis_debug_host_feed_timing: the uploads of a call bracketed by two timing events on the copy stream (their own durations, what
+    // bench.py's with_h2d.upload_GBs is made of); read back when the slot comes round again
+    bool timing = false;
+    hipEvent_t ev_t0[2] = {}, ev_t1[2] = {};
+    bool timed[2] = {false, false};
+    size_t timed_bytes[2] = {0, 0};
+    double up_ms = 0, up_bytes = 0, up_calls = 0;
+    hipStream_t pad_strm[4] = {};  // FLVIS_H2D_QPAD (A/B knob): streams created in front of the copy stream, so that its hardware queue is another one
   } hf;
+  hipEvent_t up_event = nullptr;  // set by flvis_image_feed_host for its flvis_image_feed call: the upload's event, waited for on the stream that ingests the images
   Lane& lane_of(int stream, int& local) {
     const int k = stream / lane_size;
     local = stream - k * lane_size;
@@ -294,7 +303,11 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
     for (int k = 0; k < 2; k++) {
       if (pl->hf.ev_done[k]) hipEventDestroy(pl->hf.ev_done[k]);
       if (pl->hf.ev_free[k]) hipEventDestroy(pl->hf.ev_free[k]);
+      if (pl->hf.ev_t0[k]) hipEventDestroy(pl->hf.ev_t0[k]);
+      if (pl->hf.ev_t1[k]) hipEventDestroy(pl->hf.ev_t1[k]);
     }
+    for (hipStream_t ps : pl->hf.pad_strm)
+      if (ps) hipStreamSynchronize(ps), hipStreamDestroy(ps);
     if (pl->hf.h_up) hipHostFree((void*)pl->hf.h_up);
   }
   if (pl->ev_in) hipEventDestroy(pl->ev_in);
@@ -1020,6 +1033,9 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     ImgSel l0in{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot_in, 0, nullptr};
     hipEventRecord(L->ev_lm, st);  // (the frame's input table has been uploaded)
     hipStreamWaitEvent(ds, L->ev_lm, 0);
+    // host images (flvis_image_feed_host, FLVIS_H2D_WAIT=1): the upload's event is waited for by the stream that ingests the left image; the
+    // main stream only sees the joins it has anyway (left pyramid in front of the temporal LK, right pyramid in front of the stereo LK)
+    if (pl->up_event) hipStreamWaitEvent(ds, pl->up_event, 0);
     PB(1, s_img);
     if (eq) launch_equalize_hist(s_img, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, nullptr);
     else if (!aligned) launch_copy_image_any(s_img, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
@@ -1340,10 +1356,17 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   hipSetDevice(ctx->device);
   Pipeline::HostFeed& hf = pl->hf;
   if (!hf.strm) {
-    bool ok = hipStreamCreateWithFlags(&hf.strm, hipStreamNonBlocking) == hipSuccess;
+    bool ok = true;
+    const int qpad = getenv("FLVIS_H2D_QPAD") ? std::max(0, std::min(atoi(getenv("FLVIS_H2D_QPAD")), 4)) : 0;
+    for (int k = 0; k < qpad && ok; k++) {
+      ok = hipStreamCreateWithFlags(&hf.pad_strm[k], hipStreamNonBlocking) == hipSuccess;
+      if (ok) launch_store_progress(hf.pad_strm[k], ctx->pipe->lanes[0]->d_progress + 1, 0);  // (a scratch word: the stream gets its hardware queue)
+    }
+    ok = ok && hipStreamCreateWithFlags(&hf.strm, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++)
       ok = hipEventCreateWithFlags(&hf.ev_done[k], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&hf.ev_free[k], hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&hf.ev_free[k], hipEventDisableTiming) == hipSuccess && hipEventCreate(&hf.ev_t0[k]) == hipSuccess &&
+           hipEventCreate(&hf.ev_t1[k]) == hipSuccess;
     if (!ok) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: cannot create the copy stream");
     void* hp = nullptr;
     void* dp = nullptr;
@@ -1389,6 +1412,13 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   // previous frame to start, i.e. while the frame before that may still be reading the slot -- without this wait the leg's poses differ from
   // the resident run's, bench.py's check caught it in round 5)
   if (hf.n >= 2) hipStreamWaitEvent(hf.strm, hf.ev_free[slot], 0);
+  if (hf.timed[slot]) {  // the uploads of two calls ago: done (the previous call's are, and the copy stream is in order)
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, hf.ev_t0[slot], hf.ev_t1[slot]) == hipSuccess) hf.up_ms += ms, hf.up_bytes += (double)hf.timed_bytes[slot], hf.up_calls += 1;
+    else (void)hipGetLastError();
+    hf.timed[slot] = false;
+  }
+  if (hf.timing) hipEventRecord(hf.ev_t0[slot], hf.strm);
   // (Measured in round 4, profiles/r04_h2d_full_timeline_*.txt: beside an SDMA upload the chain's latency-bound kernels run 2-3 x slower,
   // the LK launches do not.  Gating the uploads under LK launches -- left image under the previous frame's stereo LK, right image under
   // the frame's own head / temporal LK -- made the leg slower, 40k -> 31k frames/s: k_frame_head / k_track_prepare are latency-bound too
@@ -1420,11 +1450,24 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
                              hipMemcpyHostToDevice, hf.strm);
     }
   }
+  if (hf.timing && e == hipSuccess) {
+    hipEventRecord(hf.ev_t1[slot], hf.strm);
+    hf.timed[slot] = true;
+    hf.timed_bytes[slot] = (size_t)w * h * S * (bpp[0] + bpp[1]);
+  }
   if (e == hipSuccess) e = hipEventRecord(hf.ev_done[slot], hf.strm);
   if (e != hipSuccess) return ctx->hip_fail(e, "image_feed_host upload");
   launch_store_progress(hf.strm, hf.d_up, hf.n + 1);
   hipStream_t st = ctx->stream;
-  hipStreamWaitEvent(st, hf.ev_done[slot], 0);
+  // FLVIS_H2D_WAIT (round 6): which stream waits for the uploads.  0: the main stream, in front of the frame (rounds 1-5).  1: the detection
+  // stream, in front of the left image's ingest -- every reader of the staged images is ordered behind that stream already (the left
+  // pyramid's join in front of the temporal LK, the right pyramid's in front of the stereo LK, which reads the right image in place).  Only
+  // for single-channel stereo input on a single lane past the skipped start-up frames; the other cases keep the wait on the main stream.
+  static const int h2d_wait = getenv("FLVIS_H2D_WAIT") ? atoi(getenv("FLVIS_H2D_WAIT")) : 0;
+  const bool wait_on_det = h2d_wait == 1 && ch0 == 1 && ch1 == 1 && !depth_cam && pl->lanes.size() == 1 &&
+                           pl->frames_fed >= (long long)pl->cfg.skip_first_n_imgs;
+  if (wait_on_det) pl->up_event = hf.ev_done[slot];
+  else hipStreamWaitEvent(st, hf.ev_done[slot], 0);
   const uint8_t* d0 = hf.raw[slot][0];
   const uint8_t* d1 = hf.raw[slot][1];
   if (ch0 > 1) {
@@ -1442,6 +1485,7 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   pl->host_lead_cap = h2d_lead;
   const auto th2 = std::chrono::steady_clock::now();
   const int rc = flvis_image_feed(ctx, d0, d1, hf.times.data(), h_out, with_local_map);
+  pl->up_event = nullptr;
   const auto th3 = std::chrono::steady_clock::now();
   hf.ms_wait_uploads += std::chrono::duration<double, std::milli>(th1 - th0).count();
   hf.ms_issue += std::chrono::duration<double, std::milli>(th2 - th1).count();
@@ -1884,6 +1928,14 @@ int flvis_debug_host_feed_times(flvis_ctx* ctx, double* h_out4) {
   if (!ctx || !ctx->pipe || !h_out4) return FLVIS_ERR_INVALID_ARG;
   const Pipeline::HostFeed& hf = ctx->pipe->hf;
   h_out4[0] = hf.ms_wait_uploads, h_out4[1] = hf.ms_issue, h_out4[2] = hf.ms_feed, h_out4[3] = (double)hf.n;
+  return FLVIS_OK;
+}
+
+int flvis_debug_host_feed_timing(flvis_ctx* ctx, int enable, double* h_out3) {
+  if (!ctx || !ctx->pipe) return FLVIS_ERR_INVALID_ARG;
+  Pipeline::HostFeed& hf = ctx->pipe->hf;
+  if (enable >= 0) hf.timing = enable != 0;
+  if (h_out3) h_out3[0] = hf.up_ms, h_out3[1] = hf.up_bytes, h_out3[2] = hf.up_calls;
   return FLVIS_OK;
 }
 

@@ -304,6 +304,10 @@ int flvis_debug_host_times(flvis_ctx* ctx, double* h_out3);
 /* ... and of flvis_image_feed_host since the tracker was created: [0] ms blocked on the previous call's uploads (the hold_buffers contract),
  * [1] ms issuing this call's uploads, [2] ms inside flvis_image_feed, [3] calls. */
 int flvis_debug_host_feed_times(flvis_ctx* ctx, double* h_out4);
+/* ... and the uploads themselves: enable = 1 brackets every call's uploads with two timing events on the copy stream, 0 stops that, -1
+ * leaves the setting; h_out3 (may be NULL) = [0] ms of the bracketed uploads that have finished, [1] their bytes, [2] their number.
+ * (What bench.py's with_h2d.upload_GBs is made of: bytes / the copies' own durations, not the host's view.) */
+int flvis_debug_host_feed_timing(flvis_ctx* ctx, int enable, double* h_out3);
 
 /* One IMU sample of stream `stream` in the SENSOR frame; remapped per type_of_vi like imu_callback does.  Samples are
  * staged on the host and consumed by the next flvis_image_feed (feed samples with t <= image time before the image). */

@@ -4,6 +4,8 @@
 # Everything a step writes goes to gpurun_out/TAG/.  Steps, executed in order, each under its own timeout:
 #   tests=<pytest args>          python -m pytest -q -m gpu <args> (eval'ed: -k 'a or b' may be quoted)  -> tests_<n>.log
 #   smoke                        __graft_entry__.smoke()                                -> smoke.log
+#   env=<K=V> / unset=<K>        an environment variable for the steps that follow
+#   sh=<command line>            bash -c <command line>                                 -> sh_<n>.log
 #   lib=<path|->                 FLVIS_LIB_PATH for the steps that follow (a build of scripts/build_variant.sh; "-": the in-tree library)
 #   bench=<name>[,ENV=V...][,--flag...]  bench.py without the CPU / host-image legs (entries starting with -- go to bench.py) -> b_<name>.json
 #   benchh2d=<name>[,ENV=V...]   bench.py with the host-image leg, without the CPU legs -> b_<name>.json
@@ -34,6 +36,9 @@ for step in "$@"; do
     tests) eval "timeout 2400 python -m pytest -q -m gpu $val" < /dev/null > "$OUT/tests_$n.log" 2>&1; tail -4 "$OUT/tests_$n.log" ;;
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" < /dev/null > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
     lib) if [ "$val" = "-" ]; then unset FLVIS_LIB_PATH; else export FLVIS_LIB_PATH="$R/$val"; fi ;;
+    env) export "$val" ;;
+    unset) unset "$val" ;;
+    sh) timeout 1200 bash -c "$val" < /dev/null > "$OUT/sh_$n.log" 2>&1; tail -15 "$OUT/sh_$n.log" ;;
     bench|benchh2d|benchfull)
       split_env "$val"
       case "$key" in
@@ -85,7 +90,8 @@ for f in sorted(glob.glob(sys.argv[1] + "/b_*.json"), key=os.path.getmtime):
         st = r.get("stages_ms_per_step", {}) or {}
         h = r.get("with_h2d") or {}
         print(os.path.basename(f), r["value"], r["ms_per_step"], "chain p50/p99", l.get("gpu_frame_chain_p50"), l.get("gpu_frame_chain_p99"),
-              "lk", st.get("lk_track(temporal)"), st.get("lk_track(stereo)"), "h2d", h.get("value"), h.get("poses_bit_identical"))
+              "lk", st.get("lk_track(temporal)"), st.get("lk_track(stereo)"), "h2d", h.get("value") or h.get("value_unchecked"), h.get("poses_bit_identical"),
+              "up GB/s", (h.get("link") or {}).get("upload_GBs"), (h.get("link") or {}).get("upload_alone_GBs"), "h2d chain", h.get("gpu_frame_chain_p50_ms"))
     except Exception as e:
         print(os.path.basename(f), "failed", e)
 PY
