@@ -2278,9 +2278,14 @@ __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p, int plan_slo
     if (t < 64) {
       unsigned* plan = p.ba_plan + (size_t)plan_slot * (3 + p.S);
       unsigned ticket = 0;
-      if (t == 0) ticket = atomicAdd(&plan[0], 1u);
+      if (t == 0) {
+        ticket = atomicAdd(&plan[0], 1u);
+        // (the last arrival of a launch puts the counter back to 0 -- launches on one local-map HIP stream do not overlap -- so that it never
+        // wraps: with a grid size that is not a power of two a wrapped counter would leave a launch without a list maker)
+        if (ticket + 1u == gridDim.x) __hip_atomic_store(&plan[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       ticket = __shfl(ticket, 0);
-      if (ticket % gridDim.x == 0) {
+      if (ticket == 0) {
         unsigned n = 0;
         for (int j0 = 0; j0 < p.S; j0 += 64) {
           const int j = j0 + t;
@@ -2322,7 +2327,9 @@ __global__ __launch_bounds__(BA_T) BA_ATTR void k_ba_worker(Pipe p, int plan_slo
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the previous owner's window and head, the tracker's keyframes
         s_go = 1;
         s_head = __hip_atomic_load(&p.kfq_head[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // only the owner advances the head
-        s_tail = __hip_atomic_load(&p.kfq_tail[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the tail as read BEFORE the fence: the fence synchronises with the release stores of the keyframes up to that value only.  A
+        // keyframe k_frame_end appends after it is seen by the loop below (tl2 != tl), which acquires again before its slot is read.
+        s_tail = tl;
       }
     }
     __syncthreads();

@@ -13,6 +13,7 @@
 // `1 - pow(2 rho - 1, 3)`, optimization_algorithm_levenberg.cpp:124; cv::RANSACUpdateNumIters `pow(1 - ep, modelPoints)`):
 // det_powi multiplies, left to right.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -309,6 +310,78 @@ DETM_FN double det_powi(double x, int n) {
   double r = x;
   for (int i = 1; i < n; i++) r = r * x;
   return r;
+}
+
+// e_acos.c (cv::solveCubic's three-real-root branch and cv::p3p's solve_deg3 take the arc cosine of R / sqrt(Q^3))
+DETM_FN double det_acos(double x) {
+  const double one = 1.0, pi = 3.14159265358979311600e+00, pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+               pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+               pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
+               qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+               qS4 = 7.70381505559019352791e-02;
+  const int32_t hx = dhi(x);
+  const int32_t ix = hx & 0x7fffffff;
+  if (ix >= 0x3ff00000) {  // |x| >= 1
+    if (((uint32_t)(ix - 0x3ff00000) | dlo(x)) == 0) return hx > 0 ? 0.0 : pi + 2.0 * pio2_lo;
+    return (x - x) / (x - x);  // NaN
+  }
+  if (ix < 0x3fe00000) {  // |x| < 0.5
+    if (ix <= 0x3c600000) return pio2_hi + pio2_lo;
+    const double z = x * x;
+    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const double q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const double r = p / q;
+    return pio2_hi - (x - (pio2_lo - r * x));
+  }
+  if (hx < 0) {  // x < -0.5
+    const double z = (one + x) * 0.5;
+    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const double q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const double s = sqrt(z);
+    const double r = p / q;
+    const double w = r * s - pio2_lo;
+    return pi - 2.0 * (s + w);
+  }
+  const double z = (one - x) * 0.5;  // x > 0.5
+  const double s = sqrt(z);
+  const double df = from_dbits(dbits(s) & 0xffffffff00000000ull);
+  const double c = (z - df * df) / (s + df);
+  const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+  const double q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+  const double r = p / q;
+  const double w = r * s + c;
+  return 2.0 * (df + w);
+}
+
+// s_cbrt.c (normal numbers; 0, inf and NaN returned as they are)
+DETM_FN double det_cbrt(double x) {
+  const uint32_t B1 = 715094163u;
+  const double C = 5.42857142857142815906e-01, D = -7.05306122448979611050e-01, E = 1.41428571428571436819e+00,
+               F = 1.60714285714285720630e+00, G = 3.57142857142857150787e-01;
+  int32_t hx = dhi(x);
+  const uint32_t sign = (uint32_t)hx & 0x80000000u;
+  hx ^= (int32_t)sign;
+  if (hx >= 0x7ff00000) return x + x;
+  if (((uint32_t)hx | dlo(x)) == 0) return x;
+  x = with_hi(x, hx);  // |x|
+  double t;
+  if (hx < 0x00100000) {  // subnormal
+    t = with_hi(0.0, 0x43500000);
+    t *= x;
+    t = with_hi(t, (int32_t)((uint32_t)dhi(t) / 3u + 696219795u));
+  } else {
+    t = with_hi(0.0, (int32_t)((uint32_t)hx / 3u + B1));
+  }
+  double r = t * t / x;
+  double s = C + r * t;
+  t *= G + F / (s + E + D / s);
+  t = from_dbits(((uint64_t)(uint32_t)(dhi(t) + 1)) << 32);  // chopped to 20 bits, made larger than cbrt(x)
+  s = t * t;  // exact
+  r = x / s;
+  const double w = t + t;
+  r = (r - t) / (w + r);
+  t = t + t * r;
+  return from_dbits(dbits(t) | ((uint64_t)sign << 32));
 }
 
 }  // namespace detm

@@ -137,8 +137,18 @@ struct Pipeline {
   // frame N+1 overlaps the kernels of frame N (allocated by the first call)
   struct HostFeed {
     hipStream_t strm = nullptr;
-    uint8_t* raw[2][2] = {};   // [slot][camera]: the images as handed over (tightly packed rows of w * bytes-per-pixel)
-    uint8_t* gray[2][2] = {};  // [slot][camera]: cvtColor output for 3/4-channel input
+    static constexpr int SLOTS = 3;   // (mode 2 cycles through three staging slots, mode 1 through two)
+    uint8_t* raw[SLOTS][2] = {};   // [slot][camera]: the images as handed over (tightly packed rows of w * bytes-per-pixel)
+    uint8_t* gray[SLOTS][2] = {};  // [slot][camera]: cvtColor output for 3/4-channel input
+    // mode 2 (round 6, default): nothing but copies on the copy stream.  Behind the images of a call the copy engine writes a block of
+    // sequence numbers (FLAG_WORDS x the call's number, from a page-locked ring: large enough not to be turned into a blit kernel);
+    // k_wait_flag on the stream that ingests the images waits for it; the host learns that the uploads are done from hipStreamQuery
+    // and that a slot is free from the frame-progress word.  No event, no kernel, no AQL barrier packet on the copy stream's queue.
+    int mode = 2;
+    static constexpr int FLAG_WORDS = 4096, FLAG_RING = 4;
+    long long* h_flag[FLAG_RING] = {};
+    long long* d_flag = nullptr;
+    long long slot_frame[SLOTS] = {0, 0, 0};  // the lane frame number (frames_uploaded) that read the slot last
     size_t raw_bytes[2] = {}, gray_bytes = 0;
     hipEvent_t ev_done[2] = {}, ev_free[2] = {};
     long long n = 0;
@@ -156,6 +166,9 @@ struct Pipeline {
     hipStream_t pad_strm[4] = {};  // FLVIS_H2D_QPAD (A/B knob): streams created in front of the copy stream, so that its hardware queue is another one
   } hf;
   hipEvent_t up_event = nullptr;  // set by flvis_image_feed_host for its flvis_image_feed call: the upload's event, waited for on the stream that ingests the images
+  const long long* up_flag = nullptr;  // ... or (mode 2) the sequence block the copy engine writes behind the images, and the number to wait for
+  long long up_seq = 0;
+  unsigned ev_flags = hipEventDisableTiming;  // flags of every event of the pipeline (FLVIS_EVENT_SCOPE)
   Lane& lane_of(int stream, int& local) {
     const int k = stream / lane_size;
     local = stream - k * lane_size;
@@ -309,6 +322,8 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
     for (hipStream_t ps : pl->hf.pad_strm)
       if (ps) hipStreamSynchronize(ps), hipStreamDestroy(ps);
     if (pl->hf.h_up) hipHostFree((void*)pl->hf.h_up);
+    for (long long* fp : pl->hf.h_flag)
+      if (fp) hipHostFree(fp);
   }
   if (pl->ev_in) hipEventDestroy(pl->ev_in);
   for (void* p : pl->allocs) hipFree(p);
@@ -566,9 +581,9 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   static_assert(Lane::HOLD_RING == 8, "event list below");
   for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
                         &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
-    evok = evok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    evok = evok && hipEventCreateWithFlags(e, pl->ev_flags) == hipSuccess;
   for (int k = 0; k < Lane::BAQ && evok; k++)
-    evok = hipEventCreateWithFlags(&L->ev_ba_done[k], hipEventDisableTiming) == hipSuccess;
+    evok = hipEventCreateWithFlags(&L->ev_ba_done[k], pl->ev_flags) == hipSuccess;
   return evok;
 }
 
@@ -589,6 +604,14 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   hipSetDevice(ctx->device);
   Pipeline* pl = new Pipeline();
   ctx->pipe = pl;
+  // FLVIS_EVENT_SCOPE (round 6): the fences of an event record.  The runtime turns every hipEventRecord into a barrier packet that acquires
+  // and releases at SYSTEM scope by default (L2 written back and invalidated towards the host, ~30 times per frame); the pipeline's events
+  // order kernels of one device among each other -- its host-visible words are stored with system-scope atomics by the kernels themselves,
+  // its read-backs are copies the runtime fences itself -- so agent scope (hipEventReleaseToDevice) is enough.  "system": the old flags.
+  {
+    const char* e = getenv("FLVIS_EVENT_SCOPE");
+    if (!(e && !strcmp(e, "system"))) pl->ev_flags |= hipEventReleaseToDevice;
+  }
   const int S = n_streams;
   pl->S = S;
   pl->cfg = *cfg;
@@ -654,7 +677,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   if (const char* e = getenv("FLVIS_BA_PRIORITY")) prio_least = atoi(e);  // tuning knob
   for (int k = 0; k < pl->nba && ok; k++)
     ok = hipStreamCreateWithPriority(&pl->ba_stream[k], hipStreamNonBlocking, prio_least) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&pl->ev_in, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&pl->ev_in, pl->ev_flags) == hipSuccess;
   if (!ok) {
     flvis_pipeline_destroy_internal(ctx);
     (void)hipGetLastError();
@@ -1036,6 +1059,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     // host images (flvis_image_feed_host, FLVIS_H2D_WAIT=1): the upload's event is waited for by the stream that ingests the left image; the
     // main stream only sees the joins it has anyway (left pyramid in front of the temporal LK, right pyramid in front of the stereo LK)
     if (pl->up_event) hipStreamWaitEvent(ds, pl->up_event, 0);
+    if (pl->up_flag) launch_wait_flag(ds, pl->up_flag, Pipeline::HostFeed::FLAG_WORDS, pl->up_seq, L->d_progress + 2);
     PB(1, s_img);
     if (eq) launch_equalize_hist(s_img, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, nullptr);
     else if (!aligned) launch_copy_image_any(s_img, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
@@ -1364,8 +1388,8 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
     }
     ok = ok && hipStreamCreateWithFlags(&hf.strm, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; k < 2 && ok; k++)
-      ok = hipEventCreateWithFlags(&hf.ev_done[k], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&hf.ev_free[k], hipEventDisableTiming) == hipSuccess && hipEventCreate(&hf.ev_t0[k]) == hipSuccess &&
+      ok = hipEventCreateWithFlags(&hf.ev_done[k], pl->ev_flags) == hipSuccess &&
+           hipEventCreateWithFlags(&hf.ev_free[k], pl->ev_flags) == hipSuccess && hipEventCreate(&hf.ev_t0[k]) == hipSuccess &&
            hipEventCreate(&hf.ev_t1[k]) == hipSuccess;
     if (!ok) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: cannot create the copy stream");
     void* hp = nullptr;
@@ -1376,30 +1400,57 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
     hf.d_up = (long long*)dp;
     *hf.h_up = 0;
     hf.times.assign(S, 0.0);
+    if (const char* e = getenv("FLVIS_H2D_MODE")) hf.mode = atoi(e) == 1 ? 1 : 2;
+    if (hf.mode == 2) {
+      // (fine-grained device memory: the copy engine writes it past the XCDs' L2 caches, the waiting wave must never see a cached line)
+      void* dfp = nullptr;
+      bool fok = hipExtMallocWithFlags(&dfp, sizeof(long long) * Pipeline::HostFeed::FLAG_WORDS, hipDeviceMallocFinegrained) == hipSuccess;
+      if (fok) {
+        hipMemset(dfp, 0, sizeof(long long) * Pipeline::HostFeed::FLAG_WORDS);
+        pl->allocs.push_back(dfp);
+        hf.d_flag = (long long*)dfp;
+      }
+      for (int k = 0; k < Pipeline::HostFeed::FLAG_RING && fok; k++) {
+        void* fp = nullptr;
+        fok = hipHostMalloc(&fp, sizeof(long long) * Pipeline::HostFeed::FLAG_WORDS, hipHostMallocDefault) == hipSuccess;
+        hf.h_flag[k] = (long long*)fp;
+      }
+      if (!fok) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: cannot allocate the sequence blocks");
+    }
   }
+  const int n_slots = hf.mode == 2 ? Pipeline::HostFeed::SLOTS : 2;
   const size_t npix = (size_t)S * w * h;
   for (int c = 0; c < 2; c++) {
     const size_t need = npix * bpp[c] + 256;
     if (hf.raw_bytes[c] < need) {
       hipStreamSynchronize(hf.strm);
       hipStreamSynchronize(ctx->stream);
-      for (int k = 0; k < 2; k++)
+      for (Lane* L : pl->lanes) hipStreamSynchronize(L->det_stream);
+      for (int k = 0; k < n_slots; k++)
         if (!(hf.raw[k][c] = dalloc<uint8_t>(pl->allocs, need, false))) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: device allocation failed");
       hf.raw_bytes[c] = need;
     }
   }
   if ((ch0 > 1 || (ch1 > 1 && !depth_cam)) && hf.gray_bytes < npix + 256) {
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < n_slots; k++)
       for (int c = 0; c < 2; c++)
         if (!(hf.gray[k][c] = dalloc<uint8_t>(pl->allocs, npix + 256, false))) return ctx->fail(FLVIS_ERR_HIP, "image_feed_host: device allocation failed");
     hf.gray_bytes = npix + 256;
   }
-  const int slot = (int)(hf.n & 1);
-  // hold_buffers contract: the previous call's buffers are free when this call returns -- its uploads must be done.  Polled on a
-  // host-mapped counter the copy stream stores after the uploads (hipEventSynchronize on its event also waited for the KERNELS of the
-  // previous frame, so uploads and frames never overlapped: measured 2.25 ms per step = upload + frame)
+  const int slot = (int)(hf.n % n_slots), tslot = (int)(hf.n & 1);
+  // hold_buffers contract: the previous call's buffers are free when this call returns -- its uploads must be done.
+  // Mode 1: polled on a host-mapped counter a kernel of the copy stream stores after the uploads (hipEventSynchronize on its event also
+  // waited for the KERNELS of the previous frame, so uploads and frames never overlapped: measured 2.25 ms per step = upload + frame).
+  // Mode 2: hipStreamQuery on the copy stream, which holds nothing but the copies (the host reads the last copy's signal; no packet).
   auto wait_uploads = [&](long long calls) {
     int polls = 0;
+    if (hf.mode == 2) {
+      while (hipStreamQuery(hf.strm) == hipErrorNotReady) {
+        if (++polls > 16) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
+      (void)hipGetLastError();
+      return;
+    }
     while (*hf.h_up < calls) {
       if ((++polls & 255) == 0 && hipStreamQuery(hf.strm) == hipSuccess && *hf.h_up < calls) break;  // (idle copy stream: a failed copy)
       std::this_thread::sleep_for(std::chrono::microseconds(30));
@@ -1411,20 +1462,37 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   // the frame that used this slot has been consumed.  (NOT implied by the host lead: the uploads are issued before this call waits for the
   // previous frame to start, i.e. while the frame before that may still be reading the slot -- without this wait the leg's poses differ from
   // the resident run's, bench.py's check caught it in round 5)
-  if (hf.n >= 2) hipStreamWaitEvent(hf.strm, hf.ev_free[slot], 0);
-  if (hf.timed[slot]) {  // the uploads of two calls ago: done (the previous call's are, and the copy stream is in order)
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, hf.ev_t0[slot], hf.ev_t1[slot]) == hipSuccess) hf.up_ms += ms, hf.up_bytes += (double)hf.timed_bytes[slot], hf.up_calls += 1;
-    else (void)hipGetLastError();
-    hf.timed[slot] = false;
+  // Mode 1: the copy stream waits for an event recorded behind that frame.  Mode 2: the HOST looks at the lanes' progress words -- the slot
+  // was read by lane frame slot_frame[slot]; once a later frame of every lane has started (k_frame_head publishes its number when it
+  // starts, behind k_frame_end of its predecessor and the joins in front of that), or the lane's stream has run dry, nothing reads it any
+  // more.  With three slots the frame in question lies three calls back: the test is true when it is made.
+  if (hf.mode == 2) {
+    const long long need = hf.slot_frame[slot] + 1;
+    if (hf.slot_frame[slot] > 0)
+      for (Lane* L : pl->lanes) {
+        int polls = 0;
+        while (*L->h_progress < need) {
+          if ((++polls & 63) == 0 && hipStreamQuery(L->st) == hipSuccess) break;  // (an idle stream: the frame is over, or its launch failed)
+          std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+      }
+  } else if (hf.n >= 2) {
+    hipStreamWaitEvent(hf.strm, hf.ev_free[slot], 0);
   }
-  if (hf.timing) hipEventRecord(hf.ev_t0[slot], hf.strm);
+  if (hf.timed[tslot]) {  // the uploads of two calls ago: done (the previous call's are, and the copy stream is in order)
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, hf.ev_t0[tslot], hf.ev_t1[tslot]) == hipSuccess) hf.up_ms += ms, hf.up_bytes += (double)hf.timed_bytes[tslot], hf.up_calls += 1;
+    else (void)hipGetLastError();
+    hf.timed[tslot] = false;
+  }
+  if (hf.timing) hipEventRecord(hf.ev_t0[tslot], hf.strm);
   // (Measured in round 4, profiles/r04_h2d_full_timeline_*.txt: beside an SDMA upload the chain's latency-bound kernels run 2-3 x slower,
   // the LK launches do not.  Gating the uploads under LK launches -- left image under the previous frame's stereo LK, right image under
   // the frame's own head / temporal LK -- made the leg slower, 40k -> 31k frames/s: k_frame_head / k_track_prepare are latency-bound too
   // and the later start of the copies costs host lead.  A copy KERNEL of 8 .. 128 workgroups reading the caller's page-locked buffer over
   // PCIe instead of the SDMA engine: 19-34k frames/s against 35.3k (profiles/r04_lk_ab.md).  The uploads start as soon as their
-  // staging slot is free, on the SDMA engine.)
+  // staging slot is free, on the SDMA engine.  Round 6: what slowed the chain was not the copy but the barrier packets that waited for
+  // it on the copy stream's hardware queue -- mode 2 has none, profiles/r06_h2d.md.)
   hipError_t e = hipSuccess;
   for (int c = 0; c < 2 && e == hipSuccess; c++) {
     const flvis_image* im = c ? h_img1 : h_img0;
@@ -1432,11 +1500,11 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
     bool contiguous = true;  // one block [S][h][w*bpp]: a single copy
     for (int s = 0; s < S && contiguous; s++)
       contiguous = (size_t)im[s].pitch == row && im[s].data == im[0].data + (size_t)s * img_bytes;
-    // (FLVIS_H2D_CHUNK_MB, A/B knob of round 5: the block in chunks with a tiny kernel between two of them -- the engine switch leaves the
-    // link idle for a few microseconds, a window for the command processor's own traffic.  Measured, lost: 32.6k frames/s at 4 and 8 MB,
-    // 22.7k at 2 MB against 28.7-37k in one piece: the uploads take longer and the chain is as long, profiles/r05_h2d.md)
+    // (FLVIS_H2D_CHUNK_MB, A/B knob of round 5, mode 1 only: the block in chunks with a tiny kernel between two of them -- the engine switch
+    // leaves the link idle for a few microseconds, a window for the command processor's own traffic.  Measured, lost: 32.6k frames/s at 4 and
+    // 8 MB, 22.7k at 2 MB against 28.7-37k in one piece: the uploads take longer and the chain is as long, profiles/r05_h2d.md)
     static const size_t h2d_chunk = getenv("FLVIS_H2D_CHUNK_MB") ? (size_t)atoi(getenv("FLVIS_H2D_CHUNK_MB")) << 20 : 0;
-    if (contiguous && h2d_chunk) {
+    if (contiguous && h2d_chunk && hf.mode == 1) {
       const size_t total = img_bytes * S;
       for (size_t off = 0; off < total && e == hipSuccess; off += h2d_chunk) {
         e = hipMemcpyAsync(hf.raw[slot][c] + off, im[0].data + off, std::min(h2d_chunk, total - off), hipMemcpyHostToDevice, hf.strm);
@@ -1451,23 +1519,38 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
     }
   }
   if (hf.timing && e == hipSuccess) {
-    hipEventRecord(hf.ev_t1[slot], hf.strm);
-    hf.timed[slot] = true;
-    hf.timed_bytes[slot] = (size_t)w * h * S * (bpp[0] + bpp[1]);
+    hipEventRecord(hf.ev_t1[tslot], hf.strm);
+    hf.timed[tslot] = true;
+    hf.timed_bytes[tslot] = (size_t)w * h * S * (bpp[0] + bpp[1]);
   }
-  if (e == hipSuccess) e = hipEventRecord(hf.ev_done[slot], hf.strm);
-  if (e != hipSuccess) return ctx->hip_fail(e, "image_feed_host upload");
-  launch_store_progress(hf.strm, hf.d_up, hf.n + 1);
+  const long long seq = hf.n + 1;
+  if (hf.mode == 2) {
+    // the sequence block behind the images (page-locked ring of FLAG_RING blocks: the block of call n is rewritten by call n + FLAG_RING,
+    // whose predecessors' uploads the host has seen finish)
+    long long* fb = hf.h_flag[hf.n % Pipeline::HostFeed::FLAG_RING];
+    for (int k = 0; k < Pipeline::HostFeed::FLAG_WORDS; k++) fb[k] = seq;
+    if (e == hipSuccess) e = hipMemcpyAsync(hf.d_flag, fb, sizeof(long long) * Pipeline::HostFeed::FLAG_WORDS, hipMemcpyHostToDevice, hf.strm);
+    if (e != hipSuccess) return ctx->hip_fail(e, "image_feed_host upload");
+  } else {
+    if (e == hipSuccess) e = hipEventRecord(hf.ev_done[slot], hf.strm);
+    if (e != hipSuccess) return ctx->hip_fail(e, "image_feed_host upload");
+    launch_store_progress(hf.strm, hf.d_up, seq);
+  }
   hipStream_t st = ctx->stream;
-  // FLVIS_H2D_WAIT (round 6): which stream waits for the uploads.  0: the main stream, in front of the frame (rounds 1-5).  1: the detection
-  // stream, in front of the left image's ingest -- every reader of the staged images is ordered behind that stream already (the left
-  // pyramid's join in front of the temporal LK, the right pyramid's in front of the stereo LK, which reads the right image in place).  Only
-  // for single-channel stereo input on a single lane past the skipped start-up frames; the other cases keep the wait on the main stream.
-  static const int h2d_wait = getenv("FLVIS_H2D_WAIT") ? atoi(getenv("FLVIS_H2D_WAIT")) : 0;
-  const bool wait_on_det = h2d_wait == 1 && ch0 == 1 && ch1 == 1 && !depth_cam && pl->lanes.size() == 1 &&
+  // Which stream waits for the uploads.  The detection stream, in front of the left image's ingest (mode 2, or mode 1 with FLVIS_H2D_WAIT=1):
+  // every reader of the staged images is ordered behind that stream already -- the left pyramid's join in front of the temporal LK, the
+  // right pyramid's in front of the stereo LK, which reads the right image in place.  Only for single-channel stereo input on a single
+  // lane past the skipped start-up frames; otherwise the main stream waits, in front of the frame (rounds 1-5: always).
+  static const int h2d_wait = getenv("FLVIS_H2D_WAIT") ? atoi(getenv("FLVIS_H2D_WAIT")) : -1;
+  const bool wait_on_det = (h2d_wait < 0 ? hf.mode == 2 : h2d_wait == 1) && ch0 == 1 && ch1 == 1 && !depth_cam && pl->lanes.size() == 1 &&
                            pl->frames_fed >= (long long)pl->cfg.skip_first_n_imgs;
-  if (wait_on_det) pl->up_event = hf.ev_done[slot];
-  else hipStreamWaitEvent(st, hf.ev_done[slot], 0);
+  if (hf.mode == 2) {
+    if (wait_on_det) pl->up_flag = hf.d_flag, pl->up_seq = seq;
+    else launch_wait_flag(st, hf.d_flag, Pipeline::HostFeed::FLAG_WORDS, seq, pl->lanes[0]->d_progress + 2);
+  } else {
+    if (wait_on_det) pl->up_event = hf.ev_done[slot];
+    else hipStreamWaitEvent(st, hf.ev_done[slot], 0);
+  }
   const uint8_t* d0 = hf.raw[slot][0];
   const uint8_t* d1 = hf.raw[slot][1];
   if (ch0 > 1) {
@@ -1486,12 +1569,14 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   const auto th2 = std::chrono::steady_clock::now();
   const int rc = flvis_image_feed(ctx, d0, d1, hf.times.data(), h_out, with_local_map);
   pl->up_event = nullptr;
+  pl->up_flag = nullptr;
   const auto th3 = std::chrono::steady_clock::now();
   hf.ms_wait_uploads += std::chrono::duration<double, std::milli>(th1 - th0).count();
   hf.ms_issue += std::chrono::duration<double, std::milli>(th2 - th1).count();
   hf.ms_feed += std::chrono::duration<double, std::milli>(th3 - th2).count();
   pl->host_lead_cap = 4;
-  hipEventRecord(hf.ev_free[slot], st);
+  if (hf.mode == 2) hf.slot_frame[slot] = pl->lanes[0]->frames_uploaded;
+  else hipEventRecord(hf.ev_free[slot], st);
   hf.n++;
   if (rc != FLVIS_OK) return rc;
   if (!hold_buffers) wait_uploads(hf.n);  // the caller may reuse its buffers at once: wait for the uploads (not for the frame)
@@ -1546,7 +1631,7 @@ int flvis_prof_enable_stages(flvis_ctx* ctx, int max_steps, uint64_t stage_mask)
     L->prof_ev.clear();
     L->prof_ev.resize((size_t)max_steps * (2 * PROF_STAGES));
     for (auto& e : L->prof_ev)
-      if (hipEventCreate(&e) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
+      if (hipEventCreateWithFlags(&e, pl->ev_flags & hipEventReleaseToDevice) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
   }
   return FLVIS_OK;
 }

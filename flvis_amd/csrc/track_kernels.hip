@@ -2315,6 +2315,27 @@ __global__ void k_store_progress(long long* __restrict__ host_word, long long v)
 void launch_store_progress(hipStream_t st, long long* host_word, long long v) {
   hipLaunchKernelGGL(k_store_progress, dim3(1), dim3(1), 0, st, host_word, v);
 }
+// Stream-ordered wait for an upload (round 6, flvis_image_feed_host): the copy engine writes a block of `n_words` sequence numbers behind
+// the images of a call (in-order on its queue); ONE lane of one wave sleeps until the first and the last word of the block have reached
+// `seq`.  The copies were issued before this kernel was enqueued and run on the copy engine whatever the compute queues do, so the wait
+// ends by itself -- in the steady state it finds the block there and costs a launch.  Not a command-processor wait: an AQL barrier packet
+// that polls a signal (what an event recorded behind a copy is turned into) slows the packet processing of the hardware queues next to
+// it for as long as it is pending (profiles/r06_h2d.md).  A wait of more than ~4 s stores `seq` into err_word (host-mapped) and gives up.
+__global__ void k_wait_flag(const long long* __restrict__ flag, int n_words, long long seq, long long* __restrict__ err_word) {
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(&flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq ||
+         __hip_atomic_load(&flag[n_words - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > 400000000ull) {  // 100 MHz constant clock
+      if (err_word) __hip_atomic_store(err_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+void launch_wait_flag(hipStream_t st, const long long* flag, int n_words, long long seq, long long* err_word) {
+  hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, st, flag, n_words, seq, err_word);
+}
 void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time, long long* host_progress, long long frame_no) {
   hipLaunchKernelGGL(k_frame_head, dim3(p.S), dim3(64), 0, st, p, d_time, host_progress, frame_no);
 }

@@ -10,6 +10,8 @@ double ref_det_atan(double x) { return detm::det_atan(x); }
 double ref_det_atan2(double y, double x) { return detm::det_atan2(y, x); }
 double ref_det_log(double x) { return detm::det_log(x); }
 double ref_det_powi(double x, int n) { return detm::det_powi(x, n); }
+double ref_det_acos(double x) { return detm::det_acos(x); }
+double ref_det_cbrt(double x) { return detm::det_cbrt(x); }
 void ref_det_batch(int which, int n, const double* a, const double* b, double* out) {
   for (int i = 0; i < n; i++) {
     switch (which) {
@@ -17,7 +19,9 @@ void ref_det_batch(int which, int n, const double* a, const double* b, double* o
       case 1: out[i] = detm::det_cos(a[i]); break;
       case 2: out[i] = detm::det_atan(a[i]); break;
       case 3: out[i] = detm::det_atan2(a[i], b[i]); break;
-      default: out[i] = detm::det_log(a[i]); break;
+      case 4: out[i] = detm::det_log(a[i]); break;
+      case 5: out[i] = detm::det_acos(a[i]); break;
+      default: out[i] = detm::det_cbrt(a[i]); break;
     }
   }
 }

@@ -48,6 +48,24 @@ def test_atan_atan2_log_within_one_ulp_of_libm():
     assert _ulps(got[nz], want[nz]).max() <= 1.0
 
 
+def test_acos_cbrt_within_one_ulp_of_libm():
+    """det_acos / det_cbrt (round 6: the closed-form cubic and quartic of the OpenCV-shaped 7-point and P3P solvers)"""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-1, 1, 200000), rng.uniform(-1e-9, 1e-9, 1000), 1 - 10.0 ** rng.uniform(-16, -1, 20000),
+                        -1 + 10.0 ** rng.uniform(-16, -1, 20000), [0.0, 0.5, -0.5, 1.0, -1.0, 0.4999999, 0.5000001]])
+    got, want = _batch(5, x), np.arccos(x)
+    nz = want != 0
+    assert _ulps(got[nz], want[nz]).max() <= 1.0
+    assert np.array_equal(got[~nz], want[~nz])
+    assert np.isnan(_batch(5, np.array([1.0000001, -2.0]))).all()
+    y = np.concatenate([rng.uniform(-10, 10, 100000), 10.0 ** rng.uniform(-300, 300, 50000), -(10.0 ** rng.uniform(-300, 300, 50000)),
+                        [8.0, -27.0, 1e-320, -1e-310]])
+    got, want = _batch(6, y), np.cbrt(y)
+    assert _ulps(got, want).max() <= 1.0
+    assert np.array_equal(_batch(6, np.array([0.0, -0.0, math.inf, -math.inf])), np.array([0.0, -0.0, math.inf, -math.inf]))
+    assert math.copysign(1, _batch(6, np.array([-0.0]))[0]) == -1.0
+
+
 def test_special_values():
     L = O.lib()
     for f in (L.ref_det_sin, L.ref_det_cos, L.ref_det_atan, L.ref_det_log, L.ref_det_atan2, L.ref_det_powi):
