@@ -604,13 +604,13 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   hipSetDevice(ctx->device);
   Pipeline* pl = new Pipeline();
   ctx->pipe = pl;
-  // FLVIS_EVENT_SCOPE (round 6): the fences of an event record.  The runtime turns every hipEventRecord into a barrier packet that acquires
-  // and releases at SYSTEM scope by default (L2 written back and invalidated towards the host, ~30 times per frame); the pipeline's events
-  // order kernels of one device among each other -- its host-visible words are stored with system-scope atomics by the kernels themselves,
-  // its read-backs are copies the runtime fences itself -- so agent scope (hipEventReleaseToDevice) is enough.  "system": the old flags.
+  // FLVIS_EVENT_SCOPE=agent (round 6, A/B knob): events created with hipEventReleaseToDevice.  The runtime turns every hipEventRecord into a
+  // barrier packet that acquires and releases at SYSTEM scope (AMD_LOG_LEVEL=4: "BarrierValue ... acquire=2, release=2", ~30 per frame) where
+  // agent scope would do for events that order kernels of one device.  Measured: the flag changes neither the logged header nor the
+  // rate (58.6k / 56.7k frames/s resident / host images with it, 58.5k / 56.5k without): left off.
   {
     const char* e = getenv("FLVIS_EVENT_SCOPE");
-    if (!(e && !strcmp(e, "system"))) pl->ev_flags |= hipEventReleaseToDevice;
+    if (e && !strcmp(e, "agent")) pl->ev_flags |= hipEventReleaseToDevice;
   }
   const int S = n_streams;
   pl->S = S;

@@ -28,6 +28,7 @@
 #include "ref_api.h"
 #include "../flvis_amd/csrc/epnp_core.hpp"  // EPnP's arithmetic: the very functions the kernel runs, here with one lane
 #include "ref_math.hpp"
+#include "../flvis_amd/csrc/cv_solvers.hpp"  // the OpenCV-shaped minimal solvers: the very functions the kernels run
 
 namespace ref {
 
@@ -404,6 +405,19 @@ int seven_point(const double x1[][2], const double x2[][2], double F[3][9]) {
   return nm;
 }
 
+// The 7-point solver the RANSAC / LMedS loops run.  Default (round 6): OpenCV's run7Point as restated in flvis_amd/csrc/cv_solvers.hpp (SVD
+// null space of the unnormalised system, closed-form cubic, solutions in solveCubic's order, F(3,3) = 1).  -DFLVIS_SOLVERS_PRODUCT
+// (`make -C oracle SOLVERS=product` -> libflvis_ref_prod.so) keeps the product-defined solver of rounds 1-5 above buildable; the distance
+// between the two is measured on the lockstep sequences (tests/test_oracle_tracking.py, table in oracle/README.md).
+static int seven_point_sel(const double x1[][2], const double x2[][2], double F[3][9]) {
+#ifdef FLVIS_SOLVERS_PRODUCT
+  return seven_point(x1, x2, F);
+#else
+  double wk[flvis::cvs::SP_WORK];
+  return flvis::cvs::run7point<1>(x1, x2, wk, F, [](int) {});
+#endif
+}
+
 // OpenCV FMEstimatorCallback::computeError: max of the two squared point-line distances, as float
 static inline float f_error(const double* F, double x1, double y1, double x2, double y2) {
   double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
@@ -449,7 +463,7 @@ static int find_fundamental_lmeds(const float* m1, const float* m2, int n, doubl
     }
     double x1[7][2], x2[7][2], F[3][9];
     fm_sample(m1, m2, idx, x1, x2);
-    const int nm = seven_point(x1, x2, F);
+    const int nm = seven_point_sel(x1, x2, F);
     for (int m = 0; m < nm; m++) {
       for (int i = 0; i < n; i++) err[i] = f_error(F[m], m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]);
       std::sort((int32_t*)err.data(), (int32_t*)err.data() + n);  // `std::sort(errf.ptr<int>(), ...)`: ordered through the bit patterns
@@ -493,7 +507,7 @@ int find_fundamental_ransac(const float* m1, const float* m2, int n, double thr,
     double x1[7][2], x2[7][2];
     fm_sample(m1, m2, idx, x1, x2);
     double F[3][9];
-    int nm = seven_point(x1, x2, F);
+    int nm = seven_point_sel(x1, x2, F);
     for (int m = 0; m < nm; m++) {
       int good = 0;
       for (int i = 0; i < n; i++) {
@@ -702,6 +716,7 @@ int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, doubl
     if (iterative_flag) {
       if (!solve_epnp(p3d, p2d, idx, 5, fx, fy, cx, cy, Rh, th)) continue;
     } else {
+#ifdef FLVIS_SOLVERS_PRODUCT
       Vec3 P[3], f[3];
       for (int k = 0; k < 3; k++) {
         P[k] = {(double)p3d[3 * idx[k]], (double)p3d[3 * idx[k] + 1], (double)p3d[3 * idx[k] + 2]};
@@ -731,6 +746,21 @@ int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, doubl
       if (bk < 0) continue;
       Rh = Rs[bk];
       th = ts[bk];
+#else
+      // cv::solvePnP(SOLVEPNP_P3P) on the four sample points: undistortPoints to normalised float coordinates, p3p::extract_points maps
+      // them back with x * fx + cx (p3p.cpp); Gao's solver on the first three, the fourth picks the pose (cv_solvers.hpp)
+      const flvis::cvs::P3PCamera cam = flvis::cvs::p3p_camera(fx, fy, cx, cy);
+      double uv[4][2], X[4][3], Rr[9], tr[3];
+      for (int k = 0; k < 4; k++) {
+        uv[k][0] = (double)(float)(((double)p2d[2 * idx[k]] - cx) / fx) * fx + cx;
+        uv[k][1] = (double)(float)(((double)p2d[2 * idx[k] + 1] - cy) / fy) * fy + cy;
+        for (int j = 0; j < 3; j++) X[k][j] = (double)p3d[3 * idx[k] + j];
+      }
+      if (!flvis::cvs::p3p_solve4(cam, uv, X, Rr, tr)) continue;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Rh.m[i][j] = Rr[3 * i + j];
+      th = {tr[0], tr[1], tr[2]};
+#endif
     }
     int good = 0;
     for (int i = 0; i < n; i++) {
@@ -998,6 +1028,44 @@ int ref_p3p(const double* P9, const double* f9, double* R36, double* t12) {
     t12[3 * k + 2] = ts[k].z;
   }
   return n;
+}
+// the OpenCV-shaped solvers of flvis_amd/csrc/cv_solvers.hpp, one call each (tests/test_oracle_cv_solvers.py)
+int ref_cv_seven_point(const double* x1, const double* x2, double* F27) {
+  double a[7][2], b[7][2], F[3][9], wk[flvis::cvs::SP_WORK];
+  for (int i = 0; i < 7; i++) {
+    a[i][0] = x1[2 * i];
+    a[i][1] = x1[2 * i + 1];
+    b[i][0] = x2[2 * i];
+    b[i][1] = x2[2 * i + 1];
+  }
+  memset(F, 0, sizeof(F));
+  const int n = flvis::cvs::run7point<1>(a, b, wk, F, [](int) {});
+  memcpy(F27, F, sizeof(F));
+  return n;
+}
+int ref_cv_solve_cubic(const double* c4, double* r3) { return flvis::cvs::solve_cubic(c4, r3); }
+int ref_cv_solve_deg4(const double* c5, double* r4) {
+  r4[0] = r4[1] = r4[2] = r4[3] = 0;
+  return flvis::cvs::solve_deg4(c5[0], c5[1], c5[2], c5[3], c5[4], r4[0], r4[1], r4[2], r4[3]);
+}
+int ref_cv_p3p(const double* K4, const double* uv6, const double* X9, double* R36, double* t12) {
+  const flvis::cvs::P3PCamera cam = flvis::cvs::p3p_camera(K4[0], K4[1], K4[2], K4[3]);
+  double uv[3][2], X[3][3], R[4][9], t[4][3];
+  for (int k = 0; k < 3; k++) {
+    uv[k][0] = uv6[2 * k], uv[k][1] = uv6[2 * k + 1];
+    for (int j = 0; j < 3; j++) X[k][j] = X9[3 * k + j];
+  }
+  const int n = flvis::cvs::p3p_solve3(cam, uv, X, R, t);
+  for (int k = 0; k < n; k++) {
+    memcpy(R36 + 9 * k, R[k], sizeof(double) * 9);
+    memcpy(t12 + 3 * k, t[k], sizeof(double) * 3);
+  }
+  return n;
+}
+int ref_cv_jacobi4(const double* A16, double* D4, double* U16) {
+  double A[16];
+  memcpy(A, A16, sizeof(A));
+  return flvis::cvs::jacobi_4x4(A, D4, U16) ? 1 : 0;
 }
 int ref_solve_epnp(const float* p3d, const float* p2d, int n, const double* K4, double* R9, double* t3) {
   ref::Mat3 R;
