@@ -34,6 +34,12 @@
 #define CVS_FN inline
 #endif
 
+#if defined(__clang__)
+#define CVS_UNROLL _Pragma("unroll")
+#else
+#define CVS_UNROLL _Pragma("GCC unroll 9")
+#endif
+
 namespace flvis {
 namespace cvs {
 
@@ -164,8 +170,10 @@ CVS_FN int run7point(const double (*x1)[2], const double (*x2)[2], double* wk, d
     for (int i = 0; i < 6; i++)
       for (int j = i + 1; j < 7; j++) {
         double ai[9], aj[9];
+        CVS_UNROLL
         for (int k = 0; k < 9; k++) ai[k] = CVS_A(i, k), aj[k] = CVS_A(j, k);
         double a = CVS_W(i), p = 0, b = CVS_W(j);
+        CVS_UNROLL
         for (int k = 0; k < 9; k++) p += ai[k] * aj[k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
@@ -180,6 +188,7 @@ CVS_FN int run7point(const double (*x1)[2], const double (*x2)[2], double* wk, d
           s = p / (gamma * c * 2);
         }
         a = b = 0;
+        CVS_UNROLL
         for (int k = 0; k < 9; k++) {
           const double t0 = c * ai[k] + s * aj[k];
           const double t1 = -s * ai[k] + c * aj[k];
@@ -432,8 +441,10 @@ CVS_FN bool jacobi_4x4(double* A, double* D, double* U) {
     const double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
     if (sum == 0.0) return true;
     const double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+    CVS_UNROLL
     for (int i = 0; i < 3; i++) {
       int pij = 5 * i + 1;
+      CVS_UNROLL
       for (int j = i + 1; j < 4; j++) {
         const double Aij = A[pij];
         const double eps_machine = 100.0 * fabs(Aij);
@@ -457,21 +468,25 @@ CVS_FN bool jacobi_4x4(double* A, double* D, double* U) {
           const double c = 1.0 / sqrt(1 + t * t);
           const double s = t * c;
           const double tau = s / (1.0 + c);
+          CVS_UNROLL
           for (int k = 0; k <= i - 1; k++) {
             const double g = A[k * 4 + i], h = A[k * 4 + j];
             A[k * 4 + i] = g - s * (h + g * tau);
             A[k * 4 + j] = h + s * (g - h * tau);
           }
+          CVS_UNROLL
           for (int k = i + 1; k <= j - 1; k++) {
             const double g = A[i * 4 + k], h = A[k * 4 + j];
             A[i * 4 + k] = g - s * (h + g * tau);
             A[k * 4 + j] = h + s * (g - h * tau);
           }
+          CVS_UNROLL
           for (int k = j + 1; k < 4; k++) {
             const double g = A[i * 4 + k], h = A[j * 4 + k];
             A[i * 4 + k] = g - s * (h + g * tau);
             A[j * 4 + k] = h + s * (g - h * tau);
           }
+          CVS_UNROLL
           for (int k = 0; k < 4; k++) {
             const double g = U[k * 4 + i], h = U[k * 4 + j];
             U[k * 4 + i] = g - s * (h + g * tau);

@@ -94,6 +94,13 @@ struct Lane {
   // tracking stream waits for the launches of KFQ-3 frames ago before it appends new keyframes (see lane_frame)
   static constexpr int BAQ = 64;
   hipEvent_t ev_ba_done[BAQ] = {};
+  // FLVIS_JOIN (round 6; "flag" is the default, "event" the form of rounds 1-5): the joins between the lane's streams as device words instead of events -- the producing stream stores a
+  // sequence number behind its last kernel (k_store_flag), the consuming stream waits for it with one sleeping lane (k_wait_flag).  An
+  // event record is a system-scope barrier packet and a wait a barrier packet that polls the record's signal for as long as it is pending
+  // (and slows the queues beside it, profiles/r06_h2d.md); a word in HBM costs two one-lane launches.
+  static constexpr int JOIN_IDS = 8 + BAQ;
+  long long* d_join = nullptr;             // [JOIN_IDS] words, 64 bytes apart
+  long long join_seq[JOIN_IDS] = {};
   long long ba_launches = 0;
   bool ba_pending = false;       // FLVIS_BA_START > 0: the local-map launch for the last frame's keyframes has not been enqueued yet
   unsigned ba_tag = 0;           // tag of the lane's last local-map launch (k_ba_worker's stream list is valid for one tag; 0 is never used)
@@ -169,6 +176,7 @@ struct Pipeline {
   const long long* up_flag = nullptr;  // ... or (mode 2) the sequence block the copy engine writes behind the images, and the number to wait for
   long long up_seq = 0;
   unsigned ev_flags = hipEventDisableTiming;  // flags of every event of the pipeline (FLVIS_EVENT_SCOPE)
+  bool flag_joins = false;                    // FLVIS_JOIN=flag
   Lane& lane_of(int stream, int& local) {
     const int k = stream / lane_size;
     local = stream - k * lane_size;
@@ -515,6 +523,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   ok = ok && ((L->dem_roff = dalloc<int>(L->allocs, (size_t)S * 17)) != nullptr);
   ok = ok && ((L->eq_hist = dalloc<unsigned>(L->allocs, (size_t)S * 256)) != nullptr);
   ok = ok && ((L->eq_lut = dalloc<uint8_t>(L->allocs, (size_t)S * 256)) != nullptr);
+  ok = ok && ((L->d_join = dalloc<long long>(L->allocs, (size_t)Lane::JOIN_IDS * 8)) != nullptr);
   if (!ok) return false;
   // initial per-stream state (F2FTracking::init, VIMOTION ctor, landmark id counter 100, glibc rand seed 1)
   std::vector<StreamState> hs(S);
@@ -611,6 +620,8 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   {
     const char* e = getenv("FLVIS_EVENT_SCOPE");
     if (e && !strcmp(e, "agent")) pl->ev_flags |= hipEventReleaseToDevice;
+    const char* j = getenv("FLVIS_JOIN");
+    pl->flag_joins = !(j && !strcmp(j, "event"));  // (default since round 6: 58.6k -> 60.4k frames/s, chain p50 1.047 -> 1.012 ms; "event": rounds 1-5)
   }
   const int S = n_streams;
   pl->S = S;
@@ -902,15 +913,45 @@ static unsigned pyramid_levels(hipStream_t ds, bool bordered, ImgSel src0, int s
 
 // One local-map launch for the lane (a workgroup per stream takes the stream's next keyframe): on the lane's next local-map HIP stream,
 // behind `ev` of the tracking stream (recorded here when `record` is set), its completion event kept for the back-pressure.
+static int join_id(const Lane* L, hipEvent_t ev) {
+  if (ev == L->ev_img) return 0;
+  if (ev == L->ev_det) return 1;
+  if (ev == L->ev_gftt) return 2;
+  if (ev == L->ev_fe) return 3;
+  if (ev == L->ev_lm) return 4;
+  if (ev == L->ev_tri) return 5;
+  if (ev == L->ev_head) return 6;
+  for (int k = 0; k < Lane::BAQ; k++)
+    if (ev == L->ev_ba_done[k]) return 8 + k;
+  return -1;
+}
+// "stream s has reached this point" / "stream s goes on when that point has been reached": an event, or (FLVIS_JOIN=flag) a device word
+static void join_signal(Pipeline* pl, Lane* L, hipEvent_t ev, hipStream_t s) {
+  const int id = pl->flag_joins ? join_id(L, ev) : -1;
+  if (id < 0) {
+    hipEventRecord(ev, s);
+    return;
+  }
+  launch_store_flag(s, L->d_join + 8 * id, ++L->join_seq[id]);
+}
+static void join_wait(Pipeline* pl, Lane* L, hipStream_t s, hipEvent_t ev) {
+  const int id = pl->flag_joins ? join_id(L, ev) : -1;
+  if (id < 0) {
+    hipStreamWaitEvent(s, ev, 0);
+    return;
+  }
+  launch_wait_flag(s, L->d_join + 8 * id, 1, L->join_seq[id], L->d_progress + 2);
+}
+
 static void launch_local_map(Pipeline* pl, Lane* L, hipEvent_t ev, bool record, hipEvent_t* prof_begin_end) {
   const int bi = (L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba;
   hipStream_t bs = pl->ba_stream[bi];
-  if (record) hipEventRecord(ev, L->st);
-  hipStreamWaitEvent(bs, ev, 0);
+  if (record) join_signal(pl, L, ev, L->st);
+  join_wait(pl, L, bs, ev);
   if (prof_begin_end) hipEventRecord(prof_begin_end[0], bs);
   launch_ba_worker(bs, L->pipe, bi, ++L->ba_tag);
   if (prof_begin_end) hipEventRecord(prof_begin_end[1], bs);
-  hipEventRecord(L->ev_ba_done[L->ba_launches % Lane::BAQ], bs);
+  join_signal(pl, L, L->ev_ba_done[L->ba_launches % Lane::BAQ], bs);
   L->ba_launches++;
   L->ba_pending = false;
 }
@@ -1054,8 +1095,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     // Without equalizeHist the first pyrDown reads the caller's image and writes level 0 and level 1 in one pass; with it the
     // equalised image is level 0.
     ImgSel l0in{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot_in, 0, nullptr};
-    hipEventRecord(L->ev_lm, st);  // (the frame's input table has been uploaded)
-    hipStreamWaitEvent(ds, L->ev_lm, 0);
+    join_signal(pl, L, L->ev_lm, st);  // (the frame's input table has been uploaded)
+    join_wait(pl, L, ds, L->ev_lm);
     // host images (flvis_image_feed_host, FLVIS_H2D_WAIT=1): the upload's event is waited for by the stream that ingests the left image; the
     // main stream only sees the joins it has anyway (left pyramid in front of the temporal LK, right pyramid in front of the stereo LK)
     if (pl->up_event) hipStreamWaitEvent(ds, pl->up_event, 0);
@@ -1073,7 +1114,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     if (pl->levels == 0 && !eq && aligned) launch_copy_image(s_img, in0, l0in, w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, nullptr);
     if (border_left) launch_pyr_border(s_img, pyl, S, nullptr, border_left);
     PE(2, s_img);
-    if (!head_on_det) hipEventRecord(L->ev_img, ds);
+    if (!head_on_det) join_signal(pl, L, L->ev_img, ds);
   }
   PB(0, s_head);
   // the staged IMU samples, then frame_begin -- and, unless the local-map feedback has to be applied in between, the temporal tracker's
@@ -1086,8 +1127,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(0, s_head);
   // the detection stream's kernels that read what k_frame_head decides (act_img, gftt_act, gftt_maxc, img_slot) wait for this event:
   // the corner detection and the right pyramid in every FLVIS_DET_START mode (in the default mode they start behind the F-RANSAC anyway)
-  hipEventRecord(L->ev_head, s_head);
-  if (head_on_det) hipStreamWaitEvent(st, L->ev_head, 0);  // join: the head (the left pyramid is on this stream)
+  join_signal(pl, L, L->ev_head, s_head);
+  if (head_on_det) join_wait(pl, L, st, L->ev_head);  // join: the head (the left pyramid is on this stream)
   if (skipped) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
@@ -1111,7 +1152,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(3, st);
   if (!head_prepare) launch_track_prepare(st, p);
   PE(3, st);
-  if (!head_on_det) hipStreamWaitEvent(st, L->ev_img, 0);  // join: the left pyramid
+  if (!head_on_det) join_wait(pl, L, st, L->ev_img);  // join: the left pyramid
   // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
   // for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain.  The right image is only
   // read within this frame, so without equalizeHist the caller's buffer IS level 0 of the right pyramid (no copy).
@@ -1134,18 +1175,18 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // k_ransac_pnp / k_pose_lm / k_reproj_filter are latency chains on 64 CUs and leave the rest of the chip to the detection.
   static const int gftt_after_lk = getenv("FLVIS_DET_START") ? atoi(getenv("FLVIS_DET_START")) : 3;
   auto detect_corners = [&] {
-    if (!head_on_det) hipStreamWaitEvent(ds, L->ev_head, 0);
+    if (!head_on_det) join_wait(pl, L, ds, L->ev_head);
     launch_gftt(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, L->gftt, nullptr, p.cam.gftt_ql, p.gftt_maxc, p.cam.gftt_num,
                 (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
                 (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
     // FeatureDEM's image part (regions, Harris scores, per-region order of the corners) follows at once, off the critical path
     launch_feature_dem_prep(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
                             p.gftt_act, L->dem_sorted, L->dem_roff);
-    hipEventRecord(L->ev_gftt, ds);
+    join_signal(pl, L, L->ev_gftt, ds);
   };
   if (gftt_first && !gftt_after_lk) detect_corners();
   auto right_pyramid_on = [&](hipStream_t ds, bool on_main) {  // (ds: the stream it runs on -- the detection stream, or the main one)
-    if (!on_main && !head_on_det) hipStreamWaitEvent(ds, L->ev_head, 0);
+    if (!on_main && !head_on_det) join_wait(pl, L, ds, L->ev_head);
     if (!depth_cam) {
       if (eq) launch_equalize_hist(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, L->eq_hist, L->eq_lut, p.act_img);
       else if (!aligned) launch_copy_image_any(ds, in1, img_plain(L->pyr1[0]), w, h, w, pl->lpitch[0], (size_t)w * h, pl->lstride[0], S, p.act_img);
@@ -1164,7 +1205,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       launch_feature_dem_prep(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
                               p.gftt_act, L->dem_sorted, L->dem_roff);
     }
-    if (!on_main) hipEventRecord(L->ev_det, ds);
+    if (!on_main) join_signal(pl, L, L->ev_det, ds);
   };
   auto right_pyramid = [&] { right_pyramid_on(ds, false); };
   // 5 (round 5, A/B knob): the corners as in 3; the right pyramid -- two light launches, 36 us -- on the MAIN stream behind the reprojection
@@ -1197,13 +1238,13 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   }
   PE(4, st);
   if (gftt_first && gftt_after_lk == 1) {
-    hipEventRecord(L->ev_lm, st);
-    hipStreamWaitEvent(ds, L->ev_lm, 0);
+    join_signal(pl, L, L->ev_lm, st);
+    join_wait(pl, L, ds, L->ev_lm);
     detect_corners();
   }
   if (pyramid_mid) {
-    hipEventRecord(L->ev_lm, st);
-    hipStreamWaitEvent(ds, L->ev_lm, 0);
+    join_signal(pl, L, L->ev_lm, st);
+    join_wait(pl, L, ds, L->ev_lm);
     right_pyramid();
   }
   PB(5, st);
@@ -1214,8 +1255,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   launch_ransac_f(st, p);
   PE(6, st);
   if (gftt_first && gftt_after_lk >= 2) {
-    hipEventRecord(L->ev_lm, st);
-    hipStreamWaitEvent(ds, L->ev_lm, 0);
+    join_signal(pl, L, L->ev_lm, st);
+    join_wait(pl, L, ds, L->ev_lm);
     detect_corners();
     if (pyramid_late) right_pyramid();
     if (ba_start == 1 && L->ba_pending) launch_local_map(pl, L, L->ev_lm, false, prof18);
@@ -1232,11 +1273,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(9, st);
   if (pyramid_main) right_pyramid_on(st, true);
   // the IMU filter's correction from this frame's pose: on the detection stream (joined with the triangulation before the depth innovation)
-  hipEventRecord(L->ev_lm, st);
-  hipStreamWaitEvent(ds, L->ev_lm, 0);
+  join_signal(pl, L, L->ev_lm, st);
+  join_wait(pl, L, ds, L->ev_lm);
   launch_vi_correction(ds, p);
   // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners; the right pyramid is joined before the stereo LK
-  hipStreamWaitEvent(st, gftt_first ? L->ev_gftt : L->ev_det, 0);
+  join_wait(pl, L, st, gftt_first ? L->ev_gftt : L->ev_det);
   PB(13, st);
   launch_feature_dem(st, w, h, S, p.cam.dem, L->dem_sorted, L->dem_roff, 2 * p.cam.gftt_num, p.det_mode, p.exist_xy, p.n_exist, NMAX,
                      p.new_xy, p.n_new, NEW_MAX);
@@ -1247,11 +1288,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   launch_depth_seeds(st, p);
   PE(14, st);
   // the two-view triangulation that k_depth_innovate consumes: on the detection stream (idle by now), under the stereo LK
-  hipEventRecord(L->ev_lm, st);
-  hipStreamWaitEvent(ds, L->ev_lm, 0);
+  join_signal(pl, L, L->ev_lm, st);
+  join_wait(pl, L, ds, L->ev_lm);
   launch_depth_triangulate(ds, p);
-  hipEventRecord(L->ev_tri, ds);
-  if (gftt_first && !pyramid_main) hipStreamWaitEvent(st, L->ev_det, 0);
+  join_signal(pl, L, L->ev_tri, ds);
+  if (gftt_first && !pyramid_main) join_wait(pl, L, st, L->ev_det);
   PB(15, st);
   if (!depth_cam) {
     PyrSel prev, next;
@@ -1274,7 +1315,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts, 2);
   }
   PE(15, st);
-  hipStreamWaitEvent(st, L->ev_tri, 0);
+  join_wait(pl, L, st, L->ev_tri);
   PB(16, st);
   launch_depth_innovate(st, p);
   PE(16, st);
@@ -1289,7 +1330,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     const long long D = std::max(0, KFQ / 2 / pl->ba_every - 2 - (ba_start != 0 ? 1 : 0));  // (a deferred launch is one frame late)
     for (int k = 0; k < pl->nba_lane; k++) {
       const long long j = L->ba_launches - 1 - D - k;
-      if (j >= 0 && L->ba_launches - j <= Lane::BAQ) hipStreamWaitEvent(st, L->ev_ba_done[j % Lane::BAQ], 0);
+      if (j >= 0 && L->ba_launches - j <= Lane::BAQ) join_wait(pl, L, st, L->ev_ba_done[j % Lane::BAQ]);
     }
   }
   PB(17, st);

@@ -28,6 +28,7 @@ static __device__ long long g_sp_last = 0;
 #include "dev_geom.hpp"
 #include "epnp_core.hpp"
 #include "track_kernels.hpp"
+#include "cv_solvers.hpp"
 #include "vi_motion.hpp"
 
 namespace flvis {
@@ -485,7 +486,11 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
   const int n = st.n_surv;
   __shared__ float sm1[NMAX * 2], sm2[NMAX * 2];
   __shared__ double Fm[64 * 3][9];
+#ifdef FLVIS_SOLVERS_PRODUCT
   __shared__ double spw[63 * 64];  // 7-point workspaces of the 64 hypothesis lanes (element-major: conflict-free)
+#else
+  __shared__ double spw[cvs::SP_WORK * 64];  // run7Point's workspaces of the 64 hypothesis lanes (element-major: conflict-free)
+#endif
   __shared__ int hnm[64], mcnt[64 * 3];
   __shared__ int hcnt[64], hmodel[64];
   __shared__ int s_sub[64][8];  // the batch's subsets (7 indices each)
@@ -589,6 +594,56 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
     __syncthreads();
     bool stop = false;
     for (int base = 0; base < niters && !stop; base += 64) {
+#ifndef FLVIS_SOLVERS_PRODUCT
+      int nm = -1;
+      double* const xw = spw + lane;
+      if (wv == 0) {
+        draw_batch(base, 64, niters, 1000, false);
+        const int iter = base + lane;
+        double F[3][9];
+        if (iter < niters) {
+          if (s_sub[lane][7]) {
+            double x1[7][2], x2[7][2];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+              const int ik = s_sub[lane][k];
+              x1[k][0] = sm1[2 * ik];
+              x1[k][1] = sm1[2 * ik + 1];
+              x2[k][0] = sm2[2 * ik];
+              x2[k][1] = sm2[2 * ik + 1];
+            }
+            nm = cvs::run7point<64>(x1, x2, xw, F, [](int) {});
+          } else {
+            nm = -2;
+          }
+        }
+        if (nm > 0) {
+          for (int m = 0; m < nm; m++) {
+            // `std::sort(errf.ptr<int>(), errf.ptr<int>() + count)`: the float errors ordered through their bit patterns
+            int err[14];
+#pragma unroll
+            for (int i = 0; i < 14; i++)
+              err[i] = i < n ? __float_as_int(f_error(F[m], sm1[2 * i], sm1[2 * i + 1], sm2[2 * i], sm2[2 * i + 1])) : 0x7fffffff;
+            // (padding sorts last): odd-even transposition network on registers
+#pragma unroll
+            for (int pass = 0; pass < 14; pass++)
+#pragma unroll
+              for (int i = pass & 1; i + 1 < 14; i += 2) {
+                const int a = err[i], b = err[i + 1];
+                err[i] = a < b ? a : b;
+                err[i + 1] = a < b ? b : a;
+              }
+            float e_lo = 0.f, e_hi = 0.f, e_mid = 0.f;
+#pragma unroll
+            for (int i = 0; i < 14; i++) {
+              if (i == n / 2 - 1) e_lo = __int_as_float(err[i]);
+              if (i == n / 2) e_hi = e_mid = __int_as_float(err[i]);
+            }
+            s_med[lane * 3 + m] = (n & 1) ? (double)e_mid : ((double)(float)(e_lo + e_hi)) * 0.5;
+            for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
+          }
+        }
+#else
       SevenPointMid sp_mid;
       PolyBracket sp_t;
       double sp_roots[4];
@@ -653,6 +708,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
             for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
           }
         }
+#endif
         hnm[lane] = nm;
       }
       __syncthreads();
@@ -690,6 +746,45 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
 #ifdef FLVIS_RANSAC_PROF
       if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[24 + 6], 1ull);
 #endif
+#ifndef FLVIS_SOLVERS_PRODUCT
+      // hypotheses of this batch, one per lane of wave 0: cv::run7Point (cv_solvers.hpp) -- the one-sided Jacobi SVD of the 7 x 9 system
+      // in the lane's LDS workspace, the closed-form cubic, up to three matrices
+      int nm = -1;  // -1: beyond niters, -2: subset impossible (the reference loop stops)
+      double* const xw = spw + lane;  // element e of this lane at xw[e * 64]
+      if (wv == 0) {
+        draw_batch(base, B, ctl[0], 10000, base == 0 && B == F_TAB_B && n < F_TAB_N);
+        const int iter = base + lane;
+        if (lane < B && iter < ctl[0]) {
+#ifdef FLVIS_RANSAC_PROF
+          if (tid == 0) {
+            g_sp_prof = p.counters ? p.counters + 40 : nullptr;
+            g_sp_last = (long long)wall_clock64();
+          }
+#endif
+          if (s_sub[lane][7]) {
+            double x1[7][2], x2[7][2];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+              const int ik = s_sub[lane][k];
+              x1[k][0] = sm1[2 * ik];
+              x1[k][1] = sm1[2 * ik + 1];
+              x2[k][0] = sm2[2 * ik];
+              x2[k][1] = sm2[2 * ik + 1];
+            }
+            double F[3][9];
+            nm = cvs::run7point<64>(x1, x2, xw, F, [&](int i) { SP_STAMP(i); });
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+              if (m < nm)
+#pragma unroll
+                for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
+          } else {
+            nm = -2;
+          }
+        }
+        hnm[lane] = nm;
+      }
+#else
       // hypotheses of this batch, one per lane of wave 0.  The bisections of the cubic's (up to three) sign-change intervals are
       // handed to waves 0..2, one interval each (a lane's whole bracketing level inside wave 0 was a third of the generation time:
       // a single wave is VALU-issue bound); the level travels through the per-lane workspace, which is free after the elimination
@@ -761,6 +856,7 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
         }
         hnm[lane] = nm;
       }
+#endif
       __syncthreads();
       RPROF(24, 1);
       // score + replay in sub-batches of 16 hypotheses: the adaptive stop usually ends the search within the first few hypotheses
@@ -1096,6 +1192,34 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
 #pragma unroll
             for (int j = 0; j < 5; j++) idx[j] = s_sub[lane][j];
             have = true;
+#ifndef FLVIS_SOLVERS_PRODUCT
+            // cv::solvePnP(SOLVEPNP_P3P) on the four sample points (cv_solvers.hpp): undistortPoints to normalised float coordinates,
+            // mapped back with x * fx + cx by p3p::extract_points; Gao's solver on the first three, the fourth picks the pose
+            const cvs::P3PCamera cam = cvs::p3p_camera(fx, fy, cx, cy);
+            double uv[4][2], X[4][3], Rr[9], tr[3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              uv[k][0] = (double)(float)(((double)s2d[2 * idx[k]] - cx) / fx) * fx + cx;
+              uv[k][1] = (double)(float)(((double)s2d[2 * idx[k] + 1] - cy) / fy) * fy + cy;
+#pragma unroll
+              for (int j = 0; j < 3; j++) X[k][j] = (double)s3d[3 * idx[k] + j];
+            }
+            if (cvs::p3p_solve4(cam, uv, X, Rr, tr)) {
+#pragma unroll
+              for (int j = 0; j < 9; j++) hpose[lane][j] = Rr[j];
+              hpose[lane][9] = tr[0];
+              hpose[lane][10] = tr[1];
+              hpose[lane][11] = tr[2];
+              cnt = -3;
+            }
+          } else {
+            cnt = -2;
+          }
+        }
+        hcnt[lane] = cnt;
+      }
+      __syncthreads();
+#else
             V3 P[3], f[3];
             for (int k = 0; k < 3; k++) {
               P[k] = V3{(double)s3d[3 * idx[k]], (double)s3d[3 * idx[k] + 1], (double)s3d[3 * idx[k] + 2]};
@@ -1186,6 +1310,7 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
         hcnt[lane] = cnt;
       }
       __syncthreads();
+#endif
       }  // (P3P hypotheses)
       PNP_PROF(1);
       // score + replay in sub-batches of 16 hypotheses (the adaptive stop usually ends the search within the first few)
@@ -2333,6 +2458,11 @@ __global__ void k_wait_flag(const long long* __restrict__ flag, int n_words, lon
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
+// stream-ordered store of a sequence number into a device word (the producing side of a flag join, pipeline.cpp)
+__global__ void k_store_flag(long long* __restrict__ word, long long v) {
+  __hip_atomic_store(word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_store_flag(hipStream_t st, long long* word, long long v) { hipLaunchKernelGGL(k_store_flag, dim3(1), dim3(1), 0, st, word, v); }
 void launch_wait_flag(hipStream_t st, const long long* flag, int n_words, long long seq, long long* err_word) {
   hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, st, flag, n_words, seq, err_word);
 }

@@ -90,6 +90,7 @@ void launch_pnp_ransac_sets(hipStream_t st, const float* p3d, const float* p2d, 
                             int iterative, const double* guess7, const unsigned long long* seeds, int max_iters, double reproj_px,
                             double conf, double* pose7, unsigned char* mask, int* n_inliers);
 void launch_store_progress(hipStream_t st, long long* host_word, long long v);  // stream-ordered store into host-mapped memory
+void launch_store_flag(hipStream_t st, long long* word, long long v);  // stream-ordered store of a sequence number into a device word
 void launch_wait_flag(hipStream_t st, const long long* flag, int n_words, long long seq, long long* err_word);  // stream-ordered wait for an upload's sequence block
 void launch_frame_head(hipStream_t st, const Pipe& p, const double* d_time, long long* host_progress, long long frame_no);  // imu_feed + frame_begin in one launch
 // ... + track_prepare (only when nothing runs between the two: no local-map feedback to apply)
