@@ -1,5 +1,5 @@
 // flvis_amd: the minimal solvers inside the two RANSACs of LKORBTracking::tracking (lkorb_tracking.cpp:134-135, 170-177), restated from
-// the algorithms OpenCV 3.x runs there -- one header for the HIP kernels and for the CPU checker (oracle/), plain C++ with + - * / sqrt
+// the algorithms OpenCV 3.x runs there -- one header for the HIP kernels and for the CPU checker of the tests, plain C++ with + - * / sqrt
 // and the det_math.hpp functions, compiled with -ffp-contract=off on both sides, so that both execute the same IEEE operations in the
 // same order.  No OpenCV exists in this image: what is restated is the published structure of its code (calib3d/src/fundam.cpp
 // run7Point, core/src/lapack.cpp JacobiSVDImpl_, core/src/mathfuncs.cpp solveCubic, calib3d/src/p3p.cpp + polynom_solver.cpp) -- the
@@ -18,7 +18,7 @@
 //                  quaternion method with the 4 x 4 cyclic Jacobi eigen-solver of p3p.cpp; the four-point form picks the pose that
 //                  reprojects the fourth point best.
 //
-// Departures that remain (stated in oracle/README.md): std::hypot is cvs::hypot2 below (scaled sqrt, not glibc's), acos / cos / cbrt are
+// Departures that remain (stated in the checker's README): std::hypot is cvs::hypot2 below (scaled sqrt, not glibc's), acos / cos / cbrt are
 // det_math's fdlibm forms, pow(x, 0.333333333333) is cbrt(x) (1 + (0.333333333333 - 1/3) log x) (first order; the neglected term is 1e-25),
 // pow(x, 1/3.) in solve_deg3 is cbrt(x).
 #pragma once
