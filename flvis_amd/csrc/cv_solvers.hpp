@@ -135,12 +135,11 @@ CVS_FN int solve_cubic(const double* c, double* r) {
 constexpr int SP_WORK = 9 * 9 + 7;
 constexpr int SVD_MAX_SWEEPS = 30;  // max(m, 30), m = 9
 
-// x1, x2: the seven correspondences (Point2f values as doubles).  F: up to three matrices, row-major.  Returns their number (0: none).
-template <int WS, typename Stamp>
-CVS_FN int run7point(const double (*x1)[2], const double (*x2)[2], double* wk, double (*F)[9], Stamp&& stamp) {
 #define CVS_A(i, k) wk[(9 * (i) + (k)) * WS]
 #define CVS_W(i) wk[(81 + (i)) * WS]
-  // form a linear system: i-th row of A represents the equation (m2[i], 1)' F (m1[i], 1) = 0
+// form a linear system: i-th row of A represents the equation (m2[i], 1)' F (m1[i], 1) = 0; then the squared row norms
+template <int WS>
+CVS_FN void sp_fill(const double (*x1)[2], const double (*x2)[2], double* wk) {
   for (int i = 0; i < 7; i++) {
     const double px0 = x1[i][0], py0 = x1[i][1];
     const double px1 = x2[i][0], py1 = x2[i][1];
@@ -155,8 +154,6 @@ CVS_FN int run7point(const double (*x1)[2], const double (*x2)[2], double* wk, d
     CVS_A(i, 8) = 1;
   }
   for (int k = 0; k < 9; k++) CVS_A(7, k) = 0, CVS_A(8, k) = 0;
-  // ---- JacobiSVDImpl_<double>(At = A (n = 7 rows of m = 9), n1 = 9, minval = DBL_MIN, eps = 10 DBL_EPSILON); the left factor is not formed
-  const double eps = DBL_EPSILON * 10;
   for (int i = 0; i < 7; i++) {
     double sd = 0;
     for (int k = 0; k < 9; k++) {
@@ -165,44 +162,51 @@ CVS_FN int run7point(const double (*x1)[2], const double (*x2)[2], double* wk, d
     }
     CVS_W(i) = sd;
   }
-  for (int iter = 0; iter < SVD_MAX_SWEEPS; iter++) {
-    bool changed = false;
-    for (int i = 0; i < 6; i++)
-      for (int j = i + 1; j < 7; j++) {
-        double ai[9], aj[9];
-        CVS_UNROLL
-        for (int k = 0; k < 9; k++) ai[k] = CVS_A(i, k), aj[k] = CVS_A(j, k);
-        double a = CVS_W(i), p = 0, b = CVS_W(j);
-        CVS_UNROLL
-        for (int k = 0; k < 9; k++) p += ai[k] * aj[k];
-        if (fabs(p) <= eps * sqrt(a * b)) continue;
-        p *= 2;
-        const double beta = a - b, gamma = hypot2(p, beta);
-        double c, s;
-        if (beta < 0) {
-          const double delta = (gamma - beta) * 0.5;
-          s = sqrt(delta / gamma);
-          c = p / (gamma * s * 2);
-        } else {
-          c = sqrt((gamma + beta) / (gamma * 2));
-          s = p / (gamma * c * 2);
-        }
-        a = b = 0;
-        CVS_UNROLL
-        for (int k = 0; k < 9; k++) {
-          const double t0 = c * ai[k] + s * aj[k];
-          const double t1 = -s * ai[k] + c * aj[k];
-          CVS_A(i, k) = t0;
-          CVS_A(j, k) = t1;
-          a += t0 * t0;
-          b += t1 * t1;
-        }
-        CVS_W(i) = a;
-        CVS_W(j) = b;
-        changed = true;
-      }
-    if (!changed) break;
+}
+
+// One pair (i, j) of a Jacobi sweep of JacobiSVDImpl_<double> (eps = 10 DBL_EPSILON): rows i and j of A are rotated so that they become
+// orthogonal.  true: rotated.  Pairs that share no row commute exactly -- the kernel runs the pairs of a sweep (and the head of the next)
+// on their anti-diagonals i + j, three at a time, and obtains the bits of the cyclic order (i, j) = (0, 1), (0, 2) .. (5, 6) executed here.
+template <int WS>
+CVS_FN bool sp_pair(double* wk, int i, int j) {
+  const double eps = DBL_EPSILON * 10;
+  double ai[9], aj[9];
+  CVS_UNROLL
+  for (int k = 0; k < 9; k++) ai[k] = CVS_A(i, k), aj[k] = CVS_A(j, k);
+  double a = CVS_W(i), p = 0, b = CVS_W(j);
+  CVS_UNROLL
+  for (int k = 0; k < 9; k++) p += ai[k] * aj[k];
+  if (fabs(p) <= eps * sqrt(a * b)) return false;
+  p *= 2;
+  const double beta = a - b, gamma = hypot2(p, beta);
+  double c, s;
+  if (beta < 0) {
+    const double delta = (gamma - beta) * 0.5;
+    s = sqrt(delta / gamma);
+    c = p / (gamma * s * 2);
+  } else {
+    c = sqrt((gamma + beta) / (gamma * 2));
+    s = p / (gamma * c * 2);
   }
+  a = b = 0;
+  CVS_UNROLL
+  for (int k = 0; k < 9; k++) {
+    const double t0 = c * ai[k] + s * aj[k];
+    const double t1 = -s * ai[k] + c * aj[k];
+    CVS_A(i, k) = t0;
+    CVS_A(j, k) = t1;
+    a += t0 * t0;
+    b += t1 * t1;
+  }
+  CVS_W(i) = a;
+  CVS_W(j) = b;
+  return true;
+}
+
+// behind the sweeps: singular values, their order, the completed basis, the cubic, the matrices.  Returns the number of matrices.
+template <int WS, typename Stamp>
+CVS_FN int sp_finish(double* wk, double (*F)[9], Stamp&& stamp) {
+  const double eps = DBL_EPSILON * 10;
   stamp(1);
   for (int i = 0; i < 7; i++) {
     double sd = 0;
@@ -262,8 +266,6 @@ CVS_FN int run7point(const double (*x1)[2], const double (*x2)[2], double* wk, d
   // f1, f2: a basis of the null space; f ~ lambda f1 + (1 - lambda) f2; det(f) = 0 is a cubic in lambda
   double f1[9], f2[9];
   for (int k = 0; k < 9; k++) f1[k] = CVS_A(7, k), f2[k] = CVS_A(8, k);
-#undef CVS_A
-#undef CVS_W
   for (int k = 0; k < 9; k++) f1[k] -= f2[k];
   double c[4], r[3];
   double t0 = f2[4] * f2[8] - f2[5] * f2[7];
@@ -308,6 +310,87 @@ CVS_FN int run7point(const double (*x1)[2], const double (*x2)[2], double* wk, d
   }
   stamp(4);
   return n;
+}
+#undef CVS_A
+#undef CVS_W
+
+// The schedule of the kernel.  Pairs on one anti-diagonal i + j share no row, and of two pairs that do share a row the one with the
+// smaller i + j is the earlier one of the cyclic order: running the anti-diagonals 1 .. 11 of a sweep in order, all pairs of one at once,
+// reproduces the cyclic order's bits.  The same holds across sweeps when sweep s + 1 starts seven steps behind sweep s (its first pairs
+// touch rows the last pairs of sweep s have left).  Step T = 7 s_hi + sigma (sigma = 1 .. 7) therefore holds at most three pairs: those of
+// sweep s_hi on anti-diagonal sigma and those of sweep s_hi - 1 on anti-diagonal sigma + 7.  A sweep that follows an unchanged one
+// rotates nothing (it tests the same rows), so starting it before its predecessor's verdict is known changes nothing either.
+struct SpSlot {
+  signed char ds, i, j;  // sweep = s_hi + ds (ds = 0 or -1); i < 0: no pair
+};
+CVS_FN SpSlot sp_slot(int sigma, int q) {
+  // sigma = 1 .. 7, q = 0 .. 2
+  switch (sigma * 4 + q) {
+    case 1 * 4 + 0: return SpSlot{0, 0, 1};
+    case 1 * 4 + 1: return SpSlot{-1, 2, 6};
+    case 1 * 4 + 2: return SpSlot{-1, 3, 5};
+    case 2 * 4 + 0: return SpSlot{0, 0, 2};
+    case 2 * 4 + 1: return SpSlot{-1, 3, 6};
+    case 2 * 4 + 2: return SpSlot{-1, 4, 5};
+    case 3 * 4 + 0: return SpSlot{0, 0, 3};
+    case 3 * 4 + 1: return SpSlot{0, 1, 2};
+    case 3 * 4 + 2: return SpSlot{-1, 4, 6};
+    case 4 * 4 + 0: return SpSlot{0, 0, 4};
+    case 4 * 4 + 1: return SpSlot{0, 1, 3};
+    case 4 * 4 + 2: return SpSlot{-1, 5, 6};
+    case 5 * 4 + 0: return SpSlot{0, 0, 5};
+    case 5 * 4 + 1: return SpSlot{0, 1, 4};
+    case 5 * 4 + 2: return SpSlot{0, 2, 3};
+    case 6 * 4 + 0: return SpSlot{0, 0, 6};
+    case 6 * 4 + 1: return SpSlot{0, 1, 5};
+    case 6 * 4 + 2: return SpSlot{0, 2, 4};
+    case 7 * 4 + 0: return SpSlot{0, 1, 6};
+    case 7 * 4 + 1: return SpSlot{0, 2, 5};
+    case 7 * 4 + 2: return SpSlot{0, 3, 4};
+    default: return SpSlot{0, -1, -1};
+  }
+}
+// the sweeps in the kernel's schedule, one step after the other (what three lanes do at once): the CPU statement of that schedule, which
+// the tests hold against run7point bit for bit
+template <int WS>
+CVS_FN void sp_sweeps_scheduled(double* wk) {
+  bool chg_prev = false, chg_cur = false;
+  for (int T = 1;; T++) {
+    const int s_hi = (T - 1) / 7, sigma = T - 7 * s_hi;
+    for (int q = 0; q < 3; q++) {
+      const SpSlot e = sp_slot(sigma, q);
+      const int sw = s_hi + e.ds;
+      if (e.i < 0 || sw < 0 || sw >= SVD_MAX_SWEEPS) continue;
+      const bool rot = sp_pair<WS>(wk, e.i, e.j);
+      if (e.ds == 0) chg_cur = chg_cur || rot;
+      else chg_prev = chg_prev || rot;
+    }
+    if (sigma == 4 && s_hi >= 1 && (!chg_prev || s_hi == SVD_MAX_SWEEPS)) return;  // sweep s_hi - 1 is complete: unchanged, or the last one
+    if (sigma == 7) {
+      chg_prev = chg_cur;
+      chg_cur = false;
+    }
+  }
+}
+template <int WS, typename Stamp>
+CVS_FN int run7point_scheduled(const double (*x1)[2], const double (*x2)[2], double* wk, double (*F)[9], Stamp&& stamp) {
+  sp_fill<WS>(x1, x2, wk);
+  sp_sweeps_scheduled<WS>(wk);
+  return sp_finish<WS>(wk, F, stamp);
+}
+
+// x1, x2: the seven correspondences (Point2f values as doubles).  F: up to three matrices, row-major.  Returns their number (0: none).
+template <int WS, typename Stamp>
+CVS_FN int run7point(const double (*x1)[2], const double (*x2)[2], double* wk, double (*F)[9], Stamp&& stamp) {
+  sp_fill<WS>(x1, x2, wk);
+  // ---- JacobiSVDImpl_<double>(At = A (n = 7 rows of m = 9), n1 = 9, minval = DBL_MIN, eps = 10 DBL_EPSILON); the left factor is not formed
+  for (int iter = 0; iter < SVD_MAX_SWEEPS; iter++) {
+    bool changed = false;
+    for (int i = 0; i < 6; i++)
+      for (int j = i + 1; j < 7; j++) changed = sp_pair<WS>(wk, i, j) || changed;
+    if (!changed) break;
+  }
+  return sp_finish<WS>(wk, F, stamp);
 }
 
 // ------------------------------------------------------------------------------------------------ polynom_solver.cpp
@@ -673,6 +756,407 @@ CVS_FN bool p3p_solve4(const P3PCamera& cam, const double uv[4][2], const double
   }
   for (int i = 0; i < 9; i++) R[i] = Rs[ns][i];
   for (int i = 0; i < 3; i++) t[i] = ts[ns][i];
+  return true;
+}
+
+// ================================================================================================ SOLVEPNP_ITERATIVE on the inliers
+// cv::solvePnP(..., useExtrinsicGuess = false, SOLVEPNP_ITERATIVE) = cvFindExtrinsicCameraParams2 (calib3d/src/calibration.cpp), the final
+// solve of cv::solvePnPRansac(ITERATIVE) on its inliers (lkorb_tracking.cpp:172): a DLT start (non-planar point sets) and CvLevMarq (at most
+// 20 iterations, stop when the relative change of (rvec, tvec) falls below FLT_EPSILON) on the reprojection error, rotation as a Rodrigues
+// vector.  Restated for the CPU checker only (`make -C oracle TAIL=cv`): the kernels and the default checker refine the RANSAC's winning
+// model by Gauss-Newton to the same minimum; the 12 x 12 SVD of the DLT start would add ~50 us to the frame chain, and what it buys is
+// measured by the tests (the two tails agree to ~1e-7 relative, CvLevMarq's own stopping tolerance).  Zero distortion (rectified images).
+
+// cv::JacobiSVDImpl_<double>: At holds n rows of m doubles (the columns of the matrix to decompose); on return row i = sigma_i u_i scaled to
+// unit length (for i < n1; rows beyond the rank are completed), W the singular values in decreasing order, Vt (n x n, may be null) the
+// right singular vectors in rows.  At must have room for n1 rows.
+CVS_FN void jacobi_svd(double* At, int astep, double* W, double* Vt, int vstep, int m, int n, int n1) {
+  const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+  const int max_iter = m > 30 ? m : 30;
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) {
+      const double t = At[i * astep + k];
+      sd += t * t;
+    }
+    W[i] = sd;
+    if (Vt) {
+      for (int k = 0; k < n; k++) Vt[i * vstep + k] = 0;
+      Vt[i * vstep + i] = 1;
+    }
+  }
+  for (int iter = 0; iter < max_iter; iter++) {
+    bool changed = false;
+    for (int i = 0; i < n - 1; i++)
+      for (int j = i + 1; j < n; j++) {
+        double *Ai = At + i * astep, *Aj = At + j * astep;
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
+        if (fabs(p) <= eps * sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = hypot2(p, beta);
+        double c, s;
+        if (beta < 0) {
+          const double delta = (gamma - beta) * 0.5;
+          s = sqrt(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = sqrt((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = b = 0;
+        for (int k = 0; k < m; k++) {
+          const double t0 = c * Ai[k] + s * Aj[k];
+          const double t1 = -s * Ai[k] + c * Aj[k];
+          Ai[k] = t0;
+          Aj[k] = t1;
+          a += t0 * t0;
+          b += t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = true;
+        if (Vt) {
+          double *Vi = Vt + i * vstep, *Vj = Vt + j * vstep;
+          for (int k = 0; k < n; k++) {
+            const double t0 = c * Vi[k] + s * Vj[k];
+            const double t1 = -s * Vi[k] + c * Vj[k];
+            Vi[k] = t0;
+            Vj[k] = t1;
+          }
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < n; i++) {
+    double sd = 0;
+    for (int k = 0; k < m; k++) {
+      const double t = At[i * astep + k];
+      sd += t * t;
+    }
+    W[i] = sqrt(sd);
+  }
+  for (int i = 0; i < n - 1; i++) {
+    int j = i;
+    for (int k = i + 1; k < n; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      const double t = W[i];
+      W[i] = W[j];
+      W[j] = t;
+      if (Vt) {
+        for (int k = 0; k < m; k++) {
+          const double u = At[i * astep + k];
+          At[i * astep + k] = At[j * astep + k];
+          At[j * astep + k] = u;
+        }
+        for (int k = 0; k < n; k++) {
+          const double u = Vt[i * vstep + k];
+          Vt[i * vstep + k] = Vt[j * vstep + k];
+          Vt[j * vstep + k] = u;
+        }
+      }
+    }
+  }
+  if (!Vt) return;
+  uint64_t rng = 0x12345678ull;
+  for (int i = 0; i < n1; i++) {
+    double sd = i < n ? W[i] : 0;
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+      const double val0 = 1. / m;
+      for (int k = 0; k < m; k++) At[i * astep + k] = (rng_next(rng) & 256) != 0 ? val0 : -val0;
+      for (int it = 0; it < 2; it++)
+        for (int j = 0; j < i; j++) {
+          sd = 0;
+          for (int k = 0; k < m; k++) sd += At[i * astep + k] * At[j * astep + k];
+          double asum = 0;
+          for (int k = 0; k < m; k++) {
+            const double t = At[i * astep + k] - sd * At[j * astep + k];
+            At[i * astep + k] = t;
+            asum += fabs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+          for (int k = 0; k < m; k++) At[i * astep + k] *= asum;
+        }
+      sd = 0;
+      for (int k = 0; k < m; k++) {
+        const double t = At[i * astep + k];
+        sd += t * t;
+      }
+      sd = sqrt(sd);
+    }
+    const double s = sd > minval ? 1 / sd : 0.;
+    for (int k = 0; k < m; k++) At[i * astep + k] *= s;
+  }
+}
+
+// cv::SVD::compute of a square n x n matrix A (row-major, n <= 12): w, u (columns = left vectors), vt (rows = right vectors)
+CVS_FN void svd_square(const double* A, int n, double* w, double* u, double* vt) {
+  double at[144];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) at[i * n + j] = A[j * n + i];  // transpose(src, temp_a)
+  jacobi_svd(at, n, w, vt, n, n, n, n);
+  if (u)
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) u[j * n + i] = at[i * n + j];  // transpose(temp_u, _u)
+}
+
+// cv::solve(A, b, x, DECOMP_SVD), A n x n (n <= 6): JacobiSVD on A^T + SVBkSb
+CVS_FN void solve_svd(const double* A, const double* b, int n, double* x) {
+  double at[36], w[6], vt[36];
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) at[i * n + j] = A[j * n + i];
+  jacobi_svd(at, n, w, vt, n, n, n, n);
+  double threshold = 0;
+  for (int i = 0; i < n; i++) threshold += w[i];
+  threshold *= DBL_EPSILON * 2;
+  for (int k = 0; k < n; k++) x[k] = 0;
+  for (int i = 0; i < n; i++) {
+    double wi = w[i];
+    if (fabs(wi) <= threshold) continue;
+    wi = 1 / wi;
+    double sv = 0;
+    for (int k = 0; k < n; k++) sv += at[i * n + k] * b[k];  // u_i . b
+    sv *= wi;
+    for (int k = 0; k < n; k++) x[k] += sv * vt[i * n + k];
+  }
+}
+
+// cvRodrigues2, vector -> matrix, with dR/dr (3 x 9: row i = d vec(R) / d r_i) when J != null
+CVS_FN void rodrigues(const double* rv, double* R, double* J) {
+  const double theta = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+  if (theta < DBL_EPSILON) {
+    for (int i = 0; i < 9; i++) R[i] = 0;
+    R[0] = R[4] = R[8] = 1;
+    if (J) {
+      for (int i = 0; i < 27; i++) J[i] = 0;
+      J[5] = J[15] = J[19] = -1;
+      J[7] = J[11] = J[21] = 1;
+    }
+    return;
+  }
+  const double c = detm::det_cos(theta), s = detm::det_sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+  const double rx = rv[0] * itheta, ry = rv[1] * itheta, rz = rv[2] * itheta;
+  const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+  const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+  const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+  if (J) {
+    const double drrt[27] = {rx + rx, ry, rz, ry, 0, 0, rz, 0, 0, 0, rx, 0, rx, ry + ry, rz, 0, rz, 0, 0, 0, rx, 0, 0, ry, rx, ry, rz + rz};
+    const double d_r_x_[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+      const double ri = i == 0 ? rx : i == 1 ? ry : rz;
+      const double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+      const double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+      for (int k = 0; k < 9; k++) J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x_[i * 9 + k];
+    }
+  }
+}
+
+// cvRodrigues2, matrix -> vector (the matrix is first projected onto SO(3) by its SVD)
+CVS_FN void rodrigues_inv(const double* Rin, double* rv) {
+  double w[3], u[9], vt[9], R[9];
+  svd_square(Rin, 3, w, u, vt);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[3 * i + j] = u[3 * i] * vt[j] + u[3 * i + 1] * vt[3 + j] + u[3 * i + 2] * vt[6 + j];
+  double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+  const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+  double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+  c = c > 1. ? 1. : c < -1. ? -1. : c;
+  const double theta = detm::det_acos(c);
+  if (s < 1e-5) {
+    if (c > 0) {
+      rx = ry = rz = 0;
+    } else {
+      double t;
+      t = (R[0] + 1) * 0.5;
+      rx = sqrt(t > 0. ? t : 0.);
+      t = (R[4] + 1) * 0.5;
+      ry = sqrt(t > 0. ? t : 0.) * (R[1] < 0 ? -1. : 1.);
+      t = (R[8] + 1) * 0.5;
+      rz = sqrt(t > 0. ? t : 0.) * (R[2] < 0 ? -1. : 1.);
+      if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+      const double nn = sqrt(rx * rx + ry * ry + rz * rz);
+      const double k = theta / nn;
+      rx *= k, ry *= k, rz *= k;
+    }
+  } else {
+    double vth = 1 / (2 * s);
+    vth *= theta;
+    rx *= vth, ry *= vth, rz *= vth;
+  }
+  rv[0] = rx, rv[1] = ry, rv[2] = rz;
+}
+
+// cvProjectPoints2 without distortion: residuals err[2 n] = projection - measurement and (J != null) the 2 n x 6 Jacobian (dp/dr, dp/dt)
+CVS_FN void project_residuals(int n, const double* M, const double* m, const double* param, double fx, double fy, double cx, double cy, double* err,
+                              double* J) {
+  double R[9], dRdr[27];
+  rodrigues(param, R, J ? dRdr : nullptr);
+  const double* t = param + 3;
+  for (int i = 0; i < n; i++) {
+    const double X = M[3 * i], Y = M[3 * i + 1], Z = M[3 * i + 2];
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z ? 1. / z : 1;
+    x *= z;
+    y *= z;
+    err[2 * i] = (x * fx + cx) - m[2 * i];
+    err[2 * i + 1] = (y * fy + cy) - m[2 * i + 1];
+    if (J) {
+      double* Jx = J + (size_t)(2 * i) * 6;
+      double* Jy = Jx + 6;
+      const double dx0dr[3] = {X * dRdr[0] + Y * dRdr[1] + Z * dRdr[2], X * dRdr[9] + Y * dRdr[10] + Z * dRdr[11], X * dRdr[18] + Y * dRdr[19] + Z * dRdr[20]};
+      const double dy0dr[3] = {X * dRdr[3] + Y * dRdr[4] + Z * dRdr[5], X * dRdr[12] + Y * dRdr[13] + Z * dRdr[14], X * dRdr[21] + Y * dRdr[22] + Z * dRdr[23]};
+      const double dz0dr[3] = {X * dRdr[6] + Y * dRdr[7] + Z * dRdr[8], X * dRdr[15] + Y * dRdr[16] + Z * dRdr[17], X * dRdr[24] + Y * dRdr[25] + Z * dRdr[26]};
+      for (int j = 0; j < 3; j++) {
+        const double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
+        const double dydr = z * (dy0dr[j] - y * dz0dr[j]);
+        Jx[j] = fx * dxdr;
+        Jy[j] = fy * dydr;
+      }
+      const double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
+      for (int j = 0; j < 3; j++) {
+        Jx[3 + j] = fx * dxdt[j];
+        Jy[3 + j] = fy * dydt[j];
+      }
+    }
+  }
+}
+
+// CvLevMarq::step for six free parameters: (JtJ with its diagonal scaled by 1 + lambda) x = JtErr by SVD, param = prev - x
+CVS_FN void levmarq_step(const double* JtJ, const double* JtErr, const double* prev, int lambdaLg10, double* param) {
+  // exp(lambdaLg10 * log(10.)): the power of ten itself (the library's exp is within an ulp of it)
+  const double p10[34] = {1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1e0,
+                          1e1,   1e2,   1e3,   1e4,   1e5,   1e6,   1e7,   1e8,  1e9,  1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17};
+  const double lambda = p10[lambdaLg10 + 16];
+  double A[36], x[6];
+  for (int i = 0; i < 36; i++) A[i] = JtJ[i];
+  for (int i = 0; i < 6; i++) A[7 * i] *= 1. + lambda;
+  solve_svd(A, JtErr, 6, x);
+  for (int i = 0; i < 6; i++) param[i] = prev[i] - x[i];
+}
+
+CVS_FN double norm2(const double* v, int n) {
+  double s = 0;
+  for (int i = 0; i < n; i++) s += v[i] * v[i];
+  return sqrt(s);
+}
+
+// cvFindExtrinsicCameraParams2(useExtrinsicGuess = 0) for n >= 6 non-planar points: M world points (3 n), m pixels (2 n); work: >= 24 n
+// doubles.  rvec / tvec out.  false: the point set is planar (OpenCV starts from a homography there: not restated) or n < 6.
+CVS_FN bool find_extrinsic_iterative(int n, const double* M, const double* m, double fx, double fy, double cx, double cy, double* work, double* rvec,
+                                     double* tvec, int* iterations_out) {
+  if (n < 6) return false;
+  // planarity test: SVD of the covariance of the points
+  double Mc[3] = {0, 0, 0};
+  for (int i = 0; i < n; i++) Mc[0] += M[3 * i], Mc[1] += M[3 * i + 1], Mc[2] += M[3 * i + 2];
+  for (int k = 0; k < 3; k++) Mc[k] /= n;
+  double MM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < 3; a++)
+    for (int b = a; b < 3; b++) {
+      double sacc = 0;
+      for (int i = 0; i < n; i++) sacc += (M[3 * i + a] - Mc[a]) * (M[3 * i + b] - Mc[b]);
+      MM[3 * a + b] = MM[3 * b + a] = sacc;
+    }
+  double W3[3], V3[9];
+  svd_square(MM, 3, W3, nullptr, V3);
+  if (W3[2] / W3[1] < 1e-3) return false;
+  // ---- DLT: L (2 n x 12), LL = L^T L, the right singular vector of the smallest singular value -> [R | t] up to scale
+  double LL[144];
+  for (int i = 0; i < 144; i++) LL[i] = 0;
+  {
+    // MulTransposed: entry (a, b) = sum over the rows of L, in row order
+    double* L = work;  // 2 n x 12
+    for (int i = 0; i < n; i++) {
+      const double xn = (m[2 * i] - cx) * (1. / fx), yn = (m[2 * i + 1] - cy) * (1. / fy);  // cvUndistortPoints, zero distortion
+      const double x = -xn, y = -yn;
+      double* r0 = L + (size_t)(2 * i) * 12;
+      double* r1 = r0 + 12;
+      r0[0] = r1[4] = M[3 * i];
+      r0[1] = r1[5] = M[3 * i + 1];
+      r0[2] = r1[6] = M[3 * i + 2];
+      r0[3] = r1[7] = 1.;
+      r0[4] = r0[5] = r0[6] = r0[7] = 0.;
+      r1[0] = r1[1] = r1[2] = r1[3] = 0.;
+      r0[8] = x * M[3 * i];
+      r0[9] = x * M[3 * i + 1];
+      r0[10] = x * M[3 * i + 2];
+      r0[11] = x;
+      r1[8] = y * M[3 * i];
+      r1[9] = y * M[3 * i + 1];
+      r1[10] = y * M[3 * i + 2];
+      r1[11] = y;
+    }
+    for (int a = 0; a < 12; a++)
+      for (int b = a; b < 12; b++) {
+        double sacc = 0;
+        for (int k = 0; k < 2 * n; k++) sacc += L[(size_t)k * 12 + a] * L[(size_t)k * 12 + b];
+        LL[12 * a + b] = LL[12 * b + a] = sacc;
+      }
+  }
+  double LW[12], LV[144];
+  svd_square(LL, 12, LW, nullptr, LV);
+  double RRt[12];
+  for (int k = 0; k < 12; k++) RRt[k] = LV[11 * 12 + k];
+  double RR[9] = {RRt[0], RRt[1], RRt[2], RRt[4], RRt[5], RRt[6], RRt[8], RRt[9], RRt[10]};
+  double tt[3] = {RRt[3], RRt[7], RRt[11]};
+  const double det = RR[0] * (RR[4] * RR[8] - RR[5] * RR[7]) - RR[1] * (RR[3] * RR[8] - RR[5] * RR[6]) + RR[2] * (RR[3] * RR[7] - RR[4] * RR[6]);
+  if (det < 0) {
+    for (int k = 0; k < 9; k++) RR[k] = -RR[k];
+    for (int k = 0; k < 3; k++) tt[k] = -tt[k];
+  }
+  const double sc = norm2(RR, 9);
+  double W[3], U[9], Vt[9], R0[9];
+  svd_square(RR, 3, W, U, Vt);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R0[3 * i + j] = U[3 * i] * Vt[j] + U[3 * i + 1] * Vt[3 + j] + U[3 * i + 2] * Vt[6 + j];
+  const double tscale = norm2(R0, 9) / sc;
+  double param[6], prev[6];
+  rodrigues_inv(R0, param);
+  for (int k = 0; k < 3; k++) param[3 + k] = tt[k] * tscale;
+  // ---- CvLevMarq(6, 2 n, (20, FLT_EPSILON), completeSymmFlag = true), lambdaLg10 = -3
+  double* err = work;               // 2 n
+  double* J = work + 2 * (size_t)n; // 2 n x 6
+  int lambdaLg10 = -3, iters = 0;
+  double prevErrNorm = DBL_MAX, errNorm = 0;
+  project_residuals(n, M, m, param, fx, fy, cx, cy, err, J);
+  for (;;) {
+    double JtJ[36], JtErr[6];
+    for (int a = 0; a < 6; a++) {
+      for (int b = a; b < 6; b++) {
+        double sacc = 0;
+        for (int k = 0; k < 2 * n; k++) sacc += J[(size_t)k * 6 + a] * J[(size_t)k * 6 + b];
+        JtJ[6 * a + b] = JtJ[6 * b + a] = sacc;
+      }
+      double sacc = 0;
+      for (int k = 0; k < 2 * n; k++) sacc += J[(size_t)k * 6 + a] * err[k];
+      JtErr[a] = sacc;
+    }
+    for (int k = 0; k < 6; k++) prev[k] = param[k];
+    levmarq_step(JtJ, JtErr, prev, lambdaLg10, param);
+    if (iters == 0) prevErrNorm = norm2(err, 2 * n);
+    for (;;) {
+      project_residuals(n, M, m, param, fx, fy, cx, cy, err, nullptr);
+      errNorm = norm2(err, 2 * n);
+      if (errNorm > prevErrNorm) {
+        if (++lambdaLg10 <= 16) {
+          levmarq_step(JtJ, JtErr, prev, lambdaLg10, param);
+          continue;
+        }
+      }
+      break;
+    }
+    lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+    double dn = 0, pn = 0;
+    for (int k = 0; k < 6; k++) dn += (param[k] - prev[k]) * (param[k] - prev[k]), pn += prev[k] * prev[k];
+    if (++iters >= 20 || sqrt(dn) / sqrt(pn) < FLT_EPSILON) break;
+    prevErrNorm = errNorm;
+    project_residuals(n, M, m, param, fx, fy, cx, cy, err, J);
+  }
+  for (int k = 0; k < 3; k++) rvec[k] = param[k], tvec[k] = param[3 + k];
+  if (iterations_out) *iterations_out = iters;
   return true;
 }
 

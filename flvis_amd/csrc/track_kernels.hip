@@ -747,42 +747,74 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
       if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[24 + 6], 1ull);
 #endif
 #ifndef FLVIS_SOLVERS_PRODUCT
-      // hypotheses of this batch, one per lane of wave 0: cv::run7Point (cv_solvers.hpp) -- the one-sided Jacobi SVD of the 7 x 9 system
-      // in the lane's LDS workspace, the closed-form cubic, up to three matrices
-      int nm = -1;  // -1: beyond niters, -2: subset impossible (the reference loop stops)
-      double* const xw = spw + lane;  // element e of this lane at xw[e * 64]
-      if (wv == 0) {
-        draw_batch(base, B, ctl[0], 10000, base == 0 && B == F_TAB_B && n < F_TAB_N);
-        const int iter = base + lane;
-        if (lane < B && iter < ctl[0]) {
-#ifdef FLVIS_RANSAC_PROF
-          if (tid == 0) {
-            g_sp_prof = p.counters ? p.counters + 40 : nullptr;
-            g_sp_last = (long long)wall_clock64();
-          }
-#endif
-          if (s_sub[lane][7]) {
-            double x1[7][2], x2[7][2];
-#pragma unroll
-            for (int k = 0; k < 7; k++) {
-              const int ik = s_sub[lane][k];
-              x1[k][0] = sm1[2 * ik];
-              x1[k][1] = sm1[2 * ik + 1];
-              x2[k][0] = sm2[2 * ik];
-              x2[k][1] = sm2[2 * ik + 1];
-            }
-            double F[3][9];
-            nm = cvs::run7point<64>(x1, x2, xw, F, [&](int i) { SP_STAMP(i); });
-#pragma unroll
-            for (int m = 0; m < 3; m++)
-              if (m < nm)
-#pragma unroll
-                for (int j = 0; j < 9; j++) Fm[lane * 3 + m][j] = F[m][j];
-          } else {
-            nm = -2;
-          }
+      // hypotheses of this batch: cv::run7Point (cv_solvers.hpp).  Four lanes per hypothesis, sixteen hypotheses per wave (the first batch is
+      // one wave's work): the one-sided Jacobi SVD of the 7 x 9 system lives in the hypothesis' LDS workspace and its rotations run on the
+      // anti-diagonals of two overlapping sweeps, three pairs at a time (cvs::sp_slot: the bits of the cyclic order, in a third of its
+      // steps -- a rotation is a chain of three divisions and three square roots, ~0.4 us); lane 0 of the four then completes the basis,
+      // solves the cubic and writes up to three matrices.
+      if (wv == 0) draw_batch(base, B, ctl[0], 10000, base == 0 && B == F_TAB_B && n < F_TAB_N);
+      __syncthreads();
+      if (16 * wv < B) {
+        const int q = lane & 3, hyp = 16 * wv + (lane >> 2);
+        const int iter = base + hyp;
+        int nm = -1;  // -1: beyond niters, -2: subset impossible (the reference loop stops)
+        bool have = false;
+        double* const xw = spw + hyp;  // element e of this hypothesis at xw[e * 64]
+        if (iter < ctl[0]) {
+          if (s_sub[hyp][7]) have = true;
+          else nm = -2;
         }
-        hnm[lane] = nm;
+#ifdef FLVIS_RANSAC_PROF
+        if (tid == 0) {
+          g_sp_prof = p.counters ? p.counters + 40 : nullptr;
+          g_sp_last = (long long)wall_clock64();
+        }
+#endif
+        if (have && q == 0) {
+          double x1[7][2], x2[7][2];
+#pragma unroll
+          for (int k = 0; k < 7; k++) {
+            const int ik = s_sub[hyp][k];
+            x1[k][0] = sm1[2 * ik];
+            x1[k][1] = sm1[2 * ik + 1];
+            x2[k][0] = sm2[2 * ik];
+            x2[k][1] = sm2[2 * ik + 1];
+          }
+          cvs::sp_fill<64>(x1, x2, xw);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SP_STAMP(0);
+        bool done = !have, chg_prev = false, chg_cur = false;
+        const int sh = lane & ~3;
+        for (int T = 1;; T++) {
+          const int s_hi = (T - 1) / 7, sigma = T - 7 * s_hi;
+          const cvs::SpSlot e = cvs::sp_slot(sigma, q);
+          const int sw = s_hi + e.ds;
+          bool rot = false;
+          if (!done && e.i >= 0 && sw >= 0 && sw < cvs::SVD_MAX_SWEEPS) rot = cvs::sp_pair<64>(xw, e.i, e.j);
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long bc = __ballot(rot && e.ds == 0), bp = __ballot(rot && e.ds != 0);
+          chg_cur = chg_cur || ((bc >> sh) & 0xFull) != 0;
+          chg_prev = chg_prev || ((bp >> sh) & 0xFull) != 0;
+          if (sigma == 4 && s_hi >= 1 && (!chg_prev || s_hi == cvs::SVD_MAX_SWEEPS)) done = true;  // sweep s_hi - 1: unchanged, or the last
+          if (sigma == 7) {
+            chg_prev = chg_cur;
+            chg_cur = false;
+          }
+          if (__ballot(!done) == 0ull) break;
+        }
+        if (have && q == 0) {
+          double F[3][9];
+          nm = cvs::sp_finish<64>(xw, F, [&](int i) { SP_STAMP(i); });
+#pragma unroll
+          for (int m = 0; m < 3; m++)
+            if (m < nm)
+#pragma unroll
+              for (int j = 0; j < 9; j++) Fm[hyp * 3 + m][j] = F[m][j];
+        }
+        if (q == 0) hnm[hyp] = nm;
       }
 #else
       // hypotheses of this batch, one per lane of wave 0.  The bisections of the cubic's (up to three) sign-change intervals are

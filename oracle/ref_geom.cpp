@@ -804,6 +804,29 @@ int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, doubl
       pw.push_back({(double)p3d[3 * i], (double)p3d[3 * i + 1], (double)p3d[3 * i + 2]});
       z.push_back({(double)p2d[2 * i], (double)p2d[2 * i + 1]});
     }
+#ifdef FLVIS_TAIL_CV
+  // `make -C oracle TAIL=cv` (libflvis_ref_cvtail.so): the final solve as cv::solvePnP(ITERATIVE, useExtrinsicGuess = false) runs it -- a DLT
+  // start and CvLevMarq on the inliers (cv_solvers.hpp: find_extrinsic_iterative), independent of the RANSAC's winning model.  Kept beside
+  // the default (Gauss-Newton from the winning model, what the kernels run) to measure the distance (tests/test_oracle_tracking.py).
+  {
+    const int ni = (int)pw.size();
+    std::vector<double> Mw(3 * (size_t)ni), mz(2 * (size_t)ni), work(24 * (size_t)ni + 64);
+    for (int i = 0; i < ni; i++) {
+      Mw[3 * i] = pw[i].x, Mw[3 * i + 1] = pw[i].y, Mw[3 * i + 2] = pw[i].z;
+      mz[2 * i] = z[i].x, mz[2 * i + 1] = z[i].y;
+    }
+    double rv[3], tv[3];
+    if (flvis::cvs::find_extrinsic_iterative(ni, Mw.data(), mz.data(), fx, fy, cx, cy, work.data(), rv, tv, nullptr)) {
+      double Rm[9];
+      flvis::cvs::rodrigues(rv, Rm, nullptr);
+      Mat3 R;
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R.m[i][j] = Rm[3 * i + j];
+      T = se3_from_mat(R, {tv[0], tv[1], tv[2]});
+      return maxGood;
+    }
+  }
+#endif
   pnp_refine(Tb, pw, z, fx, fy, cx, cy);
   // SE3_from_rvec_tvec: Rodrigues(rvec) -> R -> SE3(R,t)   (common.h:151-158)
   T = se3_from_mat(quat_to_mat(Tb.q), Tb.t);
@@ -1043,6 +1066,20 @@ int ref_cv_seven_point(const double* x1, const double* x2, double* F27) {
   memcpy(F27, F, sizeof(F));
   return n;
 }
+// the same solve in the kernel's schedule (anti-diagonals of two overlapping sweeps): must equal ref_cv_seven_point bit for bit
+int ref_cv_seven_point_scheduled(const double* x1, const double* x2, double* F27) {
+  double a[7][2], b[7][2], F[3][9], wk[flvis::cvs::SP_WORK];
+  for (int i = 0; i < 7; i++) {
+    a[i][0] = x1[2 * i];
+    a[i][1] = x1[2 * i + 1];
+    b[i][0] = x2[2 * i];
+    b[i][1] = x2[2 * i + 1];
+  }
+  memset(F, 0, sizeof(F));
+  const int n = flvis::cvs::run7point_scheduled<1>(a, b, wk, F, [](int) {});
+  memcpy(F27, F, sizeof(F));
+  return n;
+}
 int ref_cv_solve_cubic(const double* c4, double* r3) { return flvis::cvs::solve_cubic(c4, r3); }
 int ref_cv_solve_deg4(const double* c5, double* r4) {
   r4[0] = r4[1] = r4[2] = r4[3] = 0;
@@ -1062,6 +1099,16 @@ int ref_cv_p3p(const double* K4, const double* uv6, const double* X9, double* R3
   }
   return n;
 }
+// cvFindExtrinsicCameraParams2 without a guess (cv_solvers.hpp): pose from n >= 6 non-planar correspondences; returns the LM iterations (0: refused)
+int ref_cv_find_extrinsic(int n, const double* M, const double* m, const double* K4, double* rvec3, double* tvec3) {
+  std::vector<double> work(24 * (size_t)n + 64);
+  int it = 0;
+  if (!flvis::cvs::find_extrinsic_iterative(n, M, m, K4[0], K4[1], K4[2], K4[3], work.data(), rvec3, tvec3, &it)) return 0;
+  return it;
+}
+void ref_cv_rodrigues(const double* r3, double* R9, double* J27) { flvis::cvs::rodrigues(r3, R9, J27); }
+void ref_cv_rodrigues_inv(const double* R9, double* r3) { flvis::cvs::rodrigues_inv(R9, r3); }
+void ref_cv_svd_square(const double* A, int n, double* w, double* u, double* vt) { flvis::cvs::svd_square(A, n, w, u, vt); }
 int ref_cv_jacobi4(const double* A16, double* D4, double* U16) {
   double A[16];
   memcpy(A, A16, sizeof(A));

@@ -31,8 +31,9 @@ def use_sum_order(order):
     edge / point-by-point order).  Objects created under one build must not be used under the other."""
     global _LIB
     lib()                                             # (builds both libraries when stale)
-    name = {"product": "libflvis_ref.so", "g2o": "libflvis_ref_g2o.so"}[order]
-    _LIB = C.CDLL(os.path.join(ROOT, "oracle", name))
+    name = {"product": "libflvis_ref.so", "g2o": "libflvis_ref_g2o.so", "solvers_product": "libflvis_ref_prod.so",
+            "tail_cv": "libflvis_ref_cvtail.so"}[order]
+    _LIB = C.CDLL(os.path.join(ROOT, "oracle", name))     # ("solvers_product": `make -C oracle SOLVERS=product`, the minimal solvers of rounds 1-5)
     assert _LIB.ref_sum_order() == (1 if order == "g2o" else 0)
 
 

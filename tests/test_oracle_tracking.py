@@ -350,11 +350,16 @@ def test_chunk_sums_against_the_reference_order():
             (synth.KITTI_LIKE_YAML, "kitti", synth.kitti_like_rig(), 5, 16, None, False)]
     runs = {}
     try:
-        for order in ("product", "g2o"):
+        for order in ("product", "g2o", "solvers_product"):
             O.use_sum_order(order)
             runs[order] = [_lockstep_sequence(*s) for s in seqs]
     finally:
         O.use_sum_order("product")
+    # Round 6: the minimal solvers inside the two RANSACs follow OpenCV's published algorithms by default (cv_solvers.hpp); `make -C oracle
+    # SOLVERS=product` keeps the product-defined ones of rounds 1-5.  Only their inlier masks reach the rest of the frame (and, for the P3P
+    # flag, EPnP on those inliers): on the four sequences every discrete output AND every pose is identical, bit for bit.
+    for (da, pa), (db, pb), s in zip(runs["product"], runs["solvers_product"], seqs):
+        assert da == db and np.array_equal(pa, pb), s[1]
     early = late = 0.0
     for (da, pa), (db, pb), s in zip(runs["product"], runs["g2o"], seqs):
         tracked = [f for f, d in enumerate(da) if d[0] == 1]
