@@ -236,31 +236,43 @@ CVS_FN int sp_finish(double* wk, double (*F)[9], Stamp&& stamp) {
   uint64_t rng = 0x12345678ull;
   for (int i = 0; i < 9; i++) {
     double sd = i < 7 ? CVS_W(i) : 0;
+    double row[9];  // (row i stays in registers while it is built: the same operations, without a round trip through the workspace per step)
+    CVS_UNROLL
+    for (int k = 0; k < 9; k++) row[k] = CVS_A(i, k);
     for (int ii = 0; ii < 100 && sd <= DBL_MIN; ii++) {
       const double val0 = 1. / 9;
-      for (int k = 0; k < 9; k++) CVS_A(i, k) = (rng_next(rng) & 256) != 0 ? val0 : -val0;
+      CVS_UNROLL
+      for (int k = 0; k < 9; k++) row[k] = (rng_next(rng) & 256) != 0 ? val0 : -val0;
       for (int it = 0; it < 2; it++)
         for (int j = 0; j < i; j++) {
+          double rj[9];
+          CVS_UNROLL
+          for (int k = 0; k < 9; k++) rj[k] = CVS_A(j, k);
           sd = 0;
-          for (int k = 0; k < 9; k++) sd += CVS_A(i, k) * CVS_A(j, k);
+          CVS_UNROLL
+          for (int k = 0; k < 9; k++) sd += row[k] * rj[k];
           double asum = 0;
+          CVS_UNROLL
           for (int k = 0; k < 9; k++) {
-            const double t = CVS_A(i, k) - sd * CVS_A(j, k);
-            CVS_A(i, k) = t;
+            const double t = row[k] - sd * rj[k];
+            row[k] = t;
             asum += fabs(t);
           }
           asum = asum > eps * 100 ? 1 / asum : 0;
-          for (int k = 0; k < 9; k++) CVS_A(i, k) *= asum;
+          CVS_UNROLL
+          for (int k = 0; k < 9; k++) row[k] *= asum;
         }
       sd = 0;
+      CVS_UNROLL
       for (int k = 0; k < 9; k++) {
-        const double t = CVS_A(i, k);
+        const double t = row[k];
         sd += t * t;
       }
       sd = sqrt(sd);
     }
     const double s = sd > DBL_MIN ? 1 / sd : 0.;
-    for (int k = 0; k < 9; k++) CVS_A(i, k) *= s;
+    CVS_UNROLL
+    for (int k = 0; k < 9; k++) CVS_A(i, k) = row[k] * s;
   }
   stamp(2);
   // f1, f2: a basis of the null space; f ~ lambda f1 + (1 - lambda) f2; det(f) = 0 is a cubic in lambda

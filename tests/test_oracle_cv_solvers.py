@@ -198,3 +198,78 @@ def test_distance_to_the_product_defined_solvers_on_noisy_sets():
             cnt = lib.ref_solve_pnp_ransac(p3.ctypes.data, p2.ctypes.data, n, k4.ctypes.data, 0, 100, 3.0, 0.99, 0, pose.ctypes.data, m.ctypes.data)
             res.append((cnt, m, pose))
         assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_scheduled_sweeps_equal_the_cyclic_order_bit_for_bit():
+    """k_ransac_f runs the Jacobi sweeps of run7Point's SVD on the anti-diagonals of two overlapping sweeps, three pairs at a time
+    (cv_solvers.hpp: sp_slot); pairs that share no row commute exactly and conflicting pairs keep their order, so the matrices must have
+    the bits of OpenCV's cyclic order -- also for degenerate samples (repeated points, integer coordinates)."""
+    L = O.lib()
+    rng = np.random.default_rng(11)
+    for t in range(4000):
+        if t % 4 == 0:
+            x1 = np.round(rng.uniform(0, 640, (7, 2)))
+            x2 = x1 + np.round(rng.normal(size=(7, 2)) * 2)
+            if t % 8 == 0:
+                x1[3], x2[3] = x1[2], x2[2]
+        else:
+            x1 = rng.uniform(0, 640, (7, 2)).astype(np.float32).astype(np.float64)
+            x2 = (x1 + rng.normal(size=(7, 2)) * 5).astype(np.float32).astype(np.float64)
+        fa, fb = np.zeros(27), np.zeros(27)
+        na = L.ref_cv_seven_point(_d(x1), _d(x2), _d(fa))
+        nb = L.ref_cv_seven_point_scheduled(_d(x1), _d(x2), _d(fb))
+        assert na == nb and fa.tobytes() == fb.tobytes()
+
+
+def test_rodrigues_and_svd_against_scipy():
+    from scipy.spatial.transform import Rotation as Rot
+    L = O.lib()
+    rng = np.random.default_rng(12)
+    for _ in range(200):
+        r = rng.normal(size=3)
+        r *= rng.uniform(0.001, 3.1) / np.linalg.norm(r)
+        rm, jac, r2 = np.zeros(9), np.zeros(27), np.zeros(3)
+        L.ref_cv_rodrigues(_d(r), _d(rm), _d(jac))
+        assert np.abs(rm.reshape(3, 3) - Rot.from_rotvec(r).as_matrix()).max() <= 1e-14
+        L.ref_cv_rodrigues_inv(_d(rm), _d(r2))
+        assert np.abs(r - r2).max() <= 1e-8
+        for i in range(3):   # dR/dr_i against central differences
+            dr = np.zeros(3)
+            dr[i] = 1e-6
+            num = (Rot.from_rotvec(r + dr).as_matrix() - Rot.from_rotvec(r - dr).as_matrix()).ravel() / 2e-6
+            assert np.abs(num - jac[9 * i:9 * i + 9]).max() <= 1e-6
+    for n in (3, 6, 12):
+        for _ in range(20):
+            a = rng.normal(size=(n, n))
+            w, u, vt = np.zeros(n), np.zeros(n * n), np.zeros(n * n)
+            L.ref_cv_svd_square(_d(a), n, _d(w), _d(u), _d(vt))
+            assert np.abs(u.reshape(n, n) @ np.diag(w) @ vt.reshape(n, n) - a).max() <= 1e-12
+            assert np.abs(w - np.linalg.svd(a)[1]).max() <= 1e-12 and np.all(np.diff(w) <= 0)
+
+
+def test_iterative_tail_reaches_the_least_squares_minimum():
+    """cvFindExtrinsicCameraParams2 without a guess (DLT start, CvLevMarq, at most 20 iterations, FLT_EPSILON): lands within 1e-8 of the
+    minimum scipy finds from its result, in 3 .. 6 iterations, on 8 .. 250 noisy correspondences; a planar set is refused (OpenCV starts
+    from a homography there, not restated)."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation as Rot
+    L = O.lib()
+    rng = np.random.default_rng(13)
+    k4 = np.array([FX, FY, CX, CY])
+    for _ in range(60):
+        n = int(rng.integers(8, 250))
+        r, t = rng.normal(size=3) * 0.4, rng.normal(size=3) * 0.5 + np.array([0, 0, 0.5])
+        xc = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(2, 8, n)], 1)
+        xw = (Rot.from_rotvec(r).as_matrix().T @ (xc - t).T).T.astype(np.float32).astype(np.float64)
+        uv = ((xc / xc[:, 2:3])[:, :2] * [FX, FY] + [CX, CY] + rng.normal(size=(n, 2)) * 0.5).astype(np.float32).astype(np.float64)
+        rv, tv = np.zeros(3), np.zeros(3)
+        it = L.ref_cv_find_extrinsic(n, _d(xw), _d(uv), _d(k4), _d(rv), _d(tv))
+        assert 1 <= it <= 8
+
+        def res(p):
+            xp = (Rot.from_rotvec(p[:3]).as_matrix() @ xw.T).T + p[3:]
+            return ((xp / xp[:, 2:3])[:, :2] * [FX, FY] + [CX, CY] - uv).ravel()
+        sol = least_squares(res, np.r_[rv, tv], xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        assert np.abs(sol.x - np.r_[rv, tv]).max() <= 1e-8
+    flat = np.c_[rng.uniform(-2, 2, (40, 2)), np.zeros(40)]
+    assert L.ref_cv_find_extrinsic(40, _d(flat), _d(rng.uniform(0, 600, (40, 2))), _d(k4), _d(np.zeros(3)), _d(np.zeros(3))) == 0

@@ -350,7 +350,7 @@ def test_chunk_sums_against_the_reference_order():
             (synth.KITTI_LIKE_YAML, "kitti", synth.kitti_like_rig(), 5, 16, None, False)]
     runs = {}
     try:
-        for order in ("product", "g2o", "solvers_product"):
+        for order in ("product", "g2o", "solvers_product", "tail_cv"):
             O.use_sum_order(order)
             runs[order] = [_lockstep_sequence(*s) for s in seqs]
     finally:
@@ -360,6 +360,25 @@ def test_chunk_sums_against_the_reference_order():
     # flag, EPnP on those inliers): on the four sequences every discrete output AND every pose is identical, bit for bit.
     for (da, pa), (db, pb), s in zip(runs["product"], runs["solvers_product"], seqs):
         assert da == db and np.array_equal(pa, pb), s[1]
+    # ... and `make -C oracle TAIL=cv` the final solve of solvePnPRansac(ITERATIVE) as OpenCV runs it: a DLT start and CvLevMarq on the inliers
+    # (stops when the parameters change by less than FLT_EPSILON, relative) instead of the Gauss-Newton refinement of the RANSAC's winning
+    # model that the kernels and the default checker share.  Both reach the same minimum; CvLevMarq stops ~1e-9 short of it.  Measured: the
+    # first five tracked frames identical in every discrete output, poses within 4.4e-9; over the whole sequences the same states and keyframe
+    # decisions in every frame, then the front-end's amplification: 2.4e-4 (D435 stream, 30 frames), 3.3e-4 (EuRoC-like, one landmark of
+    # 440 differs from frame 15 on, nine by the end), 8.4e-5 (depth camera); the KITTI-like rig (P3P flag, no iterative tail): identical.
+    t_early = t_late = 0.0
+    for (da, pa), (db, pb), s in zip(runs["product"], runs["tail_cv"], seqs):
+        tracked = [f for f, d in enumerate(da) if d[0] == 1]
+        head = tracked[:5]
+        assert [da[f] for f in head] == [db[f] for f in head], s[1]
+        t_early = max(t_early, float(np.abs(pa[head] - pb[head]).max()))
+        assert [d[:2] for d in da] == [d[:2] for d in db], s[1]
+        assert max(abs(x[2] - y[2]) for x, y in zip(da, db)) <= 16, s[1]
+        t_late = max(t_late, float(np.abs(pa - pb).max()))
+        if s[1] == "kitti":
+            assert da == db and np.array_equal(pa, pb)
+    assert 0.0 < t_early <= 1e-7, t_early
+    assert t_late <= 2e-3, t_late
     early = late = 0.0
     for (da, pa), (db, pb), s in zip(runs["product"], runs["g2o"], seqs):
         tracked = [f for f, d in enumerate(da) if d[0] == 1]
