@@ -38,6 +38,41 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 #ifndef FLVIS_CHAIN_PRIO
 #define FLVIS_CHAIN_PRIO 0
 #endif
+// folded joins (KJoin, track_kernels.hpp).  kj_wait: thread 0 sleeps until the words have reached their numbers (system-scope loads: never
+// a cached line), the workgroup follows it through the barrier; gives up after ~4 s like k_wait_flag.  kj_signal: behind the workgroup's
+// last store -- barrier, one agent-scope release by thread 0, one arrival; the last arrival stores the number (release) and resets the counter.
+template <typename KJ>
+__device__ __forceinline__ void kj_wait(const KJ& kj) {
+  if (!kj.wait[0] && !kj.wait[1]) return;
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    const unsigned long long t0 = wall_clock64();
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      if (!kj.wait[k]) continue;
+      while (__hip_atomic_load(kj.wait[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < kj.wait_seq[k]) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 400000000ull) break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+template <typename KJ>
+__device__ __forceinline__ void kj_signal(const KJ& kj) {
+  if (!kj.sig) return;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+    if (atomicAdd(kj.sig_cnt, 1u) == nb - 1u) {
+      __hip_atomic_store(kj.sig_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the other workgroups' releases, before the word says they are done)
+      __hip_atomic_store(kj.sig, kj.sig_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 __device__ __forceinline__ void chain_priority() {
   if (FLVIS_CHAIN_PRIO > 0) __builtin_amdgcn_s_setprio(FLVIS_CHAIN_PRIO);
 }

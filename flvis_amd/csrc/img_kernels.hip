@@ -982,7 +982,7 @@ struct LaneArray {
   __device__ __forceinline__ bool before(int a, int b) const { return (a >> 16) < (b >> 16); }
 };
 
-__global__ __launch_bounds__(DEMP_T) void k_feature_dem_prep(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
+__device__ __forceinline__ void k_feature_dem_prep_body(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
                                                             const float* __restrict__ corners, const int* __restrict__ ncorners,
                                                             int corner_cap, const int* __restrict__ active, float* __restrict__ sorted_xy,
                                                             int* __restrict__ region_off) {
@@ -1108,8 +1108,16 @@ __global__ __launch_bounds__(DEMP_T) void k_feature_dem_prep(ImgSel src, int w, 
   }
   if (tid < 17) region_off[(size_t)s * 17 + tid] = roff[tid];
 }
+__global__ __launch_bounds__(DEMP_T) void k_feature_dem_prep(ImgSel src, int w, int h, int pitch, size_t sstride, DemParams prm,
+                                                            const float* __restrict__ corners, const int* __restrict__ ncorners,
+                                                            int corner_cap, const int* __restrict__ active, float* __restrict__ sorted_xy,
+                                                            int* __restrict__ region_off, KJoin kj) {
+  kj_wait(kj);
+  k_feature_dem_prep_body(src, w, h, pitch, sstride, prm, corners, ncorners, corner_cap, active, sorted_xy, region_off);
+  kj_signal(kj);
+}
 
-__global__ __launch_bounds__(DEM_T) void k_feature_dem(int w, int h, DemParams prm, const float* __restrict__ sorted_xy,
+__device__ __forceinline__ void k_feature_dem_body(int w, int h, DemParams prm, const float* __restrict__ sorted_xy,
                                                        const int* __restrict__ region_off, int corner_cap, const int* __restrict__ mode,
                                                        const double* __restrict__ exist_xy, const int* __restrict__ nexist,
                                                        int exist_cap, float* __restrict__ out_xy, int* __restrict__ out_n,
@@ -1245,6 +1253,15 @@ __global__ __launch_bounds__(DEM_T) void k_feature_dem(int w, int h, DemParams p
     }
   }
 }
+__global__ __launch_bounds__(DEM_T) void k_feature_dem(int w, int h, DemParams prm, const float* __restrict__ sorted_xy,
+                                                       const int* __restrict__ region_off, int corner_cap, const int* __restrict__ mode,
+                                                       const double* __restrict__ exist_xy, const int* __restrict__ nexist,
+                                                       int exist_cap, float* __restrict__ out_xy, int* __restrict__ out_n,
+                                                       int out_cap, KJoin kj) {
+  kj_wait(kj);
+  k_feature_dem_body(w, h, prm, sorted_xy, region_off, corner_cap, mode, exist_xy, nexist, exist_cap, out_xy, out_n, out_cap);
+  kj_signal(kj);
+}
 
 // ------------------------------------------------------------------------------------------------ launchers
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
@@ -1357,17 +1374,17 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
 
 void launch_feature_dem_prep(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
                              const float* corners, const int* ncorners, int corner_cap, const int* active, float* sorted_xy,
-                             int* region_off) {
+                             int* region_off, const KJoin* kj) {
   const int cmax = ((corner_cap < DEM_MAXC ? corner_cap : DEM_MAXC) + 1) & ~1;
   hipLaunchKernelGGL(k_feature_dem_prep, dim3(S), dim3(DEMP_T), (size_t)cmax * 20, st, src, w, h, pitch, sstride, prm, corners, ncorners,
-                     corner_cap, active, sorted_xy, region_off);
+                     corner_cap, active, sorted_xy, region_off, kj ? *kj : KJoin{});
 }
 void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, const float* sorted_xy, const int* region_off,
                         int corner_cap, const int* mode, const double* exist_xy, const int* nexist, int exist_cap, float* out_xy,
-                        int* out_n, int out_cap) {
+                        int* out_n, int out_cap, const KJoin* kj) {
   const int cmax = ((corner_cap < DEM_MAXC ? corner_cap : DEM_MAXC) + 1) & ~1;
   hipLaunchKernelGGL(k_feature_dem, dim3(S), dim3(DEM_T), (size_t)cmax * 8, st, w, h, prm, sorted_xy, region_off, corner_cap, mode,
-                     exist_xy, nexist, exist_cap, out_xy, out_n, out_cap);
+                     exist_xy, nexist, exist_cap, out_xy, out_n, out_cap, kj ? *kj : KJoin{});
 }
 
 hipError_t img_kernels_init() {

@@ -5,6 +5,19 @@
 
 namespace flvis {
 
+// Joins folded into a launch (round 6, pipeline.cpp: FLVIS_JOIN_FOLD): the kernel's workgroups wait for up to two device words before their
+// first instruction that needs another stream's results (only kernels of one workgroup per stream do: 64 sleeping lanes cannot keep a
+// producer off the chip), and the last workgroup to finish stores a sequence number for the streams that wait for this kernel -- instead
+// of a k_wait_flag / k_store_flag launch (~5 us each on the frame's chain) in front of / behind it.
+struct KJoin {
+  const long long* wait[2];
+  long long wait_seq[2];
+  long long* sig;
+  long long sig_seq;
+  unsigned* sig_cnt;  // arrival counter of the signalling launch's workgroups (the last one puts it back to 0)
+};
+
+
 // Selects, per stream, one of two image slots (frame ping-pong: reference F2FTracking swaps last_frame/curr_frame,
 // src/frontend/f2f_tracking.cpp:70; the swap is per stream here because streams fail/recover independently).
 struct ImgSel {
@@ -122,10 +135,11 @@ void launch_sqrt_check(hipStream_t st, unsigned first_bits, unsigned n, unsigned
 // [S][corner_cap][2], region_off [S][17]; then the part that needs the existing landmarks (fill, greedy spacing, output)
 void launch_feature_dem_prep(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sstride, int S, DemParams prm,
                              const float* corners, const int* ncorners, int corner_cap, const int* active, float* sorted_xy,
-                             int* region_off);
+                             int* region_off, const KJoin* kj = nullptr);
+// (kj, may be null: joins folded into the launch -- k_feature_dem waits, k_feature_dem_prep signals)
 void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, const float* sorted_xy, const int* region_off,
                         int corner_cap, const int* mode, const double* exist_xy, const int* nexist, int exist_cap, float* out_xy,
-                        int* out_n, int out_cap);
+                        int* out_n, int out_cap, const KJoin* kj = nullptr);
 // pyramidal LK, 31x31 window: one wave per (stream, point)
 // max_pts: upper bound of count[] known to the caller (sizes the grid; any value is correct, the kernel strides), <= 0: nmax
 // role: 0 stand-alone call, 1 the tracker's temporal launch, 2 its stereo launch (kernel instances k_lk_track<role>: named apart in

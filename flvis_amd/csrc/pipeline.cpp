@@ -83,6 +83,8 @@ struct Lane {
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
   hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_lm = nullptr, ev_tri = nullptr, ev_head = nullptr;
+  hipEvent_t ev_endf = nullptr;  // "k_frame_end has finished": the next frame's ingest and an immediate local-map launch wait for it (folded joins)
+  bool endf_valid = false;       // the last k_frame_end carried that signal
   int idx = 0;  // position in Pipeline::lanes
   // multi-lane trackers: ev_end[n % HOLD_RING] follows the lane's n-th frame (the context's stream waits for the frame whose
   // input buffers the caller may reuse next, see flvis_set_input_hold); ev_stagger follows the temporal LK of the lane's first
@@ -100,6 +102,7 @@ struct Lane {
   // (and slows the queues beside it, profiles/r06_h2d.md); a word in HBM costs two one-lane launches.
   static constexpr int JOIN_IDS = 8 + BAQ;
   long long* d_join = nullptr;             // [JOIN_IDS] words, 64 bytes apart
+  unsigned* d_join_cnt = nullptr;          // [JOIN_IDS] arrival counters of the launches that signal a word themselves (KJoin)
   long long join_seq[JOIN_IDS] = {};
   long long ba_launches = 0;
   bool ba_pending = false;       // FLVIS_BA_START > 0: the local-map launch for the last frame's keyframes has not been enqueued yet
@@ -177,6 +180,7 @@ struct Pipeline {
   long long up_seq = 0;
   unsigned ev_flags = hipEventDisableTiming;  // flags of every event of the pipeline (FLVIS_EVENT_SCOPE)
   bool flag_joins = false;                    // FLVIS_JOIN=flag
+  bool fold_joins = false;                    // FLVIS_JOIN_FOLD: the chain's own kernels wait for / store the words (KJoin)
   Lane& lane_of(int stream, int& local) {
     const int k = stream / lane_size;
     local = stream - k * lane_size;
@@ -292,7 +296,7 @@ static void lane_destroy(Lane* L) {
     hipStreamDestroy(L->det_stream);
   }
   if (L->own_st && L->st) hipStreamDestroy(L->st);
-  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_head, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
+  for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_head, L->ev_endf, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
                        L->ev_end[4], L->ev_end[5], L->ev_end[6], L->ev_end[7]})
     if (e) hipEventDestroy(e);
   for (int k = 0; k < Lane::BAQ; k++)
@@ -524,6 +528,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   ok = ok && ((L->eq_hist = dalloc<unsigned>(L->allocs, (size_t)S * 256)) != nullptr);
   ok = ok && ((L->eq_lut = dalloc<uint8_t>(L->allocs, (size_t)S * 256)) != nullptr);
   ok = ok && ((L->d_join = dalloc<long long>(L->allocs, (size_t)Lane::JOIN_IDS * 8)) != nullptr);
+  ok = ok && ((L->d_join_cnt = dalloc<unsigned>(L->allocs, (size_t)Lane::JOIN_IDS)) != nullptr);
   if (!ok) return false;
   // initial per-stream state (F2FTracking::init, VIMOTION ctor, landmark id counter 100, glibc rand seed 1)
   std::vector<StreamState> hs(S);
@@ -587,8 +592,8 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   } else {
     evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
   }
-  static_assert(Lane::HOLD_RING == 8, "event list below");
-  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
+  static_assert(Lane::HOLD_RING == 8, "event list below");  // (ev_endf included)
+  for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_endf, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
                         &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
     evok = evok && hipEventCreateWithFlags(e, pl->ev_flags) == hipSuccess;
   for (int k = 0; k < Lane::BAQ && evok; k++)
@@ -621,7 +626,9 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     const char* e = getenv("FLVIS_EVENT_SCOPE");
     if (e && !strcmp(e, "agent")) pl->ev_flags |= hipEventReleaseToDevice;
     const char* j = getenv("FLVIS_JOIN");
-    pl->flag_joins = !(j && !strcmp(j, "event"));  // (default since round 6: 58.6k -> 60.4k frames/s, chain p50 1.047 -> 1.012 ms; "event": rounds 1-5)
+    pl->flag_joins = !(j && !strcmp(j, "event"));
+    const char* f = getenv("FLVIS_JOIN_FOLD");
+    pl->fold_joins = pl->flag_joins && !(f && atoi(f) == 0);  // (default since round 6: 58.6k -> 60.4k frames/s, chain p50 1.047 -> 1.012 ms; "event": rounds 1-5)
   }
   const int S = n_streams;
   pl->S = S;
@@ -921,6 +928,7 @@ static int join_id(const Lane* L, hipEvent_t ev) {
   if (ev == L->ev_lm) return 4;
   if (ev == L->ev_tri) return 5;
   if (ev == L->ev_head) return 6;
+  if (ev == L->ev_endf) return 7;
   for (int k = 0; k < Lane::BAQ; k++)
     if (ev == L->ev_ba_done[k]) return 8 + k;
   return -1;
@@ -941,6 +949,23 @@ static void join_wait(Pipeline* pl, Lane* L, hipStream_t s, hipEvent_t ev) {
     return;
   }
   launch_wait_flag(s, L->d_join + 8 * id, 1, L->join_seq[id], L->d_progress + 2);
+}
+
+// folded forms (KJoin): the NEXT launch that is handed `kj` stores the word behind its last workgroup / waits for it in front of its first
+static bool fold_signal(Pipeline* pl, Lane* L, hipEvent_t ev, KJoin& kj) {
+  const int id = pl->fold_joins ? join_id(L, ev) : -1;
+  if (id < 0) return false;
+  kj.sig = L->d_join + 8 * id;
+  kj.sig_seq = ++L->join_seq[id];
+  kj.sig_cnt = L->d_join_cnt + id;
+  return true;
+}
+static bool fold_wait(Pipeline* pl, Lane* L, hipEvent_t ev, KJoin& kj, int slot) {
+  const int id = pl->fold_joins ? join_id(L, ev) : -1;
+  if (id < 0) return false;
+  kj.wait[slot] = L->d_join + 8 * id;
+  kj.wait_seq[slot] = L->join_seq[id];
+  return true;
 }
 
 static void launch_local_map(Pipeline* pl, Lane* L, hipEvent_t ev, bool record, hipEvent_t* prof_begin_end) {
@@ -1095,8 +1120,14 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     // Without equalizeHist the first pyrDown reads the caller's image and writes level 0 and level 1 in one pass; with it the
     // equalised image is level 0.
     ImgSel l0in{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot_in, 0, nullptr};
-    join_signal(pl, L, L->ev_lm, st);  // (the frame's input table has been uploaded)
-    join_wait(pl, L, ds, L->ev_lm);
+    // what the detection stream needs from the main one here is k_frame_end of the previous frame (the slot the image goes to) and, in
+    // the copying mode, the upload of the input table: a signal of its own -- or, folded, the word the last k_frame_end stored itself
+    if (pl->fold_joins && zerocopy && L->endf_valid) {
+      join_wait(pl, L, ds, L->ev_endf);
+    } else {
+      join_signal(pl, L, L->ev_lm, st);  // (the frame's input table has been uploaded)
+      join_wait(pl, L, ds, L->ev_lm);
+    }
     // host images (flvis_image_feed_host, FLVIS_H2D_WAIT=1): the upload's event is waited for by the stream that ingests the left image; the
     // main stream only sees the joins it has anyway (left pyramid in front of the temporal LK, right pyramid in front of the stereo LK)
     if (pl->up_event) hipStreamWaitEvent(ds, pl->up_event, 0);
@@ -1121,19 +1152,23 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // inputs in the same launch (FLVIS_HEAD_PREPARE=0, A/B knob: two launches)
   static const bool head_prepare_knob = !(getenv("FLVIS_HEAD_PREPARE") && atoi(getenv("FLVIS_HEAD_PREPARE")) == 0);
   const bool head_prepare = head_prepare_knob && !pl->feedback_used && !skipped;
+  const bool head_signals = !pl->feedback_used && fold_signal(pl, L, L->ev_head, p.kj);  // (the head kernel is the last one in front of the signal)
   if (head_prepare) launch_frame_head_prepare(s_head, p, L->d_time, L->d_progress, frame_no);
   else launch_frame_head(s_head, p, L->d_time, L->d_progress, frame_no);
+  p.kj = KJoin{};
   if (pl->feedback_used) launch_apply_correction(s_head, p);  // STEP1 of the Tracking case (local-map feedback, opt-in)
   PE(0, s_head);
   // the detection stream's kernels that read what k_frame_head decides (act_img, gftt_act, gftt_maxc, img_slot) wait for this event:
   // the corner detection and the right pyramid in every FLVIS_DET_START mode (in the default mode they start behind the F-RANSAC anyway)
-  join_signal(pl, L, L->ev_head, s_head);
+  if (!head_signals) join_signal(pl, L, L->ev_head, s_head);
   if (head_on_det) join_wait(pl, L, st, L->ev_head);  // join: the head (the left pyramid is on this stream)
   if (skipped) {
     // the reference drops the first skip_first_n_imgs frames before any processing (vo_tracking.cpp image callback): every
     // stream is idle for this frame, so only the IMU filter, the frame counter and the per-frame outputs are advanced
     PB(17, st);
+    L->endf_valid = fold_signal(pl, L, L->ev_endf, p.kj);
     launch_frame_end(st, p);
+    p.kj = KJoin{};
     PE(17, st);
     PE(19, st);
     if (prof)
@@ -1180,9 +1215,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
                 (double)p.cam.gftt_dis, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num, p.gftt_act,
                 (prof && ((pl->prof_mask >> 10) & 7ull) == 7ull) ? &pev[2 * 10] : nullptr, false);
     // FeatureDEM's image part (regions, Harris scores, per-region order of the corners) follows at once, off the critical path
+    KJoin prep_kj{};
+    const bool prep_signals = fold_signal(pl, L, L->ev_gftt, prep_kj);
     launch_feature_dem_prep(ds, l0cur, w, h, pl->lpitch[0], pl->lstride[0], S, p.cam.dem, L->gftt_xy, L->gftt_n, 2 * p.cam.gftt_num,
-                            p.gftt_act, L->dem_sorted, L->dem_roff);
-    join_signal(pl, L, L->ev_gftt, ds);
+                            p.gftt_act, L->dem_sorted, L->dem_roff, &prep_kj);
+    if (!prep_signals) join_signal(pl, L, L->ev_gftt, ds);
   };
   if (gftt_first && !gftt_after_lk) detect_corners();
   auto right_pyramid_on = [&](hipStream_t ds, bool on_main) {  // (ds: the stream it runs on -- the detection stream, or the main one)
@@ -1252,46 +1289,58 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(5, st);
   if (first_processed && pl->lanes.size() > 1) hipEventRecord(L->ev_stagger, st);
   PB(6, st);
+  const bool rf_signals = gftt_first && gftt_after_lk >= 2 && fold_signal(pl, L, L->ev_lm, p.kj);
   launch_ransac_f(st, p);
+  p.kj = KJoin{};
   PE(6, st);
   if (gftt_first && gftt_after_lk >= 2) {
-    join_signal(pl, L, L->ev_lm, st);
+    if (!rf_signals) join_signal(pl, L, L->ev_lm, st);
     join_wait(pl, L, ds, L->ev_lm);
     detect_corners();
     if (pyramid_late) right_pyramid();
     if (ba_start == 1 && L->ba_pending) launch_local_map(pl, L, L->ev_lm, false, prof18);
   }
   PB(7, st);
+  const bool ba_here = ba_start == 2 && L->ba_pending;
+  const bool pnp_signals = ba_here && fold_signal(pl, L, L->ev_fe, p.kj);  // (the deferred local-map launch starts behind this kernel)
   launch_ransac_pnp(st, p);
+  p.kj = KJoin{};
   PE(7, st);
-  if (ba_start == 2 && L->ba_pending) launch_local_map(pl, L, L->ev_fe, true, prof18);
+  if (ba_here) launch_local_map(pl, L, L->ev_fe, !pnp_signals, prof18);
   PB(8, st);
   launch_pose_lm(st, p);  // (with k_track_post's work in its prologue)
   PE(8, st);
   PB(9, st);
+  const bool rp_signals = !pyramid_main && fold_signal(pl, L, L->ev_lm, p.kj);
   launch_reproj_filter(st, p);
+  p.kj = KJoin{};
   PE(9, st);
   if (pyramid_main) right_pyramid_on(st, true);
   // the IMU filter's correction from this frame's pose: on the detection stream (joined with the triangulation before the depth innovation)
-  join_signal(pl, L, L->ev_lm, st);
+  if (!rp_signals) join_signal(pl, L, L->ev_lm, st);
   join_wait(pl, L, ds, L->ev_lm);
   launch_vi_correction(ds, p);
   // join: FeatureDEM (init: detect, tracking: redetect) consumes the corners; the right pyramid is joined before the stereo LK
-  join_wait(pl, L, st, gftt_first ? L->ev_gftt : L->ev_det);
+  KJoin dem_kj{};
+  if (!fold_wait(pl, L, gftt_first ? L->ev_gftt : L->ev_det, dem_kj, 0)) join_wait(pl, L, st, gftt_first ? L->ev_gftt : L->ev_det);
   PB(13, st);
   launch_feature_dem(st, w, h, S, p.cam.dem, L->dem_sorted, L->dem_roff, 2 * p.cam.gftt_num, p.det_mode, p.exist_xy, p.n_exist, NMAX,
-                     p.new_xy, p.n_new, NEW_MAX);
+                     p.new_xy, p.n_new, NEW_MAX, &dem_kj);
   launch_add_new(st, p);
   PE(13, st);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
   PB(14, st);
+  const bool ds_signals = fold_signal(pl, L, L->ev_lm, p.kj);
   launch_depth_seeds(st, p);
+  p.kj = KJoin{};
   PE(14, st);
   // the two-view triangulation that k_depth_innovate consumes: on the detection stream (idle by now), under the stereo LK
-  join_signal(pl, L, L->ev_lm, st);
+  if (!ds_signals) join_signal(pl, L, L->ev_lm, st);
   join_wait(pl, L, ds, L->ev_lm);
+  const bool tri_signals = fold_signal(pl, L, L->ev_tri, p.kj);
   launch_depth_triangulate(ds, p);
-  join_signal(pl, L, L->ev_tri, ds);
+  p.kj = KJoin{};
+  if (!tri_signals) join_signal(pl, L, L->ev_tri, ds);
   if (gftt_first && !pyramid_main) join_wait(pl, L, st, L->ev_det);
   PB(15, st);
   if (!depth_cam) {
@@ -1315,9 +1364,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts, 2);
   }
   PE(15, st);
-  join_wait(pl, L, st, L->ev_tri);
+  const bool inn_waits = fold_wait(pl, L, L->ev_tri, p.kj, 0);
+  if (!inn_waits) join_wait(pl, L, st, L->ev_tri);
   PB(16, st);
   launch_depth_innovate(st, p);
+  p.kj = KJoin{};
   PE(16, st);
   if (with_local_map) {
     // Keyframe-queue back-pressure, expressed in stream order (never by spinning inside a kernel).  Once every local-map launch of
@@ -1330,16 +1381,21 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     const long long D = std::max(0, KFQ / 2 / pl->ba_every - 2 - (ba_start != 0 ? 1 : 0));  // (a deferred launch is one frame late)
     for (int k = 0; k < pl->nba_lane; k++) {
       const long long j = L->ba_launches - 1 - D - k;
-      if (j >= 0 && L->ba_launches - j <= Lane::BAQ) join_wait(pl, L, st, L->ev_ba_done[j % Lane::BAQ]);
+      if (j >= 0 && L->ba_launches - j <= Lane::BAQ) {
+        if (!(k < 2 && fold_wait(pl, L, L->ev_ba_done[j % Lane::BAQ], p.kj, k))) join_wait(pl, L, st, L->ev_ba_done[j % Lane::BAQ]);
+      }
     }
   }
   PB(17, st);
+  L->endf_valid = fold_signal(pl, L, L->ev_endf, p.kj);
   launch_frame_end(st, p);
+  p.kj = KJoin{};
   PE(17, st);
   PE(19, st);
   if (with_local_map && (pl->frames_fed % pl->ba_every) == 0) {
     if (L->ba_pending) launch_local_map(pl, L, L->ev_fe, true, nullptr);  // (a deferred launch this frame had no place for: skipped frames)
     if (ba_start != 0 && pl->defer_ba) L->ba_pending = true;
+    else if (L->endf_valid) launch_local_map(pl, L, L->ev_endf, false, prof18);  // (k_frame_end has stored the word itself)
     else launch_local_map(pl, L, L->ev_fe, true, prof18);
   } else if (!with_local_map) {
     // without a local map nobody consumes the keyframe queue: drop what frame_end appended

@@ -211,7 +211,7 @@ __global__ void k_frame_begin(Pipe p, const double* __restrict__ frame_time) {
 // the head of a frame in one launch: the staged IMU samples (F2FTracking::imu_feed), then the frame set-up
 // One wavefront per stream: the integration itself is sequential (a sample's state follows from the previous one: lane 0 runs it), but
 // its inputs need not arrive one global round trip at a time -- the wave copies the stream's staged samples into LDS first.
-__global__ __launch_bounds__(64) void k_frame_head(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
+__device__ __forceinline__ void k_frame_head_body(const Pipe& p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
                                                    long long frame_no) {
   chain_priority();
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -228,6 +228,12 @@ __global__ __launch_bounds__(64) void k_frame_head(Pipe p, const double* __restr
   if (tid != 0) return;
   imu_feed_dev(p, s, s_in);
   frame_begin_dev(p, s, t_frame);
+}
+__global__ __launch_bounds__(64) void k_frame_head(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
+                                                   long long frame_no) {
+  kj_wait(p.kj);
+  k_frame_head_body(p, frame_time, host_progress, frame_no);
+  kj_signal(p.kj);
 }
 __device__ inline void frame_begin_dev(const Pipe& p, int s, double time) {
   StreamState& st = p.st[s];
@@ -354,7 +360,7 @@ __device__ __forceinline__ void track_prepare_dev(const Pipe& p, int s, int i) {
 __global__ __launch_bounds__(256) void k_track_prepare(Pipe p) { track_prepare_dev(p, blockIdx.y, blockIdx.x * 256 + threadIdx.x); }
 // k_frame_head and k_track_prepare in one launch (one workgroup of 256 threads per stream): the tracker's inputs follow the frame set-up
 // after a barrier instead of after a launch -- one dependent launch less at the head of every frame's chain
-__global__ __launch_bounds__(256) void k_frame_head_prepare(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
+__device__ __forceinline__ void k_frame_head_prepare_body(const Pipe& p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
                                                             long long frame_no) {
   chain_priority();
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -372,6 +378,12 @@ __global__ __launch_bounds__(256) void k_frame_head_prepare(Pipe p, const double
   }
   __syncthreads();  // (workgroup-scope release / acquire: the stream's state as thread 0 left it)
   for (int i = tid; i < NMAX; i += 256) track_prepare_dev(p, s, i);
+}
+__global__ __launch_bounds__(256) void k_frame_head_prepare(Pipe p, const double* __restrict__ frame_time, long long* __restrict__ host_progress,
+                                                            long long frame_no) {
+  kj_wait(p.kj);
+  k_frame_head_prepare_body(p, frame_time, host_progress, frame_no);
+  kj_signal(p.kj);
 }
 
 // ------------------------------------------------------------------------------------------------ LK survivors
@@ -473,7 +485,7 @@ __device__ unsigned long long g_f_rng7[F_TAB_N][F_TAB_B];
 #endif
 
 constexpr int RF_T = 1024;
-__global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
+__device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
@@ -973,6 +985,11 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
     }
   }
   RPROF(24, 4);
+}
+__global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
+  kj_wait(p.kj);
+  k_ransac_f_body(p);
+  kj_signal(p.kj);
 }
 
 // ------------------------------------------------------------------------------------------------ PnP RANSAC
@@ -1559,7 +1576,7 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
 #undef PNP_PROF
 }
 
-__global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
+__device__ __forceinline__ void k_ransac_pnp_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
@@ -1628,6 +1645,11 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
     if (inliers < 10) st.ok = 0;
   }
   RPROF(32, 4);
+}
+__global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
+  kj_wait(p.kj);
+  k_ransac_pnp_body(p);
+  kj_signal(p.kj);
 }
 
 // The same solver on caller-supplied correspondences: the geometric check of the loop closing, isLoopClosureKF
@@ -2007,7 +2029,7 @@ __global__ __launch_bounds__(PL_T) void k_pose_lm(Pipe p) {
 // ------------------------------------------------------------------------------------------------ reprojection filter
 // calReprjInlierOutlier(1.5) + eraseReprjOutlier + viCorrectionFromVision; prepares the redetect inputs.
 // One workgroup of NMAX threads per stream, one landmark per thread.
-__global__ __launch_bounds__(NMAX) void k_reproj_filter(Pipe p) {
+__device__ __forceinline__ void k_reproj_filter_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
@@ -2078,6 +2100,11 @@ __global__ __launch_bounds__(NMAX) void k_reproj_filter(Pipe p) {
     st.vi_corr_due = st.has_imu ? 1 : 0;  // viCorrectionFromVision follows in k_vi_correction (off the critical path)
   }
 }
+__global__ __launch_bounds__(NMAX) void k_reproj_filter(Pipe p) {
+  kj_wait(p.kj);
+  k_reproj_filter_body(p);
+  kj_signal(p.kj);
+}
 // VIMOTION::viCorrectionFromVision of the Tracking branch (f2f_tracking.cpp:256-262, after eraseReprjOutlier): one thread per stream.
 // Nothing on the frame's chain before k_frame_end reads the filter state, and the searches through the IMU ring are dependent global
 // loads (25 us of one thread): the detection stream runs it beside FeatureDEM / the stereo LK.
@@ -2142,7 +2169,7 @@ __global__ __launch_bounds__(64) void k_add_new(Pipe p) {
 // ------------------------------------------------------------------------------------------------ depth: inputs
 // Two kernels, because only the first is on the critical path: the stereo matcher needs its seeds; the two-view triangulation of
 // recover3DPts_c_FromTriangulation is consumed by k_depth_innovate and runs beside the stereo LK on the detection stream.
-__global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
+__device__ __forceinline__ void k_depth_seeds_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.y;
   const StreamState& st = p.st[s];
@@ -2173,7 +2200,12 @@ __global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
     p1[1] = p0[1];
   }
 }
-__global__ __launch_bounds__(256) void k_depth_triangulate(Pipe p) {
+__global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
+  kj_wait(p.kj);
+  k_depth_seeds_body(p);
+  kj_signal(p.kj);
+}
+__device__ __forceinline__ void k_depth_triangulate_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.y;
   const StreamState& st = p.st[s];
@@ -2203,13 +2235,18 @@ __global__ __launch_bounds__(256) void k_depth_triangulate(Pipe p) {
   }
   p.tri_mask[(size_t)s * NMAX + i] = tm;
 }
+__global__ __launch_bounds__(256) void k_depth_triangulate(Pipe p) {
+  kj_wait(p.kj);
+  k_depth_triangulate_body(p);
+  kj_signal(p.kj);
+}
 
 // ------------------------------------------------------------------------------------------------ depth innovation
 // recover3DPts_c_FromStereo (after LK) + depthInnovation + eraseNoDepthPoint.  One workgroup of NMAX threads per stream,
 // one landmark per thread (read once, updated in registers, written to its compacted position).  The rand()-drawn dummy
 // depths (quirk A11) are consumed in landmark order: failures are ranked with a workgroup prefix, thread 0 advances the
 // stream's glibc generator by the number of failures.
-__global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
+__device__ __forceinline__ void k_depth_innovate_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
@@ -2310,11 +2347,16 @@ __global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
   if (keep) lms[k] = lm;
   if (i == 0) st.n_lm[cur] = kept;
 }
+__global__ __launch_bounds__(NMAX) void k_depth_innovate(Pipe p) {
+  kj_wait(p.kj);
+  k_depth_innovate_body(p);
+  kj_signal(p.kj);
+}
 
 // ------------------------------------------------------------------------------------------------ frame end
 // init_frame's success test, keyframe decision (f2f_tracking.cpp:329-354,442-452), outputs, KeyFrame payload.
 constexpr int FE_T = 256;
-__global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
+__device__ __forceinline__ void k_frame_end_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
@@ -2455,6 +2497,11 @@ __global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
     __syncthreads();
     if (lane == 0) __hip_atomic_store(&p.kfq_tail[s], s_tail + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+__global__ __launch_bounds__(FE_T) void k_frame_end(Pipe p) {
+  kj_wait(p.kj);
+  k_frame_end_body(p);
+  kj_signal(p.kj);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

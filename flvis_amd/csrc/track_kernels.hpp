@@ -77,6 +77,7 @@ struct Pipe {
   // ... and the second image's base itself (a kernel argument: it changes from frame to frame with the caller's buffer)
   const uint8_t* in_img1;
   CorrectionDev* corr_in;   // [S] correction waiting for the stream's next Tracking frame (valid flag), or nullptr
+  KJoin kj;                 // joins folded into THIS launch (set by the host in front of it, cleared behind it)
 };
 
 int ba_lds_budget_max();
