@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-local-map", action="store_true")
     ap.add_argument("--no-epilogue", action="store_true", help="skip the untimed per-stage epilogue")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-image (PCIe-inclusive) variant")
+    ap.add_argument("--euroc", default=os.environ.get("FLVIS_EUROC_DIR"), help="EuRoC ASL sequence folder (e.g. MH_05_difficult/mav0): BASELINE "
+                    "configs[0..1] -- the sequence through the HIP path and through the CPU restatement, ATE of each against the ground "
+                    "truth and of one against the other; absent: the line says \"dataset missing\" (SURVEY 8d)")
     ap.add_argument("--pmc", action="store_true", help="collect FETCH_SIZE / WRITE_SIZE of k_lk_track under rocprofv3")
     ap.add_argument("--stub", action="store_true",
                     help="CPU test hook: no GPU work, gloo instead of RCCL; exercises rank spawning + result exchange only")
@@ -718,6 +721,15 @@ def main():
                                 per_it = r["valu_insts_per_launch"] / lk_iters[tag]["window_evaluations_per_launch"]
                                 r["valu_insts_per_iteration"] = round(per_it, 1)
                                 r["valu_insts_per_window_pixel"] = round(per_it * 64 / 961.0, 2)
+                # the ceiling the dominant kernel actually runs against (the contract's fields above price it on HBM bytes): VALU issue
+                lkrows = [r for r in out["roofline"]["kernels"] if r["kernel"].startswith("k_lk_track") and r.get("valu_issue_frac")]
+                if lkrows:
+                    out["roofline"]["binding_resource"] = {
+                        "resource": "valu_issue", "frac": round(sum(r["valu_issue_frac"] for r in lkrows) / len(lkrows), 4),
+                        "peak": rf.VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
+                        "per_launch": {r["kernel"]: r["valu_issue_frac"] for r in lkrows},
+                        "note": "k_lk_track is bound by VALU issue, not by HBM (frac above: algorithmic bytes / 8 TB/s); counters of "
+                                "profiles/*_kernel_pmc.json at this source tree"}
                 out["roofline"]["kernels_note"] = (
                     "avg_launch_ms: HIP events of this run (epilogue frames); counters / rocprof_avg_launch_ms: %s; valu_issue_frac against "
                     "%.1f G wave-instructions/s (1024 SIMDs x 2.4 GHz / 4); k_ba_worker: SURVEY 8d's flop formula on the kernel's own trial / "
@@ -726,7 +738,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out.setdefault("leg_errors", []).append("kernel table: %s: %s" % (type(e).__name__, e))
         # ---- legs that must never suppress the GPU line: host-image variant, CPU baselines, ATE
-        for leg in (leg_h2d, leg_cpu):
+        for leg in (leg_h2d, leg_cpu, leg_euroc):
             try:
                 leg(locals())
             except Exception as e:  # noqa: BLE001
@@ -933,6 +945,46 @@ def leg_h2d(L):
         out["with_h2d"]["host_call_ms"] = [round(v, 3) for v in calls]
         out["with_h2d"]["loop_ms"] = round(t_loop * 1e3, 3)
         out["with_h2d"]["total_ms"] = round(dt * 1e3, 3)
+
+
+def leg_euroc(L):
+    """BASELINE.json configs[0] / configs[1]: the EuRoC sequence of --euroc / FLVIS_EUROC_DIR (MH_05_difficult is the one the metric names)
+    through scripts/run_sequence.py on both backends -- the reference's EuRoC calibration and parameters (launch/EuRoC_MAV/euroc.yaml, the
+    values flvis_amd.synth.EUROC_LIKE_YAML carries), front-end + local map -- and the three numbers of the metric: ATE of the HIP path and of
+    the CPU restatement against the ground truth, and camera-centre RMSE of one against the other.  No dataset exists offline: the line
+    then says so instead of dropping the key."""
+    args, out = L["args"], L["out"]
+    d = args.euroc
+    if not d or not os.path.isdir(d):
+        out["euroc"] = {"status": "dataset missing", "looked_in": d or "(no --euroc DIR / FLVIS_EUROC_DIR given)",
+                        "would_run": "scripts/run_sequence.py DIR <euroc.yaml values> OUT --local-map, --backend hip and --backend cpu; "
+                                     "ATE vs ground truth of each + HIP vs CPU"}
+        return
+    from flvis_amd import synth, traj_io
+    frames = int(os.environ.get("FLVIS_EUROC_FRAMES", "400"))   # (bounded: the CPU restatement runs ~25 frames/s)
+    tmp = tempfile.mkdtemp(prefix="flvis_euroc_")
+    ypath = os.path.join(tmp, "euroc.yaml")
+    open(ypath, "w").write(synth.EUROC_LIKE_YAML)
+    res = {"status": "ran", "sequence": d, "frames": frames}
+    for backend in ("hip", "cpu"):
+        est = os.path.join(tmp, "est_%s.txt" % backend)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "run_sequence.py"), d, ypath, est, "--backend", backend,
+                            "--frames", str(frames), "--local-map"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+        if r.returncode != 0:
+            res[backend] = {"error": r.stderr.decode(errors="replace")[-400:]}
+            continue
+        try:
+            res[backend] = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001
+            res[backend] = {"error": "unparsable output: %s" % e}
+    a, b = os.path.join(tmp, "est_hip.txt"), os.path.join(tmp, "est_cpu.txt")
+    if os.path.exists(a) and os.path.exists(b):
+        rmse, n = traj_io.ate_from_files(a, b)
+        res["hip_vs_cpu_rmse_m"], res["hip_vs_cpu_poses"] = rmse, n
+        ha, ca = (res.get("hip") or {}).get("ate_rmse_m"), (res.get("cpu") or {}).get("ate_rmse_m")
+        if ha is not None and ca:
+            res["ate_relative_difference"] = abs(ha - ca) / ca      # north_star: within 1 % of the CPU reference
+    out["euroc"] = res
 
 
 _HUGE_KEEP = []

@@ -159,6 +159,7 @@ struct Pipeline {
     long long* h_flag[FLAG_RING] = {};
     long long* d_flag = nullptr;
     long long slot_frame[SLOTS] = {0, 0, 0};  // the lane frame number (frames_uploaded) that read the slot last
+    long long last_call_frame = -1;           // frames_fed behind this entry's last call (another entry in between: the chain is not continuous)
     size_t raw_bytes[2] = {}, gray_bytes = 0;
     hipEvent_t ev_done[2] = {}, ev_free[2] = {};
     long long n = 0;
@@ -181,6 +182,7 @@ struct Pipeline {
   unsigned ev_flags = hipEventDisableTiming;  // flags of every event of the pipeline (FLVIS_EVENT_SCOPE)
   bool flag_joins = false;                    // FLVIS_JOIN=flag
   bool fold_joins = false;                    // FLVIS_JOIN_FOLD: the chain's own kernels wait for / store the words (KJoin)
+  bool chain_continuous = false;              // this frame follows the previous one on the main stream with nothing of the caller's in between
   Lane& lane_of(int stream, int& local) {
     const int k = stream / lane_size;
     local = stream - k * lane_size;
@@ -1122,7 +1124,9 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     ImgSel l0in{{L->pyr0[0][0], L->pyr0[1][0]}, p.img_slot_in, 0, nullptr};
     // what the detection stream needs from the main one here is k_frame_end of the previous frame (the slot the image goes to) and, in
     // the copying mode, the upload of the input table: a signal of its own -- or, folded, the word the last k_frame_end stored itself
-    if (pl->fold_joins && zerocopy && L->endf_valid) {
+    // (only where nothing can have been enqueued on the main stream since that k_frame_end: between the steps of one flvis_run_steps call,
+    // and for host images that arrive through the copy stream -- a caller of flvis_image_feed may have produced its images on this stream)
+    if (pl->fold_joins && zerocopy && L->endf_valid && pl->chain_continuous) {
       join_wait(pl, L, ds, L->ev_endf);
     } else {
       join_signal(pl, L, L->ev_lm, st);  // (the frame's input table has been uploaded)
@@ -1330,16 +1334,16 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(13, st);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
   PB(14, st);
-  const bool ds_signals = fold_signal(pl, L, L->ev_lm, p.kj);
+  // (not folded: k_depth_seeds and k_depth_triangulate are 256 workgroups each -- every workgroup's release is a write-back of its XCD's
+  // L2, and beside the stereo LK's template stores the kernels doubled their time: 5.9 -> 12.7 us, 87 -> 180 us)
+  const bool ds_signals = false;
   launch_depth_seeds(st, p);
-  p.kj = KJoin{};
   PE(14, st);
   // the two-view triangulation that k_depth_innovate consumes: on the detection stream (idle by now), under the stereo LK
   if (!ds_signals) join_signal(pl, L, L->ev_lm, st);
   join_wait(pl, L, ds, L->ev_lm);
-  const bool tri_signals = fold_signal(pl, L, L->ev_tri, p.kj);
+  const bool tri_signals = false;
   launch_depth_triangulate(ds, p);
-  p.kj = KJoin{};
   if (!tri_signals) join_signal(pl, L, L->ev_tri, ds);
   if (gftt_first && !pyramid_main) join_wait(pl, L, st, L->ev_det);
   PB(15, st);
@@ -1664,7 +1668,10 @@ int flvis_image_feed_host(flvis_ctx* ctx, const flvis_image* h_img0, const flvis
   static const int h2d_lead = getenv("FLVIS_H2D_LEAD") ? std::max(1, std::min(atoi(getenv("FLVIS_H2D_LEAD")), 4)) : 1;  // (A/B knob)
   pl->host_lead_cap = h2d_lead;
   const auto th2 = std::chrono::steady_clock::now();
+  pl->chain_continuous = wait_on_det && hf.mode == 2 && hf.last_call_frame == pl->frames_fed;  // (the previous frame was this entry's too)
   const int rc = flvis_image_feed(ctx, d0, d1, hf.times.data(), h_out, with_local_map);
+  pl->chain_continuous = false;
+  hf.last_call_frame = pl->frames_fed;
   pl->up_event = nullptr;
   pl->up_flag = nullptr;
   const auto th3 = std::chrono::steady_clock::now();
@@ -1706,8 +1713,10 @@ int flvis_run_steps(flvis_ctx* ctx, int n_steps, const flvis_step* steps, int wi
       if (rc != FLVIS_OK) return rc;
     }
     ctx->pipe->defer_ba = k + 1 < n_steps;
+    ctx->pipe->chain_continuous = k > 0;
     const int rc = flvis_image_feed(ctx, f.d_img0, f.d_img1, f.h_times, nullptr, with_local_map);
     ctx->pipe->defer_ba = false;
+    ctx->pipe->chain_continuous = false;
     if (rc != FLVIS_OK) return rc;
     if (h_call_ms) h_call_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
