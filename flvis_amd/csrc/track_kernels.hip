@@ -501,7 +501,13 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
 #ifdef FLVIS_SOLVERS_PRODUCT
   __shared__ double spw[63 * 64];  // 7-point workspaces of the 64 hypothesis lanes (element-major: conflict-free)
 #else
-  __shared__ double spw[cvs::SP_WORK * 64];  // run7Point's workspaces of the 64 hypothesis lanes (element-major: conflict-free)
+  // run7Point's workspaces of the 64 hypotheses: element e of hypothesis h at spw[e * SPW_S + h].  (A/B knob FLVIS_SPW_S: 65 would keep the three lanes of a
+  // hypothesis, which work on rows 9 elements apart, out of one LDS bank -- measured: 59.5k / 59.7k against 59.8k frames/s, no gain)
+#ifndef FLVIS_SPW_S
+#define FLVIS_SPW_S 64
+#endif
+  constexpr int SPW_S = FLVIS_SPW_S;
+  __shared__ double spw[cvs::SP_WORK * SPW_S];
 #endif
   __shared__ int hnm[64], mcnt[64 * 3];
   __shared__ int hcnt[64], hmodel[64];
@@ -569,9 +575,40 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
 #pragma unroll
         for (int j = 0; j < 7; j++) s_sub[lane][j] = g_f_sub7[n][lane][j];
       }
+      // (round 6: the B x 30 collinearity tests of the table's candidates in ceil(30 B / 64) passes of the wave instead of one candidate
+      // after the other -- the serial form was ~20 us of the kernel; the first refused candidate ends the table's part as before)
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      unsigned refused = 0;  // bit c: candidate c has a collinear last point (wave-uniform)
+      const int nchk = 30 * (B < 32 ? B : 32);
+      for (int c0 = 0; c0 < nchk; c0 += 64) {
+        const int c = c0 + lane;
+        bool bad = false;
+        int cand = 0;
+        if (c < nchk) {
+          cand = c / 30;
+          const int t = c - 30 * cand;
+          const int pr = t < 15 ? t : t - 15;
+          int j = 1, kk = pr;
+          while (kk >= j) {
+            kk -= j;
+            j++;
+          }
+          const float* m = t < 15 ? sm1 : sm2;
+          const int ii = s_sub[cand][6], ij = s_sub[cand][j], ik = s_sub[cand][kk];
+          const double dx1 = m[2 * ij] - m[2 * ii], dy1 = m[2 * ij + 1] - m[2 * ii + 1];
+          const double dx2 = m[2 * ik] - m[2 * ii], dy2 = m[2 * ik + 1] - m[2 * ii + 1];
+          bad = fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+        }
+        unsigned long long bm = __ballot(bad);
+        while (bm) {  // (rare: a refused candidate)
+          const int l = __builtin_ctzll(bm);
+          bm &= bm - 1;
+          refused |= 1u << __shfl(cand, l);
+        }
+      }
       for (k = 0; k < B && base + k < limit; k++) {
-        s_chk = s_sub[k];
-        if (!fm_check_staged()) break;
+        if (k < 32 ? ((refused >> k) & 1u) : 0u) break;
         if (lane == 0) s_sub[k][7] = 1;
       }
       if (k > 0) rng.state = g_f_rng7[n][k - 1];
@@ -624,7 +661,7 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
               x2[k][0] = sm2[2 * ik];
               x2[k][1] = sm2[2 * ik + 1];
             }
-            nm = cvs::run7point<64>(x1, x2, xw, F, [](int) {});
+            nm = cvs::run7point<SPW_S>(x1, x2, xw, F, [](int) {});
           } else {
             nm = -2;
           }
@@ -764,24 +801,26 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
       // anti-diagonals of two overlapping sweeps, three pairs at a time (cvs::sp_slot: the bits of the cyclic order, in a third of its
       // steps -- a rotation is a chain of three divisions and three square roots, ~0.4 us); lane 0 of the four then completes the basis,
       // solves the cubic and writes up to three matrices.
+#ifdef FLVIS_RANSAC_PROF
+      if (tid == 0) {
+        g_sp_prof = p.counters ? p.counters + 40 : nullptr;
+        g_sp_last = (long long)wall_clock64();
+      }
+#endif
       if (wv == 0) draw_batch(base, B, ctl[0], 10000, base == 0 && B == F_TAB_B && n < F_TAB_N);
+      SP_STAMP(5);
       __syncthreads();
+      SP_STAMP(6);
       if (16 * wv < B) {
         const int q = lane & 3, hyp = 16 * wv + (lane >> 2);
         const int iter = base + hyp;
         int nm = -1;  // -1: beyond niters, -2: subset impossible (the reference loop stops)
         bool have = false;
-        double* const xw = spw + hyp;  // element e of this hypothesis at xw[e * 64]
+        double* const xw = spw + hyp;  // element e of this hypothesis at xw[e * SPW_S]
         if (iter < ctl[0]) {
           if (s_sub[hyp][7]) have = true;
           else nm = -2;
         }
-#ifdef FLVIS_RANSAC_PROF
-        if (tid == 0) {
-          g_sp_prof = p.counters ? p.counters + 40 : nullptr;
-          g_sp_last = (long long)wall_clock64();
-        }
-#endif
         if (have && q == 0) {
           double x1[7][2], x2[7][2];
 #pragma unroll
@@ -792,7 +831,7 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
             x2[k][0] = sm2[2 * ik];
             x2[k][1] = sm2[2 * ik + 1];
           }
-          cvs::sp_fill<64>(x1, x2, xw);
+          cvs::sp_fill<SPW_S>(x1, x2, xw);
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -804,7 +843,7 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
           const cvs::SpSlot e = cvs::sp_slot(sigma, q);
           const int sw = s_hi + e.ds;
           bool rot = false;
-          if (!done && e.i >= 0 && sw >= 0 && sw < cvs::SVD_MAX_SWEEPS) rot = cvs::sp_pair<64>(xw, e.i, e.j);
+          if (!done && e.i >= 0 && sw >= 0 && sw < cvs::SVD_MAX_SWEEPS) rot = cvs::sp_pair<SPW_S>(xw, e.i, e.j);
           __builtin_amdgcn_wave_barrier();
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           const unsigned long long bc = __ballot(rot && e.ds == 0), bp = __ballot(rot && e.ds != 0);
@@ -819,7 +858,7 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
         }
         if (have && q == 0) {
           double F[3][9];
-          nm = cvs::sp_finish<64>(xw, F, [&](int i) { SP_STAMP(i); });
+          nm = cvs::sp_finish<SPW_S>(xw, F, [&](int i) { SP_STAMP(i); });
 #pragma unroll
           for (int m = 0; m < 3; m++)
             if (m < nm)
