@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 from flvis_amd import bench_plan as plan  # noqa: E402  (pure python, no GPU)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
-ROUND_TAG = "r05"
+ROUND_TAG = "r06"
 
 # algorithmic HBM bytes per launch of the image-scan kernels for ONE stream, 640x480:
 PYR_BYTES = 307200 + 76800 + 19200 + 4800          # one pyramid (levels 0..3)

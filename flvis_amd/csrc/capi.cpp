@@ -72,6 +72,7 @@ int flvis_hip_create(int device, void* hip_stream, flvis_ctx** out) {
 
 void flvis_pipeline_destroy_internal(flvis_ctx* ctx);  // pipeline.cpp
 void flvis_pipeline_sync_internal(flvis_ctx* ctx);
+long long flvis_pipeline_join_timeout_internal(flvis_ctx* ctx);
 
 void flvis_hip_destroy(flvis_ctx* ctx) {
   if (!ctx) return;
@@ -91,6 +92,12 @@ int flvis_hip_synchronize(flvis_ctx* ctx) {
   hipError_t e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) return ctx->hip_fail(e, "hipStreamSynchronize");
   flvis_pipeline_sync_internal(ctx);
+  // a stream join (k_wait_flag, a folded wait) that gave up after its ~4 s: the frames behind it ran on whatever was there
+  if (const long long seq = flvis_pipeline_join_timeout_internal(ctx)) {
+    char msg[128];
+    snprintf(msg, sizeof msg, "a stream join or an upload wait timed out (sequence number %lld): results since then are invalid", seq);
+    return ctx->fail(FLVIS_ERR_HIP, msg);
+  }
   return FLVIS_OK;
 }
 

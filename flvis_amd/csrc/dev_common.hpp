@@ -51,7 +51,10 @@ __device__ __forceinline__ void kj_wait(const KJ& kj) {
       if (!kj.wait[k]) continue;
       while (__hip_atomic_load(kj.wait[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < kj.wait_seq[k]) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 400000000ull) break;
+        if (wall_clock64() - t0 > 400000000ull) {
+          if (kj.err) __hip_atomic_store(kj.err, kj.wait_seq[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

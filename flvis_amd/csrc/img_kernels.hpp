@@ -15,6 +15,7 @@ struct KJoin {
   long long* sig;
   long long sig_seq;
   unsigned* sig_cnt;  // arrival counter of the signalling launch's workgroups (the last one puts it back to 0)
+  long long* err;     // host-mapped word that receives the sequence number of a wait that gave up (~4 s), or null
 };
 
 

@@ -316,6 +316,18 @@ extern "C" void flvis_pipeline_sync_internal(flvis_ctx* ctx) {
   if (ctx && ctx->pipe) sync_all(ctx);
 }
 
+// the sequence number a timed-out join stored (k_wait_flag's err_word = word 2 of the lane's host-mapped progress block), or 0; cleared when read
+extern "C" long long flvis_pipeline_join_timeout_internal(flvis_ctx* ctx) {
+  long long seq = 0;
+  if (ctx && ctx->pipe)
+    for (Lane* L : ctx->pipe->lanes)
+      if (L->h_progress && L->h_progress[2]) {
+        seq = L->h_progress[2];
+        L->h_progress[2] = 0;
+      }
+  return seq;
+}
+
 extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   if (!ctx || !ctx->pipe) return;
   Pipeline* pl = ctx->pipe;
@@ -576,7 +588,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
     if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) return false;
     L->h_progress = (volatile long long*)hp;
     L->d_progress = (long long*)dp;
-    *L->h_progress = 0;
+    for (int k = 0; k < 8; k++) L->h_progress[k] = 0;  // (word 0: frame progress, 1: scratch, 2: a timed-out join's sequence number)
   }
   if (own_stream) {
     if (hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking) != hipSuccess) return false;
@@ -967,6 +979,7 @@ static bool fold_wait(Pipeline* pl, Lane* L, hipEvent_t ev, KJoin& kj, int slot)
   if (id < 0) return false;
   kj.wait[slot] = L->d_join + 8 * id;
   kj.wait_seq[slot] = L->join_seq[id];
+  kj.err = L->d_progress + 2;
   return true;
 }
 

@@ -480,8 +480,18 @@ __device__ unsigned long long g_f_rng7[F_TAB_N][F_TAB_B];
       tlast_ = now_;                                                                                     \
     }                                                                                                    \
   } while (0)
+// (a second clock for stamps inside a phase of the outer profile)
+#define RPROF2(base, i)                                                                                  \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && p.counters) {                                                                \
+      long long now_ = (long long)wall_clock64();                                                        \
+      atomicAdd((unsigned long long*)&p.counters[(base) + (i)], (unsigned long long)(now_ - tlast2_));  \
+      tlast2_ = now_;                                                                                    \
+    }                                                                                                    \
+  } while (0)
 #else
 #define RPROF(base, i) do { } while (0)
+#define RPROF2(base, i) do { } while (0)
 #endif
 
 constexpr int RF_T = 1024;
@@ -493,6 +503,7 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef FLVIS_RANSAC_PROF
   long long tlast_ = (long long)wall_clock64();
+  long long tlast2_ = tlast_;
   if (tid == 0 && p.counters) atomicAdd((unsigned long long*)&p.counters[24 + 7], 1ull);
 #endif
   const int n = st.n_surv;
@@ -801,16 +812,10 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
       // anti-diagonals of two overlapping sweeps, three pairs at a time (cvs::sp_slot: the bits of the cyclic order, in a third of its
       // steps -- a rotation is a chain of three divisions and three square roots, ~0.4 us); lane 0 of the four then completes the basis,
       // solves the cubic and writes up to three matrices.
-#ifdef FLVIS_RANSAC_PROF
-      if (tid == 0) {
-        g_sp_prof = p.counters ? p.counters + 40 : nullptr;
-        g_sp_last = (long long)wall_clock64();
-      }
-#endif
       if (wv == 0) draw_batch(base, B, ctl[0], 10000, base == 0 && B == F_TAB_B && n < F_TAB_N);
-      SP_STAMP(5);
+      RPROF2(40, 5);
       __syncthreads();
-      SP_STAMP(6);
+      RPROF2(40, 6);
       if (16 * wv < B) {
         const int q = lane & 3, hyp = 16 * wv + (lane >> 2);
         const int iter = base + hyp;
@@ -835,7 +840,7 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        SP_STAMP(0);
+        RPROF2(40, 0);
         bool done = !have, chg_prev = false, chg_cur = false;
         const int sh = lane & ~3;
         for (int T = 1;; T++) {
@@ -856,9 +861,10 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
           }
           if (__ballot(!done) == 0ull) break;
         }
+        RPROF2(40, 1);
         if (have && q == 0) {
           double F[3][9];
-          nm = cvs::sp_finish<SPW_S>(xw, F, [&](int i) { SP_STAMP(i); });
+          nm = cvs::sp_finish<SPW_S>(xw, F, [&](int) {});
 #pragma unroll
           for (int m = 0; m < 3; m++)
             if (m < nm)
@@ -866,6 +872,7 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
               for (int j = 0; j < 9; j++) Fm[hyp * 3 + m][j] = F[m][j];
         }
         if (q == 0) hnm[hyp] = nm;
+        RPROF2(40, 2);
       }
 #else
       // hypotheses of this batch, one per lane of wave 0.  The bisections of the cubic's (up to three) sign-change intervals are

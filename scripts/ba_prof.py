@@ -67,7 +67,7 @@ if c[24 + 7] or c[32 + 7]:
 
 if c[24 + 7]:
     n = max(c[24 + 7], 1)
-    print("seven_point (thread 0): " + "  ".join("%s=%.1fus" % (nm, c[40 + i] / n / 100.0) for i, nm in enumerate(["fill (r5: subset+normalise)", "sweeps (r5: eliminate)", "norms+sort+completion (r5: nullspace)", "cubic", "matrices", "draw", "barrier"])))
+    print("seven_point (thread 0): " + "  ".join("%s=%.1fus" % (nm, c[40 + i] / n / 100.0) for i, nm in enumerate(["fill", "sweeps", "finish (norms, sort, completion, cubic, matrices)", "-", "-", "load .. draw", "barrier"])))
     if c[56 + 6]:
         n = c[56 + 6]
         print("EPnP (wave 0's hypotheses, %d solves): " % n + "  ".join("%s=%.1fus" % (nm, c[56 + i] / n / 100.0) for i, nm in enumerate(

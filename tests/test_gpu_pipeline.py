@@ -1029,3 +1029,111 @@ def test_local_map_parity(ctx):
             assert np.allclose(got["lm_3d"], want["lm_3d"], atol=1e-6, rtol=0), (
                 k, np.abs(got["lm_3d"] - want["lm_3d"]).max())
         assert produced == len(seq["kfs"]) - cfg.window_size + 1
+
+
+def _mode_frames(S, nframes, streams):
+    from flvis_amd import synth
+    trajs = [synth.Trajectory(s) for s in streams]
+    rnd = synth.Renderer("cuda")
+    frames, t_prev = [], -0.05
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        smp = [synth.imu_samples(trajs[i], s, t_prev, t) for i, s in enumerate(streams)]
+        t_prev = t
+        cnt = np.array([len(x) for x in smp], np.int32)
+        blk = np.zeros((S, max(max(len(x) for x in smp), 1), 7))
+        for i, x in enumerate(smp):
+            blk[i, :len(x)] = x
+        i0, i1 = rnd.stereo_frame(trajs, t, f)
+        frames.append((i0.clone(), i1.clone(), [t] * S, cnt, blk))
+    return frames
+
+
+def _mode_result(trk, ctx, S, nframes):
+    ctx.synchronize()
+    rows = np.stack([trk.trajectory(i, 0, nframes) for i in range(S)])
+    lms = [trk.landmarks(i) for i in (0, S - 1)]
+    corr = [trk.correction(i) for i in (0, S - 1)]
+    kf, ba = trk.local_map_counts()
+    return rows, lms, corr, list(trk.counters()), kf, ba
+
+
+def _assert_same_run(a, b, what):
+    (ra, la, ca, na, ka, ba_a), (rb, lb, cb, nb_, kb, ba_b) = a, b
+    assert np.array_equal(ka, kb) and np.array_equal(ba_a, ba_b), what
+    assert np.array_equal(ra, rb), (what, np.abs(ra - rb).max())
+    for x, y in zip(la, lb):
+        for k in ("ids", "flags", "p2d", "p2u", "p3w"):
+            assert np.array_equal(x[k], y[k]), (what, k)
+    for x, y in zip(ca, cb):
+        assert (x is None) == (y is None), what
+        if x is not None:
+            assert x["frame_id"] == y["frame_id"] and np.array_equal(x["pose7"], y["pose7"]) and np.array_equal(x["lm_3d"], y["lm_3d"]), what
+    assert na == nb_, (what, na, nb_)
+
+
+def test_stream_join_forms_leave_the_same_results(ctx, monkeypatch):
+    """Round 6: the joins between a lane's streams are device words (k_store_flag / k_wait_flag) and, where the chain's own kernels can
+    carry them, folded into those kernels (KJoin) -- instead of hipEventRecord / hipStreamWaitEvent.  FLVIS_JOIN=event (rounds 1-5),
+    flag joins without folding and the default must leave the same trajectories, landmarks, CorrectionInf and counters, bit for bit --
+    frame by frame (per-frame callers: the explicit frame-start join) and in batches (flvis_run_steps: the folded one, the deferred
+    local-map launch behind k_ransac_pnp)."""
+    import flvis_amd
+    cfg, _ = _cfgs()
+    S, nframes = 8, 50 + 36
+    frames = _mode_frames(S, nframes, [3 + 7 * i for i in range(S)])
+    res = {}
+    for name, env in (("event", {"FLVIS_JOIN": "event"}), ("flag", {"FLVIS_JOIN_FOLD": "0"}), ("default", {})):
+        for k in ("FLVIS_JOIN", "FLVIS_JOIN_FOLD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for feed in ("frames", "batches"):
+            trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715, traj_capacity=nframes)
+            if feed == "frames":
+                for (i0, i1, ts, cnt, blk) in frames:
+                    for i in range(S):
+                        trk.imu_feed_flvis(i, blk[i, :cnt[i]])
+                    trk.image_feed(i0, i1, ts, want_out=False, with_local_map=True)
+            else:
+                f = 0
+                for nb in (50, 1, 5, 2, nframes):
+                    nb = min(nb, nframes - f)
+                    if nb > 0:
+                        trk.run_steps(frames[f:f + nb], with_local_map=True)
+                    f += nb
+            res[(name, feed)] = _mode_result(trk, ctx, S, nframes)
+            del trk
+    ref = res[("event", "frames")]
+    assert np.all((ref[0][:, 50:, 8].astype(int) & 15) == 1) and ref[4].sum() > 2 * S and ref[5].sum() >= S
+    for key, r in res.items():
+        _assert_same_run(ref, r, key)
+
+
+def test_host_feed_upload_forms_leave_the_same_results(ctx, monkeypatch):
+    """flvis_image_feed_host, mode 2 (round 6: nothing but copies on the copy stream -- a sequence block behind the images, k_wait_flag on the
+    ingesting stream, host-side slot gating over three staging slots) against mode 1 (FLVIS_H2D_MODE=1: events on the copy stream, two
+    slots; rounds 4-5) and against the resident entry: 40 frames handed over without readback, buffers rewritten as soon as the contract
+    allows, must leave the same trajectories, landmarks and counters, bit for bit."""
+    import flvis_amd
+    cfg, _ = _cfgs()
+    S, nframes = 8, 50 + 40
+    frames = _mode_frames(S, nframes, [11 + 3 * i for i in range(S)])
+    res = {}
+    for mode in ("resident", "2", "1"):
+        monkeypatch.delenv("FLVIS_H2D_MODE", raising=False)
+        if mode == "1":
+            monkeypatch.setenv("FLVIS_H2D_MODE", "1")
+        trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715, traj_capacity=nframes)
+        feeder = None if mode == "resident" else _HostFeeder(S, channels=1, hold=1, layout="block", pinned=True)
+        for (i0, i1, ts, cnt, blk) in frames:
+            for i in range(S):
+                trk.imu_feed_flvis(i, blk[i, :cnt[i]])
+            if feeder is None:
+                trk.image_feed(i0, i1, ts, want_out=False, with_local_map=True)
+            else:
+                feeder.feed(trk, i0.cpu().numpy(), i1.cpu().numpy(), ts, False, want_out=False, with_local_map=True)
+        res[mode] = _mode_result(trk, ctx, S, nframes)
+        del trk
+    for mode in ("2", "1"):
+        _assert_same_run(res["resident"], res[mode], "host-image mode " + mode)
