@@ -256,6 +256,9 @@ int flvis_hip_stereo_depth(flvis_ctx* ctx, const flvis_cfg* cfg, const uint8_t* 
   if (cfg->cam_type == CAM_DEPTH) return ctx->fail(FLVIS_ERR_CONFIG, "stereo_depth: the rig has a depth camera (recover3DPts_c_FromDepthImg), no stereo pair");
   const int w = cfg->image_width, h = cfg->image_height;
   if (w < 32 || h < 32) return ctx->fail(FLVIS_ERR_CONFIG, "stereo_depth: image too small");
+  // (a configuration that never went through flvis_config_finalize has empty rectified projections: fx = 0 and points at infinity)
+  if (cfg->P0[0] == 0.0 || cfg->P0[5] == 0.0 || cfg->P1[0] == 0.0)
+    return ctx->fail(FLVIS_ERR_CONFIG, "stereo_depth: the configuration is not finalised (flvis_config_finalize: P0 / P1 are empty)");
   flvis_sd_cam cam;
   memcpy(cam.K1, cfg->cam1_intrinsics, 32);
   memcpy(cam.D1, cfg->cam1_distortion, 32);

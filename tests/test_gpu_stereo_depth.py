@@ -78,4 +78,11 @@ def test_stereo_depth_parity(rig_name):
     with pytest.raises(flvis_amd.FlvisError):                    # a depth-camera rig has no stereo pair
         dcfg, _ = _cfgs(synth.D435I_DEPTH_YAML, "depth")
         ctx.stereo_depth(dcfg, dev(img0), dev(img1), dev(p2d), dev(p2u), dev(p3w), dev(has), dev(cnt), poses, 3.0, state)
+    with pytest.raises(flvis_amd.FlvisError):                    # a configuration that was never finalised: empty projections, refused
+        import copy
+        raw = copy.copy(cfg)
+        for k in range(12):
+            raw.P0[k] = 0.0
+            raw.P1[k] = 0.0
+        ctx.stereo_depth(raw, dev(img0), dev(img1), dev(p2d), dev(p2u), dev(p3w), dev(has), dev(cnt), poses, 3.0, state)
     ctx.close()
