@@ -494,7 +494,10 @@ __device__ unsigned long long g_f_rng7[F_TAB_N][F_TAB_B];
 #define RPROF2(base, i) do { } while (0)
 #endif
 
-constexpr int RF_T = 1024;
+#ifndef FLVIS_RF_T
+#define FLVIS_RF_T 1024
+#endif
+constexpr int RF_T = FLVIS_RF_T;  // (A/B knob: 256 or 512 threads leave room for the detection stream's waves on the workgroup's CU)
 __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
