@@ -282,6 +282,11 @@ def run_pmc(args):
     base = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
             "--streams", str(args.streams), "--cpu-frames", "0", "--cpu-mt-frames", "0", "--no-epilogue", "--no-h2d"]
     env = dict(os.environ, TMPDIR="/tmp")
+    # (counter collection serialises kernel execution: a k_wait_flag that sleeps until a kernel of another stream has stored its word would
+    # wait for a kernel that cannot start -- each such join would end by its 4 s limit.  The counter passes therefore run with the joins of
+    # rounds 1-5, hipEvents, which the command processor resolves between kernels; the per-kernel instruction and byte counts do not depend
+    # on how the streams are joined, and the tracker's kernels are the same)
+    env_pmc = dict(env, FLVIS_JOIN="event")
     kern = {}
 
     def second_half(rows):
@@ -303,7 +308,7 @@ def run_pmc(args):
     for ctr, key in (("FETCH_SIZE", "fetch_kb"), ("WRITE_SIZE", "write_kb"), ("SQ_INSTS_VALU", "valu_insts")):
         d = tempfile.mkdtemp(prefix="flvis_pmc_%s_" % ctr, dir="/tmp")
         r = subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base,
-                           cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+                           cwd="/tmp", env=env_pmc, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
             raise SystemExit("rocprofv3 --pmc %s failed (rc %d):\n%s" % (ctr, r.returncode, r.stdout.decode(errors="replace")[-2000:]))

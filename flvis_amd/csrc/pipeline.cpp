@@ -640,9 +640,17 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
     const char* e = getenv("FLVIS_EVENT_SCOPE");
     if (e && !strcmp(e, "agent")) pl->ev_flags |= hipEventReleaseToDevice;
     const char* j = getenv("FLVIS_JOIN");
-    pl->flag_joins = !(j && !strcmp(j, "event"));
+    pl->flag_joins = !(j && !strcmp(j, "event"));  // (default since round 6: 58.6k -> 60.4k frames/s, chain p50 1.047 -> 1.012 ms; "event": rounds 1-5)
+    // Under a profiler that collects hardware counters (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION in the application's environment)
+    // kernels run ONE AT A TIME: a k_wait_flag that sleeps until a kernel of another stream has stored its word would wait for a kernel
+    // that cannot start, and end by its 4 s limit.  Events are resolved by the command processor between kernels: taken there unless
+    // FLVIS_JOIN says otherwise.  (The wait for an upload is not affected: the copy engine runs beside a serialised kernel.)
+    if (!j) {
+      const char* cc = getenv("ROCPROF_COUNTER_COLLECTION");
+      if (cc && cc[0] && strcmp(cc, "0") && strcmp(cc, "False") && strcmp(cc, "false")) pl->flag_joins = false;
+    }
     const char* f = getenv("FLVIS_JOIN_FOLD");
-    pl->fold_joins = pl->flag_joins && !(f && atoi(f) == 0);  // (default since round 6: 58.6k -> 60.4k frames/s, chain p50 1.047 -> 1.012 ms; "event": rounds 1-5)
+    pl->fold_joins = pl->flag_joins && !(f && atoi(f) == 0);
   }
   const int S = n_streams;
   pl->S = S;
