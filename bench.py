@@ -738,7 +738,9 @@ def main():
                 out["roofline"]["kernels_note"] = (
                     "avg_launch_ms: HIP events of this run (epilogue frames); counters / rocprof_avg_launch_ms: %s; valu_issue_frac against "
                     "%.1f G wave-instructions/s (1024 SIMDs x 2.4 GHz / 4); k_ba_worker: SURVEY 8d's flop formula on the kernel's own trial / "
-                    "observation / landmark counters, time = the kernel's wall clock per optimisation"
+                    "observation / landmark counters, time = the kernel's wall clock per optimisation; k_ransac_pnp's event time is ~0.11 ms above its "
+                    "rocprof duration since the joins are folded into the kernels: with every stage bracketed by event packets (epilogue only) the "
+                    "corner response reaches the chip ahead of it -- the timed region carries no such packets (rocprof_avg_launch_ms is the kernel there)"
                     % (kpmc_src or "no PMC file matches this source tree (run `bench.py --pmc`)", rf.VALU_ISSUE_PEAK_GINST))
             except Exception as e:  # noqa: BLE001
                 out.setdefault("leg_errors", []).append("kernel table: %s: %s" % (type(e).__name__, e))
