@@ -43,6 +43,7 @@ from flvis_amd import bench_plan as plan  # noqa: E402  (pure python, no GPU)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
 ROUND_TAG = "r06"
+H2D_LEG_FRAMES = 60
 
 # algorithmic HBM bytes per launch of the image-scan kernels for ONE stream, 640x480:
 PYR_BYTES = 307200 + 76800 + 19200 + 4800          # one pyramid (levels 0..3)
@@ -432,7 +433,7 @@ def main():
     cfg = flvis_amd.load_config(ypath)
     skip = cfg.skip_first_n_imgs
     epi = 0 if args.no_epilogue else plan.EPILOGUE
-    nmax = plan.max_frames(K, Wm, skip, epilogue=epi)
+    nmax = plan.max_frames(K, Wm, skip, epilogue=epi) + (0 if args.no_h2d else H2D_LEG_FRAMES + 4)   # (+ the host-image leg's own frames)
     # multi-lane trackers run on their own streams: a private context stream keeps torch's (null) stream out of the frame loop;
     # the rendered inputs are synchronised explicitly below
     own_stream = int(os.environ.get("FLVIS_LANES", "1") or 1) > 1 or os.environ.get("FLVIS_BENCH_OWN_STREAM", "0") != "0"   # (A/B knob)
@@ -791,7 +792,8 @@ def leg_h2d(L):
     WU = 4                       # untimed calls in front: the first one allocates the device staging buffers and the copy stream, and ONE
                                  # of the first three takes 75-85 ms on this stack (lazy set-up inside the runtime; which one varies from run
                                  # to run: profiles/r04_lk_ab.md) -- inside the clock it halved the leg's rate in one run of four
-    n = min(max(K, 40), 60) + WU  # (>= 40 frames: the start-up and the local map's tail after the last frame weigh less)
+    n = H2D_LEG_FRAMES + WU      # (60 frames whatever K is: the local map's drain after the last frame -- ~2.5 ms, inside the clock -- weighs the same in
+                                 # every line; round 6's first driver-argument line had 40 frames and read 0.92 x where the 60-frame line read 0.995 x)
     f0 = sched["n_frames"]
     if f0 + n > imu.shape[0]:
         n = imu.shape[0] - f0
