@@ -62,6 +62,20 @@ __device__ __forceinline__ void kj_wait(const KJ& kj) {
   __syncthreads();
 }
 template <typename KJ>
+__device__ __forceinline__ void kj_post_wait(const KJ& kj) {
+  if (!kj.post) return;
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(kj.post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < kj.post_seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 400000000ull) {
+        if (kj.err) __hip_atomic_store(kj.err, kj.post_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+}
+template <typename KJ>
 __device__ __forceinline__ void kj_signal(const KJ& kj) {
   if (!kj.sig) return;
   __syncthreads();

@@ -16,6 +16,11 @@ struct KJoin {
   long long sig_seq;
   unsigned* sig_cnt;  // arrival counter of the signalling launch's workgroups (the last one puts it back to 0)
   long long* err;     // host-mapped word that receives the sequence number of a wait that gave up (~4 s), or null
+  // a word the kernel waits for BEHIND its work (thread 0 of every workgroup, loads only): the kernel does not end before another
+  // stream's result is there, and the launch that follows it on its stream -- an LK launch, which cannot carry a wait itself: thousands of
+  // sleeping workgroups would keep a producer off the chip -- needs no k_wait_flag in front.  The next kernel's own acquire orders the data.
+  const long long* post;
+  long long post_seq;
 };
 
 

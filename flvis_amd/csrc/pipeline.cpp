@@ -991,6 +991,16 @@ static bool fold_wait(Pipeline* pl, Lane* L, hipEvent_t ev, KJoin& kj, int slot)
   return true;
 }
 
+// ... or keeps the launch from ENDING before the word is there (KJoin::post): the launch behind it needs no wait of its own
+static bool fold_post(Pipeline* pl, Lane* L, hipEvent_t ev, KJoin& kj) {
+  const int id = pl->fold_joins ? join_id(L, ev) : -1;
+  if (id < 0) return false;
+  kj.post = L->d_join + 8 * id;
+  kj.post_seq = L->join_seq[id];
+  kj.err = L->d_progress + 2;
+  return true;
+}
+
 static void launch_local_map(Pipeline* pl, Lane* L, hipEvent_t ev, bool record, hipEvent_t* prof_begin_end) {
   const int bi = (L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba;
   hipStream_t bs = pl->ba_stream[bi];
@@ -1178,6 +1188,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   static const bool head_prepare_knob = !(getenv("FLVIS_HEAD_PREPARE") && atoi(getenv("FLVIS_HEAD_PREPARE")) == 0);
   const bool head_prepare = head_prepare_knob && !pl->feedback_used && !skipped;
   const bool head_signals = !pl->feedback_used && fold_signal(pl, L, L->ev_head, p.kj);  // (the head kernel is the last one in front of the signal)
+  // ... and it does not end before the left pyramid is there (the temporal LK follows it, directly or behind k_track_prepare)
+  const bool head_posts = !skipped && !head_on_det && fold_post(pl, L, L->ev_img, p.kj);
   if (head_prepare) launch_frame_head_prepare(s_head, p, L->d_time, L->d_progress, frame_no);
   else launch_frame_head(s_head, p, L->d_time, L->d_progress, frame_no);
   p.kj = KJoin{};
@@ -1212,7 +1224,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(3, st);
   if (!head_prepare) launch_track_prepare(st, p);
   PE(3, st);
-  if (!head_on_det) join_wait(pl, L, st, L->ev_img);  // join: the left pyramid
+  if (!head_on_det && !head_posts) join_wait(pl, L, st, L->ev_img);  // join: the left pyramid
   // fork: the right pyramid (first used by the stereo matcher) and the corner detection of the new left image (speculative
   // for tracking frames: used only if tracking succeeds) run beside the temporal tracking chain.  The right image is only
   // read within this frame, so without equalizeHist the caller's buffer IS level 0 of the right pyramid (no copy).
@@ -1351,14 +1363,21 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PB(13, st);
   launch_feature_dem(st, w, h, S, p.cam.dem, L->dem_sorted, L->dem_roff, 2 * p.cam.gftt_num, p.det_mode, p.exist_xy, p.n_exist, NMAX,
                      p.new_xy, p.n_new, NEW_MAX, &dem_kj);
+  // k_add_new (one wave per stream) stores the word the two-view triangulation waits for: that kernel reads the landmarks as k_add_new leaves
+  // them and nothing k_depth_seeds writes
+  const bool an_signals = fold_signal(pl, L, L->ev_lm, p.kj);
   launch_add_new(st, p);
+  p.kj = KJoin{};
   PE(13, st);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
   PB(14, st);
-  // (not folded: k_depth_seeds and k_depth_triangulate are 256 workgroups each -- every workgroup's release is a write-back of its XCD's
-  // L2, and beside the stereo LK's template stores the kernels doubled their time: 5.9 -> 12.7 us, 87 -> 180 us)
-  const bool ds_signals = false;
+  // (k_depth_seeds and k_depth_triangulate store no word themselves: 256 workgroups each -- every workgroup's release is a write-back of its
+  // XCD's L2, and beside the stereo LK's template stores the kernels doubled their time: 5.9 -> 12.7 us, 87 -> 180 us)
+  const bool ds_signals = an_signals;
+  // ... and k_depth_seeds does not end before the right pyramid is there (the stereo LK follows it)
+  const bool seeds_post = gftt_first && !pyramid_main && fold_post(pl, L, L->ev_det, p.kj);
   launch_depth_seeds(st, p);
+  p.kj = KJoin{};
   PE(14, st);
   // the two-view triangulation that k_depth_innovate consumes: on the detection stream (idle by now), under the stereo LK
   if (!ds_signals) join_signal(pl, L, L->ev_lm, st);
@@ -1366,7 +1385,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   const bool tri_signals = false;
   launch_depth_triangulate(ds, p);
   if (!tri_signals) join_signal(pl, L, L->ev_tri, ds);
-  if (gftt_first && !pyramid_main) join_wait(pl, L, st, L->ev_det);
+  if (gftt_first && !pyramid_main && !seeds_post) join_wait(pl, L, st, L->ev_det);
   PB(15, st);
   if (!depth_cam) {
     PyrSel prev, next;

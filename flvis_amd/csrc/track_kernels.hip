@@ -234,6 +234,7 @@ __global__ __launch_bounds__(64) void k_frame_head(Pipe p, const double* __restr
   kj_wait(p.kj);
   k_frame_head_body(p, frame_time, host_progress, frame_no);
   kj_signal(p.kj);
+  kj_post_wait(p.kj);
 }
 __device__ inline void frame_begin_dev(const Pipe& p, int s, double time) {
   StreamState& st = p.st[s];
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(256) void k_frame_head_prepare(Pipe p, const double
   kj_wait(p.kj);
   k_frame_head_prepare_body(p, frame_time, host_progress, frame_no);
   kj_signal(p.kj);
+  kj_post_wait(p.kj);
 }
 
 // ------------------------------------------------------------------------------------------------ LK survivors
@@ -2170,7 +2172,7 @@ __global__ void k_vi_correction(Pipe p) {
 }
 
 // ------------------------------------------------------------------------------------------------ new landmarks
-__global__ __launch_bounds__(64) void k_add_new(Pipe p) {
+__device__ __forceinline__ void k_add_new_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
@@ -2214,6 +2216,11 @@ __global__ __launch_bounds__(64) void k_add_new(Pipe p) {
     st.n_new = nn;
   }
 }
+__global__ __launch_bounds__(64) void k_add_new(Pipe p) {
+  kj_wait(p.kj);
+  k_add_new_body(p);
+  kj_signal(p.kj);
+}
 
 // ------------------------------------------------------------------------------------------------ depth: inputs
 // Two kernels, because only the first is on the critical path: the stereo matcher needs its seeds; the two-view triangulation of
@@ -2253,6 +2260,7 @@ __global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
   kj_wait(p.kj);
   k_depth_seeds_body(p);
   kj_signal(p.kj);
+  kj_post_wait(p.kj);
 }
 __device__ __forceinline__ void k_depth_triangulate_body(const Pipe& p) {
   chain_priority();
