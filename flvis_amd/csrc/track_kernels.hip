@@ -1056,20 +1056,6 @@ __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
 // closing's geometric check loads caller arrays) and is entered by the WHOLE workgroup; only wave 0 returns with the result.
 constexpr int RP_T = 512;
 constexpr int PNP_GN_ROW = 29;
-// sum over one DPP row (16 lanes) into its lane 0 in a fixed order: lane i += lane i + 8, + 4, + 2, + 1 (sources beyond the row read as 0)
-template <int CTRL>
-__device__ __forceinline__ double dpp_row_shl(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row16_sum_to_lane0(double v) {
-  v += dpp_row_shl<0x108>(v);
-  v += dpp_row_shl<0x104>(v);
-  v += dpp_row_shl<0x102>(v);
-  v += dpp_row_shl<0x101>(v);
-  return v;
-}
 // PnPRansacCallback has no checkSubset and every run starts from cv::RNG((uint64)-1): the subsets of a run depend on the number of
 // correspondences alone.  The first batch of either branch (8 subsets of 5 / 16 subsets of 4) is therefore tabulated per count at start-up
 // (host, the same generator and getSubset loop), together with the generator state behind it, and a kernel whose search ends within the
@@ -1556,7 +1542,7 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
       }
     }
   }
-  // (every wave stays: the refinement's sums use the whole workgroup)
+  if (wv != 0) return;  // final refinement: one wave
   if (!have_final) {
     T = iterative ? guess : se3_identity();
     if (iterative) T = se3_from_mat(q_to_mat(T.q), T.t);
@@ -1570,20 +1556,16 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
     }
   } else if (found) {
     inliers = ctl[1];
-    // Gauss-Newton refinement on the inliers (stand-in for OpenCV's final solvePnP).  The 21 + 6 normal-equation sums (round 6): thread i
-    // computes the terms of correspondence i (zeros for an outlier); 16 consecutive correspondences are summed by the fixed tree of a DPP
-    // row ((x0 + x8) + (x4 + x12)) + ... ; the row sums are then added in row order by one thread per term -- the CPU restatement sums the same
-    // way (pnp_refine), `make -C oracle REF_ORDER=g2o` keeps the point-after-point order.  Every thread then solves the same 6 x 6.
-    // (Rounds 3-5: one wave, the terms of 64 correspondences at a time through LDS, 27 lanes adding 64 values each in order: 33 us per call.)
+    // Gauss-Newton refinement on the inliers (stand-in for OpenCV's final solvePnP).  The 21 + 6 normal-equation sums are
+    // SEQUENTIAL sums over the inliers in index order (as the CPU restatement adds them): lane l computes the terms of
+    // correspondence 64 c + l into an LDS row, lanes 0..26 then each add one column of the chunk in order.
     constexpr int GN_ROW = PNP_GN_ROW;
     SE3d Tb = g2o_from_mat(R, t);
-    const int nrows = (np + 15) >> 4;
     for (int it = 0; it < 10; it++) {
-      for (int base = 0; base < np; base += RP_T) {
-        const int i = base + tid;
-        double tm[27];
-#pragma unroll
-        for (int k = 0; k < 27; k++) tm[k] = 0.0;
+      double sum = 0;
+      for (int c0 = 0; c0 < np; c0 += 64) {
+        const int i = c0 + lane;
+        double* row = gterms + lane * GN_ROW;
         if (i < np && smask[i]) {
           double e[2], J[2][6];
           proj_edge(Tb, V3{(double)s3d[3 * i], (double)s3d[3 * i + 1], (double)s3d[3 * i + 2]}, (double)s2d[2 * i],
@@ -1591,26 +1573,32 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
           int q = 0;
 #pragma unroll
           for (int r = 0; r < 6; r++) {
-            tm[21 + r] = -(J[0][r] * e[0] + J[1][r] * e[1]);  // b[r] -= J^T e
+            row[21 + r] = J[0][r] * e[0] + J[1][r] * e[1];
 #pragma unroll
-            for (int c = r; c < 6; c++) tm[q++] = J[0][r] * J[0][c] + J[1][r] * J[1][c];
+            for (int c = r; c < 6; c++) row[q++] = J[0][r] * J[0][c] + J[1][r] * J[1][c];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 27; k++) row[k] = 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 27) {
+          const double* col = gterms + lane;
+          if (lane < 21) {
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) sum += col[k * GN_ROW];
+          } else {
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) sum -= col[k * GN_ROW];  // b[r] -= J^T e
           }
         }
-#pragma unroll
-        for (int k = 0; k < 27; k++) tm[k] = row16_sum_to_lane0(tm[k]);
-        if ((lane & 15) == 0 && (i >> 4) < nrows) {
-          double* row = gterms + (i >> 4) * GN_ROW;
-#pragma unroll
-          for (int k = 0; k < 27; k++) row[k] = tm[k];
-        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
       }
-      __syncthreads();
-      if (tid < 27) {
-        double sum = 0;
-        for (int r = 0; r < nrows; r++) sum += gterms[r * GN_ROW + tid];
-        gn[tid] = sum;
-      }
-      __syncthreads();
+      if (lane < 27) gn[lane] = sum;
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       double H[36], b[6], dx[6];
       int q = 0;
 #pragma unroll
@@ -1623,7 +1611,8 @@ __device__ __forceinline__ void pnp_ransac_core(const PnpShared sh, const int np
           q++;
         }
       }
-      __syncthreads();  // (everybody has read gn and the row sums before the next pass rewrites them)
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
       if (!solve_spd6(H, b, dx)) break;
       // CvLevMarq's termination test (relative change of the six parameters below FLT_EPSILON), on the increment
       const double pn = 4.0 * (Tb.q.x * Tb.q.x + Tb.q.y * Tb.q.y + Tb.q.z * Tb.q.z) + (Tb.t.x * Tb.t.x + Tb.t.y * Tb.t.y + Tb.t.z * Tb.t.z);

@@ -635,50 +635,17 @@ static inline void proj_edge(const SE3& T, Vec3 pw, Vec2 z, double fx, double fy
   }
 }
 
-// Gauss-Newton refinement of T on the inliers (stand-in for OpenCV's final solvePnP on them).  The normal-equation sums (round 6): the terms of
-// 16 consecutive correspondences of the FULL list (an outlier contributes zeros) are summed by a fixed tree -- x[i] += x[i + 8], += x[i + 4],
-// += x[i + 2], += x[i + 1]: what a DPP row of the device adds -- and the row sums then in row order; `make -C oracle REF_ORDER=g2o` keeps the
-// point-after-point order OpenCV's MulTransposed has (one "row" holds every point).
-static void pnp_refine(SE3& T, const float* p3d, const float* p2d, const uint8_t* mask, int n, double fx, double fy, double cx, double cy) {
+// Gauss-Newton refinement of T on the given correspondences (stand-in for OpenCV's final solvePnP on the inliers)
+static void pnp_refine(SE3& T, const std::vector<Vec3>& pw, const std::vector<Vec2>& z, double fx, double fy, double cx,
+                       double cy) {
   for (int it = 0; it < 10; it++) {
-    double acc[27] = {0};
-    auto terms = [&](int i, double* tm) {
-      for (int k = 0; k < 27; k++) tm[k] = 0.0;
-      if (i >= n || !mask[i]) return;
+    double H[36] = {0}, b[6] = {0};
+    for (size_t i = 0; i < pw.size(); i++) {
       double e[2], J[2][6];
-      proj_edge(T, {(double)p3d[3 * i], (double)p3d[3 * i + 1], (double)p3d[3 * i + 2]}, {(double)p2d[2 * i], (double)p2d[2 * i + 1]}, fx, fy, cx, cy,
-                e, J);
-      int q = 0;
+      proj_edge(T, pw[i], z[i], fx, fy, cx, cy, e, J);
       for (int r = 0; r < 6; r++) {
-        tm[21 + r] = -(J[0][r] * e[0] + J[1][r] * e[1]);
-        for (int c = r; c < 6; c++) tm[q++] = J[0][r] * J[0][c] + J[1][r] * J[1][c];
-      }
-    };
-#ifdef FLVIS_REF_ORDER_G2O
-    for (int i = 0; i < n; i++) {
-      if (!mask[i]) continue;
-      double tm[27];
-      terms(i, tm);
-      for (int k = 0; k < 27; k++) acc[k] += tm[k];
-    }
-#else
-    for (int base = 0; base < n; base += 16) {
-      double v[16][27];
-      for (int i = 0; i < 16; i++) terms(base + i, v[i]);
-      for (int off = 8; off >= 1; off >>= 1)
-        for (int i = 0; i < off; i++)
-          for (int k = 0; k < 27; k++) v[i][k] += v[i + off][k];
-      for (int k = 0; k < 27; k++) acc[k] += v[0][k];
-    }
-#endif
-    double H[36], b[6];
-    int q = 0;
-    for (int r = 0; r < 6; r++) {
-      b[r] = acc[21 + r];
-      for (int c = r; c < 6; c++) {
-        H[6 * r + c] = acc[q];
-        H[6 * c + r] = acc[q];
-        q++;
+        b[r] -= J[0][r] * e[0] + J[1][r] * e[1];
+        for (int c = 0; c < 6; c++) H[6 * r + c] += J[0][r] * J[0][c] + J[1][r] * J[1][c];
       }
     }
     double dx[6];
@@ -860,7 +827,7 @@ int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, doubl
     }
   }
 #endif
-  pnp_refine(Tb, p3d, p2d, mask, n, fx, fy, cx, cy);
+  pnp_refine(Tb, pw, z, fx, fy, cx, cy);
   // SE3_from_rvec_tvec: Rodrigues(rvec) -> R -> SE3(R,t)   (common.h:151-158)
   T = se3_from_mat(quat_to_mat(Tb.q), Tb.t);
   return maxGood;
