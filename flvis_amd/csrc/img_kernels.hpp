@@ -71,7 +71,9 @@ struct LKParams {
   // tracker of frame t + 1 needs exactly that template (previous image = that image, previous point = that pixel).  tc_mode 1: every
   // point p < tc_cap stores its templates in slot p, with the position bits and tc_tag[s] in the slot's header.  tc_mode 2: the caller
   // has compared the headers already (lk_tc_lookup): tc_slot[s * nmax + p] = slot | (mask of the levels stored << 16) if the slot was
-  // written for this very position of the image tagged tc_tag[s], else -1 (the point computes its templates).
+  // written for this very position of the image tagged tc_tag[s], else -1 (the point computes its templates).  tc_mode 3 (the stereo
+  // launch behind launch_lk_templates_ahead, role 4): tc_slot as in mode 2, or -(slot + 2): the point computes its templates and stores
+  // them in that slot.
   // HBM capacity and bandwidth (idle on this path) spent to save the VALU work that bounds the kernel.
   uint32_t* tc = nullptr;             // [S][tc_cap][tc_stride]
   int tc_mode = 0, tc_cap = 0, tc_stride = 0;
@@ -149,9 +151,14 @@ void launch_feature_dem(hipStream_t st, int w, int h, int S, DemParams prm, cons
 // pyramidal LK, 31x31 window: one wave per (stream, point)
 // max_pts: upper bound of count[] known to the caller (sizes the grid; any value is correct, the kernel strides), <= 0: nmax
 // role: 0 stand-alone call, 1 the tracker's temporal launch, 2 its stereo launch (kernel instances k_lk_track<role>: named apart in
-// the profiles; only <1> reads and only <2> writes the template cache)
+// the profiles; <1> reads and <2> writes the template cache), 4 the stereo launch that takes the templates launch_lk_templates_ahead
+// made and stores those of the other points (tc_mode 3)
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
                      uint8_t* status, const int* count, int nmax, int S, LKParams prm, const int* active, int max_pts = 0, int role = 0);
+// the templates of the points pts[s][0 .. count[s]) of the pyramid `img`, on every level, into the cache slots 0 .. count[s] - 1 of stream s
+// with (position bits, tag[s], mask of the levels stored) in the header: what a later LK launch with tc_mode 2 / 3 finds there
+void launch_lk_templates_ahead(hipStream_t st, const PyrSel& img, const float* pts, const int* count, int nmax, int S, uint32_t* tc, int tc_cap,
+                               int tc_stride, const long long* tag, int max_pts);
 
 // recover3DPts_c_FromStereo on caller arrays (stereo_depth.hip): the rig constants the two kernels need, and their launchers
 struct flvis_sd_cam {

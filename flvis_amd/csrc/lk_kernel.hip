@@ -315,6 +315,29 @@ __device__ __noinline__ void lk_template_level_cold(const uint8_t* img, int W, i
   out->a22 = a22;
 }
 
+// one level's templates into a cache slot: the 24 template registers of the 64 lanes as six 1 KB rows; lane 63 (window row 31: no template)
+// carries the three Hessian sums in the place of its tI registers
+__device__ __forceinline__ void lk_tc_store_level(uint32_t* tc_ptr, int level, int lane, const lk_s2 (&tI)[8], const lk_s2 (&tX)[8],
+                                                  const lk_s2 (&tY)[8], long long iA11, long long iA12, long long iA22) {
+  lk_u4* dst = reinterpret_cast<lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
+  uint32_t wI[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) wI[k] = __builtin_bit_cast(uint32_t, tI[k]);
+  if (lane == 63) {
+    wI[0] = (uint32_t)iA11; wI[1] = (uint32_t)((unsigned long long)iA11 >> 32);
+    wI[2] = (uint32_t)iA12; wI[3] = (uint32_t)((unsigned long long)iA12 >> 32);
+    wI[4] = (uint32_t)iA22; wI[5] = (uint32_t)((unsigned long long)iA22 >> 32);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    __builtin_nontemporal_store(lk_u4{wI[4 * k], wI[4 * k + 1], wI[4 * k + 2], wI[4 * k + 3]}, dst + 64 * k);
+    __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tX[4 * k]), __builtin_bit_cast(uint32_t, tX[4 * k + 1]),
+                                      __builtin_bit_cast(uint32_t, tX[4 * k + 2]), __builtin_bit_cast(uint32_t, tX[4 * k + 3])}, dst + 64 * (2 + k));
+    __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tY[4 * k]), __builtin_bit_cast(uint32_t, tY[4 * k + 1]),
+                                      __builtin_bit_cast(uint32_t, tY[4 * k + 2]), __builtin_bit_cast(uint32_t, tY[4 * k + 3])}, dst + 64 * (4 + k));
+  }
+}
+
 // Base address of one pyramid level for stream s.  The slot choice cur[s] (a global load the compiler may not hoist: memory could have
 // changed) is read ONCE per wave and passed in: every level of a pyramid that selects by slot shares one slot array (fill_pyr); ind0 =
 // the already loaded base of an indirect level 0.  A level then costs kernel-argument reads only, no dependent global round trip.
@@ -335,7 +358,8 @@ __device__ __forceinline__ const uint8_t* lk_level_ptr(const PyrSel& P, int leve
 #endif
 // 4 waves per SIMD (<= 128 VGPRs): this kernel is latency-bound (PMC: VALU busy ~20%), occupancy is what pays
 // ROLE names the launch in the profiles and fixes what the template cache may do: 0 the stand-alone entry point (no cache), 1 the
-// tracker's temporal launch (may take templates from the cache), 2 its stereo launch (may store them)
+// tracker's temporal launch (may take templates from the cache), 2 its stereo launch (may store them), 4 the stereo launch fed by
+// k_lk_templates_ahead (tc_mode 3: takes the templates that kernel made for the tracked landmarks, computes and stores the others)
 template <int ROLE>
 __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& next, const float* __restrict__ prev_pts,
                                               float* __restrict__ next_pts, uint8_t* __restrict__ status,
@@ -388,13 +412,17 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
         tc_store = true;
         tc_ptr = prm.tc + ((size_t)s * prm.tc_cap + p) * prm.tc_stride;
       }
-    } else if (ROLE == 1 && prm.tc_mode == 2) {
-      // the caller has compared the slot's header (position bits, tag) with this point: code = slot | (mask of stored levels << 16), or -1
+    } else if ((ROLE == 1 && prm.tc_mode == 2) || (ROLE == 4 && prm.tc_mode == 3)) {
+      // the caller has compared the slot's header (position bits, tag) with this point: code = slot | (mask of stored levels << 16), or -1;
+      // tc_mode 3: or -(slot + 2), the slot a point without templates stores its own in
       const int code = __builtin_amdgcn_readfirstlane(prm.tc_slot[(size_t)s * nmax + p]);
       if (code >= 0 && (code & 0xffff) < prm.tc_cap) {
         tc_ptr = prm.tc + ((size_t)s * prm.tc_cap + (code & 0xffff)) * prm.tc_stride;
         tc_hit = true;
         tc_mask = (uint32_t)code >> 16;
+      } else if (ROLE == 4 && code <= -2 && -code - 2 < prm.tc_cap) {
+        tc_ptr = prm.tc + ((size_t)s * prm.tc_cap + (-code - 2)) * prm.tc_stride;
+        tc_store = true;
       }
     }
     lk_u4 pq[6] = {};  // templates of level pq_level, in flight or arrived (-1: none)
@@ -435,7 +463,7 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
       // position), or computed: stage source patch rows ipy-1..ipy+32, cols ipx-1..ipx+34, Scharr + bilinear interpolation
       lk_s2 tI[8], tX[8], tY[8];  // pixel pairs (c, c+1)
       long long iA11, iA12, iA22;
-      const bool cached = ROLE == 1 && tc_hit && ((tc_mask >> level) & 1u);
+      const bool cached = (ROLE == 1 || ROLE == 4) && tc_hit && ((tc_mask >> level) & 1u);
       if (cached) {
         if (prm.stats_tc && lane == 0) atomicAdd(&prm.stats_tc[0], 1ull);
         if (pq_level != level) {  // (the top level, or the level above did not get this far)
@@ -470,7 +498,7 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
           tY[4 * k + 0] = lk_as_s2(q[4 + k].x); tY[4 * k + 1] = lk_as_s2(q[4 + k].y);
           tY[4 * k + 2] = lk_as_s2(q[4 + k].z); tY[4 * k + 3] = lk_as_s2(q[4 + k].w);
         }
-      } else if (ROLE == 1) {
+      } else if (ROLE == 1 || ROLE == 4) {
         LKTmpl T;
         lk_template_level_cold(lk_level_ptr(prev, level, s, kc_prev, ind_prev0), W, H, prev.pitch[level], prev.bx[level], prev.by[level], ipx, ipy, iw00,
                                iw01, iw10, iw11, patch, lane, &T);
@@ -483,6 +511,10 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
         iA11 = T.a11;
         iA12 = T.a12;
         iA22 = T.a22;
+        if (ROLE == 4 && tc_store) {
+          lk_tc_store_level(tc_ptr, level, lane, tI, tX, tY, iA11, iA12, iA22);
+          tc_mask |= 1u << level;
+        }
       } else {
         const bool slow = lk_template_level(lk_level_ptr(prev, level, s, kc_prev, ind_prev0), W, H, prev.pitch[level], prev.bx[level], prev.by[level], ipx,
                                             ipy, iw00, iw01, iw10, iw11, patch, lane, tI, tX, tY, iA11, iA12, iA22);
@@ -490,24 +522,7 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
 #ifndef FLVIS_LK_NO_TC_STORE  // (timing-only build variant: is the stereo launch bound by its template-cache stores?  the next frame's temporal
                               //  launch then finds no templates; results unchanged -- profiles/r05_lk_ab.md)
         if (ROLE == 2 && tc_store) {
-          lk_u4* dst = reinterpret_cast<lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
-          // lane 63 (window row 31: no template) carries the three Hessian sums in the place of its tI registers
-          uint32_t wI[8];
-#pragma unroll
-          for (int k = 0; k < 8; k++) wI[k] = __builtin_bit_cast(uint32_t, tI[k]);
-          if (lane == 63) {
-            wI[0] = (uint32_t)iA11; wI[1] = (uint32_t)((unsigned long long)iA11 >> 32);
-            wI[2] = (uint32_t)iA12; wI[3] = (uint32_t)((unsigned long long)iA12 >> 32);
-            wI[4] = (uint32_t)iA22; wI[5] = (uint32_t)((unsigned long long)iA22 >> 32);
-          }
-#pragma unroll
-          for (int k = 0; k < 2; k++) {
-            __builtin_nontemporal_store(lk_u4{wI[4 * k], wI[4 * k + 1], wI[4 * k + 2], wI[4 * k + 3]}, dst + 64 * k);
-            __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tX[4 * k]), __builtin_bit_cast(uint32_t, tX[4 * k + 1]),
-                                              __builtin_bit_cast(uint32_t, tX[4 * k + 2]), __builtin_bit_cast(uint32_t, tX[4 * k + 3])}, dst + 64 * (2 + k));
-            __builtin_nontemporal_store(lk_u4{__builtin_bit_cast(uint32_t, tY[4 * k]), __builtin_bit_cast(uint32_t, tY[4 * k + 1]),
-                                              __builtin_bit_cast(uint32_t, tY[4 * k + 2]), __builtin_bit_cast(uint32_t, tY[4 * k + 3])}, dst + 64 * (4 + k));
-          }
+          lk_tc_store_level(tc_ptr, level, lane, tI, tX, tY, iA11, iA12, iA22);
           tc_mask |= 1u << level;
         }
 #endif
@@ -615,7 +630,7 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
       next_pts[pi] = nx;
       next_pts[pi + 1] = ny;
       status[(size_t)s * nmax + p] = (uint8_t)st;
-      if (ROLE == 2 && tc_store) {
+      if ((ROLE == 2 || ROLE == 4) && tc_store) {
         tc_ptr[0] = __float_as_uint(ppx0);
         tc_ptr[1] = __float_as_uint(ppy0);
         *reinterpret_cast<long long*>(tc_ptr + 2) = prm.tc_tag[s];
@@ -642,6 +657,89 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAV
   lk_track_body<2>(prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
 }
 
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAVES_T, FLVIS_LK_WAVES_T))) void k_lk_track_stereo_fed(
+    PyrSel prev, PyrSel next, const float* __restrict__ prev_pts, float* __restrict__ next_pts, uint8_t* __restrict__ status,
+    const int* __restrict__ count, int nmax, LKParams prm, const int* __restrict__ active) {
+  lk_track_body<4>(prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+}
+
+// The templates of a frame's tracked landmarks, made AHEAD of the stereo matcher (round 6).  recover3DPts_c_FromStereo's LK call
+// (camera_frame.cpp:124-128) takes its templates at the landmarks' pixels in the frame's left image; for a landmark the temporal tracker
+// has just followed into this frame that pixel is known as soon as LKORBTracking's optical flow is (lkorb_tracking.cpp:64-73), ~0.4 ms
+// before the stereo matcher runs -- and the kernels in between (the two RANSACs, the pose optimisation, the outlier filter) are one
+// workgroup per stream on a quarter of the CUs.  This kernel computes those templates there, on a low-priority stream of its own, into
+// the cache slots the stereo launch (ROLE 4) and the next frame's temporal launch read: slot j = the survivor's index in the frame
+// (k_track_collect), header = position bits, frame id, mask of the levels stored.  Same code, same arithmetic as the stereo launch's own
+// template stage (lk_template_level): the results of the tracker do not change by a bit.  One wave per (stream, point), XCD-aware map.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FLVIS_LK_WAVES, FLVIS_LK_WAVES))) void k_lk_templates_ahead(
+    PyrSel img, const float* __restrict__ pts, const int* __restrict__ count, int nmax, uint32_t* __restrict__ tc, int tc_cap, int tc_stride,
+    const long long* __restrict__ tag) {
+  int s = blockIdx.y, bx = blockIdx.x;
+  {
+    const int G = gridDim.x, N = G * gridDim.y;
+    if ((N & 7) == 0) {
+      const int L = bx + G * s;
+      const int Lp = (L & 7) * (N >> 3) + (L >> 3);
+      s = Lp / G;
+      bx = Lp - s * G;
+    }
+  }
+  int n = count[s];
+  if (n > nmax) n = nmax;
+  if (n > tc_cap) n = tc_cap;
+  if (bx >= n) return;
+  __shared__ __attribute__((aligned(16))) uint8_t patch[LK_RROWS * LK_RS + 12];
+  const int lane = threadIdx.x;
+  int kc = 0;
+#pragma unroll
+  for (int l = LK_MAX_LEVELS - 1; l >= 0; l--)
+    if (l <= img.levels && img.lvl[l].cur) kc = img.lvl[l].cur[s];
+  const uint8_t* const ind0 = img.lvl[0].ind ? *img.lvl[0].ind : nullptr;
+  const int W_BITS = 14;
+  const float halfWin = (LK_WIN - 1) * 0.5f;
+  for (int p = bx; p < n; p += gridDim.x) {
+    const size_t pi = ((size_t)s * nmax + p) * 2;
+    const float ppx0 = pts[pi], ppy0 = pts[pi + 1];
+    uint32_t* const tc_ptr = tc + ((size_t)s * tc_cap + p) * tc_stride;
+    uint32_t mask = 0;
+    for (int level = img.levels; level >= 0; level--) {
+      // (the position arithmetic of lk_track_body, operation for operation)
+      const float sc = (float)(1. / (1 << level));
+      float ppx = ppx0 * sc, ppy = ppy0 * sc;
+      const int W = img.w[level], H = img.h[level];
+      ppx -= halfWin;
+      ppy -= halfWin;
+      const int ipx = (int)floorf(ppx), ipy = (int)floorf(ppy);
+      if (ipx < -LK_WIN || ipx >= W || ipy < -LK_WIN || ipy >= H) continue;
+      const float a = ppx - (float)ipx, b = ppy - (float)ipy;
+      const int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+      const int iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
+      const int iw10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
+      const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+      lk_s2 tI[8], tX[8], tY[8];
+      long long iA11, iA12, iA22;
+      lk_template_level(lk_level_ptr(img, level, s, kc, ind0), W, H, img.pitch[level], img.bx[level], img.by[level], ipx, ipy, iw00, iw01, iw10,
+                        iw11, patch, lane, tI, tX, tY, iA11, iA12, iA22);
+      lk_tc_store_level(tc_ptr, level, lane, tI, tX, tY, iA11, iA12, iA22);
+      mask |= 1u << level;
+    }
+    if (lane == 0) {
+      tc_ptr[0] = __float_as_uint(ppx0);
+      tc_ptr[1] = __float_as_uint(ppy0);
+      *reinterpret_cast<long long*>(tc_ptr + 2) = tag[s];
+      tc_ptr[4] = mask;
+    }
+  }
+}
+
+void launch_lk_templates_ahead(hipStream_t st, const PyrSel& img, const float* pts, const int* count, int nmax, int S, uint32_t* tc, int tc_cap,
+                               int tc_stride, const long long* tag, int max_pts) {
+  int gx = nmax < 512 ? nmax : 512;
+  if (max_pts > 0 && max_pts < gx) gx = (max_pts + 7) & ~7;
+  if (gx > nmax) gx = nmax;
+  hipLaunchKernelGGL(k_lk_templates_ahead, dim3(gx, S), dim3(64), 0, st, img, pts, count, nmax, tc, tc_cap, tc_stride, tag);
+}
+
 int lk_tc_slot_dwords(int levels) { return LK_TC_HDR + (levels + 1) * LK_TC_LVL; }
 
 void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, const float* prev_pts, float* next_pts,
@@ -656,6 +754,8 @@ void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, con
     hipLaunchKernelGGL(k_lk_track_temporal, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
   else if (role == 2)
     hipLaunchKernelGGL(k_lk_track_stereo, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
+  else if (role == 4)
+    hipLaunchKernelGGL(k_lk_track_stereo_fed, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
   else
     hipLaunchKernelGGL(k_lk_track, dim3(gx, S), dim3(64), 0, st, prev, next, prev_pts, next_pts, status, count, nmax, prm, active);
 }

@@ -84,6 +84,10 @@ struct Lane {
   hipStream_t det_stream = nullptr;
   hipEvent_t ev_img = nullptr, ev_det = nullptr, ev_gftt = nullptr, ev_fe = nullptr, ev_lm = nullptr, ev_tri = nullptr, ev_head = nullptr;
   hipEvent_t ev_endf = nullptr;  // "k_frame_end has finished": the next frame's ingest and an immediate local-map launch wait for it (folded joins)
+  // templates ahead of the stereo matcher (FLVIS_TPL_AHEAD, round 6): k_lk_templates_ahead on a low-priority stream of its own, beside the
+  // one-workgroup-per-stream geometry kernels of the frame's chain; ev_tpl: "the frame's templates are in the cache" (k_depth_seeds waits)
+  hipStream_t tpl_stream = nullptr;
+  hipEvent_t ev_tpl = nullptr;
   bool endf_valid = false;       // the last k_frame_end carried that signal
   int idx = 0;  // position in Pipeline::lanes
   // multi-lane trackers: ev_end[n % HOLD_RING] follows the lane's n-th frame (the context's stream waits for the frame whose
@@ -100,7 +104,7 @@ struct Lane {
   // sequence number behind its last kernel (k_store_flag), the consuming stream waits for it with one sleeping lane (k_wait_flag).  An
   // event record is a system-scope barrier packet and a wait a barrier packet that polls the record's signal for as long as it is pending
   // (and slows the queues beside it, profiles/r06_h2d.md); a word in HBM costs two one-lane launches.
-  static constexpr int JOIN_IDS = 8 + BAQ;
+  static constexpr int JOIN_IDS = 9 + BAQ;
   long long* d_join = nullptr;             // [JOIN_IDS] words, 64 bytes apart
   unsigned* d_join_cnt = nullptr;          // [JOIN_IDS] arrival counters of the launches that signal a word themselves (KJoin)
   long long join_seq[JOIN_IDS] = {};
@@ -119,6 +123,7 @@ struct Pipeline {
   size_t lstride[LK_MAX_LEVELS];
   int lbx = 0, lby = 0;  // physical border of every pyramid level (columns / rows on each side)
   int max_pts = 0;  // bound on the landmarks of a frame (16 regions x max_region_feature_num): sizes the LK grid
+  int tpl_start = 1;  // FLVIS_TPL_START: where k_lk_templates_ahead starts (lane_frame)
   long long frames_fed = 0;
   std::vector<void*> allocs;  // context-level device allocations (host-feed staging)
   int prof_cap = 0, prof_step = 0;
@@ -139,6 +144,7 @@ struct Pipeline {
   int ba_every = 1;              // launch the local-map worker every n-th frame (FLVIS_BA_EVERY)
   bool lk_stats = false;         // flvis_debug_lk_stats: the LK launches count their iterations per level into counters[36 .. 59]
   hipStream_t ba_stream[NBA] = {};
+  std::vector<hipStream_t> pad_streams;  // idle streams in front of the lanes' template streams (FLVIS_TPL_QPAD)
   long long ba_rr = 0;           // round-robin counter over the local-map streams
   hipEvent_t ev_in = nullptr;    // the caller's inputs are ready (recorded on the context's stream)
   bool defer_ba = false;         // inside flvis_run_steps, not its last step: the local-map launch of this frame may wait for the next frame (FLVIS_BA_START)
@@ -297,6 +303,11 @@ static void lane_destroy(Lane* L) {
     hipStreamSynchronize(L->det_stream);
     hipStreamDestroy(L->det_stream);
   }
+  if (L->tpl_stream) {
+    hipStreamSynchronize(L->tpl_stream);
+    hipStreamDestroy(L->tpl_stream);
+  }
+  if (L->ev_tpl) hipEventDestroy(L->ev_tpl);
   if (L->own_st && L->st) hipStreamDestroy(L->st);
   for (hipEvent_t e : {L->ev_img, L->ev_det, L->ev_gftt, L->ev_fe, L->ev_lm, L->ev_tri, L->ev_head, L->ev_endf, L->ev_stagger, L->ev_end[0], L->ev_end[1], L->ev_end[2], L->ev_end[3],
                        L->ev_end[4], L->ev_end[5], L->ev_end[6], L->ev_end[7]})
@@ -336,6 +347,11 @@ extern "C" void flvis_pipeline_destroy_internal(flvis_ctx* ctx) {
   for (Lane* L : pl->lanes) lane_destroy(L);
   for (int k = 0; k < Pipeline::NBA; k++)
     if (pl->ba_stream[k]) hipStreamDestroy(pl->ba_stream[k]);
+  for (hipStream_t ps : pl->pad_streams) {
+    hipStreamSynchronize(ps);
+    hipStreamDestroy(ps);
+  }
+  pl->pad_streams.clear();
   if (pl->hf.strm) {
     hipStreamSynchronize(pl->hf.strm);
     hipStreamDestroy(pl->hf.strm);
@@ -414,6 +430,10 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   DA(lk_count, int, S);
   DA(lk_slot, int, (size_t)S * NMAX);
   DA(lk_tag, long long, S);
+  DA(tpl_pts, float, (size_t)S * NMAX * 2);
+  DA(tpl_count, int, S);
+  DA(tpl_tag, long long, S);
+  p.tpl_ahead = 0;
   DA(m1, float, (size_t)S * NMAX * 2);
   DA(m2, float, (size_t)S * NMAX * 2);
   DA(tri, double, (size_t)S * NMAX * 3);
@@ -513,8 +533,23 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   {
     const char* e = getenv("FLVIS_LK_TCACHE");
     const bool on = !(e && atoi(e) == 0) && pl->cfg.cam_type != CAM_DEPTH && pl->levels_s == pl->levels_t;
+    // FLVIS_TPL_AHEAD=1 (round 6, opt-in A/B knob; default 0 = rounds 4-5): the templates of the landmarks the temporal tracker has followed
+    // into the frame are computed by k_lk_templates_ahead beside the frame's geometry kernels, the stereo launch takes them from the cache
+    // (lane_frame).  Needs the corner detection behind the F-RANSAC (FLVIS_DET_START >= 2, the default): the signal that starts it starts
+    // this too.  Bit-identical results (test_templates_ahead_leave_the_same_results).  Measured (profiles/r06_templates_ahead.md): the
+    // stereo launch 0.259 -> 0.215 ms, and the kernels the template kernel runs beside pay it back -- k_ransac_pnp 0.187 -> 0.211 ms,
+    // k_gftt_pick 0.121 -> 0.157 ms (FeatureDEM then waits 25 us longer for the corners): 59.0k against 59.9k frames/s; and only with the
+    // template stream on a hardware queue of its own that does not share the main or the detection stream's pipe (FLVIS_TPL_QPAD,
+    // GPU_MAX_HW_QUEUES=8): 47.7k on the detection stream's pipe, 38.6k on the main stream's.
+    const char* ea = getenv("FLVIS_TPL_AHEAD");
+    const bool det_late = !(getenv("FLVIS_DET_START") && atoi(getenv("FLVIS_DET_START")) < 2) &&
+                          !(getenv("FLVIS_DET_ORDER") && atoi(getenv("FLVIS_DET_ORDER")) == 0);
+    const bool ahead = ea && atoi(ea) == 1 && det_late;
+    pl->tpl_start = getenv("FLVIS_TPL_START") && atoi(getenv("FLVIS_TPL_START")) == 0 ? 0 : 1;
     if (ok && on) {
-      const int cap = std::min(NMAX, (pl->max_pts + 63) / 64 * 64);
+      // slots: the stereo launch's points (rounds 4-5) or, with templates ahead, the survivors of the temporal tracker followed by the
+      // frame's new landmarks
+      const int cap = std::min(NMAX, (pl->max_pts + 63) / 64 * 64 * (ahead ? 2 : 1));
       L->tc_stride = lk_tc_slot_dwords(pl->levels_t);
       const size_t n = (size_t)S * cap * L->tc_stride;
       L->tc = dalloc<uint32_t>(L->allocs, n, false);
@@ -523,6 +558,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
         p.tc_cap = cap;
         p.tc = L->tc;
         p.tc_stride = L->tc_stride;
+        p.tpl_ahead = ahead ? 1 : 0;
       } else {
         (void)hipGetLastError();  // no memory for it: run without
       }
@@ -606,6 +642,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   } else {
     evok = hipStreamCreateWithFlags(&L->det_stream, hipStreamNonBlocking) == hipSuccess;
   }
+  if (L->pipe.tpl_ahead) evok = evok && hipEventCreateWithFlags(&L->ev_tpl, pl->ev_flags) == hipSuccess;  // (its stream: flvis_tracker_create)
   static_assert(Lane::HOLD_RING == 8, "event list below");  // (ev_endf included)
   for (hipEvent_t* e : {&L->ev_img, &L->ev_det, &L->ev_gftt, &L->ev_fe, &L->ev_lm, &L->ev_tri, &L->ev_head, &L->ev_endf, &L->ev_stagger, &L->ev_end[0], &L->ev_end[1], &L->ev_end[2],
                         &L->ev_end[3], &L->ev_end[4], &L->ev_end[5], &L->ev_end[6], &L->ev_end[7]})
@@ -718,6 +755,27 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   for (int k = 0; k < pl->nba && ok; k++)
     ok = hipStreamCreateWithPriority(&pl->ba_stream[k], hipStreamNonBlocking, prio_least) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&pl->ev_in, pl->ev_flags) == hipSuccess;
+  // the streams of k_lk_templates_ahead, created LAST and behind FLVIS_TPL_QPAD idle streams: a fifth compute queue shares a pipe of the
+  // command processor with one of the first four (queue i sits on pipe i mod 4 in creation order, profiles/r06_h2d.md), and whichever
+  // queue that is pays for the neighbour in every dispatch -- it must not be the main stream's
+  {
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (const char* e = getenv("FLVIS_TPL_PRIO")) lo = atoi(e);  // A/B knob
+    const int qpad = getenv("FLVIS_TPL_QPAD") ? std::max(0, std::min(atoi(getenv("FLVIS_TPL_QPAD")), 8)) : 2;
+    bool any = false;
+    for (Lane* L : pl->lanes) any = any || L->pipe.tpl_ahead;
+    for (int k = 0; k < qpad && ok && any; k++) {
+      hipStream_t ps = nullptr;
+      ok = hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, lo) == hipSuccess;
+      if (ok) {
+        pl->pad_streams.push_back(ps);
+        launch_store_progress(ps, pl->lanes[0]->d_progress + 1, 0);  // (a scratch word: the stream gets its hardware queue)
+      }
+    }
+    for (Lane* L : pl->lanes)
+      if (ok && L->pipe.tpl_ahead) ok = hipStreamCreateWithPriority(&L->tpl_stream, hipStreamNonBlocking, lo) == hipSuccess;
+  }
   if (!ok) {
     flvis_pipeline_destroy_internal(ctx);
     (void)hipGetLastError();
@@ -951,8 +1009,9 @@ static int join_id(const Lane* L, hipEvent_t ev) {
   if (ev == L->ev_tri) return 5;
   if (ev == L->ev_head) return 6;
   if (ev == L->ev_endf) return 7;
+  if (ev == L->ev_tpl) return 8;
   for (int k = 0; k < Lane::BAQ; k++)
-    if (ev == L->ev_ba_done[k]) return 8 + k;
+    if (ev == L->ev_ba_done[k]) return 9 + k;
   return -1;
 }
 // "stream s has reached this point" / "stream s goes on when that point has been reached": an event, or (FLVIS_JOIN=flag) a device word
@@ -1021,6 +1080,7 @@ static void sync_streams(flvis_ctx* ctx) {
   for (Lane* L : pl->lanes) {
     hipStreamSynchronize(L->st);
     hipStreamSynchronize(L->det_stream);
+    if (L->tpl_stream) hipStreamSynchronize(L->tpl_stream);
   }
   for (int k = 0; k < Pipeline::NBA; k++)
     if (pl->ba_stream[k]) hipStreamSynchronize(pl->ba_stream[k]);
@@ -1321,9 +1381,25 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     join_wait(pl, L, ds, L->ev_lm);
     right_pyramid();
   }
+  // templates ahead of the stereo matcher (lane_create: FLVIS_TPL_AHEAD): the survivors' pixels are known when k_track_collect has run.
+  // FLVIS_TPL_START (A/B knob): 1 (default) the kernel starts with the corner detection, behind the F-RANSAC, on that join's word;
+  // 0 behind k_track_collect, beside the F-RANSAC, on a word of its own (one more one-lane launch on the chain)
+  const int tpl_start = pl->tpl_start;
+  auto templates_ahead = [&] {
+    hipStream_t ts = L->tpl_stream;
+    join_wait(pl, L, ts, tpl_start == 1 ? L->ev_lm : L->ev_tpl);
+    PyrSel img;
+    fill_pyr(pl, img, L->pyr0[0], L->pyr0[1], p.img_slot, 0, pl->levels_s);
+    launch_lk_templates_ahead(ts, img, p.tpl_pts, p.tpl_count, NMAX, S, L->tc, p.tc_cap, L->tc_stride, p.tpl_tag, pl->max_pts);
+    join_signal(pl, L, L->ev_tpl, ts);
+  };
   PB(5, st);
   launch_track_collect(st, p);
   PE(5, st);
+  if (p.tpl_ahead && tpl_start == 0) {
+    join_signal(pl, L, L->ev_tpl, st);
+    templates_ahead();
+  }
   if (first_processed && pl->lanes.size() > 1) hipEventRecord(L->ev_stagger, st);
   PB(6, st);
   const bool rf_signals = gftt_first && gftt_after_lk >= 2 && fold_signal(pl, L, L->ev_lm, p.kj);
@@ -1332,6 +1408,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   PE(6, st);
   if (gftt_first && gftt_after_lk >= 2) {
     if (!rf_signals) join_signal(pl, L, L->ev_lm, st);
+    if (p.tpl_ahead && tpl_start == 1) templates_ahead();
     join_wait(pl, L, ds, L->ev_lm);
     detect_corners();
     if (pyramid_late) right_pyramid();
@@ -1376,6 +1453,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   const bool ds_signals = an_signals;
   // ... and k_depth_seeds does not end before the right pyramid is there (the stereo LK follows it)
   const bool seeds_post = gftt_first && !pyramid_main && fold_post(pl, L, L->ev_det, p.kj);
+  // ... and with templates ahead it looks them up: they must be there
+  if (p.tpl_ahead && !fold_wait(pl, L, L->ev_tpl, p.kj, 0)) join_wait(pl, L, st, L->ev_tpl);
   launch_depth_seeds(st, p);
   p.kj = KJoin{};
   PE(14, st);
@@ -1400,12 +1479,14 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     if (pl->lk_stats) prm.stats_tc = reinterpret_cast<unsigned long long*>(p.counters) + 61;
     if (L->tc) {  // ... which stores its templates for the next frame's temporal tracker
       prm.tc = L->tc;
-      prm.tc_mode = 1;
+      prm.tc_mode = p.tpl_ahead ? 3 : 1;  // (3: takes those k_lk_templates_ahead made, k_depth_seeds has looked the slots up)
       prm.tc_cap = p.tc_cap;
       prm.tc_stride = L->tc_stride;
       prm.tc_tag = p.lk_tag;
+      prm.tc_slot = p.lk_slot;
     }
-    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts, 2);
+    launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts,
+                    L->tc && p.tpl_ahead ? 4 : 2);
   }
   PE(15, st);
   const bool inn_waits = fold_wait(pl, L, L->ev_tri, p.kj, 0);

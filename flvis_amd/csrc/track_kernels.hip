@@ -395,13 +395,17 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
   chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
-  if (st.phase != PH_TRACK) return;
+  if (st.phase != PH_TRACK) {
+    if (p.tpl_ahead && threadIdx.x == 0) p.tpl_count[s] = 0;
+    return;
+  }
   const int lane = threadIdx.x;
   const int cur = st.cur, last = cur ^ 1;
   const int n = st.n_lm[last];
   const Landmark* from = lm_ptr(p, last, s);
   Landmark* to = lm_ptr(p, cur, s);
   const float* tr = p.next_pts + (size_t)s * NMAX * 2;
+  float* const tpl = p.tpl_ahead ? p.tpl_pts + (size_t)s * NMAX * 2 : nullptr;
   const uint8_t* status = p.lk_status + (size_t)s * NMAX;
   const int w = p.cam.w - 1, h = p.cam.h - 1;
   // total survivors
@@ -436,6 +440,11 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
       lm.p2d[1] = (double)ty;
       lm.p2u[0] = (double)und[0];
       lm.p2u[1] = (double)und[1];
+      if (tpl) {  // the templates of this pixel of the frame's left image go to cache slot j (k_lk_templates_ahead)
+        lm.tslot = j < p.tc_cap ? (short)j : (short)-1;
+        tpl[2 * j] = tx;
+        tpl[2 * j + 1] = ty;
+      }
       to[j] = lm;
       float* m1 = p.m1 + ((size_t)s * NMAX + k) * 2;
       float* m2 = p.m2 + ((size_t)s * NMAX + k) * 2;
@@ -451,6 +460,10 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
     st.n_surv = total;
     st.of_cnt = total;
     if (total < 10) st.ok = 0;
+    if (tpl) {
+      p.tpl_count[s] = total < 10 ? 0 : total;  // (a frame that fails here never reaches the stereo matcher)
+      p.tpl_tag[s] = st.frame_id[cur];
+    }
   }
 }
 
@@ -2240,12 +2253,30 @@ __device__ __forceinline__ void k_depth_seeds_body(const Pipe& p) {
   if (i >= n) return;
   if (p.cam.cam_type == CAM_DEPTH) return;  // the measurement comes from the depth image, no stereo matching
   Landmark& lm = lm_ptr(p, cur, s)[i];
-  lm.tslot = i < p.tc_cap ? (short)i : (short)-1;  // where the stereo LK stores point i's templates (read back by the next frame's temporal LK)
   // stereo LK seeds (camera_frame.cpp:108-122)
   float* p0 = p.prev_pts + ((size_t)s * NMAX + i) * 2;
   float* p1 = p.next_pts + ((size_t)s * NMAX + i) * 2;
   p0[0] = (float)lm.p2d[0];
   p0[1] = (float)lm.p2d[1];
+  if (!p.tpl_ahead) {
+    lm.tslot = i < p.tc_cap ? (short)i : (short)-1;  // where the stereo LK stores point i's templates (read back by the next frame's temporal LK)
+  } else {
+    // templates made ahead (k_lk_templates_ahead) are in the slot the landmark has carried since k_track_collect; a landmark without them
+    // (new in this frame: behind the n_old older ones) gets a slot behind the survivors' and the stereo launch fills it
+    int code = lk_tc_lookup(p.tc, p.tc_cap, p.tc_stride, s, lm.tslot, p0[0], p0[1], st.frame_id[cur]);
+    if (code < 0) {
+      const int n_old = n - st.n_new, base = p.det_mode[s] == 2 ? st.n_surv : 0;
+      const int slot = i >= n_old ? base + (i - n_old) : (int)lm.tslot;
+      if (slot >= 0 && slot < p.tc_cap) {
+        code = -(slot + 2);
+        lm.tslot = (short)slot;
+      } else {
+        code = -1;
+        lm.tslot = -1;
+      }
+    }
+    p.lk_slot[(size_t)s * NMAX + i] = code;
+  }
   if (lm.has3d) {
     const SE3d T = load_pose7(st.T_c_w[cur]);
     SE3d T1c = se3_mul(load_pose7(p.cam.T_c1_c0), T);

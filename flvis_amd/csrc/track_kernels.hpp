@@ -25,6 +25,12 @@ struct Pipe {
   int tc_cap;               // slots per stream of the lane's template cache (0: no cache)
   const uint32_t* tc;       // the cache itself (k_track_prepare compares the slot headers) and its slot size in dwords
   int tc_stride;
+  // templates ahead of the stereo matcher (round 6, lk_kernel.hip k_lk_templates_ahead): k_track_collect leaves the survivors' pixels, their
+  // count and the frame's id here and gives survivor j the cache slot j; k_depth_seeds looks the slots up for the stereo launch
+  int tpl_ahead;            // 0: the stereo launch computes every template itself (rounds 4-5)
+  float* tpl_pts;           // [S][NMAX][2]
+  int* tpl_count;           // [S]
+  long long* tpl_tag;       // [S]
   float* m1;                // [S][NMAX][2]  F-RANSAC inputs (ascending survivors)
   float* m2;
   double* tri;              // [S][NMAX][3]

@@ -1110,6 +1110,48 @@ def test_stream_join_forms_leave_the_same_results(ctx, monkeypatch):
         _assert_same_run(ref, r, key)
 
 
+def test_templates_ahead_leave_the_same_results(ctx, monkeypatch):
+    """Round 6: the stereo matcher's templates of the landmarks the temporal tracker has followed into the frame are computed AHEAD, by
+    k_lk_templates_ahead on a stream of its own beside the frame's geometry kernels, and the stereo launch takes them from the cache
+    (FLVIS_TPL_AHEAD=1, an opt-in knob: measured, not faster -- profiles/r06_templates_ahead.md).  With them, with the kernel started behind
+    k_track_collect instead of behind the F-RANSAC (FLVIS_TPL_START=0), with event joins, and without them (the default: rounds 4-5) a
+    run must leave the same trajectories, landmarks, CorrectionInf and counters, bit for bit -- frame by frame and in batches."""
+    import flvis_amd
+    cfg, _ = _cfgs()
+    S, nframes = 8, 50 + 36
+    frames = _mode_frames(S, nframes, [5 + 3 * i for i in range(S)])
+    res = {}
+    knobs = ("FLVIS_TPL_AHEAD", "FLVIS_TPL_START", "FLVIS_JOIN")
+    for name, env in (("off", {}), ("ahead", {"FLVIS_TPL_AHEAD": "1"}), ("start0", {"FLVIS_TPL_AHEAD": "1", "FLVIS_TPL_START": "0"}),
+                      ("event", {"FLVIS_TPL_AHEAD": "1", "FLVIS_JOIN": "event"})):
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for feed in ("frames", "batches"):
+            trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715, traj_capacity=nframes)
+            if feed == "frames":
+                for (i0, i1, ts, cnt, blk) in frames:
+                    for i in range(S):
+                        trk.imu_feed_flvis(i, blk[i, :cnt[i]])
+                    trk.image_feed(i0, i1, ts, want_out=False, with_local_map=True)
+            else:
+                f = 0
+                for nb in (50, 1, 5, 2, nframes):
+                    nb = min(nb, nframes - f)
+                    if nb > 0:
+                        trk.run_steps(frames[f:f + nb], with_local_map=True)
+                    f += nb
+            res[(name, feed)] = _mode_result(trk, ctx, S, nframes)
+            del trk
+    for k in knobs:
+        monkeypatch.delenv(k, raising=False)
+    ref = res[("off", "frames")]
+    assert np.all((ref[0][:, 50:, 8].astype(int) & 15) == 1) and ref[4].sum() > 2 * S and ref[5].sum() >= 1
+    for key, r in res.items():
+        _assert_same_run(ref, r, key)
+
+
 def test_host_feed_upload_forms_leave_the_same_results(ctx, monkeypatch):
     """flvis_image_feed_host, mode 2 (round 6: nothing but copies on the copy stream -- a sequence block behind the images, k_wait_flag on the
     ingesting stream, host-side slot gating over three staging slots) against mode 1 (FLVIS_H2D_MODE=1: events on the copy stream, two
