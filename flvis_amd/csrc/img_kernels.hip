@@ -1352,12 +1352,12 @@ void launch_gftt(hipStream_t st, ImgSel src, int w, int h, int pitch, size_t sst
     hipMemsetAsync(sc.nkeys, 0, sizeof(int) * S, st);
   }
   if (ev) hipEventRecord(ev[0], st);
-  // which kernel computes the corner response: the wave walk (eig_walk.hip) with 120 rows per chunk unless FLVIS_EIG_WALK=<rows> says
+  // which kernel computes the corner response: the wave walk (eig_walk.hip) with 60 rows per chunk unless FLVIS_EIG_WALK=<rows> says
   // otherwise; FLVIS_EIG_WALK=0 selects the LDS-tile kernel k_eig_cand, FLVIS_EIG_WALK=0 FLVIS_EIG_STRIP=1 its strip-mined form (both
   // kept for the A/B of profiles/r03_eig_walk_ab.md and as independent implementations in the parity tests)
   static const int variant_rows = [] {
     const char* e = getenv("FLVIS_EIG_WALK");
-    if (!e) return 120;
+    if (!e) return 60;
     if (atoi(e) > 0) return atoi(e);
     e = getenv("FLVIS_EIG_STRIP");
     return (e && atoi(e) != 0) ? -2 : -1;

@@ -124,6 +124,7 @@ struct Pipeline {
   int lbx = 0, lby = 0;  // physical border of every pyramid level (columns / rows on each side)
   int max_pts = 0;  // bound on the landmarks of a frame (16 regions x max_region_feature_num): sizes the LK grid
   int tpl_start = 1;  // FLVIS_TPL_START: where k_lk_templates_ahead starts (lane_frame)
+  int chain_merge = 3;  // FLVIS_CHAIN_MERGE: launches of the frame's chain folded into their neighbours (lane_frame)
   long long frames_fed = 0;
   std::vector<void*> allocs;  // context-level device allocations (host-feed staging)
   int prof_cap = 0, prof_step = 0;
@@ -736,6 +737,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   if (const char* e = getenv("FLVIS_LANE_STAGGER")) pl->stagger = atoi(e) != 0;
   if (const char* e = getenv("FLVIS_HOST_LEAD")) pl->host_lead = std::max(1, std::min(atoi(e), (int)Lane::PIN_RING));
   if (const char* e = getenv("FLVIS_SYNC_EACH_FRAME")) pl->sync_each_frame = atoi(e) != 0;
+  if (const char* e = getenv("FLVIS_CHAIN_MERGE")) pl->chain_merge = atoi(e) & 3;
   if (const char* e = getenv("FLVIS_BA_EVERY")) {
     int v = atoi(e);
     if (v >= 1 && v <= KFQ / 4) pl->ba_every = v;  // (the back-pressure in lane_frame needs (D + 2) * ba_every <= KFQ / 2)
@@ -1393,8 +1395,13 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     launch_lk_templates_ahead(ts, img, p.tpl_pts, p.tpl_count, NMAX, S, L->tc, p.tc_cap, L->tc_stride, p.tpl_tag, pl->max_pts);
     join_signal(pl, L, L->ev_tpl, ts);
   };
+  // FLVIS_CHAIN_MERGE (round 6; bits, default 3): launches of the frame's chain folded into their neighbours -- every launch on the chain is
+  // ~8 us of dispatch, ramp and drain whatever it computes.  Bit 0: k_add_new + k_depth_seeds as one launch (a barrier between them);
+  // bit 1: k_track_collect as the prologue of k_ransac_f (and by sixteen waves instead of one).  0: rounds 1-5's launches.
+  const int chain_merge = pl->chain_merge;
+  const bool merge_collect = (chain_merge & 2) && !(p.tpl_ahead && tpl_start == 0);
   PB(5, st);
-  launch_track_collect(st, p);
+  if (!merge_collect) launch_track_collect(st, p);
   PE(5, st);
   if (p.tpl_ahead && tpl_start == 0) {
     join_signal(pl, L, L->ev_tpl, st);
@@ -1403,7 +1410,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   if (first_processed && pl->lanes.size() > 1) hipEventRecord(L->ev_stagger, st);
   PB(6, st);
   const bool rf_signals = gftt_first && gftt_after_lk >= 2 && fold_signal(pl, L, L->ev_lm, p.kj);
-  launch_ransac_f(st, p);
+  launch_ransac_f(st, p, merge_collect);
   p.kj = KJoin{};
   PE(6, st);
   if (gftt_first && gftt_after_lk >= 2) {
@@ -1443,8 +1450,11 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   // k_add_new (one wave per stream) stores the word the two-view triangulation waits for: that kernel reads the landmarks as k_add_new leaves
   // them and nothing k_depth_seeds writes
   const bool an_signals = fold_signal(pl, L, L->ev_lm, p.kj);
-  launch_add_new(st, p);
-  p.kj = KJoin{};
+  const bool merge_seeds = (chain_merge & 1) != 0;  // (k_add_new_seeds carries both launches' joins)
+  if (!merge_seeds) {
+    launch_add_new(st, p);
+    p.kj = KJoin{};
+  }
   PE(13, st);
   // depth innovation: stereo LK img0 -> img1 + DLT + IIR
   PB(14, st);
@@ -1455,7 +1465,8 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   const bool seeds_post = gftt_first && !pyramid_main && fold_post(pl, L, L->ev_det, p.kj);
   // ... and with templates ahead it looks them up: they must be there
   if (p.tpl_ahead && !fold_wait(pl, L, L->ev_tpl, p.kj, 0)) join_wait(pl, L, st, L->ev_tpl);
-  launch_depth_seeds(st, p);
+  if (merge_seeds) launch_add_new_seeds(st, p);
+  else launch_depth_seeds(st, p);
   p.kj = KJoin{};
   PE(14, st);
   // the two-view triangulation that k_depth_innovate consumes: on the detection stream (idle by now), under the stereo LK

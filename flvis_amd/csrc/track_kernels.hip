@@ -390,16 +390,17 @@ __global__ __launch_bounds__(256) void k_frame_head_prepare(Pipe p, const double
 
 // ------------------------------------------------------------------------------------------------ LK survivors
 // lkorb_tracking.cpp:93-125: survivors are appended in DESCENDING index order (quirk A1); the parallel from_* arrays
-// keep ascending order.  One wave per stream.
-__global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
-  chain_priority();
-  const int s = blockIdx.x;
+// keep ascending order.  Entered by a whole workgroup of T threads (a multiple of 64): every wave takes chunks of 64 landmarks, the chunks'
+// survivor counts meet in LDS.  k_track_collect (one wave per stream) is the stand-alone launch; since round 6 the work is the prologue
+// of k_ransac_f (FLVIS_CHAIN_MERGE bit 1: one launch less on the frame's chain, sixteen waves instead of one).
+template <int T>
+__device__ __forceinline__ void track_collect_dev(const Pipe& p, int s, int* s_cnt /* [NMAX / 64 + 1] LDS */) {
   StreamState& st = p.st[s];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (st.phase != PH_TRACK) {
-    if (p.tpl_ahead && threadIdx.x == 0) p.tpl_count[s] = 0;
+    if (p.tpl_ahead && tid == 0) p.tpl_count[s] = 0;
     return;
   }
-  const int lane = threadIdx.x;
   const int cur = st.cur, last = cur ^ 1;
   const int n = st.n_lm[last];
   const Landmark* from = lm_ptr(p, last, s);
@@ -408,18 +409,25 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
   float* const tpl = p.tpl_ahead ? p.tpl_pts + (size_t)s * NMAX * 2 : nullptr;
   const uint8_t* status = p.lk_status + (size_t)s * NMAX;
   const int w = p.cam.w - 1, h = p.cam.h - 1;
-  // total survivors
-  int total = 0;
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    bool pass = i < n && status[i] == 1 && tr[2 * i] > 0 && tr[2 * i + 1] > 0 && tr[2 * i] < (float)w && tr[2 * i + 1] < (float)h;
-    total += __popcll(__ballot(pass));
+  constexpr int NCH = NMAX / 64;
+  // survivors per chunk of 64
+  for (int c = wv; c < NCH; c += T / 64) {
+    const int i = 64 * c + lane;
+    const bool pass = i < n && status[i] == 1 && tr[2 * i] > 0 && tr[2 * i + 1] > 0 && tr[2 * i] < (float)w && tr[2 * i + 1] < (float)h;
+    const int cnt = __popcll(__ballot(pass));
+    if (lane == 0) s_cnt[c] = cnt;
   }
-  int before = 0;  // survivors with smaller index than this chunk
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    bool pass = i < n && status[i] == 1 && tr[2 * i] > 0 && tr[2 * i + 1] > 0 && tr[2 * i] < (float)w && tr[2 * i + 1] < (float)h;
-    unsigned long long b = __ballot(pass);
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++) total += s_cnt[c];
+  for (int c = wv; c < NCH; c += T / 64) {
+    if (64 * c >= n) break;
+    int before = 0;  // survivors with smaller index than this chunk
+    for (int k = 0; k < c; k++) before += s_cnt[k];
+    const int i = 64 * c + lane;
+    const bool pass = i < n && status[i] == 1 && tr[2 * i] > 0 && tr[2 * i + 1] > 0 && tr[2 * i] < (float)w && tr[2 * i + 1] < (float)h;
+    const unsigned long long b = __ballot(pass);
     if (pass) {
       int k = before + lane_prefix(b);  // ascending rank
       int j = total - 1 - k;            // position in to.landmarks (descending)
@@ -453,9 +461,8 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
       m2[0] = und[0];
       m2[1] = und[1];
     }
-    before += __popcll(b);
   }
-  if (lane == 0) {
+  if (tid == 0) {
     st.n_lm[cur] = total;
     st.n_surv = total;
     st.of_cnt = total;
@@ -465,6 +472,11 @@ __global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
       p.tpl_tag[s] = st.frame_id[cur];
     }
   }
+}
+__global__ __launch_bounds__(64) void k_track_collect(Pipe p) {
+  chain_priority();
+  __shared__ int s_cnt[NMAX / 64 + 1];
+  track_collect_dev<64>(p, blockIdx.x, s_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------ F-matrix RANSAC
@@ -513,10 +525,16 @@ __device__ unsigned long long g_f_rng7[F_TAB_N][F_TAB_B];
 #define FLVIS_RF_T 1024
 #endif
 constexpr int RF_T = FLVIS_RF_T;  // (A/B knob: 256 or 512 threads leave room for the detection stream's waves on the workgroup's CU)
+template <bool COLLECT>
 __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
   StreamState& st = p.st[s];
+  if (COLLECT) {  // k_track_collect's work as this launch's prologue: the survivors, m1 / m2, the stream's counts
+    __shared__ int s_cnt[NMAX / 64 + 1];
+    track_collect_dev<RF_T>(p, s, s_cnt);
+    __syncthreads();  // (workgroup scope: what thread 0 and the copying lanes stored is what everybody reads below)
+  }
   if (st.phase != PH_TRACK || !st.ok) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef FLVIS_RANSAC_PROF
@@ -1052,7 +1070,12 @@ __device__ __forceinline__ void k_ransac_f_body(const Pipe& p) {
 }
 __global__ __launch_bounds__(RF_T) void k_ransac_f(Pipe p) {
   kj_wait(p.kj);
-  k_ransac_f_body(p);
+  k_ransac_f_body<false>(p);
+  kj_signal(p.kj);
+}
+__global__ __launch_bounds__(RF_T) void k_collect_ransac_f(Pipe p) {
+  kj_wait(p.kj);
+  k_ransac_f_body<true>(p);
   kj_signal(p.kj);
 }
 
@@ -2185,6 +2208,7 @@ __global__ void k_vi_correction(Pipe p) {
 }
 
 // ------------------------------------------------------------------------------------------------ new landmarks
+template <int T>
 __device__ __forceinline__ void k_add_new_body(const Pipe& p) {
   chain_priority();
   const int s = blockIdx.x;
@@ -2199,7 +2223,7 @@ __device__ __forceinline__ void k_add_new_body(const Pipe& p) {
   if (n0 + nn > NMAX) nn = NMAX - n0;
   const float* xy = p.new_xy + (size_t)s * NEW_MAX * 2;
   const bool as_inlier = (mode == 1) ? true : (st.orig_size < 60);
-  for (int k = lane; k < nn; k += 64) {
+  for (int k = lane; k < nn; k += T) {
     float src[2] = {xy[2 * k], xy[2 * k + 1]};
     float und[2] = {src[0], src[1]};
     // init_frame undistorts in both stereo modes, redetect only in STEREO_UNRECT, DEPTH_D435 never (f2f_tracking.cpp:294-304,410-437)
@@ -2231,21 +2255,17 @@ __device__ __forceinline__ void k_add_new_body(const Pipe& p) {
 }
 __global__ __launch_bounds__(64) void k_add_new(Pipe p) {
   kj_wait(p.kj);
-  k_add_new_body(p);
+  k_add_new_body<64>(p);
   kj_signal(p.kj);
 }
 
 // ------------------------------------------------------------------------------------------------ depth: inputs
 // Two kernels, because only the first is on the critical path: the stereo matcher needs its seeds; the two-view triangulation of
 // recover3DPts_c_FromTriangulation is consumed by k_depth_innovate and runs beside the stereo LK on the detection stream.
-__device__ __forceinline__ void k_depth_seeds_body(const Pipe& p) {
-  chain_priority();
-  const int s = blockIdx.y;
+__device__ __forceinline__ void depth_seed_dev(const Pipe& p, int s, int i) {
   const StreamState& st = p.st[s];
-  if (p.det_mode[s] == 0) return;
   const int cur = st.cur;
   const int n = st.n_lm[cur];
-  const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0) {
     p.lk_count[s] = n;
     p.lk_tag[s] = st.frame_id[cur];  // the stereo matcher's templates come from this frame's left image
@@ -2287,9 +2307,28 @@ __device__ __forceinline__ void k_depth_seeds_body(const Pipe& p) {
     p1[1] = p0[1];
   }
 }
+__device__ __forceinline__ void k_depth_seeds_body(const Pipe& p) {
+  chain_priority();
+  const int s = blockIdx.y;
+  if (p.det_mode[s] == 0) return;
+  depth_seed_dev(p, s, blockIdx.x * 256 + threadIdx.x);
+}
 __global__ __launch_bounds__(256) void k_depth_seeds(Pipe p) {
   kj_wait(p.kj);
   k_depth_seeds_body(p);
+  kj_signal(p.kj);
+  kj_post_wait(p.kj);
+}
+// k_add_new and k_depth_seeds in one launch (round 6, FLVIS_CHAIN_MERGE bit 0): one workgroup of 256 threads per stream, the seeds behind a
+// barrier instead of behind a launch
+__global__ __launch_bounds__(256) void k_add_new_seeds(Pipe p) {
+  kj_wait(p.kj);
+  const int s = blockIdx.x;
+  if (p.det_mode[s] != 0) {  // (uniform per workgroup)
+    k_add_new_body<256>(p);
+    __syncthreads();  // (workgroup scope: the landmarks and the count as the threads above left them)
+    for (int i = threadIdx.x; i < NMAX; i += 256) depth_seed_dev(p, s, i);
+  }
   kj_signal(p.kj);
   kj_post_wait(p.kj);
 }
@@ -2646,7 +2685,10 @@ void launch_track_prepare(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_track_prepare, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
 }
 void launch_track_collect(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_track_collect, dim3(p.S), dim3(64), 0, st, p); }
-void launch_ransac_f(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_f, dim3(p.S), dim3(RF_T), 0, st, p); }
+void launch_ransac_f(hipStream_t st, const Pipe& p, bool with_collect) {
+  if (with_collect) hipLaunchKernelGGL(k_collect_ransac_f, dim3(p.S), dim3(RF_T), 0, st, p);
+  else hipLaunchKernelGGL(k_ransac_f, dim3(p.S), dim3(RF_T), 0, st, p);
+}
 void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_pnp, dim3(p.S), dim3(RP_T), 0, st, p); }
 int pnp_ransac_max_points() { return PNP_MAXN; }
 static hipError_t pnp_tables_init();
@@ -2733,6 +2775,7 @@ void launch_add_new(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_add_ne
 void launch_depth_seeds(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_depth_seeds, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
 }
+void launch_add_new_seeds(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_add_new_seeds, dim3(p.S), dim3(256), 0, st, p); }
 void launch_depth_triangulate(hipStream_t st, const Pipe& p) {
   hipLaunchKernelGGL(k_depth_triangulate, dim3(NMAX / 256, p.S), dim3(256), 0, st, p);
 }

@@ -105,7 +105,7 @@ void launch_frame_head_prepare(hipStream_t st, const Pipe& p, const double* d_ti
 void launch_apply_correction(hipStream_t st, const Pipe& p);
 void launch_track_prepare(hipStream_t st, const Pipe& p);
 void launch_track_collect(hipStream_t st, const Pipe& p);
-void launch_ransac_f(hipStream_t st, const Pipe& p);
+void launch_ransac_f(hipStream_t st, const Pipe& p, bool with_collect = false);  // (with_collect: k_track_collect's work as its prologue)
 void launch_ransac_pnp(hipStream_t st, const Pipe& p);
 void launch_track_post(hipStream_t st, const Pipe& p);
 void launch_pose_lm(hipStream_t st, const Pipe& p);
@@ -113,6 +113,7 @@ void launch_reproj_filter(hipStream_t st, const Pipe& p);
 void launch_vi_correction(hipStream_t st, const Pipe& p);  // viCorrectionFromVision of the streams k_reproj_filter marked
 void launch_add_new(hipStream_t st, const Pipe& p);
 void launch_depth_seeds(hipStream_t st, const Pipe& p);        // stereo-LK seeds of the current landmarks (critical path)
+void launch_add_new_seeds(hipStream_t st, const Pipe& p);      // the two above in one launch
 void launch_depth_triangulate(hipStream_t st, const Pipe& p);  // two-view triangulation for k_depth_innovate (beside the stereo LK)
 void launch_depth_innovate(hipStream_t st, const Pipe& p);
 void launch_frame_end(hipStream_t st, const Pipe& p);

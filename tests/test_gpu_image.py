@@ -286,9 +286,9 @@ def test_corner_response_sqrt_is_correctly_rounded(ctx):
     assert ctx.debug_sqrt_check(0x00800000, 1 << 20) > 0     # (outside the domain the two do differ: the check is not vacuous)
 
 
-@pytest.mark.parametrize("walk", ["60", "0"])
+@pytest.mark.parametrize("walk", ["120", "0"])
 def test_gftt_parity_with_the_other_response_kernels(walk):
-    """The corner-response pass inside flvis_hip_gftt / FeatureDEM is the wave walk with 120 rows per chunk; FLVIS_EIG_WALK=<rows>
+    """The corner-response pass inside flvis_hip_gftt / FeatureDEM is the wave walk with 60 rows per chunk (120 until round 6); FLVIS_EIG_WALK=<rows>
     changes the chunk height, FLVIS_EIG_WALK=0 selects the LDS-tile kernel.  The switch is read once per process, so the parity tests
     of this file are re-run in a child process with it set: the same corners, bit for bit."""
     import os

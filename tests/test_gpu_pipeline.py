@@ -1152,6 +1152,42 @@ def test_templates_ahead_leave_the_same_results(ctx, monkeypatch):
         _assert_same_run(ref, r, key)
 
 
+def test_chain_merge_forms_leave_the_same_results(ctx, monkeypatch):
+    """Round 6: launches of the frame's chain folded into their neighbours (FLVIS_CHAIN_MERGE, bits: 1 = k_add_new + k_depth_seeds as one
+    launch, 2 = k_track_collect as the prologue of k_ransac_f, by sixteen waves instead of one; default 3).  Every combination must leave
+    the same trajectories, landmarks, CorrectionInf and counters as rounds 1-5's launches (0), bit for bit -- frame by frame and in batches."""
+    import flvis_amd
+    cfg, _ = _cfgs()
+    S, nframes = 8, 50 + 36
+    frames = _mode_frames(S, nframes, [2 + 5 * i for i in range(S)])
+    res = {}
+    for merge in ("0", "1", "2", "3", None):
+        monkeypatch.delenv("FLVIS_CHAIN_MERGE", raising=False)
+        if merge is not None:
+            monkeypatch.setenv("FLVIS_CHAIN_MERGE", merge)
+        for feed in ("frames", "batches"):
+            trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715, traj_capacity=nframes)
+            if feed == "frames":
+                for (i0, i1, ts, cnt, blk) in frames:
+                    for i in range(S):
+                        trk.imu_feed_flvis(i, blk[i, :cnt[i]])
+                    trk.image_feed(i0, i1, ts, want_out=False, with_local_map=True)
+            else:
+                f = 0
+                for nb in (50, 1, 5, 2, nframes):
+                    nb = min(nb, nframes - f)
+                    if nb > 0:
+                        trk.run_steps(frames[f:f + nb], with_local_map=True)
+                    f += nb
+            res[(merge, feed)] = _mode_result(trk, ctx, S, nframes)
+            del trk
+    monkeypatch.delenv("FLVIS_CHAIN_MERGE", raising=False)
+    ref = res[("0", "frames")]
+    assert np.all((ref[0][:, 50:, 8].astype(int) & 15) == 1) and ref[4].sum() > 2 * S and ref[5].sum() >= 1
+    for key, r in res.items():
+        _assert_same_run(ref, r, key)
+
+
 def test_host_feed_upload_forms_leave_the_same_results(ctx, monkeypatch):
     """flvis_image_feed_host, mode 2 (round 6: nothing but copies on the copy stream -- a sequence block behind the images, k_wait_flag on the
     ingesting stream, host-side slot gating over three staging slots) against mode 1 (FLVIS_H2D_MODE=1: events on the copy stream, two
