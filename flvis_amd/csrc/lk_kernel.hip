@@ -171,6 +171,54 @@ __device__ __forceinline__ long long lk_wave_sum_wide(int v) {
   return ((long long)hi << 16) + (long long)lo;
 }
 
+// Instruction diet of the iteration (round 6).  The LK launches are bound by INSTRUCTION ISSUE -- one instruction of any kind per 4 cycles
+// and SIMD, vector, scalar, LDS, wait and no-op alike (profiles/r06_chain_ab.md; SQ counters: 0.44 scalar instructions per vector one) --
+// not by latency: what shortens them is fewer instructions per iteration.  -DFLVIS_LK_DIET=0 keeps rounds 3-5's forms.
+#ifndef FLVIS_LK_DIET
+#define FLVIS_LK_DIET 1
+#endif
+// a . b + c with c in a SCALAR register (v_dot2_i32_i16, the three-source form): the rounding bias of a bilinear interpolation is a
+// constant, and the accumulate-in-place form the compiler picks for the builtin (v_dot2c_i32_i16) needs a v_mov of it per pixel
+__device__ __forceinline__ int lk_dot2_bias(lk_s2 a, lk_s2 b, int bias_uniform) {
+#if FLVIS_LK_DIET
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(bias_uniform));
+  return r;
+#else
+  return __builtin_amdgcn_sdot2(a, b, bias_uniform, false);
+#endif
+}
+// the exact wave totals of two per-lane int32 as floats, (float)(long long) of each (round to nearest even): the four 16-bit-half chains
+// advance together, step by step (every DPP step's operands were written four instructions earlier: no wait states to fill), and the
+// totals are put together in double -- hi * 65536 + lo is exact below 2^53, one rounding into float -- on the vector unit in lane 63
+// instead of ~13 scalar instructions per value (count leading zeros, shift, sticky bit, convert, scale); two read-lanes instead of four
+__device__ __forceinline__ void lk_wave_sum2_f32(int v1, int v2, float& f1, float& f2) {
+#if FLVIS_LK_DIET
+  int a = v1 & 0xffff, b = v1 >> 16, c = v2 & 0xffff, d = v2 >> 16;
+#define LK_STEP4(CTRL, RM)                                           \
+  {                                                                  \
+    const int ta = __builtin_amdgcn_update_dpp(0, a, CTRL, RM, 0xf, false); \
+    const int tb = __builtin_amdgcn_update_dpp(0, b, CTRL, RM, 0xf, false); \
+    const int tc = __builtin_amdgcn_update_dpp(0, c, CTRL, RM, 0xf, false); \
+    const int td = __builtin_amdgcn_update_dpp(0, d, CTRL, RM, 0xf, false); \
+    a += ta, b += tb, c += tc, d += td;                              \
+  }
+  LK_STEP4(0xB1, 0xf)   // quad_perm [1,0,3,2]
+  LK_STEP4(0x4E, 0xf)   // quad_perm [2,3,0,1]
+  LK_STEP4(0x141, 0xf)  // row_half_mirror
+  LK_STEP4(0x140, 0xf)  // row_mirror
+  LK_STEP4(0x142, 0xa)  // row_bcast:15, rows 1 and 3
+  LK_STEP4(0x143, 0xc)  // row_bcast:31, rows 2 and 3
+#undef LK_STEP4
+  const float g1 = (float)__builtin_fma((double)b, 65536.0, (double)a), g2 = (float)__builtin_fma((double)d, 65536.0, (double)c);
+  f1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1), 63));
+  f2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g2), 63));
+#else
+  f1 = (float)lk_wave_sum_wide(v1);
+  f2 = (float)lk_wave_sum_wide(v2);
+#endif
+}
+
 // The interpolated template of one level: I, Ix, Iy of the 31 x 31 window as packed int16 pairs in the lane's registers (lane = window
 // row lane >> 1, 16-column half lane & 1) and this lane's share of the three Hessian sums.  Packed 16-bit path: two columns per
 // instruction (v_pk_*), the bilinear weights applied with v_dot2c_i32_i16.  Every lane (window rows 0 .. 31: the lanes of row 31 only
@@ -242,12 +290,10 @@ __device__ __forceinline__ void lk_template(const uint8_t* patch, int lane, int 
           y0 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[0][c2 + 1]), __builtin_bit_cast(uint32_t, DY[0][c2]), 0x05040302u));
           y1 = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, DY[1][c2 + 1]), __builtin_bit_cast(uint32_t, DY[1][c2]), 0x05040302u));
         }
-        int ax = 1 << (W_BITS - 1), ay = 1 << (W_BITS - 1), ai = 1 << (W_BITS - 5 - 1);
-        ax = __builtin_amdgcn_sdot2(x0, wT, ax, false);
+        int ax = lk_dot2_bias(x0, wT, 1 << (W_BITS - 1)), ay = lk_dot2_bias(y0, wT, 1 << (W_BITS - 1));
+        int ai = lk_dot2_bias(__builtin_bit_cast(lk_s2, LK_PAIR(d[1], c + 1)), wT, 1 << (W_BITS - 5 - 1));
         ax = __builtin_amdgcn_sdot2(x1, wB, ax, false);
-        ay = __builtin_amdgcn_sdot2(y0, wT, ay, false);
         ay = __builtin_amdgcn_sdot2(y1, wB, ay, false);
-        ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[1], c + 1)), wT, ai, false);
         ai = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, LK_PAIR(d[2], c + 1)), wB, ai, false);
         const bool on = c0 + c < LK_WIN;  // window column 31 of the second half does not exist
         ix[hh] = on ? (ax >> W_BITS) : 0;
@@ -587,8 +633,7 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
             for (int hh = 0; hh < 2; hh++) {
               const int c = 2 * c2 + hh;
               const uint32_t pt = LK_PAIR(e[0], c), pb = LK_PAIR(e[1], c);
-              int acc = 1 << (W_BITS - 5 - 1);
-              acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, pt), wT, acc, false);
+              int acc = lk_dot2_bias(__builtin_bit_cast(lk_s2, pt), wT, 1 << (W_BITS - 5 - 1));
               acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, pb), wB, acc, false);
               iv[hh] = acc >> (W_BITS - 5);
             }
@@ -599,8 +644,9 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
             b2 = __builtin_amdgcn_sdot2(diff, tY[c2], b2, false);
           }
         }
-        const long long ib1 = lk_wave_sum_wide(b1), ib2 = lk_wave_sum_wide(b2);
-        const float fb1 = (float)ib1 * FLT_SCALE, fb2 = (float)ib2 * FLT_SCALE;
+        float sb1, sb2;
+        lk_wave_sum2_f32(b1, b2, sb1, sb2);
+        const float fb1 = sb1 * FLT_SCALE, fb2 = sb2 * FLT_SCALE;
         const float ddx = (A12 * fb2 - A22 * fb1) * D;
         const float ddy = (A12 * fb1 - A11 * fb2) * D;
         npx += ddx;
