@@ -320,6 +320,32 @@ def run_pmc(args):
         for k, v in per.items():
             t = second_half(v)
             kern.setdefault(k, {})[key] = sum(t) / len(t)
+    # ... and the other instruction classes in one pass of SQ counters (round 6: a SIMD issues ONE instruction of any class per 4 cycles --
+    # profiles/r06_chain_ab.md --, so a kernel's issue fraction is priced on all of them, not on the vector ones alone).  A counter the
+    # profiler does not know is dropped and the pass repeated without it; a pass that fails leaves the fields out.
+    others = [("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("SQ_INSTS_SMEM", "smem_insts"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"),
+              ("SQ_INSTS_VMEM_WR", "vmem_wr_insts")]
+    for attempt in range(len(others)):
+        d = tempfile.mkdtemp(prefix="flvis_pmc_insts_", dir="/tmp")
+        r = subprocess.run(["rocprofv3", "--pmc"] + [c for c, _ in others] + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base,
+                           cwd="/tmp", env=env_pmc, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode == 0 and files:
+            for ctr, key in others:
+                per = {}
+                for x in csv.DictReader(open(files[0])):
+                    if "flvis::" in x["Kernel_Name"] and x["Counter_Name"] == ctr:
+                        per.setdefault(short_kernel_name(x["Kernel_Name"]), []).append(float(x["Counter_Value"]))
+                for k, v in per.items():
+                    t = second_half(v)
+                    kern.setdefault(k, {})[key] = sum(t) / len(t)
+            break
+        txt = r.stdout.decode(errors="replace")
+        bad = [c for c, _ in others if c in txt[-4000:]]
+        sys.stderr.write("[pmc] instruction-class pass failed (rc %d)%s\n" % (r.returncode, ": dropping %s" % bad[0] if bad else ""))
+        if not bad or len(others) <= 2:
+            break
+        others = [o for o in others if o[0] != bad[0]]
     cal = read_calibration()
     if cal:   # known-byte probes on this hardware (scripts/pmc_calibrate.py): counter reading x factor = bytes
         for k in kern.values():
@@ -734,8 +760,16 @@ def main():
                         "resource": "valu_issue", "frac": round(sum(r["valu_issue_frac"] for r in lkrows) / len(lkrows), 4),
                         "peak": rf.VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
                         "per_launch": {r["kernel"]: r["valu_issue_frac"] for r in lkrows},
-                        "note": "k_lk_track is bound by VALU issue, not by HBM (frac above: algorithmic bytes / 8 TB/s); counters of "
+                        "note": "k_lk_track is bound by instruction issue, not by HBM (frac above: algorithmic bytes / 8 TB/s); counters of "
                                 "profiles/*_kernel_pmc.json at this source tree"}
+                    allrows = [r for r in lkrows if r.get("issue_frac_counted_classes")]
+                    if allrows:   # vector + scalar + LDS + memory instructions against the same one-per-4-cycles-and-SIMD ceiling
+                        out["roofline"]["binding_resource"]["issue_frac_counted_classes"] = round(
+                            sum(r["issue_frac_counted_classes"] for r in allrows) / len(allrows), 4)
+                        out["roofline"]["binding_resource"]["issue_note"] = (
+                            "a SIMD issues one instruction of ANY class per 4 cycles (profiles/r06_chain_ab.md: the corner response saturates "
+                            "at exactly that); issue_frac_counted_classes = (VALU + SALU + LDS + SMEM + VMEM) wave instructions / peak -- waits, "
+                            "no-ops and branches take slots too and are not counted")
                 out["roofline"]["kernels_note"] = (
                     "avg_launch_ms: HIP events of this run (epilogue frames); counters / rocprof_avg_launch_ms: %s; valu_issue_frac against "
                     "%.1f G wave-instructions/s (1024 SIMDs x 2.4 GHz / 4); k_ba_worker: SURVEY 8d's flop formula on the kernel's own trial / "

@@ -136,7 +136,7 @@ struct Pipeline {
   static_assert(NBA == BA_PLAN_SLOTS, "one stream list per local-map HIP stream");
   int nba = 2;                   // local-map streams in use: 2 per lane (FLVIS_BA_STREAMS per lane, tuning knob)
   int nba_lane = 2;              // ... of which every lane uses its own nba_lane
-  int host_lead = 2;             // frames the host may run ahead of the GPU (FLVIS_HOST_LEAD, 1 .. PIN_RING)
+  int host_lead = 3;             // frames the host may run ahead of the GPU (FLVIS_HOST_LEAD, 1 .. PIN_RING; 2 until round 6: a host thread that is held up for a millisecond then leaves the GPU dry)
   int host_lead_cap = 4;         // (flvis_image_feed_host lowers it to 1 for its call: its copies and events add to the queued commands)
   int input_hold = 0;            // flvis_set_input_hold: frames the caller keeps its input buffers untouched after handing them over
   bool stagger = true;           // FLVIS_LANE_STAGGER=0: lanes start their first frame together

@@ -76,6 +76,12 @@ def kernel_table(stages, S, w, h, copy_gbs, pmc=None, ba=None, ms_per_step=None)
                 rate = k["valu_insts"] / (row["avg_launch_ms"] * 1e-3) / 1e9
                 row["valu_ginst_per_s"] = round(rate, 1)
                 row["valu_issue_frac"] = round(rate / VALU_ISSUE_PEAK_GINST, 4)
+                other = [k.get(f) for f in ("salu_insts", "lds_insts", "smem_insts", "vmem_rd_insts", "vmem_wr_insts")]
+                if any(o is not None for o in other):   # (round 6) every counted instruction class against the same ceiling
+                    tot = k["valu_insts"] + sum(o for o in other if o is not None)
+                    row["insts_per_launch_counted_classes"] = int(tot)
+                    row["salu_insts_per_launch"] = int(k["salu_insts"]) if k.get("salu_insts") is not None else None
+                    row["issue_frac_counted_classes"] = round(tot / (row["avg_launch_ms"] * 1e-3) / 1e9 / VALU_ISSUE_PEAK_GINST, 4)
         if k.get("fetch_kb_calibrated") is not None and k.get("write_kb_calibrated") is not None:   # counter x probe factor (round 4)
             row["traffic_bytes_per_launch"] = int((k["fetch_kb_calibrated"] + k["write_kb_calibrated"]) * 1024)
             row["traffic_calibrated"] = True
