@@ -219,6 +219,39 @@ __device__ __forceinline__ void lk_wave_sum2_f32(int v1, int v2, float& f1, floa
 #endif
 }
 
+// the exact 64-bit wave totals of three per-lane int32 (the Hessian sums of a template level): six 16-bit-half chains advancing together
+// -- a DPP step's operand was written six instructions earlier, so none of the ~30 wait-state no-ops of three reductions one after the
+// other (lk_wave_sum_wide x 3)
+__device__ __forceinline__ void lk_wave_sum3_wide(int v1, int v2, int v3, long long& s1, long long& s2, long long& s3) {
+#if FLVIS_LK_DIET
+  int a = v1 & 0xffff, b = v1 >> 16, c = v2 & 0xffff, d = v2 >> 16, e = v3 & 0xffff, f = v3 >> 16;
+#define LK_STEP6(CTRL, RM)                                                    \
+  {                                                                           \
+    const int ta = __builtin_amdgcn_update_dpp(0, a, CTRL, RM, 0xf, false);  \
+    const int tb = __builtin_amdgcn_update_dpp(0, b, CTRL, RM, 0xf, false);  \
+    const int tc = __builtin_amdgcn_update_dpp(0, c, CTRL, RM, 0xf, false);  \
+    const int td = __builtin_amdgcn_update_dpp(0, d, CTRL, RM, 0xf, false);  \
+    const int te = __builtin_amdgcn_update_dpp(0, e, CTRL, RM, 0xf, false);  \
+    const int tf = __builtin_amdgcn_update_dpp(0, f, CTRL, RM, 0xf, false);  \
+    a += ta, b += tb, c += tc, d += td, e += te, f += tf;                     \
+  }
+  LK_STEP6(0xB1, 0xf)
+  LK_STEP6(0x4E, 0xf)
+  LK_STEP6(0x141, 0xf)
+  LK_STEP6(0x140, 0xf)
+  LK_STEP6(0x142, 0xa)
+  LK_STEP6(0x143, 0xc)
+#undef LK_STEP6
+  s1 = ((long long)__builtin_amdgcn_readlane(b, 63) << 16) + (long long)__builtin_amdgcn_readlane(a, 63);
+  s2 = ((long long)__builtin_amdgcn_readlane(d, 63) << 16) + (long long)__builtin_amdgcn_readlane(c, 63);
+  s3 = ((long long)__builtin_amdgcn_readlane(f, 63) << 16) + (long long)__builtin_amdgcn_readlane(e, 63);
+#else
+  s1 = lk_wave_sum_wide(v1);
+  s2 = lk_wave_sum_wide(v2);
+  s3 = lk_wave_sum_wide(v3);
+#endif
+}
+
 // The interpolated template of one level: I, Ix, Iy of the 31 x 31 window as packed int16 pairs in the lane's registers (lane = window
 // row lane >> 1, 16-column half lane & 1) and this lane's share of the three Hessian sums.  Packed 16-bit path: two columns per
 // instruction (v_pk_*), the bilinear weights applied with v_dot2c_i32_i16.  Every lane (window rows 0 .. 31: the lanes of row 31 only
@@ -333,9 +366,7 @@ __device__ __forceinline__ bool lk_template_level(const uint8_t* img, int W, int
     lk_template<true>(patch, lane, ipx, ipy, W, H, wT, wB, tI, tX, tY, a11, a12, a22);
   else
     lk_template<false>(patch, lane, ipx, ipy, W, H, wT, wB, tI, tX, tY, a11, a12, a22);
-  iA11 = lk_wave_sum_wide(a11);
-  iA12 = lk_wave_sum_wide(a12);
-  iA22 = lk_wave_sum_wide(a22);
+  lk_wave_sum3_wide(a11, a12, a22, iA11, iA12, iA22);
   return slow;
 }
 // The same as a CALL, for the temporal launch: there nearly every template comes from the cache, and with the computation out of line
@@ -396,6 +427,9 @@ __device__ __forceinline__ const uint8_t* lk_level_ptr(const PyrSel& P, int leve
 #ifndef FLVIS_LK_PREFETCH
 #define FLVIS_LK_PREFETCH 0  // (build-variant knob; measured: the 24 registers it holds cost more than the round trip it saves)
 #endif
+#ifndef FLVIS_LK_EARLY_REGION
+#define FLVIS_LK_EARLY_REGION 1  // (build-variant knob, round 6: a cached level stages its first search region beside the template loads)
+#endif
 #ifndef FLVIS_LK_WAVES
 #define FLVIS_LK_WAVES 4  // (build-variant knob: waves per SIMD the register allocation aims at)
 #endif
@@ -440,6 +474,12 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
   const int r = lane >> 1;
   const int c0 = (lane & 1) * 16;
   const int W_BITS = 14;
+  // (epsilon^2 in a VECTOR register pair: the scalar registers are oversubscribed by the two pyramids' argument blocks, and the compiler
+  // re-read this kernel argument with an s_load + s_waitcnt in front of the convergence test of EVERY iteration)
+  double eps2 = prm.eps2;
+#if FLVIS_LK_DIET
+  if (ROLE == 1 || ROLE == 4) asm volatile("" : "+v"(eps2));  // (the launches with registers to spare: 121 of 128; the others are at 128)
+#endif
   const float FLT_SCALE = 1.f / (1 << 20);
   const float halfWin = (LK_WIN - 1) * 0.5f;
 
@@ -510,12 +550,39 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
       lk_s2 tI[8], tX[8], tY[8];  // pixel pairs (c, c+1)
       long long iA11, iA12, iA22;
       const bool cached = (ROLE == 1 || ROLE == 4) && tc_hit && ((tc_mask >> level) & 1u);
+      // (the launches that may take templates from the cache look at the search image before the template stage: see below)
+      constexpr bool kEarlyRegion = (ROLE == 1 || ROLE == 4) && FLVIS_LK_EARLY_REGION;
+      int JW = 0, JH = 0;
+      const uint8_t* Jimg = nullptr;
+      if (kEarlyRegion) {
+        JW = next.w[level], JH = next.h[level];
+        Jimg = lk_level_ptr(next, level, s, kc_next, ind_next0);
+      }
+      bool region_ok = false;
+      int RX0 = 0, RY0 = 0;
       if (cached) {
         if (prm.stats_tc && lane == 0) atomicAdd(&prm.stats_tc[0], 1ull);
         if (pq_level != level) {  // (the top level, or the level above did not get this far)
           const lk_u4* src = reinterpret_cast<const lk_u4*>(tc_ptr + LK_TC_HDR + (size_t)level * LK_TC_LVL) + lane;
 #pragma unroll
           for (int k = 0; k < 6; k++) pq[k] = __builtin_nontemporal_load(src + 64 * k);
+        }
+        if (kEarlyRegion) {
+        // the search region of the level's FIRST iteration, staged while the templates travel: its position is the level's start position,
+        // known before the templates are (a cached level needs no source patch, so the LDS buffer is free) -- one memory round trip per
+        // level instead of two.  Same region, same bytes as the iteration would stage itself.
+        {
+          const int einx = (int)floorf(npx - halfWin), einy = (int)floorf(npy - halfWin);
+          if (!(einx < -LK_WIN || einx >= JW || einy < -LK_WIN || einy >= JH)) {
+            RX0 = (einx - LK_RM) & ~3;
+            RY0 = einy - LK_RM;
+            __syncthreads();
+            const bool slow = lk_load_region(Jimg, JW, JH, next.pitch[level], next.bx[level], next.by[level], RX0, RY0, patch);
+            __syncthreads();
+            if (prm.stats_tc && slow && lane == 0) atomicAdd(&prm.stats_tc[2], 1ull);
+            region_ok = true;
+          }
+        }
         }
         lk_u4 q[6];
 #pragma unroll
@@ -585,10 +652,10 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
       npx -= halfWin;
       npy -= halfWin;
       float pdx = 0.f, pdy = 0.f;
-      const int JW = next.w[level], JH = next.h[level];
-      const uint8_t* Jimg = lk_level_ptr(next, level, s, kc_next, ind_next0);
-      bool region_ok = false;
-      int RX0 = 0, RY0 = 0;
+      if (!kEarlyRegion) {
+        JW = next.w[level], JH = next.h[level];
+        Jimg = lk_level_ptr(next, level, s, kc_next, ind_next0);
+      }
       int iters_run = 0;
       for (int j = 0; j < prm.max_iter; j++) {
         iters_run = j + 1;
@@ -653,7 +720,7 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
         npy += ddy;
         nx = npx + halfWin;
         ny = npy + halfWin;
-        if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= prm.eps2) break;
+        if ((double)ddx * (double)ddx + (double)ddy * (double)ddy <= eps2) break;
         if (j > 0 && fabs((double)(ddx + pdx)) < 0.01 && fabs((double)(ddy + pdy)) < 0.01) {
           nx -= ddx * 0.5f;
           ny -= ddy * 0.5f;
