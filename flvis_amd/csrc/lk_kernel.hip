@@ -440,6 +440,21 @@ __device__ __forceinline__ const uint8_t* lk_level_ptr(const PyrSel& P, int leve
 // ROLE names the launch in the profiles and fixes what the template cache may do: 0 the stand-alone entry point (no cache), 1 the
 // tracker's temporal launch (may take templates from the cache), 2 its stereo launch (may store them), 4 the stereo launch fed by
 // k_lk_templates_ahead (tc_mode 3: takes the templates that kernel made for the tracked landmarks, computes and stores the others)
+#ifdef FLVIS_LK_UTIL
+// (build variant, scripts/lk_util.py: how full the chip is during an LK launch.  Every wave that tracks a point leaves its start and end
+// time (wall clock, 100 MHz) in a slot of its own: [launch kind: role % 3][the launch's slot, 8 of them][wave][start, end])
+__device__ unsigned long long g_lk_wt[3][8][32768][2];
+#define LK_UTIL_BEGIN const unsigned long long lk_t0_ = wall_clock64(); const unsigned lk_widx_ = (blockIdx.y * gridDim.x + blockIdx.x) & 32767u;
+#define LK_UTIL_END(ROLE)                                                              \
+  if (threadIdx.x == 0) {                                                              \
+    unsigned long long* u_ = g_lk_wt[(ROLE) % 3][prm.dbg_slot & 7][lk_widx_];          \
+    u_[0] = lk_t0_;                                                                    \
+    u_[1] = wall_clock64();                                                            \
+  }
+#else
+#define LK_UTIL_BEGIN
+#define LK_UTIL_END(ROLE)
+#endif
 template <int ROLE>
 __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& next, const float* __restrict__ prev_pts,
                                               float* __restrict__ next_pts, uint8_t* __restrict__ status,
@@ -461,6 +476,8 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
   if (active && !active[s]) return;
   int n = count[s];
   if (n > nmax) n = nmax;
+  if (bx >= n) return;
+  LK_UTIL_BEGIN
   __shared__ __attribute__((aligned(16))) uint8_t patch[LK_RROWS * LK_RS + 12];  // template patch, then search region
   const int lane = threadIdx.x;
   int kc_prev = 0, kc_next = 0;
@@ -751,6 +768,7 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
       }
     }
   }
+  LK_UTIL_END(ROLE)
 }
 
 // the three launches (named apart in the profiles; the register budget is per launch kind)
@@ -874,3 +892,15 @@ void launch_lk_track(hipStream_t st, const PyrSel& prev, const PyrSel& next, con
 }
 
 }  // namespace flvis
+
+#ifdef FLVIS_LK_UTIL
+extern "C" int flvis_debug_lk_util(unsigned long long* out, int reset) {  // out: 3 * 8 * 32768 * 2 values
+  const size_t bytes = sizeof(unsigned long long) * 3 * 8 * 32768 * 2;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(flvis::g_lk_wt), bytes) != hipSuccess) return -1;
+  if (reset) {
+    void* dp = nullptr;
+    if (hipGetSymbolAddress(&dp, HIP_SYMBOL(flvis::g_lk_wt)) != hipSuccess || hipMemset(dp, 0, bytes) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -1370,6 +1370,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       prm.tc_slot = p.lk_slot;
       prm.tc_tag = p.lk_tag;
     }
+    prm.dbg_slot = (int)(pl->frames_fed & 7);
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track, pl->max_pts, 1);
   }
   PE(4, st);
@@ -1496,6 +1497,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       prm.tc_tag = p.lk_tag;
       prm.tc_slot = p.lk_slot;
     }
+    prm.dbg_slot = (int)(pl->frames_fed & 7);
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts,
                     L->tc && p.tpl_ahead ? 4 : 2);
   }
