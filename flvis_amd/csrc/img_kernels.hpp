@@ -79,6 +79,7 @@ struct LKParams {
   int tc_mode = 0, tc_cap = 0, tc_stride = 0;
   const int* tc_slot = nullptr;       // [S][nmax]
   const long long* tc_tag = nullptr;  // [S] identity of the template image (the stream's frame id)
+  int order = 0;                      // dispatch order of a stream's points: 0 first to last, 1 last to first (speed only)
   int dbg_slot = 0;                   // (-DFLVIS_LK_UTIL builds: which of 8 slots the launch's wave times go to; scripts/lk_util.py)
 };
 // dwords of one template-cache slot for a pyramid with levels 0 .. levels

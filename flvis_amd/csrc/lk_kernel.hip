@@ -500,7 +500,11 @@ __device__ __forceinline__ void lk_track_body(const PyrSel& prev, const PyrSel& 
   const float FLT_SCALE = 1.f / (1 << 20);
   const float halfWin = (LK_WIN - 1) * 0.5f;
 
-  for (int p = bx; p < n; p += gridDim.x) {
+  for (int pb = bx; pb < n; pb += gridDim.x) {
+    // (order of dispatch: a launch ends one wave's duration after its last workgroup has started, so the long points should start first.
+    //  prm.order 1: the stream's points from the last to the first -- a frame's new landmarks, which the stereo matcher has no depth to
+    //  start from, are appended behind the tracked ones)
+    const int p = prm.order == 1 ? n - 1 - pb : pb;
     const size_t pi = ((size_t)s * nmax + p) * 2;
     const float ppx0 = prev_pts[pi], ppy0 = prev_pts[pi + 1];
     float nx = next_pts[pi], ny = next_pts[pi + 1];

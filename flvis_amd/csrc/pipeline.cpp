@@ -124,6 +124,7 @@ struct Pipeline {
   int lbx = 0, lby = 0;  // physical border of every pyramid level (columns / rows on each side)
   int max_pts = 0;  // bound on the landmarks of a frame (16 regions x max_region_feature_num): sizes the LK grid
   int tpl_start = 1;  // FLVIS_TPL_START: where k_lk_templates_ahead starts (lane_frame)
+  int lk_order = 2;     // FLVIS_LK_ORDER (bits: 1 temporal, 2 stereo; default 2): the launch takes a stream's points from the last to the first
   int chain_merge = 3;  // FLVIS_CHAIN_MERGE: launches of the frame's chain folded into their neighbours (lane_frame)
   long long frames_fed = 0;
   std::vector<void*> allocs;  // context-level device allocations (host-feed staging)
@@ -738,6 +739,7 @@ int flvis_tracker_create(flvis_ctx* ctx, const flvis_cfg* cfg, int n_streams, ui
   if (const char* e = getenv("FLVIS_HOST_LEAD")) pl->host_lead = std::max(1, std::min(atoi(e), (int)Lane::PIN_RING));
   if (const char* e = getenv("FLVIS_SYNC_EACH_FRAME")) pl->sync_each_frame = atoi(e) != 0;
   if (const char* e = getenv("FLVIS_CHAIN_MERGE")) pl->chain_merge = atoi(e) & 3;
+  if (const char* e = getenv("FLVIS_LK_ORDER")) pl->lk_order = atoi(e) & 3;
   if (const char* e = getenv("FLVIS_BA_EVERY")) {
     int v = atoi(e);
     if (v >= 1 && v <= KFQ / 4) pl->ba_every = v;  // (the back-pressure in lane_frame needs (D + 2) * ba_every <= KFQ / 2)
@@ -1371,6 +1373,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       prm.tc_tag = p.lk_tag;
     }
     prm.dbg_slot = (int)(pl->frames_fed & 7);
+    prm.order = pl->lk_order & 1;
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.act_track, pl->max_pts, 1);
   }
   PE(4, st);
@@ -1498,6 +1501,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
       prm.tc_slot = p.lk_slot;
     }
     prm.dbg_slot = (int)(pl->frames_fed & 7);
+    prm.order = (pl->lk_order >> 1) & 1;
     launch_lk_track(st, prev, next, p.prev_pts, p.next_pts, p.lk_status, p.lk_count, NMAX, S, prm, p.det_mode, pl->max_pts,
                     L->tc && p.tpl_ahead ? 4 : 2);
   }
