@@ -143,6 +143,13 @@ struct BAShared {
   int fixed_slot;  // ring slot of the fixed pose if it has observations (its pixels are the only ones read from HBM per phase then), else -1
   int CI, CL, bufd, nchunk;         // chunk capacities (items, landmarks), doubles per buffer, chunk count
   int npairs, slices, rs;           // role partition of the Schur phase
+  // ... balanced (round 6): lanes per pose pair in proportion to the landmarks the pair shares (powers of two, 4 .. 64), the diagonal
+  // pairs in whole waves of their own.  pair_tab[pair] = first thread | log2(lanes) << 12 | i1 << 16 | i2 << 20; role_pair[thread] = its
+  // pair (255: none); pair_cnt = landmarks seen by both poses of the pair
+  int balance, balanced, max_slices;
+  int pair_cnt[64];
+  unsigned pair_tab[64];
+  unsigned char role_pair[BA_T];
   int use_mfma, NRp, CLm, nchunk_m;  // MFMA variant of the Schur phase: padded system size, landmarks per dense chunk
   // IMU rotation edges (optional factor): edge k links ring slots imu_a[k] -> imu_b[k]
   int n_imu, imu_a[BA_WMAX], imu_b[BA_WMAX];
@@ -342,6 +349,108 @@ FD Chol3 chol3(const double* H, double lambda) {
   return g;
 }
 
+// sum over the wave as a wave-uniform value
+FD int ba_wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+FD int ba_wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int u = __shfl_xor(v, o, 64);
+    v = u > v ? u : v;
+  }
+  return v;
+}
+
+// Lanes of the Schur accumulate per pose pair (round 6; ONE wave, lane = pair, pairs numbered as ba_schur_role numbers them: the P
+// diagonal pairs, then i1 < i2 row by row).  A pair's lanes split the landmarks both of its poses see among them; with 16 lanes for every
+// pair a window's neighbouring keyframes (~150-190 shared landmarks) kept their waves busy four to eight times as long as the pairs six
+// keyframes apart (~20), and the phase ended with the slowest wave (profiles/r05_ba_phases.md: 108 us of waiting per optimisation).
+// Here a pair gets a power of two of lanes (4 .. 64) in proportion to its landmark count (a diagonal pair's product, which carries the
+// right-hand side, counts 4 : 3), the largest counts that fit the workgroup: the diagonal pairs in whole waves of their own (a wave
+// holding both kinds would run the two product bodies one after the other), each region sorted by lane count so that a group never
+// straddles a DPP row it does not fill.  A function of the window's structure only: the same partition, the same order of summation, run
+// after run.
+FD void ba_balance_pairs() {
+  BAShared& sh = ba_sh();
+  const int p = threadIdx.x & 63, P = sh.P, NP = P + P * (P - 1) / 2;
+  const bool diag = p < P, on = p < NP;
+  // work of the pair per LM trial in units of a ninth of an off-diagonal block product (two records, a 6x6 tile: measured ~1.8 times the
+  // diagonal product with its lower triangle and right-hand side)
+  const int load = on ? sh.pair_cnt[p] * (diag ? 5 : 9) : 0;
+  const int total = ba_wave_sum_i(load);
+  int sl = on ? 4 : 0, dsum = 0, osum = 0;
+  if (total > 0) {
+    const float base = (float)load * (float)BA_T / (float)total;  // lanes at the even share of work per lane
+    for (int k = 0; k < 40; k++) {                                // ... at 2^(k/4) times that share: the first that fits
+      const float need = base * exp2f(-0.25f * (float)k);
+      const int c = !on ? 0 : need <= 4.f ? 4 : need <= 8.f ? 8 : need <= 16.f ? 16 : need <= 32.f ? 32 : 64;
+      dsum = ba_wave_sum_i(diag ? c : 0);
+      osum = ba_wave_sum_i(diag ? 0 : c);
+      if (((dsum + 63) & ~63) + osum <= BA_T) {
+        sl = c;
+        break;
+      }
+    }
+  }
+  dsum = ba_wave_sum_i(diag ? sl : 0);
+  osum = ba_wave_sum_i(diag ? 0 : sl);
+  // what is left over goes to the busiest lanes, one doubling at a time
+  for (int it = 0; it < 8; it++) {
+    const int q = on && sl < 64 ? (load << 8) / sl : -1;  // load per lane (sl is a power of two: a shift)
+    const int qm = ba_wave_max_i(q);
+    if (qm <= 0) break;
+    const unsigned long long who = __ballot(q == qm);
+    const int w0 = __builtin_ctzll(who);  // (one pair per step: the first of the busiest)
+    const int wsl = __shfl(sl, w0, 64);
+    const int nd = dsum + (w0 < P ? wsl : 0), no = osum + (w0 < P ? 0 : wsl);
+    if (((nd + 63) & ~63) + no > BA_T) break;
+    if (p == w0) sl *= 2;
+    dsum = nd;
+    osum = no;
+  }
+  // first thread of every pair: its region's pairs with more lanes in front of it, equal ones in pair order
+  int off = 0;
+  for (int q = 0; q < NP; q++) {
+    const int sq = __shfl(sl, q, 64);
+    if ((q < P) == diag && (sq > sl || (sq == sl && q < p))) off += sq;
+  }
+  if (!diag) off += (dsum + 63) & ~63;
+  if (on) {
+    int i1 = p, i2 = p;
+    if (!diag) {
+      int rem = p - P;
+      i1 = 0;
+      while (rem >= P - 1 - i1) {
+        rem -= P - 1 - i1;
+        i1++;
+      }
+      i2 = i1 + 1 + rem;
+    }
+    sh.pair_tab[p] = (unsigned)off | ((unsigned)(31 - __builtin_clz(sl)) << 12) | ((unsigned)i1 << 16) | ((unsigned)i2 << 20);
+  }
+  // role_pair: the lanes write the table side by side, pair after pair
+  for (int q = 0; q < NP; q++) {
+    const int sq = __shfl(sl, q, 64), oq = __shfl(off, q, 64);
+    if (p < sq) sh.role_pair[oq + p] = (unsigned char)q;
+  }
+  const int ms = ba_wave_max_i(sl);
+  if (p == 0) sh.max_slices = ms;
+#ifdef FLVIS_BA_PROF
+  // (the partition by keyframe distance: debug counters 48 + 2 d: lanes, 49 + 2 d: landmarks, d = i2 - i1 of the pair)
+  if (on && sh.prof) {
+    const unsigned tab = sh.pair_tab[p];
+    const int d = (int)((tab >> 20) & 15u) - (int)((tab >> 16) & 15u);
+    if (d < 7) {
+      atomicAdd((unsigned long long*)&sh.prof[40 + 2 * d], (unsigned long long)sl);
+      atomicAdd((unsigned long long*)&sh.prof[41 + 2 * d], (unsigned long long)sh.pair_cnt[p]);
+    }
+  }
+#endif
+}
+
 // rebuilds the observation table from the alive edges: free-pose numbering (hessian order = slot order), per-landmark
 // masks, the item numbering and the chunk table of the Schur phase
 __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
@@ -358,6 +467,8 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     sh.hidx_of[t] = -1;
     sh.slot_cnt[t] = 0;
   }
+  if (t < 64) sh.pair_cnt[t] = 0;
+  sh.role_pair[t] = 255;
   for (int i = t; i < W * Lc; i += BA_T) sc.eid[i] = -1;
   __syncthreads();
   int na = 0;
@@ -398,10 +509,10 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     const int NR = 6 * P, LD = (P & 1) ? NR + 4 : NR + 2;
     sh.NR = NR;
     sh.LD = LD;
-    sh.off_linv = NR * LD;
+    sh.off_linv = (NR + 1) * LD;  // (row NR: the right-hand side rides through the factorisation, ba_chol_factor_wg)
     // the per-wave partials of the linearisation (BA_NW x P x 27) lie over Hs / Linv: nothing behind them may start inside
     const int wacc_end = BA_NW * 27 * P;
-    sh.off_imu = NR * LD + P * 36 > wacc_end ? NR * LD + P * 36 : wacc_end;
+    sh.off_imu = (NR + 1) * LD + P * 36 > wacc_end ? (NR + 1) * LD + P * 36 : wacc_end;
     sh.off_stage = sh.off_imu + (sh.n_imu > 0 ? 120 * W : 0);
     // pair groups of the Schur accumulate: the P diagonal pairs first, padded to whole waves -- a wave that held both kinds of pairs
     // would run the two product bodies one after the other --, then the P (P - 1) / 2 pairs i1 < i2
@@ -414,6 +525,8 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     sh.npairs = npairs;
     sh.slices = slices;
     sh.rs = 1;
+    sh.balanced = sh.balance && P >= 2 && P + P * (P - 1) / 2 <= 64 ? 1 : 0;
+    sh.max_slices = slices;
     // MFMA variant: the chunk is the DENSE (NR + 1 rows padded to 16) x (3 columns per landmark) slice of Z' = [Z; c^T]
     const int NRp = (NR + 1 + 15) & ~15;
     const int avail_m = ((int)((sh.lds_budget - BA_SH_BYTES) / 8) - sh.off_stage) & ~1;
@@ -436,7 +549,26 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
     sc.omask[l] = m;
     sc.fmask[l] = fm;
   }
+  if (sh.balanced) {  // landmarks per pose pair (a, b), a <= b: the work of the pair's lanes in the Schur accumulate (one vote per pair and wave)
+    const int P = sh.P;
+    for (int l0 = 0; l0 < L; l0 += BA_T) {
+      const unsigned fm = l0 + t < L ? sc.fmask[l0 + t] : 0u;  // (this thread wrote it above)
+      int idx = 0;
+      for (int a = 0; a < P; a++) {
+        const int n = __popcll(__ballot((fm >> a) & 1u));
+        if (lane == 0 && n) atomicAdd(&sh.pair_cnt[a], n);
+      }
+      idx = P;
+      for (int a = 0; a < P; a++)
+        for (int b = a + 1; b < P; b++, idx++) {
+          const unsigned need = (1u << a) | (1u << b);
+          const int n = __popcll(__ballot((fm & need) == need));
+          if (lane == 0 && n) atomicAdd(&sh.pair_cnt[idx], n);
+        }
+    }
+  }
   __syncthreads();
+  if (sh.balanced && wv == 0) ba_balance_pairs();
   // item numbering: exclusive scan of popc(fmask) over the landmarks (thread = contiguous run of landmarks)
   int* lbase = reinterpret_cast<int*>(ba_dyn() + sh.off_stage);  // LDS copy of ibase for the chunk search below
   {
@@ -527,6 +659,7 @@ __device__ __noinline__ void ba_build_structure(const WindowDev& w) {
 
 // blocked (6x6) left-looking Cholesky of the lower triangle of Hs (leading dimension LD) by ONE wave, then the two
 // triangular solves on sh.x; Linv receives the inverted diagonal blocks.  Returns false on a non-positive pivot.
+FD void ba_chol_subst(bool fwd);
 __device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
   BAShared& sh = ba_sh();
   double* Hs = ba_dyn();
@@ -654,8 +787,26 @@ __device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
     wave_lds_fence();
   }
   BAPROF(5);
+  ba_chol_subst(true);
+  return okc;
+}
+
+// the two triangular solves on sh.x with the factor in Hs / Linv, by ONE wave.  fwd = false: the forward substitution happened inside
+// the factorisation (ba_chol_factor_wg), y is row NR of Hs.
+FD void ba_chol_subst(bool fwd) {
+  BAShared& sh = ba_sh();
+  double* Hs = ba_dyn();
+  double* Linv = Hs + sh.off_linv;
+  double* xs = sh.x;
+  const int P = sh.P, LD = sh.LD;
+  const int lane = threadIdx.x & 63;
+  const int NR = 6 * P;
+  if (!fwd) {
+    for (int i = lane; i < NR; i += 64) xs[i] = Hs[NR * LD + i];
+    wave_lds_fence();
+  }
   // forward substitution L y = rhs (block-wise)
-  for (int jb = 0; jb < P; jb++) {
+  for (int jb = 0; fwd && jb < P; jb++) {
     const int c0 = 6 * jb;
     double y[6];
 #pragma unroll
@@ -708,6 +859,128 @@ __device__ FLVIS_BA_PHASE_FN bool ba_chol_solve() {
     }
     wave_lds_fence();
   }
+}
+
+#ifndef FLVIS_BA_CHOL_WG
+#ifdef FLVIS_BA_SOLVE_MFMA
+#define FLVIS_BA_CHOL_WG 0
+#else
+#define FLVIS_BA_CHOL_WG 1
+#endif
+#endif
+// The factorisation of the reduced system by the WHOLE workgroup (round 6), right-looking.  Wave 0 factors the diagonal block of block
+// column jb and scales the rows below it -- the chain of six pivots nobody can help with; then every wave takes one block column kb > jb
+// of the trailing matrix, lane = row: the very products, in the very order, that the one-wave left-looking form (ba_chol_solve) subtracts
+// when it reaches column kb, so the factor is the same bit for bit.  The one-wave form walked all finished block columns per panel with
+// seven waves waiting at the phase's barrier (12.5 us per LM trial, 20 trials per optimisation); here a block column costs its pivot chain,
+// one 36-FMA update and two barriers.  -DFLVIS_BA_CHOL_WG=0 keeps the one-wave form.
+__device__ FLVIS_BA_PHASE_FN bool ba_chol_factor_wg() {
+  BAShared& sh = ba_sh();
+  double* Hs = ba_dyn();
+  double* Linv = Hs + sh.off_linv;
+  const int P = sh.P, LD = sh.LD;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int NR = 6 * P;
+  bool okc = true;
+  // the right-hand side as row NR of the matrix: scaled and updated like every other row below the diagonal, it leaves the loop as
+  // y = L^-1 rhs -- the forward substitution (14 dependent LDS round trips on one wave before) for nothing, the same products in the same
+  // order
+  if (wv == 0)
+    for (int i = lane; i < NR; i += 64) Hs[NR * LD + i] = sh.x[i];
+  for (int jb = 0; jb < P; jb++) {
+    const int c0 = 6 * jb;
+    if (wv == 0) {
+      // diagonal block: every lane factors it redundantly in registers and inverts the factor
+      double d[6][6], li[6][6];
+#pragma unroll
+      for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) d[r][c] = Hs[(c0 + r) * LD + c0 + c];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        double s = d[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= d[j][k] * d[j][k];
+        if (!(s > 0) || !isfinite(s)) {
+          okc = false;
+          s = 1.0;
+        }
+        const double inv = rsqrt_nr(s), dj = s * inv;
+        d[j][j] = dj;
+        li[j][j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+          double v = d[i][j];
+#pragma unroll
+          for (int k = 0; k < j; k++) v -= d[i][k] * d[j][k];
+          d[i][j] = v * inv;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++)  // li = d^-1 (lower): column c by forward substitution
+#pragma unroll
+        for (int r = c + 1; r < 6; r++) {
+          double v = 0;
+#pragma unroll
+          for (int k = c; k < r; k++) v -= d[r][k] * li[k][c];
+          li[r][c] = v * li[r][r];
+        }
+      wave_lds_fence();
+      if (lane < 36) {
+        const int r = lane / 6, c = lane - 6 * r;
+        double dv = 0, lv = 0;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+          for (int cc = 0; cc <= rr; cc++)
+            if (rr == r && cc == c) {
+              dv = d[rr][cc];
+              lv = li[rr][cc];
+            }
+        Linv[jb * 36 + lane] = lv;  // zero above the diagonal
+        if (r >= c) Hs[(c0 + r) * LD + c0 + c] = dv;
+      }
+      // rows below the block: L_row = a_row * d^-T
+      for (int rr = c0 + 6 + lane; rr <= NR; rr += 64) {
+        double a[6], xr[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) a[c] = Hs[rr * LD + c0 + c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double v = 0;
+#pragma unroll
+          for (int k = 0; k <= c; k++) v = fma(a[k], li[c][k], v);
+          xr[c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) Hs[rr * LD + c0 + c] = xr[c];
+      }
+      wave_lds_fence();
+    }
+    if (jb + 1 == P) break;
+    __syncthreads();
+    // trailing matrix: block column kb, rows from its diagonal block down, minus L[row, jb] L[kb rows, jb]^T
+    for (int kb = jb + 1 + wv; kb < P; kb += BA_NW) {
+      const int k0 = 6 * kb;
+      for (int rr = k0 + lane; rr <= NR; rr += 64) {
+        double2* own = reinterpret_cast<double2*>(Hs + rr * LD);  // (rows are 16-byte aligned: three 128-bit accesses per 6-column block)
+        const double2 a0 = own[k0 / 2], a1 = own[k0 / 2 + 1], a2 = own[k0 / 2 + 2];
+        double a[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+        const double2 l0 = own[3 * jb], l1 = own[3 * jb + 1], l2 = own[3 * jb + 2];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          const double2* dr = reinterpret_cast<const double2*>(Hs + (k0 + c) * LD) + 3 * jb;  // (the same address in every lane: a broadcast)
+          const double2 d0 = dr[0], d1 = dr[1], d2 = dr[2];
+          a[c] = fma(-l2.y, d2.y, fma(-l2.x, d2.x, fma(-l1.y, d1.y, fma(-l1.x, d1.x, fma(-l0.y, d0.y, fma(-l0.x, d0.x, a[c]))))));
+        }
+        own[k0 / 2] = double2{a[0], a[1]};
+        own[k0 / 2 + 1] = double2{a[2], a[3]};
+        own[k0 / 2 + 2] = double2{a[4], a[5]};
+      }
+    }
+    __syncthreads();
+  }
+  BAPROF(5);
   return okc;
 }
 
@@ -1202,10 +1475,22 @@ __device__ FLVIS_BA_PHASE_FN double ba_phase_max_diag() {
 // this thread's role in the accumulation: pose pair (i1, i2) and landmark slice sl -- the diagonal pairs first (pr < P: (pr, pr)), then
 // the pairs i1 < i2 row by row.  A diagonal pair walks every observation of its pose: it also sums the pose's right-hand side.
 struct SchurRole {
-  int i1, i2, sl;
+  int i1, i2, sl, slices;
 };
 FD SchurRole ba_schur_role(int t, int P, int npairs, int slices) {
-  SchurRole r{-1, -1, 0};
+  SchurRole r{-1, -1, 0, slices};
+  if (ba_sh().balanced) {  // (ba_balance_pairs)
+    const BAShared& sh = ba_sh();
+    const int pr = sh.role_pair[t];
+    if (pr != 255) {
+      const unsigned tab = sh.pair_tab[pr];
+      r.sl = t - (int)(tab & 0xfffu);
+      r.slices = 1 << ((tab >> 12) & 15u);
+      r.i1 = (int)((tab >> 16) & 15u);
+      r.i2 = (int)((tab >> 20) & 15u);
+    }
+    return r;
+  }
   if (t < npairs * slices) {
     const int pr = t / slices, ppw = 64 / slices, dpad = ((P + ppw - 1) / ppw) * ppw;  // (diagonal pairs padded to whole waves)
     r.sl = t - pr * slices;
@@ -1319,6 +1604,12 @@ FD double ba_dpp(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROWS>
+FD double ba_dpp_bcast(double v) {  // (rows outside ROWS read 0)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 FD double ba_row16_sum_to_lane0(double v) {
   v += ba_dpp<0x108>(v);  // row_shl:8  (lane i += lane i + 8; out-of-row sources read as 0)
   v += ba_dpp<0x104>(v);  // row_shl:4
@@ -1336,7 +1627,7 @@ FD double ba_row16_sum_to_lane0(double v) {
 FD void ba_schur_accumulate(const SchurRole& ro, int buf, int nl, int inl, double (&acc)[36]) {
   BAShared& sh = ba_sh();
   if (ro.i1 < 0) return;
-  const int CI = sh.CI, CL = sh.CL, slices = sh.slices;
+  const int CI = sh.CI, CL = sh.CL, slices = ro.slices;
   const double fx = sh.K[0], fy = sh.K[1], cx = sh.K[2], cy = sh.K[3];
   const SchurBuf B = ba_schur_buf(buf);
   const double2* z2 = B.z;
@@ -1465,8 +1756,28 @@ FD void ba_schur_combine(const SchurRole& ro, double lambda, double (&acc)[36]) 
   BAShared& sh = ba_sh();
   double* Hs = ba_dyn();
   const int LD = sh.LD, slices = sh.slices;
-  // (the lanes of one pair are contiguous and aligned to `slices`; 16 slices -- the usual partition -- are one DPP row: summed into
-  // the row's lane 0 without touching LDS)
+  if (sh.balanced) {
+    // a pair's lanes are contiguous and aligned to their (power of two) count: summed into the group's LAST lane, inside a DPP row by
+    // row shifts (a step as wide as the group or wider is switched off by a factor 0: the lane it would read belongs to another pair),
+    // across rows by the two row broadcasts -- no LDS
+    const double k4 = ro.slices >= 8 ? 1.0 : 0.0, k8 = ro.slices >= 16 ? 1.0 : 0.0, k16 = ro.slices >= 32 ? 1.0 : 0.0,
+                 k32 = ro.slices >= 64 ? 1.0 : 0.0;
+    const bool wide = sh.max_slices > 16;
+#pragma unroll
+    for (int k = 0; k < 36; k++) {
+      double v = acc[k];
+      v += ba_dpp<0x111>(v);  // row_shr:1 (lane i += lane i - 1; out-of-row sources read as 0)
+      v += ba_dpp<0x112>(v);  // row_shr:2
+      v = fma(ba_dpp<0x114>(v), k4, v);
+      v = fma(ba_dpp<0x118>(v), k8, v);
+      if (wide) {
+        v = fma(ba_dpp_bcast<0x142, 0xa>(v), k16, v);  // row_bcast:15 into rows 1 and 3
+        v = fma(ba_dpp_bcast<0x143, 0xc>(v), k32, v);  // row_bcast:31 into rows 2 and 3
+      }
+      acc[k] = v;
+    }
+    if (ro.i1 < 0 || ro.sl != ro.slices - 1) return;
+  } else {
   if (slices == 16) {
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = ba_row16_sum_to_lane0(acc[k]);
@@ -1477,6 +1788,7 @@ FD void ba_schur_combine(const SchurRole& ro, double lambda, double (&acc)[36]) 
     }
   }
   if (ro.i1 < 0 || ro.sl != 0) return;
+  }
   if (ro.i1 != ro.i2) {
 #pragma unroll
     for (int r = 0; r < 6; r++)
@@ -1512,7 +1824,14 @@ __device__ FLVIS_BA_PHASE_FN void ba_phase_schur_resident(double lambda, int inl
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; k++) acc[k] = 0;
+#ifdef FLVIS_BA_PROF
+  const long long t0_ = (long long)wall_clock64();
+#endif
   ba_schur_accumulate(ro, 0, sh.chunk_l0[1] - sh.chunk_l0[0], inl, acc);
+#ifdef FLVIS_BA_PROF
+  // (how long every wave's accumulation takes: debug counters 40 .. 47)
+  if ((threadIdx.x & 63) == 0 && sh.prof) atomicAdd((unsigned long long*)&sh.prof[32 + (threadIdx.x >> 6)], (unsigned long long)((long long)wall_clock64() - t0_));
+#endif
   BAPROF(12);
   ba_schur_combine(ro, lambda, acc);
   BAPROF(13);
@@ -1687,10 +2006,15 @@ __device__ __noinline__ void ba_phase_schur_mfma(double lambda) {
 
 // wave 0: factor + solve the reduced system, then form the trial poses x (+) pose (unchanged poses if the factorisation
 // failed) and their (R | t) tables
-__device__ FLVIS_BA_PHASE_FN void ba_phase_solve_poses() {
+__device__ FLVIS_BA_PHASE_FN void ba_phase_solve_poses(bool okc_wg) {
   BAShared& sh = ba_sh();
   const int lane = threadIdx.x & 63;
+#if FLVIS_BA_CHOL_WG
+  const bool okc = okc_wg;
+  ba_chol_subst(false);
+#else
   const bool okc = ba_chol_solve();
+#endif
   wave_lds_fence();
   BAPROF(6);
   if (lane == 0) sh.flag = okc ? 1 : 0;
@@ -1983,7 +2307,12 @@ __device__ __noinline__ void ba_optimize(const WindowDev& w, int iterations) {
         __syncthreads();
       }
       BAPROF(7);
-      if (t < 64) ba_phase_solve_poses();
+#if FLVIS_BA_CHOL_WG
+      const bool okc_wg = ba_chol_factor_wg();  // (ends behind wave 0's last diagonal block: the substitutions below are wave 0's too)
+#else
+      const bool okc_wg = true;
+#endif
+      if (t < 64) ba_phase_solve_poses(okc_wg);
       __syncthreads();
       BAPROF(8);
       const int ok2 = sh.flag;
@@ -2061,6 +2390,7 @@ __device__ __noinline__ void ba_solve_dev(const Pipe& p, int s, long long frame_
     sh.lds_budget = p.ba_lds_bytes;
     sh.W = W;
     sh.use_mfma = p.ba_mfma;
+    sh.balance = p.ba_balance && !p.ba_mfma;
     sh.K[0] = p.cam.fx;
     sh.K[1] = p.cam.fy;
     sh.K[2] = p.cam.cx;

@@ -489,6 +489,13 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   p.ba_remap = getenv("FLVIS_BA_REMAP") && atoi(getenv("FLVIS_BA_REMAP")) == 1;
   p.ba_mfma = 0;
   if (const char* e = getenv("FLVIS_BA_MFMA")) p.ba_mfma = atoi(e) != 0;
+  // FLVIS_BA_BALANCE=1 (opt-in, round 6): the Schur accumulate's lanes per pose pair in proportion to the landmarks the pair shares
+  // (ba_balance_pairs) instead of 16 each.  Measured (profiles/r06_ba_phases.md): the benchmark's windows share their landmarks almost
+  // evenly (155 per pose, 76-114 per pair of poses), the per-SIMD sums of the accumulate are 262-300 us either way -- the "wait for the
+  // slowest wave" of round 5 is the younger wave of each SIMD finishing behind the older one, not an imbalance -- and the partition's own
+  // cost (+27 us structure, +19 us combine per optimisation) is not paid back: off by default.
+  p.ba_balance = 0;
+  if (const char* e = getenv("FLVIS_BA_BALANCE")) p.ba_balance = atoi(e) != 0;
   // LDS a local-map workgroup claims (FLVIS_BA_LDS_KB, 64 .. 159): whatever it leaves of the CU's 160 KB lets LK / corner-response
   // waves run on the same CU, whose SIMDs a latency-bound BA workgroup keeps mostly idle
   p.ba_lds_bytes = ba_lds_budget_max();

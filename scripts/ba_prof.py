@@ -55,6 +55,11 @@ if c[32]:
     n = c[32]
     print("Schur accumulate per call, over the pair threads: slowest %.2f us, mean %.2f us; block products: most %.1f, mean %.2f per thread (%d calls)"
           % (c[28] / n / 100.0, c[29] / n / 100.0, c[30] / n, c[31] / n / 16.0, n))
+if c[40]:
+    print("Schur accumulate per wave, us/run: " + "  ".join("%.1f" % (c[40 + w] / runs / 100.0) for w in range(8)))
+if c[48]:
+    print("partition by keyframe distance d (lanes per pair, landmarks per pair): " + "  ".join(
+        "d%d: %.1f / %.0f" % (d, c[48 + 2 * d] / max(runs * 2, 1) / (7 - d), c[49 + 2 * d] / max(runs * 2, 1) / (7 - d)) for d in range(7)))
 if c[27]:
     print("keyframe bookkeeping (ba_update_dev): %.1f us per keyframe (%d keyframes)" % (c[26] / c[27] / 100.0, c[27]))
 
