@@ -8,9 +8,20 @@
 
 // ------------------------------------------------------------------------------------------------ bookkeeping
 // landmark id -> bag index; the id list of the bag is staged in LDS (sid) by ba_update_dev and kept in sync with appends
+// (eight entries per trip, all eight reads in flight before the first comparison: one LDS round trip per eight ids instead of one per id --
+// the loop with its early exit waited for every read.  Ids are unique in the bag: any match is the first.  The list lies at the start of
+// the worker's dynamic LDS: the up to seven entries read past n are inside the allocation and are not looked at.)
 FD int bag_find(const long long* sid, int n, long long id) {
-  for (int i = 0; i < n; i++)
-    if (sid[i] == id) return i;
+  for (int i = 0; i < n; i += 8) {
+    long long v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = sid[i + k];
+    int hit = -1;
+#pragma unroll
+    for (int k = 7; k >= 0; k--)
+      if (v[k] == id && i + k < n) hit = i + k;
+    if (hit >= 0) return hit;
+  }
   return -1;
 }
 
@@ -173,13 +184,28 @@ __device__ __noinline__ void ba_update_dev(const Pipe& p, int s, const KeyFrameD
   {  // kfs.push_back(kf)
     KeyFrameDev& dst = ring[(w.kfs_head + w.kfs_size) % W];
     const int n = src.lm_count;
+    unsigned hsum = 0u;
     for (int i = tid; i < n; i += BU_T) {
-      dst.lm_id[i] = src.lm_id[i];
-      dst.lm_2d[i][0] = src.lm_2d[i][0];
-      dst.lm_2d[i][1] = src.lm_2d[i][1];
-      dst.lm_3d[i][0] = src.lm_3d[i][0];
-      dst.lm_3d[i][1] = src.lm_3d[i][1];
-      dst.lm_3d[i][2] = src.lm_3d[i][2];
+      const long long id = src.lm_id[i];
+      const double p2[2] = {src.lm_2d[i][0], src.lm_2d[i][1]}, p3[3] = {src.lm_3d[i][0], src.lm_3d[i][1], src.lm_3d[i][2]};
+      dst.lm_id[i] = id;
+      dst.lm_2d[i][0] = p2[0];
+      dst.lm_2d[i][1] = p2[1];
+      dst.lm_3d[i][0] = p3[0];
+      dst.lm_3d[i][1] = p3[1];
+      dst.lm_3d[i][2] = p3[2];
+      if (p.kf_check) hsum += kf_entry_hash(i, id, p2, p3);
+    }
+    if (p.kf_check) {  // (test knob, FLVIS_KF_CHECK: the payload as this workgroup sees it against the checksum its producer left)
+      __syncthreads();
+      if (tid == 0) s_cnt[0] = 0;
+      __syncthreads();
+      if (hsum) atomicAdd(reinterpret_cast<unsigned*>(&s_cnt[0]), hsum);
+      __syncthreads();
+      if (tid == 0 && p.counters) {
+        atomicAdd((unsigned long long*)&p.counters[30], 1ull);
+        if ((int)(unsigned)s_cnt[0] != src.imu_pad) atomicAdd((unsigned long long*)&p.counters[31], 1ull);
+      }
     }
     __syncthreads();
     if (tid == 0) {

@@ -100,6 +100,17 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// one landmark entry's share of a keyframe payload's checksum (FLVIS_KF_CHECK): position-weighted, summed in any order
+__device__ __forceinline__ unsigned kf_word_hash(unsigned long long v) { return (unsigned)v * 2654435761u + (unsigned)(v >> 32) * 40503u; }
+__device__ __forceinline__ unsigned kf_entry_hash(int k, long long id, const double* p2, const double* p3) {
+  unsigned h = kf_word_hash((unsigned long long)id);
+  h = h * 31u + kf_word_hash((unsigned long long)__double_as_longlong(p2[0]));
+  h = h * 31u + kf_word_hash((unsigned long long)__double_as_longlong(p2[1]));
+  h = h * 31u + kf_word_hash((unsigned long long)__double_as_longlong(p3[0]));
+  h = h * 31u + kf_word_hash((unsigned long long)__double_as_longlong(p3[1]));
+  h = h * 31u + kf_word_hash((unsigned long long)__double_as_longlong(p3[2]));
+  return h * (unsigned)(k + 1);
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -494,6 +494,11 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   // evenly (155 per pose, 76-114 per pair of poses), the per-SIMD sums of the accumulate are 262-300 us either way -- the "wait for the
   // slowest wave" of round 5 is the younger wave of each SIMD finishing behind the older one, not an imbalance -- and the partition's own
   // cost (+27 us structure, +19 us combine per optimisation) is not paid back: off by default.
+  // FLVIS_KF_CHECK=1 (test knob): k_frame_end leaves a checksum of the keyframe's landmark arrays (written by all of its waves) in the
+  // payload, the local-map worker -- another workgroup, usually on another XCD -- recomputes it from what it reads after its acquire:
+  // debug counters 30 (payloads checked) and 31 (mismatches).  The hand-over publishes with ONE agent-scope release by one thread behind a
+  // workgroup barrier; tests/test_gpu_pipeline.py runs 64 streams under this check.
+  p.kf_check = getenv("FLVIS_KF_CHECK") && atoi(getenv("FLVIS_KF_CHECK")) == 1;
   p.ba_balance = 0;
   if (const char* e = getenv("FLVIS_BA_BALANCE")) p.ba_balance = atoi(e) != 0;
   // LDS a local-map workgroup claims (FLVIS_BA_LDS_KB, 64 .. 159): whatever it leaves of the CU's 160 KB lets LK / corner-response

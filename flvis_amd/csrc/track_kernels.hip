@@ -2562,7 +2562,9 @@ __device__ __forceinline__ void k_frame_end_body(const Pipe& p) {
     // subscriber queue does when the local map is slower than the tracker (src/backend/vo_localmap.cpp:452-456).
     __shared__ unsigned s_tail;
     __shared__ int s_full;
+    __shared__ unsigned s_hash;
     if (lane == 0) {
+      s_hash = 0u;
       const unsigned tl = p.kfq_tail[s];
       s_full = (tl - __hip_atomic_load(&p.kfq_head[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)KFQ) ? 1 : 0;
       if (s_full) atomicAdd((unsigned long long*)&p.counters[3], 1ull);
@@ -2574,6 +2576,7 @@ __device__ __forceinline__ void k_frame_end_body(const Pipe& p) {
     Landmark* lms = lm_ptr(p, cur, s);
     const int n = st.n_lm[cur];
     int cnt = 0;
+    unsigned hsum = 0u;
     for (int base = 0; base < n; base += FE_T) {
       int i = base + lane;
       bool sel = i < n && lms[i].has3d && lms[i].inlier;
@@ -2588,9 +2591,14 @@ __device__ __forceinline__ void k_frame_end_body(const Pipe& p) {
           kf.lm_3d[k][0] = lms[i].p3w[0];
           kf.lm_3d[k][1] = lms[i].p3w[1];
           kf.lm_3d[k][2] = lms[i].p3w[2];
+          if (p.kf_check) hsum += kf_entry_hash(k, lms[i].id, lms[i].p2u, lms[i].p3w);
         }
       }
       cnt += tot;
+    }
+    if (p.kf_check) {  // (test knob: the checksum of what every wave wrote, verified by the consumer -- ba_update_dev)
+      if (hsum) atomicAdd(&s_hash, hsum);
+      __syncthreads();
     }
     if (lane == 0) {
       kf.frame_id = st.frame_id[cur];
@@ -2602,7 +2610,7 @@ __device__ __forceinline__ void k_frame_end_body(const Pipe& p) {
       for (int j = 0; j < 4; j++) kf.imu_dq[j] = st.kf_dq[j];
       kf.imu_dt = st.kf_dt;
       kf.imu_valid = (s_chain && st.kf_dt > 0) ? 1 : 0;
-      kf.imu_pad = 0;
+      kf.imu_pad = p.kf_check ? (int)s_hash : 0;
       // ... and the position part: the displacement preintegrated over the same interval and the filter velocity recorded when the
       // previous keyframe was made; the velocity at THIS keyframe is kept for the next payload
       for (int j = 0; j < 3; j++) {

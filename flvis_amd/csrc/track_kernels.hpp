@@ -72,6 +72,7 @@ struct Pipe {
   int ba_drain;             // keyframes a local-map workgroup takes from its stream's queue per launch (0: until the queue is empty) ...
   int ba_backlog;           // ... and it goes on while the queue still holds this many or more: the bound the back-pressure relies on
   int ba_mfma;              // Schur complement of the window solver on the matrix cores (v_mfma_f64_16x16x4_f64) or as register tiles
+  int kf_check;             // keyframe payloads carry a checksum the local-map worker verifies (FLVIS_KF_CHECK=1: stress test of the hand-over's fences)
   int ba_balance;           // Schur accumulate: lanes per pose pair in proportion to the landmarks the pair shares (1) or 16 each (0)
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
   // local-map feedback (F2FTracking::correction_feed, dead in the reference's v2)

@@ -51,10 +51,6 @@ tot = sum(c[8:8 + 14])
 for i, n in enumerate(names):
     print("%-16s %8.1f us/run  %5.1f%%" % (n, c[8 + i] / runs / 100.0, 100.0 * c[8 + i] / max(tot, 1)))
 print("total %.1f us/run (100 MHz counter assumed)" % (tot / runs / 100.0))
-if c[32]:
-    n = c[32]
-    print("Schur accumulate per call, over the pair threads: slowest %.2f us, mean %.2f us; block products: most %.1f, mean %.2f per thread (%d calls)"
-          % (c[28] / n / 100.0, c[29] / n / 100.0, c[30] / n, c[31] / n / 16.0, n))
 if c[40]:
     print("Schur accumulate per wave, us/run: " + "  ".join("%.1f" % (c[40 + w] / runs / 100.0) for w in range(8)))
 if c[48]:

@@ -469,6 +469,49 @@ def test_keyframe_queue_is_bounded_when_the_local_map_lags(ctx):
     del trk
 
 
+@pytest.mark.gpu
+def test_keyframe_hand_over_checksum_64_streams(ctx):
+    """The tracker hands a keyframe to the local map with ONE agent-scope release by one thread behind a workgroup barrier (k_frame_end);
+    the worker -- another workgroup, on whichever XCD the dispatcher picks -- acquires once (k_ba_worker).  With FLVIS_KF_CHECK=1 the
+    producer leaves a checksum of the landmark arrays ALL of its waves wrote, and the consumer recomputes it from what it reads: 64
+    streams running flat out (no read-back, the local map beside the frames), every payload checked, none torn."""
+    import ctypes as C
+    import flvis_amd
+    from flvis_amd import synth
+    cfg, _ = _cfgs()
+    S, nframes = 64, 50 + 100
+    old = os.environ.get("FLVIS_KF_CHECK")
+    os.environ["FLVIS_KF_CHECK"] = "1"
+    try:
+        trk = flvis_amd.Tracker(ctx, cfg, S, seed_base=0xF1715)
+    finally:
+        if old is None:
+            os.environ.pop("FLVIS_KF_CHECK", None)
+        else:
+            os.environ["FLVIS_KF_CHECK"] = old
+    trajs = [synth.Trajectory(s) for s in range(S)]
+    rnd = synth.Renderer("cuda")
+    skip = cfg.skip_first_n_imgs
+    frames = {f: rnd.stereo_frame(trajs, f / synth.FRAME_HZ, f) for f in range(skip, nframes)}   # (up front: the frames run back to back)
+    t_prev = -0.05
+    for f in range(nframes):
+        t = f / synth.FRAME_HZ
+        for i in range(S):
+            trk.imu_feed_flvis(i, synth.imu_samples(trajs[i], i, t_prev, t))
+        t_prev = t
+        i0, i1 = frames[max(f, skip)]   # (the skipped start-up frames are never looked at)
+        trk.image_feed(i0, i1, [t] * S, want_out=False, with_local_map=True)
+    ctx.synchronize()
+    kf, ba = trk.local_map_counts()
+    dbg = (C.c_int64 * 64)()
+    ctx._check(ctx._lib.flvis_debug_counters(ctx._h, dbg), "debug_counters")
+    assert trk.dropped_keyframes() == 0
+    assert kf.min() >= 20, kf
+    assert dbg[30] == kf.sum(), (dbg[30], kf.sum())       # every keyframe the local map took was checked ...
+    assert dbg[31] == 0, "%d of %d keyframe payloads arrived torn" % (dbg[31], dbg[30])
+    del trk
+
+
 def _run_plain(ctx, cfg, streams, nframes, env):
     """One tracker run under the given environment knobs (read when the tracker is created): per frame the outputs that the LK feeds
     (pose, inlier counts, landmark count, landmark pixels) + the LK statistics of the run."""
