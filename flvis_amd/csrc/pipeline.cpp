@@ -79,6 +79,8 @@ struct Lane {
   long long frames_uploaded = 0;             // frames this lane has enqueued
   std::vector<void*> allocs;
   std::vector<hipEvent_t> prof_ev;  // optional per-stage HIP-event timing (flvis_prof_enable)
+  std::vector<unsigned char> prof18_rec;  // per armed step: the local-map launch's event pair (stage 18) was recorded -- a deferred launch
+                                          // (FLVIS_BA_START) belongs to the NEXT step, the first step of a batch has none, the last one two
   // corner detection on its own HIP stream: goodFeaturesToTrack only needs the new image, so it runs beside the temporal
   // tracking chain (LK -> RANSACs -> pose LM) and joins before FeatureDEM consumes the corners
   hipStream_t det_stream = nullptr;
@@ -1079,6 +1081,11 @@ static bool fold_post(Pipeline* pl, Lane* L, hipEvent_t ev, KJoin& kj) {
 static void launch_local_map(Pipeline* pl, Lane* L, hipEvent_t ev, bool record, hipEvent_t* prof_begin_end) {
   const int bi = (L->idx * pl->nba_lane + (int)(L->ba_launches % pl->nba_lane)) % pl->nba;
   hipStream_t bs = pl->ba_stream[bi];
+  if (prof_begin_end) {  // (one timed launch per armed step: the first; a second one in the same step keeps its hands off the pair)
+    unsigned char& rec = L->prof18_rec[(size_t)pl->prof_step];
+    if (rec) prof_begin_end = nullptr;
+    else rec = 1;
+  }
   if (record) join_signal(pl, L, ev, L->st);
   join_wait(pl, L, bs, ev);
   if (prof_begin_end) hipEventRecord(prof_begin_end[0], bs);
@@ -1557,6 +1564,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
     if (prof) {
       PB(18, st);
       PE(18, st);
+      L->prof18_rec[(size_t)pl->prof_step] = 1;
     }
   }
 #undef PB
@@ -1886,6 +1894,7 @@ int flvis_prof_enable_stages(flvis_ctx* ctx, int max_steps, uint64_t stage_mask)
     for (hipEvent_t e : L->prof_ev) hipEventDestroy(e);
     L->prof_ev.clear();
     L->prof_ev.resize((size_t)max_steps * (2 * PROF_STAGES));
+    L->prof18_rec.assign((size_t)max_steps + 1, 0);
     for (auto& e : L->prof_ev)
       if (hipEventCreateWithFlags(&e, pl->ev_flags & hipEventReleaseToDevice) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
   }
@@ -1909,11 +1918,16 @@ int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps) {
   Pipeline* pl = ctx->pipe;
   sync_all(ctx);
   for (int i = 0; i < PROF_STAGES; i++) h_ms_per_stage[i] = 0;
+  size_t rec18 = 0;
   for (Lane* L : pl->lanes)
     for (int k = 0; k < pl->prof_step; k++)
       for (int i = 0; i < PROF_STAGES; i++) {
         float ms = 0;
         if (!prof_stage_timed(pl, i)) continue;
+        if (i == 18) {
+          if (!L->prof18_rec[(size_t)k]) continue;
+          rec18++;
+        }
         // (a stage that was not enqueued in this frame -- a deferred local-map launch, FLVIS_BA_START -- has no recorded events: it counts 0)
         if (hipEventElapsedTime(&ms, L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i], L->prof_ev[(size_t)k * (2 * PROF_STAGES) + 2 * i + 1]) != hipSuccess) {
           (void)hipGetLastError();
@@ -1921,6 +1935,8 @@ int flvis_prof_read(flvis_ctx* ctx, double* h_ms_per_stage, int* n_steps) {
         }
         h_ms_per_stage[i] += ms / (double)pl->lanes.size();
       }
+  // (stage 18 as the mean over the steps that timed a launch: the caller divides every stage's sum by n_steps)
+  if (rec18 > 0 && rec18 < pl->lanes.size() * (size_t)pl->prof_step) h_ms_per_stage[18] *= (double)(pl->lanes.size() * (size_t)pl->prof_step) / (double)rec18;
   *n_steps = pl->prof_step;
   return FLVIS_OK;
 }
