@@ -562,6 +562,8 @@ def main():
     timed_mask = sum(1 << i for i in lk_idx) | (1 << chain_idx)
     if os.environ.get("FLVIS_BENCH_FRAMES"):   # diagnosis: every stage carries events in the timed region (slows it a little)
         timed_mask = (1 << nst) - 1
+    if os.environ.get("FLVIS_BENCH_NO_EVENTS"):   # diagnosis: what the LK launches' events cost the timed region (no roofline from such a run)
+        timed_mask = 1 << chain_idx
 
     def read_stages():
         ms = (C.c_double * nst)()

@@ -1890,13 +1890,16 @@ int flvis_prof_enable_stages(flvis_ctx* ctx, int max_steps, uint64_t stage_mask)
   sync_all(ctx);
   pl->prof_cap = max_steps;
   pl->prof_step = 0;
+  // release scope of the stage events (FLVIS_PROF_EVENT_SCOPE=agent|system; default: what the pipeline's own events use)
+  unsigned prof_scope = pl->ev_flags & hipEventReleaseToDevice;
+  if (const char* e = getenv("FLVIS_PROF_EVENT_SCOPE")) prof_scope = !strcmp(e, "agent") ? hipEventReleaseToDevice : 0u;
   for (Lane* L : pl->lanes) {
     for (hipEvent_t e : L->prof_ev) hipEventDestroy(e);
     L->prof_ev.clear();
     L->prof_ev.resize((size_t)max_steps * (2 * PROF_STAGES));
     L->prof18_rec.assign((size_t)max_steps + 1, 0);
     for (auto& e : L->prof_ev)
-      if (hipEventCreateWithFlags(&e, pl->ev_flags & hipEventReleaseToDevice) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
+      if (hipEventCreateWithFlags(&e, prof_scope) != hipSuccess) return ctx->fail(FLVIS_ERR_HIP, "prof_enable: hipEventCreate failed");
   }
   return FLVIS_OK;
 }
