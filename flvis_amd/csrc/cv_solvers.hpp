@@ -775,9 +775,11 @@ CVS_FN bool p3p_solve4(const P3PCamera& cam, const double uv[4][2], const double
 // cv::solvePnP(..., useExtrinsicGuess = false, SOLVEPNP_ITERATIVE) = cvFindExtrinsicCameraParams2 (calib3d/src/calibration.cpp), the final
 // solve of cv::solvePnPRansac(ITERATIVE) on its inliers (lkorb_tracking.cpp:172): a DLT start (non-planar point sets) and CvLevMarq (at most
 // 20 iterations, stop when the relative change of (rvec, tvec) falls below FLT_EPSILON) on the reprojection error, rotation as a Rodrigues
-// vector.  Restated for the CPU checker only (`make -C oracle TAIL=cv`): the kernels and the default checker refine the RANSAC's winning
-// model by Gauss-Newton to the same minimum; the 12 x 12 SVD of the DLT start would add ~50 us to the frame chain, and what it buys is
-// measured by the tests (the two tails agree to ~1e-7 relative, CvLevMarq's own stopping tolerance).  Zero distortion (rectified images).
+// vector.  By default the kernels and the checker refine the RANSAC's winning model by Gauss-Newton to the same minimum; this tail is what
+// `make -C oracle TAIL=cv` builds into the checker and what FLVIS_PNP_TAIL=cv makes the device run behind k_ransac_pnp (k_pnp_tail_cv: this
+// very function, one lane per stream, in lockstep with that checker -- and slow: its loops walk the 2 n x 12 / 2 n x 6 matrices in global
+// memory one element at a time, ~9 ms per frame at 64 streams); what it buys is measured by the tests (the two tails agree to ~1e-7
+// relative, CvLevMarq's own stopping tolerance).  Zero distortion (rectified images).
 
 // cv::JacobiSVDImpl_<double>: At holds n rows of m doubles (the columns of the matrix to decompose); on return row i = sigma_i u_i scaled to
 // unit length (for i < n1; rows beyond the rank are completed), W the singular values in decreasing order, Vt (n x n, may be null) the

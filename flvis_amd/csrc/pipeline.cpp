@@ -511,6 +511,19 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
     if (kb >= 64 && kb * 1024 <= ba_lds_budget_max()) p.ba_lds_bytes = kb * 1024;
   }  // A/B knob, see DESIGN.md section 4
   DA(ba_scratch, double, (size_t)S * p.ba_scratch_stride);
+  // FLVIS_PNP_TAIL=cv (opt-in fidelity mode, round 6): behind k_ransac_pnp the pose of the ITERATIVE flag is replaced by what
+  // cv::solvePnP(ITERATIVE, useExtrinsicGuess = false) leaves on the RANSAC's inliers -- a DLT start and CvLevMarq, the very function the
+  // checker's `make -C oracle TAIL=cv` build runs (cv_solvers.hpp), bit-identical to it (tests/test_gpu_pipeline.py) -- instead of the
+  // Gauss-Newton refinement of the winning model.  One lane per stream walks OpenCV's loops as they are written: ~0.7 ms per frame, which
+  // is why it is not the default (the two tails agree to 4.4e-9 m on the first tracked frames, oracle/README.md).
+  p.pnp_tail_cv = 0;
+  p.pnp_tail_ws = nullptr;
+  p.pnp_tail_stride = 0;
+  if (const char* e = getenv("FLVIS_PNP_TAIL")) p.pnp_tail_cv = !strcmp(e, "cv");
+  if (p.pnp_tail_cv) {
+    p.pnp_tail_stride = (size_t)29 * NMAX + 64;  // world points (3 n), pixels (2 n), find_extrinsic_iterative's work (24 n + 64)
+    DA(pnp_tail_ws, double, (size_t)S * p.pnp_tail_stride);
+  }
   unsigned long long* seeds = dalloc<unsigned long long>(L->allocs, S);
   ok = ok && seeds;
   p.seeds = seeds;
@@ -1449,6 +1462,7 @@ static void lane_frame(flvis_ctx* ctx, Pipeline* pl, Lane* L, const uint8_t* d_i
   const bool pnp_signals = ba_here && fold_signal(pl, L, L->ev_fe, p.kj);  // (the deferred local-map launch starts behind this kernel)
   launch_ransac_pnp(st, p);
   p.kj = KJoin{};
+  if (p.pnp_tail_cv) launch_pnp_tail_cv(st, p);
   PE(7, st);
   if (ba_here) launch_local_map(pl, L, L->ev_fe, !pnp_signals, prof18);
   PB(8, st);

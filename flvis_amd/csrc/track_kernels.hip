@@ -1739,6 +1739,53 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
   kj_signal(p.kj);
 }
 
+// FLVIS_PNP_TAIL=cv (opt-in): the final solve of cv::solvePnPRansac(..., SOLVEPNP_ITERATIVE) (lkorb_tracking.cpp:172) on its inliers as
+// OpenCV runs it -- cv::solvePnP(ITERATIVE, useExtrinsicGuess = false) = cvFindExtrinsicCameraParams2: a DLT start and CvLevMarq -- in
+// place of k_ransac_pnp's Gauss-Newton refinement of the winning model.  The function is the checker's (cv_solvers.hpp:
+// find_extrinsic_iterative, `make -C oracle TAIL=cv`), compiled for the device and run by ONE lane per stream, loop by loop as written:
+// every sum in OpenCV's order, bit-identical to the checker.  The RANSAC's inliers are the landmarks k_ransac_pnp left with has3d &&
+// inlier, in landmark order (= the order of the correspondences).  A planar point set or fewer than six inliers (OpenCV starts from a
+// homography there) keeps the Gauss-Newton pose, as the checker does.
+__global__ __launch_bounds__(64) void k_pnp_tail_cv(Pipe p) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  StreamState& st = p.st[s];
+  if (st.phase != PH_TRACK || !st.ok || st.use_guess == 0 || st.pnp_cnt <= 0) return;
+  const int cur = st.cur;
+  const Landmark* to = lm_ptr(p, cur, s);
+  const int nl = st.n_lm[cur];
+  double* const M = p.pnp_tail_ws + (size_t)s * p.pnp_tail_stride;
+  double* const m = M + 3 * NMAX;
+  double* const work = m + 2 * NMAX;
+  int n = 0;
+  for (int base = 0; base < nl; base += 64) {
+    const int i = base + lane;
+    const bool sel = i < nl && to[i].has3d && to[i].inlier;
+    const unsigned long long b = __ballot(sel);
+    if (sel) {
+      const int k = n + lane_prefix(b);
+      // (the correspondences are cv::Point3f / cv::Point2f: camera_frame.cpp:415-427)
+      M[3 * k] = (double)(float)to[i].p3w[0], M[3 * k + 1] = (double)(float)to[i].p3w[1], M[3 * k + 2] = (double)(float)to[i].p3w[2];
+      m[2 * k] = (double)(float)to[i].p2u[0], m[2 * k + 1] = (double)(float)to[i].p2u[1];
+    }
+    n += __popcll(b);
+  }
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  if (lane != 0) return;
+  double rv[3], tv[3];
+  if (!cvs::find_extrinsic_iterative(n, M, m, p.cam.fx, p.cam.fy, p.cam.cx, p.cam.cy, work, rv, tv, nullptr)) return;
+  double Rm[9];
+  cvs::rodrigues(rv, Rm, nullptr);
+  M3 R;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) R.m[r][c] = Rm[3 * r + c];
+  const SE3d T = se3_from_mat(R, V3{tv[0], tv[1], tv[2]});
+  store_pose7(st.T_c_w[cur], T);
+  store_pose7(st.dbg_T_pnp, T);
+}
+
 // The same solver on caller-supplied correspondences: the geometric check of the loop closing, isLoopClosureKF
 // (vo_loopclosing.cpp:660-686: solvePnPRansac(p3d, p2d, K, Mat(), r, t, false, 100, 2.0, 0.99, inliers, SOLVEPNP_P3P)); one
 // workgroup per correspondence set.
@@ -2698,6 +2745,7 @@ void launch_ransac_f(hipStream_t st, const Pipe& p, bool with_collect) {
   else hipLaunchKernelGGL(k_ransac_f, dim3(p.S), dim3(RF_T), 0, st, p);
 }
 void launch_ransac_pnp(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_ransac_pnp, dim3(p.S), dim3(RP_T), 0, st, p); }
+void launch_pnp_tail_cv(hipStream_t st, const Pipe& p) { hipLaunchKernelGGL(k_pnp_tail_cv, dim3(p.S), dim3(64), 0, st, p); }
 int pnp_ransac_max_points() { return PNP_MAXN; }
 static hipError_t pnp_tables_init();
 void launch_pnp_ransac_sets(hipStream_t st, const float* p3d, const float* p2d, const int* count, int cap, int n_sets, const double* K4,

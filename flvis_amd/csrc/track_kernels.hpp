@@ -72,6 +72,11 @@ struct Pipe {
   int ba_drain;             // keyframes a local-map workgroup takes from its stream's queue per launch (0: until the queue is empty) ...
   int ba_backlog;           // ... and it goes on while the queue still holds this many or more: the bound the back-pressure relies on
   int ba_mfma;              // Schur complement of the window solver on the matrix cores (v_mfma_f64_16x16x4_f64) or as register tiles
+  // FLVIS_PNP_TAIL=cv: the final solve of solvePnPRansac(ITERATIVE) as OpenCV runs it (DLT start + CvLevMarq on the inliers,
+  // cv_solvers.hpp: find_extrinsic_iterative) in a kernel of its own behind k_ransac_pnp; workspace [S][pnp_tail_stride] doubles
+  int pnp_tail_cv;
+  double* pnp_tail_ws;
+  size_t pnp_tail_stride;
   int kf_check;             // keyframe payloads carry a checksum the local-map worker verifies (FLVIS_KF_CHECK=1: stress test of the hand-over's fences)
   int ba_balance;           // Schur accumulate: lanes per pose pair in proportion to the landmarks the pair shares (1) or 16 each (0)
   long long* counters;      // [8]: frames, keyframes, ba_runs, track_fail frames ...
@@ -109,6 +114,7 @@ void launch_track_prepare(hipStream_t st, const Pipe& p);
 void launch_track_collect(hipStream_t st, const Pipe& p);
 void launch_ransac_f(hipStream_t st, const Pipe& p, bool with_collect = false);  // (with_collect: k_track_collect's work as its prologue)
 void launch_ransac_pnp(hipStream_t st, const Pipe& p);
+void launch_pnp_tail_cv(hipStream_t st, const Pipe& p);
 void launch_track_post(hipStream_t st, const Pipe& p);
 void launch_pose_lm(hipStream_t st, const Pipe& p);
 void launch_reproj_filter(hipStream_t st, const Pipe& p);

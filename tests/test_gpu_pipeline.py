@@ -251,6 +251,25 @@ def test_frontend_parity_depth_camera_mode(ctx):
     _run_frontend_parity(ctx, cfg, ocfg, None, [3, 77], 50 + 36, 35, 3, depth_range=3.3)
 
 
+def test_frontend_parity_with_opencvs_iterative_tail(ctx, monkeypatch):
+    """FLVIS_PNP_TAIL=cv: behind the PnP RANSAC the device runs the final solve of solvePnPRansac(ITERATIVE) the way OpenCV does -- a DLT
+    start and CvLevMarq on the inliers (k_pnp_tail_cv: cv_solvers.hpp's find_extrinsic_iterative, one lane per stream) -- instead of the
+    Gauss-Newton refinement of the winning model.  Against the checker built the same way (`make -C oracle TAIL=cv`) the closed loop is in
+    LOCKSTEP again, bit for bit, on the D435 rig (two streams, 100 frames) and the EuRoC-like one; the two tails differ from each other
+    from the first tracked frame on (4.4e-9 m, tests/test_oracle_tracking.py), so a device that still ran the default tail would fail
+    here, and the default tests would fail with this one."""
+    from flvis_amd import synth
+    monkeypatch.setenv("FLVIS_PNP_TAIL", "cv")
+    O.use_sum_order("tail_cv")
+    try:
+        cfg, ocfg = _cfgs()
+        _run_frontend_parity(ctx, cfg, ocfg, None, [3, 140], 100, 49, 4)
+        cfg, ocfg = _cfgs_yaml(synth.EUROC_LIKE_YAML, "euroc_like")
+        _run_frontend_parity(ctx, cfg, ocfg, synth.euroc_rig(), [9], 60, 50, 2)
+    finally:
+        O.use_sum_order("product")
+
+
 def test_frontend_parity_kitti_mode(ctx):
     """type_of_vi 4 (vo_tracking.cpp:146,265-306): rectified stereo from two projection matrices, no IMU (fixed initial
     attitude, P3P without a prior), no skipped frames, 1241 x 376 tightly packed images (rows not dword aligned: both images
