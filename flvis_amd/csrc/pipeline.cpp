@@ -515,7 +515,7 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   // cv::solvePnP(ITERATIVE, useExtrinsicGuess = false) leaves on the RANSAC's inliers -- a DLT start and CvLevMarq, the very function the
   // checker's `make -C oracle TAIL=cv` build runs (cv_solvers.hpp), bit-identical to it (tests/test_gpu_pipeline.py) -- instead of the
   // Gauss-Newton refinement of the winning model.  One lane per stream walks OpenCV's loops as they are written: ~0.7 ms per frame, which
-  // is why it is not the default (the two tails agree to 4.4e-9 m on the first tracked frames, oracle/README.md).
+  // is why it is not the default (the two tails agree to 4.4e-9 m on the first tracked frames: the checker's README).
   p.pnp_tail_cv = 0;
   p.pnp_tail_ws = nullptr;
   p.pnp_tail_stride = 0;
