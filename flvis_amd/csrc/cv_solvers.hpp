@@ -777,8 +777,8 @@ CVS_FN bool p3p_solve4(const P3PCamera& cam, const double uv[4][2], const double
 // 20 iterations, stop when the relative change of (rvec, tvec) falls below FLT_EPSILON) on the reprojection error, rotation as a Rodrigues
 // vector.  By default the kernels and the checker refine the RANSAC's winning model by Gauss-Newton to the same minimum; this tail is what
 // `make -C oracle TAIL=cv` builds into the checker and what FLVIS_PNP_TAIL=cv makes the device run behind k_ransac_pnp (k_pnp_tail_cv: this
-// very function, one lane per stream, in lockstep with that checker -- and slow: its loops walk the 2 n x 12 / 2 n x 6 matrices in global
-// memory one element at a time, ~9 ms per frame at 64 streams); what it buys is measured by the tests (the two tails agree to ~1e-7
+// very function, one wave per stream -- LANES below --, in lockstep with that checker; +2.2 ms per frame at 64 streams: the Jacobi SVDs walk
+// their matrices in private memory); what it buys is measured by the tests (the two tails agree to ~1e-7
 // relative, CvLevMarq's own stopping tolerance).  Zero distortion (rectified images).
 
 // cv::JacobiSVDImpl_<double>: At holds n rows of m doubles (the columns of the matrix to decompose); on return row i = sigma_i u_i scaled to
@@ -1002,13 +1002,25 @@ CVS_FN void rodrigues_inv(const double* Rin, double* rv) {
   rv[0] = rx, rv[1] = ry, rv[2] = rz;
 }
 
+// How the long loops of find_extrinsic_iterative are shared out.  The checker runs them as written (SerialLanes: one "lane").  On the device
+// (k_pnp_tail_cv) every lane of a wave executes the function -- the small dense algebra redundantly, lane for lane the same values -- and
+// the loops over the correspondences are dealt out: a lane takes whole points (rows of L, residuals, Jacobian rows) or whole SUMS (an entry
+// of L^T L or of J^T J: still ONE lane adding its 2 n terms in row order), the results go through `work`, `sync` makes them visible.  The
+// arithmetic, and its order, is the same either way.
+struct SerialLanes {
+  CVS_FN int lane() const { return 0; }
+  CVS_FN int lanes() const { return 1; }
+  CVS_FN void sync() const {}
+};
+
 // cvProjectPoints2 without distortion: residuals err[2 n] = projection - measurement and (J != null) the 2 n x 6 Jacobian (dp/dr, dp/dt)
+template <class LANES>
 CVS_FN void project_residuals(int n, const double* M, const double* m, const double* param, double fx, double fy, double cx, double cy, double* err,
-                              double* J) {
+                              double* J, LANES ln) {
   double R[9], dRdr[27];
   rodrigues(param, R, J ? dRdr : nullptr);
   const double* t = param + 3;
-  for (int i = 0; i < n; i++) {
+  for (int i = ln.lane(); i < n; i += ln.lanes()) {
     const double X = M[3 * i], Y = M[3 * i + 1], Z = M[3 * i + 2];
     double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
     double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
@@ -1037,6 +1049,7 @@ CVS_FN void project_residuals(int n, const double* M, const double* m, const dou
       }
     }
   }
+  ln.sync();
 }
 
 // CvLevMarq::step for six free parameters: (JtJ with its diagonal scaled by 1 + lambda) x = JtErr by SVD, param = prev - x
@@ -1059,10 +1072,13 @@ CVS_FN double norm2(const double* v, int n) {
 }
 
 // cvFindExtrinsicCameraParams2(useExtrinsicGuess = 0) for n >= 6 non-planar points: M world points (3 n), m pixels (2 n); work: >= 24 n
-// doubles.  rvec / tvec out.  false: the point set is planar (OpenCV starts from a homography there: not restated) or n < 6.
+// + 192 doubles (the last 192: the sums the lanes hand each other).  rvec / tvec out.  false: the point set is planar (OpenCV starts from a
+// homography there: not restated) or n < 6.
+template <class LANES>
 CVS_FN bool find_extrinsic_iterative(int n, const double* M, const double* m, double fx, double fy, double cx, double cy, double* work, double* rvec,
-                                     double* tvec, int* iterations_out) {
+                                     double* tvec, int* iterations_out, LANES ln) {
   if (n < 6) return false;
+  double* const shared_sums = work + 24 * (size_t)n;  // [192]
   // planarity test: SVD of the covariance of the points
   double Mc[3] = {0, 0, 0};
   for (int i = 0; i < n; i++) Mc[0] += M[3 * i], Mc[1] += M[3 * i + 1], Mc[2] += M[3 * i + 2];
@@ -1083,7 +1099,7 @@ CVS_FN bool find_extrinsic_iterative(int n, const double* M, const double* m, do
   {
     // MulTransposed: entry (a, b) = sum over the rows of L, in row order
     double* L = work;  // 2 n x 12
-    for (int i = 0; i < n; i++) {
+    for (int i = ln.lane(); i < n; i += ln.lanes()) {
       const double xn = (m[2 * i] - cx) * (1. / fx), yn = (m[2 * i + 1] - cy) * (1. / fy);  // cvUndistortPoints, zero distortion
       const double x = -xn, y = -yn;
       double* r0 = L + (size_t)(2 * i) * 12;
@@ -1103,12 +1119,18 @@ CVS_FN bool find_extrinsic_iterative(int n, const double* M, const double* m, do
       r1[10] = y * M[3 * i + 2];
       r1[11] = y;
     }
+    ln.sync();
+    for (int e = ln.lane(); e < 144; e += ln.lanes()) {  // (entry (a, b), a <= b: one lane, its 2 n terms in row order)
+      const int a = e / 12, b = e - 12 * a;
+      if (b < a) continue;
+      double sacc = 0;
+      for (int k = 0; k < 2 * n; k++) sacc += L[(size_t)k * 12 + a] * L[(size_t)k * 12 + b];
+      shared_sums[e] = sacc;
+    }
+    ln.sync();
     for (int a = 0; a < 12; a++)
-      for (int b = a; b < 12; b++) {
-        double sacc = 0;
-        for (int k = 0; k < 2 * n; k++) sacc += L[(size_t)k * 12 + a] * L[(size_t)k * 12 + b];
-        LL[12 * a + b] = LL[12 * b + a] = sacc;
-      }
+      for (int b = a; b < 12; b++) LL[12 * a + b] = LL[12 * b + a] = shared_sums[12 * a + b];
+    ln.sync();  // (the buffer is written again below)
   }
   double LW[12], LV[144];
   svd_square(LL, 12, LW, nullptr, LV);
@@ -1135,24 +1157,31 @@ CVS_FN bool find_extrinsic_iterative(int n, const double* M, const double* m, do
   double* J = work + 2 * (size_t)n; // 2 n x 6
   int lambdaLg10 = -3, iters = 0;
   double prevErrNorm = DBL_MAX, errNorm = 0;
-  project_residuals(n, M, m, param, fx, fy, cx, cy, err, J);
+  project_residuals(n, M, m, param, fx, fy, cx, cy, err, J, ln);
   for (;;) {
     double JtJ[36], JtErr[6];
-    for (int a = 0; a < 6; a++) {
-      for (int b = a; b < 6; b++) {
-        double sacc = 0;
-        for (int k = 0; k < 2 * n; k++) sacc += J[(size_t)k * 6 + a] * J[(size_t)k * 6 + b];
-        JtJ[6 * a + b] = JtJ[6 * b + a] = sacc;
-      }
+    for (int e = ln.lane(); e < 42; e += ln.lanes()) {  // (36 entries of J^T J, of which a <= b are summed, and the 6 of J^T err)
       double sacc = 0;
-      for (int k = 0; k < 2 * n; k++) sacc += J[(size_t)k * 6 + a] * err[k];
-      JtErr[a] = sacc;
+      if (e < 36) {
+        const int a = e / 6, b = e - 6 * a;
+        if (b < a) continue;
+        for (int k = 0; k < 2 * n; k++) sacc += J[(size_t)k * 6 + a] * J[(size_t)k * 6 + b];
+      } else {
+        const int a = e - 36;
+        for (int k = 0; k < 2 * n; k++) sacc += J[(size_t)k * 6 + a] * err[k];
+      }
+      shared_sums[e] = sacc;
+    }
+    ln.sync();
+    for (int a = 0; a < 6; a++) {
+      for (int b = a; b < 6; b++) JtJ[6 * a + b] = JtJ[6 * b + a] = shared_sums[6 * a + b];
+      JtErr[a] = shared_sums[36 + a];
     }
     for (int k = 0; k < 6; k++) prev[k] = param[k];
     levmarq_step(JtJ, JtErr, prev, lambdaLg10, param);
     if (iters == 0) prevErrNorm = norm2(err, 2 * n);
     for (;;) {
-      project_residuals(n, M, m, param, fx, fy, cx, cy, err, nullptr);
+      project_residuals(n, M, m, param, fx, fy, cx, cy, err, nullptr, ln);
       errNorm = norm2(err, 2 * n);
       if (errNorm > prevErrNorm) {
         if (++lambdaLg10 <= 16) {
@@ -1167,11 +1196,17 @@ CVS_FN bool find_extrinsic_iterative(int n, const double* M, const double* m, do
     for (int k = 0; k < 6; k++) dn += (param[k] - prev[k]) * (param[k] - prev[k]), pn += prev[k] * prev[k];
     if (++iters >= 20 || sqrt(dn) / sqrt(pn) < FLT_EPSILON) break;
     prevErrNorm = errNorm;
-    project_residuals(n, M, m, param, fx, fy, cx, cy, err, J);
+    ln.sync();  // (everybody has read err and the sums of this iteration)
+    project_residuals(n, M, m, param, fx, fy, cx, cy, err, J, ln);
   }
   for (int k = 0; k < 3; k++) rvec[k] = param[k], tvec[k] = param[3 + k];
   if (iterations_out) *iterations_out = iters;
   return true;
+}
+
+CVS_FN bool find_extrinsic_iterative(int n, const double* M, const double* m, double fx, double fy, double cx, double cy, double* work, double* rvec,
+                                     double* tvec, int* iterations_out) {
+  return find_extrinsic_iterative(n, M, m, fx, fy, cx, cy, work, rvec, tvec, iterations_out, SerialLanes());
 }
 
 }  // namespace cvs

@@ -514,14 +514,15 @@ static bool lane_create(flvis_ctx* ctx, Pipeline* pl, Lane* L, int s0, int S, ui
   // FLVIS_PNP_TAIL=cv (opt-in fidelity mode, round 6): behind k_ransac_pnp the pose of the ITERATIVE flag is replaced by what
   // cv::solvePnP(ITERATIVE, useExtrinsicGuess = false) leaves on the RANSAC's inliers -- a DLT start and CvLevMarq, the very function the
   // checker's `make -C oracle TAIL=cv` build runs (cv_solvers.hpp), bit-identical to it (tests/test_gpu_pipeline.py) -- instead of the
-  // Gauss-Newton refinement of the winning model.  One lane per stream walks OpenCV's loops as they are written: ~0.7 ms per frame, which
-  // is why it is not the default (the two tails agree to 4.4e-9 m on the first tracked frames: the checker's README).
+  // Gauss-Newton refinement of the winning model.  One wave per stream: the small dense algebra (the 12 x 12 and 6 x 6 Jacobi SVDs, OpenCV's
+  // loops as they are written) redundantly in every lane, the sums over the correspondences dealt to the lanes; still milliseconds per
+  // frame, which is why it is not the default (the two tails agree to 4.4e-9 m on the first tracked frames: the checker's README).
   p.pnp_tail_cv = 0;
   p.pnp_tail_ws = nullptr;
   p.pnp_tail_stride = 0;
   if (const char* e = getenv("FLVIS_PNP_TAIL")) p.pnp_tail_cv = !strcmp(e, "cv");
   if (p.pnp_tail_cv) {
-    p.pnp_tail_stride = (size_t)29 * NMAX + 64;  // world points (3 n), pixels (2 n), find_extrinsic_iterative's work (24 n + 64)
+    p.pnp_tail_stride = (size_t)29 * NMAX + 192;  // world points (3 n), pixels (2 n), find_extrinsic_iterative's work (24 n + 192)
     DA(pnp_tail_ws, double, (size_t)S * p.pnp_tail_stride);
   }
   unsigned long long* seeds = dalloc<unsigned long long>(L->allocs, S);

@@ -1742,10 +1742,19 @@ __global__ __launch_bounds__(RP_T) void k_ransac_pnp(Pipe p) {
 // FLVIS_PNP_TAIL=cv (opt-in): the final solve of cv::solvePnPRansac(..., SOLVEPNP_ITERATIVE) (lkorb_tracking.cpp:172) on its inliers as
 // OpenCV runs it -- cv::solvePnP(ITERATIVE, useExtrinsicGuess = false) = cvFindExtrinsicCameraParams2: a DLT start and CvLevMarq -- in
 // place of k_ransac_pnp's Gauss-Newton refinement of the winning model.  The function is the checker's (cv_solvers.hpp:
-// find_extrinsic_iterative, `make -C oracle TAIL=cv`), compiled for the device and run by ONE lane per stream, loop by loop as written:
-// every sum in OpenCV's order, bit-identical to the checker.  The RANSAC's inliers are the landmarks k_ransac_pnp left with has3d &&
+// find_extrinsic_iterative, `make -C oracle TAIL=cv`), compiled for the device and run by one WAVE per stream: every sum in OpenCV's order
+// (by one lane each), bit-identical to the checker.  The RANSAC's inliers are the landmarks k_ransac_pnp left with has3d &&
 // inlier, in landmark order (= the order of the correspondences).  A planar point set or fewer than six inliers (OpenCV starts from a
 // homography there) keeps the Gauss-Newton pose, as the checker does.
+struct PnpTailLanes {  // the 64 lanes of the stream's wave; sync: what one lane stored to global memory is there for the others
+  int l;
+  __device__ int lane() const { return l; }
+  __device__ int lanes() const { return 64; }
+  __device__ void sync() const {
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();
+  }
+};
 __global__ __launch_bounds__(64) void k_pnp_tail_cv(Pipe p) {
   const int s = blockIdx.x, lane = threadIdx.x;
   StreamState& st = p.st[s];
@@ -1769,11 +1778,12 @@ __global__ __launch_bounds__(64) void k_pnp_tail_cv(Pipe p) {
     }
     n += __popcll(b);
   }
-  __threadfence_block();
-  __builtin_amdgcn_wave_barrier();
-  if (lane != 0) return;
+  const PnpTailLanes ln{lane};
+  ln.sync();
   double rv[3], tv[3];
-  if (!cvs::find_extrinsic_iterative(n, M, m, p.cam.fx, p.cam.fy, p.cam.cx, p.cam.cy, work, rv, tv, nullptr)) return;
+  // (every lane runs the function: the dense algebra redundantly, the loops over the correspondences dealt out -- cv_solvers.hpp)
+  if (!cvs::find_extrinsic_iterative(n, M, m, p.cam.fx, p.cam.fy, p.cam.cx, p.cam.cy, work, rv, tv, nullptr, ln)) return;
+  if (lane != 0) return;
   double Rm[9];
   cvs::rodrigues(rv, Rm, nullptr);
   M3 R;

@@ -810,7 +810,7 @@ int solve_pnp_ransac(const float* p3d, const float* p2d, int n, double fx, doubl
   // the default (Gauss-Newton from the winning model, what the kernels run) to measure the distance (tests/test_oracle_tracking.py).
   {
     const int ni = (int)pw.size();
-    std::vector<double> Mw(3 * (size_t)ni), mz(2 * (size_t)ni), work(24 * (size_t)ni + 64);
+    std::vector<double> Mw(3 * (size_t)ni), mz(2 * (size_t)ni), work(24 * (size_t)ni + 192);
     for (int i = 0; i < ni; i++) {
       Mw[3 * i] = pw[i].x, Mw[3 * i + 1] = pw[i].y, Mw[3 * i + 2] = pw[i].z;
       mz[2 * i] = z[i].x, mz[2 * i + 1] = z[i].y;
@@ -1101,7 +1101,7 @@ int ref_cv_p3p(const double* K4, const double* uv6, const double* X9, double* R3
 }
 // cvFindExtrinsicCameraParams2 without a guess (cv_solvers.hpp): pose from n >= 6 non-planar correspondences; returns the LM iterations (0: refused)
 int ref_cv_find_extrinsic(int n, const double* M, const double* m, const double* K4, double* rvec3, double* tvec3) {
-  std::vector<double> work(24 * (size_t)n + 64);
+  std::vector<double> work(24 * (size_t)n + 192);
   int it = 0;
   if (!flvis::cvs::find_extrinsic_iterative(n, M, m, K4[0], K4[1], K4[2], K4[3], work.data(), rvec3, tvec3, &it)) return 0;
   return it;

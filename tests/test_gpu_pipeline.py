@@ -253,7 +253,7 @@ def test_frontend_parity_depth_camera_mode(ctx):
 
 def test_frontend_parity_with_opencvs_iterative_tail(ctx, monkeypatch):
     """FLVIS_PNP_TAIL=cv: behind the PnP RANSAC the device runs the final solve of solvePnPRansac(ITERATIVE) the way OpenCV does -- a DLT
-    start and CvLevMarq on the inliers (k_pnp_tail_cv: cv_solvers.hpp's find_extrinsic_iterative, one lane per stream) -- instead of the
+    start and CvLevMarq on the inliers (k_pnp_tail_cv: cv_solvers.hpp's find_extrinsic_iterative, one wave per stream) -- instead of the
     Gauss-Newton refinement of the winning model.  Against the checker built the same way (`make -C oracle TAIL=cv`) the closed loop is in
     LOCKSTEP again, bit for bit, on the D435 rig (two streams, 100 frames) and the EuRoC-like one; the two tails differ from each other
     from the first tracked frame on (4.4e-9 m, tests/test_oracle_tracking.py), so a device that still ran the default tail would fail
