@@ -1067,9 +1067,14 @@ def test_local_map_imu_factor_at_window_size_16(ctx, pos_rows):
         trk.set_imu_factor_accel(0.0)
 
 
-def test_local_map_parity(ctx):
+@pytest.mark.parametrize("balance", ["0", "1"])
+def test_local_map_parity(ctx, monkeypatch, balance):
+    """The window optimiser against the oracle, keyframe by keyframe.  balance = 1: the Schur accumulate's lanes dealt to the pose pairs in
+    proportion to the landmarks they share (FLVIS_BA_BALANCE=1, opt-in; profiles/r06_ba_phases.md) -- another order of the same sums, the
+    same tolerance."""
     import flvis_amd
     cfg, _ = _cfgs()
+    monkeypatch.setenv("FLVIS_BA_BALANCE", balance)
     trk = flvis_amd.Tracker(ctx, cfg, 2, seed_base=1)
     K4 = np.array([cfg.P0[0], cfg.P0[5], cfg.P0[2], cfg.P0[6]])
     for stream, seed in ((0, 11), (1, 12)):
