@@ -1181,6 +1181,7 @@ CVS_FN bool find_extrinsic_iterative(int n, const double* M, const double* m, do
     levmarq_step(JtJ, JtErr, prev, lambdaLg10, param);
     if (iters == 0) prevErrNorm = norm2(err, 2 * n);
     for (;;) {
+      ln.sync();  // (every lane has read the residuals it needed -- the sums above, the norms -- before they are written again)
       project_residuals(n, M, m, param, fx, fy, cx, cy, err, nullptr, ln);
       errNorm = norm2(err, 2 * n);
       if (errNorm > prevErrNorm) {

@@ -23,6 +23,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ref_api.h"
@@ -1100,6 +1103,48 @@ int ref_cv_p3p(const double* K4, const double* uv6, const double* X9, double* R3
   return n;
 }
 // cvFindExtrinsicCameraParams2 without a guess (cv_solvers.hpp): pose from n >= 6 non-planar correspondences; returns the LM iterations (0: refused)
+// ... the same with its loops dealt to `lanes` host threads the way k_pnp_tail_cv deals them to the lanes of a wave (cv_solvers.hpp: a
+// lane takes whole points or whole sums; `sync` is a barrier of the threads): the test expects the serial call's bits.
+namespace {
+struct ThreadLanes {
+  int l, nl;
+  struct Bar {
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0, gen = 0;
+  }* bar;
+  int lane() const { return l; }
+  int lanes() const { return nl; }
+  void sync() const {
+    std::unique_lock<std::mutex> lk(bar->mu);
+    const int g = bar->gen;
+    if (++bar->waiting == nl) {
+      bar->waiting = 0;
+      bar->gen++;
+      bar->cv.notify_all();
+    } else {
+      bar->cv.wait(lk, [&] { return bar->gen != g; });
+    }
+  }
+};
+}  // namespace
+int ref_cv_find_extrinsic_lanes(int n, const double* M, const double* m, const double* K4, int lanes, double* rvec3, double* tvec3) {
+  std::vector<double> work(24 * (size_t)n + 192);
+  ThreadLanes::Bar bar;
+  std::vector<int> its(lanes, 0), oks(lanes, 0);
+  std::vector<double> rv(3 * (size_t)lanes), tv(3 * (size_t)lanes);
+  std::vector<std::thread> th;
+  for (int l = 0; l < lanes; l++)
+    th.emplace_back([&, l] {
+      oks[l] = flvis::cvs::find_extrinsic_iterative(n, M, m, K4[0], K4[1], K4[2], K4[3], work.data(), &rv[3 * l], &tv[3 * l], &its[l], ThreadLanes{l, lanes, &bar});
+    });
+  for (auto& t : th) t.join();
+  for (int l = 1; l < lanes; l++)  // every lane leaves with the same answer
+    if (oks[l] != oks[0] || its[l] != its[0] || memcmp(&rv[3 * l], &rv[0], 24) || memcmp(&tv[3 * l], &tv[0], 24)) return -1;
+  memcpy(rvec3, &rv[0], 24);
+  memcpy(tvec3, &tv[0], 24);
+  return oks[0] ? its[0] : 0;
+}
 int ref_cv_find_extrinsic(int n, const double* M, const double* m, const double* K4, double* rvec3, double* tvec3) {
   std::vector<double> work(24 * (size_t)n + 192);
   int it = 0;

@@ -273,3 +273,29 @@ def test_iterative_tail_reaches_the_least_squares_minimum():
         assert np.abs(sol.x - np.r_[rv, tv]).max() <= 1e-8
     flat = np.c_[rng.uniform(-2, 2, (40, 2)), np.zeros(40)]
     assert L.ref_cv_find_extrinsic(40, _d(flat), _d(rng.uniform(0, 600, (40, 2))), _d(k4), _d(np.zeros(3)), _d(np.zeros(3))) == 0
+
+
+def test_iterative_tail_dealt_to_lanes_leaves_the_serial_bits():
+    """FLVIS_PNP_TAIL=cv runs find_extrinsic_iterative by one WAVE per stream: every lane executes it, the loops over the correspondences
+    dealt out (a lane takes whole points / whole sums, `sync` between writers and readers).  The same dealing on the host -- 2, 5 and 8
+    threads with a barrier as `sync`, free-running in between, so a missing `sync` shows -- leaves the serial call's rvec, tvec and
+    iteration count bit for bit, in every lane."""
+    from scipy.spatial.transform import Rotation as Rot
+    L = O.lib()
+    rng = np.random.default_rng(29)
+    k4 = np.array([FX, FY, CX, CY])
+    for trial in range(12):
+        n = int(rng.integers(8, 300))
+        r, t = rng.normal(size=3) * 0.4, rng.normal(size=3) * 0.5 + np.array([0, 0, 0.5])
+        xc = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(2, 8, n)], 1)
+        xw = (Rot.from_rotvec(r).as_matrix().T @ (xc - t).T).T.astype(np.float32).astype(np.float64)
+        uv = ((xc / xc[:, 2:3])[:, :2] * [FX, FY] + [CX, CY] + rng.normal(size=(n, 2)) * 0.7).astype(np.float32).astype(np.float64)
+        rv, tv = np.zeros(3), np.zeros(3)
+        it = L.ref_cv_find_extrinsic(n, _d(xw), _d(uv), _d(k4), _d(rv), _d(tv))
+        assert it >= 1
+        for lanes in (2, 5, 8):
+            rl, tl = np.zeros(3), np.zeros(3)
+            itl = L.ref_cv_find_extrinsic_lanes(n, _d(xw), _d(uv), _d(k4), lanes, _d(rl), _d(tl))
+            assert itl == it, (trial, lanes, itl, it)          # (-1: the lanes disagreed among themselves)
+            assert rl.tobytes() == rv.tobytes() and tl.tobytes() == tv.tobytes(), (trial, lanes)
+
